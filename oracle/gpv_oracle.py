@@ -1,0 +1,676 @@
+"""CPU oracle for the GPV-1 hot path  --  TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
+leg may import this module.  The product package (``gpv-1_amd``) never does; it
+fails loudly when its HIP library is missing.
+
+What it is: a plain-PyTorch fp32, *functional* restatement of the reference's
+algorithm for the path named by BASELINE.json (GPV.forward train / greedy /
+beam + criterion).  It takes the reference's own ``state_dict`` (same 836 key
+names) as a flat ``dict[str, Tensor]`` and recomputes everything with explicit
+matmul / softmax / mean-var arithmetic (no nn.MultiheadAttention, no
+nn.TransformerDecoder, no torchvision) so that it is an independent statement
+of the math.  Every function cites the reference file:line it follows
+(paths relative to /root/reference).
+
+Pinning status (see tests/test_oracle_golden.py and tools/gen_golden.py):
+  * everything below except the three items listed next is pinned against
+    golden vectors produced by importing and running the reference itself in
+    the build container (tests/golden/*.npz, generator committed);
+  * torchvision 0.7 ``resnet50`` topology and ``ops.roi_align`` are not present
+    in the image (torchvision absent) -> restated from their published
+    semantics: **parity unpinned** for those two; the golden generator plugs
+    the oracle's own ResNet / RoIAlign into the reference as the torchvision
+    stand-in, so everything around them is still pinned;
+  * BERT is pinned against the installed HF ``transformers`` BertModel with
+    random-init weights (bert-base-uncased weights/tokenizer are not available
+    offline): **parity unpinned** w.r.t. real weights/tokenisation.
+"""
+import math
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from scipy.optimize import linear_sum_assignment
+
+Tensor = torch.Tensor
+P = Dict[str, Tensor]
+
+
+# --------------------------------------------------------------------------
+# small primitives
+# --------------------------------------------------------------------------
+def linear(x: Tensor, w: Tensor, b: Optional[Tensor] = None) -> Tensor:
+    y = x @ w.t()
+    return y if b is None else y + b
+
+
+def layer_norm(x: Tensor, w: Optional[Tensor], b: Optional[Tensor], eps: float) -> Tensor:
+    """mean / biased variance over last dim; eps inside the sqrt.
+    nn.LayerNorm (transformer.py:137-138) and BertLayerNorm (vilbert.py:303-316)
+    are the same formula with eps 1e-5 / 1e-12."""
+    u = x.mean(-1, keepdim=True)
+    s = ((x - u) ** 2).mean(-1, keepdim=True)
+    y = (x - u) / torch.sqrt(s + eps)
+    if w is not None:
+        y = y * w + b
+    return y
+
+
+def gelu_erf(x: Tensor) -> Tensor:
+    """vilbert.py:111-117"""
+    return x * 0.5 * (1.0 + torch.erf(x / math.sqrt(2.0)))
+
+
+def attention_core(q: Tensor, k: Tensor, v: Tensor, nhead: int,
+                   key_padding_mask: Optional[Tensor] = None,
+                   causal: bool = False) -> Tensor:
+    """q (B,Tq,D) k,v (B,Tk,D) already projected.  softmax(q k^T / sqrt(dh)) v.
+    key_padding_mask (B,Tk) bool True = ignore.  causal: key j > query i masked."""
+    B, Tq, D = q.shape
+    Tk = k.shape[1]
+    dh = D // nhead
+    qh = q.view(B, Tq, nhead, dh).transpose(1, 2)
+    kh = k.view(B, Tk, nhead, dh).transpose(1, 2)
+    vh = v.view(B, Tk, nhead, dh).transpose(1, 2)
+    s = (qh @ kh.transpose(-1, -2)) / math.sqrt(dh)
+    if key_padding_mask is not None:
+        s = s.masked_fill(key_padding_mask[:, None, None, :], float('-inf'))
+    if causal:
+        cm = torch.ones(Tq, Tk, dtype=torch.bool, device=q.device).triu(1)
+        s = s.masked_fill(cm, float('-inf'))
+    p = torch.softmax(s, -1)
+    o = p @ vh
+    return o.transpose(1, 2).reshape(B, Tq, D)
+
+
+def torch_mha(Pm: P, pre: str, query: Tensor, key: Tensor, value: Tensor, nhead: int,
+              key_padding_mask=None, causal=False) -> Tensor:
+    """nn.MultiheadAttention with packed in_proj (torch semantics), batch-first here.
+    Used by transformer.py:131,191-192 and gpv.py:38-43."""
+    D = query.shape[-1]
+    w = Pm[pre + 'in_proj_weight']
+    b = Pm[pre + 'in_proj_bias']
+    q = linear(query, w[:D], b[:D])
+    k = linear(key, w[D:2 * D], b[D:2 * D])
+    v = linear(value, w[2 * D:], b[2 * D:])
+    o = attention_core(q, k, v, nhead, key_padding_mask, causal)
+    return linear(o, Pm[pre + 'out_proj.weight'], Pm[pre + 'out_proj.bias'])
+
+
+# --------------------------------------------------------------------------
+# backbone: ResNet-50 v1.5 + FrozenBN  (backbone.py:19-54,82-97; torchvision 0.7 topology)
+# --------------------------------------------------------------------------
+RESNET50_LAYERS = ((64, 3, 1), (128, 4, 2), (256, 6, 2), (512, 3, 2))
+
+
+def frozen_bn(x: Tensor, Pm: P, pre: str) -> Tensor:
+    """backbone.py:44-54 (eps 1e-5 added before rsqrt)."""
+    scale = Pm[pre + 'weight'] * (Pm[pre + 'running_var'] + 1e-5).rsqrt()
+    bias = Pm[pre + 'bias'] - Pm[pre + 'running_mean'] * scale
+    return x * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1)
+
+
+def bottleneck(x: Tensor, Pm: P, pre: str, stride: int, downsample: bool) -> Tensor:
+    """torchvision Bottleneck v1.5: stride lives on the 3x3."""
+    out = F.relu(frozen_bn(F.conv2d(x, Pm[pre + 'conv1.weight']), Pm, pre + 'bn1.'))
+    out = F.relu(frozen_bn(F.conv2d(out, Pm[pre + 'conv2.weight'], stride=stride, padding=1), Pm, pre + 'bn2.'))
+    out = frozen_bn(F.conv2d(out, Pm[pre + 'conv3.weight']), Pm, pre + 'bn3.')
+    if downsample:
+        x = frozen_bn(F.conv2d(x, Pm[pre + 'downsample.0.weight'], stride=stride), Pm, pre + 'downsample.1.')
+    return F.relu(out + x)
+
+
+def resnet50_c5(x: Tensor, Pm: P, pre: str = 'detr.backbone.0.body.') -> Tensor:
+    x = F.relu(frozen_bn(F.conv2d(x, Pm[pre + 'conv1.weight'], stride=2, padding=3), Pm, pre + 'bn1.'))
+    x = F.max_pool2d(x, 3, 2, 1)
+    for li, (planes, nblk, stride) in enumerate(RESNET50_LAYERS, 1):
+        for bi in range(nblk):
+            x = bottleneck(x, Pm, f'{pre}layer{li}.{bi}.', stride if bi == 0 else 1, bi == 0)
+    return x
+
+
+def downsample_mask(mask: Tensor, h: int, w: int) -> Tensor:
+    """backbone.py:77  F.interpolate(m[None].float(), size) nearest -> bool.
+    nearest: src = floor(dst * in/out)."""
+    H, W = mask.shape[-2:]
+    iy = torch.div(torch.arange(h) * H, h, rounding_mode='floor')
+    ix = torch.div(torch.arange(w) * W, w, rounding_mode='floor')
+    return mask[:, iy][:, :, ix]
+
+
+def sine_position(mask: Tensor, num_pos_feats: int = 128, temperature: float = 10000.0) -> Tensor:
+    """position_encoding.py:28-48 (normalize=True, scale=2pi).  mask (B,h,w) bool -> (B,2*npf,h,w)."""
+    not_mask = (~mask).float()
+    y_embed = not_mask.cumsum(1)
+    x_embed = not_mask.cumsum(2)
+    eps = 1e-6
+    y_embed = y_embed / (y_embed[:, -1:, :] + eps) * (2 * math.pi)
+    x_embed = x_embed / (x_embed[:, :, -1:] + eps) * (2 * math.pi)
+    i = torch.arange(num_pos_feats, dtype=torch.float32)
+    dim_t = temperature ** (2 * torch.div(i, 2, rounding_mode='floor') / num_pos_feats)
+    px = x_embed[..., None] / dim_t
+    py = y_embed[..., None] / dim_t
+    px = torch.stack((px[..., 0::2].sin(), px[..., 1::2].cos()), dim=4).flatten(3)
+    py = torch.stack((py[..., 0::2].sin(), py[..., 1::2].cos()), dim=4).flatten(3)
+    return torch.cat((py, px), dim=3).permute(0, 3, 1, 2)
+
+
+# --------------------------------------------------------------------------
+# DETR transformer (transformer.py:46-58,148-161,211-232,94-123), batch-first internally
+# --------------------------------------------------------------------------
+def detr_encoder_layer(Pm: P, pre: str, src: Tensor, pos: Tensor, kpm: Tensor, nhead: int) -> Tensor:
+    qk = src + pos
+    a = torch_mha(Pm, pre + 'self_attn.', qk, qk, src, nhead, kpm)
+    src = layer_norm(src + a, Pm[pre + 'norm1.weight'], Pm[pre + 'norm1.bias'], 1e-5)
+    f = linear(F.relu(linear(src, Pm[pre + 'linear1.weight'], Pm[pre + 'linear1.bias'])),
+               Pm[pre + 'linear2.weight'], Pm[pre + 'linear2.bias'])
+    return layer_norm(src + f, Pm[pre + 'norm2.weight'], Pm[pre + 'norm2.bias'], 1e-5)
+
+
+def detr_decoder_layer(Pm: P, pre: str, tgt: Tensor, memory: Tensor, pos: Tensor, qpos: Tensor,
+                       kpm: Tensor, nhead: int) -> Tensor:
+    qk = tgt + qpos
+    a = torch_mha(Pm, pre + 'self_attn.', qk, qk, tgt, nhead)
+    tgt = layer_norm(tgt + a, Pm[pre + 'norm1.weight'], Pm[pre + 'norm1.bias'], 1e-5)
+    a = torch_mha(Pm, pre + 'multihead_attn.', tgt + qpos, memory + pos, memory, nhead, kpm)
+    tgt = layer_norm(tgt + a, Pm[pre + 'norm2.weight'], Pm[pre + 'norm2.bias'], 1e-5)
+    f = linear(F.relu(linear(tgt, Pm[pre + 'linear1.weight'], Pm[pre + 'linear1.bias'])),
+               Pm[pre + 'linear2.weight'], Pm[pre + 'linear2.bias'])
+    return layer_norm(tgt + f, Pm[pre + 'norm3.weight'], Pm[pre + 'norm3.bias'], 1e-5)
+
+
+def detr_transformer(Pm: P, cfg, src: Tensor, mask: Tensor, pos: Tensor) -> Tuple[Tensor, Tensor]:
+    """src (B,256,h,w), mask (B,h,w), pos (B,256,h,w) -> hs (L,B,Q,256) (decoder-normed), memory (B,S,256)."""
+    pre = 'detr.transformer.'
+    B, C, h, w = src.shape
+    x = src.flatten(2).transpose(1, 2)      # (B,S,C)
+    pe = pos.flatten(2).transpose(1, 2)
+    kpm = mask.flatten(1)
+    nhead = cfg['nheads']
+    for i in range(cfg['num_encoder_layers']):
+        x = detr_encoder_layer(Pm, f'{pre}encoder.layers.{i}.', x, pe, kpm, nhead)
+    memory = x
+    qpos = Pm['detr.query_embed.weight'][None].expand(B, -1, -1)
+    tgt = torch.zeros_like(qpos)
+    inter = []
+    for i in range(cfg['num_decoder_layers']):
+        tgt = detr_decoder_layer(Pm, f'{pre}decoder.layers.{i}.', tgt, memory, pe, qpos, kpm, nhead)
+        inter.append(layer_norm(tgt, Pm[pre + 'decoder.norm.weight'], Pm[pre + 'decoder.norm.bias'], 1e-5))
+    return torch.stack(inter), memory
+
+
+# --------------------------------------------------------------------------
+# RoIAlign(7x7, aligned) -> mean  (detr_roi_head.py:44-56; torchvision 0.7 ops.roi_align)
+# --------------------------------------------------------------------------
+def _roi_axis_samples(start: float, length: float, size: int, pooled: int = 7):
+    """per-bin sample lists [(low, high, w_low, w_high, valid)] along one axis, torchvision
+    roi_align bilinear_interpolate semantics (aligned=True => caller subtracted 0.5)."""
+    grid = int(math.ceil(length / pooled))
+    bins = []
+    bin_sz = length / pooled
+    for p in range(pooled):
+        out = []
+        for i in range(grid):
+            c = start + p * bin_sz + (i + 0.5) * bin_sz / grid
+            if c < -1.0 or c > size:
+                out.append((0, 0, 0.0, 0.0, False))
+                continue
+            if c <= 0:
+                c = 0.0
+            lo = int(c)
+            if lo >= size - 1:
+                hi = lo = size - 1
+                c = float(lo)
+            else:
+                hi = lo + 1
+            l = c - lo
+            out.append((lo, hi, 1.0 - l, l, True))
+        bins.append(out)
+    return grid, bins
+
+
+def roi_align_direct(feat: Tensor, boxes_xyxy: Tensor, pooled: int = 7) -> Tensor:
+    """Literal per-sample restatement of torchvision.ops.roi_align(aligned=True, spatial_scale=1,
+    sampling_ratio=-1) for ONE image. feat (C,H,W), boxes (N,4) xyxy in feature-map units
+    -> (N,C,pooled,pooled).  Slow python loops: small cases, and the check of roi_axis_weights()."""
+    C, H, W = feat.shape
+    outs = []
+    for bx in boxes_xyxy.tolist():
+        x1, y1, x2, y2 = [v - 0.5 for v in bx]
+        gh, ys = _roi_axis_samples(y1, y2 - y1, H, pooled)
+        gw, xs = _roi_axis_samples(x1, x2 - x1, W, pooled)
+        count = max(gh * gw, 1)
+        rows = []
+        for ph in range(pooled):
+            cols = []
+            for pw in range(pooled):
+                acc = torch.zeros(C, dtype=feat.dtype)
+                for (yl, yh, wyl, wyh, vy) in ys[ph]:
+                    for (xl, xh, wxl, wxh, vx) in xs[pw]:
+                        if not (vy and vx):
+                            continue
+                        acc = acc + (wyl * wxl * feat[:, yl, xl] + wyl * wxh * feat[:, yl, xh]
+                                     + wyh * wxl * feat[:, yh, xl] + wyh * wxh * feat[:, yh, xh])
+                cols.append(acc / count)
+            rows.append(torch.stack(cols, -1))
+        outs.append(torch.stack(rows, -2))
+    return torch.stack(outs)
+
+
+def roi_align_mean_direct(feat: Tensor, boxes_xyxy: Tensor) -> Tensor:
+    return roi_align_direct(feat, boxes_xyxy).mean(-1).mean(-1)
+
+
+def roi_axis_weights(start: Tensor, length: Tensor, size: int, pooled: int = 7) -> Tensor:
+    """Vectorised: per-roi accumulated bilinear weights along one axis, already divided by
+    pooled*grid so that out = sum_yx Ay[y] Ax[x] feat[y,x] equals roi_align(...).mean over bins.
+    start,length (N,) -> (N,size).  Works because every sample's weight and validity are separable."""
+    N = start.shape[0]
+    grid = torch.ceil(length / pooled).clamp(min=0)                     # (N,)
+    gmax = int(grid.max().item()) if N > 0 else 0
+    A = torch.zeros(N, size, dtype=start.dtype)
+    if gmax == 0:
+        return A
+    p = torch.arange(pooled, dtype=start.dtype).view(1, pooled, 1)
+    i = torch.arange(gmax, dtype=start.dtype).view(1, 1, gmax)
+    bin_sz = (length / pooled).view(N, 1, 1)
+    g = grid.view(N, 1, 1)
+    c = start.view(N, 1, 1) + p * bin_sz + (i + 0.5) * bin_sz / g.clamp(min=1)
+    live = (i < g) & ~((c < -1.0) | (c > size))
+    c = c.clamp(min=0)
+    lo = c.floor().long()
+    edge = lo >= size - 1
+    lo = torch.where(edge, torch.full_like(lo, size - 1), lo)
+    hi = torch.where(edge, lo, lo + 1)
+    c = torch.where(edge, lo.to(c.dtype), c)
+    l = c - lo.to(c.dtype)
+    wl = torch.where(live, 1.0 - l, torch.zeros_like(l)).reshape(N, -1)
+    wh = torch.where(live, l, torch.zeros_like(l)).reshape(N, -1)
+    A = A.scatter_add(1, lo.reshape(N, -1), wl).scatter_add(1, hi.reshape(N, -1), wh)
+    return A / (pooled * grid.clamp(min=1)).view(N, 1)
+
+
+def extract_roi(feat: Tensor, boxes: Tensor) -> Tensor:
+    """detr_roi_head.py:44-56.  feat (B,C,H,W), boxes (B,N,4) n-cxcywh -> (B,N,C)."""
+    B, C, H, W = feat.shape
+    x1 = W * (boxes[..., 0] - 0.5 * boxes[..., 2]) - 0.5
+    y1 = H * (boxes[..., 1] - 0.5 * boxes[..., 3]) - 0.5
+    x2 = W * (boxes[..., 0] + 0.5 * boxes[..., 2]) - 0.5
+    y2 = H * (boxes[..., 1] + 0.5 * boxes[..., 3]) - 0.5
+    N = boxes.shape[1]
+    Ay = roi_axis_weights(y1.reshape(-1), (y2 - y1).reshape(-1), H).view(B, N, H)
+    Ax = roi_axis_weights(x1.reshape(-1), (x2 - x1).reshape(-1), W).view(B, N, W)
+    # roi_align has no gradient w.r.t. boxes (torchvision) -> weights are constants
+    Wgt = (Ay.detach()[:, :, :, None] * Ax.detach()[:, :, None, :]).reshape(B, N, H * W)
+    return Wgt @ feat.flatten(2).transpose(1, 2)
+
+
+# --------------------------------------------------------------------------
+# DETR with RoI head (detr_roi_head.py:58-94) / plain (detr.py:19-73)
+# --------------------------------------------------------------------------
+def detr_forward(Pm: P, cfg: dict, images: Tensor, mask: Tensor, training: bool = False) -> dict:
+    dc = cfg['detr']
+    c5 = resnet50_c5(images, Pm)
+    m = downsample_mask(mask, c5.shape[-2], c5.shape[-1])
+    pos = sine_position(m, dc['hidden_dim'] // 2)
+    src = F.conv2d(c5, Pm['detr.input_proj.weight'], Pm['detr.input_proj.bias'])
+    hs, _ = detr_transformer(Pm, dc, src, m, pos)
+    if dc['last_layer_only'] or not training:
+        hs = hs[-1:]
+    logits = linear(hs, Pm['detr.class_embed.weight'], Pm['detr.class_embed.bias'])
+    x = hs
+    for i in range(3):
+        x = linear(x, Pm[f'detr.bbox_embed.layers.{i}.weight'], Pm[f'detr.bbox_embed.layers.{i}.bias'])
+        if i < 2:
+            x = F.relu(x)
+    boxes = x.sigmoid()
+    out = {'pred_relevance_logits': logits[-1], 'pred_boxes': boxes[-1], 'detr_hs': hs, 'c5': c5}
+    if dc.get('aux_loss', False):
+        out['aux_outputs'] = [{'pred_relevance_logits': a, 'pred_boxes': b}
+                              for a, b in zip(logits[:-1], boxes[:-1])]
+    if cfg.get('roi_head', True):
+        roi = extract_roi(c5, out['pred_boxes'])[None]
+        roi = layer_norm(roi, None, None, 1e-5)
+        out['detr_hs'] = torch.cat((roi, hs), -1)
+    return out
+
+
+# --------------------------------------------------------------------------
+# BERT-base encoder (HF BertModel semantics; bert.py:11-22).  no_grad feature extractor.
+# --------------------------------------------------------------------------
+def bert_forward(Pm: P, input_ids: Tensor, attention_mask: Tensor,
+                 token_type_ids: Optional[Tensor] = None, pre: str = 'bert.model.',
+                 nhead: int = 12) -> Tensor:
+    B, T = input_ids.shape
+    if token_type_ids is None:
+        token_type_ids = torch.zeros_like(input_ids)
+    e = pre + 'embeddings.'
+    x = (Pm[e + 'word_embeddings.weight'][input_ids]
+         + Pm[e + 'position_embeddings.weight'][:T][None]
+         + Pm[e + 'token_type_embeddings.weight'][token_type_ids])
+    x = layer_norm(x, Pm[e + 'LayerNorm.weight'], Pm[e + 'LayerNorm.bias'], 1e-12)
+    kpm = attention_mask == 0
+    i = 0
+    while f'{pre}encoder.layer.{i}.attention.self.query.weight' in Pm:
+        l = f'{pre}encoder.layer.{i}.'
+        q = linear(x, Pm[l + 'attention.self.query.weight'], Pm[l + 'attention.self.query.bias'])
+        k = linear(x, Pm[l + 'attention.self.key.weight'], Pm[l + 'attention.self.key.bias'])
+        v = linear(x, Pm[l + 'attention.self.value.weight'], Pm[l + 'attention.self.value.bias'])
+        a = attention_core(q, k, v, nhead, kpm)
+        a = linear(a, Pm[l + 'attention.output.dense.weight'], Pm[l + 'attention.output.dense.bias'])
+        x = layer_norm(x + a, Pm[l + 'attention.output.LayerNorm.weight'], Pm[l + 'attention.output.LayerNorm.bias'], 1e-12)
+        h = gelu_erf(linear(x, Pm[l + 'intermediate.dense.weight'], Pm[l + 'intermediate.dense.bias']))
+        h = linear(h, Pm[l + 'output.dense.weight'], Pm[l + 'output.dense.bias'])
+        x = layer_norm(x + h, Pm[l + 'output.LayerNorm.weight'], Pm[l + 'output.LayerNorm.bias'], 1e-12)
+        i += 1
+    return x
+
+
+# --------------------------------------------------------------------------
+# co-attention (vilbert.py:737-900).  stream 1 = language, stream 2 = vision (gpv.py:149-154)
+# --------------------------------------------------------------------------
+def co_attention_layer(Pm: P, pre: str, t1: Tensor, t2: Tensor, nhead: int) -> Tuple[Tensor, Tensor]:
+    b = pre + 'biattention.'
+    q1 = linear(t1, Pm[b + 'query1.weight'], Pm[b + 'query1.bias'])
+    k1 = linear(t1, Pm[b + 'key1.weight'], Pm[b + 'key1.bias'])
+    v1 = linear(t1, Pm[b + 'value1.weight'], Pm[b + 'value1.bias'])
+    q2 = linear(t2, Pm[b + 'query2.weight'], Pm[b + 'query2.bias'])
+    k2 = linear(t2, Pm[b + 'key2.weight'], Pm[b + 'key2.bias'])
+    v2 = linear(t2, Pm[b + 'value2.weight'], Pm[b + 'value2.bias'])
+    ctx1 = attention_core(q2, k1, v1, nhead)      # vision queries over language keys  (len T2)
+    ctx2 = attention_core(q1, k2, v2, nhead)      # language queries over vision keys  (len T1)
+    o = pre + 'biOutput.'
+    # BertConnectionLayer.forward passes (bi_output2, input1, bi_output1, input2)  vilbert.py:889-891
+    a1 = layer_norm(linear(ctx2, Pm[o + 'dense1.weight'], Pm[o + 'dense1.bias']) + t1,
+                    Pm[o + 'LayerNorm1.weight'], Pm[o + 'LayerNorm1.bias'], 1e-12)
+    a2 = layer_norm(linear(ctx1, Pm[o + 'dense2.weight'], Pm[o + 'dense2.bias']) + t2,
+                    Pm[o + 'LayerNorm2.weight'], Pm[o + 'LayerNorm2.bias'], 1e-12)
+    h1 = gelu_erf(linear(a1, Pm[pre + 'v_intermediate.dense.weight'], Pm[pre + 'v_intermediate.dense.bias']))
+    o1 = layer_norm(linear(h1, Pm[pre + 'v_output.dense.weight'], Pm[pre + 'v_output.dense.bias']) + a1,
+                    Pm[pre + 'v_output.LayerNorm.weight'], Pm[pre + 'v_output.LayerNorm.bias'], 1e-12)
+    h2 = gelu_erf(linear(a2, Pm[pre + 't_intermediate.dense.weight'], Pm[pre + 't_intermediate.dense.bias']))
+    o2 = layer_norm(linear(h2, Pm[pre + 't_output.dense.weight'], Pm[pre + 't_output.dense.bias']) + a2,
+                    Pm[pre + 't_output.LayerNorm.weight'], Pm[pre + 't_output.LayerNorm.bias'], 1e-12)
+    return o1, o2
+
+
+# --------------------------------------------------------------------------
+# text decoder (gpv.py:37-43,449-466 -> torch nn.TransformerDecoderLayer post-norm, relu, ff 2048)
+# --------------------------------------------------------------------------
+def text_decoder_layer(Pm: P, pre: str, tgt: Tensor, memory: Tensor, nhead: int) -> Tensor:
+    a = torch_mha(Pm, pre + 'self_attn.', tgt, tgt, tgt, nhead, causal=True)
+    tgt = layer_norm(tgt + a, Pm[pre + 'norm1.weight'], Pm[pre + 'norm1.bias'], 1e-5)
+    a = torch_mha(Pm, pre + 'multihead_attn.', tgt, memory, memory, nhead)
+    tgt = layer_norm(tgt + a, Pm[pre + 'norm2.weight'], Pm[pre + 'norm2.bias'], 1e-5)
+    f = linear(F.relu(linear(tgt, Pm[pre + 'linear1.weight'], Pm[pre + 'linear1.bias'])),
+               Pm[pre + 'linear2.weight'], Pm[pre + 'linear2.bias'])
+    return layer_norm(tgt + f, Pm[pre + 'norm3.weight'], Pm[pre + 'norm3.bias'], 1e-5)
+
+
+def answer_head(Pm: P, h: Tensor) -> Tensor:
+    """answer_head.py:26-33"""
+    wc = linear(Pm['answer_head.vocab_embed'], Pm['answer_head.classifier_transform.weight'],
+                Pm['answer_head.classifier_transform.bias'])
+    return h @ wc.t()
+
+
+def answer_input_embed(Pm: P, ids: Tensor) -> Tensor:
+    """gpv.py:46-55"""
+    e = Pm['answer_input_embedings.embedding_layer.weight'][ids]
+    return linear(e, Pm['answer_input_embedings.transform.weight'], Pm['answer_input_embedings.transform.bias'])
+
+
+def decode_text(Pm: P, cfg: dict, target: Tensor, memory: Tensor) -> Tensor:
+    """gpv.py:449-466. target (B,Tt,D) memory (B,Tm,D) -> logits (B,Tt,V)."""
+    tc = cfg['text_decoder']
+    if tc.get('pos_enc', False):
+        target = target + Pm['pos_enc'][0, :target.shape[1]]
+    x = target
+    for i in range(tc['num_layers']):
+        x = text_decoder_layer(Pm, f'text_decoder.layers.{i}.', x, memory, tc['nheads'])
+    return answer_head(Pm, x)
+
+
+# --------------------------------------------------------------------------
+# GPV forward (gpv.py:137-207)
+# --------------------------------------------------------------------------
+def gpv_encode(Pm: P, cfg: dict, images: Tensor, mask: Tensor, query_ids: Tensor,
+               query_attn: Tensor, training: bool = False) -> Tuple[dict, Tensor]:
+    out = detr_forward(Pm, cfg, images, mask, training)
+    out['detr_hs'] = linear(out['detr_hs'], Pm['detr_joiner.weight'], Pm['detr_joiner.bias'])
+    with torch.no_grad():
+        q = bert_forward(Pm, query_ids, query_attn)
+    lv = linear(q.detach(), Pm['bert_joiner.weight'], Pm['bert_joiner.bias'])
+    vl = out['detr_hs'][-1]
+    ca = cfg['co_att']
+    for i in range(ca['num_layers']):
+        lv, vl = co_attention_layer(Pm, f'co_att_transformer.{i}.', lv, vl, ca['bi_num_attention_heads'])
+    rel = linear(vl, Pm['relevance_predictor.weight'], Pm['relevance_predictor.bias'])
+    out['pred_relevance_logits'] = out['pred_relevance_logits'] + rel
+    if cfg.get('relevance_conditioning', True):          # gpv.py:364-375
+        prob = out['pred_relevance_logits'].softmax(-1)   # B,R,2
+        vl = vl + prob @ Pm['relevance_tokens']
+    memory = torch.cat((vl, lv), 1)
+    return out, memory
+
+
+def gpv_forward(Pm: P, cfg: dict, images: Tensor, mask: Tensor, query_ids: Tensor, query_attn: Tensor,
+                answer_token_ids: Optional[Tensor] = None, vocab_mask: Optional[Tensor] = None,
+                training: bool = False) -> dict:
+    out, memory = gpv_encode(Pm, cfg, images, mask, query_ids, query_attn, training)
+    B = memory.shape[0]
+    if answer_token_ids is None:                          # greedy, gpv.py:178-196
+        ids = torch.full((B, 1), cfg['_cls_id'], dtype=torch.long)
+        for _ in range(cfg['max_text_len'] - 1):
+            logits = decode_text(Pm, cfg, answer_input_embed(Pm, ids), memory)[:, -1]
+            if vocab_mask is not None:
+                logits = logits + vocab_mask
+            ids = torch.cat((ids, logits.topk(1, -1).indices), -1)
+        logits = decode_text(Pm, cfg, answer_input_embed(Pm, ids), memory)
+        if vocab_mask is not None:
+            logits = logits + vocab_mask
+        out['answer_logits'] = logits[None]
+        out['greedy_ids'] = ids
+    else:                                                 # teacher forcing, gpv.py:197-201
+        logits = decode_text(Pm, cfg, answer_input_embed(Pm, answer_token_ids), memory)
+        out['answer_logits'] = logits[None, :, :-1]
+    out['memory'] = memory
+    return out
+
+
+def beam_search(Pm: P, cfg: dict, memory: Tensor, K: int, vocab: List[str]):
+    """gpv.py:256-362 with its quirks kept: no length normalisation; finished beams keep
+    extending (the `is True` identity test never fires); slot max_text_len-1 of seqs is never
+    written (stays 0); ties keep (k1,k2) order (python sorted is stable, reverse=True keeps
+    original order among equals)."""
+    B = memory.shape[0]
+    T = cfg['max_text_len']
+    tok = torch.full((K, B, 1), cfg['_cls_id'], dtype=torch.long)
+    seq_lp = torch.zeros(B, K)
+    seqs = torch.zeros(K, B, T, dtype=torch.long)
+    for t in range(T - 1):
+        scores = torch.empty(B, K, K)
+        last = torch.empty(K, B, K, dtype=torch.long)
+        for k1 in range(K):
+            lp = F.log_softmax(decode_text(Pm, cfg, answer_input_embed(Pm, tok[k1]), memory), -1)[:, -1]
+            top = lp.topk(K, -1)
+            last[k1] = top.indices
+            scores[:, k1] = seq_lp[:, k1:k1 + 1] + top.values
+            if t == 0 and k1 > 0:
+                scores[:, k1] = scores[:, k1] * 0 - 1e9
+        flat = scores.reshape(B, K * K)
+        order = torch.sort(flat, dim=1, descending=True, stable=True).indices[:, :K]
+        new_tok = torch.empty(K, B, tok.shape[2] + 1, dtype=torch.long)
+        new_seqs = torch.zeros_like(seqs)
+        for b in range(B):
+            for k in range(K):
+                k1, k2 = divmod(int(order[b, k]), K)
+                w = last[k1, b, k2]
+                new_tok[k, b, :-1] = tok[k1, b]
+                new_tok[k, b, -1] = w
+                seq_lp[b, k] = flat[b, order[b, k]]
+                new_seqs[k, b, :t] = seqs[k1, b, :t]
+                new_seqs[k, b, t] = w
+        tok, seqs = new_tok, new_seqs
+    answers, probs = [], []
+    for b in range(B):
+        answers.append([])
+        probs.append([])
+        for k in range(K):
+            words = []
+            for t in range(T):
+                wd = vocab[int(seqs[k, b, t])]
+                if wd in ('__stop__', '__pad__'):
+                    break
+                words.append(wd)
+            answers[b].append(words)
+            probs[b].append(float(seq_lp[b, k].exp()))
+    return answers, probs, seqs
+
+
+# --------------------------------------------------------------------------
+# losses (losses.py, utils/set_criterion.py, utils/matcher.py, utils/box_ops.py)
+# --------------------------------------------------------------------------
+def box_cxcywh_to_xyxy(x: Tensor) -> Tensor:
+    cx, cy, w, h = x.unbind(-1)
+    return torch.stack((cx - 0.5 * w, cy - 0.5 * h, cx + 0.5 * w, cy + 0.5 * h), -1)
+
+
+def generalized_box_iou(a: Tensor, b: Tensor) -> Tensor:
+    """box_ops.py:24-59 pairwise (N,M)."""
+    assert (a[:, 2:] >= a[:, :2]).all() and (b[:, 2:] >= b[:, :2]).all()
+    area_a = (a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1])
+    area_b = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+    lt = torch.max(a[:, None, :2], b[:, :2])
+    rb = torch.min(a[:, None, 2:], b[:, 2:])
+    wh = (rb - lt).clamp(min=0)
+    inter = wh[..., 0] * wh[..., 1]
+    union = area_a[:, None] + area_b - inter
+    iou = inter / union
+    lt = torch.min(a[:, None, :2], b[:, :2])
+    rb = torch.max(a[:, None, 2:], b[:, 2:])
+    wh = (rb - lt).clamp(min=0)
+    area = wh[..., 0] * wh[..., 1]
+    return iou - (area - union) / area
+
+
+def matcher_cost(logits: Tensor, boxes: Tensor, tgt_ids: Tensor, tgt_boxes: Tensor,
+                 w_class=1.0, w_bbox=5.0, w_giou=2.0) -> Tensor:
+    """matcher.py:53-72.  logits (N,2) boxes (N,4) -> C (N, M)."""
+    prob = logits.softmax(-1)
+    c_class = -prob[:, tgt_ids]
+    c_bbox = (boxes[:, None, :] - tgt_boxes[None]).abs().sum(-1)
+    c_giou = -generalized_box_iou(box_cxcywh_to_xyxy(boxes), box_cxcywh_to_xyxy(tgt_boxes))
+    return w_bbox * c_bbox + w_class * c_class + w_giou * c_giou
+
+
+@torch.no_grad()
+def hungarian_match(logits: Tensor, boxes: Tensor, targets: List[dict], wts=(1.0, 5.0, 2.0)):
+    """matcher.py:32-77 -> list of (idx_pred, idx_tgt) int64."""
+    B, Q = logits.shape[:2]
+    tgt_ids = torch.cat([t['labels'] for t in targets])
+    tgt_boxes = torch.cat([t['boxes'] for t in targets])
+    C = matcher_cost(logits.flatten(0, 1), boxes.flatten(0, 1), tgt_ids, tgt_boxes, *wts).view(B, Q, -1)
+    sizes = [len(t['boxes']) for t in targets]
+    res = []
+    for i, c in enumerate(C.split(sizes, -1)):
+        r, cidx = linear_sum_assignment(c[i].numpy())
+        res.append((torch.as_tensor(r, dtype=torch.int64), torch.as_tensor(cidx, dtype=torch.int64)))
+    return res, C
+
+
+def set_criterion(logits: Tensor, boxes: Tensor, targets: List[dict], eos_coef=0.1, num_classes=1,
+                  wts=(1.0, 5.0, 2.0)) -> dict:
+    """set_criterion.py:150-191 with losses ['labels','boxes'] (no aux)."""
+    indices, _ = hungarian_match(logits, boxes, targets, wts)
+    num_boxes = max(float(sum(len(t['labels']) for t in targets)), 1.0)
+    bidx = torch.cat([torch.full_like(s, i) for i, (s, _) in enumerate(indices)])
+    sidx = torch.cat([s for s, _ in indices])
+    tco = torch.cat([t['labels'][j] for t, (_, j) in zip(targets, indices)])
+    tc = torch.full(logits.shape[:2], num_classes, dtype=torch.int64)
+    tc[bidx, sidx] = tco
+    ew = torch.ones(num_classes + 1)
+    ew[-1] = eos_coef
+    lp = F.log_softmax(logits, -1)
+    nll = -lp.gather(-1, tc[..., None])[..., 0]
+    wt = ew[tc]
+    loss_ce = (nll * wt).sum() / wt.sum()
+    sb = boxes[bidx, sidx]
+    tb = torch.cat([t['boxes'][j] for t, (_, j) in zip(targets, indices)], 0)
+    loss_bbox = (sb - tb).abs().sum() / num_boxes
+    giou = torch.diag(generalized_box_iou(box_cxcywh_to_xyxy(sb), box_cxcywh_to_xyxy(tb)))
+    loss_giou = (1 - giou).sum() / num_boxes
+    return {'loss_ce': loss_ce, 'loss_bbox': loss_bbox, 'loss_giou': loss_giou, 'indices': indices}
+
+
+def answer_ce(logits: Tensor, tgt: Tensor) -> Tensor:
+    """losses.py:20-26 : CE(reduction none) over (L=1,B,S,V) -> mean over batch, sum over positions."""
+    lp = F.log_softmax(logits, -1)
+    nll = -lp.gather(-1, tgt[..., None])[..., 0]        # (B,S)
+    return nll.mean(0).sum()
+
+
+TASK_LOSS = {'CocoCaptioning': 'loss_caption', 'CocoVqa': 'loss_vqa', 'CocoClassification': 'loss_cls'}
+
+
+def gpv_criterion(out: dict, targets: List[dict], loss_cfg: dict):
+    """losses.py:141-176."""
+    ld = {}
+    for mod in ('CaptionLoss', 'VqaLoss', 'ClsLoss'):
+        if mod not in loss_cfg:
+            continue
+        name = list(loss_cfg[mod]['loss_wts'].keys())[0]
+        task = [k for k, v in TASK_LOSS.items() if v == name][0]
+        idxs = [i for i, t in enumerate(targets) if 'answer' in t and t['task'] == task]
+        if not idxs:
+            ld[name] = None
+            continue
+        lg = out['answer_logits'][0][idxs]
+        tg = torch.stack([targets[i]['answer_token_ids'] for i in idxs])
+        ld[name] = answer_ce(lg, tg)
+    if 'Localization' in loss_cfg:
+        lc = loss_cfg['Localization']
+        idxs = [i for i, t in enumerate(targets) if 'boxes' in t]
+        if not idxs:
+            ld.update({'loss_ce': None, 'loss_bbox': None, 'loss_giou': None})
+        else:
+            cw = lc['cost_wts']
+            r = set_criterion(out['pred_relevance_logits'][idxs], out['pred_boxes'][idxs],
+                              [targets[i] for i in idxs], lc['eos_coef'], lc['num_classes'],
+                              (cw['ce'], cw['bbox'], cw['giou']))
+            ld.update({k: r[k] for k in ('loss_ce', 'loss_bbox', 'loss_giou')})
+            ld['_indices'] = r['indices']
+    if all(v is None for k, v in ld.items() if not k.startswith('_')):
+        return None, ld
+    total = 0
+    for mod, mc in loss_cfg.items():
+        for k, wt in mc['loss_wts'].items():
+            if ld.get(k) is not None:
+                total = total + wt * ld[k]
+    return total, ld
+
+
+# --------------------------------------------------------------------------
+# host text side (gpv.py:377-447).  nltk is absent: the tokenizer is injectable; the default
+# covers what the reference's answers contain (lower-cased words, punctuation split off).
+# --------------------------------------------------------------------------
+def simple_word_tokenize(s: str) -> List[str]:
+    import re
+    return re.findall(r"__\w+__|\w+(?:'\w+)?|[^\w\s]", s)
+
+
+def encode_answers(targets: List[dict], word_to_idx: Dict[str, int], max_text_len: int,
+                   tokenize=simple_word_tokenize):
+    answers = [t.get('answer', '') for t in targets]
+    toks = []
+    for a in answers:
+        sent = '__cls__ __stop__' if a == '' else f'__cls__ {a} __stop__'
+        toks.append([w.lower() for w in tokenize(sent)])
+    S = max(len(t) for t in toks)
+    ids = []
+    for t in toks:
+        t.extend(['__pad__'] * (S - len(t)))
+        ids.append([word_to_idx.get(w, word_to_idx['__unk__']) for w in t][:max_text_len])
+    return toks, torch.tensor(ids, dtype=torch.long)

@@ -1,0 +1,170 @@
+"""Deterministic synthetic configs / weights / inputs shared by the golden generator
+(tools/gen_golden.py, run in the build container against the real reference), the CPU
+oracle tests and the GPU parity tests.  Nothing here reads /root/reference.
+
+Weights are a pure function of (parameter name, shape): ``torch.Generator`` seeded with
+crc32(name), so a fixture only has to store the name->shape manifest and the reference's
+OUTPUTS; the inputs/weights are regenerated bit-identically wherever the test runs.
+"""
+import copy
+import zlib
+
+import torch
+
+
+def model_cfg(**over):
+    """Mirror of configs/exp/gpv.yaml:27-117 (model + losses) as a plain dict."""
+    cfg = {
+        'pretr_detr': None, 'vocab': None, 'vocab_embed': None,
+        'max_pos_enc_len': 30, 'max_text_len': 20, 'answer_head': None,
+        'answering_type': 'generation', 'hidden_dim': 768, 'roi_head': True,
+        'relevance_conditioning': True,
+        'detr': {'num_queries': 100, 'num_classes': 1, 'hidden_dim': 256, 'nheads': 8,
+                 'num_encoder_layers': 6, 'num_decoder_layers': 6, 'backbone': 'resnet50',
+                 'lr_backbone': 1e-5, 'position_embedding': 'sine', 'masks': False,
+                 'dilation': False, 'dropout': 0.1, 'dim_feedforward': 2048, 'pre_norm': False,
+                 'aux_loss': False, 'frozenbatchnorm': True, 'last_layer_only': True},
+        'detr_joiner': {'detr_dim': 2304, 'out_dim': 768},
+        'bert_joiner': {'bert_dim': 768, 'out_dim': 768},
+        'text_decoder': {'hidden_dim': 768, 'dropout': 0.1, 'nheads': 8, 'pos_enc': False,
+                         'num_layers': 3},
+        'co_att': {'visualization': False, 'bi_num_attention_heads': 16, 'bi_hidden_size': 768,
+                   'hidden_size': 768, 'intermediate_size': 3072, 'output_size': 768,
+                   'attention_probs_dropout_prob': 0.1, 'hidden_dropout_prob': 0.1,
+                   'hidden_act': 'gelu', 'v_hidden_size': 768, 'v_intermediate_size': 3072,
+                   'v_output_size': 768, 'v_attention_probs_dropout_prob': 0.1,
+                   'v_hidden_dropout_prob': 0.1, 'v_hidden_act': 'gelu', 'num_layers': 3},
+        'losses': {
+            'CaptionLoss': {'name': 'caption_criterion', 'pad_idx': None, 'loss_wts': {'loss_caption': 5e-2}},
+            'VqaLoss': {'name': 'vqa_criterion', 'pad_idx': None, 'loss_wts': {'loss_vqa': 1}},
+            'ClsLoss': {'name': 'cls_criterion', 'pad_idx': None, 'loss_wts': {'loss_cls': 1}},
+            'Localization': {'name': 'localization_criterion',
+                             'cost_wts': {'ce': 1, 'bbox': 5, 'giou': 2},
+                             'loss_wts': {'loss_ce': 1, 'loss_bbox': 5, 'loss_giou': 2},
+                             'eos_coef': 0.1, 'num_classes': 1},
+        },
+    }
+    cfg = copy.deepcopy(cfg)
+
+    def merge(d, o):
+        for k, v in o.items():
+            if isinstance(v, dict) and isinstance(d.get(k), dict):
+                merge(d[k], v)
+            else:
+                d[k] = v
+    merge(cfg, over)
+    return cfg
+
+
+def small_cfg(dropout=0.0, **over):
+    """Reduced problem used by the committed goldens: real widths/head sizes (dh 32/48/96), but
+    10 queries, 2+2 DETR layers, 2 co-attention layers, 2 text-decoder layers, max_text_len 6."""
+    c = model_cfg(
+        max_text_len=6,
+        detr={'num_queries': 10, 'num_encoder_layers': 2, 'num_decoder_layers': 2, 'dropout': dropout},
+        text_decoder={'num_layers': 2, 'dropout': dropout},
+        co_att={'num_layers': 2, 'attention_probs_dropout_prob': dropout, 'hidden_dropout_prob': dropout,
+                'v_attention_probs_dropout_prob': dropout, 'v_hidden_dropout_prob': dropout})
+    for k, v in over.items():
+        c[k] = v
+    return c
+
+
+def make_vocab(V):
+    """specials are the LAST four entries (exp/gpv/compute_vocab_bert.py:35-41)."""
+    words = [f'w{i}' for i in range(V - 4)]
+    return words + ['__pad__', '__cls__', '__stop__', '__unk__']
+
+
+def synth_tensor(name, shape, dtype=torch.float32):
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()))
+    shape = tuple(shape)
+    if dtype in (torch.int64, torch.long):          # e.g. bert position_ids buffers
+        n = 1
+        for s in shape:
+            n *= s
+        return torch.arange(shape[-1]).expand(shape).clone() if shape else torch.zeros((), dtype=torch.long)
+    last = name.rsplit('.', 1)[-1]
+    if last == 'empty_weight':
+        return None                                   # criterion buffer [1, eos_coef]: derived from cfg
+    if last == 'running_var':
+        return torch.rand(shape, generator=g) + 0.5
+    if last == 'running_mean':
+        return 0.1 * torch.randn(shape, generator=g)
+    if last == 'num_batches_tracked':
+        return torch.zeros(shape)
+    if len(shape) <= 1:
+        low = name.lower()
+        if last == 'weight' and ('norm' in low or '.bn' in low or 'downsample.1' in low):
+            return 1.0 + 0.1 * torch.randn(shape, generator=g)
+        if last in ('vision_token', 'lang_token'):
+            return 0.1 * torch.randn(shape, generator=g)
+        return 0.02 * torch.randn(shape, generator=g)
+    if name == 'pos_enc':
+        return None                                   # deterministic buffer, kept from the model
+    if 'embed' in name.lower() and len(shape) == 2:
+        return 0.1 * torch.randn(shape, generator=g) if 'vocab_embed' in name or 'embedding_layer' in name \
+            else 0.5 * torch.randn(shape, generator=g)
+    if name == 'relevance_tokens':
+        return 0.1 * torch.randn(shape, generator=g)
+    fan_in = 1
+    for s in shape[1:]:
+        fan_in *= s
+    gain = 1.4 if ('conv' in name or 'downsample.0' in name) else 1.0
+    return gain * torch.randn(shape, generator=g) / fan_in ** 0.5
+
+
+def synth_state(manifest):
+    """manifest: {name: [shape, dtype_str]} -> {name: tensor} (skips entries synth returns None for)."""
+    out = {}
+    for name, (shape, dt) in manifest.items():
+        dtype = getattr(torch, dt.replace('torch.', ''))
+        t = synth_tensor(name, shape, dtype)
+        if t is not None:
+            out[name] = t.to(dtype)
+    # the two frozen copies of the vocabulary embedding are one tensor in the reference
+    if 'answer_head.vocab_embed' in out and 'answer_input_embedings.embedding_layer.weight' in out:
+        out['answer_input_embedings.embedding_layer.weight'] = out['answer_head.vocab_embed'].clone()
+    return out
+
+
+def synth_batch(B, H, W, Tl, V, seed=1234, pad_to=None):
+    """images N(0,1) NCHW fp32, all-False padding mask (or ragged sizes padded, if pad_to),
+    BERT token ids in [1000,30000) with a ragged attention mask."""
+    g = torch.Generator().manual_seed(seed)
+    images = torch.randn(B, 3, H, W, generator=g)
+    mask = torch.zeros(B, H, W, dtype=torch.bool)
+    if pad_to is not None:                       # ragged: image i is valid on [:h_i,:w_i]
+        for i, (h, w) in enumerate(pad_to):
+            mask[i, h:, :] = True
+            mask[i, :, w:] = True
+            images[i, :, h:, :] = 0
+            images[i, :, :, w:] = 0
+    ids = torch.randint(1000, 30000, (B, Tl), generator=g)
+    attn = torch.ones(B, Tl, dtype=torch.long)
+    for i in range(B):
+        n = Tl - (i % 3)
+        attn[i, n:] = 0
+        ids[i, n:] = 0
+    return images, mask, ids, attn
+
+
+def synth_targets(B, V, S, seed=99, tasks=('CocoCaptioning', 'CocoVqa', 'CocoClassification', 'CocoDetection')):
+    """one target dict per sample, cycling through the four task types
+    (schema: datasets/coco_generic_dataset.py:98-114 + train_distr.py:410-412)."""
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for i in range(B):
+        task = tasks[i % len(tasks)]
+        t = {'task': task}
+        if task == 'CocoDetection':
+            n = int(torch.randint(1, 5, (1,), generator=g))
+            cxcy = 0.25 + 0.5 * torch.rand(n, 2, generator=g)
+            wh = 0.05 + 0.3 * torch.rand(n, 2, generator=g)
+            t['boxes'] = torch.cat((cxcy, wh), 1)
+            t['labels'] = torch.zeros(n, dtype=torch.long)
+        else:
+            n = {'CocoCaptioning': S - 2, 'CocoVqa': 1, 'CocoClassification': 1}[task]
+            t['answer'] = ' '.join(f'w{int(j)}' for j in torch.randint(0, V - 4, (n,), generator=g))
+        out.append(t)
+    return out
