@@ -1,0 +1,520 @@
+// Multi-head attention core for short sequences (Sk <= 320) on gfx950 MFMA.
+//
+// Forward / dQ kernels: one workgroup (4 waves) per (batch, head, 64-query tile); each wave owns
+// 16 queries and holds the WHOLE score row block in registers (no online softmax needed: Sk <= 320).
+//   S^T tile  = mfma(A = K rows (keys), B = Q cols (queries))  -> lane holds S^T[key=4g+i][q=lane&15]
+//   so a lane owns ONE query: row max / sum are a register reduction + two xor-shuffles (16, 32),
+//   and the exponentiated scores are directly the B-operand fragments of  O^T = V^T P^T
+//   (k-slot order {4g+i} U {16+4g+i} is used consistently for both operands).
+// dK/dV kernel: one workgroup per (batch, head, 64-key tile); each wave owns 16 keys and streams
+// query chunks through LDS (Q, dO and their transposes).
+// K is staged [key][d] (ds_read_b128 fragments), V / K / Q / dO transposes are staged [d][t] through
+// a register transpose (pairs of rows -> ds_write_b32) and read with ds_read_b64.
+// T = bf16: bf16 I/O.  T = float: fp32 I/O, every operand split hi+lo bf16 (3 MFMAs per product).
+#include "common.h"
+#include "../../include/gpv_hip.h"
+
+namespace {
+
+struct AttnK {
+  const void* q; const void* k; const void* v; void* o;
+  int64_t q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs;
+  int B, H, Sq, Sk, dh, skp;
+  float scale;
+  const uint8_t* kpm; int causal;
+  uint32_t dthresh; float dscale; uint64_t seed;
+  float* lse;
+  const void* dout; int64_t do_bs, do_rs;
+  void* dq; void* dk; void* dv;
+};
+
+template <typename T> struct R8 {  // 8 staged values as floats
+  float v[8];
+  __device__ __forceinline__ void zero() {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = 0.f;
+  }
+  __device__ __forceinline__ void load(const T* p) { Ld8<T>::ld(p, v); }
+  __device__ __forceinline__ bf16x8 hi() const {
+    bf16x8 r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r[i] = (bf16)v[i];
+    return r;
+  }
+  __device__ __forceinline__ bf16x8 lo() const {
+    bf16x8 r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r[i] = (bf16)(v[i] - (float)(bf16)v[i]);
+    return r;
+  }
+};
+
+// stage a [rows_valid x dh] row-major global tile into LDS [rows_pad][PITCH] (k-contiguous), zero padded
+template <typename T, bool PRECISE, int DHK>
+__device__ __forceinline__ void stage_rows(const T* g, int64_t rs, int rows_valid, int rows_pad, int dh, bf16* hi, bf16* lo) {
+  constexpr int PITCH = DHK + 8;
+  constexpr int SL = DHK / 8;
+  for (int idx = threadIdx.x; idx < rows_pad * SL; idx += 256) {
+    int r = idx / SL, sl = idx - r * SL;
+    R8<T> x;
+    if (r < rows_valid && sl * 8 < dh) x.load(g + (int64_t)r * rs + sl * 8); else x.zero();
+    *reinterpret_cast<bf16x8*>(hi + r * PITCH + sl * 8) = x.hi();
+    if (PRECISE) *reinterpret_cast<bf16x8*>(lo + r * PITCH + sl * 8) = x.lo();
+  }
+}
+// stage transposed: LDS [DHV][pitch] with element (d, r) = g[r][d]; rows_pad even
+template <typename T, bool PRECISE, int DHV>
+__device__ __forceinline__ void stage_cols(const T* g, int64_t rs, int rows_valid, int rows_pad, int pitch, bf16* hi, bf16* lo) {
+  constexpr int DG = DHV / 8;
+  const int np = rows_pad / 2;
+  for (int idx = threadIdx.x; idx < np * DG; idx += 256) {
+    int dg = idx / np, rp = idx - dg * np;
+    R8<T> a, b;
+    if (2 * rp < rows_valid) a.load(g + (int64_t)(2 * rp) * rs + dg * 8); else a.zero();
+    if (2 * rp + 1 < rows_valid) b.load(g + (int64_t)(2 * rp + 1) * rs + dg * 8); else b.zero();
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      bf16x2 h; h[0] = (bf16)a.v[c]; h[1] = (bf16)b.v[c];
+      *reinterpret_cast<bf16x2*>(hi + (dg * 8 + c) * pitch + 2 * rp) = h;
+      if (PRECISE) {
+        bf16x2 l; l[0] = (bf16)(a.v[c] - (float)h[0]); l[1] = (bf16)(b.v[c] - (float)h[1]);
+        *reinterpret_cast<bf16x2*>(lo + (dg * 8 + c) * pitch + 2 * rp) = l;
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ bf16x8 ld_pair64(const bf16* p0, const bf16* p1) {
+  bf16x4 a = *reinterpret_cast<const bf16x4*>(p0);
+  bf16x4 b = *reinterpret_cast<const bf16x4*>(p1);
+  bf16x8 r;
+  r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = a[3]; r[4] = b[0]; r[5] = b[1]; r[6] = b[2]; r[7] = b[3];
+  return r;
+}
+
+// MODE 0: forward (writes o, lse).  MODE 1: dQ (reads dout, o, lse; writes dq)
+template <typename T, int DHK, int DHV, int NT, int MODE>
+__global__ __launch_bounds__(256) void attn_q_kernel(AttnK p) {
+  constexpr bool PRECISE = sizeof(T) == 4;
+  constexpr int KP = DHK + 8;
+  constexpr int KC = DHK / 32;
+  constexpr int DT = DHV / 16;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  bf16* sm = reinterpret_cast<bf16*>(smem_raw);
+  const int skp = p.skp, ntr = skp / 16, vtp = skp + 8;
+  // LDS carve: K[skp][KP] (hi,lo) | X^T[DHV][vtp] (hi,lo)  (X = V fwd, K for dQ) | (dQ only) V[skp][KP] (hi,lo)
+  bf16* Kh = sm;
+  bf16* Kl = Kh + (PRECISE ? skp * KP : 0);
+  bf16* Th = Kl + skp * KP;
+  bf16* Tl = Th + (PRECISE ? DHV * vtp : 0);
+  bf16* Vh = Tl + DHV * vtp;
+  bf16* Vl = Vh + (PRECISE ? skp * KP : 0);
+
+  const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
+  const T* kg = reinterpret_cast<const T*>(p.k) + b * p.k_bs + h * p.dh;
+  const T* vg = reinterpret_cast<const T*>(p.v) + b * p.v_bs + h * p.dh;
+  stage_rows<T, PRECISE, DHK>(kg, p.k_rs, p.Sk, skp, p.dh, Kh, Kl);
+  if (MODE == 0) stage_cols<T, PRECISE, DHV>(vg, p.v_rs, p.Sk, skp, vtp, Th, Tl);
+  else {
+    stage_cols<T, PRECISE, DHV>(kg, p.k_rs, p.Sk, skp, vtp, Th, Tl);
+    stage_rows<T, PRECISE, DHK>(vg, p.v_rs, p.Sk, skp, p.dh, Vh, Vl);
+  }
+  __syncthreads();
+
+  const int q = q0 + wave * 16 + (lane & 15);
+  const bool qok = q < p.Sq;
+  // Q (and dO, O) fragments straight from global: lane (q, g) holds d = kc*32 + g*8 .. +7
+  bf16x8 qh[KC], ql[KC], doh[KC], dol[KC];
+  float delta = 0.f;
+  {
+    const T* qp = reinterpret_cast<const T*>(p.q) + b * p.q_bs + (int64_t)q * p.q_rs + h * p.dh;
+    const T* dop = MODE ? reinterpret_cast<const T*>(p.dout) + b * p.do_bs + (int64_t)q * p.do_rs + h * p.dh : nullptr;
+    const T* op = MODE ? reinterpret_cast<const T*>(p.o) + b * p.o_bs + (int64_t)q * p.o_rs + h * p.dh : nullptr;
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) {
+      const int d0 = kc * 32 + g * 8;
+      R8<T> x;
+      if (qok && d0 < p.dh) x.load(qp + d0); else x.zero();
+      qh[kc] = x.hi(); ql[kc] = x.lo();
+      if (MODE) {
+        R8<T> y, z;
+        if (qok && d0 < p.dh) { y.load(dop + d0); z.load(op + d0); } else { y.zero(); z.zero(); }
+        doh[kc] = y.hi(); dol[kc] = y.lo();
+#pragma unroll
+        for (int e = 0; e < 8; ++e) delta += y.v[e] * z.v[e];
+      }
+    }
+    if (MODE) { delta += __shfl_xor(delta, 16); delta += __shfl_xor(delta, 32); }
+  }
+
+  // ---- scores S^T[key][q] for all key tiles ----
+  f32x4 s[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    s[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (j < ntr) {
+#pragma unroll
+      for (int kc = 0; kc < KC; ++kc) {
+        const int off = (j * 16 + (lane & 15)) * KP + kc * 32 + g * 8;
+        bf16x8 kh = *reinterpret_cast<const bf16x8*>(Kh + off);
+        s[j] = mfma16(kh, qh[kc], s[j]);
+        if (PRECISE) {
+          bf16x8 kl = *reinterpret_cast<const bf16x8*>(Kl + off);
+          s[j] = mfma16(kl, qh[kc], s[j]);
+          s[j] = mfma16(kh, ql[kc], s[j]);
+        }
+      }
+    }
+  }
+  const uint8_t* kpm = p.kpm ? p.kpm + (int64_t)b * p.Sk : nullptr;
+  float mx = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int key = j * 16 + g * 4 + i;
+      bool dead = key >= p.Sk || (p.causal && key > q);
+      if (!dead && kpm) dead = kpm[key] != 0;
+      float x = dead ? -INFINITY : s[j][i] * p.scale;
+      s[j][i] = x;
+      mx = fmaxf(mx, x);
+    }
+  }
+  float lsum = 0.f, lse_q = 0.f;
+  if (MODE == 0) {
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float mref = mx == -INFINITY ? 0.f : mx;
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { float e = __expf(s[j][i] - mref); s[j][i] = e; lsum += e; }
+    lsum += __shfl_xor(lsum, 16);
+    lsum += __shfl_xor(lsum, 32);
+    if (g == 0 && qok && p.lse) p.lse[((int64_t)b * p.H + h) * p.Sq + q] = mref + logf(lsum);
+  } else {
+    lse_q = qok ? p.lse[((int64_t)b * p.H + h) * p.Sq + q] : 0.f;
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) s[j][i] = __expf(s[j][i] - lse_q);   // normalised P (masked -> 0)
+  }
+
+  const uint64_t rng_row = (((uint64_t)b * p.H + h) * p.Sq + q) * (uint64_t)p.Sk;
+  if (MODE == 1) {
+    // dP^T[key][q] = sum_d V[key][d] dO[q][d] ; dS = P * (dPd - delta) * scale
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      f32x4 dp = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (j < ntr) {
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {
+          const int off = (j * 16 + (lane & 15)) * KP + kc * 32 + g * 8;
+          bf16x8 vh = *reinterpret_cast<const bf16x8*>(Vh + off);
+          dp = mfma16(vh, doh[kc], dp);
+          if (PRECISE) {
+            bf16x8 vl = *reinterpret_cast<const bf16x8*>(Vl + off);
+            dp = mfma16(vl, doh[kc], dp);
+            dp = mfma16(vh, dol[kc], dp);
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float d = dp[i];
+        if (p.dthresh) d = drop_keep(p.seed, rng_row + (j * 16 + g * 4 + i), p.dthresh) ? d * p.dscale : 0.f;
+        s[j][i] = s[j][i] * (d - delta) * p.scale;
+      }
+    }
+  } else if (p.dthresh) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        s[j][i] = drop_keep(p.seed, rng_row + (j * 16 + g * 4 + i), p.dthresh) ? s[j][i] * p.dscale : 0.f;
+  }
+
+  // ---- out^T[d][q] = sum_key X^T[d][key] * s[key][q]   (X = V forward, K for dQ) ----
+  f32x4 oacc[DT];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kb = 0; kb < NT / 2; ++kb) {
+    if (kb * 2 < ntr) {
+      bf16x8 ph, pl;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float a = s[2 * kb][i], c = s[2 * kb + 1][i];
+        ph[i] = (bf16)a; ph[4 + i] = (bf16)c;
+        pl[i] = (bf16)(a - (float)ph[i]); pl[4 + i] = (bf16)(c - (float)ph[4 + i]);
+      }
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        const int off = (dt * 16 + (lane & 15)) * vtp + kb * 32 + g * 4;
+        bf16x8 xh = ld_pair64(Th + off, Th + off + 16);
+        oacc[dt] = mfma16(xh, ph, oacc[dt]);
+        if (PRECISE) {
+          bf16x8 xl = ld_pair64(Tl + off, Tl + off + 16);
+          oacc[dt] = mfma16(xl, ph, oacc[dt]);
+          oacc[dt] = mfma16(xh, pl, oacc[dt]);
+        }
+      }
+    }
+  }
+  if (!qok) return;
+  T* outp = (MODE == 0 ? reinterpret_cast<T*>(p.o) + b * p.o_bs + (int64_t)q * p.o_rs
+                       : reinterpret_cast<T*>(p.dq) + b * p.q_bs + (int64_t)q * p.q_rs) + h * p.dh;
+  const float inv = MODE == 0 ? (lsum > 0.f ? 1.f / lsum : 0.f) : 1.f;
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) {
+    const int d = dt * 16 + g * 4;
+    if (sizeof(T) == 4) {
+      *reinterpret_cast<float4*>(reinterpret_cast<float*>(outp) + d) =
+          make_float4(oacc[dt][0] * inv, oacc[dt][1] * inv, oacc[dt][2] * inv, oacc[dt][3] * inv);
+    } else {
+      bf16x4 o4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o4[i] = (bf16)(oacc[dt][i] * inv);
+      *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(outp) + d) = o4;
+    }
+  }
+}
+
+// dK / dV: workgroup = 64 keys of one (b,h); wave = 16 keys; queries streamed in chunks of 64.
+template <typename T, int DHK, int DHV>
+__global__ __launch_bounds__(256) void attn_kv_kernel(AttnK p) {
+  constexpr bool PRECISE = sizeof(T) == 4;
+  constexpr int KP = DHK + 8, KC = DHK / 32, DT = DHV / 16, QC = 64, QTP = QC + 8;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  bf16* sm = reinterpret_cast<bf16*>(smem_raw);
+  bf16* Qh = sm;                 bf16* Ql = Qh + (PRECISE ? QC * KP : 0);
+  bf16* Dh = Ql + QC * KP;       bf16* Dl = Dh + (PRECISE ? QC * KP : 0);
+  bf16* QTh = Dl + QC * KP;      bf16* QTl = QTh + (PRECISE ? DHV * QTP : 0);
+  bf16* DTh = QTl + DHV * QTP;   bf16* DTl = DTh + (PRECISE ? DHV * QTP : 0);
+  float* lse_s = reinterpret_cast<float*>(DTl + DHV * QTP);
+  float* del_s = lse_s + QC;
+
+  const int b = blockIdx.z, h = blockIdx.y, k0 = blockIdx.x * 64;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
+  const int key = k0 + wave * 16 + (lane & 15);
+  const bool kok = key < p.Sk;
+  bool kdead = !kok;
+  if (kok && p.kpm) kdead = p.kpm[(int64_t)b * p.Sk + key] != 0;
+
+  bf16x8 kh[KC], kl[KC], vh[KC], vl[KC];
+  {
+    const T* kp_ = reinterpret_cast<const T*>(p.k) + b * p.k_bs + (int64_t)key * p.k_rs + h * p.dh;
+    const T* vp_ = reinterpret_cast<const T*>(p.v) + b * p.v_bs + (int64_t)key * p.v_rs + h * p.dh;
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) {
+      const int d0 = kc * 32 + g * 8;
+      R8<T> x, y;
+      if (kok && d0 < p.dh) { x.load(kp_ + d0); y.load(vp_ + d0); } else { x.zero(); y.zero(); }
+      kh[kc] = x.hi(); kl[kc] = x.lo(); vh[kc] = y.hi(); vl[kc] = y.lo();
+    }
+  }
+  f32x4 dkacc[DT], dvacc[DT];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) { dkacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dvacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+  const T* qg = reinterpret_cast<const T*>(p.q) + b * p.q_bs + h * p.dh;
+  const T* dog = reinterpret_cast<const T*>(p.dout) + b * p.do_bs + h * p.dh;
+  const T* og = reinterpret_cast<const T*>(p.o) + b * p.o_bs + h * p.dh;
+
+  for (int qc0 = 0; qc0 < p.Sq; qc0 += QC) {
+    const int nq = min(QC, p.Sq - qc0);
+    __syncthreads();
+    stage_rows<T, PRECISE, DHK>(qg + (int64_t)qc0 * p.q_rs, p.q_rs, nq, QC, p.dh, Qh, Ql);
+    stage_rows<T, PRECISE, DHK>(dog + (int64_t)qc0 * p.do_rs, p.do_rs, nq, QC, p.dh, Dh, Dl);
+    stage_cols<T, PRECISE, DHV>(qg + (int64_t)qc0 * p.q_rs, p.q_rs, nq, QC, QTP, QTh, QTl);
+    stage_cols<T, PRECISE, DHV>(dog + (int64_t)qc0 * p.do_rs, p.do_rs, nq, QC, QTP, DTh, DTl);
+    if (threadIdx.x < QC) {
+      const int r = threadIdx.x;
+      float dl = 0.f, ls = INFINITY;
+      if (r < nq) {
+        const T* a = dog + (int64_t)(qc0 + r) * p.do_rs;
+        const T* c = og + (int64_t)(qc0 + r) * p.o_rs;
+        for (int d = 0; d < p.dh; d += 8) {
+          float u[8], w[8];
+          Ld8<T>::ld(a + d, u); Ld8<T>::ld(c + d, w);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) dl += u[e] * w[e];
+        }
+        ls = p.lse[((int64_t)b * p.H + h) * p.Sq + qc0 + r];
+      }
+      lse_s[r] = ls; del_s[r] = dl;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int qb = 0; qb < QC / 32; ++qb) {
+      if (qb * 32 >= nq) break;
+      f32x4 pr[2], ds[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        f32x4 sa = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {
+          const int off = (qb * 32 + t * 16 + (lane & 15)) * KP + kc * 32 + g * 8;
+          bf16x8 qh_ = *reinterpret_cast<const bf16x8*>(Qh + off);
+          bf16x8 dh_ = *reinterpret_cast<const bf16x8*>(Dh + off);
+          sa = mfma16(qh_, kh[kc], sa);
+          dp = mfma16(dh_, vh[kc], dp);
+          if (PRECISE) {
+            bf16x8 ql_ = *reinterpret_cast<const bf16x8*>(Ql + off);
+            bf16x8 dl_ = *reinterpret_cast<const bf16x8*>(Dl + off);
+            sa = mfma16(ql_, kh[kc], sa); sa = mfma16(qh_, kl[kc], sa);
+            dp = mfma16(dl_, vh[kc], dp); dp = mfma16(dh_, vl[kc], dp);
+          }
+        }
+        const int qr = qb * 32 + t * 16 + g * 4;   // local query row of element i = qr + i
+        const float4 l4 = *reinterpret_cast<const float4*>(lse_s + qr);
+        const float4 d4 = *reinterpret_cast<const float4*>(del_s + qr);
+        const float ls[4] = {l4.x, l4.y, l4.z, l4.w};
+        const float dl[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int qq = qc0 + qr + i;
+          bool dead = kdead || (p.causal && key > qq);
+          float pv = dead ? 0.f : __expf(sa[i] * p.scale - ls[i]);   // ls = +inf for padded queries -> 0
+          float d = dp[i], pd = pv;
+          if (p.dthresh) {
+            const bool keep = drop_keep(p.seed, (((uint64_t)b * p.H + h) * p.Sq + qq) * (uint64_t)p.Sk + key, p.dthresh);
+            d = keep ? d * p.dscale : 0.f;
+            pd = keep ? pv * p.dscale : 0.f;
+          }
+          pr[t][i] = pd;
+          ds[t][i] = pv * (d - dl[i]) * p.scale;
+        }
+      }
+      bf16x8 ph, pl, sh, sl;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        ph[i] = (bf16)pr[0][i]; ph[4 + i] = (bf16)pr[1][i];
+        pl[i] = (bf16)(pr[0][i] - (float)ph[i]); pl[4 + i] = (bf16)(pr[1][i] - (float)ph[4 + i]);
+        sh[i] = (bf16)ds[0][i]; sh[4 + i] = (bf16)ds[1][i];
+        sl[i] = (bf16)(ds[0][i] - (float)sh[i]); sl[4 + i] = (bf16)(ds[1][i] - (float)sh[4 + i]);
+      }
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        const int off = (dt * 16 + (lane & 15)) * QTP + qb * 32 + g * 4;
+        bf16x8 dth = ld_pair64(DTh + off, DTh + off + 16);
+        bf16x8 qth = ld_pair64(QTh + off, QTh + off + 16);
+        dvacc[dt] = mfma16(dth, ph, dvacc[dt]);
+        dkacc[dt] = mfma16(qth, sh, dkacc[dt]);
+        if (PRECISE) {
+          bf16x8 dtl = ld_pair64(DTl + off, DTl + off + 16);
+          bf16x8 qtl = ld_pair64(QTl + off, QTl + off + 16);
+          dvacc[dt] = mfma16(dtl, ph, dvacc[dt]); dvacc[dt] = mfma16(dth, pl, dvacc[dt]);
+          dkacc[dt] = mfma16(qtl, sh, dkacc[dt]); dkacc[dt] = mfma16(qth, sl, dkacc[dt]);
+        }
+      }
+    }
+  }
+  if (!kok) return;
+  T* dkp = reinterpret_cast<T*>(p.dk) + b * p.k_bs + (int64_t)key * p.k_rs + h * p.dh;
+  T* dvp = reinterpret_cast<T*>(p.dv) + b * p.v_bs + (int64_t)key * p.v_rs + h * p.dh;
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) {
+    const int d = dt * 16 + g * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { dkp[d + i] = (T)dkacc[dt][i]; dvp[d + i] = (T)dvacc[dt][i]; }
+  }
+}
+
+template <typename T, int DHK, int DHV, int NT, int MODE>
+int launch_q(const AttnK& p, hipStream_t st) {
+  constexpr bool PRECISE = sizeof(T) == 4;
+  constexpr int KP = DHK + 8;
+  const int vtp = p.skp + 8;
+  size_t elems = (size_t)p.skp * KP + (size_t)DHV * vtp + (MODE ? (size_t)p.skp * KP : 0);
+  size_t lds = elems * 2 * (PRECISE ? 2 : 1);
+  auto fn = attn_q_kernel<T, DHK, DHV, NT, MODE>;
+  static size_t attr = 0;
+  if (lds > 64 * 1024 && lds > attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    attr = lds;
+  }
+  dim3 grid((p.Sq + 63) / 64, p.H, p.B);
+  hipLaunchKernelGGL(fn, grid, dim3(256), lds, st, p);
+  GPV_CHECK_LAUNCH();
+  return 0;
+}
+template <typename T, int DHK, int DHV>
+int launch_kv(const AttnK& p, hipStream_t st) {
+  constexpr bool PRECISE = sizeof(T) == 4;
+  constexpr int KP = DHK + 8, QC = 64, QTP = QC + 8;
+  size_t lds = ((size_t)2 * QC * KP + (size_t)2 * DHV * QTP) * 2 * (PRECISE ? 2 : 1) + 2 * QC * sizeof(float);
+  auto fn = attn_kv_kernel<T, DHK, DHV>;
+  static size_t attr = 0;
+  if (lds > 64 * 1024 && lds > attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    attr = lds;
+  }
+  dim3 grid((p.Sk + 63) / 64, p.H, p.B);
+  hipLaunchKernelGGL(fn, grid, dim3(256), lds, st, p);
+  GPV_CHECK_LAUNCH();
+  return 0;
+}
+
+template <typename T, int MODE>
+int dispatch_q(const AttnK& p, hipStream_t st) {
+  const bool small = p.skp <= 128;
+#define GO(DHK, DHV) return small ? launch_q<T, DHK, DHV, 8, MODE>(p, st) : launch_q<T, DHK, DHV, 20, MODE>(p, st)
+  switch (p.dh) {
+    case 32: GO(32, 32);
+    case 48: GO(64, 48);
+    case 64: GO(64, 64);
+    case 96: GO(96, 96);
+  }
+#undef GO
+  return (int)hipErrorInvalidValue;
+}
+template <typename T>
+int dispatch_kv(const AttnK& p, hipStream_t st) {
+  switch (p.dh) {
+    case 32: return launch_kv<T, 32, 32>(p, st);
+    case 48: return launch_kv<T, 64, 48>(p, st);
+    case 64: return launch_kv<T, 64, 64>(p, st);
+    case 96: return launch_kv<T, 96, 96>(p, st);
+  }
+  return (int)hipErrorInvalidValue;
+}
+
+int fill(const gpv_attn_args* a, AttnK& p) {
+  if (!a || !a->q || !a->k || !a->v || a->Sk <= 0 || a->Sq <= 0 || a->Sk > 320) return (int)hipErrorInvalidValue;
+  p.q = a->q; p.k = a->k; p.v = a->v; p.o = a->o;
+  p.q_bs = a->q_bs; p.q_rs = a->q_rs; p.k_bs = a->k_bs; p.k_rs = a->k_rs; p.v_bs = a->v_bs; p.v_rs = a->v_rs;
+  p.o_bs = a->o_bs; p.o_rs = a->o_rs;
+  p.B = a->B; p.H = a->H; p.Sq = a->Sq; p.Sk = a->Sk; p.dh = a->dh;
+  p.skp = ((a->Sk + 31) / 32) * 32;
+  p.scale = a->scale; p.kpm = a->kpm; p.causal = a->causal;
+  p.dthresh = a->drop_p > 0.f ? drop_thresh(a->drop_p) : 0u;
+  p.dscale = a->drop_p > 0.f ? 1.f / (1.f - a->drop_p) : 1.f;
+  p.seed = a->seed; p.lse = a->lse;
+  p.dout = a->dout; p.do_bs = a->do_bs; p.do_rs = a->do_rs; p.dq = a->dq; p.dk = a->dk; p.dv = a->dv;
+  return 0;
+}
+}  // namespace
+
+extern "C" int gpv_attention_fwd(const gpv_attn_args* a, void* stream) {
+  AttnK p{};
+  int e = fill(a, p);
+  if (e) return e;
+  if (!a->o) return (int)hipErrorInvalidValue;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  return a->dtype == GPV_F32 ? dispatch_q<float, 0>(p, st) : dispatch_q<bf16, 0>(p, st);
+}
+
+extern "C" int gpv_attention_bwd(const gpv_attn_args* a, void* stream) {
+  AttnK p{};
+  int e = fill(a, p);
+  if (e) return e;
+  if (!a->o || !a->dout || !a->dq || !a->dk || !a->dv || !a->lse) return (int)hipErrorInvalidValue;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  e = a->dtype == GPV_F32 ? dispatch_q<float, 1>(p, st) : dispatch_q<bf16, 1>(p, st);
+  if (e) return e;
+  return a->dtype == GPV_F32 ? dispatch_kv<float>(p, st) : dispatch_kv<bf16>(p, st);
+}

@@ -1,0 +1,90 @@
+// Shared device helpers for the gfx950 kernels (wave = 64 lanes, MFMA 16x16x32 bf16).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <type_traits>
+
+typedef __bf16 bf16;
+typedef bf16 __attribute__((ext_vector_type(8))) bf16x8;
+typedef bf16 __attribute__((ext_vector_type(4))) bf16x4;
+typedef bf16 __attribute__((ext_vector_type(2))) bf16x2;
+typedef float __attribute__((ext_vector_type(4))) f32x4;
+
+#define GPV_CHECK_LAUNCH() \
+  do {                     \
+    hipError_t e_ = hipGetLastError(); \
+    if (e_ != hipSuccess) return (int)e_; \
+  } while (0)
+
+__device__ __forceinline__ float bf2f(bf16 x) { return (float)x; }
+__device__ __forceinline__ bf16 f2bf(float x) { return (bf16)x; }
+
+// split an fp32 value into hi + lo bf16 (hi = RNE(x), lo = RNE(x - hi)): |x - hi - lo| <~ 2^-17 |x|
+__device__ __forceinline__ void split_bf16(float x, bf16& hi, bf16& lo) {
+  hi = (bf16)x;
+  lo = (bf16)(x - (float)hi);
+}
+
+// D(16x16) += A(16x32, row = lane&15, k = 8*(lane>>4)..+7) * B(32x16, col = lane&15, same k)
+// result: lane holds D[row = 4*(lane>>4)+i][col = lane&15], i = 0..3
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+// counter-based RNG for dropout: one 32-bit hash per element index (murmur3 fmix64 of seed ^ idx).
+__device__ __forceinline__ uint32_t hash_u32(uint64_t seed, uint64_t idx) {
+  uint64_t z = seed + idx * 0x9E3779B97F4A7C15ull;
+  z ^= z >> 33; z *= 0xff51afd7ed558ccdull;
+  z ^= z >> 33; z *= 0xc4ceb9fe1a85ec53ull;
+  z ^= z >> 33;
+  return (uint32_t)z;
+}
+// keep-probability (1-p): element kept iff hash >= p * 2^32
+__device__ __forceinline__ bool drop_keep(uint64_t seed, uint64_t idx, uint32_t thresh) {
+  return hash_u32(seed, idx) >= thresh;
+}
+__host__ __device__ __forceinline__ uint32_t drop_thresh(float p) {
+  double t = (double)p * 4294967296.0;
+  if (t < 0) t = 0;
+  if (t > 4294967295.0) t = 4294967295.0;
+  return (uint32_t)t;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+template <typename T> struct Ld8;   // load 8 consecutive elements as float[8]
+template <> struct Ld8<bf16> {
+  static __device__ __forceinline__ void ld(const bf16* p, float* o) {
+    bf16x8 v = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (float)v[i];
+  }
+  static __device__ __forceinline__ void st(bf16* p, const float* o) {
+    bf16x8 v;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (bf16)o[i];
+    *reinterpret_cast<bf16x8*>(p) = v;
+  }
+};
+template <> struct Ld8<float> {
+  static __device__ __forceinline__ void ld(const float* p, float* o) {
+    float4 a = *reinterpret_cast<const float4*>(p);
+    float4 b = *reinterpret_cast<const float4*>(p + 4);
+    o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+  }
+  static __device__ __forceinline__ void st(float* p, const float* o) {
+    *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]);
+    *reinterpret_cast<float4*>(p + 4) = make_float4(o[4], o[5], o[6], o[7]);
+  }
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}

@@ -1,0 +1,611 @@
+// Memory-bound kernels: LayerNorm(+residual+dropout) fwd/bwd, vocabulary softmax-CE, max-pool,
+// image layout conversion, RoI separable weights, casts / weight prep, element-wise helpers,
+// fused AdamW.  All use 16-byte vector accesses where the layout allows (gfx950 HBM-bound rules).
+#include "common.h"
+#include "../../include/gpv_hip.h"
+
+namespace {
+
+inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+inline int grid1d(int64_t n, int per_block) {
+  int64_t g = cdiv(n, per_block);
+  return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
+}
+
+// ------------------------------------------------------------------------------------------
+// LayerNorm forward: one wave per row (cols <= 8*64*MAXV), values kept in registers.
+// y = LN(x + drop(s)) * g + b
+// ------------------------------------------------------------------------------------------
+template <typename T, int NV>   // NV = number of 8-element vectors per lane (cols <= NV*512)
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const T* __restrict__ s,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     T* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd,
+                                                     int rows, int cols, float eps, uint32_t dthresh, float dscale,
+                                                     uint64_t seed) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const T* xr = x + (int64_t)row * cols;
+  const T* sr = s ? s + (int64_t)row * cols : nullptr;
+  float v[NV][8];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (i * 64 + lane) * 8;
+    if (c < cols) {
+      Ld8<T>::ld(xr + c, v[i]);
+      if (sr) {
+        float t[8];
+        Ld8<T>::ld(sr + c, t);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float sv = t[e];
+          if (dthresh) sv = drop_keep(seed, (uint64_t)row * cols + c + e, dthresh) ? sv * dscale : 0.f;
+          v[i][e] += sv;
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sum += v[i][e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
+    }
+  }
+  sum = wave_sum(sum);
+  const float mu = sum / cols;
+  float var = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (i * 64 + lane) * 8;
+    if (c < cols) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { float d = v[i][e] - mu; var += d * d; }
+    }
+  }
+  var = wave_sum(var) / cols;
+  const float rs = rsqrtf(var + eps);
+  if (lane == 0) { if (mean) mean[row] = mu; if (rstd) rstd[row] = rs; }
+  T* yr = y + (int64_t)row * cols;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (i * 64 + lane) * 8;
+    if (c < cols) {
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float n = (v[i][e] - mu) * rs;
+        o[e] = gamma ? n * gamma[c + e] + beta[c + e] : n;
+      }
+      Ld8<T>::st(yr + c, o);
+    }
+  }
+}
+
+// LayerNorm backward: one wave per row. z = x + drop(s) is recomputed.
+// dz = rstd * (g*dy - mean(g*dy) - zhat*mean(g*dy*zhat)); dx = dz ; ds = dz * dropmask
+// dgamma/dbeta accumulated per block in LDS then atomics.
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ s,
+                                                     const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, T* __restrict__ dx, T* __restrict__ ds,
+                                                     float* __restrict__ dgamma, float* __restrict__ dbeta, int rows, int cols,
+                                                     int rows_per_block, uint32_t dthresh, float dscale, uint64_t seed) {
+  extern __shared__ float lds[];   // [2][cols]
+  float* sg = lds;
+  float* sb = lds + cols;
+  if (dgamma) {
+    for (int c = threadIdx.x; c < 2 * cols; c += 256) lds[c] = 0.f;
+    __syncthreads();
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float ag[NV][8], ab[NV][8];
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ag[i][e] = ab[i][e] = 0.f;
+
+  const int r_begin = blockIdx.x * rows_per_block;
+  const int r_end = min(rows, r_begin + rows_per_block);
+  for (int row = r_begin + wave; row < r_end; row += 4) {
+    const float mu = mean[row], rs = rstd[row];
+    float zh[NV][8], gy[NV][8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (i * 64 + lane) * 8;
+      if (c < cols) {
+        float xv[8], dv[8];
+        Ld8<T>::ld(x + (int64_t)row * cols + c, xv);
+        Ld8<T>::ld(dy + (int64_t)row * cols + c, dv);
+        if (s) {
+          float t[8];
+          Ld8<T>::ld(s + (int64_t)row * cols + c, t);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float sv = t[e];
+            if (dthresh) sv = drop_keep(seed, (uint64_t)row * cols + c + e, dthresh) ? sv * dscale : 0.f;
+            xv[e] += sv;
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          zh[i][e] = (xv[e] - mu) * rs;
+          float g = gamma ? gamma[c + e] : 1.f;
+          gy[i][e] = dv[e] * g;
+          s1 += gy[i][e];
+          s2 += gy[i][e] * zh[i][e];
+          ag[i][e] += dv[e] * zh[i][e];
+          ab[i][e] += dv[e];
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) zh[i][e] = gy[i][e] = 0.f;
+      }
+    }
+    s1 = wave_sum(s1) / cols;
+    s2 = wave_sum(s2) / cols;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (i * 64 + lane) * 8;
+      if (c < cols) {
+        float o[8], o2[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          o[e] = rs * (gy[i][e] - s1 - zh[i][e] * s2);
+          if (dthresh) o2[e] = drop_keep(seed, (uint64_t)row * cols + c + e, dthresh) ? o[e] * dscale : 0.f;
+        }
+        Ld8<T>::st(dx + (int64_t)row * cols + c, o);
+        if (dthresh && ds) Ld8<T>::st(ds + (int64_t)row * cols + c, o2);
+      }
+    }
+  }
+  if (dgamma) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (i * 64 + lane) * 8;
+      if (c < cols) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { atomicAdd(&sg[c + e], ag[i][e]); atomicAdd(&sb[c + e], ab[i][e]); }
+      }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < cols; c += 256) { atomicAdd(&dgamma[c], sg[c]); atomicAdd(&dbeta[c], sb[c]); }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// softmax cross-entropy: one block per row, V up to any size (3 passes over L2-resident row).
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void ce_kernel(const T* __restrict__ logits, int64_t ld, const int64_t* __restrict__ target,
+                                                 float* __restrict__ loss, T* __restrict__ dlogits, const float* __restrict__ gscale,
+                                                 int V) {
+  __shared__ float red[8];
+  const int row = blockIdx.x;
+  const T* lr = logits + (int64_t)row * ld;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float mx = -INFINITY;
+  for (int c = tid; c < V; c += 256) mx = fmaxf(mx, (float)lr[c]);
+  mx = wave_max(mx);
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float sum = 0.f;
+  for (int c = tid; c < V; c += 256) sum += __expf((float)lr[c] - mx);
+  sum = wave_sum(sum);
+  if (lane == 0) red[4 + wave] = sum;
+  __syncthreads();
+  sum = red[4] + red[5] + red[6] + red[7];
+  const float lse = mx + logf(sum);
+  const int64_t t = target[row];
+  const bool valid = t >= 0 && t < V;
+  if (tid == 0) loss[row] = valid ? lse - (float)lr[t] : 0.f;
+  if (dlogits) {
+    const float gs = valid ? (gscale ? gscale[row] : 1.f) : 0.f;
+    T* dr = dlogits + (int64_t)row * ld;
+    for (int c = tid; c < V; c += 256) {
+      float p = __expf((float)lr[c] - lse);
+      dr[c] = (T)((p - (c == t ? 1.f : 0.f)) * gs);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void image_to_nhwc4_kernel(const float* __restrict__ img, T* __restrict__ out, int B, int H, int W, int pad, int Hp,
+                                      int Wp) {
+  const int64_t total = (int64_t)B * Hp * Wp;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int xp = (int)(i % Wp);
+    int64_t r = i / Wp;
+    int yp = (int)(r % Hp);
+    int b = (int)(r / Hp);
+    int x = xp - pad, y = yp - pad;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (x >= 0 && x < W && y >= 0 && y < H) {
+      const float* s = img + ((int64_t)b * 3 * H + y) * W + x;
+      v[0] = s[0]; v[1] = s[(int64_t)H * W]; v[2] = s[2 * (int64_t)H * W];
+    }
+    T* d = out + i * 4;
+    d[0] = (T)v[0]; d[1] = (T)v[1]; d[2] = (T)v[2]; d[3] = (T)v[3];
+  }
+}
+
+template <typename T>
+__global__ void maxpool_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int C, int OH, int OW) {
+  const int C8 = C / 8;
+  const int64_t total = (int64_t)B * OH * OW * C8;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int c8 = (int)(i % C8);
+    int64_t r = i / C8;
+    int ow = (int)(r % OW); r /= OW;
+    int oh = (int)(r % OH);
+    int b = (int)(r / OH);
+    float m[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) m[e] = -INFINITY;
+    for (int dy = 0; dy < 3; ++dy) {
+      int ih = oh * 2 - 1 + dy;
+      if (ih < 0 || ih >= H) continue;
+      for (int dx = 0; dx < 3; ++dx) {
+        int iw = ow * 2 - 1 + dx;
+        if (iw < 0 || iw >= W) continue;
+        float v[8];
+        Ld8<T>::ld(x + (((int64_t)b * H + ih) * W + iw) * C + c8 * 8, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], v[e]);
+      }
+    }
+    Ld8<T>::st(y + (((int64_t)b * OH + oh) * OW + ow) * C + c8 * 8, m);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// RoI separable weights (oracle.roi_axis_weights): one wave per roi.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void roi_axis(float start, float length, int size, float* acc /* LDS [size] */, int lane) {
+  // accumulate bilinear weights of all 7*grid sample points into acc (lanes cooperate by sample)
+  const int pooled = 7;
+  const int grid = (int)ceilf(length / pooled);
+  if (grid <= 0) return;
+  const float bin = length / pooled;
+  const float norm = 1.0f / (pooled * grid);
+  for (int sidx = lane; sidx < pooled * grid; sidx += 64) {
+    int p = sidx / grid, i = sidx - p * grid;
+    float c = start + p * bin + (i + 0.5f) * bin / grid;
+    if (c < -1.0f || c > (float)size) continue;
+    if (c <= 0.f) c = 0.f;
+    int lo = (int)c, hi;
+    if (lo >= size - 1) { hi = lo = size - 1; c = (float)lo; } else hi = lo + 1;
+    float l = c - lo;
+    atomicAdd(&acc[lo], (1.f - l) * norm);
+    atomicAdd(&acc[hi], l * norm);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void roi_weights_kernel(const float* __restrict__ boxes, T* __restrict__ wgt, int n_roi, int H,
+                                                         int W, int64_t ldw) {
+  __shared__ float ay[64], ax[64];
+  const int roi = blockIdx.x, lane = threadIdx.x;
+  ay[lane] = 0.f; ax[lane] = 0.f;
+  __syncthreads();
+  const float cx = boxes[roi * 4 + 0], cy = boxes[roi * 4 + 1], w = boxes[roi * 4 + 2], h = boxes[roi * 4 + 3];
+  const float x1 = W * (cx - 0.5f * w) - 0.5f, x2 = W * (cx + 0.5f * w) - 0.5f;
+  const float y1 = H * (cy - 0.5f * h) - 0.5f, y2 = H * (cy + 0.5f * h) - 0.5f;
+  roi_axis(y1, y2 - y1, H, ay, lane);
+  roi_axis(x1, x2 - x1, W, ax, lane);
+  __syncthreads();
+  T* out = wgt + (int64_t)roi * ldw;
+  for (int i = lane; i < ldw; i += 64) {
+    float v = 0.f;
+    if (i < H * W) { int y = i / W, x = i - y * W; v = ay[y] * ax[x]; }
+    out[i] = (T)v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void add_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ y, int64_t n8, int64_t nb8) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+    float u[8], v[8];
+    Ld8<T>::ld(a + i * 8, u);
+    Ld8<T>::ld(b + (i % nb8) * 8, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) u[e] += v[e];
+    Ld8<T>::st(y + i * 8, u);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, float* __restrict__ out, int rows, int cols, int64_t ld,
+                                                     int rows_per_block) {
+  // block handles a [rows_per_block x 256-col] slab; thread = column
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= cols) return;
+  const int r0 = blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+  float s = 0.f;
+  for (int r = r0; r < r1; ++r) s += (float)x[(int64_t)r * ld + c];
+  atomicAdd(&out[c], s);
+}
+
+template <typename TS, typename TD>
+__global__ void cast_kernel(const TS* __restrict__ s, TD* __restrict__ d, int64_t n) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) d[i] = (TD)(float)s[i];
+}
+
+// dst[r][c] = src[r][c]*scale[r]; dstT[c][r] likewise: 32x32 tiles through LDS
+template <typename TD>
+__global__ __launch_bounds__(256) void cast_rowscale_t_kernel(const float* __restrict__ src, const float* __restrict__ scale,
+                                                              TD* __restrict__ dst, TD* __restrict__ dstT, int rows, int cols) {
+  __shared__ float tile[32][33];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int j = ty; j < 32; j += 8) {
+    int r = r0 + j, c = c0 + tx;
+    float v = 0.f;
+    if (r < rows && c < cols) {
+      v = src[(int64_t)r * cols + c] * (scale ? scale[r] : 1.f);
+      if (dst) dst[(int64_t)r * cols + c] = (TD)v;
+    }
+    tile[j][tx] = v;
+  }
+  if (!dstT) return;
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    int c = c0 + j, r = r0 + tx;
+    if (r < rows && c < cols) dstT[(int64_t)c * rows + r] = (TD)tile[tx][j];
+  }
+}
+
+// src [Cout][T][Cin] fp32 -> wf [Cout][T][Cin] scaled, wd [Cin][T][Cout] scaled
+template <typename TD>
+__global__ __launch_bounds__(256) void prep_conv_w_kernel(const float* __restrict__ src, const float* __restrict__ scale,
+                                                          TD* __restrict__ wf, TD* __restrict__ wd, int Cout, int T, int Cin) {
+  __shared__ float tile[32][33];
+  const int t = blockIdx.z;
+  const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int j = ty; j < 32; j += 8) {
+    int co = co0 + j, ci = ci0 + tx;
+    float v = 0.f;
+    if (co < Cout && ci < Cin) {
+      v = src[((int64_t)co * T + t) * Cin + ci] * (scale ? scale[co] : 1.f);
+      if (wf) wf[((int64_t)co * T + t) * Cin + ci] = (TD)v;
+    }
+    tile[j][tx] = v;
+  }
+  if (!wd) return;
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    int ci = ci0 + j, co = co0 + tx;
+    if (co < Cout && ci < Cin) wd[((int64_t)ci * T + t) * Cout + co] = (TD)tile[tx][j];
+  }
+}
+
+template <typename TT, typename TO>
+__global__ void embedding_kernel(const TT* __restrict__ table, const int64_t* __restrict__ ids, TO* __restrict__ out, int64_t n_ids,
+                                 int dim) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_ids * dim; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t r = i / dim;
+    int c = (int)(i - r * dim);
+    out[i] = (TO)(float)table[ids[r] * dim + c];
+  }
+}
+
+template <typename T>
+__global__ void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n, uint32_t dthresh, float dscale, uint64_t seed) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    y[i] = (T)(drop_keep(seed, (uint64_t)i, dthresh) ? (float)x[i] * dscale : 0.f);
+}
+
+template <typename T>
+__global__ void relevance_condition_kernel(const T* __restrict__ x, const float* __restrict__ logits, const float* __restrict__ tok,
+                                           T* __restrict__ y, int rows, int dim) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < (int64_t)rows * dim; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t r = i / dim;
+    int c = (int)(i - r * dim);
+    float l0 = logits[r * 2], l1 = logits[r * 2 + 1];
+    float m = fmaxf(l0, l1);
+    float e0 = __expf(l0 - m), e1 = __expf(l1 - m);
+    float p0 = e0 / (e0 + e1), p1 = e1 / (e0 + e1);
+    y[i] = (T)((float)x[i] + p0 * tok[c] + p1 * tok[dim + c]);
+  }
+}
+
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                             bf16* __restrict__ plow, int64_t n, float lr, float b1, float b2, float eps, float wd, float bc1,
+                             float bc2, const float* __restrict__ gscale) {
+  const float gs = gscale ? *gscale : 1.f;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float gi = g[i] * gs;
+    float pi = p[i] * (1.f - lr * wd);
+    float mi = b1 * m[i] + (1.f - b1) * gi;
+    float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    float denom = sqrtf(vi) / sqrtf(bc2) + eps;
+    pi -= (lr / bc1) * mi / denom;
+    p[i] = pi;
+    if (plow) plow[i] = (bf16)pi;
+  }
+}
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ out) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) s += x[i] * x[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+
+#define ST(s) reinterpret_cast<hipStream_t>(s)
+}  // namespace
+
+extern "C" int gpv_layernorm_fwd(const void* x, const void* s, const float* gamma, const float* beta, void* y, float* mean,
+                                 float* rstd, int rows, int cols, float eps, float drop_p, uint64_t seed, int dtype, void* stream) {
+  if (cols % 8 != 0 || cols > 4096 || rows <= 0) return (int)hipErrorInvalidValue;
+  const uint32_t th = drop_p > 0.f ? drop_thresh(drop_p) : 0u;
+  const float sc = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  dim3 grid((rows + 3) / 4), block(256);
+#define LN_F(T, NV) hipLaunchKernelGGL((ln_fwd_kernel<T, NV>), grid, block, 0, ST(stream), (const T*)x, (const T*)s, gamma, beta, (T*)y, mean, rstd, rows, cols, eps, th, sc, seed)
+  const int nv = (cols + 511) / 512;
+  if (dtype == GPV_BF16) { if (nv <= 1) LN_F(bf16, 1); else if (nv <= 2) LN_F(bf16, 2); else if (nv <= 5) LN_F(bf16, 5); else LN_F(bf16, 8); }
+  else { if (nv <= 1) LN_F(float, 1); else if (nv <= 2) LN_F(float, 2); else if (nv <= 5) LN_F(float, 5); else LN_F(float, 8); }
+#undef LN_F
+  GPV_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int gpv_layernorm_bwd(const void* dy, const void* x, const void* s, const float* gamma, const float* mean,
+                                 const float* rstd, void* dx, void* ds, float* dgamma, float* dbeta, int rows, int cols,
+                                 float drop_p, uint64_t seed, int dtype, void* stream) {
+  if (cols % 8 != 0 || cols > 4096 || rows <= 0) return (int)hipErrorInvalidValue;
+  const uint32_t th = drop_p > 0.f ? drop_thresh(drop_p) : 0u;
+  const float sc = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  int rpb = (rows + 1023) / 1024;
+  if (rpb < 8) rpb = 8;
+  dim3 grid((rows + rpb - 1) / rpb), block(256);
+  const size_t lds = dgamma ? 2 * (size_t)cols * sizeof(float) : 0;
+#define LN_B(T, NV) hipLaunchKernelGGL((ln_bwd_kernel<T, NV>), grid, block, lds, ST(stream), (const T*)dy, (const T*)x, (const T*)s, gamma, mean, rstd, (T*)dx, (T*)ds, dgamma, dbeta, rows, cols, rpb, th, sc, seed)
+  const int nv = (cols + 511) / 512;
+  if (dtype == GPV_BF16) { if (nv <= 1) LN_B(bf16, 1); else if (nv <= 2) LN_B(bf16, 2); else if (nv <= 5) LN_B(bf16, 5); else LN_B(bf16, 8); }
+  else { if (nv <= 1) LN_B(float, 1); else if (nv <= 2) LN_B(float, 2); else if (nv <= 5) LN_B(float, 5); else LN_B(float, 8); }
+#undef LN_B
+  GPV_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int gpv_softmax_ce(const void* logits, int64_t ld, const int64_t* target, float* loss, void* dlogits, const float* gscale,
+                              int rows, int V, int dtype, void* stream) {
+  if (rows <= 0 || V <= 0) return (int)hipErrorInvalidValue;
+  if (dtype == GPV_BF16) hipLaunchKernelGGL((ce_kernel<bf16>), dim3(rows), dim3(256), 0, ST(stream), (const bf16*)logits, ld, target, loss, (bf16*)dlogits, gscale, V);
+  else hipLaunchKernelGGL((ce_kernel<float>), dim3(rows), dim3(256), 0, ST(stream), (const float*)logits, ld, target, loss, (float*)dlogits, gscale, V);
+  GPV_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int gpv_image_to_nhwc4(const float* img, void* out, int B, int H, int W, int pad, int Hp, int Wp, int dtype_out,
+                                  void* stream) {
+  const int64_t n = (int64_t)B * Hp * Wp;
+  if (dtype_out == GPV_BF16) hipLaunchKernelGGL((image_to_nhwc4_kernel<bf16>), dim3(grid1d(n, 256)), dim3(256), 0, ST(stream), img, (bf16*)out, B, H, W, pad, Hp, Wp);
+  else hipLaunchKernelGGL((image_to_nhwc4_kernel<float>), dim3(grid1d(n, 256)), dim3(256), 0, ST(stream), img, (float*)out, B, H, W, pad, Hp, Wp);
+  GPV_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int gpv_maxpool3x3s2(const void* x, void* y, int B, int H, int W, int C, int OH, int OW, int dtype, void* stream) {
+  if (C % 8) return (int)hipErrorInvalidValue;
+  const int64_t n = (int64_t)B * OH * OW * (C / 8);
+  if (dtype == GPV_BF16) hipLaunchKernelGGL((maxpool_kernel<bf16>), dim3(grid1d(n, 256)), dim3(256), 0, ST(stream), (const bf16*)x, (bf16*)y, B, H, W, C, OH, OW);
+  else hipLaunchKernelGGL((maxpool_kernel<float>), dim3(grid1d(n, 256)), dim3(256), 0, ST(stream), (const float*)x, (float*)y, B, H, W, C, OH, OW);
+  GPV_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int gpv_roi_weights(const float* boxes, void* wgt, int n_roi, int H, int W, int64_t ldw, int dtype, void* stream) {
+  if (H > 64 || W > 64 || ldw < (int64_t)H * W) return (int)hipErrorInvalidValue;
+  if (dtype == GPV_BF16) hipLaunchKernelGGL((roi_weights_kernel<bf16>), dim3(n_roi), dim3(64), 0, ST(stream), boxes, (bf16*)wgt, n_roi, H, W, ldw);
+  else hipLaunchKernelGGL((roi_weights_kernel<float>), dim3(n_roi), dim3(64), 0, ST(stream), boxes, (float*)wgt, n_roi, H, W, ldw);
+  GPV_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int gpv_add(const void* a, const void* b, void* y, int64_t n, int dtype, void* stream) {
+  if (n % 8) return (int)hipErrorInvalidValue;
+  if (dtype == GPV_BF16) hipLaunchKernelGGL((add_kernel<bf16>), dim3(grid1d(n / 8, 256)), dim3(256), 0, ST(stream), (const bf16*)a, (const bf16*)b, (bf16*)y, n / 8, n / 8);
+  else hipLaunchKernelGGL((add_kernel<float>), dim3(grid1d(n / 8, 256)), dim3(256), 0, ST(stream), (const float*)a, (const float*)b, (float*)y, n / 8, n / 8);
+  GPV_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int gpv_add_rowbcast(const void* a, const void* b, void* y, int64_t rows_total, int64_t rows_b, int cols, int dtype,
+                                void* stream) {
+  if (cols % 8) return (int)hipErrorInvalidValue;
+  const int64_t n8 = rows_total * cols / 8, nb8 = rows_b * cols / 8;
+  if (dtype == GPV_BF16) hipLaunchKernelGGL((add_kernel<bf16>), dim3(grid1d(n8, 256)), dim3(256), 0, ST(stream), (const bf16*)a, (const bf16*)b, (bf16*)y, n8, nb8);
+  else hipLaunchKernelGGL((add_kernel<float>), dim3(grid1d(n8, 256)), dim3(256), 0, ST(stream), (const float*)a, (const float*)b, (float*)y, n8, nb8);
+  GPV_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int gpv_colsum(const void* x, float* out, int rows, int cols, int64_t ld, int dtype, void* stream) {
+  int rpb = (rows + 255) / 256;
+  if (rpb < 32) rpb = 32;
+  dim3 grid((cols + 255) / 256, (rows + rpb - 1) / rpb);
+  if (dtype == GPV_BF16) hipLaunchKernelGGL((colsum_kernel<bf16>), grid, dim3(256), 0, ST(stream), (const bf16*)x, out, rows, cols, ld, rpb);
+  else hipLaunchKernelGGL((colsum_kernel<float>), grid, dim3(256), 0, ST(stream), (const float*)x, out, rows, cols, ld, rpb);
+  GPV_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int gpv_cast(const void* src, void* dst, int64_t n, int ds, int dd, void* stream) {
+  dim3 g(grid1d(n, 256)), b(256);
+  if (ds == GPV_F32 && dd == GPV_BF16) hipLaunchKernelGGL((cast_kernel<float, bf16>), g, b, 0, ST(stream), (const float*)src, (bf16*)dst, n);
+  else if (ds == GPV_BF16 && dd == GPV_F32) hipLaunchKernelGGL((cast_kernel<bf16, float>), g, b, 0, ST(stream), (const bf16*)src, (float*)dst, n);
+  else if (ds == GPV_F32 && dd == GPV_F32) hipLaunchKernelGGL((cast_kernel<float, float>), g, b, 0, ST(stream), (const float*)src, (float*)dst, n);
+  else hipLaunchKernelGGL((cast_kernel<bf16, bf16>), g, b, 0, ST(stream), (const bf16*)src, (bf16*)dst, n);
+  GPV_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int gpv_cast_rowscale_t(const float* src, const float* scale, void* dst, void* dstT, int rows, int cols, int dtype_dst,
+                                   void* stream) {
+  dim3 grid((cols + 31) / 32, (rows + 31) / 32);
+  if (dtype_dst == GPV_BF16) hipLaunchKernelGGL((cast_rowscale_t_kernel<bf16>), grid, dim3(256), 0, ST(stream), src, scale, (bf16*)dst, (bf16*)dstT, rows, cols);
+  else hipLaunchKernelGGL((cast_rowscale_t_kernel<float>), grid, dim3(256), 0, ST(stream), src, scale, (float*)dst, (float*)dstT, rows, cols);
+  GPV_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int gpv_prep_conv_weight(const float* src, const float* scale, void* wf, void* wd, int Cout, int T, int Cin, int dtype_dst,
+                                    void* stream) {
+  dim3 grid((Cin + 31) / 32, (Cout + 31) / 32, T);
+  if (dtype_dst == GPV_BF16) hipLaunchKernelGGL((prep_conv_w_kernel<bf16>), grid, dim3(256), 0, ST(stream), src, scale, (bf16*)wf, (bf16*)wd, Cout, T, Cin);
+  else hipLaunchKernelGGL((prep_conv_w_kernel<float>), grid, dim3(256), 0, ST(stream), src, scale, (float*)wf, (float*)wd, Cout, T, Cin);
+  GPV_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int gpv_embedding(const void* table, const int64_t* ids, void* out, int64_t n_ids, int dim, int dt, int dout, void* stream) {
+  dim3 g(grid1d(n_ids * dim, 256)), b(256);
+  if (dt == GPV_F32 && dout == GPV_BF16) hipLaunchKernelGGL((embedding_kernel<float, bf16>), g, b, 0, ST(stream), (const float*)table, ids, (bf16*)out, n_ids, dim);
+  else if (dt == GPV_F32 && dout == GPV_F32) hipLaunchKernelGGL((embedding_kernel<float, float>), g, b, 0, ST(stream), (const float*)table, ids, (float*)out, n_ids, dim);
+  else if (dt == GPV_BF16 && dout == GPV_BF16) hipLaunchKernelGGL((embedding_kernel<bf16, bf16>), g, b, 0, ST(stream), (const bf16*)table, ids, (bf16*)out, n_ids, dim);
+  else return (int)hipErrorInvalidValue;
+  GPV_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int gpv_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, int dtype, void* stream) {
+  const uint32_t th = drop_thresh(p);
+  const float sc = 1.f / (1.f - p);
+  dim3 g(grid1d(n, 256)), b(256);
+  if (dtype == GPV_BF16) hipLaunchKernelGGL((dropout_kernel<bf16>), g, b, 0, ST(stream), (const bf16*)x, (bf16*)y, n, th, sc, seed);
+  else hipLaunchKernelGGL((dropout_kernel<float>), g, b, 0, ST(stream), (const float*)x, (float*)y, n, th, sc, seed);
+  GPV_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int gpv_relevance_condition(const void* x, const float* logits, const float* tokens, void* y, int rows, int dim, int dtype,
+                                       void* stream) {
+  dim3 g(grid1d((int64_t)rows * dim, 256)), b(256);
+  if (dtype == GPV_BF16) hipLaunchKernelGGL((relevance_condition_kernel<bf16>), g, b, 0, ST(stream), (const bf16*)x, logits, tokens, (bf16*)y, rows, dim);
+  else hipLaunchKernelGGL((relevance_condition_kernel<float>), g, b, 0, ST(stream), (const float*)x, logits, tokens, (float*)y, rows, dim);
+  GPV_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int gpv_adamw(float* p, const float* g, float* m, float* v, void* p_lowp, int64_t n, float lr, float beta1, float beta2,
+                         float eps, float wd, float bc1, float bc2, const float* gscale, void* stream) {
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid1d(n, 256)), dim3(256), 0, ST(stream), p, g, m, v, (bf16*)p_lowp, n, lr, beta1, beta2, eps, wd, bc1, bc2, gscale);
+  GPV_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int gpv_sumsq(const float* x, int64_t n, float* out, void* stream) {
+  hipLaunchKernelGGL(sumsq_kernel, dim3(grid1d(n, 1024)), dim3(256), 0, ST(stream), x, n, out);
+  GPV_CHECK_LAUNCH();
+  return 0;
+}

@@ -1,0 +1,264 @@
+"""ctypes binding of libgpv_hip.so (C ABI in include/gpv_hip.h).
+
+This is the ONLY compute backend of the package: there is no CPU / eager fallback.  If the
+shared library is missing or a kernel returns an error, a RuntimeError is raised.
+Tensors are passed as raw device pointers (``tensor.data_ptr()``) + the current HIP stream.
+"""
+import ctypes as C
+import os
+
+import torch
+
+BF16, F32 = 0, 1
+ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
+KMAJOR, TRANS = 0, 1
+
+_LIB = None
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc', 'libgpv_hip.so')
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [('A', C.c_void_p), ('B', C.c_void_p), ('C', C.c_void_p),
+                ('M', C.c_int), ('N', C.c_int), ('K', C.c_int), ('batch', C.c_int),
+                ('lda', C.c_int64), ('ldb', C.c_int64), ('ldc', C.c_int64),
+                ('sA', C.c_int64), ('sB', C.c_int64), ('sC', C.c_int64),
+                ('layoutA', C.c_int), ('layoutB', C.c_int), ('dtype_in', C.c_int), ('dtype_out', C.c_int),
+                ('alpha', C.c_float), ('rowscale', C.c_void_p), ('bias', C.c_void_p),
+                ('res', C.c_void_p), ('ldr', C.c_int64), ('sR', C.c_int64),
+                ('relu_mask', C.c_void_p), ('ldm', C.c_int64),
+                ('act', C.c_int), ('drop_p', C.c_float), ('seed', C.c_uint64),
+                ('accumulate', C.c_int), ('split_k', C.c_int)]
+
+
+class ConvArgs(C.Structure):
+    _fields_ = [('mode', C.c_int), ('x', C.c_void_p), ('w', C.c_void_p), ('y', C.c_void_p),
+                ('B', C.c_int), ('IH', C.c_int), ('IW', C.c_int), ('Cs', C.c_int), ('Cin', C.c_int),
+                ('OH', C.c_int), ('OW', C.c_int), ('Cout', C.c_int),
+                ('KH', C.c_int), ('KW', C.c_int), ('SH', C.c_int), ('SW', C.c_int), ('PH', C.c_int), ('PW', C.c_int),
+                ('dtype_in', C.c_int), ('dtype_out', C.c_int),
+                ('rowscale', C.c_void_p), ('bias', C.c_void_p), ('res', C.c_void_p), ('relu_mask', C.c_void_p),
+                ('act', C.c_int), ('split_k', C.c_int)]
+
+
+class AttnArgs(C.Structure):
+    _fields_ = [('q', C.c_void_p), ('k', C.c_void_p), ('v', C.c_void_p), ('o', C.c_void_p),
+                ('q_bs', C.c_int64), ('q_rs', C.c_int64), ('k_bs', C.c_int64), ('k_rs', C.c_int64),
+                ('v_bs', C.c_int64), ('v_rs', C.c_int64), ('o_bs', C.c_int64), ('o_rs', C.c_int64),
+                ('B', C.c_int), ('H', C.c_int), ('Sq', C.c_int), ('Sk', C.c_int), ('dh', C.c_int),
+                ('scale', C.c_float), ('kpm', C.c_void_p), ('causal', C.c_int),
+                ('drop_p', C.c_float), ('seed', C.c_uint64), ('lse', C.c_void_p), ('dtype', C.c_int),
+                ('dout', C.c_void_p), ('do_bs', C.c_int64), ('do_rs', C.c_int64),
+                ('dq', C.c_void_p), ('dk', C.c_void_p), ('dv', C.c_void_p)]
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(_LIB_PATH):
+            raise RuntimeError(
+                f'gpv1_amd: HIP kernel library not found at {_LIB_PATH}. Build it with '
+                f'`python -c "import __graft_entry__ as g; g.build()"` (make -C gpv-1_amd/csrc). '
+                f'There is no CPU/eager fallback by design.')
+        _LIB = C.CDLL(_LIB_PATH)
+        _LIB.gpv_abi_version.restype = C.c_int
+        if _LIB.gpv_abi_version() != 1:
+            raise RuntimeError('gpv1_amd: libgpv_hip.so ABI version mismatch')
+    return _LIB
+
+
+EXPORTS = ['gpv_abi_version', 'gpv_gemm', 'gpv_conv2d', 'gpv_image_to_nhwc4', 'gpv_maxpool3x3s2',
+           'gpv_attention_fwd', 'gpv_attention_bwd', 'gpv_layernorm_fwd', 'gpv_layernorm_bwd',
+           'gpv_softmax_ce', 'gpv_roi_weights', 'gpv_add', 'gpv_add_rowbcast', 'gpv_colsum', 'gpv_cast',
+           'gpv_cast_rowscale_t', 'gpv_prep_conv_weight', 'gpv_embedding', 'gpv_dropout',
+           'gpv_relevance_condition', 'gpv_adamw', 'gpv_sumsq']
+
+
+def dcode(t):
+    if t.dtype == torch.bfloat16:
+        return BF16
+    if t.dtype == torch.float32:
+        return F32
+    raise TypeError(f'gpv1_amd: unsupported dtype {t.dtype}')
+
+
+def _p(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError('gpv1_amd: tensors must live on the GPU (no CPU path exists)')
+    return C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(err, what):
+    if err != 0:
+        raise RuntimeError(f'gpv1_amd: {what} failed with hipError {err}')
+
+
+def _f32(t):
+    if t is not None and t.dtype != torch.float32:
+        raise TypeError('expected fp32 tensor')
+    return t
+
+
+def gemm(A, B, Cm, M, N, K, lda, ldb, ldc, layoutA=KMAJOR, layoutB=KMAJOR, batch=1, sA=0, sB=0, sC=0,
+         alpha=1.0, rowscale=None, bias=None, res=None, ldr=0, sR=0, relu_mask=None, ldm=0, act=ACT_NONE,
+         drop_p=0.0, seed=0, accumulate=False, split_k=1):
+    a = GemmArgs()
+    a.A, a.B, a.C = _p(A), _p(B), _p(Cm)
+    a.M, a.N, a.K, a.batch = M, N, K, batch
+    a.lda, a.ldb, a.ldc, a.sA, a.sB, a.sC = lda, ldb, ldc, sA, sB, sC
+    a.layoutA, a.layoutB = layoutA, layoutB
+    if A.dtype != B.dtype:
+        raise TypeError('gemm: A and B dtypes differ')
+    a.dtype_in, a.dtype_out = dcode(A), dcode(Cm)
+    a.alpha = alpha
+    a.rowscale, a.bias = _p(_f32(rowscale)), _p(_f32(bias))
+    if res is not None and res.dtype != Cm.dtype:
+        raise TypeError('gemm: residual dtype must equal output dtype')
+    if relu_mask is not None and relu_mask.dtype != Cm.dtype:
+        raise TypeError('gemm: mask dtype must equal output dtype')
+    a.res, a.ldr, a.sR = _p(res), ldr, sR
+    a.relu_mask, a.ldm = _p(relu_mask), ldm
+    a.act, a.drop_p, a.seed = act, drop_p, seed
+    a.accumulate, a.split_k = int(accumulate), split_k
+    _chk(lib().gpv_gemm(C.byref(a), _stream()), 'gpv_gemm')
+
+
+def conv2d(mode, x, w, y, B, IH, IW, Cs, Cin, OH, OW, Cout, KH, KW, SH, SW, PH, PW, rowscale=None, bias=None,
+           res=None, relu_mask=None, act=ACT_NONE, split_k=0):
+    a = ConvArgs()
+    a.mode = mode
+    a.x, a.w, a.y = _p(x), _p(w), _p(y)
+    a.B, a.IH, a.IW, a.Cs, a.Cin, a.OH, a.OW, a.Cout = B, IH, IW, Cs, Cin, OH, OW, Cout
+    a.KH, a.KW, a.SH, a.SW, a.PH, a.PW = KH, KW, SH, SW, PH, PW
+    a.dtype_in, a.dtype_out = dcode(x), dcode(y)
+    if x.dtype != w.dtype:
+        raise TypeError('conv2d: operand dtypes differ')
+    a.rowscale, a.bias = _p(_f32(rowscale)), _p(_f32(bias))
+    for t in (res, relu_mask):
+        if t is not None and t.dtype != y.dtype:
+            raise TypeError('conv2d: res/mask dtype must equal output dtype')
+    a.res, a.relu_mask = _p(res), _p(relu_mask)
+    a.act, a.split_k = act, split_k
+    _chk(lib().gpv_conv2d(C.byref(a), _stream()), 'gpv_conv2d')
+
+
+def _attn_args(q, k, v, o, strides, B, H, Sq, Sk, dh, scale, kpm, causal, drop_p, seed, lse):
+    a = AttnArgs()
+    a.q, a.k, a.v, a.o = _p(q), _p(k), _p(v), _p(o)
+    (a.q_bs, a.q_rs), (a.k_bs, a.k_rs), (a.v_bs, a.v_rs), (a.o_bs, a.o_rs) = strides
+    a.B, a.H, a.Sq, a.Sk, a.dh = B, H, Sq, Sk, dh
+    a.scale = scale
+    if kpm is not None and kpm.dtype != torch.uint8:
+        raise TypeError('key padding mask must be uint8')
+    a.kpm, a.causal = _p(kpm), int(causal)
+    a.drop_p, a.seed = drop_p, seed
+    a.lse = _p(_f32(lse))
+    a.dtype = dcode(q)
+    return a
+
+
+def attention_fwd(q, k, v, o, strides, B, H, Sq, Sk, dh, scale, kpm=None, causal=False, drop_p=0.0, seed=0,
+                  lse=None):
+    """strides = ((q_bs,q_rs),(k_bs,k_rs),(v_bs,v_rs),(o_bs,o_rs)) in elements."""
+    a = _attn_args(q, k, v, o, strides, B, H, Sq, Sk, dh, scale, kpm, causal, drop_p, seed, lse)
+    _chk(lib().gpv_attention_fwd(C.byref(a), _stream()), 'gpv_attention_fwd')
+
+
+def attention_bwd(q, k, v, o, dout, dq, dk, dv, strides, do_strides, B, H, Sq, Sk, dh, scale, kpm=None,
+                  causal=False, drop_p=0.0, seed=0, lse=None):
+    a = _attn_args(q, k, v, o, strides, B, H, Sq, Sk, dh, scale, kpm, causal, drop_p, seed, lse)
+    a.dout = _p(dout)
+    a.do_bs, a.do_rs = do_strides
+    a.dq, a.dk, a.dv = _p(dq), _p(dk), _p(dv)
+    _chk(lib().gpv_attention_bwd(C.byref(a), _stream()), 'gpv_attention_bwd')
+
+
+def layernorm_fwd(x, s, gamma, beta, y, mean, rstd, rows, cols, eps, drop_p=0.0, seed=0):
+    _chk(lib().gpv_layernorm_fwd(_p(x), _p(s), _p(_f32(gamma)), _p(_f32(beta)), _p(y), _p(mean), _p(rstd),
+                                 C.c_int(rows), C.c_int(cols), C.c_float(eps), C.c_float(drop_p),
+                                 C.c_uint64(seed), C.c_int(dcode(x)), _stream()), 'gpv_layernorm_fwd')
+
+
+def layernorm_bwd(dy, x, s, gamma, mean, rstd, dx, ds, dgamma, dbeta, rows, cols, drop_p=0.0, seed=0):
+    _chk(lib().gpv_layernorm_bwd(_p(dy), _p(x), _p(s), _p(_f32(gamma)), _p(mean), _p(rstd), _p(dx), _p(ds),
+                                 _p(_f32(dgamma)), _p(_f32(dbeta)), C.c_int(rows), C.c_int(cols),
+                                 C.c_float(drop_p), C.c_uint64(seed), C.c_int(dcode(x)), _stream()),
+         'gpv_layernorm_bwd')
+
+
+def softmax_ce(logits, ld, target, loss, dlogits, gscale, rows, V):
+    _chk(lib().gpv_softmax_ce(_p(logits), C.c_int64(ld), _p(target), _p(loss), _p(dlogits), _p(gscale),
+                              C.c_int(rows), C.c_int(V), C.c_int(dcode(logits)), _stream()), 'gpv_softmax_ce')
+
+
+def image_to_nhwc4(img, out, B, H, W, pad, Hp, Wp):
+    _chk(lib().gpv_image_to_nhwc4(_p(_f32(img)), _p(out), B, H, W, pad, Hp, Wp, dcode(out), _stream()),
+         'gpv_image_to_nhwc4')
+
+
+def maxpool3x3s2(x, y, B, H, W, Cc, OH, OW):
+    _chk(lib().gpv_maxpool3x3s2(_p(x), _p(y), B, H, W, Cc, OH, OW, dcode(x), _stream()), 'gpv_maxpool3x3s2')
+
+
+def roi_weights(boxes, wgt, n_roi, H, W, ldw):
+    _chk(lib().gpv_roi_weights(_p(_f32(boxes)), _p(wgt), n_roi, H, W, C.c_int64(ldw), dcode(wgt), _stream()),
+         'gpv_roi_weights')
+
+
+def add(a, b, y, n):
+    _chk(lib().gpv_add(_p(a), _p(b), _p(y), C.c_int64(n), dcode(a), _stream()), 'gpv_add')
+
+
+def add_rowbcast(a, b, y, rows_total, rows_b, cols):
+    _chk(lib().gpv_add_rowbcast(_p(a), _p(b), _p(y), C.c_int64(rows_total), C.c_int64(rows_b), cols, dcode(a),
+                                _stream()), 'gpv_add_rowbcast')
+
+
+def colsum(x, out, rows, cols, ld):
+    _chk(lib().gpv_colsum(_p(x), _p(_f32(out)), rows, cols, C.c_int64(ld), dcode(x), _stream()), 'gpv_colsum')
+
+
+def cast(src, dst, n):
+    _chk(lib().gpv_cast(_p(src), _p(dst), C.c_int64(n), dcode(src), dcode(dst), _stream()), 'gpv_cast')
+
+
+def cast_rowscale_t(src, scale, dst, dstT, rows, cols):
+    d = dst if dst is not None else dstT
+    _chk(lib().gpv_cast_rowscale_t(_p(_f32(src)), _p(scale), _p(dst), _p(dstT), rows, cols, dcode(d), _stream()),
+         'gpv_cast_rowscale_t')
+
+
+def prep_conv_weight(src, scale, wf, wd, Cout, T, Cin):
+    d = wf if wf is not None else wd
+    _chk(lib().gpv_prep_conv_weight(_p(_f32(src)), _p(scale), _p(wf), _p(wd), Cout, T, Cin, dcode(d), _stream()),
+         'gpv_prep_conv_weight')
+
+
+def embedding(table, ids, out, n_ids, dim):
+    _chk(lib().gpv_embedding(_p(table), _p(ids), _p(out), C.c_int64(n_ids), dim, dcode(table), dcode(out),
+                             _stream()), 'gpv_embedding')
+
+
+def dropout(x, y, n, p, seed):
+    _chk(lib().gpv_dropout(_p(x), _p(y), C.c_int64(n), C.c_float(p), C.c_uint64(seed), dcode(x), _stream()),
+         'gpv_dropout')
+
+
+def relevance_condition(x, logits, tokens, y, rows, dim):
+    _chk(lib().gpv_relevance_condition(_p(x), _p(_f32(logits)), _p(_f32(tokens)), _p(y), rows, dim, dcode(x),
+                                       _stream()), 'gpv_relevance_condition')
+
+
+def adamw(p, g, m, v, p_lowp, n, lr, beta1, beta2, eps, wd, bc1, bc2, gscale=None):
+    _chk(lib().gpv_adamw(_p(p), _p(g), _p(m), _p(v), _p(p_lowp), C.c_int64(n), C.c_float(lr), C.c_float(beta1),
+                         C.c_float(beta2), C.c_float(eps), C.c_float(wd), C.c_float(bc1), C.c_float(bc2),
+                         _p(gscale), _stream()), 'gpv_adamw')
+
+
+def sumsq(x, n, out):
+    _chk(lib().gpv_sumsq(_p(x), C.c_int64(n), _p(out), _stream()), 'gpv_sumsq')

@@ -1,0 +1,185 @@
+/* gpv_hip.h -- C ABI of libgpv_hip.so: hand-written HIP kernels (gfx950 / CDNA4) for the GPV-1
+ * encoder-decoder hot path.
+ *
+ * The reference (allenai/gpv-1) is 100 % Python and has no FFI/plugin layer: every device kernel
+ * it runs is implicit (cuDNN / cuBLAS / torchvision / apex through torch 1.6).  The boundary this
+ * library replaces is therefore "the torch op the reference calls at file:line"; each entry point
+ * below cites that call site (paths relative to the reference checkout).  INTEGRATION.md shows the
+ * ctypes stub a maintainer of the reference would add to route those call sites here.
+ *
+ * Conventions
+ *   - every function returns hipError_t as int (0 = success); never throws, never allocates,
+ *     no global state; work is enqueued asynchronously on `stream` (a hipStream_t passed as void*).
+ *   - all pointers are DEVICE pointers; sizes / leading dimensions are in ELEMENTS.
+ *   - dtype codes: GPV_BF16 = 0 (bfloat16, fp32 accumulate on MFMA), GPV_F32 = 1
+ *     ("precise" mode: fp32 in HBM, operands split hi+lo bf16 on the fly, 3 MFMAs per product,
+ *     ~1e-6 relative error; used for parity tests and for the fp32 box/class heads).
+ *   - matrices are row-major.  Activations are (rows = tokens/pixels, cols = channels); images /
+ *     feature maps are NHWC.
+ */
+#ifndef GPV_HIP_H
+#define GPV_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GPV_BF16 0
+#define GPV_F32 1
+
+#define GPV_ACT_NONE 0
+#define GPV_ACT_RELU 1
+#define GPV_ACT_GELU 2 /* erf form, vilbert.py:111-117 */
+
+/* operand storage for gpv_gemm */
+#define GPV_KMAJOR 0 /* element (row r, red k) at ptr[r*ld + k]  (nn.Linear weight, activations) */
+#define GPV_TRANS 1  /* element (row r, red k) at ptr[k*ld + r]  (reduction index is the slow dim) */
+
+int gpv_abi_version(void); /* = 1 */
+
+/* ---------------------------------------------------------------------------------------------
+ * GEMM with fused epilogue:   C[b] = epi( alpha * A[b] x B[b]^T )        b = 0..batch-1
+ *   A: M x K (layoutA), B: N x K (layoutB), C: M x N row-major (ldc), dtype_out.
+ *   epi (in this order): * rowscale[m] -> + bias[n] -> + res[m,n] -> act -> dropout(p, seed)
+ *                        -> * (relu_mask[m,n] > 0) -> store  (or atomic += when accumulate != 0)
+ *   split_k > 1 requires accumulate = 1, dtype_out = GPV_F32 and a linear epilogue.
+ * Replaces: nn.Linear forward/backward everywhere (transformer.py:131-135, vilbert.py:748-766,
+ *   gpv.py:69-88, answer_head.py:31-33), torch.matmul, 1x1 Conv2d (detr_roi_head.py:39),
+ *   and (through the separable form, see gpv_roi_weights) torchvision.ops.roi_align+mean
+ *   (detr_roi_head.py:44-56).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+  const void* A; const void* B; void* C;
+  int M, N, K, batch;
+  int64_t lda, ldb, ldc;          /* leading dims (elements) */
+  int64_t sA, sB, sC;             /* batch strides (elements) */
+  int layoutA, layoutB;           /* GPV_KMAJOR / GPV_TRANS */
+  int dtype_in, dtype_out;        /* A,B dtype ; C (and res) dtype */
+  float alpha;
+  const float* rowscale;          /* [M] or NULL */
+  const float* bias;              /* [N] or NULL */
+  const void* res; int64_t ldr, sR; /* [M,N] dtype_out or NULL */
+  const void* relu_mask; int64_t ldm; /* bf16/f32 (dtype_out) [M,N] or NULL */
+  int act;
+  float drop_p; uint64_t seed;    /* inverted dropout after act; drop_p = 0 disables */
+  int accumulate, split_k;
+} gpv_gemm_args;
+int gpv_gemm(const gpv_gemm_args* a, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * NHWC convolution as implicit GEMM (ResNet-50 body, backbone.py:93-95 + FrozenBatchNorm2d
+ * backbone.py:44-54 folded into rowscale/bias, ReLU and the bottleneck residual fused).
+ *   mode 0 forward : y[b,oh,ow,co] = epi( sum_{r,s,ci} x[b, oh*SH+r-PH, ow*SW+s-PW, ci] w[co,r,s,ci] )
+ *   mode 1 dgrad   : dx[b,ih,iw,ci] = epi( sum_{r,s,co} dy[b,(ih+PH-r)/SH,(iw+PW-s)/SW,co] wd[ci,r,s,co] )
+ *                    (taps whose division is inexact / out of range contribute 0)
+ *   mode 2 wgrad   : dw[co,r,s,ci] += rowscale[co] * sum_{b,oh,ow} dy[b,oh,ow,co] x[b,oh*SH+r-PH,..,ci]
+ *                    (fp32 atomics, split over the pixel dimension)
+ * `x` may have a pixel stride Cs != Cin (the 7x7 stem reads 8-pixel x 4-channel runs of a
+ * zero-padded NHWC4 image as one 32-wide "channel" chunk).
+ * epilogue as in gpv_gemm (bias = folded BN bias, res = identity branch, act = ReLU; for dgrad:
+ * res = gradient arriving through the identity branch, relu_mask = the saved block output).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+  int mode;
+  const void* x; const void* w; void* y;   /* roles per mode: (x,w,y) / (dy,wd,dx) / (x,dy,dw) */
+  int B, IH, IW, Cs, Cin;                  /* gathered tensor: B x IH x IW pixels, pixel stride Cs, Cin used */
+  int OH, OW, Cout;                        /* the other tensor: B x OH x OW x Cout */
+  int KH, KW, SH, SW, PH, PW;
+  int dtype_in, dtype_out;
+  const float* rowscale; const float* bias;
+  const void* res; const void* relu_mask;  /* same shape as y */
+  int act;
+  int split_k;                             /* wgrad only */
+} gpv_conv_args;
+int gpv_conv2d(const gpv_conv_args* a, void* stream);
+
+/* NCHW fp32 image -> zero-padded NHWC4 (bf16 or f32) with `pad` pixels on every side and the
+ * row length rounded up to Wp pixels (nested_tensor images, detr_misc.py:282-299 -> backbone). */
+int gpv_image_to_nhwc4(const float* img, void* out, int B, int H, int W, int pad, int Hp, int Wp,
+                       int dtype_out, void* stream);
+/* 3x3 stride-2 pad-1 max-pool, NHWC (torchvision resnet maxpool). */
+int gpv_maxpool3x3s2(const void* x, void* y, int B, int H, int W, int C, int OH, int OW, int dtype,
+                     void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Multi-head attention core  O = dropout(softmax(Q K^T * scale + masks)) V   per (batch, head).
+ * Q/K/V/O are addressed as ptr[b*bs + t*rs + h*dh + d] so they can be slices of fused projection
+ * buffers.  Sk <= 320.  dh in {32,48,64,96}.  kpm: uint8 [B,Sk] (1 = ignore key) or NULL.
+ * causal: key j > query i masked.  lse: fp32 [B,H,Sq] (saved for backward).
+ * Replaces nn.MultiheadAttention's core (transformer.py:153-155,218-226; gpv.py:38-43), the
+ * two co-attention products of BertBiAttention (vilbert.py:770-810) and BERT self-attention.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+  const void* q; const void* k; const void* v; void* o;
+  int64_t q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs;
+  int B, H, Sq, Sk, dh;
+  float scale;
+  const uint8_t* kpm; int causal;
+  float drop_p; uint64_t seed;
+  float* lse;
+  int dtype;                       /* GPV_BF16 / GPV_F32 (precise) for q,k,v,o (+ grads) */
+  /* backward only */
+  const void* dout; int64_t do_bs, do_rs;
+  void* dq; void* dk; void* dv;    /* same addressing as q / k / v */
+} gpv_attn_args;
+int gpv_attention_fwd(const gpv_attn_args* a, void* stream);
+int gpv_attention_bwd(const gpv_attn_args* a, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * y = LayerNorm(x + dropout(s)) * gamma + beta     (post-norm residual blocks:
+ * transformer.py:156-160,227-231; BertBiOutput/BertOutput vilbert.py:845-856,510-516;
+ * F.layer_norm without affine detr_roi_head.py:91 when gamma == NULL; s == NULL -> plain LN).
+ * Saves mean / rstd (fp32 [rows]) for backward.  Backward returns dx (gradient w.r.t. x, also the
+ * gradient w.r.t. the pre-dropout s when drop_p == 0), ds (only written when drop_p > 0), and
+ * accumulates dgamma / dbeta (fp32 atomics).
+ * ------------------------------------------------------------------------------------------- */
+int gpv_layernorm_fwd(const void* x, const void* s, const float* gamma, const float* beta, void* y,
+                      float* mean, float* rstd, int rows, int cols, float eps, float drop_p,
+                      uint64_t seed, int dtype, void* stream);
+int gpv_layernorm_bwd(const void* dy, const void* x, const void* s, const float* gamma,
+                      const float* mean, const float* rstd, void* dx, void* ds, float* dgamma,
+                      float* dbeta, int rows, int cols, float drop_p, uint64_t seed, int dtype,
+                      void* stream);
+
+/* softmax cross-entropy over the vocabulary (losses.py:20-26, nn.CrossEntropyLoss reduction none).
+ * logits [rows, V] (ld), target int64 [rows] (ignore_index < 0 rows give loss 0);
+ * loss[rows] fp32; if dlogits != NULL writes dlogits = (softmax - onehot) * gscale[row]. */
+int gpv_softmax_ce(const void* logits, int64_t ld, const int64_t* target, float* loss, void* dlogits,
+                   const float* gscale, int rows, int V, int dtype, void* stream);
+
+/* RoIAlign(7x7, aligned, adaptive sampling) + mean over bins in separable form
+ * (detr_roi_head.py:44-56): wgt[b,q,y*W+x] = Ay[b,q,y]*Ax[b,q,x]; pooled = wgt x feat via gpv_gemm.
+ * boxes: fp32 [B*Q,4] normalised cxcywh.  wgt row stride ldw >= H*W (zero filled up to ldw). */
+int gpv_roi_weights(const float* boxes, void* wgt, int n_roi, int H, int W, int64_t ldw, int dtype,
+                    void* stream);
+
+/* ---- element-wise / reduction helpers (all NHWC / row-major contiguous) ---- */
+int gpv_add(const void* a, const void* b, void* y, int64_t n, int dtype, void* stream);             /* y = a + b  */
+int gpv_add_rowbcast(const void* a, const void* b, void* y, int64_t rows_total, int64_t rows_b,
+                     int cols, int dtype, void* stream);                    /* y[r] = a[r] + b[r % rows_b] */
+int gpv_colsum(const void* x, float* out, int rows, int cols, int64_t ld, int dtype, void* stream);  /* out[c] += sum_r x[r,c] */
+int gpv_cast(const void* src, void* dst, int64_t n, int dtype_src, int dtype_dst, void* stream);
+/* dst[r,c] = cast(src[r,c] * scale[r]);  dstT[c,r] = same (optional) */
+int gpv_cast_rowscale_t(const float* src, const float* scale, void* dst, void* dstT, int rows, int cols,
+                        int dtype_dst, void* stream);
+/* conv weight prep: src fp32 [Cout][T][Cin] -> wf [Cout][T][Cin] (x scale[Cout]) and wd [Cin][T][Cout] */
+int gpv_prep_conv_weight(const float* src, const float* scale, void* wf, void* wd, int Cout, int T,
+                         int Cin, int dtype_dst, void* stream);
+int gpv_embedding(const void* table, const int64_t* ids, void* out, int64_t n_ids, int dim, int dtype_table,
+                  int dtype_out, void* stream);
+int gpv_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, int dtype, void* stream);
+/* relevance conditioning gpv.py:364-375: y = x + softmax(logits)[.,0]*tok[0] + softmax(logits)[.,1]*tok[1] */
+int gpv_relevance_condition(const void* x, const float* logits, const float* tokens, void* y, int rows,
+                            int dim, int dtype, void* stream);
+
+/* fused AdamW over a flat fp32 parameter buffer (torch.optim.AdamW semantics, train_distr.py:247-253),
+ * optionally writing the bf16 compute copy; grad is multiplied by *gscale (device scalar, clip factor)
+ * when gscale != NULL. */
+int gpv_adamw(float* p, const float* g, float* m, float* v, void* p_lowp, int64_t n, float lr, float beta1,
+              float beta2, float eps, float wd, float bc1, float bc2, const float* gscale, void* stream);
+int gpv_sumsq(const float* x, int64_t n, float* out /* += */, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
