@@ -1,0 +1,314 @@
+"""ResNet-50 (v1.5) backbone with frozen BatchNorm on the HIP implicit-GEMM convolution kernel, NHWC.
+
+Reference: exp/gpv/models/backbone.py (FrozenBatchNorm2d :19-54, BackboneBase :57-79, Backbone :82-97,
+Joiner :100-113) + torchvision 0.7 resnet50 topology (keys conv1, bn1, layerN.M.{conv1..3,bn1..3,
+downsample.0/1}).  Differences by design (MI355X-first):
+  * activations are NHWC bf16 (fp32 in precise mode); FrozenBN is folded: scale into the compute
+    copy of the weights, shift into the conv epilogue together with ReLU and the residual add;
+  * the 7x7/2 stem reads a zero-padded NHWC4 image: one (row r) tap = 8 pixels x 4 channels = a
+    contiguous 64-byte run, so the stem is the same implicit-GEMM kernel with KH=7, KW=1, Cin=32;
+  * the whole body is ONE autograd node: forward keeps the block activations, backward runs
+    dgrad (fused with the ReLU mask and the identity-branch gradient) and wgrad (fp32 atomics into
+    param.grad, BN scale applied per output channel) for the trainable layers only
+    (conv1/layer1 are always frozen: backbone.py:61-63).
+"""
+import math
+
+import torch
+import torch.nn as nn
+from torch.autograd import Function
+
+from . import hip
+from .ops import RT, ensure_grad
+from .misc import NestedTensor
+from .position_encoding import build_position_encoding
+
+RELU = hip.ACT_RELU
+PROF = None     # bench.py sets this to a list: (tag, start_event, end_event) per backbone forward / backward
+
+
+def _prof(tag):
+    if PROF is None:
+        return None
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    PROF.append((tag, a, b))
+    return b
+
+
+class FrozenBatchNorm2d(nn.Module):
+    """backbone.py:19-54: fixed statistics + affine; eps 1e-5 inside the rsqrt."""
+
+    def __init__(self, n):
+        super().__init__()
+        self.register_buffer('weight', torch.ones(n))
+        self.register_buffer('bias', torch.zeros(n))
+        self.register_buffer('running_mean', torch.zeros(n))
+        self.register_buffer('running_var', torch.ones(n))
+
+    def _load_from_state_dict(self, state_dict, prefix, *args):
+        state_dict.pop(prefix + 'num_batches_tracked', None)
+        super()._load_from_state_dict(state_dict, prefix, *args)
+
+    def scale_shift(self):
+        scale = self.weight * (self.running_var + 1e-5).rsqrt()
+        return scale.float().contiguous(), (self.bias - self.running_mean * scale).float().contiguous()
+
+
+class ConvW(nn.Module):
+    """holder of a conv weight [Cout,Cin,k,k] stored channels_last (= [Cout][kh][kw][Cin] in memory)."""
+
+    def __init__(self, cin, cout, k, stride, pad):
+        super().__init__()
+        w = torch.empty(cout, cin, k, k)
+        nn.init.kaiming_normal_(w, mode='fan_out', nonlinearity='relu')
+        self.weight = nn.Parameter(w.contiguous(memory_format=torch.channels_last))
+        self.cin, self.cout, self.k, self.stride, self.pad = cin, cout, k, stride, pad
+
+    def phys(self, t=None):
+        """[Cout, k*k, Cin] view of the parameter (or its grad) in memory order."""
+        t = self.weight if t is None else t
+        v = t.detach().permute(0, 2, 3, 1)
+        if not v.is_contiguous():
+            raise RuntimeError('conv weight / grad must be channels_last (call GPV.ensure_layout())')
+        return v.reshape(self.cout, self.k * self.k, self.cin)
+
+
+def _conv_copies(conv, bn, need_wd):
+    key = ('conv', id(conv), RT.dtype)
+    hit = RT.cache.get(key)
+    if hit is not None and hit[0] == RT.weights_epoch and (hit[2] is not None or not need_wd):
+        return hit[1:]
+    scale, shift = bn.scale_shift()
+    T = conv.k * conv.k
+    wf = torch.empty(conv.cout, T, conv.cin, device=scale.device, dtype=RT.dtype)
+    wd = torch.empty(conv.cin, T, conv.cout, device=scale.device, dtype=RT.dtype) if need_wd else None
+    hip.prep_conv_weight(conv.phys(), scale, wf, wd, conv.cout, T, conv.cin)
+    RT.cache[key] = (RT.weights_epoch, wf, wd, scale, shift)
+    return wf, wd, scale, shift
+
+
+def _out(n, k, s, p):
+    return (n + 2 * p - k) // s + 1
+
+
+class Bottleneck(nn.Module):
+    def __init__(self, inplanes, planes, stride, downsample):
+        super().__init__()
+        self.conv1 = ConvW(inplanes, planes, 1, 1, 0)
+        self.bn1 = FrozenBatchNorm2d(planes)
+        self.conv2 = ConvW(planes, planes, 3, stride, 1)
+        self.bn2 = FrozenBatchNorm2d(planes)
+        self.conv3 = ConvW(planes, planes * 4, 1, 1, 0)
+        self.bn3 = FrozenBatchNorm2d(planes * 4)
+        self.downsample = None
+        if downsample:
+            self.downsample = nn.Sequential(ConvW(inplanes, planes * 4, 1, stride, 0), FrozenBatchNorm2d(planes * 4))
+
+    def convs(self):
+        c = [(self.conv1, self.bn1), (self.conv2, self.bn2), (self.conv3, self.bn3)]
+        if self.downsample is not None:
+            c.append((self.downsample[0], self.downsample[1]))
+        return c
+
+    def trainable(self):
+        return any(c.weight.requires_grad for c, _ in self.convs())
+
+
+def _conv_fwd(x, conv, bn, need_wd, act, res=None):
+    B, H, Wd, Cin = x.shape
+    OH, OW = _out(H, conv.k, conv.stride, conv.pad), _out(Wd, conv.k, conv.stride, conv.pad)
+    wf, _, _, shift = _conv_copies(conv, bn, need_wd)
+    y = torch.empty(B, OH, OW, conv.cout, device=x.device, dtype=RT.dtype)
+    hip.conv2d(0, x, wf, y, B, H, Wd, Cin, Cin, OH, OW, conv.cout, conv.k, conv.k, conv.stride, conv.stride, conv.pad,
+               conv.pad, bias=shift, res=res, act=act)
+    return y
+
+
+def _conv_dgrad(dy, conv, bn, xshape, res=None, relu_mask=None):
+    """dx[B,H,W,Cin] = convT(dy) (+res) * (relu_mask > 0)"""
+    B, H, Wd, Cin = xshape
+    _, OH, OW, Cout = dy.shape
+    _, wd, _, _ = _conv_copies(conv, bn, True)
+    dx = torch.empty(B, H, Wd, Cin, device=dy.device, dtype=RT.dtype)
+    hip.conv2d(1, dy, wd, dx, B, OH, OW, Cout, Cout, H, Wd, Cin, conv.k, conv.k, conv.stride, conv.stride, conv.pad,
+               conv.pad, res=res, relu_mask=relu_mask)
+    return dx
+
+
+def _conv_wgrad(x, dy, conv, bn):
+    if not conv.weight.requires_grad:
+        return
+    B, H, Wd, Cin = x.shape
+    _, OH, OW, Cout = dy.shape
+    _, _, scale, _ = _conv_copies(conv, bn, False)
+    g = conv.phys(ensure_grad(conv.weight))
+    hip.conv2d(2, x, dy, g, B, H, Wd, Cin, Cin, OH, OW, Cout, conv.k, conv.k, conv.stride, conv.stride, conv.pad, conv.pad,
+               rowscale=scale)
+
+
+class ResNetBody(nn.Module):
+    """torchvision.models.resnet50 without avgpool/fc (IntermediateLayerGetter(return layer4))."""
+
+    def __init__(self):
+        super().__init__()
+        self.conv1 = ConvW(3, 64, 7, 2, 3)
+        self.bn1 = FrozenBatchNorm2d(64)
+        inpl = 64
+        for li, (planes, n, stride) in enumerate(((64, 3, 1), (128, 4, 2), (256, 6, 2), (512, 3, 2)), 1):
+            blocks = []
+            for b in range(n):
+                blocks.append(Bottleneck(inpl, planes, stride if b == 0 else 1, b == 0))
+                inpl = planes * 4
+            setattr(self, f'layer{li}', nn.Sequential(*blocks))
+
+    def blocks(self):
+        return [b for li in range(1, 5) for b in getattr(self, f'layer{li}')]
+
+    def _stem_weight(self):
+        key = ('stem', id(self), RT.dtype)
+        hit = RT.cache.get(key)
+        if hit is not None and hit[0] == RT.weights_epoch:
+            return hit[1], hit[2]
+        scale, shift = self.bn1.scale_shift()
+        w = self.conv1.weight.detach().float() * scale.view(-1, 1, 1, 1)          # [64,3,7,7]
+        ws = torch.zeros(64, 7, 8, 4, device=w.device, dtype=torch.float32)        # [co][r][8 px][4 ch]
+        ws[:, :, :7, :3] = w.permute(0, 2, 3, 1)
+        ws = ws.reshape(64, 7, 32).to(RT.dtype).contiguous()
+        RT.cache[key] = (RT.weights_epoch, ws, shift)
+        return ws, shift
+
+    def forward_nhwc(self, images, keep):
+        """images: NCHW fp32 (ImageNet-normalised).  Returns c5 [B,h,w,2048]; `keep` collects
+        (block, x, a1, a2, y) tuples of the trainable blocks for backward."""
+        B, _, H, Wd = images.shape
+        OH, OW = _out(H, 7, 2, 3), _out(Wd, 7, 2, 3)
+        Hp = H + 6
+        Wp = ((max(Wd + 6, 2 * (OW - 1) + 8) + 7) // 8) * 8
+        xin = torch.empty(B, Hp, Wp, 4, device=images.device, dtype=RT.dtype)
+        hip.image_to_nhwc4(images.contiguous(), xin, B, H, Wd, 3, Hp, Wp)
+        ws, shift = self._stem_weight()
+        y = torch.empty(B, OH, OW, 64, device=images.device, dtype=RT.dtype)
+        hip.conv2d(0, xin, ws, y, B, Hp, Wp, 4, 32, OH, OW, 64, 7, 1, 2, 2, 0, 0, bias=shift, act=RELU)
+        PH, PW = _out(OH, 3, 2, 1), _out(OW, 3, 2, 1)
+        x = torch.empty(B, PH, PW, 64, device=images.device, dtype=RT.dtype)
+        hip.maxpool3x3s2(y, x, B, OH, OW, 64, PH, PW)
+        del y, xin
+        seen_trainable = False
+        for blk in self.blocks():
+            tr = blk.trainable() and keep is not None
+            need_wd = tr and seen_trainable         # dgrad into this block's input only if something upstream trains
+            a1 = _conv_fwd(x, blk.conv1, blk.bn1, tr, RELU)
+            a2 = _conv_fwd(a1, blk.conv2, blk.bn2, tr, RELU)
+            idt = x if blk.downsample is None else _conv_fwd(x, blk.downsample[0], blk.downsample[1], need_wd, hip.ACT_NONE)
+            yb = _conv_fwd(a2, blk.conv3, blk.bn3, tr, RELU, res=idt)
+            if tr:
+                keep.append((blk, x, a1, a2, yb, seen_trainable))
+                seen_trainable = True
+            x = yb
+        return x
+
+    def backward_nhwc(self, keep, dc5):
+        """dc5: gradient w.r.t. the (post-ReLU) c5 output, [B,h,w,2048] compute dtype."""
+        if not keep:
+            return
+        y_last = keep[-1][4]
+        gz = torch.empty_like(y_last)
+        hip.act_bwd(dc5.contiguous(), y_last, gz, gz.numel(), RELU, 1.0)          # through the final ReLU
+        for blk, x, a1, a2, yb, need_dx in reversed(keep):
+            # gz = gradient w.r.t. (conv3 + shift + identity), i.e. already masked by (yb > 0)
+            _conv_wgrad(a2, gz, blk.conv3, blk.bn3)
+            g2 = _conv_dgrad(gz, blk.conv3, blk.bn3, a2.shape, relu_mask=a2)
+            _conv_wgrad(a1, g2, blk.conv2, blk.bn2)
+            g1 = _conv_dgrad(g2, blk.conv2, blk.bn2, a1.shape, relu_mask=a1)
+            del g2
+            _conv_wgrad(x, g1, blk.conv1, blk.bn1)
+            if blk.downsample is not None:
+                _conv_wgrad(x, gz, blk.downsample[0], blk.downsample[1])
+            if not need_dx:
+                break
+            if blk.downsample is not None:
+                side = _conv_dgrad(gz, blk.downsample[0], blk.downsample[1], x.shape)
+            else:
+                side = gz
+            # input gradient, masked by the previous block's ReLU (x is that block's output)
+            gz = _conv_dgrad(g1, blk.conv1, blk.bn1, x.shape, res=side, relu_mask=x)
+            del g1, side
+
+
+class ResNetFn(Function):
+    @staticmethod
+    def forward(ctx, images, body, dummy, need_bwd):
+        keep = [] if need_bwd else None          # (grad mode is always off inside Function.forward)
+        ev = _prof('conv_fwd')
+        c5 = body.forward_nhwc(images, keep)
+        if ev is not None:
+            ev.record()
+        ctx.body, ctx.keep = body, keep
+        return c5
+
+    @staticmethod
+    def backward(ctx, dc5):
+        ev = _prof('conv_bwd')
+        ctx.body.backward_nhwc(ctx.keep, dc5.to(RT.dtype))
+        if ev is not None:
+            ev.record()
+        ctx.keep = None
+        return None, None, None, None
+
+
+class BackboneBase(nn.Module):
+    def __init__(self, body, train_backbone, num_channels):
+        super().__init__()
+        for name, p in body.named_parameters():
+            if not train_backbone or ('layer2' not in name and 'layer3' not in name and 'layer4' not in name):
+                p.requires_grad_(False)
+        self.body = body
+        self.num_channels = num_channels
+        self._dummy = None
+
+    def forward(self, tensor_list: NestedTensor):
+        """-> {'0': NestedTensor(c5 as [B,h,w,C] NHWC, mask [B,h,w])}   (backbone.py:71-79)"""
+        x, m = tensor_list.tensors, tensor_list.mask
+        assert m is not None
+        if self._dummy is None or self._dummy.device != x.device:
+            self._dummy = torch.zeros(1, device=x.device, requires_grad=True)       # makes autograd call backward
+        need_bwd = torch.is_grad_enabled() and any(b.trainable() for b in self.body.blocks())
+        c5 = ResNetFn.apply(x.float(), self.body, self._dummy, need_bwd)
+        h, w = c5.shape[1:3]
+        H, Wd = m.shape[-2:]
+        iy = torch.div(torch.arange(h, device=m.device) * H, h, rounding_mode='floor')   # F.interpolate nearest
+        ix = torch.div(torch.arange(w, device=m.device) * Wd, w, rounding_mode='floor')
+        mask = m[:, iy][:, :, ix]
+        return {'0': NestedTensor(c5, mask)}
+
+
+class Backbone(BackboneBase):
+    def __init__(self, name, train_backbone, return_interm_layers, dilation, frozenbatchnorm=True):
+        if name != 'resnet50' or return_interm_layers or dilation or not frozenbatchnorm:
+            raise NotImplementedError('gpv1_amd builds the configuration GPV-1 ships: resnet50, C5 only, no dilation, '
+                                      'FrozenBatchNorm (configs/exp/gpv.yaml:41-52)')
+        super().__init__(ResNetBody(), train_backbone, 2048)
+
+
+class Joiner(nn.Sequential):
+    """backbone.py:100-113"""
+
+    def __init__(self, backbone, position_embedding):
+        super().__init__(backbone, position_embedding)
+
+    def forward(self, tensor_list):
+        xs = self[0](tensor_list)
+        out, pos = [], []
+        for _, x in xs.items():
+            out.append(x)
+            pos.append(self[1](x))
+        return out, pos
+
+
+def build_backbone(args):
+    position_embedding = build_position_encoding(args)
+    backbone = Backbone(args.backbone, args.lr_backbone > 0, args.masks, args.dilation, args.frozenbatchnorm)
+    model = Joiner(backbone, position_embedding)
+    model.num_channels = backbone.num_channels
+    return model

@@ -413,6 +413,39 @@ __global__ void relevance_condition_kernel(const T* __restrict__ x, const float*
   }
 }
 
+// y = act(x) (act: 1 relu, 2 gelu-erf)
+template <typename T>
+__global__ void act_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n8, int act) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+    float v[8];
+    Ld8<T>::ld(x + i * 8, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = act == GPV_ACT_RELU ? fmaxf(v[e], 0.f) : gelu_erf(v[e]);
+    Ld8<T>::st(y + i * 8, v);
+  }
+}
+// dx = dy * act'(ref) * alpha ; relu: ref = OUTPUT (ref > 0), gelu: ref = pre-activation
+template <typename T>
+__global__ void act_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ ref, T* __restrict__ dx, int64_t n8, int act,
+                               float alpha) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+    float g[8], r[8];
+    Ld8<T>::ld(dy + i * 8, g);
+    Ld8<T>::ld(ref + i * 8, r);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      if (act == GPV_ACT_RELU) g[e] = r[e] > 0.f ? g[e] * alpha : 0.f;
+      else {
+        const float z = r[e];
+        const float cdf = 0.5f * (1.0f + erff(z * 0.70710678118654752f));
+        const float pdf = 0.3989422804014327f * __expf(-0.5f * z * z);
+        g[e] = g[e] * (cdf + z * pdf) * alpha;
+      }
+    }
+    Ld8<T>::st(dx + i * 8, g);
+  }
+}
+
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                              bf16* __restrict__ plow, int64_t n, float lr, float b1, float b2, float eps, float wd, float bc1,
                              float bc2, const float* __restrict__ gscale) {
@@ -593,6 +626,24 @@ extern "C" int gpv_relevance_condition(const void* x, const float* logits, const
   dim3 g(grid1d((int64_t)rows * dim, 256)), b(256);
   if (dtype == GPV_BF16) hipLaunchKernelGGL((relevance_condition_kernel<bf16>), g, b, 0, ST(stream), (const bf16*)x, logits, tokens, (bf16*)y, rows, dim);
   else hipLaunchKernelGGL((relevance_condition_kernel<float>), g, b, 0, ST(stream), (const float*)x, logits, tokens, (float*)y, rows, dim);
+  GPV_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int gpv_act_fwd(const void* x, void* y, int64_t n, int act, int dtype, void* stream) {
+  if (n % 8 || (act != GPV_ACT_RELU && act != GPV_ACT_GELU)) return (int)hipErrorInvalidValue;
+  dim3 g(grid1d(n / 8, 256)), b(256);
+  if (dtype == GPV_BF16) hipLaunchKernelGGL((act_fwd_kernel<bf16>), g, b, 0, ST(stream), (const bf16*)x, (bf16*)y, n / 8, act);
+  else hipLaunchKernelGGL((act_fwd_kernel<float>), g, b, 0, ST(stream), (const float*)x, (float*)y, n / 8, act);
+  GPV_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int gpv_act_bwd(const void* dy, const void* ref, void* dx, int64_t n, int act, float alpha, int dtype, void* stream) {
+  if (n % 8 || (act != GPV_ACT_RELU && act != GPV_ACT_GELU)) return (int)hipErrorInvalidValue;
+  dim3 g(grid1d(n / 8, 256)), b(256);
+  if (dtype == GPV_BF16) hipLaunchKernelGGL((act_bwd_kernel<bf16>), g, b, 0, ST(stream), (const bf16*)dy, (const bf16*)ref, (bf16*)dx, n / 8, act, alpha);
+  else hipLaunchKernelGGL((act_bwd_kernel<float>), g, b, 0, ST(stream), (const float*)dy, (const float*)ref, (float*)dx, n / 8, act, alpha);
   GPV_CHECK_LAUNCH();
   return 0;
 }

@@ -1,0 +1,300 @@
+"""GPV: the drop-in for ``exp.gpv.models.gpv.GPV`` (reference: exp/gpv/models/gpv.py:58-466).
+
+Same constructor config schema (configs/exp/gpv.yaml ``model:`` block), same 836 state-dict keys,
+same methods/attributes the reference's drivers use: ``forward``, ``forward_beam_search``,
+``encode_answers``, ``token_ids_to_words``, ``vocab``, ``word_to_idx``, ``init_detr_params``,
+``load_pretr_detr``, ``criterion``.  All tensor math runs on the HIP kernels (gpv1_amd.hip) -- there is
+no CPU path; the module raises if it is called with CPU tensors or without the library.
+"""
+import copy
+import json
+import math
+import re
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+from .ops import W, RT
+from .detr import create_detr, create_detr_roi_head
+from .bert import Bert
+from .vilbert import BertConnectionLayer
+from .transformer import LinearP, LayerNormP, MultiheadAttention
+from .criterion import GPVCriterion
+from .misc import AttrDict, NestedTensor
+
+try:                                              # the reference uses nltk's word_tokenize (gpv.py:4,409)
+    from nltk.tokenize import word_tokenize as _word_tokenize
+except Exception:                                 # nltk is not in the image: Treebank-like regex split
+    def _word_tokenize(s):
+        return re.findall(r"__\w+__|\w+(?:'\w+)?|[^\w\s]", s)
+
+
+def positionalencoding1d(d_model, length):
+    """gpv.py:18-34"""
+    if d_model % 2 != 0:
+        raise ValueError("Cannot use sin/cos positional encoding with odd dim (got dim={:d})".format(d_model))
+    pe = torch.zeros(length, d_model)
+    position = torch.arange(0, length).unsqueeze(1)
+    div_term = torch.exp((torch.arange(0, d_model, 2, dtype=torch.float) * -(math.log(10000.0) / d_model)))
+    pe[:, 0::2] = torch.sin(position.float() * div_term)
+    pe[:, 1::2] = torch.cos(position.float() * div_term)
+    return pe
+
+
+class TextDecoderLayer(nn.Module):
+    """torch.nn.TransformerDecoderLayer(d_model, nhead, dim_feedforward=2048, relu, post-norm) parameters."""
+
+    def __init__(self, d_model, nhead, dropout, dim_feedforward=2048):
+        super().__init__()
+        self.self_attn = MultiheadAttention(d_model, nhead, dropout=dropout)
+        self.multihead_attn = MultiheadAttention(d_model, nhead, dropout=dropout)
+        self.linear1 = LinearP(d_model, dim_feedforward)
+        self.linear2 = LinearP(dim_feedforward, d_model)
+        self.norm1, self.norm2, self.norm3 = LayerNormP(d_model), LayerNormP(d_model), LayerNormP(d_model)
+        self.p = dropout
+
+    def forward(self, tgt, memory, B, Tt, Tm):
+        p = self.p if self.training else 0.0
+        tgt = self.norm1(tgt, self.self_attn(tgt, tgt, tgt, B, Tt, Tt, causal=True), p)
+        tgt = self.norm2(tgt, self.multihead_attn(tgt, memory, memory, B, Tt, Tm), p)   # no memory padding mask
+        h = self.linear1(tgt, ops.ACT_RELU, p)
+        return self.norm3(tgt, self.linear2(h), p)
+
+
+class TextDecoder(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.layers = nn.ModuleList([TextDecoderLayer(cfg.hidden_dim, cfg.nheads, cfg.dropout) for _ in range(cfg.num_layers)])
+
+
+class AnswerHead(nn.Module):
+    """answer_head.py:8-33: logits = h @ Linear(vocab_embed)^T (frozen vocabulary embedding)."""
+
+    def __init__(self, vocab, classifier_transform, vocab_embed):
+        super().__init__()
+        self.vocab = vocab
+        self.vocab_embed = nn.Parameter(vocab_embed, requires_grad=False)
+        self.classifier_transform = classifier_transform
+        self._wc = None
+
+    def classifiers(self):
+        # W_c is batch independent: in eval it is computed once per weights version
+        if not torch.is_grad_enabled() and self._wc is not None and self._wc[0] == (RT.weights_epoch, RT.dtype):
+            return self._wc[1]
+        e = ops._as_compute(self.vocab_embed.detach())
+        wc = self.classifier_transform(e)                       # [V, D]
+        if not torch.is_grad_enabled():
+            self._wc = ((RT.weights_epoch, RT.dtype), wc)
+        return wc
+
+    def forward(self, h):
+        """h [..., D] -> [..., V]"""
+        D = h.shape[-1]
+        return ops.matmul_nt(h.reshape(-1, D), self.classifiers()).reshape(*h.shape[:-1], -1)
+
+
+class AnswerInputEmbedding(nn.Module):
+    """gpv.py:46-55"""
+
+    def __init__(self, weight, transform, freeze_embeddings=True):
+        super().__init__()
+        self.transform = transform
+        self.embedding_layer = nn.Embedding.from_pretrained(weight.clone(), freeze=freeze_embeddings)
+
+    def forward(self, token_ids):
+        return self.transform(ops.embedding(self.embedding_layer.weight, token_ids))
+
+
+class GPV(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        if isinstance(cfg, dict) and not isinstance(cfg, AttrDict):
+            cfg = AttrDict.wrap(cfg)
+        self.cfg = cfg
+        if cfg.answer_head is not None or cfg.answering_type != 'generation':
+            raise NotImplementedError('gpv1_amd covers the shipped configuration: answer_head null, answering_type generation')
+        self.detr = create_detr_roi_head(cfg.detr) if cfg.roi_head is True else create_detr(cfg.detr)
+        self.detr_joiner = LinearP(cfg.detr_joiner.detr_dim, cfg.detr_joiner.out_dim)
+        self.init_detr_params = []
+        self.bert = Bert(num_layers=cfg.get('bert_layers', 12) if isinstance(cfg, dict) else 12)
+        self.bert_joiner = LinearP(cfg.bert_joiner.bert_dim, cfg.bert_joiner.out_dim)
+        layer = BertConnectionLayer(cfg.co_att)
+        self.co_att_transformer = nn.ModuleList([copy.deepcopy(layer) for _ in range(cfg.co_att.num_layers)])
+        self.relevance_predictor = LinearP(cfg.hidden_dim, cfg.detr.num_classes + 1)
+        self.text_decoder = TextDecoder(cfg.text_decoder)
+        if isinstance(cfg.vocab, (list, tuple)):
+            vocab = list(cfg.vocab)
+        else:
+            with open(cfg.vocab) as f:
+                vocab = json.load(f)
+        if cfg.vocab_embed is None:
+            vocab_embed = 0.1 * torch.randn(len(vocab), cfg.bert_joiner.bert_dim)
+        elif torch.is_tensor(cfg.vocab_embed):
+            vocab_embed = cfg.vocab_embed.float()
+        else:
+            vocab_embed = torch.from_numpy(np.load(cfg.vocab_embed)).float()
+        self.answer_head = AnswerHead(vocab, LinearP(cfg.bert_joiner.bert_dim, cfg.bert_joiner.out_dim), vocab_embed)
+        self.vocab = self.answer_head.vocab
+        self.word_to_idx = {w: i for i, w in enumerate(self.vocab)}
+        self.answer_input_embedings = AnswerInputEmbedding(
+            self.answer_head.vocab_embed.data, LinearP(cfg.bert_joiner.bert_dim, cfg.bert_joiner.out_dim))
+        self.vision_token = nn.Parameter(0.1 * torch.randn([cfg.hidden_dim]))        # declared, unused (gpv.py:107-110)
+        self.lang_token = nn.Parameter(0.1 * torch.randn([cfg.hidden_dim]))
+        self.relevance_tokens = nn.Parameter(0.1 * torch.randn([2, cfg.hidden_dim]))
+        self.criterion = GPVCriterion(cfg.losses)
+        self.pos_enc = nn.Parameter(positionalencoding1d(cfg.text_decoder.hidden_dim, cfg.max_pos_enc_len)
+                                    .view(1, cfg.max_pos_enc_len, -1), requires_grad=False)
+
+    # ------------------------------------------------------------------ plumbing
+    def _apply(self, fn, *a, **k):
+        r = super()._apply(fn, *a, **k)
+        RT.bump_weights()
+        return r
+
+    def load_state_dict(self, *a, **k):
+        r = super().load_state_dict(*a, **k)
+        RT.bump_weights()
+        return r
+
+    def load_pretr_detr(self):
+        """gpv.py:122-135"""
+        loaded = torch.load(self.cfg.pretr_detr, map_location='cpu')['model']
+        cur = self.state_dict()
+        for lk in loaded.keys():
+            k = 'detr.' + lk
+            if k in cur:
+                if cur[k].size() == loaded[lk].size():
+                    self.init_detr_params.append(k)
+                    cur[k] = loaded[lk]
+                else:
+                    print(f'    {lk} size does not match')
+        self.load_state_dict(cur)
+
+    # ------------------------------------------------------------------ encoder shared by all branches
+    def _encode(self, images, queries):
+        outputs = self.detr(images)
+        outputs['detr_hs'] = self.detr_joiner(outputs['detr_hs'])                  # [L,B,Q,768]
+        with torch.no_grad():
+            query_encodings, _ = self.bert(queries)
+        lv = self.bert_joiner(query_encodings.detach())                            # [B,Tl,768]
+        B, Tl, D = lv.shape
+        vl = outputs['detr_hs'][-1]
+        Tv = vl.shape[1]
+        lv2, vl2 = lv.reshape(B * Tl, D), vl.reshape(B * Tv, D)
+        for layer in self.co_att_transformer:
+            lv2, vl2 = layer(lv2, vl2, B, Tl, Tv)
+        rel = self.relevance_predictor(vl2, out_f32=True).reshape(B, Tv, -1)       # fp32
+        outputs['pred_relevance_logits'] = outputs['pred_relevance_logits'] + rel
+        if self.cfg.detr.aux_loss:
+            for aux in outputs['aux_outputs']:
+                aux['pred_relevance_logits'] = aux['pred_relevance_logits'] + rel
+        if self.cfg.relevance_conditioning is not False:                            # gpv.py:364-375
+            vl2 = ops.relevance_condition(vl2, outputs['pred_relevance_logits'].reshape(B * Tv, 2), self.relevance_tokens)
+        memory = torch.cat((vl2.reshape(B, Tv, D), lv2.reshape(B, Tl, D)), 1)      # [B, Tv+Tl, D]
+        return outputs, memory
+
+    def decode_text(self, target, memory):
+        """target [B,Tt,D], memory [B,Tm,D] -> logits [B,Tt,V]   (gpv.py:449-466)"""
+        B, Tt, D = target.shape
+        Tm = memory.shape[1]
+        if self.cfg.text_decoder.pos_enc is True:
+            target = ops.add(target.reshape(B * Tt, D), self.pos_enc[0, :Tt].to(RT.dtype)).reshape(B, Tt, D)
+        x = target.reshape(B * Tt, D)
+        mem = memory.reshape(B * Tm, D)
+        for layer in self.text_decoder.layers:
+            x = layer(x, mem, B, Tt, Tm)
+        return self.answer_head(x).reshape(B, Tt, -1)
+
+    # ------------------------------------------------------------------ reference API
+    def forward(self, images, queries, answer_token_ids, targets=None, vocab_mask=None):
+        outputs, memory = self._encode(images, queries)
+        B = memory.shape[0]
+        dev = memory.device
+        if answer_token_ids is None:                                               # greedy, gpv.py:178-196
+            ids = torch.full((B, 1), self.word_to_idx['__cls__'], dtype=torch.long, device=dev)
+            for _ in range(self.cfg.max_text_len - 1):
+                logits = self.decode_text(self.answer_input_embedings(ids), memory)[:, -1].float()
+                if vocab_mask is not None:
+                    logits = logits + vocab_mask
+                ids = torch.cat((ids, torch.topk(logits, k=1, dim=-1).indices), -1)
+            logits = self.decode_text(self.answer_input_embedings(ids), memory)
+            if vocab_mask is not None:
+                logits = logits.float() + vocab_mask
+            outputs['answer_logits'] = logits.unsqueeze(0)
+        else:                                                                      # teacher forcing, :197-201
+            target = self.answer_input_embedings(answer_token_ids.to(dev))
+            outputs['answer_logits'] = self.decode_text(target, memory)[:, :-1].unsqueeze(0)
+        if targets is None:
+            return outputs
+        return self.criterion(outputs, targets)[0]
+
+    @torch.no_grad()
+    def forward_beam_search(self, images, queries, beam_size=1):
+        """gpv.py:209-362, quirks preserved (no length normalisation, finished beams keep extending --
+        the reference's `is True` test never fires --, last seqs slot never written, stable tie order)."""
+        outputs, memory = self._encode(images, queries)
+        B, K, T = memory.shape[0], beam_size, self.cfg.max_text_len
+        dev = memory.device
+        tok = torch.full((K, B, 1), self.word_to_idx['__cls__'], dtype=torch.long, device=dev)
+        seq_lp = torch.zeros(B, K, device=dev)
+        seqs = torch.zeros(K, B, T, dtype=torch.long, device=dev)
+        memK = memory.repeat(K, 1, 1)                                              # all K beams in ONE decoder pass
+        for t in range(T - 1):
+            logits = self.decode_text(self.answer_input_embedings(tok.reshape(K * B, -1)), memK)[:, -1].float()
+            top = torch.log_softmax(logits, -1).topk(K, -1)                        # [K*B, K]
+            vals, last = top.values.view(K, B, K), top.indices.view(K, B, K)
+            scores = (seq_lp.t().unsqueeze(-1) + vals).permute(1, 0, 2).contiguous()   # [B, K1, K2]
+            if t == 0:
+                scores[:, 1:] = scores[:, 1:] * 0 - 1e9
+            flat = scores.view(B, K * K)
+            order = torch.sort(flat, dim=1, descending=True, stable=True).indices[:, :K]   # [B,K]
+            k1, k2 = order // K, order % K
+            bi = torch.arange(B, device=dev).unsqueeze(1).expand(B, K)
+            w = last[k1, bi, k2]                                                   # [B,K]
+            seq_lp = flat.gather(1, order)
+            new_tok = torch.cat((tok[k1, bi], w.unsqueeze(-1)), -1).permute(1, 0, 2).contiguous()
+            new_seqs = seqs[k1, bi].permute(1, 0, 2).contiguous()
+            new_seqs[:, :, t] = w.t()
+            tok, seqs = new_tok, new_seqs
+        seqs_c, lp = seqs.cpu(), seq_lp.exp().cpu()
+        answers, probs = [], []
+        for b in range(B):
+            answers.append([])
+            probs.append([])
+            for k in range(K):
+                words = []
+                for t in range(T):
+                    word = self.vocab[int(seqs_c[k, b, t])]
+                    if word in ('__stop__', '__pad__'):
+                        break
+                    words.append(word)
+                answers[b].append(words)
+                probs[b].append(float(lp[b, k]))
+        outputs['answers'], outputs['answer_probs'] = answers, probs
+        return outputs
+
+    def encode_answers(self, targets):
+        """gpv.py:377-430 (generation branch)"""
+        answers = [t.get('answer', '') for t in targets]
+        padded_inputs, S = [], 0
+        for a in answers:
+            sent = '__cls__ __stop__' if a == '' else f'__cls__ {a} __stop__'
+            padded_inputs.append([w.lower() for w in _word_tokenize(sent)])
+            S = max(S, len(padded_inputs[-1]))
+        ids = []
+        for toks in padded_inputs:
+            toks.extend(['__pad__'] * (S - len(toks)))
+            ids.append([self.word_to_idx.get(w, self.word_to_idx['__unk__']) for w in toks][:self.cfg.max_text_len])
+        dev = self.vision_token.device
+        return padded_inputs, torch.tensor(ids, dtype=torch.long, device=dev)
+
+    def token_ids_to_words(self, token_ids):
+        B, S = token_ids.shape
+        return [[self.vocab[int(token_ids[i, j])] for j in range(S)] for i in range(B)]
+
+    @property
+    def cls_token(self):
+        dev = self.vision_token.device
+        return self.answer_input_embedings(torch.tensor([self.word_to_idx['__cls__']], device=dev))[0]

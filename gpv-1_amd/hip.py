@@ -70,7 +70,7 @@ EXPORTS = ['gpv_abi_version', 'gpv_gemm', 'gpv_conv2d', 'gpv_image_to_nhwc4', 'g
            'gpv_attention_fwd', 'gpv_attention_bwd', 'gpv_layernorm_fwd', 'gpv_layernorm_bwd',
            'gpv_softmax_ce', 'gpv_roi_weights', 'gpv_add', 'gpv_add_rowbcast', 'gpv_colsum', 'gpv_cast',
            'gpv_cast_rowscale_t', 'gpv_prep_conv_weight', 'gpv_embedding', 'gpv_dropout',
-           'gpv_relevance_condition', 'gpv_adamw', 'gpv_sumsq']
+           'gpv_relevance_condition', 'gpv_adamw', 'gpv_sumsq', 'gpv_act_fwd', 'gpv_act_bwd']
 
 
 def dcode(t):
@@ -262,3 +262,12 @@ def adamw(p, g, m, v, p_lowp, n, lr, beta1, beta2, eps, wd, bc1, bc2, gscale=Non
 
 def sumsq(x, n, out):
     _chk(lib().gpv_sumsq(_p(x), C.c_int64(n), _p(out), _stream()), 'gpv_sumsq')
+
+
+def act_fwd(x, y, n, act):
+    _chk(lib().gpv_act_fwd(_p(x), _p(y), C.c_int64(n), act, dcode(x), _stream()), 'gpv_act_fwd')
+
+
+def act_bwd(dy, ref, dx, n, act, alpha=1.0):
+    _chk(lib().gpv_act_bwd(_p(dy), _p(ref), _p(dx), C.c_int64(n), act, C.c_float(alpha), dcode(dy), _stream()),
+         'gpv_act_bwd')

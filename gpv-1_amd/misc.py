@@ -1,0 +1,79 @@
+"""Batch container + collate helpers (reference: utils/detr_misc.py:267-322, 394-410)."""
+from typing import List, Optional
+
+import torch
+
+
+class NestedTensor(object):
+    """detr_misc.py:302-322"""
+
+    def __init__(self, tensors, mask: Optional[torch.Tensor]):
+        self.tensors = tensors
+        self.mask = mask
+
+    def to(self, device):
+        mask = self.mask.to(device) if self.mask is not None else None
+        return NestedTensor(self.tensors.to(device), mask)
+
+    def decompose(self):
+        return self.tensors, self.mask
+
+    def __repr__(self):
+        return str(self.tensors)
+
+
+def nested_tensor_from_tensor_list(tensor_list: List[torch.Tensor]):
+    """zero-pad (3,H,W) images to the batch max and build the bool padding mask (detr_misc.py:282-299)."""
+    if isinstance(tensor_list, torch.Tensor):
+        tensor_list = list(tensor_list) if tensor_list.ndim == 4 else [tensor_list]
+    if tensor_list[0].ndim != 3:
+        raise ValueError('not supported')
+    c = tensor_list[0].shape[0]
+    h = max(img.shape[1] for img in tensor_list)
+    w = max(img.shape[2] for img in tensor_list)
+    b = len(tensor_list)
+    tensor = torch.zeros((b, c, h, w), dtype=tensor_list[0].dtype, device=tensor_list[0].device)
+    mask = torch.ones((b, h, w), dtype=torch.bool, device=tensor_list[0].device)
+    for img, pad_img, m in zip(tensor_list, tensor, mask):
+        pad_img[:img.shape[0], :img.shape[1], :img.shape[2]].copy_(img)
+        m[:img.shape[1], :img.shape[2]] = False
+    return NestedTensor(tensor, mask)
+
+
+def collate_fn(batch):
+    """detr_misc.py:267-270"""
+    batch = list(zip(*batch))
+    batch[0] = nested_tensor_from_tensor_list(batch[0])
+    return tuple(batch)
+
+
+@torch.no_grad()
+def accuracy(output, target, topk=(1,)):
+    """detr_misc.py:394-410"""
+    if target.numel() == 0:
+        return [torch.zeros([], device=output.device)]
+    maxk = max(topk)
+    _, pred = output.topk(maxk, 1, True, True)
+    correct = pred.t().eq(target.view(1, -1).expand_as(pred.t()))
+    return [correct[:k].reshape(-1).float().sum(0) * (100.0 / target.size(0)) for k in topk]
+
+
+class AttrDict(dict):
+    """Minimal OmegaConf stand-in: attribute + item access, real bools, `.items()`."""
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k)
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+    @staticmethod
+    def wrap(d):
+        if isinstance(d, dict):
+            return AttrDict({k: AttrDict.wrap(v) for k, v in d.items()})
+        if isinstance(d, (list, tuple)):
+            return [AttrDict.wrap(v) for v in d]
+        return d

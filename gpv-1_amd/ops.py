@@ -1,0 +1,474 @@
+"""Autograd layer over the C-ABI kernels (gpv1_amd.hip).
+
+Design
+  * Activations are 2-D row-major [rows, channels] tensors in the COMPUTE dtype
+    (``RT.dtype``: bf16 for production, fp32 "precise" split-bf16 MFMA mode for parity runs).
+  * Parameters stay fp32 nn.Parameters with the reference's names/shapes (state-dict compatible).
+    Kernels read low-precision compute copies (W and W^T) that are rebuilt whenever
+    ``RT.weights_epoch`` changes (after an optimizer step / load_state_dict).
+  * Parameter gradients never travel through torch.autograd: every backward accumulates straight
+    into ``param.grad`` (fp32, pre-allocated, e.g. a view of one flat buffer) with the GEMM/conv
+    wgrad kernels (fp32 atomics, split-K) -- so the data-parallel all-reduce can run over one flat
+    buffer (train.py).  torch.autograd only carries activation gradients between our Functions.
+  * No CPU / eager fallback: everything below calls the HIP library and raises if it is missing.
+"""
+import math
+
+import torch
+from torch.autograd import Function
+
+from . import hip
+
+ACT_NONE, ACT_RELU, ACT_GELU = hip.ACT_NONE, hip.ACT_RELU, hip.ACT_GELU
+
+
+class Runtime:
+    def __init__(self):
+        self.dtype = torch.bfloat16
+        self.weights_epoch = 0
+        self.seed = 0x5EED
+        self._ctr = 0
+        self.cache = {}
+
+    def set_precise(self, on=True):
+        self.dtype = torch.float32 if on else torch.bfloat16
+        self.cache.clear()
+
+    def bump_weights(self):
+        """call after parameters changed (optimizer step, load_state_dict, .to(device))"""
+        self.weights_epoch += 1
+
+    def manual_seed(self, s):
+        self.seed, self._ctr = int(s), 0
+
+    def next_seed(self):
+        self._ctr += 1
+        return (self.seed * 0x9E3779B1 + self._ctr * 0x85EBCA77) & 0xFFFFFFFFFFFF
+
+
+RT = Runtime()
+
+
+def ensure_grad(p):
+    """fp32 gradient buffer with the SAME physical layout as the parameter."""
+    if p.grad is None:
+        p.grad = torch.zeros_like(p, memory_format=torch.preserve_format)
+    touch = getattr(p, '_gpv_touch', None)          # train.FlatTrainer keeps the torch-1.6 "touched" set
+    if touch is not None:
+        touch()
+    return p.grad
+
+
+# --------------------------------------------------------------------------------------------
+# weight references
+# --------------------------------------------------------------------------------------------
+def _lp_pair(p):
+    """(W [N,K], W^T [K,N]) of a 2-D (or [N,K,1,1]) parameter in the compute dtype, cached per epoch."""
+    key = ('lin', id(p), RT.dtype)
+    hit = RT.cache.get(key)
+    if hit is not None and hit[0] == RT.weights_epoch:
+        return hit[1], hit[2]
+    N = p.shape[0]
+    K = p.numel() // N
+    src = p.detach().reshape(N, K)
+    if not src.is_contiguous():
+        src = src.contiguous()
+    wt = torch.empty(K, N, device=p.device, dtype=RT.dtype)
+    if RT.dtype == torch.float32:
+        w = src
+        hip.cast_rowscale_t(src, None, None, wt, N, K)
+    else:
+        w = torch.empty(N, K, device=p.device, dtype=RT.dtype)
+        hip.cast_rowscale_t(src, None, w, wt, N, K)
+    RT.cache[key] = (RT.weights_epoch, w, wt)
+    return w, wt
+
+
+class W:
+    """rows [r0:r1) of a Linear-style weight parameter [N_total, K] (+ matching bias slice)."""
+
+    def __init__(self, weight, bias=None, r0=0, r1=None):
+        self.weight, self.bias = weight, bias
+        self.r0 = r0
+        self.r1 = weight.shape[0] if r1 is None else r1
+        self.N = self.r1 - self.r0
+        self.Ntot = weight.shape[0]
+        self.K = weight.numel() // weight.shape[0]
+
+    def lp(self):
+        w, _ = _lp_pair(self.weight)
+        return w[self.r0:self.r1]                     # [N, K] contiguous rows, ld = K
+
+    def lpT(self):
+        _, wt = _lp_pair(self.weight)
+        return wt[:, self.r0:self.r1]                 # [K, N] view, ld = Ntot
+
+    def bias_f32(self):
+        return None if self.bias is None else self.bias.detach()[self.r0:self.r1]
+
+    def wgrad(self):
+        g = ensure_grad(self.weight)
+        return g.reshape(self.Ntot, self.K)[self.r0:self.r1]
+
+    def bgrad(self):
+        return ensure_grad(self.bias)[self.r0:self.r1]
+
+
+def _split_k(out_rows, out_cols, red):
+    tiles = ((out_rows + 63) // 64) * ((out_cols + 63) // 64)
+    kt = (red + 31) // 32
+    return max(1, min(kt // 8, 1024 // max(tiles, 1)))
+
+
+def _c(x):
+    return x if x.is_contiguous() else x.contiguous()
+
+
+def _as_compute(x):
+    return x if x.dtype == RT.dtype else x.to(RT.dtype)
+
+
+# --------------------------------------------------------------------------------------------
+# Linear:  y = dropout(act(x W^T + b))      (x: [..., K])
+# --------------------------------------------------------------------------------------------
+class LinearFn(Function):
+    @staticmethod
+    def forward(ctx, x, w, act, drop_p, out_f32, dummy=None):
+        K, N = w.K, w.N
+        x2 = _c(_as_compute(x)).reshape(-1, K)
+        M = x2.shape[0]
+        out_dtype = torch.float32 if out_f32 else RT.dtype
+        y = torch.empty(M, N, device=x.device, dtype=out_dtype)
+        seed = RT.next_seed() if drop_p > 0 else 0
+        z = None
+        if act == ACT_GELU:                       # keep the pre-activation for backward
+            z = torch.empty_like(y)
+            hip.gemm(x2, w.lp(), z, M, N, K, K, K, N, bias=w.bias_f32())
+            hip.act_fwd(z, y, M * N, ACT_GELU)
+        else:
+            hip.gemm(x2, w.lp(), y, M, N, K, K, K, N, bias=w.bias_f32(), act=act, drop_p=drop_p, seed=seed)
+        ctx.w, ctx.act, ctx.drop_p, ctx.xshape, ctx.in_dtype = w, act, drop_p, x.shape, x.dtype
+        ctx.save_for_backward(x2, y if act == ACT_RELU else None, z)
+        return y.reshape(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        w, act = ctx.w, ctx.act
+        x2, y, z = ctx.saved_tensors
+        K, N = w.K, w.N
+        M = x2.shape[0]
+        dz = _c(_as_compute(dy)).reshape(M, N)
+        if act == ACT_RELU:
+            t = torch.empty_like(dz)
+            hip.act_bwd(dz, _as_compute(y), t, M * N, ACT_RELU, 1.0 / (1.0 - ctx.drop_p) if ctx.drop_p > 0 else 1.0)
+            dz = t
+        elif act == ACT_GELU:
+            t = torch.empty_like(dz)
+            hip.act_bwd(dz, _as_compute(z), t, M * N, ACT_GELU, 1.0)
+            dz = t
+        if w.weight.requires_grad:
+            hip.gemm(dz, x2, w.wgrad(), N, K, M, N, K, K, layoutA=hip.TRANS, layoutB=hip.TRANS, accumulate=True,
+                     split_k=_split_k(N, K, M))
+        if w.bias is not None and w.bias.requires_grad:
+            hip.colsum(dz, w.bgrad(), M, N, N)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(M, K, device=dz.device, dtype=RT.dtype)
+            hip.gemm(dz, w.lpT(), dx, M, K, N, N, w.Ntot, K)
+            dx = dx.reshape(ctx.xshape)
+        return dx, None, None, None, None, None
+
+
+_DUMMY = {}
+
+
+def _dummy(device):
+    """1-element leaf that requires grad: forces autograd to call our backward (parameter gradients are
+    accumulated by the kernels, not by autograd) when the activation input itself needs no gradient."""
+    d = _DUMMY.get(device)
+    if d is None:
+        d = _DUMMY[device] = torch.zeros(1, device=device, requires_grad=True)
+    return d
+
+
+def linear(x, w, act=ACT_NONE, drop_p=0.0, out_f32=False):
+    assert not (drop_p > 0 and act != ACT_RELU), 'epilogue dropout is only differentiated through the ReLU form'
+    dummy = None
+    if torch.is_grad_enabled() and not x.requires_grad and (w.weight.requires_grad or (w.bias is not None and w.bias.requires_grad)):
+        dummy = _dummy(x.device)
+    return LinearFn.apply(x, w, act, drop_p, out_f32, dummy)
+
+
+# y = a @ b^T with both operands activations (answer head: h x Wc^T)
+class MatmulNTFn(Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        M, K = a.shape
+        N = b.shape[0]
+        y = torch.empty(M, N, device=a.device, dtype=RT.dtype)
+        hip.gemm(a, b, y, M, N, K, K, K, N)
+        ctx.save_for_backward(a, b)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        a, b = ctx.saved_tensors
+        M, K = a.shape
+        N = b.shape[0]
+        dy = _c(_as_compute(dy))
+        da = db = None
+        if ctx.needs_input_grad[0]:
+            da = torch.empty(M, K, device=a.device, dtype=RT.dtype)
+            hip.gemm(dy, b, da, M, K, N, N, K, K, layoutB=hip.TRANS)
+        if ctx.needs_input_grad[1]:
+            db = torch.empty(N, K, device=a.device, dtype=RT.dtype)
+            hip.gemm(dy, a, db, N, K, M, N, K, K, layoutA=hip.TRANS, layoutB=hip.TRANS)
+        return da, db
+
+
+def matmul_nt(a, b):
+    return MatmulNTFn.apply(_c(_as_compute(a)), _c(_as_compute(b)))
+
+
+# --------------------------------------------------------------------------------------------
+# y = LayerNorm(x + dropout(s)) * gamma + beta
+# --------------------------------------------------------------------------------------------
+class AddLayerNormFn(Function):
+    @staticmethod
+    def forward(ctx, x, s, gamma, beta, eps, drop_p):
+        cols = x.shape[-1]
+        x2 = _c(_as_compute(x)).reshape(-1, cols)
+        s2 = None if s is None else _c(_as_compute(s)).reshape(-1, cols)
+        rows = x2.shape[0]
+        y = torch.empty_like(x2)
+        mean = torch.empty(rows, device=x.device, dtype=torch.float32)
+        rstd = torch.empty_like(mean)
+        seed = RT.next_seed() if (drop_p > 0 and s is not None) else 0
+        if s is None:
+            drop_p = 0.0
+        hip.layernorm_fwd(x2, s2, None if gamma is None else gamma.detach(), None if beta is None else beta.detach(),
+                          y, mean, rstd, rows, cols, eps, drop_p, seed)
+        ctx.gamma, ctx.beta, ctx.drop_p, ctx.seed, ctx.shape = gamma, beta, drop_p, seed, x.shape
+        ctx.has_s = s is not None
+        ctx.save_for_backward(x2, s2, mean, rstd)
+        return y.reshape(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, s2, mean, rstd = ctx.saved_tensors
+        rows, cols = x2.shape
+        dy2 = _c(_as_compute(dy)).reshape(rows, cols)
+        dx = torch.empty_like(x2)
+        ds = torch.empty_like(x2) if (ctx.has_s and ctx.drop_p > 0) else None
+        gamma, beta = ctx.gamma, ctx.beta
+        need_g = gamma is not None and gamma.requires_grad
+        hip.layernorm_bwd(dy2, x2, s2, None if gamma is None else gamma.detach(), mean, rstd, dx, ds,
+                          ensure_grad(gamma) if need_g else None, ensure_grad(beta) if need_g else None,
+                          rows, cols, ctx.drop_p, ctx.seed)
+        dxr = dx.reshape(ctx.shape)
+        dsr = None
+        if ctx.has_s:
+            dsr = (ds if ds is not None else dx).reshape(ctx.shape)
+        return (dxr if ctx.needs_input_grad[0] else None), (dsr if ctx.needs_input_grad[1] else None), None, None, None, None
+
+
+def add_layernorm(x, s, gamma, beta, eps, drop_p=0.0):
+    return AddLayerNormFn.apply(x, s, gamma, beta, eps, drop_p)
+
+
+# --------------------------------------------------------------------------------------------
+# attention core over (possibly fused) projection buffers
+# --------------------------------------------------------------------------------------------
+class AttentionFn(Function):
+    """bufs: distinct [B*S, width] tensors; roles: ((buf_idx, col_off) for q, k, v).  Every column of
+    every buf must be covered by exactly one role (true for qk|v, qkv, q|kv fusions)."""
+
+    @staticmethod
+    def forward(ctx, meta, *bufs):
+        roles, B, H, Sq, Sk, dh, kpm, causal, drop_p = meta
+        D = H * dh
+        bufs = tuple(_c(_as_compute(b)) for b in bufs)
+        (qi, qo), (ki, ko), (vi, vo) = roles
+        qb, kb, vb = bufs[qi], bufs[ki], bufs[vi]
+        o = torch.empty(B * Sq, D, device=qb.device, dtype=RT.dtype)
+        lse = torch.empty(B, H, Sq, device=qb.device, dtype=torch.float32)
+        st = ((Sq * qb.shape[1], qb.shape[1]), (Sk * kb.shape[1], kb.shape[1]), (Sk * vb.shape[1], vb.shape[1]), (Sq * D, D))
+        seed = RT.next_seed() if drop_p > 0 else 0
+        scale = 1.0 / math.sqrt(dh)
+        hip.attention_fwd(qb[:, qo:], kb[:, ko:], vb[:, vo:], o, st, B, H, Sq, Sk, dh, scale, kpm=kpm, causal=causal,
+                          drop_p=drop_p, seed=seed, lse=lse)
+        ctx.meta, ctx.seed, ctx.st, ctx.scale = meta, seed, st, scale
+        ctx.save_for_backward(o, lse, *bufs)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        roles, B, H, Sq, Sk, dh, kpm, causal, drop_p = ctx.meta
+        D = H * dh
+        o, lse, *bufs = ctx.saved_tensors
+        (qi, qo), (ki, ko), (vi, vo) = roles
+        do = _c(_as_compute(do))
+        grads = [torch.empty_like(b) for b in bufs]
+        hip.attention_bwd(bufs[qi][:, qo:], bufs[ki][:, ko:], bufs[vi][:, vo:], o, do,
+                          grads[qi][:, qo:], grads[ki][:, ko:], grads[vi][:, vo:], ctx.st, (Sq * D, D),
+                          B, H, Sq, Sk, dh, ctx.scale, kpm=kpm, causal=causal, drop_p=drop_p, seed=ctx.seed, lse=lse)
+        return (None, *grads)
+
+
+def attention(bufs, roles, B, H, Sq, Sk, dh, kpm=None, causal=False, drop_p=0.0):
+    return AttentionFn.apply((roles, B, H, Sq, Sk, dh, kpm, causal, drop_p), *bufs)
+
+
+# --------------------------------------------------------------------------------------------
+# small element-wise autograd ops
+# --------------------------------------------------------------------------------------------
+class AddFn(Function):
+    """y = a + b (same shape) or a + b broadcast over leading rows (b: [rows_b, cols])"""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a2, b2 = _c(_as_compute(a)), _c(_as_compute(b))
+        y = torch.empty_like(a2)
+        cols = a2.shape[-1]
+        ctx.bshape, ctx.ashape = b.shape, a.shape
+        if a2.numel() == b2.numel():
+            hip.add(a2, b2, y, a2.numel())
+        else:
+            hip.add_rowbcast(a2, b2, y, a2.numel() // cols, b2.numel() // cols, cols)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        db = None
+        if ctx.needs_input_grad[1]:
+            if math.prod(ctx.bshape) == dy.numel():
+                db = dy.reshape(ctx.bshape)
+            else:                                           # broadcast rows: sum over the leading repeats
+                cols = ctx.bshape[-1]
+                rows_b = math.prod(ctx.bshape) // cols
+                acc = torch.zeros(rows_b * cols, device=dy.device, dtype=torch.float32)
+                d2 = _c(dy).reshape(-1, rows_b * cols)
+                hip.colsum(d2, acc, d2.shape[0], rows_b * cols, rows_b * cols)
+                db = acc.to(dy.dtype).reshape(ctx.bshape)
+        return (dy if ctx.needs_input_grad[0] else None), db
+
+
+def add(a, b):
+    return AddFn.apply(a, b)
+
+
+class EmbeddingFn(Function):
+    """frozen-table gather (nn.Embedding.from_pretrained(freeze=True), gpv.py:50-51; BERT embeddings)"""
+
+    @staticmethod
+    def forward(ctx, table, ids):
+        ids = _c(ids)
+        dim = table.shape[1]
+        out = torch.empty(ids.numel(), dim, device=ids.device, dtype=RT.dtype)
+        hip.embedding(table.detach(), ids.reshape(-1), out, ids.numel(), dim)
+        return out.reshape(*ids.shape, dim)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return None, None
+
+
+def embedding(table, ids):
+    return EmbeddingFn.apply(table, ids)
+
+
+class RelevanceConditionFn(Function):
+    """gpv.py:364-375: y = x + softmax(logits) @ tokens   x:[rows,D] logits:[rows,2] fp32 tokens:[2,D] fp32 param"""
+
+    @staticmethod
+    def forward(ctx, x, logits, tokens):
+        x2 = _c(_as_compute(x))
+        lg = _c(logits.float())
+        y = torch.empty_like(x2)
+        hip.relevance_condition(x2, lg, tokens.detach(), y, x2.shape[0], x2.shape[1])
+        ctx.tokens = tokens
+        ctx.save_for_backward(lg)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (lg,) = ctx.saved_tensors
+        tokens = ctx.tokens
+        rows, D = dy.shape
+        dyc = _c(_as_compute(dy))
+        p = lg.softmax(-1)                                             # [rows,2] fp32 (tiny)
+        # dp[r,j] = dy[r] . tok[j]   ;  dtok[j] += sum_r p[r,j] dy[r]
+        tok_lp = _as_compute(tokens.detach())
+        dp = torch.empty(rows, 2, device=dy.device, dtype=torch.float32)
+        hip.gemm(dyc, tok_lp, dp, rows, 2, D, D, D, 2)
+        if tokens.requires_grad:
+            hip.gemm(_as_compute(p), dyc, ensure_grad(tokens), 2, D, rows, 2, D, D, layoutA=hip.TRANS, layoutB=hip.TRANS,
+                     accumulate=True, split_k=_split_k(2, D, rows))
+        dlg = p * (dp - (p * dp).sum(-1, keepdim=True))
+        return (dy if ctx.needs_input_grad[0] else None), (dlg if ctx.needs_input_grad[1] else None), None
+
+
+def relevance_condition(x, logits, tokens):
+    return RelevanceConditionFn.apply(x, logits, tokens)
+
+
+class SoftmaxCEFn(Function):
+    """per-row cross entropy (reduction none), logits [rows, V]"""
+
+    @staticmethod
+    def forward(ctx, logits, target):
+        lg = _c(logits)
+        rows, V = lg.shape
+        loss = torch.empty(rows, device=lg.device, dtype=torch.float32)
+        hip.softmax_ce(lg, V, _c(target), loss, None, None, rows, V)
+        ctx.save_for_backward(lg, target)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        lg, target = ctx.saved_tensors
+        rows, V = lg.shape
+        dl = torch.empty_like(lg)
+        scratch = torch.empty(rows, device=lg.device, dtype=torch.float32)
+        hip.softmax_ce(lg, V, _c(target), scratch, dl, _c(dloss.float()), rows, V)
+        return dl, None
+
+
+def softmax_ce(logits, target):
+    return SoftmaxCEFn.apply(logits, target)
+
+
+# --------------------------------------------------------------------------------------------
+# RoIAlign(7x7, aligned) + mean over bins, separable form (detr_roi_head.py:44-56)
+# --------------------------------------------------------------------------------------------
+class RoiPoolFn(Function):
+    """feat [B, H*W, C] (NHWC rows), boxes [B, Q, 4] fp32 n-cxcywh (no gradient to boxes: torchvision
+    roi_align has none) -> pooled [B, Q, C]"""
+
+    @staticmethod
+    def forward(ctx, feat, boxes, H, Wd):
+        B, Pn, Cc = feat.shape
+        Q = boxes.shape[1]
+        ldw = ((Pn + 31) // 32) * 32
+        wgt = torch.empty(B * Q, ldw, device=feat.device, dtype=RT.dtype)
+        hip.roi_weights(_c(boxes.detach().float().reshape(-1, 4)), wgt, B * Q, H, Wd, ldw)
+        f = _c(_as_compute(feat))
+        out = torch.empty(B, Q, Cc, device=feat.device, dtype=RT.dtype)
+        hip.gemm(wgt, f, out, Q, Cc, Pn, ldw, Cc, Cc, layoutB=hip.TRANS, batch=B, sA=Q * ldw, sB=Pn * Cc, sC=Q * Cc)
+        ctx.dims = (B, Pn, Cc, Q, ldw)
+        ctx.save_for_backward(wgt)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (wgt,) = ctx.saved_tensors
+        B, Pn, Cc, Q, ldw = ctx.dims
+        d = _c(_as_compute(dout))
+        df = torch.empty(B, Pn, Cc, device=d.device, dtype=RT.dtype)
+        hip.gemm(wgt, d, df, Pn, Cc, Q, ldw, Cc, Cc, layoutA=hip.TRANS, layoutB=hip.TRANS, batch=B, sA=Q * ldw,
+                 sB=Q * Cc, sC=Pn * Cc)
+        return df, None, None, None
+
+
+def roi_pool(feat, boxes, H, Wd):
+    return RoiPoolFn.apply(feat, boxes, H, Wd)

@@ -1,0 +1,58 @@
+"""2-D sine position embedding (reference: exp/gpv/models/position_encoding.py:12-48).
+
+The embedding depends only on the padding mask; at GPV's fixed 480x640 input the mask is all-False
+and the result is a constant, so it is computed once per (B,h,w) and cached.  Returned in
+the row layout the transformer kernels use: [B, h*w, 2*num_pos_feats] in the compute dtype.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from .ops import RT
+
+
+class PositionEmbeddingSine(nn.Module):
+    def __init__(self, num_pos_feats=64, temperature=10000, normalize=False, scale=None):
+        super().__init__()
+        if scale is not None and normalize is False:
+            raise ValueError("normalize should be True if scale is passed")
+        self.num_pos_feats, self.temperature, self.normalize = num_pos_feats, temperature, normalize
+        self.scale = 2 * math.pi if scale is None else scale
+        self._cache = {}
+
+    def compute(self, mask):
+        not_mask = (~mask).float()
+        y_embed = not_mask.cumsum(1)
+        x_embed = not_mask.cumsum(2)
+        if self.normalize:
+            eps = 1e-6
+            y_embed = y_embed / (y_embed[:, -1:, :] + eps) * self.scale
+            x_embed = x_embed / (x_embed[:, :, -1:] + eps) * self.scale
+        i = torch.arange(self.num_pos_feats, dtype=torch.float32, device=mask.device)
+        dim_t = self.temperature ** (2 * torch.div(i, 2, rounding_mode='floor') / self.num_pos_feats)
+        px = x_embed[..., None] / dim_t
+        py = y_embed[..., None] / dim_t
+        px = torch.stack((px[..., 0::2].sin(), px[..., 1::2].cos()), dim=4).flatten(3)
+        py = torch.stack((py[..., 0::2].sin(), py[..., 1::2].cos()), dim=4).flatten(3)
+        return torch.cat((py, px), dim=3)                     # [B,h,w,2*npf]  (channels last)
+
+    def forward(self, tensor_list):
+        mask = tensor_list.mask
+        assert mask is not None
+        B, h, w = mask.shape
+        plain = not bool(mask.any())
+        key = (B, h, w, str(mask.device), RT.dtype)
+        if plain and key in self._cache:
+            return self._cache[key]
+        pos = self.compute(mask).reshape(B, h * w, -1).to(RT.dtype).contiguous()
+        if plain:
+            self._cache[key] = pos
+        return pos
+
+
+def build_position_encoding(args):
+    n_steps = args.hidden_dim // 2
+    if args.position_embedding in ('v2', 'sine'):
+        return PositionEmbeddingSine(n_steps, normalize=True)
+    raise ValueError(f"not supported {args.position_embedding} (GPV-1 ships position_embedding: sine)")

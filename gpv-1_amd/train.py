@@ -1,0 +1,161 @@
+"""Training step driver: the hot loop of exp/gpv/train_distr.py:399-428 rebuilt for one process per GPU.
+
+  encode_answers -> model(imgs, queries, answer_token_ids, targets) -> backward -> gradient all-reduce
+  (RCCL over xGMI, flat fp32 buffer, bucketed + asynchronous) -> clip_grad_norm_(DETR params, 0.1)
+  -> AdamW (4 parameter groups, train_distr.py:228-253) -> WarmupLinearSchedule step.
+
+MI355X-first choices
+  * every parameter that can receive a gradient lives in ONE flat fp32 buffer (and so do its gradient
+    and Adam moments): zero_grad is one memset, the all-reduce runs over a few large contiguous
+    buckets (ring all-reduce over xGMI is per-link bound, so fewer/larger messages), the clip norm is
+    one reduction kernel and AdamW is one fused kernel per contiguous touched range;
+  * parameters that can never receive a gradient (BERT under no_grad, vision_token, lang_token,
+    q_dense1/2 -- 113 M of the reference's 224 M "trainable" parameters) are left out of the
+    gradient exchange instead of relying on DDP find_unused_parameters=True;
+  * torch-1.6 optimizer semantics kept: a parameter is only updated (incl. weight decay) once it has
+    received a gradient at least once; the touched set is agreed across ranks (MAX all-reduce).
+"""
+import torch
+import torch.distributed as dist
+
+from . import hip
+from .ops import RT
+
+GROUPS = ('detr_backbone', 'detr_head', 'bert', 'others')
+
+
+def param_group_of(name):
+    """train_distr.py:234-242"""
+    if 'detr.backbone' in name:
+        return 'detr_backbone'
+    if 'detr' in name:
+        return 'detr_head'
+    if 'bert.' in name:
+        return 'bert'
+    return 'others'
+
+
+NEVER_GRAD = ('bert.', 'vision_token', 'lang_token', 'q_dense1', 'q_dense2', 'pos_enc', 'vocab_embed', 'embedding_layer',
+              'pooler')
+
+
+def warmup_linear(step, warmup_steps, t_total):
+    """pytorch_transformers.WarmupLinearSchedule (train_distr.py:298-302)"""
+    if step < warmup_steps:
+        return float(step) / float(max(1, warmup_steps))
+    return max(0.0, float(t_total - step) / float(max(1.0, t_total - warmup_steps)))
+
+
+class FlatTrainer:
+    def __init__(self, model, lr=1e-4, lr_backbone=1e-5, weight_decay=1e-4, clip_max_norm=0.1, warmup_steps=0,
+                 t_total=0, betas=(0.9, 0.999), eps=1e-8, bucket_mb=128, process_group=None):
+        self.model = model
+        self.lr = {'detr_backbone': lr_backbone, 'detr_head': lr, 'bert': lr, 'others': lr}
+        self.wd, self.clip, self.betas, self.eps = weight_decay, clip_max_norm, betas, eps
+        self.warmup_steps, self.t_total = warmup_steps, t_total
+        self.step_count = 0
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        named = [(n, p) for n, p in model.named_parameters() if p.requires_grad and not any(s in n for s in NEVER_GRAD)]
+        named.sort(key=lambda np_: GROUPS.index(param_group_of(np_[0])))           # stable: module order inside a group
+        self.entries = []                                                           # (name, param, group, offset, numel)
+        off = 0
+        for n, p in named:
+            self.entries.append((n, p, param_group_of(n), off, p.numel()))
+            off += (p.numel() + 7) // 8 * 8                                          # keep every segment 32-B aligned
+        self.total = off
+        dev = named[0][1].device
+        self.P = torch.zeros(off, device=dev, dtype=torch.float32)
+        self.G = torch.zeros_like(self.P)
+        self.M = torch.zeros_like(self.P)
+        self.V = torch.zeros_like(self.P)
+        self.touched = torch.zeros(len(self.entries), dtype=torch.bool)
+        self._touched_dev = torch.zeros(len(self.entries), device=dev, dtype=torch.int32)
+        for i, (n, p, g, o, k) in enumerate(self.entries):
+            pv, gv = self._view(self.P, p, o, k), self._view(self.G, p, o, k)
+            pv.copy_(p.data)
+            p.data = pv
+            p.grad = gv
+            p._gpv_touch = (lambda i=i: self._mark(i))                            # kernel-accumulated gradients
+            p.register_hook(lambda grad, i=i: self._mark(i))                       # autograd-delivered gradients
+        self.gsq = torch.zeros(1, device=dev, dtype=torch.float32)
+        self.gscale = torch.ones(1, device=dev, dtype=torch.float32)
+        b = bucket_mb * 1024 * 1024 // 4
+        self.buckets = [(s, min(off, s + b)) for s in range(0, off, b)]
+        if self.world > 1:
+            dist.broadcast(self.P, src=0, group=self.pg)
+        RT.bump_weights()
+
+    @staticmethod
+    def _view(flat, p, off, numel):
+        if p.dim() == 4:                                                            # conv weight: channels_last memory
+            co, ci, kh, kw = p.shape
+            return flat[off:off + numel].view(co, kh, kw, ci).permute(0, 3, 1, 2)
+        return flat[off:off + numel].view(p.shape)
+
+    def _mark(self, i):
+        self.touched[i] = True
+
+    def zero_grad(self):
+        self.G.zero_()
+
+    # ---- gradient exchange: average over ranks, a few large buckets, async ----
+    def allreduce_grads(self):
+        if self.world == 1:
+            return
+        works = [dist.all_reduce(self.G[s:e], op=dist.ReduceOp.SUM, group=self.pg, async_op=True) for s, e in self.buckets]
+        t = self._touched_dev
+        t.copy_(self.touched.to(torch.int32), non_blocking=False)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.pg)
+        self.touched |= t.cpu().bool()
+        for w in works:
+            w.wait()
+        self.G.mul_(1.0 / self.world)
+
+    def _ranges(self, pred):
+        """contiguous flat ranges of touched entries satisfying pred(group), merged per group"""
+        out = []
+        for i, (n, p, g, o, k) in enumerate(self.entries):
+            if not self.touched[i] or not pred(g):
+                continue
+            end = o + (k + 7) // 8 * 8
+            if out and out[-1][0] == g and out[-1][2] == o:
+                out[-1][2] = end
+            else:
+                out.append([g, o, end])
+        return out
+
+    def step(self):
+        """clip_grad_norm_(detr params) + AdamW + schedule (train_distr.py:423-428,468-469)"""
+        sched = warmup_linear(self.step_count, self.warmup_steps, self.t_total) if self.t_total > 0 else 1.0
+        use_clip = self.clip is not None and self.clip > 0
+        if use_clip:
+            self.gsq.zero_()
+            for g, s, e in self._ranges(lambda g: g in ('detr_backbone', 'detr_head')):
+                hip.sumsq(self.G[s:e], e - s, self.gsq)
+            # scale = min(1, max_norm / (norm + 1e-6)) on device, no host sync
+            torch.clamp(self.clip / (self.gsq.sqrt() + 1e-6), max=1.0, out=self.gscale)
+        self.step_count += 1
+        t = self.step_count
+        b1, b2 = self.betas
+        bc1, bc2 = 1 - b1 ** t, 1 - b2 ** t
+        for g, s, e in self._ranges(lambda g: True):
+            clip_here = use_clip and g in ('detr_backbone', 'detr_head')
+            hip.adamw(self.P[s:e], self.G[s:e], self.M[s:e], self.V[s:e], None, e - s, self.lr[g] * sched, b1, b2,
+                      self.eps, self.wd, bc1, bc2, self.gscale if clip_here else None)
+        RT.bump_weights()
+
+    def train_step(self, images, queries, targets):
+        """one iteration of train_distr.py:399-428; returns the loss tensor (or None: no applicable target)"""
+        model = self.model
+        model.train()
+        _, answer_token_ids = model.encode_answers(targets)
+        for i, t in enumerate(targets):
+            t['answer_token_ids'] = answer_token_ids[i, 1:]
+        loss = model(images, queries, answer_token_ids, targets)
+        if loss is not None:
+            self.zero_grad()
+            loss.backward()
+            self.allreduce_grads()
+            self.step()
+        return loss

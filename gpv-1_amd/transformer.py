@@ -1,0 +1,173 @@
+"""DETR transformer on the HIP kernels (reference: exp/gpv/models/transformer.py).
+
+Same parameter names as the reference (``self_attn.in_proj_weight``, ``out_proj``, ``linear1`` ...), post-norm
+layers only (configs/exp/gpv.yaml: pre_norm False).  Internally batch-first: activations are
+[B*S, C] row matrices in the compute dtype; every block is
+    projection GEMM(s) -> attention kernel -> out-proj GEMM -> fused (residual + dropout + LayerNorm)
+    -> FFN GEMM (bias+ReLU+dropout epilogue) -> GEMM -> fused (residual + dropout + LayerNorm).
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+from .ops import W
+
+
+class LinearP(nn.Module):
+    """nn.Linear parameters (same init) evaluated by the GEMM kernel."""
+
+    def __init__(self, in_features, out_features, bias=True):
+        super().__init__()
+        ref = nn.Linear(in_features, out_features, bias=bias)
+        self.weight = nn.Parameter(ref.weight.detach().clone())
+        self.bias = nn.Parameter(ref.bias.detach().clone()) if bias else None
+        self.in_features, self.out_features = in_features, out_features
+
+    def forward(self, x, act=ops.ACT_NONE, drop_p=0.0, out_f32=False):
+        return ops.linear(x, W(self.weight, self.bias), act, drop_p, out_f32)
+
+
+class LayerNormP(nn.Module):
+    def __init__(self, dim, eps=1e-5):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(dim))
+        self.bias = nn.Parameter(torch.zeros(dim))
+        self.eps = eps
+
+    def forward(self, x, s=None, drop_p=0.0):
+        """LayerNorm(x + dropout(s))"""
+        return ops.add_layernorm(x, s, self.weight, self.bias, self.eps, drop_p)
+
+
+class MultiheadAttention(nn.Module):
+    """torch.nn.MultiheadAttention parameters (packed in_proj), HIP attention core."""
+
+    def __init__(self, embed_dim, num_heads, dropout=0.0):
+        super().__init__()
+        self.embed_dim, self.num_heads, self.dropout = embed_dim, num_heads, dropout
+        self.head_dim = embed_dim // num_heads
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * embed_dim, embed_dim))
+        self.in_proj_bias = nn.Parameter(torch.zeros(3 * embed_dim))
+        self.out_proj = LinearP(embed_dim, embed_dim)
+        nn.init.xavier_uniform_(self.in_proj_weight)
+        nn.init.constant_(self.out_proj.bias, 0.)
+
+    def forward(self, q_in, k_in, v_in, B, Sq, Sk, key_padding_mask=None, causal=False):
+        E = self.embed_dim
+        w, b = self.in_proj_weight, self.in_proj_bias
+        if q_in is k_in and k_in is v_in:
+            bufs = [ops.linear(q_in, W(w, b, 0, 3 * E))]
+            roles = ((0, 0), (0, E), (0, 2 * E))
+        elif q_in is k_in:
+            bufs = [ops.linear(q_in, W(w, b, 0, 2 * E)), ops.linear(v_in, W(w, b, 2 * E, 3 * E))]
+            roles = ((0, 0), (0, E), (1, 0))
+        elif k_in is v_in:
+            bufs = [ops.linear(q_in, W(w, b, 0, E)), ops.linear(k_in, W(w, b, E, 3 * E))]
+            roles = ((0, 0), (1, 0), (1, E))
+        else:
+            bufs = [ops.linear(q_in, W(w, b, 0, E)), ops.linear(k_in, W(w, b, E, 2 * E)), ops.linear(v_in, W(w, b, 2 * E, 3 * E))]
+            roles = ((0, 0), (1, 0), (2, 0))
+        o = ops.attention(bufs, roles, B, self.num_heads, Sq, Sk, self.head_dim, kpm=key_padding_mask, causal=causal,
+                          drop_p=self.dropout if self.training else 0.0)
+        return self.out_proj(o)
+
+
+class TransformerEncoderLayer(nn.Module):
+    def __init__(self, d_model, nhead, dim_feedforward=2048, dropout=0.1):
+        super().__init__()
+        self.self_attn = MultiheadAttention(d_model, nhead, dropout=dropout)
+        self.linear1 = LinearP(d_model, dim_feedforward)
+        self.linear2 = LinearP(dim_feedforward, d_model)
+        self.norm1 = LayerNormP(d_model)
+        self.norm2 = LayerNormP(d_model)
+        self.p = dropout
+
+    def forward(self, src, pos, B, S, kpm):
+        """transformer.py:148-161 (forward_post)"""
+        p = self.p if self.training else 0.0
+        qk = ops.add(src, pos)
+        src = self.norm1(src, self.self_attn(qk, qk, src, B, S, S, kpm), p)
+        h = self.linear1(src, ops.ACT_RELU, p)
+        return self.norm2(src, self.linear2(h), p)
+
+
+class TransformerDecoderLayer(nn.Module):
+    def __init__(self, d_model, nhead, dim_feedforward=2048, dropout=0.1):
+        super().__init__()
+        self.self_attn = MultiheadAttention(d_model, nhead, dropout=dropout)
+        self.multihead_attn = MultiheadAttention(d_model, nhead, dropout=dropout)
+        self.linear1 = LinearP(d_model, dim_feedforward)
+        self.linear2 = LinearP(dim_feedforward, d_model)
+        self.norm1 = LayerNormP(d_model)
+        self.norm2 = LayerNormP(d_model)
+        self.norm3 = LayerNormP(d_model)
+        self.p = dropout
+
+    def forward(self, tgt, memory, mem_pos, query_pos, B, Q, S, kpm):
+        """transformer.py:211-232 (forward_post); mem_pos = memory + pos is layer-invariant."""
+        p = self.p if self.training else 0.0
+        qk = ops.add(tgt, query_pos)
+        tgt = self.norm1(tgt, self.self_attn(qk, qk, tgt, B, Q, Q), p)
+        a = self.multihead_attn(ops.add(tgt, query_pos), mem_pos, memory, B, Q, S, kpm)
+        tgt = self.norm2(tgt, a, p)
+        h = self.linear1(tgt, ops.ACT_RELU, p)
+        return self.norm3(tgt, self.linear2(h), p)
+
+
+class TransformerEncoder(nn.Module):
+    def __init__(self, make_layer, num_layers):
+        super().__init__()
+        self.layers = nn.ModuleList([make_layer() for _ in range(num_layers)])
+        self.norm = None
+
+
+class TransformerDecoder(nn.Module):
+    def __init__(self, make_layer, num_layers, d_model):
+        super().__init__()
+        self.layers = nn.ModuleList([make_layer() for _ in range(num_layers)])
+        self.norm = LayerNormP(d_model)
+
+
+class Transformer(nn.Module):
+    def __init__(self, d_model=512, nhead=8, num_encoder_layers=6, num_decoder_layers=6, dim_feedforward=2048,
+                 dropout=0.1, normalize_before=False, return_intermediate_dec=False):
+        super().__init__()
+        if normalize_before:
+            raise NotImplementedError('pre_norm is False in every GPV-1 config (configs/exp/gpv*.yaml)')
+        self.encoder = TransformerEncoder(lambda: TransformerEncoderLayer(d_model, nhead, dim_feedforward, dropout),
+                                          num_encoder_layers)
+        self.decoder = TransformerDecoder(lambda: TransformerDecoderLayer(d_model, nhead, dim_feedforward, dropout),
+                                          num_decoder_layers, d_model)
+        self.d_model, self.nhead = d_model, nhead
+        for p in self.parameters():                       # transformer.py:41-44
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+
+    def forward(self, src, mask, query_embed, pos, need_all_layers):
+        """src [B,S,C] rows (input_proj output), mask [B,S] bool, query_embed [Q,C] param, pos [B,S,C].
+        Returns list of decoder-normed outputs [B,Q,C] (all layers, or only the last) -- transformer.py:46-58,94-123."""
+        B, S, C = src.shape
+        Q = query_embed.shape[0]
+        kpm = mask.to(torch.uint8).contiguous() if mask is not None else None
+        x = src.reshape(B * S, C)
+        pe = pos.reshape(B * S, C)
+        for layer in self.encoder.layers:
+            x = layer(x, pe, B, S, kpm)
+        memory = x
+        mem_pos = ops.add(memory, pe)
+        qpos = query_embed.to(ops.RT.dtype).unsqueeze(0).expand(B, Q, C).reshape(B * Q, C)
+        tgt = torch.zeros(B * Q, C, device=src.device, dtype=ops.RT.dtype)
+        outs = []
+        n = len(self.decoder.layers)
+        for i, layer in enumerate(self.decoder.layers):
+            tgt = layer(tgt, memory, mem_pos, qpos, B, Q, S, kpm)
+            if need_all_layers or i == n - 1:
+                outs.append(self.decoder.norm(tgt).reshape(B, Q, C))
+        return outs, memory.reshape(B, S, C)
+
+
+def build_transformer(args):
+    return Transformer(d_model=args.hidden_dim, dropout=args.dropout, nhead=args.nheads,
+                       dim_feedforward=args.dim_feedforward, num_encoder_layers=args.num_encoder_layers,
+                       num_decoder_layers=args.num_decoder_layers, normalize_before=args.pre_norm,
+                       return_intermediate_dec=True)

@@ -1,0 +1,106 @@
+"""Co-attention layer (the live part of the reference's ViLBERT copy: exp/gpv/models/vilbert.py
+BertConnectionLayer :859-900, BertBiAttention :696-824, BertBiOutput :827-856,
+Bert(Image)Intermediate/Output :488-516,649-677, erf-GELU :111-117, BertLayerNorm eps 1e-12).
+
+Stream 1 = language tokens, stream 2 = vision tokens (gpv.py:149-154).  The six Q/K/V projections are
+GEMMs (per-stream fusion is a follow-up); both attention directions run on the same MFMA attention
+kernel (dh = 48, K-dim padded to 64); residual+dropout+LayerNorm is one kernel, GELU a second pass
+that keeps the pre-activation for backward.  Parameter names match the reference so checkpoints load,
+including the declared-but-unused q_dense1/q_dense2 (vilbert.py:835-843).
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+from .ops import W
+from .transformer import LinearP, LayerNormP
+
+
+class BertBiAttention(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        if cfg.bi_hidden_size % cfg.bi_num_attention_heads != 0:
+            raise ValueError('bi_hidden_size must be a multiple of bi_num_attention_heads')
+        self.num_attention_heads = cfg.bi_num_attention_heads
+        self.attention_head_size = cfg.bi_hidden_size // cfg.bi_num_attention_heads
+        self.all_head_size = cfg.bi_hidden_size
+        self.query1 = LinearP(cfg.v_hidden_size, self.all_head_size)
+        self.key1 = LinearP(cfg.v_hidden_size, self.all_head_size)
+        self.value1 = LinearP(cfg.v_hidden_size, self.all_head_size)
+        self.query2 = LinearP(cfg.hidden_size, self.all_head_size)
+        self.key2 = LinearP(cfg.hidden_size, self.all_head_size)
+        self.value2 = LinearP(cfg.hidden_size, self.all_head_size)
+        self.p1 = cfg.v_attention_probs_dropout_prob
+        self.p2 = cfg.attention_probs_dropout_prob
+
+    def forward(self, t1, t2, B, T1, T2):
+        """t1 [B*T1, D] (language), t2 [B*T2, D] (vision) -> ctx1 [B*T2, D], ctx2 [B*T1, D]"""
+        H, dh, D = self.num_attention_heads, self.attention_head_size, self.all_head_size
+        q1, k1, v1 = self.query1(t1), self.key1(t1), self.value1(t1)
+        q2, k2, v2 = self.query2(t2), self.key2(t2), self.value2(t2)
+        p1 = self.p1 if self.training else 0.0
+        p2 = self.p2 if self.training else 0.0
+        # scores1 = q2 k1^T -> probs (dropout1) @ v1 : vision queries over language keys (vilbert.py:770-787)
+        ctx1 = ops.attention([q2, k1, v1], ((0, 0), (1, 0), (2, 0)), B, H, T2, T1, dh, drop_p=p1)
+        # scores2 = q1 k2^T -> probs (dropout2) @ v2 : language queries over vision keys (:790-810)
+        ctx2 = ops.attention([q1, k2, v2], ((0, 0), (1, 0), (2, 0)), B, H, T1, T2, dh, drop_p=p2)
+        return ctx1, ctx2
+
+
+class BertBiOutput(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.dense1 = LinearP(cfg.bi_hidden_size, cfg.v_hidden_size)
+        self.LayerNorm1 = LayerNormP(cfg.v_hidden_size, eps=1e-12)
+        self.q_dense1 = LinearP(cfg.bi_hidden_size, cfg.v_hidden_size)     # unused in forward (as in the reference)
+        self.dense2 = LinearP(cfg.bi_hidden_size, cfg.hidden_size)
+        self.LayerNorm2 = LayerNormP(cfg.hidden_size, eps=1e-12)
+        self.q_dense2 = LinearP(cfg.bi_hidden_size, cfg.hidden_size)       # unused in forward
+        self.p1, self.p2 = cfg.v_hidden_dropout_prob, cfg.hidden_dropout_prob
+
+    def forward(self, hidden1, input1, hidden2, input2):
+        p1 = self.p1 if self.training else 0.0
+        p2 = self.p2 if self.training else 0.0
+        return (self.LayerNorm1(input1, self.dense1(hidden1), p1),
+                self.LayerNorm2(input2, self.dense2(hidden2), p2))
+
+
+class _Intermediate(nn.Module):
+    def __init__(self, hidden, inter, act):
+        super().__init__()
+        if act != 'gelu':
+            raise NotImplementedError('GPV-1 configs use hidden_act: gelu')
+        self.dense = LinearP(hidden, inter)
+
+    def forward(self, x):
+        return self.dense(x, ops.ACT_GELU)
+
+
+class _Output(nn.Module):
+    def __init__(self, inter, hidden, p):
+        super().__init__()
+        self.dense = LinearP(inter, hidden)
+        self.LayerNorm = LayerNormP(hidden, eps=1e-12)
+        self.p = p
+
+    def forward(self, h, inp):
+        return self.LayerNorm(inp, self.dense(h), self.p if self.training else 0.0)
+
+
+class BertConnectionLayer(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.biattention = BertBiAttention(cfg)
+        self.biOutput = BertBiOutput(cfg)
+        self.v_intermediate = _Intermediate(cfg.v_hidden_size, cfg.v_intermediate_size, cfg.v_hidden_act)
+        self.v_output = _Output(cfg.v_intermediate_size, cfg.v_hidden_size, cfg.v_hidden_dropout_prob)
+        self.t_intermediate = _Intermediate(cfg.hidden_size, cfg.intermediate_size, cfg.hidden_act)
+        self.t_output = _Output(cfg.intermediate_size, cfg.hidden_size, cfg.hidden_dropout_prob)
+
+    def forward(self, t1, t2, B, T1, T2):
+        """vilbert.py:872-900.  No attention masks: GPV passes None, so padded BERT tokens are attended."""
+        bi1, bi2 = self.biattention(t1, t2, B, T1, T2)
+        a1, a2 = self.biOutput(bi2, t1, bi1, t2)
+        o1 = self.v_output(self.v_intermediate(a1), a1)
+        o2 = self.t_output(self.t_intermediate(a2), a2)
+        return o1, o2

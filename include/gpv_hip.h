@@ -167,6 +167,10 @@ int gpv_prep_conv_weight(const float* src, const float* scale, void* wf, void* w
                          int Cin, int dtype_dst, void* stream);
 int gpv_embedding(const void* table, const int64_t* ids, void* out, int64_t n_ids, int dim, int dtype_table,
                   int dtype_out, void* stream);
+/* y = act(x), act in {RELU, GELU};  dx = dy * act'(ref) * alpha with ref = OUTPUT for relu (works through a
+ * fused inverted dropout: alpha = 1/(1-p)), ref = PRE-activation for gelu.  n % 8 == 0. */
+int gpv_act_fwd(const void* x, void* y, int64_t n, int act, int dtype, void* stream);
+int gpv_act_bwd(const void* dy, const void* ref, void* dx, int64_t n, int act, float alpha, int dtype, void* stream);
 int gpv_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, int dtype, void* stream);
 /* relevance conditioning gpv.py:364-375: y = x + softmax(logits)[.,0]*tok[0] + softmax(logits)[.,1]*tok[1] */
 int gpv_relevance_condition(const void* x, const float* logits, const float* tokens, void* y, int rows,

@@ -1,0 +1,298 @@
+"""TEST-ONLY emulation of the libgpv_hip.so entry points with plain torch on CPU.
+
+Purpose: let the `-m "not gpu"` suite exercise the HOST logic of the product package (module tree,
+state-dict keys, autograd wiring, layouts/strides passed to the kernels, criterion, trainer,
+multi-process gradient exchange over gloo) in a container without a GPU.  It is installed by
+monkeypatching ``gpv1_amd.hip`` inside tests only; the product never imports this file and has no
+CPU path of its own (gpv1_amd.hip raises without the library / with CPU tensors).
+Semantics follow include/gpv_hip.h; dropout is only supported with p = 0.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+def _sv(t, shape, strides, extra_off=0):
+    return torch.as_strided(t, shape, strides, t.storage_offset() + extra_off)
+
+
+def _mat(t, rows, cols, ld, layout, batch=1, bs=0):
+    """logical [batch, rows, cols] view of an operand stored KMAJOR ([r*ld + c]) or TRANS ([c*ld + r])"""
+    if layout == 0:
+        return _sv(t, (batch, rows, cols), (bs, ld, 1))
+    return _sv(t, (batch, rows, cols), (bs, 1, ld))
+
+
+def _act(x, act):
+    if act == 1:
+        return F.relu(x)
+    if act == 2:
+        return x * 0.5 * (1.0 + torch.erf(x / math.sqrt(2.0)))
+    return x
+
+
+def gemm(A, B, Cm, M, N, K, lda, ldb, ldc, layoutA=0, layoutB=0, batch=1, sA=0, sB=0, sC=0, alpha=1.0, rowscale=None,
+         bias=None, res=None, ldr=0, sR=0, relu_mask=None, ldm=0, act=0, drop_p=0.0, seed=0, accumulate=False, split_k=1):
+    assert drop_p == 0.0, 'cpu shim: dropout unsupported'
+    a = _mat(A, M, K, lda, layoutA, batch, sA).float()
+    b = _mat(B, N, K, ldb, layoutB, batch, sB).float()
+    y = alpha * (a @ b.transpose(1, 2))
+    if rowscale is not None:
+        y = y * rowscale[:M].view(1, M, 1)
+    if bias is not None:
+        y = y + bias[:N]
+    if res is not None:
+        y = y + _sv(res, (batch, M, N), (sR, ldr, 1)).float()
+    y = _act(y, act)
+    if relu_mask is not None:
+        y = y * (_sv(relu_mask, (1, M, N), (0, ldm, 1)).float() > 0)
+    out = _sv(Cm, (batch, M, N), (sC, ldc, 1))
+    if accumulate:
+        out += y.to(out.dtype)
+    else:
+        out.copy_(y.to(out.dtype))
+
+
+def conv2d(mode, x, w, y, B, IH, IW, Cs, Cin, OH, OW, Cout, KH, KW, SH, SW, PH, PW, rowscale=None, bias=None, res=None,
+           relu_mask=None, act=0, split_k=0):
+    if Cs != Cin:
+        # stem trick: a tap reads Cin contiguous elements starting at the pixel -> unfold explicitly
+        cols = []
+        for r in range(KH):
+            rows = _sv(x, (B, OH, OW, Cin), (IH * IW * Cs, SH * IW * Cs, SW * Cs, 1), (r - PH) * IW * Cs).float()
+            cols.append(rows)
+        a = torch.cat(cols, -1).reshape(B * OH * OW, KH * Cin)
+        out = a @ w.reshape(Cout, KH * KW * Cin).float().t()
+        out = out.view(B, OH, OW, Cout)
+        if bias is not None:
+            out = out + bias
+        y.copy_(_act(out, act).to(y.dtype))
+        return
+    xg = _sv(x, (B, IH, IW, Cin), (IH * IW * Cs, IW * Cs, Cs, 1)).float()
+    if mode == 0:
+        wt = w.reshape(Cout, KH, KW, Cin).permute(0, 3, 1, 2).float()
+        out = F.conv2d(xg.permute(0, 3, 1, 2), wt, stride=(SH, SW), padding=(PH, PW)).permute(0, 2, 3, 1)
+        if rowscale is not None:
+            out = out * rowscale
+        if bias is not None:
+            out = out + bias
+        if res is not None:
+            out = out + res.float()
+        out = _act(out, act)
+        if relu_mask is not None:
+            out = out * (relu_mask.float() > 0)
+        y.copy_(out.to(y.dtype))
+    elif mode == 1:
+        # gathered tensor = dy [B,IH,IW,Cin(=fwd Cout)], output dx [B,OH,OW,Cout(=fwd Cin)], w = wd [fwdCin][T][fwdCout]
+        wt = w.reshape(Cout, KH, KW, Cin).permute(3, 0, 1, 2).float()                # [fwdCout, fwdCin, kh, kw]
+        oph = OH - ((IH - 1) * SH - 2 * PH + KH)
+        opw = OW - ((IW - 1) * SW - 2 * PW + KW)
+        out = F.conv_transpose2d(xg.permute(0, 3, 1, 2), wt, stride=(SH, SW), padding=(PH, PW),
+                                 output_padding=(oph, opw)).permute(0, 2, 3, 1)
+        if res is not None:
+            out = out + res.float()
+        if relu_mask is not None:
+            out = out * (relu_mask.float() > 0)
+        y.copy_(out.to(y.dtype))
+    else:
+        # wgrad: x gathered fwd input, w = dy [B,OH,OW,Cout], y = dw [Cout][T][Cin] fp32 (+=)
+        xi = xg.permute(0, 3, 1, 2).requires_grad_(False)
+        dy = w.reshape(B, OH, OW, Cout).permute(0, 3, 1, 2).float()
+        wz = torch.zeros(Cout, Cin, KH, KW, requires_grad=True)
+        with torch.enable_grad():
+            o = F.conv2d(xi, wz, stride=(SH, SW), padding=(PH, PW))
+        (gw,) = torch.autograd.grad(o, wz, dy)
+        if rowscale is not None:
+            gw = gw * rowscale.view(-1, 1, 1, 1)
+        y += gw.permute(0, 2, 3, 1).reshape(y.shape)
+
+
+def _heads(t, bs, rs, B, S, H, dh):
+    return _sv(t, (B, H, S, dh), (bs, dh, rs, 1)).float()
+
+
+def _attn_core(q, k, v, scale, kpm, causal):
+    s = q @ k.transpose(-1, -2) * scale
+    if kpm is not None:
+        s = s.masked_fill(kpm.bool()[:, None, None, :], float('-inf'))
+    if causal:
+        Sq, Sk = s.shape[-2:]
+        s = s.masked_fill(torch.ones(Sq, Sk, dtype=torch.bool).triu(1), float('-inf'))
+    return s.softmax(-1) @ v, torch.logsumexp(s, -1)
+
+
+def attention_fwd(q, k, v, o, strides, B, H, Sq, Sk, dh, scale, kpm=None, causal=False, drop_p=0.0, seed=0, lse=None):
+    assert drop_p == 0.0
+    (qb, qr), (kb, kr), (vb, vr), (ob, orr) = strides
+    out, l = _attn_core(_heads(q, qb, qr, B, Sq, H, dh), _heads(k, kb, kr, B, Sk, H, dh), _heads(v, vb, vr, B, Sk, H, dh),
+                        scale, kpm, causal)
+    _sv(o, (B, H, Sq, dh), (ob, dh, orr, 1)).copy_(out.to(o.dtype))
+    if lse is not None:
+        lse.copy_(l)
+
+
+def attention_bwd(q, k, v, o, dout, dq, dk, dv, strides, do_strides, B, H, Sq, Sk, dh, scale, kpm=None, causal=False,
+                  drop_p=0.0, seed=0, lse=None):
+    assert drop_p == 0.0
+    (qb, qr), (kb, kr), (vb, vr), _ = strides
+    qq = _heads(q, qb, qr, B, Sq, H, dh).requires_grad_(True)
+    kk = _heads(k, kb, kr, B, Sk, H, dh).requires_grad_(True)
+    vv = _heads(v, vb, vr, B, Sk, H, dh).requires_grad_(True)
+    with torch.enable_grad():
+        out, _ = _attn_core(qq, kk, vv, scale, kpm, causal)
+    g = _heads(dout, do_strides[0], do_strides[1], B, Sq, H, dh)
+    gq, gk, gv = torch.autograd.grad(out, (qq, kk, vv), g)
+    _sv(dq, (B, H, Sq, dh), (qb, dh, qr, 1)).copy_(gq.to(dq.dtype))
+    _sv(dk, (B, H, Sk, dh), (kb, dh, kr, 1)).copy_(gk.to(dk.dtype))
+    _sv(dv, (B, H, Sk, dh), (vb, dh, vr, 1)).copy_(gv.to(dv.dtype))
+
+
+def layernorm_fwd(x, s, gamma, beta, y, mean, rstd, rows, cols, eps, drop_p=0.0, seed=0):
+    assert drop_p == 0.0
+    z = x.float().reshape(rows, cols) + (0 if s is None else s.float().reshape(rows, cols))
+    mu = z.mean(-1)
+    var = ((z - mu[:, None]) ** 2).mean(-1)
+    rs = (var + eps).rsqrt()
+    n = (z - mu[:, None]) * rs[:, None]
+    if gamma is not None:
+        n = n * gamma + beta
+    y.reshape(rows, cols).copy_(n.to(y.dtype))
+    mean.copy_(mu)
+    rstd.copy_(rs)
+
+
+def layernorm_bwd(dy, x, s, gamma, mean, rstd, dx, ds, dgamma, dbeta, rows, cols, drop_p=0.0, seed=0):
+    assert drop_p == 0.0
+    z = x.float().reshape(rows, cols) + (0 if s is None else s.float().reshape(rows, cols))
+    zh = (z - mean[:, None]) * rstd[:, None]
+    g = dy.float().reshape(rows, cols)
+    gy = g * (gamma if gamma is not None else 1.0)
+    dz = rstd[:, None] * (gy - gy.mean(-1, keepdim=True) - zh * (gy * zh).mean(-1, keepdim=True))
+    dx.reshape(rows, cols).copy_(dz.to(dx.dtype))
+    if dgamma is not None:
+        dgamma += (g * zh).sum(0)
+        dbeta += g.sum(0)
+
+
+def softmax_ce(logits, ld, target, loss, dlogits, gscale, rows, V):
+    lg = _sv(logits, (rows, V), (ld, 1)).float()
+    valid = (target >= 0) & (target < V)
+    t = target.clamp(0, V - 1)
+    lp = F.log_softmax(lg, -1)
+    loss.copy_(torch.where(valid, -lp.gather(1, t[:, None])[:, 0], torch.zeros(rows)))
+    if dlogits is not None:
+        gs = (gscale if gscale is not None else torch.ones(rows)) * valid
+        d = (lp.exp() - F.one_hot(t, V).float()) * gs[:, None]
+        _sv(dlogits, (rows, V), (ld, 1)).copy_(d.to(dlogits.dtype))
+
+
+def image_to_nhwc4(img, out, B, H, W, pad, Hp, Wp):
+    out.zero_()
+    out[:, pad:pad + H, pad:pad + W, :3] = img.permute(0, 2, 3, 1).to(out.dtype)
+
+
+def maxpool3x3s2(x, y, B, H, W, Cc, OH, OW):
+    y.copy_(F.max_pool2d(x.float().permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1).to(y.dtype))
+
+
+def roi_weights(boxes, wgt, n_roi, H, W, ldw):
+    from oracle import gpv_oracle as O
+    x1 = W * (boxes[:, 0] - 0.5 * boxes[:, 2]) - 0.5
+    x2 = W * (boxes[:, 0] + 0.5 * boxes[:, 2]) - 0.5
+    y1 = H * (boxes[:, 1] - 0.5 * boxes[:, 3]) - 0.5
+    y2 = H * (boxes[:, 1] + 0.5 * boxes[:, 3]) - 0.5
+    ay = O.roi_axis_weights(y1, y2 - y1, H)
+    ax = O.roi_axis_weights(x1, x2 - x1, W)
+    wgt.zero_()
+    wgt[:, :H * W] = (ay[:, :, None] * ax[:, None, :]).reshape(n_roi, H * W).to(wgt.dtype)
+
+
+def add(a, b, y, n):
+    y.copy_((a.float() + b.float()).to(y.dtype))
+
+
+def add_rowbcast(a, b, y, rows_total, rows_b, cols):
+    rep = rows_total // rows_b
+    y.reshape(rep, rows_b * cols).copy_((a.float().reshape(rep, rows_b * cols) + b.float().reshape(1, rows_b * cols)).to(y.dtype))
+
+
+def colsum(x, out, rows, cols, ld):
+    out += _sv(x, (rows, cols), (ld, 1)).float().sum(0)
+
+
+def cast(src, dst, n):
+    dst.reshape(-1).copy_(src.reshape(-1).to(dst.dtype))
+
+
+def cast_rowscale_t(src, scale, dst, dstT, rows, cols):
+    v = src.reshape(rows, cols) * (scale[:, None] if scale is not None else 1.0)
+    if dst is not None:
+        dst.copy_(v.to(dst.dtype))
+    if dstT is not None:
+        dstT.copy_(v.t().to(dstT.dtype))
+
+
+def prep_conv_weight(src, scale, wf, wd, Cout, T, Cin):
+    v = src.reshape(Cout, T, Cin) * (scale[:, None, None] if scale is not None else 1.0)
+    if wf is not None:
+        wf.copy_(v.to(wf.dtype))
+    if wd is not None:
+        wd.copy_(v.permute(2, 1, 0).to(wd.dtype))
+
+
+def embedding(table, ids, out, n_ids, dim):
+    out.copy_(table[ids.reshape(-1)].to(out.dtype))
+
+
+def dropout(x, y, n, p, seed):
+    raise NotImplementedError('cpu shim: dropout unsupported')
+
+
+def relevance_condition(x, logits, tokens, y, rows, dim):
+    y.copy_((x.float() + logits.softmax(-1) @ tokens).to(y.dtype))
+
+
+def adamw(p, g, m, v, p_lowp, n, lr, beta1, beta2, eps, wd, bc1, bc2, gscale=None):
+    gi = g * (gscale if gscale is not None else 1.0)
+    p.mul_(1 - lr * wd)
+    m.mul_(beta1).add_(gi, alpha=1 - beta1)
+    v.mul_(beta2).addcmul_(gi, gi, value=1 - beta2)
+    p.addcdiv_(m, v.sqrt() / math.sqrt(bc2) + eps, value=-lr / bc1)
+    if p_lowp is not None:
+        p_lowp.copy_(p.to(p_lowp.dtype))
+
+
+def sumsq(x, n, out):
+    out += (x * x).sum()
+
+
+def act_fwd(x, y, n, act):
+    y.copy_(_act(x.float(), act).to(y.dtype))
+
+
+def act_bwd(dy, ref, dx, n, act, alpha=1.0):
+    g, r = dy.float(), ref.float()
+    if act == 1:
+        out = torch.where(r > 0, g * alpha, torch.zeros_like(g))
+    else:
+        cdf = 0.5 * (1 + torch.erf(r / math.sqrt(2.0)))
+        pdf = torch.exp(-0.5 * r * r) / math.sqrt(2 * math.pi)
+        out = g * (cdf + r * pdf) * alpha
+    dx.copy_(out.to(dx.dtype))
+
+
+def install():
+    """monkeypatch gpv1_amd.hip with the emulations above; returns an uninstall callable"""
+    import gpv1_amd.hip as h
+    names = ['gemm', 'conv2d', 'attention_fwd', 'attention_bwd', 'layernorm_fwd', 'layernorm_bwd', 'softmax_ce',
+             'image_to_nhwc4', 'maxpool3x3s2', 'roi_weights', 'add', 'add_rowbcast', 'colsum', 'cast', 'cast_rowscale_t',
+             'prep_conv_weight', 'embedding', 'dropout', 'relevance_condition', 'adamw', 'sumsq', 'act_fwd', 'act_bwd']
+    saved = {n: getattr(h, n) for n in names}
+    for n in names:
+        setattr(h, n, globals()[n])
+
+    def undo():
+        for n, f in saved.items():
+            setattr(h, n, f)
+    return undo

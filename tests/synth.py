@@ -102,9 +102,10 @@ def synth_tensor(name, shape, dtype=torch.float32):
         return 0.02 * torch.randn(shape, generator=g)
     if name == 'pos_enc':
         return None                                   # deterministic buffer, kept from the model
-    if 'embed' in name.lower() and len(shape) == 2:
-        return 0.1 * torch.randn(shape, generator=g) if 'vocab_embed' in name or 'embedding_layer' in name \
-            else 0.5 * torch.randn(shape, generator=g)
+    if len(shape) == 2 and ('vocab_embed' in name or 'embedding_layer' in name):
+        return 0.1 * torch.randn(shape, generator=g)
+    if len(shape) == 2 and ('embeddings.' in name or 'query_embed' in name):      # lookup tables (BERT, object queries)
+        return 0.5 * torch.randn(shape, generator=g)
     if name == 'relevance_tokens':
         return 0.1 * torch.randn(shape, generator=g)
     fan_in = 1
