@@ -1,0 +1,231 @@
+"""bench.py -- GPV-1 train-step throughput on MI355X (BASELINE.json metric: images/sec/node, train
+step, 480x640, bs32/GPU; workload = configs[1]: CocoCaptioning-only train step, bf16, one rank per GPU).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]        (N>1: launched by torch.distributed.run)
+
+A "step" is one full iteration of the reference hot loop (exp/gpv/train_distr.py:399-428):
+encode_answers -> GPV.forward (ResNet-50 -> DETR 6+6 -> RoI head -> BERT -> co-attention x3 -> text
+decoder x3 -> vocabulary logits V=10000 -> caption CE) -> backward -> gradient all-reduce (N>1) ->
+clip_grad_norm_(DETR, 0.1) -> AdamW.  Dropout 0.1 is ON (train mode).  Synthetic data (seeded),
+random-init weights; inputs are resident in HBM before the timed region.
+
+Prints ONE JSON line (rank 0) with the contract fields + "roofline" (dominant kernel: the implicit-GEMM
+convolution of the backbone, timed live with HIP events on the launch stream inside the timed region)
++ "cpu_baseline" (the CPU oracle's forward+backward on this host, bounded sample, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+V = 10000
+BATCH = 32
+IMG = (480, 640)
+TL = 6
+CAP_WORDS = 18           # + __cls__ + __stop__ = 20 tokens = max_text_len
+
+
+def make_cfg():
+    from tests import synth
+    g = torch.Generator().manual_seed(0)
+    return synth.model_cfg(vocab=synth.make_vocab(V), vocab_embed=0.1 * torch.randn(V, 768, generator=g))
+
+
+def make_batch(rank, B, dev):
+    g = torch.Generator().manual_seed(1234 + rank)
+    images = torch.randn(B, 3, *IMG, generator=g).to(dev)
+    mask = torch.zeros(B, *IMG, dtype=torch.bool, device=dev)
+    ids = torch.randint(1000, 30000, (B, TL), generator=g).to(dev)
+    attn = torch.ones(B, TL, dtype=torch.long, device=dev)
+    words = torch.randint(0, V - 4, (B, CAP_WORDS), generator=g)
+    targets = [{'task': 'CocoCaptioning', 'answer': ' '.join(f'w{int(w)}' for w in row)} for row in words]
+    return images, mask, ids, attn, targets
+
+
+def conv_algorithmic(model, B):
+    """algorithmic bytes / flops of the backbone convolutions for one step (fwd, and bwd of the
+    trainable layers), bf16 activations+weights, fp32 weight gradients -- DESIGN.md 'roofline'."""
+    H, W = IMG
+    body = model.detr.backbone[0].body
+    oh, ow = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+    fb = B * (H + 6) * (W + 8) * 4 * 2 + B * oh * ow * 64 * 2 + 64 * 7 * 32 * 2
+    ff = 2.0 * B * oh * ow * 64 * 7 * 32
+    n_f, n_b = 1, 0
+    bb = bf = 0.0
+    h, w = (oh + 2 - 3) // 2 + 1, (ow + 2 - 3) // 2 + 1
+    seen = False
+    for blk in body.blocks():
+        tr = blk.trainable()
+        hin, win = h, w
+        for conv, _ in blk.convs():
+            ih, iw = (hin, win) if conv is not blk.conv3 else (h, w)
+            if conv is blk.conv1 or (blk.downsample is not None and conv is blk.downsample[0]):
+                ih, iw = hin, win
+            o_h, o_w = (ih + 2 * conv.pad - conv.k) // conv.stride + 1, (iw + 2 * conv.pad - conv.k) // conv.stride + 1
+            x_b, y_b = B * ih * iw * conv.cin * 2, B * o_h * o_w * conv.cout * 2
+            w_b = conv.cout * conv.k * conv.k * conv.cin * 2
+            fl = 2.0 * B * o_h * o_w * conv.cout * conv.k * conv.k * conv.cin
+            fb += x_b + y_b + w_b
+            ff += fl
+            n_f += 1
+            if tr:
+                bb += x_b + y_b + 2 * w_b                      # wgrad: read x, dy ; write dW (fp32)
+                bf += fl
+                n_b += 1
+                needs_dx = not (conv is blk.conv1 or (blk.downsample is not None and conv is blk.downsample[0])) or seen
+                if needs_dx:
+                    bb += x_b + y_b + w_b                      # dgrad: read dy, W ; write dx
+                    bf += fl
+                    n_b += 1
+            if conv is blk.conv2:
+                h, w = o_h, o_w
+        if tr:
+            seen = True
+    return {'fwd_bytes': fb, 'fwd_flops': ff, 'bwd_bytes': bb, 'bwd_flops': bf, 'fwd_launches': n_f, 'bwd_launches': n_b}
+
+
+def cpu_baseline(model, seconds_budget=25.0):
+    """CPU oracle (oracle/gpv_oracle.py, the pinned restatement of the reference) forward+loss+backward
+    on the host cores, B=2 at full size -- a reported baseline, not the target."""
+    from oracle import gpv_oracle as O
+    from tests import synth
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    Bc = 2
+    cfg = make_cfg()
+    cfg['_cls_id'] = V - 3
+    Pm = {k: v.detach().float().cpu().contiguous() for k, v in model.state_dict().items()}
+    images, mask, ids, attn, targets = make_batch(0, Bc, 'cpu')
+    w2i = {w: i for i, w in enumerate(cfg['vocab'])}
+    _, tok = O.encode_answers(targets, w2i, cfg['max_text_len'])
+    for i, t in enumerate(targets):
+        t['answer_token_ids'] = tok[i, 1:]
+    train_keys = [n for n, p in model.named_parameters() if p.requires_grad and not n.startswith('bert.')]
+    times = []
+    t_start = time.time()
+    for it in range(4):
+        leaves = {k: Pm[k].clone().requires_grad_(True) for k in train_keys}
+        Pg = dict(Pm)
+        Pg.update(leaves)
+        t0 = time.time()
+        out = O.gpv_forward(Pg, cfg, images, mask, ids, attn, tok, training=True)
+        loss, _ = O.gpv_criterion(out, targets, cfg['losses'])
+        loss.backward()
+        times.append(time.time() - t0)
+        if time.time() - t_start > seconds_budget:
+            break
+    t = sorted(times[1:] or times)[len(times[1:] or times) // 2]
+    return {'value': Bc / t, 'unit': 'images/sec', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': f'oracle fwd+loss+bwd (no optimizer), B={Bc}, 480x640, V={V}, fp32, median of {len(times[1:] or times)} after 1 warm-up'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=BATCH)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+    rank = int(os.environ.get('RANK', 0))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    torch.cuda.set_device(local)
+    dev = f'cuda:{local}'
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29511')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device(dev))
+
+    import gpv1_amd.hip as hip
+    import gpv1_amd.backbone as bbm
+    from gpv1_amd.gpv import GPV
+    from gpv1_amd.misc import NestedTensor
+    from gpv1_amd.train import FlatTrainer
+    from gpv1_amd.ops import RT
+    hip.lib()
+    torch.manual_seed(0)
+    model = GPV(make_cfg())
+    for n, buf in model.named_buffers():
+        if n.endswith('running_var'):
+            buf.uniform_(0.5, 1.5)
+    model.to(dev)
+    RT.manual_seed(1000 + rank)
+    total_steps = 1000
+    tr = FlatTrainer(model, lr=1e-4, lr_backbone=1e-5, weight_decay=1e-4, clip_max_norm=0.1,
+                     warmup_steps=int(0.1 * total_steps), t_total=total_steps)
+    images, mask, ids, attn, targets = make_batch(rank, args.batch, dev)
+    samples = NestedTensor(images, mask)
+
+    def step():
+        tg = [dict(t) for t in targets]
+        return tr.train_step(samples, (ids, attn), tg)
+
+    for _ in range(args.warmup):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    bbm.PROF = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    prof, bbm.PROF = bbm.PROF, None
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    # ---- roofline of the dominant kernel (implicit-GEMM conv, backbone fwd+bwd), live HIP events ----
+    alg = conv_algorithmic(model, args.batch)
+    ms = {'conv_fwd': 0.0, 'conv_bwd': 0.0}
+    for tag, a, b in prof:
+        ms[tag] += a.elapsed_time(b)
+    conv_ms = (ms['conv_fwd'] + ms['conv_bwd']) / args.steps
+    launches = alg['fwd_launches'] + alg['bwd_launches']
+    bytes_step = alg['fwd_bytes'] + alg['bwd_bytes']
+    flops_step = alg['fwd_flops'] + alg['bwd_flops']
+    ach_gbs = bytes_step / (conv_ms * 1e-3) / 1e9
+    roof = {'bound': 'hbm', 'achieved': ach_gbs, 'peak': 8000.0, 'unit': 'GB/s', 'frac': ach_gbs / 8000.0, 'traffic': None,
+            'kernel': 'gemm_kernel<OP_CONV> (NHWC implicit-GEMM conv fwd/dgrad/wgrad, ResNet-50 body)',
+            'launches_per_step': launches, 'avg_launch_us': conv_ms * 1e3 / launches,
+            'algorithmic_bytes_per_launch': bytes_step / launches,
+            'fwd_ms': ms['conv_fwd'] / args.steps, 'bwd_ms': ms['conv_bwd'] / args.steps,
+            'mfma_tflops': flops_step / (conv_ms * 1e-3) / 1e12, 'mfma_frac_of_2500': flops_step / (conv_ms * 1e-3) / 2.5e15}
+    out = {'metric': 'images/sec/node (train step, 480x640, bs32/GPU)', 'value': world * args.batch * args.steps / elapsed,
+           'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+           'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+           'dtype': 'bf16', 'data': 'synthetic',
+           'config': {'workload': 'GPV-1 (ResNet-50 + 6+6 DETR layers, 100 queries, RoI head, BERT-base, 3 co-attention, '
+                                  '3 text-decoder layers, V=10000) CocoCaptioning-only train step, dropout 0.1, AdamW',
+                      'global_batch': world * args.batch, 'image': '480x640', 'caption_tokens': 20,
+                      'parallelism': f'dp{world}', 'final_loss': float(loss)},
+           'roofline': roof}
+    if world == 1 and not args.no_cpu_baseline:
+        try:
+            out['cpu_baseline'] = cpu_baseline(model)
+        except Exception as e:                                     # the baseline must never sink the bench line
+            out['cpu_baseline'] = {'value': None, 'unit': 'images/sec', 'cores': os.cpu_count(), 'kind': 'port', 'sample': f'failed: {e}'}
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
