@@ -96,7 +96,8 @@ def cpu_baseline(model, seconds_budget=25.0):
     on the host cores, B=2 at full size -- a reported baseline, not the target."""
     from oracle import gpv_oracle as O
     from tests import synth
-    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    # 256 OpenMP threads on ~1e4 small ops is far slower than 32 (barrier cost): use min(cores, 32) and say so
+    torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
     Bc = 2
     cfg = make_cfg()
     cfg['_cls_id'] = V - 3
@@ -109,7 +110,7 @@ def cpu_baseline(model, seconds_budget=25.0):
     train_keys = [n for n, p in model.named_parameters() if p.requires_grad and not n.startswith('bert.')]
     times = []
     t_start = time.time()
-    for it in range(4):
+    for it in range(3):
         leaves = {k: Pm[k].clone().requires_grad_(True) for k in train_keys}
         Pg = dict(Pm)
         Pg.update(leaves)
