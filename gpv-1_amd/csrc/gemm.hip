@@ -90,17 +90,31 @@ template <> struct Raw8<float> {
   }
 };
 
+// masking helpers (branch-free: select after an unconditional load from a safe address)
+template <typename T> __device__ __forceinline__ void mask_raw(Raw8<T>& r, bool ok);
+template <> __device__ __forceinline__ void mask_raw<bf16>(Raw8<bf16>& r, bool ok) {
+  const uint32_t m = ok ? 0xffffffffu : 0u;
+  r.w[0] &= m; r.w[1] &= m; r.w[2] &= m; r.w[3] &= m;
+}
+template <> __device__ __forceinline__ void mask_raw<float>(Raw8<float>& r, bool ok) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r.v[i] = ok ? r.v[i] : 0.0f;
+}
+
 // ---- K-contiguous operand (PLAIN or CONV gather): tile [ROWS][32] -------------------------
-template <typename T, int ROWS, int MODE>
+template <typename T, int ROWS, int MODE, bool VEC>
 struct KStage {
   static constexpr int NIT = ROWS / 64;
   Raw8<T> raw[NIT];
   const T* base[NIT];
+  const T* safe;
   int oh[NIT], ow[NIT];
   bool rowok[NIT];
+  bool okf[NIT];
 
-  __device__ __forceinline__ void init(const T* ptr, int64_t ld, int row0, int nrows, const ConvGeom& g) {
+  __device__ __forceinline__ void init(const T* ptr, int64_t ld, int row0, int nrows, int k_begin, const ConvGeom& g) {
     const int tid = threadIdx.x;
+    safe = ptr;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       int row = (tid + it * 256) >> 2;
@@ -114,12 +128,12 @@ struct KStage {
         ow[it] = rem - oh[it] * g.OW;
         base[it] = ptr + (int64_t)b * g.IH * g.IW * g.Cs;
       } else {
-        base[it] = ptr + (int64_t)r * ld;
+        base[it] = ptr + (int64_t)(rowok[it] ? r : 0) * ld;
         oh[it] = ow[it] = 0;
       }
     }
   }
-  __device__ __forceinline__ void load(int k0, int K, bool vec, const ConvGeom& g) {
+  __device__ __forceinline__ void load(int k0, int K, const ConvGeom& g) {
     const int tid = threadIdx.x;
     int tr = 0, ts = 0, c0 = k0;
     if (MODE == OP_CONV) {
@@ -136,42 +150,52 @@ struct KStage {
       const T* p;
       if (MODE == OP_CONV) {
         int ih, iw;
-        if (g.dgrad) {
+        if (g.dgrad) {                       // strides are 1 or 2 (checked on the host)
           int th = oh[it] + g.PH - tr, tw = ow[it] + g.PW - ts;
-          ih = th / g.SH; iw = tw / g.SW;
-          ok = ok && th >= 0 && tw >= 0 && (ih * g.SH == th) && (iw * g.SW == tw) && ih < g.IH && iw < g.IW;
+          int sh = g.SH - 1, sw = g.SW - 1;  // shift amount == mask for stride in {1,2}
+          ih = th >> sh; iw = tw >> sw;
+          ok = ok && th >= 0 && tw >= 0 && ((th & sh) == 0) && ((tw & sw) == 0) && ih < g.IH && iw < g.IW;
         } else {
           ih = oh[it] * g.SH + tr - g.PH; iw = ow[it] * g.SW + ts - g.PW;
           ok = ok && ih >= 0 && iw >= 0 && ih < g.IH && iw < g.IW;
         }
-        p = base[it] + ((int64_t)ih * g.IW + iw) * g.Cs + c0 + slot * 8;
+        p = base[it] + ((int64_t)(ih * g.IW + iw)) * g.Cs + c0 + slot * 8;
       } else {
         p = base[it] + k;
       }
-      if (!ok) raw[it].zero();
-      else if (vec) raw[it].load(p);
-      else raw[it].load_n(p, K - k);
+      if (VEC) {
+        // unconditional 16-B load (from a safe address when masked); the zero-select is applied in
+        // store(), AFTER the MFMAs of the current tile, so the load latency overlaps the math
+        raw[it].load(ok ? p : safe);
+        okf[it] = ok;
+      } else {
+        if (!ok) raw[it].zero();
+        else raw[it].load_n(p, K - k);
+      }
     }
   }
-  __device__ __forceinline__ void store(bf16* hi, bf16* lo) const {
+  __device__ __forceinline__ void store(bf16* hi, bf16* lo, bool) {
     const int tid = threadIdx.x;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       int i = tid + it * 256;
       int off = (i >> 2) * LDK + (i & 3) * 8;
+      if (VEC) mask_raw<T>(raw[it], okf[it]);
       raw[it].write(hi + off, lo + off);
     }
   }
 };
 
 // ---- reduction-major operand (TRANS, or CONVT gather): memory tile [32 red][COLS], transposed --
-template <typename T, int COLS, int MODE>
+template <typename T, int COLS, int MODE, bool VEC>
 struct TStage {
   Raw8<T> raw[2];
   const T* ptr; int64_t ld; int col0, ncols;
   int tap_r, tap_s, c0;
+  bool okf[2];
+  int pb[2], poh[2], pow_[2];      // CONVT: (batch, oh, ow) of this thread's two reduction rows, advanced per k-tile
 
-  __device__ __forceinline__ void init(const T* p, int64_t ld_, int col0_, int ncols_, const ConvGeom& g) {
+  __device__ __forceinline__ void init(const T* p, int64_t ld_, int col0_, int ncols_, int k_begin, const ConvGeom& g) {
     ptr = p; ld = ld_; col0 = col0_; ncols = ncols_;
     tap_r = tap_s = c0 = 0;
     if (MODE == OP_CONV) {
@@ -179,38 +203,51 @@ struct TStage {
       c0 = col0 - tap * g.Cin;
       tap_r = tap / g.KW;
       tap_s = tap - tap_r * g.KW;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        int k = k_begin + 2 * (threadIdx.x & 15) + j;
+        pb[j] = k / (g.OH * g.OW);
+        int rem = k - pb[j] * (g.OH * g.OW);
+        poh[j] = rem / g.OW;
+        pow_[j] = rem - poh[j] * g.OW;
+      }
     }
   }
-  __device__ __forceinline__ void load(int k0, int K, bool vec, const ConvGeom& g) {
+  __device__ __forceinline__ void load(int k0, int K, const ConvGeom& g) {
     const int tid = threadIdx.x;
     const int p = tid & 15, cgp = tid >> 4;
-    if (COLS == 64 && cgp >= 8) return;
+    const bool active = !(COLS == 64 && cgp >= 8);
     const int col = col0 + cgp * 8;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       int k = k0 + 2 * p + j;
-      bool ok = k < K && col < ncols;
+      bool ok = active && k < K && col < ncols;
       const T* src;
       if (MODE == OP_CONV) {
-        int kk = ok ? k : 0;
-        int b = kk / (g.OH * g.OW);
-        int rem = kk - b * (g.OH * g.OW);
-        int oh = rem / g.OW, ow = rem - oh * g.OW;
-        int ih = oh * g.SH + tap_r - g.PH, iw = ow * g.SW + tap_s - g.PW;
+        int ih = poh[j] * g.SH + tap_r - g.PH, iw = pow_[j] * g.SW + tap_s - g.PW;
         ok = ok && ih >= 0 && iw >= 0 && ih < g.IH && iw < g.IW;
-        src = ptr + (((int64_t)b * g.IH + ih) * g.IW + iw) * g.Cs + c0 + cgp * 8;
+        src = ptr + ((int64_t)((pb[j] * g.IH + ih) * g.IW + iw)) * g.Cs + c0 + cgp * 8;
+        // advance this row by BK pixels for the next k-tile
+        pow_[j] += BK;
+        while (pow_[j] >= g.OW) { pow_[j] -= g.OW; poh[j] += 1; }
+        while (poh[j] >= g.OH) { poh[j] -= g.OH; pb[j] += 1; }
       } else {
         src = ptr + (int64_t)k * ld + col;
       }
-      if (!ok) raw[j].zero();
-      else if (vec && col + 8 <= ncols) raw[j].load(src);
-      else raw[j].load_n(src, ncols - col);
+      if (VEC) {                                 // host guarantees ncols % 8 == 0 for the VEC variant
+        raw[j].load(ok ? src : ptr);
+        okf[j] = ok;
+      } else {
+        if (!ok) raw[j].zero();
+        else raw[j].load_n(src, ncols - col);
+      }
     }
   }
-  __device__ __forceinline__ void store(bf16* hi, bf16* lo, bool precise) const {
+  __device__ __forceinline__ void store(bf16* hi, bf16* lo, bool precise) {
     const int tid = threadIdx.x;
     const int p = tid & 15, cgp = tid >> 4;
     if (COLS == 64 && cgp >= 8) return;
+    if (VEC) { mask_raw<T>(raw[0], okf[0]); mask_raw<T>(raw[1], okf[1]); }
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       int off = (cgp * 8 + c) * LDK + 2 * p;
@@ -220,9 +257,17 @@ struct TStage {
   }
 };
 
-template <typename T, int ROWS, int MODE> struct StageSel { typedef KStage<T, ROWS, MODE> type; };
+template <typename T> struct Vec8IO;
+template <> struct Vec8IO<bf16> {
+  static __device__ __forceinline__ void ld(const bf16* p, float* o) { Ld8<bf16>::ld(p, o); }
+  static __device__ __forceinline__ void st(bf16* p, const float* o) { Ld8<bf16>::st(p, o); }
+};
+template <> struct Vec8IO<float> {
+  static __device__ __forceinline__ void ld(const float* p, float* o) { Ld8<float>::ld(p, o); }
+  static __device__ __forceinline__ void st(float* p, const float* o) { Ld8<float>::st(p, o); }
+};
 
-template <typename TIn, typename TOut, int AMODE, int BMODE, int BM, int BN>
+template <typename TIn, typename TOut, int AMODE, int BMODE, int BM, int BN, bool VEC>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmK p) {
   constexpr bool PRECISE = sizeof(TIn) == 4;
   constexpr int FM = BM / 32, FN = BN / 32;
@@ -246,12 +291,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmK p) {
   const TIn* Ap = reinterpret_cast<const TIn*>(p.A) + (int64_t)batch * p.sA;
   const TIn* Bp = reinterpret_cast<const TIn*>(p.B) + (int64_t)batch * p.sB;
 
-  typedef typename std::conditional<AMODE == OP_TRANS, TStage<TIn, BM, OP_PLAIN>, KStage<TIn, BM, AMODE>>::type AStage;
-  typedef typename std::conditional<BMODE == OP_PLAIN, KStage<TIn, BN, OP_PLAIN>,
-                                    TStage<TIn, BN, (BMODE == OP_CONV ? OP_CONV : OP_PLAIN)>>::type BStage;
+  typedef typename std::conditional<AMODE == OP_TRANS, TStage<TIn, BM, OP_PLAIN, VEC>, KStage<TIn, BM, AMODE, VEC>>::type AStage;
+  typedef typename std::conditional<BMODE == OP_PLAIN, KStage<TIn, BN, OP_PLAIN, VEC>,
+                                    TStage<TIn, BN, (BMODE == OP_CONV ? OP_CONV : OP_PLAIN), VEC>>::type BStage;
   AStage as; BStage bs;
-  if constexpr (AMODE == OP_TRANS) as.init(Ap, p.lda, row0, p.M, p.cg); else as.init(Ap, p.lda, row0, p.M, p.cg);
-  if constexpr (BMODE == OP_PLAIN) bs.init(Bp, p.ldb, col0, p.N, p.cg); else bs.init(Bp, p.ldb, col0, p.N, p.cg);
+  as.init(Ap, p.lda, row0, p.M, kt0 * BK, p.cg);
+  bs.init(Bp, p.ldb, col0, p.N, kt0 * BK, p.cg);
 
   auto stage_ptr = [&](int s, int which) -> bf16* {  // which: 0 Ahi 1 Alo 2 Bhi 3 Blo
     bf16* b = smem + s * STAGE_ELEMS;
@@ -261,8 +306,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmK p) {
     return which < 2 ? b : b + A_ELEMS;
   };
   auto do_store = [&](int s) {
-    if constexpr (AMODE == OP_TRANS) as.store(stage_ptr(s, 0), stage_ptr(s, 1), PRECISE); else as.store(stage_ptr(s, 0), stage_ptr(s, 1));
-    if constexpr (BMODE == OP_PLAIN) bs.store(stage_ptr(s, 2), stage_ptr(s, 3)); else bs.store(stage_ptr(s, 2), stage_ptr(s, 3), PRECISE);
+    as.store(stage_ptr(s, 0), stage_ptr(s, 1), PRECISE);
+    bs.store(stage_ptr(s, 2), stage_ptr(s, 3), PRECISE);
   };
 
   f32x4 acc[FM][FN];
@@ -271,8 +316,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmK p) {
 #pragma unroll
     for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  as.load(kt0 * BK, p.K, p.vecA, p.cg);
-  bs.load(kt0 * BK, p.K, p.vecB, p.cg);
+  as.load(kt0 * BK, p.K, p.cg);
+  bs.load(kt0 * BK, p.K, p.cg);
   do_store(0);
   __syncthreads();
 
@@ -282,8 +327,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmK p) {
   for (int kt = kt0; kt < kt1; ++kt) {
     const bool more = kt + 1 < kt1;
     if (more) {
-      as.load((kt + 1) * BK, p.K, p.vecA, p.cg);
-      bs.load((kt + 1) * BK, p.K, p.vecB, p.cg);
+      as.load((kt + 1) * BK, p.K, p.cg);
+      bs.load((kt + 1) * BK, p.K, p.cg);
     }
     const bf16* Ah = stage_ptr(cur, 0) + a_off;
     const bf16* Bh = stage_ptr(cur, 2) + b_off;
@@ -317,63 +362,114 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmK p) {
     cur ^= 1;
   }
 
-  // ---------------- epilogue: lane holds C[m][n..n+3] ----------------
   TOut* Cp = reinterpret_cast<TOut*>(p.C) + (int64_t)batch * p.sC;
   const TOut* Rp = p.res ? reinterpret_cast<const TOut*>(p.res) + (int64_t)batch * p.sR : nullptr;
   const TOut* Mp = reinterpret_cast<const TOut*>(p.mask);
-  const bool vec_store = (p.ldc % 4 == 0) && !(p.accumulate);
+
+  if (p.accumulate) {
+    // ---------------- split-K / accumulate epilogue: fp32 atomics straight from the fragments ----------------
+    if constexpr (sizeof(TOut) == 4) {
 #pragma unroll
-  for (int i = 0; i < FM; ++i) {
-    const int m = row0 + wm * (BM / 2) + i * 16 + (lane & 15);
-    if (m >= p.M) continue;
-    const float rs = p.rowscale ? p.rowscale[m] * p.alpha : p.alpha;
+      for (int i = 0; i < FM; ++i) {
+        const int m = row0 + wm * (BM / 2) + i * 16 + (lane & 15);
+        if (m >= p.M) continue;
+        const float rs = p.rowscale ? p.rowscale[m] * p.alpha : p.alpha;
 #pragma unroll
-    for (int j = 0; j < FN; ++j) {
-      const int n = col0 + wn * (BN / 2) + j * 16 + (lane >> 4) * 4;
-      if (n >= p.N) continue;
-      float v[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float x = acc[i][j][r] * rs;
-        const int nn = n + r;
-        if (nn < p.N) {
-          if (p.bias) x += p.bias[nn];
-          if (Rp) x += (float)Rp[(int64_t)m * p.ldr + nn];
-          if (p.act == GPV_ACT_RELU) x = fmaxf(x, 0.f);
-          else if (p.act == GPV_ACT_GELU) x = gelu_erf(x);
-          if (p.dthresh) {
-            uint64_t idx = ((uint64_t)batch * p.M + m) * (uint64_t)p.N + nn;
-            x = drop_keep(p.seed, idx, p.dthresh) ? x * p.dscale : 0.f;
-          }
-          if (Mp) x = ((float)Mp[(int64_t)m * p.ldm + nn] > 0.f) ? x : 0.f;
-        }
-        v[r] = x;
-      }
-      TOut* dst = Cp + (int64_t)m * p.ldc + n;
-      if (p.accumulate) {
-        if constexpr (sizeof(TOut) == 4) {
+        for (int j = 0; j < FN; ++j) {
+          const int n = col0 + wn * (BN / 2) + j * 16 + (lane >> 4) * 4;
+          float* dst = reinterpret_cast<float*>(Cp) + (int64_t)m * p.ldc + n;
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            if (n + r < p.N) atomicAdd(reinterpret_cast<float*>(dst) + r, v[r]);
+            if (n + r < p.N) atomicAdd(dst + r, acc[i][j][r] * rs);
         }
-      } else if (vec_store && n + 3 < p.N) {
-        if constexpr (sizeof(TOut) == 4) {
-          *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-        } else {
-          bf16x4 o; o[0] = (bf16)v[0]; o[1] = (bf16)v[1]; o[2] = (bf16)v[2]; o[3] = (bf16)v[3];
-          *reinterpret_cast<bf16x4*>(dst) = o;
-        }
-      } else {
+      }
+    }
+    return;
+  }
+
+  // ---------------- coalesced epilogue: fragments -> LDS (fp32, half a tile at a time) -> full rows ----------------
+  // (a lane holds 4 consecutive columns of 16 different rows; writing that straight to HBM gives 32-byte
+  //  row segments.  Through LDS every wave-store instruction covers whole 128/256-byte row runs.)
+  float* ep = reinterpret_cast<float*>(smem_raw);
+  constexpr int EPITCH = BN + 4;
+  constexpr int HR = BM / 2;
+  constexpr int CH = BN / 8;
+  constexpr int NCH = (HR * CH) / 256;
+  const bool v_st = (p.ldc % 8 == 0) && ((reinterpret_cast<uintptr_t>(Cp) & 15) == 0);
+  const bool v_res = Rp && (p.ldr % 8 == 0) && ((reinterpret_cast<uintptr_t>(Rp) & 15) == 0);
+  const bool v_msk = Mp && (p.ldm % 8 == 0) && ((reinterpret_cast<uintptr_t>(Mp) & 15) == 0);
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (n + r < p.N) dst[r] = (TOut)v[r];
+  for (int half = 0; half < 2; ++half) {
+    if (half == 1) __syncthreads();      // (the main loop ended with a barrier)
+    if (wm == half) {
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        const int ml = i * 16 + (lane & 15);
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+          const int nl = wn * (BN / 2) + j * 16 + (lane >> 4) * 4;
+          *reinterpret_cast<float4*>(ep + ml * EPITCH + nl) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int idx = tid + c * 256;
+      const int r = idx / CH, c8 = idx - r * CH;
+      const int m = row0 + half * HR + r;
+      const int n = col0 + c8 * 8;
+      if (m >= p.M || n >= p.N) continue;
+      float v[8];
+      {
+        const float4 a = *reinterpret_cast<const float4*>(ep + r * EPITCH + c8 * 8);
+        const float4 b = *reinterpret_cast<const float4*>(ep + r * EPITCH + c8 * 8 + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+      }
+      const float rs = p.rowscale ? p.rowscale[m] * p.alpha : p.alpha;
+      const bool full = n + 8 <= p.N;
+      float rv[8], mv[8];
+      if (Rp) {
+        if (v_res && full) Vec8IO<TOut>::ld(Rp + (int64_t)m * p.ldr + n, rv);
+        else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) rv[e] = (n + e < p.N) ? (float)Rp[(int64_t)m * p.ldr + n + e] : 0.f;
+        }
+      }
+      if (Mp) {
+        if (v_msk && full) Vec8IO<TOut>::ld(Mp + (int64_t)m * p.ldm + n, mv);
+        else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) mv[e] = (n + e < p.N) ? (float)Mp[(int64_t)m * p.ldm + n + e] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float x = v[e] * rs;
+        if (p.bias && n + e < p.N) x += p.bias[n + e];
+        if (Rp) x += rv[e];
+        if (p.act == GPV_ACT_RELU) x = fmaxf(x, 0.f);
+        else if (p.act == GPV_ACT_GELU) x = gelu_erf(x);
+        if (p.dthresh) {
+          uint64_t di = ((uint64_t)batch * p.M + m) * (uint64_t)p.N + (n + e);
+          x = drop_keep(p.seed, di, p.dthresh) ? x * p.dscale : 0.f;
+        }
+        if (Mp) x = mv[e] > 0.f ? x : 0.f;
+        v[e] = x;
+      }
+      TOut* dst = Cp + (int64_t)m * p.ldc + n;
+      if (v_st && full) Vec8IO<TOut>::st(dst, v);
+      else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (n + e < p.N) dst[e] = (TOut)v[e];
       }
     }
   }
 }
 
-template <typename TIn, typename TOut, int AMODE, int BMODE, int BM, int BN>
-int launch_cfg(const GemmK& k, int batch, hipStream_t st) {
+template <typename TIn, typename TOut, int AMODE, int BMODE, int BM, int BN, bool VEC>
+int launch_cfg_v(const GemmK& k, int batch, hipStream_t st) {
   constexpr bool PRECISE = sizeof(TIn) == 4;
   constexpr size_t lds = (size_t)2 * (BM + BN) * LDK * 2 * (PRECISE ? 2 : 1);
   GemmK p = k;
@@ -384,7 +480,7 @@ int launch_cfg(const GemmK& k, int batch, hipStream_t st) {
   if (split > kt_total) split = kt_total;
   p.kt_per_split = (kt_total + split - 1) / split;
   split = (kt_total + p.kt_per_split - 1) / p.kt_per_split;
-  auto fn = gemm_kernel<TIn, TOut, AMODE, BMODE, BM, BN>;
+  auto fn = gemm_kernel<TIn, TOut, AMODE, BMODE, BM, BN, VEC>;
   static bool attr_done = false;
   if (lds > 64 * 1024 && !attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -395,6 +491,12 @@ int launch_cfg(const GemmK& k, int batch, hipStream_t st) {
   hipLaunchKernelGGL(fn, grid, dim3(256), lds, st, p);
   GPV_CHECK_LAUNCH();
   return 0;
+}
+
+template <typename TIn, typename TOut, int AMODE, int BMODE, int BM, int BN>
+int launch_cfg(const GemmK& k, int batch, hipStream_t st) {
+  if (k.vecA && k.vecB) return launch_cfg_v<TIn, TOut, AMODE, BMODE, BM, BN, true>(k, batch, st);
+  return launch_cfg_v<TIn, TOut, AMODE, BMODE, BM, BN, false>(k, batch, st);
 }
 
 template <typename TIn, typename TOut, int AMODE, int BMODE>
@@ -438,7 +540,7 @@ extern "C" int gpv_gemm(const gpv_gemm_args* a, void* stream) {
   auto vec_ok = [&](const void* ptr, int64_t ld, int64_t bs, int layout, int extent_contig) {
     bool ok = aligned16(ptr) && (ld % vecel == 0) && (a->batch == 1 || bs % vecel == 0);
     if (layout == GPV_KMAJOR) ok = ok && (a->K % 8 == 0);
-    else ok = ok && (extent_contig % 8 == 0 || true);  // partial column groups are handled per item
+    else ok = ok && (extent_contig % 8 == 0);
     return ok ? 1 : 0;
   };
   k.vecA = vec_ok(a->A, a->lda, a->sA, a->layoutA, a->M);
@@ -454,6 +556,7 @@ extern "C" int gpv_gemm(const gpv_gemm_args* a, void* stream) {
 extern "C" int gpv_conv2d(const gpv_conv_args* a, void* stream) {
   if (!a || !a->x || !a->w || !a->y) return (int)hipErrorInvalidValue;
   if (a->Cin % 32 != 0) return (int)hipErrorInvalidValue;
+  if ((a->SH != 1 && a->SH != 2) || (a->SW != 1 && a->SW != 2)) return (int)hipErrorInvalidValue;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   GemmK k{};
   k.alpha = 1.0f; k.rowscale = a->rowscale; k.bias = a->bias; k.act = a->act;
