@@ -361,10 +361,13 @@ __global__ __launch_bounds__(256) void attn_kv_kernel(AttnK p) {
           sa = mfma16(qh_, kh[kc], sa);
           dp = mfma16(dh_, vh[kc], dp);
           if (PRECISE) {
+            // SAME accumulation order as the forward / dQ kernels (hi*hi, Klo*Qhi, Khi*Qlo): the recomputed
+            // scores must be bit-identical to the forward's, otherwise exp(s - lse) drifts from the forward
+            // probabilities when |s| is large (ulp(s) ~ 0.1 at |s| ~ 1e6) and the (dP - delta) cancellation breaks.
             bf16x8 ql_ = *reinterpret_cast<const bf16x8*>(Ql + off);
             bf16x8 dl_ = *reinterpret_cast<const bf16x8*>(Dl + off);
-            sa = mfma16(ql_, kh[kc], sa); sa = mfma16(qh_, kl[kc], sa);
-            dp = mfma16(dl_, vh[kc], dp); dp = mfma16(dh_, vl[kc], dp);
+            sa = mfma16(qh_, kl[kc], sa); sa = mfma16(ql_, kh[kc], sa);
+            dp = mfma16(dh_, vl[kc], dp); dp = mfma16(dl_, vh[kc], dp);
           }
         }
         const int qr = qb * 32 + t * 16 + g * 4;   // local query row of element i = qr + i

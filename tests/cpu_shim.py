@@ -99,7 +99,7 @@ def conv2d(mode, x, w, y, B, IH, IW, Cs, Cin, OH, OW, Cout, KH, KW, SH, SW, PH, 
         # wgrad: x gathered fwd input, w = dy [B,OH,OW,Cout], y = dw [Cout][T][Cin] fp32 (+=)
         xi = xg.permute(0, 3, 1, 2).requires_grad_(False)
         dy = w.reshape(B, OH, OW, Cout).permute(0, 3, 1, 2).float()
-        wz = torch.zeros(Cout, Cin, KH, KW, requires_grad=True)
+        wz = torch.zeros(Cout, Cin, KH, KW, requires_grad=True, device=x.device)
         with torch.enable_grad():
             o = F.conv2d(xi, wz, stride=(SH, SW), padding=(PH, PW))
         (gw,) = torch.autograd.grad(o, wz, dy)
@@ -118,7 +118,7 @@ def _attn_core(q, k, v, scale, kpm, causal):
         s = s.masked_fill(kpm.bool()[:, None, None, :], float('-inf'))
     if causal:
         Sq, Sk = s.shape[-2:]
-        s = s.masked_fill(torch.ones(Sq, Sk, dtype=torch.bool).triu(1), float('-inf'))
+        s = s.masked_fill(torch.ones(Sq, Sk, dtype=torch.bool, device=s.device).triu(1), float('-inf'))
     return s.softmax(-1) @ v, torch.logsumexp(s, -1)
 
 
@@ -180,9 +180,9 @@ def softmax_ce(logits, ld, target, loss, dlogits, gscale, rows, V):
     valid = (target >= 0) & (target < V)
     t = target.clamp(0, V - 1)
     lp = F.log_softmax(lg, -1)
-    loss.copy_(torch.where(valid, -lp.gather(1, t[:, None])[:, 0], torch.zeros(rows)))
+    loss.copy_(torch.where(valid, -lp.gather(1, t[:, None])[:, 0], torch.zeros(rows, device=lg.device)))
     if dlogits is not None:
-        gs = (gscale if gscale is not None else torch.ones(rows)) * valid
+        gs = (gscale if gscale is not None else torch.ones(rows, device=lg.device)) * valid
         d = (lp.exp() - F.one_hot(t, V).float()) * gs[:, None]
         _sv(dlogits, (rows, V), (ld, 1)).copy_(d.to(dlogits.dtype))
 
@@ -202,8 +202,8 @@ def roi_weights(boxes, wgt, n_roi, H, W, ldw):
     x2 = W * (boxes[:, 0] + 0.5 * boxes[:, 2]) - 0.5
     y1 = H * (boxes[:, 1] - 0.5 * boxes[:, 3]) - 0.5
     y2 = H * (boxes[:, 1] + 0.5 * boxes[:, 3]) - 0.5
-    ay = O.roi_axis_weights(y1, y2 - y1, H)
-    ax = O.roi_axis_weights(x1, x2 - x1, W)
+    ay = O.roi_axis_weights(y1.cpu(), (y2 - y1).cpu(), H).to(wgt.device)
+    ax = O.roi_axis_weights(x1.cpu(), (x2 - x1).cpu(), W).to(wgt.device)
     wgt.zero_()
     wgt[:, :H * W] = (ay[:, :, None] * ax[:, None, :]).reshape(n_roi, H * W).to(wgt.dtype)
 
@@ -282,10 +282,11 @@ def act_bwd(dy, ref, dx, n, act, alpha=1.0):
     dx.copy_(out.to(dx.dtype))
 
 
-def install():
-    """monkeypatch gpv1_amd.hip with the emulations above; returns an uninstall callable"""
+def install(only=None):
+    """monkeypatch gpv1_amd.hip with the emulations above; returns an uninstall callable.
+    `only`: optional list of entry-point names (GPU bisecting: swap single kernels for torch math)."""
     import gpv1_amd.hip as h
-    names = ['gemm', 'conv2d', 'attention_fwd', 'attention_bwd', 'layernorm_fwd', 'layernorm_bwd', 'softmax_ce',
+    names = only or ['gemm', 'conv2d', 'attention_fwd', 'attention_bwd', 'layernorm_fwd', 'layernorm_bwd', 'softmax_ce',
              'image_to_nhwc4', 'maxpool3x3s2', 'roi_weights', 'add', 'add_rowbcast', 'colsum', 'cast', 'cast_rowscale_t',
              'prep_conv_weight', 'embedding', 'dropout', 'relevance_condition', 'adamw', 'sumsq', 'act_fwd', 'act_bwd']
     saved = {n: getattr(h, n) for n in names}

@@ -111,7 +111,10 @@ def synth_tensor(name, shape, dtype=torch.float32):
     fan_in = 1
     for s in shape[1:]:
         fan_in *= s
-    gain = 1.4 if ('conv' in name or 'downsample.0' in name) else 1.0
+    # He gain for the ReLU convs; the block-closing 1x1 (conv3) is damped so that the 16 residual adds do not
+    # blow the activations up (c5 stays O(1-10) like a trained, FrozenBN-normalised ResNet; with gain 1.4 everywhere
+    # c5 reached 1e4 and encoder attention scores 4e7, an ill-conditioned regime no real checkpoint is in)
+    gain = 0.35 if 'conv3' in name else (1.4 if ('conv' in name or 'downsample.0' in name) else 1.0)
     return gain * torch.randn(shape, generator=g) / fan_in ** 0.5
 
 
