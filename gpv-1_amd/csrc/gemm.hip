@@ -105,12 +105,11 @@ template <> __device__ __forceinline__ void mask_raw<float>(Raw8<float>& r, bool
 template <typename T, int ROWS, int MODE, bool VEC>
 struct KStage {
   static constexpr int NIT = ROWS / 64;
-  Raw8<T> raw[NIT];
+  struct Buf { Raw8<T> raw[NIT]; bool okf[NIT]; };
   const T* base[NIT];
   const T* safe;
   int oh[NIT], ow[NIT];
   bool rowok[NIT];
-  bool okf[NIT];
 
   __device__ __forceinline__ void init(const T* ptr, int64_t ld, int row0, int nrows, int k_begin, const ConvGeom& g) {
     const int tid = threadIdx.x;
@@ -133,7 +132,8 @@ struct KStage {
       }
     }
   }
-  __device__ __forceinline__ void load(int k0, int K, const ConvGeom& g) {
+  __device__ __forceinline__ void load(int k0, int K, const ConvGeom& g, Buf& bf) {
+    Raw8<T>(&raw)[NIT] = bf.raw; bool(&okf)[NIT] = bf.okf;
     const int tid = threadIdx.x;
     int tr = 0, ts = 0, c0 = k0;
     if (MODE == OP_CONV) {
@@ -174,7 +174,8 @@ struct KStage {
       }
     }
   }
-  __device__ __forceinline__ void store(bf16* hi, bf16* lo, bool) {
+  __device__ __forceinline__ void store(bf16* hi, bf16* lo, bool, Buf& bf) {
+    Raw8<T>(&raw)[NIT] = bf.raw; bool(&okf)[NIT] = bf.okf;
     const int tid = threadIdx.x;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
@@ -189,10 +190,9 @@ struct KStage {
 // ---- reduction-major operand (TRANS, or CONVT gather): memory tile [32 red][COLS], transposed --
 template <typename T, int COLS, int MODE, bool VEC>
 struct TStage {
-  Raw8<T> raw[2];
+  struct Buf { Raw8<T> raw[2]; bool okf[2]; };
   const T* ptr; int64_t ld; int col0, ncols;
   int tap_r, tap_s, c0;
-  bool okf[2];
   int pb[2], poh[2], pow_[2];      // CONVT: (batch, oh, ow) of this thread's two reduction rows, advanced per k-tile
 
   __device__ __forceinline__ void init(const T* p, int64_t ld_, int col0_, int ncols_, int k_begin, const ConvGeom& g) {
@@ -213,7 +213,8 @@ struct TStage {
       }
     }
   }
-  __device__ __forceinline__ void load(int k0, int K, const ConvGeom& g) {
+  __device__ __forceinline__ void load(int k0, int K, const ConvGeom& g, Buf& bf) {
+    Raw8<T>(&raw)[2] = bf.raw; bool(&okf)[2] = bf.okf;
     const int tid = threadIdx.x;
     const int p = tid & 15, cgp = tid >> 4;
     const bool active = !(COLS == 64 && cgp >= 8);
@@ -243,7 +244,8 @@ struct TStage {
       }
     }
   }
-  __device__ __forceinline__ void store(bf16* hi, bf16* lo, bool precise) {
+  __device__ __forceinline__ void store(bf16* hi, bf16* lo, bool precise, Buf& bf) {
+    Raw8<T>(&raw)[2] = bf.raw; bool(&okf)[2] = bf.okf;
     const int tid = threadIdx.x;
     const int p = tid & 15, cgp = tid >> 4;
     if (COLS == 64 && cgp >= 8) return;
@@ -305,10 +307,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmK p) {
     }
     return which < 2 ? b : b + A_ELEMS;
   };
-  auto do_store = [&](int s) {
-    as.store(stage_ptr(s, 0), stage_ptr(s, 1), PRECISE);
-    bs.store(stage_ptr(s, 2), stage_ptr(s, 3), PRECISE);
-  };
+  // register prefetch ring, PF tiles deep: the global loads of tile t+PF-1 are issued while tile t is being
+  // multiplied, so a load has PF-1 whole iterations (not one) to come back before its ds_write needs it.
+  constexpr int PF = 3;
+  typename AStage::Buf abuf[PF];
+  typename BStage::Buf bbuf[PF];
 
   f32x4 acc[FM][FN];
 #pragma unroll
@@ -316,22 +319,23 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmK p) {
 #pragma unroll
     for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  as.load(kt0 * BK, p.K, p.cg);
-  bs.load(kt0 * BK, p.K, p.cg);
-  do_store(0);
+#pragma unroll
+  for (int d = 0; d < PF - 1; ++d) {
+    if (kt0 + d < kt1) {
+      as.load((kt0 + d) * BK, p.K, p.cg, abuf[d]);
+      bs.load((kt0 + d) * BK, p.K, p.cg, bbuf[d]);
+    }
+  }
+  as.store(stage_ptr(0, 0), stage_ptr(0, 1), PRECISE, abuf[0]);
+  bs.store(stage_ptr(0, 2), stage_ptr(0, 3), PRECISE, bbuf[0]);
   __syncthreads();
 
   int cur = 0;
   const int a_off = (wm * (BM / 2) + (lane & 15)) * LDK + (lane >> 4) * 8;
   const int b_off = (wn * (BN / 2) + (lane & 15)) * LDK + (lane >> 4) * 8;
-  for (int kt = kt0; kt < kt1; ++kt) {
-    const bool more = kt + 1 < kt1;
-    if (more) {
-      as.load((kt + 1) * BK, p.K, p.cg);
-      bs.load((kt + 1) * BK, p.K, p.cg);
-    }
-    const bf16* Ah = stage_ptr(cur, 0) + a_off;
-    const bf16* Bh = stage_ptr(cur, 2) + b_off;
+  auto compute = [&](int st) {
+    const bf16* Ah = stage_ptr(st, 0) + a_off;
+    const bf16* Bh = stage_ptr(st, 2) + b_off;
     bf16x8 af[FM], bfr[FN];
 #pragma unroll
     for (int i = 0; i < FM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(Ah + i * 16 * LDK);
@@ -342,8 +346,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmK p) {
 #pragma unroll
       for (int j = 0; j < FN; ++j) acc[i][j] = mfma16(bfr[j], af[i], acc[i][j]);
     if constexpr (PRECISE) {
-      const bf16* Al = stage_ptr(cur, 1) + a_off;
-      const bf16* Bl = stage_ptr(cur, 3) + b_off;
+      const bf16* Al = stage_ptr(st, 1) + a_off;
+      const bf16* Bl = stage_ptr(st, 3) + b_off;
       bf16x8 al[FM], bl[FN];
 #pragma unroll
       for (int i = 0; i < FM; ++i) al[i] = *reinterpret_cast<const bf16x8*>(Al + i * 16 * LDK);
@@ -357,9 +361,25 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmK p) {
           acc[i][j] = mfma16(bfr[j], al[i], acc[i][j]);
         }
     }
-    if (more) do_store(cur ^ 1);
-    __syncthreads();
-    cur ^= 1;
+  };
+  for (int kt = kt0; kt < kt1; kt += PF) {
+#pragma unroll
+    for (int d = 0; d < PF; ++d) {       // statically indexed ring slots (runtime indices would spill to scratch)
+      const int t = kt + d;
+      if (t < kt1) {
+        if (t + PF - 1 < kt1) {
+          as.load((t + PF - 1) * BK, p.K, p.cg, abuf[(d + PF - 1) % PF]);
+          bs.load((t + PF - 1) * BK, p.K, p.cg, bbuf[(d + PF - 1) % PF]);
+        }
+        compute(cur);
+        if (t + 1 < kt1) {
+          as.store(stage_ptr(cur ^ 1, 0), stage_ptr(cur ^ 1, 1), PRECISE, abuf[(d + 1) % PF]);
+          bs.store(stage_ptr(cur ^ 1, 2), stage_ptr(cur ^ 1, 3), PRECISE, bbuf[(d + 1) % PF]);
+        }
+        __syncthreads();
+        cur ^= 1;
+      }
+    }
   }
 
   TOut* Cp = reinterpret_cast<TOut*>(p.C) + (int64_t)batch * p.sC;
@@ -413,6 +433,32 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmK p) {
       }
     }
     __syncthreads();
+    // 1) issue every residual / mask load of this half first (independent loads in flight together),
+    // 2) then read the staged accumulators, finish the epilogue math and store whole row runs.
+    float rv[NCH][8], mv[NCH][8];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int idx = tid + c * 256;
+      const int r = idx / CH, c8 = idx - r * CH;
+      const int m = row0 + half * HR + r;
+      const int n = col0 + c8 * 8;
+      const bool inb = m < p.M && n < p.N;
+      const bool full = n + 8 <= p.N;
+      if (Rp) {
+        if (inb && v_res && full) Vec8IO<TOut>::ld(Rp + (int64_t)m * p.ldr + n, rv[c]);
+        else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) rv[c][e] = (inb && n + e < p.N) ? (float)Rp[(int64_t)m * p.ldr + n + e] : 0.f;
+        }
+      }
+      if (Mp) {
+        if (inb && v_msk && full) Vec8IO<TOut>::ld(Mp + (int64_t)m * p.ldm + n, mv[c]);
+        else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) mv[c][e] = (inb && n + e < p.N) ? (float)Mp[(int64_t)m * p.ldm + n + e] : 0.f;
+        }
+      }
+    }
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       const int idx = tid + c * 256;
@@ -428,33 +474,18 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmK p) {
       }
       const float rs = p.rowscale ? p.rowscale[m] * p.alpha : p.alpha;
       const bool full = n + 8 <= p.N;
-      float rv[8], mv[8];
-      if (Rp) {
-        if (v_res && full) Vec8IO<TOut>::ld(Rp + (int64_t)m * p.ldr + n, rv);
-        else {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) rv[e] = (n + e < p.N) ? (float)Rp[(int64_t)m * p.ldr + n + e] : 0.f;
-        }
-      }
-      if (Mp) {
-        if (v_msk && full) Vec8IO<TOut>::ld(Mp + (int64_t)m * p.ldm + n, mv);
-        else {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) mv[e] = (n + e < p.N) ? (float)Mp[(int64_t)m * p.ldm + n + e] : 0.f;
-        }
-      }
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         float x = v[e] * rs;
         if (p.bias && n + e < p.N) x += p.bias[n + e];
-        if (Rp) x += rv[e];
+        if (Rp) x += rv[c][e];
         if (p.act == GPV_ACT_RELU) x = fmaxf(x, 0.f);
         else if (p.act == GPV_ACT_GELU) x = gelu_erf(x);
         if (p.dthresh) {
           uint64_t di = ((uint64_t)batch * p.M + m) * (uint64_t)p.N + (n + e);
           x = drop_keep(p.seed, di, p.dthresh) ? x * p.dscale : 0.f;
         }
-        if (Mp) x = mv[e] > 0.f ? x : 0.f;
+        if (Mp) x = mv[c][e] > 0.f ? x : 0.f;
         v[e] = x;
       }
       TOut* dst = Cp + (int64_t)m * p.ldc + n;
