@@ -15,6 +15,10 @@
 #include "common.h"
 #include "../../include/gpv_hip.h"
 
+#ifndef GPV_PF
+#define GPV_PF 2      /* register prefetch ring depth (tiles). Measured on the ResNet-50 conv shapes (tools/bench_conv.py): 1: 1968 us, 2: 1877 us, 3 (occupancy 3->2): 2136 us */
+#endif
+
 namespace {
 
 enum { OP_PLAIN = 0, OP_TRANS = 1, OP_CONV = 2 };
@@ -309,7 +313,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmK p) {
   };
   // register prefetch ring, PF tiles deep: the global loads of tile t+PF-1 are issued while tile t is being
   // multiplied, so a load has PF-1 whole iterations (not one) to come back before its ds_write needs it.
-  constexpr int PF = 3;
+  constexpr int PF = GPV_PF;
   typename AStage::Buf abuf[PF];
   typename BStage::Buf bbuf[PF];
 
@@ -433,67 +437,72 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmK p) {
       }
     }
     __syncthreads();
-    // 1) issue every residual / mask load of this half first (independent loads in flight together),
-    // 2) then read the staged accumulators, finish the epilogue math and store whole row runs.
-    float rv[NCH][8], mv[NCH][8];
+    // readback in groups of EPG chunks: the residual / mask loads of a group are issued together (independent
+    // loads in flight), then the staged accumulators are finished and stored as whole row runs.  Small groups
+    // keep the epilogue's register footprint below the main loop's, so it does not cost occupancy.
+    constexpr int EPG = NCH >= 2 ? 2 : 1;
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-      const int idx = tid + c * 256;
-      const int r = idx / CH, c8 = idx - r * CH;
-      const int m = row0 + half * HR + r;
-      const int n = col0 + c8 * 8;
-      const bool inb = m < p.M && n < p.N;
-      const bool full = n + 8 <= p.N;
-      if (Rp) {
-        if (inb && v_res && full) Vec8IO<TOut>::ld(Rp + (int64_t)m * p.ldr + n, rv[c]);
+    for (int c0 = 0; c0 < NCH; c0 += EPG) {
+      float rv[EPG][8], mv[EPG][8];
+#pragma unroll
+      for (int g = 0; g < EPG; ++g) {
+        const int idx = tid + (c0 + g) * 256;
+        const int r = idx / CH, c8 = idx - r * CH;
+        const int m = row0 + half * HR + r;
+        const int n = col0 + c8 * 8;
+        const bool inb = m < p.M && n < p.N;
+        const bool full = n + 8 <= p.N;
+        if (Rp) {
+          if (inb && v_res && full) Vec8IO<TOut>::ld(Rp + (int64_t)m * p.ldr + n, rv[g]);
+          else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) rv[g][e] = (inb && n + e < p.N) ? (float)Rp[(int64_t)m * p.ldr + n + e] : 0.f;
+          }
+        }
+        if (Mp) {
+          if (inb && v_msk && full) Vec8IO<TOut>::ld(Mp + (int64_t)m * p.ldm + n, mv[g]);
+          else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) mv[g][e] = (inb && n + e < p.N) ? (float)Mp[(int64_t)m * p.ldm + n + e] : 0.f;
+          }
+        }
+      }
+#pragma unroll
+      for (int g = 0; g < EPG; ++g) {
+        const int idx = tid + (c0 + g) * 256;
+        const int r = idx / CH, c8 = idx - r * CH;
+        const int m = row0 + half * HR + r;
+        const int n = col0 + c8 * 8;
+        if (m >= p.M || n >= p.N) continue;
+        float v[8];
+        {
+          const float4 a = *reinterpret_cast<const float4*>(ep + r * EPITCH + c8 * 8);
+          const float4 b = *reinterpret_cast<const float4*>(ep + r * EPITCH + c8 * 8 + 4);
+          v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        }
+        const float rs = p.rowscale ? p.rowscale[m] * p.alpha : p.alpha;
+        const bool full = n + 8 <= p.N;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float x = v[e] * rs;
+          if (p.bias && n + e < p.N) x += p.bias[n + e];
+          if (Rp) x += rv[g][e];
+          if (p.act == GPV_ACT_RELU) x = fmaxf(x, 0.f);
+          else if (p.act == GPV_ACT_GELU) x = gelu_erf(x);
+          if (p.dthresh) {
+            uint64_t di = ((uint64_t)batch * p.M + m) * (uint64_t)p.N + (n + e);
+            x = drop_keep(p.seed, di, p.dthresh) ? x * p.dscale : 0.f;
+          }
+          if (Mp) x = mv[g][e] > 0.f ? x : 0.f;
+          v[e] = x;
+        }
+        TOut* dst = Cp + (int64_t)m * p.ldc + n;
+        if (v_st && full) Vec8IO<TOut>::st(dst, v);
         else {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) rv[c][e] = (inb && n + e < p.N) ? (float)Rp[(int64_t)m * p.ldr + n + e] : 0.f;
+          for (int e = 0; e < 8; ++e)
+            if (n + e < p.N) dst[e] = (TOut)v[e];
         }
-      }
-      if (Mp) {
-        if (inb && v_msk && full) Vec8IO<TOut>::ld(Mp + (int64_t)m * p.ldm + n, mv[c]);
-        else {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) mv[c][e] = (inb && n + e < p.N) ? (float)Mp[(int64_t)m * p.ldm + n + e] : 0.f;
-        }
-      }
-    }
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-      const int idx = tid + c * 256;
-      const int r = idx / CH, c8 = idx - r * CH;
-      const int m = row0 + half * HR + r;
-      const int n = col0 + c8 * 8;
-      if (m >= p.M || n >= p.N) continue;
-      float v[8];
-      {
-        const float4 a = *reinterpret_cast<const float4*>(ep + r * EPITCH + c8 * 8);
-        const float4 b = *reinterpret_cast<const float4*>(ep + r * EPITCH + c8 * 8 + 4);
-        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-      }
-      const float rs = p.rowscale ? p.rowscale[m] * p.alpha : p.alpha;
-      const bool full = n + 8 <= p.N;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        float x = v[e] * rs;
-        if (p.bias && n + e < p.N) x += p.bias[n + e];
-        if (Rp) x += rv[c][e];
-        if (p.act == GPV_ACT_RELU) x = fmaxf(x, 0.f);
-        else if (p.act == GPV_ACT_GELU) x = gelu_erf(x);
-        if (p.dthresh) {
-          uint64_t di = ((uint64_t)batch * p.M + m) * (uint64_t)p.N + (n + e);
-          x = drop_keep(p.seed, di, p.dthresh) ? x * p.dscale : 0.f;
-        }
-        if (Mp) x = mv[c][e] > 0.f ? x : 0.f;
-        v[e] = x;
-      }
-      TOut* dst = Cp + (int64_t)m * p.ldc + n;
-      if (v_st && full) Vec8IO<TOut>::st(dst, v);
-      else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-          if (n + e < p.N) dst[e] = (TOut)v[e];
       }
     }
   }
@@ -542,8 +551,10 @@ int launch_tiles(const GemmK& k, int batch, hipStream_t st) {
 template <int AMODE, int BMODE>
 int launch_dtype(const GemmK& k, int batch, int dt_in, int dt_out, hipStream_t st) {
   if (dt_in == GPV_BF16 && dt_out == GPV_BF16) return launch_tiles<bf16, bf16, AMODE, BMODE>(k, batch, st);
+#ifndef GPV_EXPERIMENT      /* trimmed instantiation set for kernel-tuning builds */
   if (dt_in == GPV_BF16 && dt_out == GPV_F32) return launch_tiles<bf16, float, AMODE, BMODE>(k, batch, st);
   if (dt_in == GPV_F32 && dt_out == GPV_F32) return launch_tiles<float, float, AMODE, BMODE>(k, batch, st);
+#endif
   return (int)hipErrorInvalidValue;
 }
 

@@ -14,7 +14,7 @@ ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 KMAJOR, TRANS = 0, 1
 
 _LIB = None
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc', 'libgpv_hip.so')
+_LIB_PATH = os.environ.get('GPV_HIP_LIB') or os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc', 'libgpv_hip.so')
 
 
 class GemmArgs(C.Structure):
