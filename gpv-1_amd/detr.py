@@ -79,7 +79,9 @@ class DETR(nn.Module):
             out['aux_outputs'] = [{'pred_relevance_logits': a, 'pred_boxes': b}
                                   for a, b in zip(outputs_class[:-1], outputs_coord[:-1])]
         if self.roi_head:
-            roi = ops.roi_pool(rows, out['pred_boxes'], h, w)              # [B,Q,2048], no grad to boxes
+            # boxes are detached: torchvision's roi_align has no gradient w.r.t. the boxes, so in a batch without
+            # box targets the bbox MLP receives no gradient at all (and is not touched by the optimizer)
+            roi = ops.roi_pool(rows, out['pred_boxes'].detach(), h, w)     # [B,Q,2048]
             roi = ops.add_layernorm(roi, None, None, None, 1e-5)           # F.layer_norm, no affine (:91)
             out['detr_hs'] = torch.cat((roi.unsqueeze(0).to(hs.dtype), hs), -1)
         return out

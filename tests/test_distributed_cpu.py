@@ -1,0 +1,90 @@
+"""Multi-process data-parallel path on CPU: world_size 2 over gloo (the GPU run uses the same code over
+RCCL).  Kernels are the torch emulation (tests/cpu_shim.py); what is under test is train.FlatTrainer's
+gradient exchange: flat-buffer bucketed all-reduce (average), the cross-rank agreement on the
+"touched" parameter set, parameter broadcast at start, and that ranks stay bit-identical after steps.
+"""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _targets(rank, V):
+    from tests import synth
+    # rank 0: caption + vqa + cls + detection ; rank 1: captions only -> the box head is touched on ONE rank only
+    if rank == 0:
+        return synth.synth_targets(4, V, S=6)
+    return synth.synth_targets(4, V, S=6, seed=7, tasks=('CocoCaptioning',))
+
+
+def _worker(rank, world, port, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from tests import synth, cpu_shim
+    from tests.test_model_cpu import build_small, nested, V, B, H, W, Tl, PAD
+    import gpv1_amd.ops as ops
+    from gpv1_amd.train import FlatTrainer
+    cpu_shim.install()
+    ops.RT.set_precise(True)
+    torch.manual_seed(100 + rank)                         # different init per rank: broadcast must fix it
+    model, _ = build_small()
+    with torch.no_grad():
+        if rank == 1:
+            model.detr_joiner.weight.add_(1.0)
+    model.train()
+    model.bert.model.p = 0.0
+    tr = FlatTrainer(model, lr=1e-4, lr_backbone=1e-5, bucket_mb=8)
+    images, mask, ids, attn = synth.synth_batch(B, H, W, Tl, V, seed=1234 + rank, pad_to=PAD)
+    # one step by hand to look at the exchanged gradient
+    tg = _targets(rank, V)
+    _, tok = model.encode_answers(tg)
+    for i, t in enumerate(tg):
+        t['answer_token_ids'] = tok[i, 1:]
+    loss = model(nested(images, mask), (ids, attn), tok, tg)
+    tr.zero_grad()
+    loss.backward()
+    local = tr.G.clone()
+    touched_local = tr.touched.clone()
+    tr.allreduce_grads()
+    res = {'local': local, 'avg': tr.G.clone(), 'touched_local': touched_local, 'touched': tr.touched.clone()}
+    tr.step()
+    for _ in range(1):
+        tr.model.bert.model.p = 0.0
+        tr.train_step(nested(images, mask), (ids, attn), _targets(rank, V))
+    res['P'] = tr.P.clone()
+    res['names'] = [e[0] for e in tr.entries]
+    torch.save(res, os.path.join(out, f'rank{rank}.pt'))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_two_rank_gradient_exchange(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(os.path.join(tmp_path, 'rank0.pt'))
+    r1 = torch.load(os.path.join(tmp_path, 'rank1.pt'))
+    # exchanged gradient = average of the two local gradients, identical on both ranks
+    avg = (r0['local'] + r1['local']) / 2
+    assert torch.equal(r0['avg'], r1['avg'])
+    assert (r0['avg'] - avg).abs().max().item() <= 1e-6 * max(avg.abs().max().item(), 1.0)
+    # the box head only received gradients on rank 0 (rank 1 had captions only) ...
+    names = r0['names']
+    ib = [i for i, n in enumerate(names) if 'bbox_embed' in n]
+    assert r0['touched_local'][ib].all() and not r1['touched_local'][ib].any()
+    # ... but after the MAX exchange both ranks agree it is touched, so AdamW updates it on both
+    assert torch.equal(r0['touched'], r1['touched']) and r0['touched'][ib].all()
+    # parameters were broadcast from rank 0 at construction and stay bit-identical after two steps
+    assert torch.equal(r0['P'], r1['P'])
