@@ -74,17 +74,28 @@ class ConvW(nn.Module):
         return v.reshape(self.cout, self.k * self.k, self.cin)
 
 
+def _bn_fold(bn):
+    key = ('bn', id(bn))
+    hit = RT.cache.get(key)
+    if hit is not None and hit[0] == RT.static_epoch:
+        return hit[1], hit[2]
+    scale, shift = bn.scale_shift()
+    RT.cache[key] = (RT.static_epoch, scale, shift)
+    return scale, shift
+
+
 def _conv_copies(conv, bn, need_wd):
     key = ('conv', id(conv), RT.dtype)
     hit = RT.cache.get(key)
-    if hit is not None and hit[0] == RT.weights_epoch and (hit[2] is not None or not need_wd):
+    ep = RT.epoch_of(conv.weight)
+    if hit is not None and hit[0] == ep and (hit[2] is not None or not need_wd):
         return hit[1:]
-    scale, shift = bn.scale_shift()
+    scale, shift = _bn_fold(bn)
     T = conv.k * conv.k
     wf = torch.empty(conv.cout, T, conv.cin, device=scale.device, dtype=RT.dtype)
     wd = torch.empty(conv.cin, T, conv.cout, device=scale.device, dtype=RT.dtype) if need_wd else None
     hip.prep_conv_weight(conv.phys(), scale, wf, wd, conv.cout, T, conv.cin)
-    RT.cache[key] = (RT.weights_epoch, wf, wd, scale, shift)
+    RT.cache[key] = (ep, wf, wd, scale, shift)
     return wf, wd, scale, shift
 
 
@@ -168,14 +179,14 @@ class ResNetBody(nn.Module):
     def _stem_weight(self):
         key = ('stem', id(self), RT.dtype)
         hit = RT.cache.get(key)
-        if hit is not None and hit[0] == RT.weights_epoch:
+        if hit is not None and hit[0] == RT.static_epoch:
             return hit[1], hit[2]
-        scale, shift = self.bn1.scale_shift()
+        scale, shift = _bn_fold(self.bn1)
         w = self.conv1.weight.detach().float() * scale.view(-1, 1, 1, 1)          # [64,3,7,7]
         ws = torch.zeros(64, 7, 8, 4, device=w.device, dtype=torch.float32)        # [co][r][8 px][4 ch]
         ws[:, :, :7, :3] = w.permute(0, 2, 3, 1)
         ws = ws.reshape(64, 7, 32).to(RT.dtype).contiguous()
-        RT.cache[key] = (RT.weights_epoch, ws, shift)
+        RT.cache[key] = (RT.static_epoch, ws, shift)
         return ws, shift
 
     def forward_nhwc(self, images, keep):

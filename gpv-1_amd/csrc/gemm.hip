@@ -191,13 +191,19 @@ struct KStage {
   }
 };
 
-// ---- reduction-major operand (TRANS, or CONVT gather): memory tile [32 red][COLS], transposed --
+// ---- reduction-major operand (TRANS, or CONVT gather): memory tile [32 red][COLS] -------------------------
+// Staged ROW-MAJOR exactly as it is loaded (16-B global loads, conflict-free ds_write_b128, pitch COLS+16), and
+// consumed with the gfx950 LDS transpose read: one ds_read_b64_tr_b16 gives a lane 4 consecutive reduction rows of
+// ITS column (verified on hardware by tools/probe/trread.hip); two of them = one 16x16x32 MFMA operand fragment.
 template <typename T, int COLS, int MODE, bool VEC>
 struct TStage {
-  struct Buf { Raw8<T> raw[2]; bool okf[2]; };
+  static constexpr int CHK = COLS / 8;            // 16-B chunks per reduction row
+  static constexpr int NIT = (BK * CHK) / 256;    // chunks per thread
+  static constexpr int PITCH = COLS + 16;         // elements; (PITCH/2) % 64 in {8, 40}: 8 rows hit distinct bank octets
+  struct Buf { Raw8<T> raw[NIT]; bool okf[NIT]; };
   const T* ptr; int64_t ld; int col0, ncols;
   int tap_r, tap_s, c0;
-  int pb[2], poh[2], pow_[2];      // CONVT: (batch, oh, ow) of this thread's two reduction rows, advanced per k-tile
+  int pb[NIT], poh[NIT], pow_[NIT];      // CONVT: (batch, oh, ow) of this thread's reduction rows, advanced per k-tile
 
   __device__ __forceinline__ void init(const T* p, int64_t ld_, int col0_, int ncols_, int k_begin, const ConvGeom& g) {
     ptr = p; ld = ld_; col0 = col0_; ncols = ncols_;
@@ -208,58 +214,65 @@ struct TStage {
       tap_r = tap / g.KW;
       tap_s = tap - tap_r * g.KW;
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        int k = k_begin + 2 * (threadIdx.x & 15) + j;
-        pb[j] = k / (g.OH * g.OW);
-        int rem = k - pb[j] * (g.OH * g.OW);
-        poh[j] = rem / g.OW;
-        pow_[j] = rem - poh[j] * g.OW;
+      for (int it = 0; it < NIT; ++it) {
+        int k = k_begin + (threadIdx.x + it * 256) / CHK;
+        pb[it] = k / (g.OH * g.OW);
+        int rem = k - pb[it] * (g.OH * g.OW);
+        poh[it] = rem / g.OW;
+        pow_[it] = rem - poh[it] * g.OW;
       }
     }
   }
   __device__ __forceinline__ void load(int k0, int K, const ConvGeom& g, Buf& bf) {
-    Raw8<T>(&raw)[2] = bf.raw; bool(&okf)[2] = bf.okf;
-    const int tid = threadIdx.x;
-    const int p = tid & 15, cgp = tid >> 4;
-    const bool active = !(COLS == 64 && cgp >= 8);
-    const int col = col0 + cgp * 8;
+    Raw8<T>(&raw)[NIT] = bf.raw; bool(&okf)[NIT] = bf.okf;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      int k = k0 + 2 * p + j;
-      bool ok = active && k < K && col < ncols;
+    for (int it = 0; it < NIT; ++it) {
+      const int idx = threadIdx.x + it * 256;
+      const int kr = idx / CHK, ch = idx - kr * CHK;
+      const int k = k0 + kr, col = col0 + ch * 8;
+      bool ok = k < K && col < ncols;
       const T* src;
       if (MODE == OP_CONV) {
-        int ih = poh[j] * g.SH + tap_r - g.PH, iw = pow_[j] * g.SW + tap_s - g.PW;
+        int ih = poh[it] * g.SH + tap_r - g.PH, iw = pow_[it] * g.SW + tap_s - g.PW;
         ok = ok && ih >= 0 && iw >= 0 && ih < g.IH && iw < g.IW;
-        src = ptr + ((int64_t)((pb[j] * g.IH + ih) * g.IW + iw)) * g.Cs + c0 + cgp * 8;
-        // advance this row by BK pixels for the next k-tile
-        pow_[j] += BK;
-        while (pow_[j] >= g.OW) { pow_[j] -= g.OW; poh[j] += 1; }
-        while (poh[j] >= g.OH) { poh[j] -= g.OH; pb[j] += 1; }
+        src = ptr + ((int64_t)((pb[it] * g.IH + ih) * g.IW + iw)) * g.Cs + c0 + ch * 8;
+        pow_[it] += BK;                           // advance this reduction row by BK pixels for the next k-tile
+        while (pow_[it] >= g.OW) { pow_[it] -= g.OW; poh[it] += 1; }
+        while (poh[it] >= g.OH) { poh[it] -= g.OH; pb[it] += 1; }
       } else {
         src = ptr + (int64_t)k * ld + col;
       }
-      if (VEC) {                                 // host guarantees ncols % 8 == 0 for the VEC variant
-        raw[j].load(ok ? src : ptr);
-        okf[j] = ok;
+      if (VEC) {                                  // host guarantees ncols % 8 == 0 for the VEC variant
+        raw[it].load(ok ? src : ptr);
+        okf[it] = ok;
       } else {
-        if (!ok) raw[j].zero();
-        else raw[j].load_n(src, ncols - col);
+        if (!ok) raw[it].zero();
+        else raw[it].load_n(src, ncols - col);
       }
     }
   }
-  __device__ __forceinline__ void store(bf16* hi, bf16* lo, bool precise, Buf& bf) {
-    Raw8<T>(&raw)[2] = bf.raw; bool(&okf)[2] = bf.okf;
-    const int tid = threadIdx.x;
-    const int p = tid & 15, cgp = tid >> 4;
-    if (COLS == 64 && cgp >= 8) return;
-    if (VEC) { mask_raw<T>(raw[0], okf[0]); mask_raw<T>(raw[1], okf[1]); }
+  __device__ __forceinline__ void store(bf16* hi, bf16* lo, bool, Buf& bf) {
+    Raw8<T>(&raw)[NIT] = bf.raw; bool(&okf)[NIT] = bf.okf;
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      int off = (cgp * 8 + c) * LDK + 2 * p;
-      *reinterpret_cast<uint32_t*>(hi + off) = raw[0].hi_bits(c) | (raw[1].hi_bits(c) << 16);
-      if (precise) *reinterpret_cast<uint32_t*>(lo + off) = raw[0].lo_bits(c) | (raw[1].lo_bits(c) << 16);
+    for (int it = 0; it < NIT; ++it) {
+      const int idx = threadIdx.x + it * 256;
+      const int kr = idx / CHK, ch = idx - kr * CHK;
+      if (VEC) mask_raw<T>(raw[it], okf[it]);
+      raw[it].write(hi + kr * PITCH + ch * 8, lo + kr * PITCH + ch * 8);
     }
+  }
+  // fragment for the 16 columns starting at `cbase` of the staged tile: lane (col = lane&15, g = lane>>4) receives
+  // reduction rows 8g..8g+7
+  static __device__ __forceinline__ bf16x8 frag(const bf16* tile, int cbase, int lane) {
+    typedef short __attribute__((ext_vector_type(4))) s16x4;
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    const int g = lane >> 4, i = lane & 15;
+    const bf16* p0 = tile + (8 * g + (i >> 2)) * PITCH + cbase + (i & 3) * 4;
+    s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0));
+    s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0 + 4 * PITCH));
+    typedef short __attribute__((ext_vector_type(8))) s16x8;
+    s16x8 r = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return __builtin_bit_cast(bf16x8, r);
   }
 };
 
@@ -338,25 +351,37 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmK p) {
   const int a_off = (wm * (BM / 2) + (lane & 15)) * LDK + (lane >> 4) * 8;
   const int b_off = (wn * (BN / 2) + (lane & 15)) * LDK + (lane >> 4) * 8;
   auto compute = [&](int st) {
-    const bf16* Ah = stage_ptr(st, 0) + a_off;
-    const bf16* Bh = stage_ptr(st, 2) + b_off;
     bf16x8 af[FM], bfr[FN];
+    const bf16* At = stage_ptr(st, 0);
+    const bf16* Bt = stage_ptr(st, 2);
 #pragma unroll
-    for (int i = 0; i < FM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(Ah + i * 16 * LDK);
+    for (int i = 0; i < FM; ++i) {
+      if constexpr (AMODE == OP_TRANS) af[i] = AStage::frag(At, wm * (BM / 2) + i * 16, lane);
+      else af[i] = *reinterpret_cast<const bf16x8*>(At + a_off + i * 16 * LDK);
+    }
 #pragma unroll
-    for (int j = 0; j < FN; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(Bh + j * 16 * LDK);
+    for (int j = 0; j < FN; ++j) {
+      if constexpr (BMODE != OP_PLAIN) bfr[j] = BStage::frag(Bt, wn * (BN / 2) + j * 16, lane);
+      else bfr[j] = *reinterpret_cast<const bf16x8*>(Bt + b_off + j * 16 * LDK);
+    }
 #pragma unroll
     for (int i = 0; i < FM; ++i)
 #pragma unroll
       for (int j = 0; j < FN; ++j) acc[i][j] = mfma16(bfr[j], af[i], acc[i][j]);
     if constexpr (PRECISE) {
-      const bf16* Al = stage_ptr(st, 1) + a_off;
-      const bf16* Bl = stage_ptr(st, 3) + b_off;
+      const bf16* Alt = stage_ptr(st, 1);
+      const bf16* Blt = stage_ptr(st, 3);
       bf16x8 al[FM], bl[FN];
 #pragma unroll
-      for (int i = 0; i < FM; ++i) al[i] = *reinterpret_cast<const bf16x8*>(Al + i * 16 * LDK);
+      for (int i = 0; i < FM; ++i) {
+        if constexpr (AMODE == OP_TRANS) al[i] = AStage::frag(Alt, wm * (BM / 2) + i * 16, lane);
+        else al[i] = *reinterpret_cast<const bf16x8*>(Alt + a_off + i * 16 * LDK);
+      }
 #pragma unroll
-      for (int j = 0; j < FN; ++j) bl[j] = *reinterpret_cast<const bf16x8*>(Bl + j * 16 * LDK);
+      for (int j = 0; j < FN; ++j) {
+        if constexpr (BMODE != OP_PLAIN) bl[j] = BStage::frag(Blt, wn * (BN / 2) + j * 16, lane);
+        else bl[j] = *reinterpret_cast<const bf16x8*>(Blt + b_off + j * 16 * LDK);
+      }
 #pragma unroll
       for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -577,6 +602,11 @@ extern "C" int gpv_gemm(const gpv_gemm_args* a, void* stream) {
   k.dthresh = a->drop_p > 0.f ? drop_thresh(a->drop_p) : 0u;
   k.dscale = a->drop_p > 0.f ? 1.0f / (1.0f - a->drop_p) : 1.0f;
   k.accumulate = a->accumulate; k.split_k = a->split_k;
+  if (a->accumulate && a->split_k <= 1 && !a->res) {
+    // one block owns every output element: C += acc as a coalesced read-modify-write through the LDS epilogue
+    // (fp32 atomics run at ~70 G/s: a 10000x768 gradient costs 110 us in atomics alone)
+    k.accumulate = 0; k.res = a->C; k.ldr = a->ldc; k.sR = a->sC;
+  }
   const int esz = a->dtype_in == GPV_F32 ? 4 : 2;
   const int64_t vecel = 16 / esz;  // elements per 16 B
   auto vec_ok = [&](const void* ptr, int64_t ld, int64_t bs, int layout, int extent_contig) {
@@ -635,6 +665,7 @@ extern "C" int gpv_conv2d(const gpv_conv_args* a, void* stream) {
       split = want < 1 ? 1 : (int)want;
     }
     k.split_k = split;
+    if (split <= 1) { k.accumulate = 0; k.res = a->y; k.ldr = k.ldc; }
     k.vecA = aligned16(a->w) && (a->Cout % vecel == 0) ? 1 : 0;
     k.vecB = aligned16(a->x) && (a->Cs % vecel == 0) ? 1 : 0;
     // CONVT needs every N tile inside one tap: BN=64 divides Cin (checked above); force 64-wide tiles

@@ -81,12 +81,12 @@ class AnswerHead(nn.Module):
 
     def classifiers(self):
         # W_c is batch independent: in eval it is computed once per weights version
-        if not torch.is_grad_enabled() and self._wc is not None and self._wc[0] == (RT.weights_epoch, RT.dtype):
+        if not torch.is_grad_enabled() and self._wc is not None and self._wc[0] == (RT.weights_epoch, RT.static_epoch, RT.dtype):
             return self._wc[1]
         e = ops._as_compute(self.vocab_embed.detach())
         wc = self.classifier_transform(e)                       # [V, D]
         if not torch.is_grad_enabled():
-            self._wc = ((RT.weights_epoch, RT.dtype), wc)
+            self._wc = ((RT.weights_epoch, RT.static_epoch, RT.dtype), wc)
         return wc
 
     def forward(self, h):

@@ -25,7 +25,8 @@ ACT_NONE, ACT_RELU, ACT_GELU = hip.ACT_NONE, hip.ACT_RELU, hip.ACT_GELU
 class Runtime:
     def __init__(self):
         self.dtype = torch.bfloat16
-        self.weights_epoch = 0
+        self.weights_epoch = 0       # bumped after every optimizer step (trainer-managed parameters changed)
+        self.static_epoch = 0        # bumped only when ANY tensor may have changed (load_state_dict, .to(), manual edits)
         self.seed = 0x5EED
         self._ctr = 0
         self.cache = {}
@@ -34,9 +35,15 @@ class Runtime:
         self.dtype = torch.float32 if on else torch.bfloat16
         self.cache.clear()
 
-    def bump_weights(self):
-        """call after parameters changed (optimizer step, load_state_dict, .to(device))"""
+    def bump_weights(self, everything=True):
+        """call after parameters changed.  everything=False: only the parameters a trainer manages changed
+        (optimizer step) -> frozen weights (BERT, conv1/layer1, FrozenBN folds) keep their compute copies."""
         self.weights_epoch += 1
+        if everything:
+            self.static_epoch += 1
+
+    def epoch_of(self, p):
+        return self.weights_epoch if getattr(p, '_gpv_managed', False) else self.static_epoch
 
     def manual_seed(self, s):
         self.seed, self._ctr = int(s), 0
@@ -66,7 +73,8 @@ def _lp_pair(p):
     """(W [N,K], W^T [K,N]) of a 2-D (or [N,K,1,1]) parameter in the compute dtype, cached per epoch."""
     key = ('lin', id(p), RT.dtype)
     hit = RT.cache.get(key)
-    if hit is not None and hit[0] == RT.weights_epoch:
+    ep = RT.epoch_of(p)
+    if hit is not None and hit[0] == ep:
         return hit[1], hit[2]
     N = p.shape[0]
     K = p.numel() // N
@@ -80,7 +88,7 @@ def _lp_pair(p):
     else:
         w = torch.empty(N, K, device=p.device, dtype=RT.dtype)
         hip.cast_rowscale_t(src, None, w, wt, N, K)
-    RT.cache[key] = (RT.weights_epoch, w, wt)
+    RT.cache[key] = (ep, w, wt)
     return w, wt
 
 
@@ -115,9 +123,12 @@ class W:
 
 
 def _split_k(out_rows, out_cols, red):
+    """split of the reduction for wgrad GEMMs.  fp32 atomics cost ~ outputs x split / 70e9 s, so: just enough
+    blocks to fill the chip (~512), never more than 8 splits, never fewer than 16 k-tiles per split
+    (tools/bench_split.py sweep); split 1 is a non-atomic read-modify-write."""
     tiles = ((out_rows + 63) // 64) * ((out_cols + 63) // 64)
     kt = (red + 31) // 32
-    return max(1, min(kt // 8, 1024 // max(tiles, 1)))
+    return max(1, min(-(-512 // max(tiles, 1)), 8, kt // 16))
 
 
 def _c(x):

@@ -76,6 +76,7 @@ class FlatTrainer:
             pv.copy_(p.data)
             p.data = pv
             p.grad = gv
+            p._gpv_managed = True                                                  # compute copies follow weights_epoch
             p._gpv_touch = (lambda i=i: self._mark(i))                            # kernel-accumulated gradients
             p.register_hook(lambda grad, i=i: self._mark(i))                       # autograd-delivered gradients
         self.gsq = torch.zeros(1, device=dev, dtype=torch.float32)
@@ -143,7 +144,7 @@ class FlatTrainer:
             clip_here = use_clip and g in ('detr_backbone', 'detr_head')
             hip.adamw(self.P[s:e], self.G[s:e], self.M[s:e], self.V[s:e], None, e - s, self.lr[g] * sched, b1, b2,
                       self.eps, self.wd, bc1, bc2, self.gscale if clip_here else None)
-        RT.bump_weights()
+        RT.bump_weights(everything=False)
 
     def train_step(self, images, queries, targets):
         """one iteration of train_distr.py:399-428; returns the loss tensor (or None: no applicable target)"""

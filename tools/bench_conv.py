@@ -32,3 +32,37 @@ for name, ci, co, k, s, p, H, W, wr in SHAPES:
     tot += us
     print('%-8s M=%7d N=%4d K=%4d  %7.1f us  %6.1f TF/s  %6.0f GB/s' % (name, B * OH * OW, co, k * k * ci, us, fl / us / 1e6, by / us / 1e3))
 print('sum us', tot)
+print('--- wgrad (layer2-4 shapes) / linear wgrad')
+tot = 0
+for name, ci, co, k, s, p, H, W, wr in SHAPES[3:]:
+    OH, OW = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    x = torch.randn(B, H, W, ci, device=dev).to(torch.bfloat16)
+    dy = torch.randn(B, OH, OW, co, device=dev).to(torch.bfloat16)
+    dw = torch.zeros(co, k * k, ci, device=dev)
+    sc = torch.ones(co, device=dev)
+    def run():
+        hip.conv2d(2, x, dy, dw, B, H, W, ci, ci, OH, OW, co, k, k, s, s, p, p, rowscale=sc)
+    for _ in range(3): run()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(); e0.record()
+    for _ in range(10): run()
+    e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 100
+    fl = 2.0 * B * OH * OW * co * k * k * ci
+    tot += us
+    print('%-8s wgrad out %4dx%5d red %7d  %7.1f us  %6.1f TF/s' % (name, co, k * k * ci, B * OH * OW, us, fl / us / 1e6))
+print('sum wgrad us', tot)
+for (M, N, K) in [(9600, 512, 256), (9600, 256, 256), (9600, 2048, 256), (9600, 256, 2048), (3200, 768, 768), (3200, 3072, 768), (608, 10000, 768)]:
+    dy = torch.randn(M, N, device=dev).to(torch.bfloat16); x = torch.randn(M, K, device=dev).to(torch.bfloat16)
+    dw = torch.zeros(N, K, device=dev)
+    tiles = ((N + 63) // 64) * ((K + 63) // 64); kt = (M + 31) // 32
+    split = max(1, min(kt // 8, 1024 // max(tiles, 1)))
+    def run():
+        hip.gemm(dy, x, dw, N, K, M, N, K, K, layoutA=hip.TRANS, layoutB=hip.TRANS, accumulate=True, split_k=split)
+    for _ in range(3): run()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(); e0.record()
+    for _ in range(10): run()
+    e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 100
+    print('linear wgrad out %5dx%4d red %5d split %3d  %7.1f us  %6.1f TF/s' % (N, K, M, split, us, 2.0 * M * N * K / us / 1e6))
