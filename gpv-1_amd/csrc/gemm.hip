@@ -14,6 +14,7 @@
 // holding 4 CONSECUTIVE columns of one C row -> 8/16-byte epilogue stores.
 #include "common.h"
 #include "../../include/gpv_hip.h"
+#include <cstdlib>
 
 #ifndef GPV_PF
 #define GPV_PF 2      /* register prefetch ring depth (tiles). Measured on the ResNet-50 conv shapes (tools/bench_conv.py): 1: 1968 us, 2: 1877 us, 3 (occupancy 3->2): 2136 us */
@@ -566,10 +567,17 @@ int launch_cfg(const GemmK& k, int batch, hipStream_t st) {
 
 template <typename TIn, typename TOut, int AMODE, int BMODE>
 int launch_tiles(const GemmK& k, int batch, hipStream_t st) {
-  const int64_t t128 = (int64_t)((k.M + 127) / 128) * ((k.N + 127) / 128) * batch * (k.split_k < 1 ? 1 : k.split_k);
-  const int64_t t12864 = (int64_t)((k.M + 127) / 128) * ((k.N + 63) / 64) * batch * (k.split_k < 1 ? 1 : k.split_k);
-  if (k.N > 64 && t128 >= 384) return launch_cfg<TIn, TOut, AMODE, BMODE, 128, 128>(k, batch, st);
-  if (t12864 >= 384) return launch_cfg<TIn, TOut, AMODE, BMODE, 128, 64>(k, batch, st);
+  const int64_t sk = (k.split_k < 1 ? 1 : k.split_k);
+  const int64_t t128 = (int64_t)((k.M + 127) / 128) * ((k.N + 127) / 128) * batch * sk;
+  const int64_t t12864 = (int64_t)((k.M + 127) / 128) * ((k.N + 63) / 64) * batch * sk;
+  static const int force = [] { const char* e = getenv("GPV_FORCE_TILE"); return e ? atoi(e) : 0; }();   // tuning only
+  int cfg;   // 0: 128x128, 1: 128x64, 2: 64x64
+  if (force) cfg = force - 1;
+  else if (k.N > 64 && t128 >= 384) cfg = 0;
+  else if (t12864 >= 384) cfg = 1;
+  else cfg = 2;
+  if (cfg == 0) return launch_cfg<TIn, TOut, AMODE, BMODE, 128, 128>(k, batch, st);
+  if (cfg == 1) return launch_cfg<TIn, TOut, AMODE, BMODE, 128, 64>(k, batch, st);
   return launch_cfg<TIn, TOut, AMODE, BMODE, 64, 64>(k, batch, st);
 }
 
