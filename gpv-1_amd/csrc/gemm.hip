@@ -298,7 +298,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmK p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int tile = blockIdx.x;
+  // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed dispatch rule, used for speed only).  Give every
+  // XCD a CONTIGUOUS range of tiles so that the column tiles of one row panel (same A rows / same conv pixels) share
+  // one L2 instead of being fetched from HBM once per XCD.  Bijective for any grid size.
+  int tile;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
   const int tm = tile / p.tilesN, tn = tile - tm * p.tilesN;
   const int row0 = tm * BM, col0 = tn * BN;
   const int batch = blockIdx.z;
@@ -448,6 +456,21 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmK p) {
   const bool v_st = (p.ldc % 8 == 0) && ((reinterpret_cast<uintptr_t>(Cp) & 15) == 0);
   const bool v_res = Rp && (p.ldr % 8 == 0) && ((reinterpret_cast<uintptr_t>(Rp) & 15) == 0);
   const bool v_msk = Mp && (p.ldm % 8 == 0) && ((reinterpret_cast<uintptr_t>(Mp) & 15) == 0);
+  // every chunk this thread finishes covers the SAME 8 columns (256 % CH == 0): fetch their bias once
+  // (per-element bias loads inside the readback loop cost more than the whole GEMM on the K=64 convs)
+  float bv[8];
+  {
+    const int nb = col0 + (tid % CH) * 8;
+    const bool vb = p.bias && nb + 8 <= p.N && ((reinterpret_cast<uintptr_t>(p.bias) & 15) == 0);
+    if (vb) {
+      const float4 b0 = *reinterpret_cast<const float4*>(p.bias + nb);
+      const float4 b1 = *reinterpret_cast<const float4*>(p.bias + nb + 4);
+      bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w; bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) bv[e] = (p.bias && nb + e < p.N) ? p.bias[nb + e] : 0.f;
+    }
+  }
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
     if (half == 1) __syncthreads();      // (the main loop ended with a barrier)
@@ -511,7 +534,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmK p) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           float x = v[e] * rs;
-          if (p.bias && n + e < p.N) x += p.bias[n + e];
+          x += bv[e];
           if (Rp) x += rv[g][e];
           if (p.act == GPV_ACT_RELU) x = fmaxf(x, 0.f);
           else if (p.act == GPV_ACT_GELU) x = gelu_erf(x);
@@ -573,6 +596,7 @@ int launch_tiles(const GemmK& k, int batch, hipStream_t st) {
   static const int force = [] { const char* e = getenv("GPV_FORCE_TILE"); return e ? atoi(e) : 0; }();   // tuning only
   int cfg;   // 0: 128x128, 1: 128x64, 2: 64x64
   if (force) cfg = force - 1;
+  else if (k.K <= 256) cfg = 2;          // <= 8 k-tiles: HBM/latency bound, 64x64 keeps more bytes in flight (tools/bench_c3.py)
   else if (k.N > 64 && t128 >= 384) cfg = 0;
   else if (t12864 >= 384) cfg = 1;
   else cfg = 2;
