@@ -126,6 +126,29 @@ def cpu_baseline(model, seconds_budget=25.0):
             'sample': f'oracle fwd+loss+bwd (no optimizer), B={Bc}, 480x640, V={V}, fp32, median of {len(times[1:] or times)} after 1 warm-up'}
 
 
+def greedy_decode_bench(model, dev):
+    """second half of BASELINE.json's metric: greedy-decode ms/image (whole inference: backbone -> DETR -> BERT ->
+    co-attention -> 20-token KV-cached decode, one hipGraph per step), eval mode, bf16, inputs resident in HBM."""
+    from gpv1_amd.misc import NestedTensor
+    model.eval()
+    res = {}
+    with torch.no_grad():
+        for Bd, iters in ((1, 10), (64, 5)):
+            images, mask, ids, attn, _ = make_batch(7, Bd, dev)
+            for _ in range(2):                                   # warm-up: captures the 20 step graphs for this batch size
+                model(NestedTensor(images, mask), (ids, attn), None, None)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                o = model(NestedTensor(images, mask), (ids, attn), None, None)
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / iters * 1e3
+            res[f'bs{Bd}'] = {'ms_per_batch': ms, 'ms_per_image': ms / Bd}
+    res['what'] = 'GPV.forward(images, queries, None): max_text_len=20 greedy, KV cache + hipGraph decode step, bf16'
+    model.train()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -133,6 +156,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=BATCH)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-decode', action='store_true')
     args = ap.parse_args()
     rank = int(os.environ.get('RANK', 0))
     local = int(os.environ.get('LOCAL_RANK', 0))
@@ -218,6 +242,8 @@ def main():
                       'global_batch': world * args.batch, 'image': '480x640', 'caption_tokens': 20,
                       'parallelism': f'dp{world}', 'final_loss': float(loss)},
            'roofline': roof}
+    if world == 1 and not args.no_decode:
+        out['greedy_decode'] = greedy_decode_bench(model, dev)
     if world == 1 and not args.no_cpu_baseline:
         try:
             out['cpu_baseline'] = cpu_baseline(model)

@@ -700,10 +700,17 @@ extern "C" int gpv_conv2d(const gpv_conv_args* a, void* stream) {
     if (split <= 1) { k.accumulate = 0; k.res = a->y; k.ldr = k.ldc; }
     k.vecA = aligned16(a->w) && (a->Cout % vecel == 0) ? 1 : 0;
     k.vecB = aligned16(a->x) && (a->Cs % vecel == 0) ? 1 : 0;
-    // CONVT needs every N tile inside one tap: BN=64 divides Cin (checked above); force 64-wide tiles
+    // CONVT needs every N tile inside one tap: BN divides Cin (64 always does here; 128 when Cin % 128 == 0)
+    static const int wforce = [] { const char* e = getenv("GPV_FORCE_WGRAD_TILE"); return e ? atoi(e) : 0; }();   // tuning only
     if (a->dtype_in == GPV_BF16) {
-      if (k.M >= 128 && (int64_t)((k.M + 127) / 128) * (k.N / 64) * split >= 384)
-        return launch_cfg<bf16, float, OP_TRANS, OP_CONV, 128, 64>(k, 1, st);
+      const bool can128 = (a->Cin % 128 == 0) && k.M >= 128;
+      int cfg;   // 0: 128x128, 1: 128x64, 2: 64x64
+      if (wforce) cfg = wforce - 1;
+      else if (can128 && (int64_t)((k.M + 127) / 128) * (k.N / 128) * split >= 256) cfg = 0;
+      else if (k.M >= 128 && (int64_t)((k.M + 127) / 128) * (k.N / 64) * split >= 384) cfg = 1;
+      else cfg = 2;
+      if (cfg == 0 && can128) return launch_cfg<bf16, float, OP_TRANS, OP_CONV, 128, 128>(k, 1, st);
+      if (cfg <= 1 && k.M >= 128) return launch_cfg<bf16, float, OP_TRANS, OP_CONV, 128, 64>(k, 1, st);
       return launch_cfg<bf16, float, OP_TRANS, OP_CONV, 64, 64>(k, 1, st);
     }
     return launch_cfg<float, float, OP_TRANS, OP_CONV, 64, 64>(k, 1, st);

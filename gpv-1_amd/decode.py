@@ -1,0 +1,127 @@
+"""KV-cached greedy text decoding, one hipGraph per step (reference: the greedy branch of GPV.forward,
+exp/gpv/models/gpv.py:178-196, which re-runs the whole prefix through the decoder 20 times and re-projects
+the vocabulary embedding on every call).
+
+Per image batch:
+  * once: cross-attention keys/values of the memory for every decoder layer, the vocabulary classifiers W_c
+    (answer_head.py:31-33, batch independent) and the transformed input-embedding table row of ``__cls__``;
+  * per step t: ONE new token per sequence goes through the 3 decoder layers: q/k/v projections of the new row
+    (k, v are written straight into the [B, T, D] caches by the GEMM epilogue: ldc = T*D), single-query attention
+    over the t+1 cached keys and over the memory, FFN, logits for that position, arg-max.
+Because the decoder is causal, the hidden state of position t only depends on tokens <= t: the per-step logits
+are exactly the rows of the reference's final full pass, so ``answer_logits`` (1,B,T,V) is assembled from them.
+
+Every step has static shapes, so it is captured once into a HIP graph (torch.cuda.CUDAGraph == hipGraph on
+ROCm; our kernels are launched on the capturing stream through the C ABI) and replayed: 19+1 graph launches per
+decode instead of ~20 x 60 kernel launches from Python.
+"""
+import torch
+
+from . import hip, ops
+from .ops import RT, W
+
+
+class GreedyKVDecoder:
+    def __init__(self, model, B, Tm, use_graphs=True):
+        self.m = model
+        cfg = model.cfg
+        self.B, self.Tm, self.T = B, Tm, cfg.max_text_len
+        self.D = cfg.text_decoder.hidden_dim
+        self.H = cfg.text_decoder.nheads
+        self.V = len(model.vocab)
+        self.L = len(model.text_decoder.layers)
+        dev = model.vision_token.device
+        dt = RT.dtype
+        D, T = self.D, self.T
+        self.memory = torch.empty(B * Tm, D, device=dev, dtype=dt)
+        self.kc = [torch.zeros(B, T, D, device=dev, dtype=dt) for _ in range(self.L)]
+        self.vc = [torch.zeros(B, T, D, device=dev, dtype=dt) for _ in range(self.L)]
+        self.kvm = [torch.empty(B * Tm, 2 * D, device=dev, dtype=dt) for _ in range(self.L)]
+        self.tok = torch.zeros(B, dtype=torch.long, device=dev)
+        self.logits = torch.empty(B, T, self.V, device=dev, dtype=dt)
+        self.ids = torch.zeros(B, T, dtype=torch.long, device=dev)
+        self.vocab_mask = torch.zeros(self.V, device=dev, dtype=torch.float32)
+        self.wc = torch.empty(self.V, D, device=dev, dtype=dt)          # static: the captured graphs read these addresses
+        self.use_graphs = use_graphs and dev.type == 'cuda'
+        self.graphs = [None] * T
+        self.key = (RT.weights_epoch, RT.static_epoch, dt)
+
+    # ---- once per batch -------------------------------------------------------------------
+    def _prepare(self):
+        m = self.m
+        D = self.D
+        for l, layer in enumerate(m.text_decoder.layers):
+            a = layer.multihead_attn
+            kv = ops.linear(self.memory, W(a.in_proj_weight, a.in_proj_bias, D, 3 * D))     # [B*Tm, 2D] = k | v
+            self.kvm[l].copy_(kv)
+        self.wc.copy_(m.answer_head.classifiers())                                         # [V, D]
+
+    # ---- one decoding step (static shapes for a fixed t) ------------------------------------
+    def _step(self, t):
+        m, B, D, H, T, Tm = self.m, self.B, self.D, self.H, self.T, self.Tm
+        dh = D // H
+        x = m.answer_input_embedings(self.tok)                                              # [B, D]
+        if m.cfg.text_decoder.pos_enc is True:
+            x = ops.add(x, m.pos_enc[0, t:t + 1].to(RT.dtype).contiguous())
+        for l, layer in enumerate(m.text_decoder.layers):
+            sa = layer.self_attn
+            w, b = sa.in_proj_weight, sa.in_proj_bias
+            q = ops.linear(x, W(w, b, 0, D))
+            # k_t, v_t written in place into the caches: row b of the GEMM output lands at cache[b, t, :]
+            kt, vt = self.kc[l][:, t], self.vc[l][:, t]
+            hip.gemm(x, W(w, b, D, 2 * D).lp(), kt, B, D, D, D, D, T * D, bias=W(w, b, D, 2 * D).bias_f32())
+            hip.gemm(x, W(w, b, 2 * D, 3 * D).lp(), vt, B, D, D, D, D, T * D, bias=W(w, b, 2 * D, 3 * D).bias_f32())
+            o = torch.empty(B, D, device=x.device, dtype=RT.dtype)
+            st = ((D, D), (T * D, D), (T * D, D), (D, D))
+            hip.attention_fwd(q, self.kc[l], self.vc[l], o, st, B, H, 1, t + 1, dh, 1.0 / dh ** 0.5)
+            x = layer.norm1(x, sa.out_proj(o))
+            ca = layer.multihead_attn
+            q = ops.linear(x, W(ca.in_proj_weight, ca.in_proj_bias, 0, D))
+            o = torch.empty(B, D, device=x.device, dtype=RT.dtype)
+            kvm = self.kvm[l]
+            st = ((D, D), (Tm * 2 * D, 2 * D), (Tm * 2 * D, 2 * D), (D, D))
+            hip.attention_fwd(q, kvm, kvm[:, D:], o, st, B, H, 1, Tm, dh, 1.0 / dh ** 0.5)
+            x = layer.norm2(x, ca.out_proj(o))
+            x = layer.norm3(x, layer.linear2(layer.linear1(x, ops.ACT_RELU)))
+        lg = ops.matmul_nt(x, self.wc)                                                      # [B, V]
+        self.logits[:, t].copy_(lg)
+        nxt = torch.topk(lg.float() + self.vocab_mask, k=1, dim=-1).indices[:, 0]
+        self.tok.copy_(nxt)
+        if t + 1 < T:
+            self.ids[:, t + 1].copy_(nxt)
+
+    @torch.no_grad()
+    def decode(self, memory, vocab_mask=None):
+        """memory [B, Tm, D] -> (answer_logits [1,B,T,V] incl. the vocab mask like the reference, ids [B,T])"""
+        m = self.m
+        if self.key != (RT.weights_epoch, RT.static_epoch, RT.dtype):       # weights changed: graphs hold stale copies
+            self.graphs = [None] * self.T
+            self.key = (RT.weights_epoch, RT.static_epoch, RT.dtype)
+        self.memory.copy_(memory.reshape(self.B * self.Tm, self.D))
+        self.vocab_mask.zero_()
+        if vocab_mask is not None:
+            self.vocab_mask.copy_(vocab_mask.float())
+        self._prepare()
+        cls = m.word_to_idx['__cls__']
+        self.tok.fill_(cls)
+        self.ids.zero_()
+        self.ids[:, 0] = cls
+        for t in range(self.T):
+            if not self.use_graphs:
+                self._step(t)
+                continue
+            if self.graphs[t] is None:
+                tok_in, ids_in = self.tok.clone(), self.ids.clone()
+                self._step(t)                                   # warm-up (kernel attributes, caches) outside capture
+                torch.cuda.synchronize()
+                self.tok.copy_(tok_in)
+                self.ids.copy_(ids_in)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._step(t)
+                self.graphs[t] = g
+                self.tok.copy_(tok_in)
+                self.ids.copy_(ids_in)
+            self.graphs[t].replay()
+        out = self.logits.float() + self.vocab_mask if vocab_mask is not None else self.logits
+        return out.unsqueeze(0), self.ids.clone()

@@ -144,6 +144,7 @@ class GPV(nn.Module):
         self.lang_token = nn.Parameter(0.1 * torch.randn([cfg.hidden_dim]))
         self.relevance_tokens = nn.Parameter(0.1 * torch.randn([2, cfg.hidden_dim]))
         self.criterion = GPVCriterion(cfg.losses)
+        self._kvdec = {}
         self.pos_enc = nn.Parameter(positionalencoding1d(cfg.text_decoder.hidden_dim, cfg.max_pos_enc_len)
                                     .view(1, cfg.max_pos_enc_len, -1), requires_grad=False)
 
@@ -213,22 +214,36 @@ class GPV(nn.Module):
         B = memory.shape[0]
         dev = memory.device
         if answer_token_ids is None:                                               # greedy, gpv.py:178-196
-            ids = torch.full((B, 1), self.word_to_idx['__cls__'], dtype=torch.long, device=dev)
-            for _ in range(self.cfg.max_text_len - 1):
-                logits = self.decode_text(self.answer_input_embedings(ids), memory)[:, -1].float()
-                if vocab_mask is not None:
-                    logits = logits + vocab_mask
-                ids = torch.cat((ids, torch.topk(logits, k=1, dim=-1).indices), -1)
-            logits = self.decode_text(self.answer_input_embedings(ids), memory)
-            if vocab_mask is not None:
-                logits = logits.float() + vocab_mask
-            outputs['answer_logits'] = logits.unsqueeze(0)
+            if not self.training and self.cfg.get('kv_decode', True):
+                # KV-cached, hipGraph-captured decode step (decode.py): same outputs, 1/20th of the decoder work
+                from .decode import GreedyKVDecoder
+                key = (B, memory.shape[1], str(dev), RT.dtype)
+                dec = self._kvdec.get(key)
+                if dec is None:
+                    dec = self._kvdec[key] = GreedyKVDecoder(self, B, memory.shape[1])
+                outputs['answer_logits'], _ = dec.decode(memory, vocab_mask)
+            else:
+                outputs['answer_logits'] = self.greedy_full_prefix(memory, vocab_mask)
         else:                                                                      # teacher forcing, :197-201
             target = self.answer_input_embedings(answer_token_ids.to(dev))
             outputs['answer_logits'] = self.decode_text(target, memory)[:, :-1].unsqueeze(0)
         if targets is None:
             return outputs
         return self.criterion(outputs, targets)[0]
+
+    def greedy_full_prefix(self, memory, vocab_mask=None):
+        """the reference's own greedy schedule (gpv.py:178-196): full-prefix decoder pass per generated token"""
+        B, dev = memory.shape[0], memory.device
+        ids = torch.full((B, 1), self.word_to_idx['__cls__'], dtype=torch.long, device=dev)
+        for _ in range(self.cfg.max_text_len - 1):
+            logits = self.decode_text(self.answer_input_embedings(ids), memory)[:, -1].float()
+            if vocab_mask is not None:
+                logits = logits + vocab_mask
+            ids = torch.cat((ids, torch.topk(logits, k=1, dim=-1).indices), -1)
+        logits = self.decode_text(self.answer_input_embedings(ids), memory)
+        if vocab_mask is not None:
+            logits = logits.float() + vocab_mask
+        return logits.unsqueeze(0)
 
     @torch.no_grad()
     def forward_beam_search(self, images, queries, beam_size=1):

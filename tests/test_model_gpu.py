@@ -178,3 +178,25 @@ def test_full_size_properties(rt):
         assert torch.isfinite(tr.G).all()
         losses.append(float(loss))
     assert losses[-1] < losses[0], losses
+
+
+@pytest.mark.parametrize('precise', [True, False])
+def test_kv_cached_graph_decode_equals_full_prefix_decode(rt, precise):
+    """KV cache + hipGraph greedy (decode.py) against the reference's own schedule (full prefix per token)."""
+    rt.set_precise(precise)
+    model, _ = build_small()
+    model.to(DEV).eval()
+    images, mask, ids, attn = batch()
+    vm = torch.zeros(V, device=DEV)
+    vm[::3] = -10000.0
+    with torch.no_grad():
+        for vocab_mask in (None, vm):
+            model.cfg['kv_decode'] = True
+            a1 = model(nested(images, mask), (ids, attn), None, None, vocab_mask=vocab_mask)['answer_logits']
+            a2 = model(nested(images, mask), (ids, attn), None, None, vocab_mask=vocab_mask)['answer_logits']   # graph replay
+            model.cfg['kv_decode'] = False
+            b = model(nested(images, mask), (ids, attn), None, None, vocab_mask=vocab_mask)['answer_logits']
+            assert torch.equal(a1, a2)
+            assert rel(a1, b.float().cpu()) < (1e-4 if precise else 2e-2)
+            if precise:
+                assert torch.equal(a1[-1].topk(1, -1).indices, b[-1].topk(1, -1).indices)
