@@ -131,6 +131,8 @@ def greedy_decode_bench(model, dev):
     co-attention -> 20-token KV-cached decode, one hipGraph per step), eval mode, bf16, inputs resident in HBM."""
     from gpv1_amd.misc import NestedTensor
     model.eval()
+    if os.environ.get('GPV_DEBUG_SYNC') == '1' or os.environ.get('GPV_NO_GRAPHS') == '1':
+        model.cfg['kv_graphs'] = False                           # debug aids (hip.py): no capture while synchronising per call
     res = {}
     with torch.no_grad():
         for Bd, iters in ((1, 10), (64, 5)):

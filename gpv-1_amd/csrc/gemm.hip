@@ -28,6 +28,8 @@ constexpr int LDK = 40;  // LDS row pitch in elements (80 B: keeps ds_read_b128 
 
 struct ConvGeom {
   int IH, IW, Cs, Cin, OH, OW, KH, KW, SH, SW, PH, PW, dgrad;
+  int cm;          // stride-2 dgrad: GEMM rows are ordered parity-class-major (4 classes of (OH/2)*(OW/2) pixels per image)
+  int cls_rows;    // rows per parity class = batch * (OH/2) * (OW/2)
 };
 
 struct GemmK {
@@ -95,6 +97,16 @@ template <> struct Raw8<float> {
   }
 };
 
+// GEMM row -> output pixel (row of the NHWC output) ; identity unless the rows are parity-class-major
+__device__ __forceinline__ int conv_row_to_pixel(int m, const ConvGeom& g) {
+  if (!g.cm) return m;
+  const int cls = m / g.cls_rows, rem = m - cls * g.cls_rows;
+  const int hw2 = (g.OH >> 1) * (g.OW >> 1), w2 = g.OW >> 1;
+  const int b = rem / hw2, r2 = rem - b * hw2;
+  const int y2 = r2 / w2, x2 = r2 - y2 * w2;
+  return (b * g.OH + 2 * y2 + (cls >> 1)) * g.OW + 2 * x2 + (cls & 1);
+}
+
 // masking helpers (branch-free: select after an unconditional load from a safe address)
 template <typename T> __device__ __forceinline__ void mask_raw(Raw8<T>& r, bool ok);
 template <> __device__ __forceinline__ void mask_raw<bf16>(Raw8<bf16>& r, bool ok) {
@@ -125,7 +137,7 @@ struct KStage {
       int r = row0 + row;
       rowok[it] = r < nrows;
       if (MODE == OP_CONV) {
-        int rr = rowok[it] ? r : 0;
+        int rr = conv_row_to_pixel(rowok[it] ? r : 0, g);
         int b = rr / (g.OH * g.OW);
         int rem = rr - b * (g.OH * g.OW);
         oh[it] = rem / g.OW;
@@ -307,11 +319,49 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmK p) {
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
     tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
   }
-  const int tm = tile / p.tilesN, tn = tile - tm * p.tilesN;
+  int tm = tile / p.tilesN;
+  const int tn = tile - tm * p.tilesN;
+  if constexpr (AMODE == OP_CONV) {
+    // parity-class-major dgrad: the four classes have different tap counts (0..4 taps); cycle the classes
+    // through consecutive row panels so every XCD's contiguous tile range gets the same mix of work
+    if (p.cg.cm && p.cg.cls_rows % BM == 0) {
+      const int tpc = p.cg.cls_rows / BM;
+      tm = (tm & 3) * tpc + (tm >> 2);
+    }
+  }
   const int row0 = tm * BM, col0 = tn * BN;
   const int batch = blockIdx.z;
 
-  const int kt_total = (p.K + BK - 1) / BK;
+  int kt_total = (p.K + BK - 1) / BK;
+  // stride-2 dgrad with parity-class-major rows: a class-uniform tile only visits its own taps
+  int cm_r0 = 0, cm_s0 = 0, cm_nS = 1, cm_cpt = 1;
+  bool cm_on = false, cm_empty = false;
+  __shared__ int s_rowpix[AMODE == OP_CONV ? BM : 1];   // class-major row -> output pixel (divisions done once per tile row)
+  if constexpr (AMODE == OP_CONV) {
+    if (p.cg.cm && threadIdx.x < BM) s_rowpix[threadIdx.x] = conv_row_to_pixel(min(row0 + (int)threadIdx.x, p.M - 1), p.cg);
+  }
+  if constexpr (AMODE == OP_CONV) {
+    if (p.cg.cm) {
+      const int c_lo = row0 / p.cg.cls_rows, c_hi = min(row0 + BM - 1, p.M - 1) / p.cg.cls_rows;
+      if (c_lo == c_hi) {
+        cm_on = true;
+        cm_r0 = ((c_lo >> 1) + p.cg.PH) & 1;
+        cm_s0 = ((c_lo & 1) + p.cg.PW) & 1;
+        const int nR = (p.cg.KH - cm_r0 + 1) / 2;
+        cm_nS = (p.cg.KW - cm_s0 + 1) / 2;
+        cm_cpt = p.cg.Cin / BK;
+        kt_total = nR * cm_nS * cm_cpt;
+        if (kt_total == 0) { cm_empty = true; kt_total = 1; }   // no tap reaches this class: one fully masked k-tile, dx = res * mask
+      }
+    }
+  }
+  auto kmap = [&](int kt) -> int {      // k-tile index -> offset on the full [taps x Cin] reduction axis
+    if (!cm_on) return kt * BK;
+    if (cm_empty) return p.K;
+    const int t = kt / cm_cpt, c = kt - t * cm_cpt;
+    const int ri = t / cm_nS, si = t - ri * cm_nS;
+    return ((cm_r0 + 2 * ri) * p.cg.KW + cm_s0 + 2 * si) * p.cg.Cin + c * BK;
+  };
   const int kt0 = blockIdx.y * p.kt_per_split;
   const int kt1 = min(kt_total, kt0 + p.kt_per_split);
   if (kt0 >= kt1) return;
@@ -348,8 +398,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmK p) {
 #pragma unroll
   for (int d = 0; d < PF - 1; ++d) {
     if (kt0 + d < kt1) {
-      as.load((kt0 + d) * BK, p.K, p.cg, abuf[d]);
-      bs.load((kt0 + d) * BK, p.K, p.cg, bbuf[d]);
+      as.load(kmap(kt0 + d), p.K, p.cg, abuf[d]);
+      bs.load(kmap(kt0 + d), p.K, p.cg, bbuf[d]);
     }
   }
   as.store(stage_ptr(0, 0), stage_ptr(0, 1), PRECISE, abuf[0]);
@@ -406,8 +456,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmK p) {
       const int t = kt + d;
       if (t < kt1) {
         if (t + PF - 1 < kt1) {
-          as.load((t + PF - 1) * BK, p.K, p.cg, abuf[(d + PF - 1) % PF]);
-          bs.load((t + PF - 1) * BK, p.K, p.cg, bbuf[(d + PF - 1) % PF]);
+          as.load(kmap(t + PF - 1), p.K, p.cg, abuf[(d + PF - 1) % PF]);
+          bs.load(kmap(t + PF - 1), p.K, p.cg, bbuf[(d + PF - 1) % PF]);
         }
         compute(cur);
         if (t + 1 < kt1) {
@@ -501,18 +551,19 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmK p) {
         const int n = col0 + c8 * 8;
         const bool inb = m < p.M && n < p.N;
         const bool full = n + 8 <= p.N;
+        const int64_t mp = (AMODE == OP_CONV && p.cg.cm && inb) ? s_rowpix[m - row0] : m;     // output pixel of this GEMM row
         if (Rp) {
-          if (inb && v_res && full) Vec8IO<TOut>::ld(Rp + (int64_t)m * p.ldr + n, rv[g]);
+          if (inb && v_res && full) Vec8IO<TOut>::ld(Rp + mp * p.ldr + n, rv[g]);
           else {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) rv[g][e] = (inb && n + e < p.N) ? (float)Rp[(int64_t)m * p.ldr + n + e] : 0.f;
+            for (int e = 0; e < 8; ++e) rv[g][e] = (inb && n + e < p.N) ? (float)Rp[mp * p.ldr + n + e] : 0.f;
           }
         }
         if (Mp) {
-          if (inb && v_msk && full) Vec8IO<TOut>::ld(Mp + (int64_t)m * p.ldm + n, mv[g]);
+          if (inb && v_msk && full) Vec8IO<TOut>::ld(Mp + mp * p.ldm + n, mv[g]);
           else {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) mv[g][e] = (inb && n + e < p.N) ? (float)Mp[(int64_t)m * p.ldm + n + e] : 0.f;
+            for (int e = 0; e < 8; ++e) mv[g][e] = (inb && n + e < p.N) ? (float)Mp[mp * p.ldm + n + e] : 0.f;
           }
         }
       }
@@ -545,7 +596,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmK p) {
           if (Mp) x = mv[g][e] > 0.f ? x : 0.f;
           v[e] = x;
         }
-        TOut* dst = Cp + (int64_t)m * p.ldc + n;
+        const int64_t mp = (AMODE == OP_CONV && p.cg.cm && m < p.M) ? s_rowpix[m - row0] : m;
+        TOut* dst = Cp + mp * p.ldc + n;
         if (v_st && full) Vec8IO<TOut>::st(dst, v);
         else {
 #pragma unroll
@@ -664,7 +716,13 @@ extern "C" int gpv_conv2d(const gpv_conv_args* a, void* stream) {
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   GemmK k{};
   k.alpha = 1.0f; k.rowscale = a->rowscale; k.bias = a->bias; k.act = a->act;
-  k.cg = ConvGeom{a->IH, a->IW, a->Cs, a->Cin, a->OH, a->OW, a->KH, a->KW, a->SH, a->SW, a->PH, a->PW, a->mode == 1};
+  k.cg = ConvGeom{a->IH, a->IW, a->Cs, a->Cin, a->OH, a->OW, a->KH, a->KW, a->SH, a->SW, a->PH, a->PW, a->mode == 1, 0, 0};
+  if (a->mode == 1 && a->SH == 2 && a->SW == 2 && a->OH % 2 == 0 && a->OW % 2 == 0) {
+    // stride-2 dgrad: only taps with r = (ih+PH) mod 2, s = (iw+PW) mod 2 contribute.  Order the rows by pixel parity
+    // class so that a tile is class-uniform and skips the other taps (2.25 of 9 on average for a 3x3, 1 of 4 pixels for a 1x1)
+    k.cg.cm = 1;
+    k.cg.cls_rows = a->B * (a->OH / 2) * (a->OW / 2);
+  }
   const int T = a->KH * a->KW;
   const int esz = a->dtype_in == GPV_F32 ? 4 : 2;
   const int64_t vecel = 16 / esz;

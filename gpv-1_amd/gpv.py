@@ -12,6 +12,7 @@ import math
 import re
 
 import numpy as np
+import os
 import torch
 import torch.nn as nn
 
@@ -220,7 +221,7 @@ class GPV(nn.Module):
                 key = (B, memory.shape[1], str(dev), RT.dtype)
                 dec = self._kvdec.get(key)
                 if dec is None:
-                    dec = self._kvdec[key] = GreedyKVDecoder(self, B, memory.shape[1])
+                    dec = self._kvdec[key] = GreedyKVDecoder(self, B, memory.shape[1], use_graphs=self.cfg.get('kv_graphs', True))
                 outputs['answer_logits'], _ = dec.decode(memory, vocab_mask)
             else:
                 outputs['answer_logits'] = self.greedy_full_prefix(memory, vocab_mask)

@@ -271,3 +271,36 @@ def act_fwd(x, y, n, act):
 def act_bwd(dy, ref, dx, n, act, alpha=1.0):
     _chk(lib().gpv_act_bwd(_p(dy), _p(ref), _p(dx), C.c_int64(n), act, C.c_float(alpha), dcode(dy), _stream()),
          'gpv_act_bwd')
+
+
+def _install_debug_sync():
+    """GPV_DEBUG_SYNC=1: print every entry-point call (tensor shapes, scalars) and synchronise after it, so that
+    an asynchronous GPU fault is attributed to the launch that caused it.  Debug aid only."""
+    import functools
+    import sys
+    g = globals()
+
+    def desc(v):
+        if torch.is_tensor(v):
+            return f'{str(v.dtype)[6:]}{list(v.shape)}s{list(v.stride())}'
+        if isinstance(v, (tuple, list)):
+            return '(' + ','.join(desc(x) for x in v) + ')'
+        return repr(v)
+
+    def wrap(name, fn):
+        @functools.wraps(fn)
+        def inner(*a, **k):
+            print('[gpv-hip]', name, ' '.join(desc(x) for x in a), ' '.join(f'{n}={desc(x)}' for n, x in k.items()),
+                  file=sys.stderr, flush=True)
+            r = fn(*a, **k)
+            torch.cuda.synchronize()
+            return r
+        return inner
+    for name, fn in list(g.items()):
+        if callable(fn) and not name.startswith('_') and getattr(fn, '__module__', None) == __name__ \
+                and name not in ('lib', 'dcode') and not isinstance(fn, type):
+            g[name] = wrap(name, fn)
+
+
+if os.environ.get('GPV_DEBUG_SYNC') == '1':
+    _install_debug_sync()
