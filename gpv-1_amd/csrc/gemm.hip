@@ -12,9 +12,10 @@
 //              3 MFMAs per product (hi*hi + hi*lo + lo*hi) -> ~1e-6 relative error.
 // The MFMA is issued with swapped operands (B fragment as the MFMA "A") so that a lane ends up
 // holding 4 CONSECUTIVE columns of one C row -> 8/16-byte epilogue stores.
-#include "common.h"
-#include "../../include/gpv_hip.h"
+#include "gemm_common.h"
 #include <cstdlib>
+
+using namespace gpvk;
 
 #ifndef GPV_PF
 #define GPV_PF 2      /* register prefetch ring depth (tiles). Measured on the ResNet-50 conv shapes (tools/bench_conv.py): 1: 1968 us, 2: 1877 us, 3 (occupancy 3->2): 2136 us */
@@ -22,29 +23,8 @@
 
 namespace {
 
-enum { OP_PLAIN = 0, OP_TRANS = 1, OP_CONV = 2 };
 constexpr int BK = 32;
 constexpr int LDK = 40;  // LDS row pitch in elements (80 B: keeps ds_read_b128 16-B aligned, spreads banks)
-
-struct ConvGeom {
-  int IH, IW, Cs, Cin, OH, OW, KH, KW, SH, SW, PH, PW, dgrad;
-  int cm;          // stride-2 dgrad: GEMM rows are ordered parity-class-major (4 classes of (OH/2)*(OW/2) pixels per image)
-  int cls_rows;    // rows per parity class = batch * (OH/2) * (OW/2)
-};
-
-struct GemmK {
-  const void* A; const void* B; void* C;
-  int M, N, K;
-  int64_t lda, ldb, ldc, sA, sB, sC;
-  float alpha;
-  const float* rowscale; const float* bias;
-  const void* res; int64_t ldr, sR;
-  const void* mask; int64_t ldm;
-  int act; uint32_t dthresh; float dscale; uint64_t seed;
-  int accumulate, split_k, kt_per_split, tilesN;
-  int vecA, vecB;
-  ConvGeom cg;
-};
 
 // ---- 8 staged elements of one operand row -------------------------------------------------
 template <typename T> struct Raw8;
@@ -65,6 +45,7 @@ template <> struct Raw8<bf16> {
     }
   }
   __device__ __forceinline__ uint32_t hi_bits(int i) const { return (w[i >> 1] >> ((i & 1) * 16)) & 0xffffu; }
+  __device__ __forceinline__ float val(int i) const { return __builtin_bit_cast(float, (i & 1) ? (w[i >> 1] & 0xffff0000u) : (w[i >> 1] << 16)); }
   __device__ __forceinline__ uint32_t lo_bits(int) const { return 0u; }
   __device__ __forceinline__ void write(bf16* h, bf16*) const { *reinterpret_cast<uint4*>(h) = make_uint4(w[0], w[1], w[2], w[3]); }
 };
@@ -84,6 +65,7 @@ template <> struct Raw8<float> {
     for (int i = 0; i < 8; ++i) v[i] = i < n ? p[i] : 0.0f;
   }
   __device__ __forceinline__ uint32_t hi_bits(int i) const { return bf_bits(v[i]); }
+  __device__ __forceinline__ float val(int i) const { return v[i]; }
   __device__ __forceinline__ uint32_t lo_bits(int i) const { return bf_bits(v[i] - (float)(bf16)v[i]); }
   __device__ __forceinline__ void write(bf16* h, bf16* l) const {
     uint32_t a[4], b[4];
@@ -96,16 +78,6 @@ template <> struct Raw8<float> {
     *reinterpret_cast<uint4*>(l) = make_uint4(b[0], b[1], b[2], b[3]);
   }
 };
-
-// GEMM row -> output pixel (row of the NHWC output) ; identity unless the rows are parity-class-major
-__device__ __forceinline__ int conv_row_to_pixel(int m, const ConvGeom& g) {
-  if (!g.cm) return m;
-  const int cls = m / g.cls_rows, rem = m - cls * g.cls_rows;
-  const int hw2 = (g.OH >> 1) * (g.OW >> 1), w2 = g.OW >> 1;
-  const int b = rem / hw2, r2 = rem - b * hw2;
-  const int y2 = r2 / w2, x2 = r2 - y2 * w2;
-  return (b * g.OH + 2 * y2 + (cls >> 1)) * g.OW + 2 * x2 + (cls & 1);
-}
 
 // masking helpers (branch-free: select after an unconditional load from a safe address)
 template <typename T> __device__ __forceinline__ void mask_raw(Raw8<T>& r, bool ok);
@@ -208,7 +180,7 @@ struct KStage {
 // Staged ROW-MAJOR exactly as it is loaded (16-B global loads, conflict-free ds_write_b128, pitch COLS+16), and
 // consumed with the gfx950 LDS transpose read: one ds_read_b64_tr_b16 gives a lane 4 consecutive reduction rows of
 // ITS column (verified on hardware by tools/probe/trread.hip); two of them = one 16x16x32 MFMA operand fragment.
-template <typename T, int COLS, int MODE, bool VEC>
+template <typename T, int COLS, int MODE, bool VEC, bool SUM = false>
 struct TStage {
   static constexpr int CHK = COLS / 8;            // 16-B chunks per reduction row
   static constexpr int NIT = (BK * CHK) / 256;    // chunks per thread
@@ -217,10 +189,19 @@ struct TStage {
   const T* ptr; int64_t ld; int col0, ncols;
   int tap_r, tap_s, c0;
   int pb[NIT], poh[NIT], pow_[NIT];      // CONVT: (batch, oh, ow) of this thread's reduction rows, advanced per k-tile
+  float csum[SUM ? NIT : 1][8];          // SUM: running sum over the reduction of this thread's 8 columns (bias gradient)
+  bool do_sum;
 
   __device__ __forceinline__ void init(const T* p, int64_t ld_, int col0_, int ncols_, int k_begin, const ConvGeom& g) {
     ptr = p; ld = ld_; col0 = col0_; ncols = ncols_;
     tap_r = tap_s = c0 = 0;
+    do_sum = false;
+    if constexpr (SUM) {
+#pragma unroll
+      for (int it = 0; it < NIT; ++it)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) csum[it][e] = 0.f;
+    }
     if (MODE == OP_CONV) {
       int tap = col0 / g.Cin;
       c0 = col0 - tap * g.Cin;
@@ -271,7 +252,31 @@ struct TStage {
       const int idx = threadIdx.x + it * 256;
       const int kr = idx / CHK, ch = idx - kr * CHK;
       if (VEC) mask_raw<T>(raw[it], okf[it]);
+      if constexpr (SUM) {
+        if (do_sum) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) csum[it][e] += raw[it].val(e);
+        }
+      }
       raw[it].write(hi + kr * PITCH + ch * 8, lo + kr * PITCH + ch * 8);
+    }
+  }
+  // SUM: add this block's column sums (over its reduction range) to out[col0 + c]; threads with equal column chunk
+  // are reduced with lane shuffles first, then one atomic per column and wave
+  __device__ __forceinline__ void flush_sums(float* out) {
+    if constexpr (SUM) {
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int ch = (threadIdx.x + it * 256) % CHK;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float v = csum[it][e];
+#pragma unroll
+          for (int s = CHK; s < 64; s <<= 1) v += __shfl_xor(v, s);
+          const int col = col0 + ch * 8 + e;
+          if ((threadIdx.x & 63) < CHK && col < ncols) atomicAdd(out + col, v);
+        }
+      }
     }
   }
   // fragment for the 16 columns starting at `cbase` of the staged tile: lane (col = lane&15, g = lane>>4) receives
@@ -313,11 +318,19 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmK p) {
   // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed dispatch rule, used for speed only).  Give every
   // XCD a CONTIGUOUS range of tiles so that the column tiles of one row panel (same A rows / same conv pixels) share
   // one L2 instead of being fetched from HBM once per XCD.  Bijective for any grid size.
-  int tile;
+  // With a split reduction (gridDim.y > 1) the (tile, split) plane is remapped as a whole, split-major: an XCD then
+  // runs ALL tiles of one reduction slice together, so the slice's dy / x rows are fetched from HBM once and shared
+  // through that XCD's L2 (wgrad of a 1x1 conv has only 4..32 output tiles: tile-only remapping left every XCD
+  // with one tile and all slices, i.e. no sharing at all: TCC hit rate 0.6 %).
+  int tile, ksplit;
   {
-    const int nwg = gridDim.x, bid = blockIdx.x;
+    const bool plane = gridDim.z == 1;
+    const int gx = gridDim.x;
+    const int nwg = plane ? gx * (int)gridDim.y : gx, bid = plane ? (int)blockIdx.x + gx * (int)blockIdx.y : (int)blockIdx.x;
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
-    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    ksplit = plane ? v / gx : (int)blockIdx.y;
+    tile = plane ? v - ksplit * gx : v;
   }
   int tm = tile / p.tilesN;
   const int tn = tile - tm * p.tilesN;
@@ -362,18 +375,20 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmK p) {
     const int ri = t / cm_nS, si = t - ri * cm_nS;
     return ((cm_r0 + 2 * ri) * p.cg.KW + cm_s0 + 2 * si) * p.cg.Cin + c * BK;
   };
-  const int kt0 = blockIdx.y * p.kt_per_split;
+  const int kt0 = ksplit * p.kt_per_split;
   const int kt1 = min(kt_total, kt0 + p.kt_per_split);
   if (kt0 >= kt1) return;
 
   const TIn* Ap = reinterpret_cast<const TIn*>(p.A) + (int64_t)batch * p.sA;
   const TIn* Bp = reinterpret_cast<const TIn*>(p.B) + (int64_t)batch * p.sB;
 
-  typedef typename std::conditional<AMODE == OP_TRANS, TStage<TIn, BM, OP_PLAIN, VEC>, KStage<TIn, BM, AMODE, VEC>>::type AStage;
+  constexpr bool ASUM = AMODE == OP_TRANS && BMODE == OP_TRANS;     // linear wgrad: bias gradient = row sums of A (= dY^T)
+  typedef typename std::conditional<AMODE == OP_TRANS, TStage<TIn, BM, OP_PLAIN, VEC, ASUM>, KStage<TIn, BM, AMODE, VEC>>::type AStage;
   typedef typename std::conditional<BMODE == OP_PLAIN, KStage<TIn, BN, OP_PLAIN, VEC>,
                                     TStage<TIn, BN, (BMODE == OP_CONV ? OP_CONV : OP_PLAIN), VEC>>::type BStage;
   AStage as; BStage bs;
   as.init(Ap, p.lda, row0, p.M, kt0 * BK, p.cg);
+  if constexpr (ASUM) as.do_sum = p.a_rowsum != nullptr && tn == 0;
   bs.init(Bp, p.ldb, col0, p.N, kt0 * BK, p.cg);
 
   auto stage_ptr = [&](int s, int which) -> bf16* {  // which: 0 Ahi 1 Alo 2 Bhi 3 Blo
@@ -474,6 +489,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmK p) {
   const TOut* Rp = p.res ? reinterpret_cast<const TOut*>(p.res) + (int64_t)batch * p.sR : nullptr;
   const TOut* Mp = reinterpret_cast<const TOut*>(p.mask);
 
+  if constexpr (ASUM) {
+    if (as.do_sum) as.flush_sums(p.a_rowsum);
+  }
   if (p.accumulate) {
     // ---------------- split-K / accumulate epilogue: fp32 atomics straight from the fragments ----------------
     if constexpr (sizeof(TOut) == 4) {
@@ -686,6 +704,8 @@ extern "C" int gpv_gemm(const gpv_gemm_args* a, void* stream) {
   k.dthresh = a->drop_p > 0.f ? drop_thresh(a->drop_p) : 0u;
   k.dscale = a->drop_p > 0.f ? 1.0f / (1.0f - a->drop_p) : 1.0f;
   k.accumulate = a->accumulate; k.split_k = a->split_k;
+  k.a_rowsum = a->a_rowsum;
+  if (k.a_rowsum && !(a->layoutA == GPV_TRANS && a->layoutB == GPV_TRANS && a->batch == 1)) return (int)hipErrorInvalidValue;
   if (a->accumulate && a->split_k <= 1 && !a->res) {
     // one block owns every output element: C += acc as a coalesced read-modify-write through the LDS epilogue
     // (fp32 atomics run at ~70 G/s: a 10000x768 gradient costs 110 us in atomics alone)
@@ -703,7 +723,11 @@ extern "C" int gpv_gemm(const gpv_gemm_args* a, void* stream) {
   k.vecB = vec_ok(a->B, a->ldb, a->sB, a->layoutB, a->N);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int la = a->layoutA, lb = a->layoutB;
-  if (la == GPV_KMAJOR && lb == GPV_KMAJOR) return launch_dtype<OP_PLAIN, OP_PLAIN>(k, a->batch, a->dtype_in, a->dtype_out, st);
+  if (la == GPV_KMAJOR && lb == GPV_KMAJOR) {
+    const int g = glds_try_launch(k, OP_PLAIN, a->dtype_in, a->dtype_out, a->batch, st);      // 8-wave direct-to-LDS kernel when it qualifies
+    if (g >= 0) return g;
+    return launch_dtype<OP_PLAIN, OP_PLAIN>(k, a->batch, a->dtype_in, a->dtype_out, st);
+  }
   if (la == GPV_KMAJOR && lb == GPV_TRANS) return launch_dtype<OP_PLAIN, OP_TRANS>(k, a->batch, a->dtype_in, a->dtype_out, st);
   if (la == GPV_TRANS && lb == GPV_TRANS) return launch_dtype<OP_TRANS, OP_TRANS>(k, a->batch, a->dtype_in, a->dtype_out, st);
   return (int)hipErrorInvalidValue;
@@ -736,6 +760,10 @@ extern "C" int gpv_conv2d(const gpv_conv_args* a, void* stream) {
     // the stem reads 16-B runs at pixel granularity (Cs = 4 bf16 = 8 B): require 16-B aligned runs
     if ((a->Cs % vecel) != 0) k.vecA = ((a->SW * a->Cs) % vecel == 0 && (a->IW * a->Cs) % vecel == 0 && a->PW == 0) ? k.vecA : 0;
     k.vecB = aligned16(a->w) && (k.K % 8 == 0) ? 1 : 0;
+    if (k.vecA && k.vecB) {
+      const int g = glds_try_launch(k, OP_CONV, a->dtype_in, a->dtype_out, 1, st);
+      if (g >= 0) return g;
+    }
     return launch_dtype<OP_CONV, OP_PLAIN>(k, 1, a->dtype_in, a->dtype_out, st);
   }
   if (a->mode == 2) {

@@ -1,0 +1,47 @@
+// Shared between gemm.hip (register-staged 4-wave kernel, every mode incl. fp32 "precise") and gemm_glds.hip
+// (8-wave direct-to-LDS kernel for the large bf16 GEMM / conv forward / dgrad launches).
+#pragma once
+#include "common.h"
+#include "../../include/gpv_hip.h"
+
+namespace gpvk {
+
+enum { OP_PLAIN = 0, OP_TRANS = 1, OP_CONV = 2 };
+
+struct ConvGeom {
+  int IH, IW, Cs, Cin, OH, OW, KH, KW, SH, SW, PH, PW, dgrad;
+  int cm;          // stride-2 dgrad: GEMM rows are ordered parity-class-major (4 classes of (OH/2)*(OW/2) pixels per image)
+  int cls_rows;    // rows per parity class = batch * (OH/2) * (OW/2)
+};
+
+struct GemmK {
+  const void* A; const void* B; void* C;
+  int M, N, K;
+  int64_t lda, ldb, ldc, sA, sB, sC;
+  float alpha;
+  const float* rowscale; const float* bias;
+  const void* res; int64_t ldr, sR;
+  const void* mask; int64_t ldm;
+  int act; uint32_t dthresh; float dscale; uint64_t seed;
+  int accumulate, split_k, kt_per_split, tilesN;
+  int vecA, vecB;
+  float* a_rowsum;     // TRANS x TRANS only: a_rowsum[m] += sum_k A[m,k]  (bias gradient fused into the weight-gradient GEMM)
+  ConvGeom cg;
+};
+
+// GEMM row -> output pixel (row of the NHWC output) ; identity unless the rows are parity-class-major
+__device__ __forceinline__ int conv_row_to_pixel(int m, const ConvGeom& g) {
+  if (!g.cm) return m;
+  const int cls = m / g.cls_rows, rem = m - cls * g.cls_rows;
+  const int hw2 = (g.OH >> 1) * (g.OW >> 1), w2 = g.OW >> 1;
+  const int b = rem / hw2, r2 = rem - b * hw2;
+  const int y2 = r2 / w2, x2 = r2 - y2 * w2;
+  return (b * g.OH + 2 * y2 + (cls >> 1)) * g.OW + 2 * x2 + (cls & 1);
+}
+
+
+// gemm_glds.hip: launches the 8-wave kernel when the problem qualifies.  Returns 0 = launched, -1 = not applicable
+// (caller falls back to the 4-wave kernel), > 0 = hipError_t.
+int glds_try_launch(const GemmK& k, int amode, int dtype_in, int dtype_out, int batch, hipStream_t st);
+
+}  // namespace gpvk

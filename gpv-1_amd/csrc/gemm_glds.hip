@@ -1,0 +1,367 @@
+// 8-wave direct-to-LDS bf16 GEMM / implicit-GEMM convolution (forward and dgrad) for gfx950.
+//
+//   C[M,N] = epilogue( A[M,K] x B[N,K]^T ),   256 x BN (256 | 128) x 64 tiles, 512 threads = 8 waves,
+//   wave tile 128x64 (BN=256, waves 2x4) or 64x64 (BN=128, waves 4x2), mfma_f32_16x16x32_bf16.
+//
+// Why a second kernel next to gemm.hip: the 4-wave 128x128x32 register-staged kernel tops out at ~550-650 TFLOP/s on
+// large GEMMs (tools/bench_gemm_sq.py): a barrier and a ds_read restart every 32-deep step, 8 LDS fragment reads per
+// 16 MFMAs, the staging registers + ds_write pass in the loop.  Here
+//   * operand rows go HBM/L2 -> LDS with global_load_lds_dwordx4 (no staging VGPRs, no ds_write pass); a k-tile is one
+//     full 128-byte line per operand row, so every request is a whole cache line;
+//   * the LDS image is the lane-linear image the DMA writes (wave instruction = 8 rows x 128 B); bank conflicts are
+//     removed by an XOR swizzle applied on BOTH sides: lane (row r, slot s) FETCHES logical 16-B chunk s^(r&7), the
+//     MFMA fragment read of chunk c of row r looks at slot c^(r&7)  (ds_read_b128 conflict-free, checked by hand for
+//     the hardware's 16-lane service groups);
+//   * two LDS stages, one barrier per 64-deep k-tile; tile t+1 is in flight while tile t is multiplied;
+//   * 128x64 wave tiles: 12 fragment reads per 32 MFMAs.
+// Conv gathers (NHWC, forward or dgrad geometry, stride-2 dgrad parity classes) only change the per-lane SOURCE
+// address; padding taps fetch from a 128-byte line of zeros.
+// The epilogue is the one of gemm.hip (alpha, rowscale, bias, residual, ReLU/GELU, dropout, ReLU-mask; fp32 tile staged
+// through LDS in two halves so that stores and residual/mask loads cover whole rows).
+// bf16 operands only: the fp32 "precise" mode needs the hi/lo split on the way into LDS and stays on gemm.hip.
+#include "gemm_common.h"
+#include <cstdlib>
+
+namespace gpvk {
+namespace {
+
+constexpr int GBK = 64;       // k-tile in elements
+constexpr int ROWB = 128;     // bytes per staged operand row
+constexpr int GBM = 256;
+long g_glds_launches = 0;     // gpv_set_option(GPV_OPT_GLDS_LAUNCHES, .)
+
+__device__ __attribute__((aligned(128))) unsigned char g_zero_line[128];   // device globals are zero-initialised
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void glb_void_t;
+
+__device__ __forceinline__ void glds16(const void* g, unsigned char* l) {
+  __builtin_amdgcn_global_load_lds((glb_void_t*)g, (lds_void_t*)l, 16, 0, 0);
+}
+
+template <int AMODE, int BN, typename TOut>
+__global__ __launch_bounds__(512) void glds_kernel(GemmK p) {
+  constexpr int BM = GBM;
+  constexpr int WN = BN / 64, WM = 8 / WN;
+  constexpr int WTM = BM / WM;                 // 128 | 64
+  constexpr int FM = WTM / 16, FN = 4;
+  constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
+  constexpr int AI = BM / 64, BI = BN / 64;    // global_load_lds instructions per wave and k-tile (8 rows each)
+  extern __shared__ __attribute__((aligned(128))) unsigned char smem[];
+  __shared__ int s_rowpix[AMODE == OP_CONV ? BM : 1];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave - wm * WN;
+  // XCD-aware tile order (see gemm.hip): contiguous tile range per XCD
+  int tile;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  int tm = tile / p.tilesN;
+  const int tn = tile - tm * p.tilesN;
+  if constexpr (AMODE == OP_CONV) {
+    if (p.cg.cm && p.cg.cls_rows % BM == 0) {           // cycle the stride-2 dgrad parity classes through the row panels
+      const int tpc = p.cg.cls_rows / BM;
+      tm = (tm & 3) * tpc + (tm >> 2);
+    }
+  }
+  const int row0 = tm * BM, col0 = tn * BN;
+  const int batch = blockIdx.z;
+
+  // ---- reduction axis: k-tiles of 64; a class-uniform stride-2 dgrad tile only visits its own taps ----
+  int nk = p.K / GBK;
+  int cm_r0 = 0, cm_s0 = 0, cm_nS = 1, cm_cpt = 1;
+  bool cm_on = false, cm_empty = false;
+  if constexpr (AMODE == OP_CONV) {
+    if (p.cg.cm) {
+      if (tid < BM) s_rowpix[tid] = conv_row_to_pixel(min(row0 + tid, p.M - 1), p.cg);
+      const int c_lo = row0 / p.cg.cls_rows, c_hi = min(row0 + BM - 1, p.M - 1) / p.cg.cls_rows;
+      if (c_lo == c_hi) {
+        cm_on = true;
+        cm_r0 = ((c_lo >> 1) + p.cg.PH) & 1;
+        cm_s0 = ((c_lo & 1) + p.cg.PW) & 1;
+        const int nR = (p.cg.KH - cm_r0 + 1) / 2;
+        cm_nS = (p.cg.KW - cm_s0 + 1) / 2;
+        cm_cpt = p.cg.Cin / GBK;
+        nk = nR * cm_nS * cm_cpt;
+        if (nk == 0) { cm_empty = true; nk = 1; }       // no tap reaches this class: one all-zero k-tile, dx = res * mask
+      }
+    }
+  }
+  auto kmap = [&](int kt) -> int {
+    if (!cm_on) return kt * GBK;
+    const int t = kt / cm_cpt, c = kt - t * cm_cpt;
+    const int ri = t / cm_nS, si = t - ri * cm_nS;
+    return ((cm_r0 + 2 * ri) * p.cg.KW + cm_s0 + 2 * si) * p.cg.Cin + c * GBK;
+  };
+
+  // ---- loader state: this lane's rows and its (swizzled) 16-byte chunk ----
+  const int lrow = lane >> 3;
+  const int lchunk = (lane & 7) ^ lrow;                 // logical chunk fetched into slot (lane & 7) of row lrow
+  const bf16* a_ptr[AI];
+  int a_oh[AI], a_ow[AI];
+  const bf16* b_ptr[BI];
+  const bf16* Ab = reinterpret_cast<const bf16*>(p.A) + (int64_t)batch * p.sA;
+  const bf16* Bb = reinterpret_cast<const bf16*>(p.B) + (int64_t)batch * p.sB;
+#pragma unroll
+  for (int j = 0; j < AI; ++j) {
+    const int r = wave * (AI * 8) + j * 8 + lrow;
+    const int m = min(row0 + r, p.M - 1);
+    if constexpr (AMODE == OP_CONV) {
+      const int pix = conv_row_to_pixel(m, p.cg);
+      const int b = pix / (p.cg.OH * p.cg.OW);
+      const int rem = pix - b * (p.cg.OH * p.cg.OW);
+      a_oh[j] = rem / p.cg.OW;
+      a_ow[j] = rem - a_oh[j] * p.cg.OW;
+      a_ptr[j] = Ab + (int64_t)b * p.cg.IH * p.cg.IW * p.cg.Cs + lchunk * 8;
+    } else {
+      a_oh[j] = a_ow[j] = 0;
+      a_ptr[j] = Ab + (int64_t)m * p.lda + lchunk * 8;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < BI; ++j) {
+    const int r = wave * (BI * 8) + j * 8 + lrow;
+    const int n = min(col0 + r, p.N - 1);
+    b_ptr[j] = Bb + (int64_t)n * p.ldb + lchunk * 8;
+  }
+  const bf16* zero_src = reinterpret_cast<const bf16*>(g_zero_line) + (lane & 7) * 8;
+
+  auto issue = [&](int kt, int stage) {
+    const int k0 = kmap(kt);
+    unsigned char* sa = smem + stage * STAGE + wave * (AI * 1024);
+    unsigned char* sb = smem + stage * STAGE + A_BYTES + wave * (BI * 1024);
+    if constexpr (AMODE == OP_CONV) {
+      const ConvGeom& g = p.cg;
+      const int tap = k0 / g.Cin, c0 = k0 - tap * g.Cin;
+      const int tr = tap / g.KW, ts = tap - tr * g.KW;
+#pragma unroll
+      for (int j = 0; j < AI; ++j) {
+        int ih, iw;
+        bool ok = !cm_empty;
+        if (g.dgrad) {                               // strides are 1 or 2 (checked on the host)
+          const int th = a_oh[j] + g.PH - tr, tw = a_ow[j] + g.PW - ts;
+          const int sh = g.SH - 1, sw = g.SW - 1;
+          ih = th >> sh; iw = tw >> sw;
+          ok = ok && th >= 0 && tw >= 0 && ((th & sh) == 0) && ((tw & sw) == 0) && ih < g.IH && iw < g.IW;
+        } else {
+          ih = a_oh[j] * g.SH + tr - g.PH; iw = a_ow[j] * g.SW + ts - g.PW;
+          ok = ok && ih >= 0 && iw >= 0 && ih < g.IH && iw < g.IW;
+        }
+        const bf16* src = a_ptr[j] + (int64_t)(ih * g.IW + iw) * g.Cs + c0;
+        glds16(ok ? src : zero_src, sa + j * 1024);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < AI; ++j) glds16(a_ptr[j] + k0, sa + j * 1024);
+    }
+    const bool bz = (AMODE == OP_CONV) && cm_empty;
+#pragma unroll
+    for (int j = 0; j < BI; ++j) glds16(bz ? zero_src : b_ptr[j] + k0, sb + j * 1024);
+  };
+
+  f32x4 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // fragment addresses: row base + swizzled slot; (row & 7) == (lane & 7) because every fragment starts on a multiple of 16 rows
+  const int frow = lane & 15, fkg = lane >> 4, fsw = lane & 7;
+  const int a_off = (wm * WTM + frow) * ROWB;
+  const int b_off = A_BYTES + (wn * 64 + frow) * ROWB;
+
+  issue(0, 0);
+  for (int t = 0; t < nk; ++t) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // tile t has landed (this wave's pieces) ...
+    __syncthreads();                                      // ... everyone's pieces; and stage (t+1)&1 is no longer being read
+    if (t + 1 < nk) issue(t + 1, (t + 1) & 1);
+    const unsigned char* st = smem + (t & 1) * STAGE;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int slot = ((kk * 4 + fkg) ^ fsw) << 4;
+      bf16x8 af[FM], bfr[FN];
+#pragma unroll
+      for (int j = 0; j < FN; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(st + b_off + j * 16 * ROWB + slot);
+#pragma unroll
+      for (int i = 0; i < FM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(st + a_off + i * 16 * ROWB + slot);
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = mfma16(bfr[j], af[i], acc[i][j]);   // swapped: lane holds 4 consecutive columns
+    }
+  }
+
+  // ---------------- epilogue: fragments -> LDS (fp32, 128 rows at a time) -> whole rows ----------------
+  TOut* Cp = reinterpret_cast<TOut*>(p.C) + (int64_t)batch * p.sC;
+  const TOut* Rp = p.res ? reinterpret_cast<const TOut*>(p.res) + (int64_t)batch * p.sR : nullptr;
+  const TOut* Mp = reinterpret_cast<const TOut*>(p.mask);
+  float* ep = reinterpret_cast<float*>(smem);
+  constexpr int EPITCH = BN + 4;
+  constexpr int HR = 128;
+  constexpr int CH = BN / 8;
+  constexpr int NCH = (HR * CH) / 512;           // 8 | 4 chunks of 8 columns per thread and half
+  const bool v_st = (p.ldc % 8 == 0) && ((reinterpret_cast<uintptr_t>(Cp) & 15) == 0);
+  const bool v_res = Rp && (p.ldr % 8 == 0) && ((reinterpret_cast<uintptr_t>(Rp) & 15) == 0);
+  const bool v_msk = Mp && (p.ldm % 8 == 0) && ((reinterpret_cast<uintptr_t>(Mp) & 15) == 0);
+  float bv[8];
+  {
+    const int nb = col0 + (tid % CH) * 8;          // 512 % CH == 0: a thread always finishes the same 8 columns
+    const bool vb = p.bias && nb + 8 <= p.N && ((reinterpret_cast<uintptr_t>(p.bias) & 15) == 0);
+    if (vb) {
+      const float4 b0 = *reinterpret_cast<const float4*>(p.bias + nb);
+      const float4 b1 = *reinterpret_cast<const float4*>(p.bias + nb + 4);
+      bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w; bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) bv[e] = (p.bias && nb + e < p.N) ? p.bias[nb + e] : 0.f;
+    }
+  }
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    __syncthreads();                                 // main loop / previous half done with the LDS
+    if ((wm * WTM) / HR == half) {
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        const int r = wm * WTM + i * 16 + frow - half * HR;
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+          *reinterpret_cast<f32x4*>(ep + r * EPITCH + wn * 64 + j * 16 + fkg * 4) = acc[i][j];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < NCH; ++g) {
+      const int idx = tid + g * 512;
+      const int r = idx / CH, c8 = idx - r * CH;
+      const int m = row0 + half * HR + r;
+      const int n = col0 + c8 * 8;
+      if (m >= p.M || n >= p.N) continue;
+      const bool full = n + 8 <= p.N;
+      int64_t mp = m;
+      if constexpr (AMODE == OP_CONV) { if (p.cg.cm) mp = s_rowpix[half * HR + r]; }
+      float v[8], rv[8], mv[8];
+      {
+        const float4 a = *reinterpret_cast<const float4*>(ep + r * EPITCH + c8 * 8);
+        const float4 b = *reinterpret_cast<const float4*>(ep + r * EPITCH + c8 * 8 + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+      }
+      if (Rp) {
+        if (v_res && full) Ld8<TOut>::ld(Rp + mp * p.ldr + n, rv);
+        else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) rv[e] = (n + e < p.N) ? (float)Rp[mp * p.ldr + n + e] : 0.f;
+        }
+      }
+      if (Mp) {
+        if (v_msk && full) Ld8<TOut>::ld(Mp + mp * p.ldm + n, mv);
+        else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) mv[e] = (n + e < p.N) ? (float)Mp[mp * p.ldm + n + e] : 0.f;
+        }
+      }
+      const float rs = p.rowscale ? p.rowscale[m] * p.alpha : p.alpha;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float x = v[e] * rs;
+        x += bv[e];
+        if (Rp) x += rv[e];
+        if (p.act == GPV_ACT_RELU) x = fmaxf(x, 0.f);
+        else if (p.act == GPV_ACT_GELU) x = gelu_erf(x);
+        if (p.dthresh) {
+          const uint64_t di = ((uint64_t)batch * p.M + m) * (uint64_t)p.N + (n + e);
+          x = drop_keep(p.seed, di, p.dthresh) ? x * p.dscale : 0.f;
+        }
+        if (Mp) x = mv[e] > 0.f ? x : 0.f;
+        v[e] = x;
+      }
+      TOut* dst = Cp + mp * p.ldc + n;
+      if (v_st && full) Ld8<TOut>::st(dst, v);
+      else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (n + e < p.N) dst[e] = (TOut)v[e];
+      }
+    }
+  }
+}
+
+template <int AMODE, int BN, typename TOut>
+int launch_glds(const GemmK& k, int batch, hipStream_t st) {
+  constexpr size_t stage = (size_t)2 * (GBM + BN) * ROWB;
+  constexpr size_t epi = (size_t)128 * (BN + 4) * 4;
+  constexpr size_t lds = stage > epi ? stage : epi;
+  GemmK p = k;
+  const int tilesM = (p.M + GBM - 1) / GBM;
+  p.tilesN = (p.N + BN - 1) / BN;
+  auto fn = glds_kernel<AMODE, BN, TOut>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    attr_done = true;
+  }
+  dim3 grid(tilesM * p.tilesN, 1, batch);
+  ++g_glds_launches;
+  hipLaunchKernelGGL(fn, grid, dim3(512), lds, st, p);
+  GPV_CHECK_LAUNCH();
+  return 0;
+}
+
+template <int AMODE, int BN>
+int launch_glds_out(const GemmK& k, int dtype_out, int batch, hipStream_t st) {
+  if (dtype_out == GPV_BF16) return launch_glds<AMODE, BN, bf16>(k, batch, st);
+  return launch_glds<AMODE, BN, float>(k, batch, st);
+}
+
+int g_glds_mode = [] { const char* e = getenv("GPV_GLDS"); return e ? atoi(e) : 1; }();   // gpv_set_option(GPV_OPT_GLDS, .)
+
+inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
+
+}  // namespace
+
+int glds_try_launch(const GemmK& k, int amode, int dtype_in, int dtype_out, int batch, hipStream_t st) {
+  const int mode = g_glds_mode;     // 0 = never, 1 (default) = where it is expected to win, 2 = wherever it is legal
+  if (mode == 0 || dtype_in != GPV_BF16) return -1;
+  if (k.accumulate || k.split_k > 1) return -1;
+  if (k.K % GBK != 0 || k.K < GBK || k.N <= 64) return -1;
+  if (!al16(k.A) || !al16(k.B) || k.ldb % 8 != 0 || (batch > 1 && (k.sA % 8 != 0 || k.sB % 8 != 0))) return -1;
+  if (amode == OP_CONV) {
+    if (k.cg.Cin % GBK != 0 || k.cg.Cs % 8 != 0) return -1;
+  } else if (amode == OP_PLAIN) {
+    if (k.lda % 8 != 0) return -1;
+  } else {
+    return -1;
+  }
+  const int bn = k.N > 128 ? 256 : 128;
+  if (mode == 1) {
+    // one 8-wave block per CU: worth it when there is at least ~a chip of 256-row tiles and a real reduction
+    // Measured on the ResNet-50 / transformer shapes at B=32 (tools/bench_conv.py, bench_dgrad.py, bench_gemm_sq.py,
+    // GPV_GLDS=0 vs 2): with 1-2 tiles per CU the 4-wave kernel (3 blocks/CU, epilogues overlapped with other
+    // blocks' main loops) wins unless the reduction is long; stride-2 dgrad classes are too unbalanced for 1 block/CU.
+    const int64_t tiles = (int64_t)((k.M + GBM - 1) / GBM) * ((k.N + bn - 1) / bn) * batch;
+    const bool deep = k.K >= 2048 && tiles >= 128;
+    const bool huge = tiles >= 1024 && k.K >= 512;
+    if (!(deep || huge) || (amode == OP_CONV && k.cg.cm)) return -1;
+  }
+  if (amode == OP_CONV) return bn == 256 ? launch_glds_out<OP_CONV, 256>(k, dtype_out, batch, st) : launch_glds_out<OP_CONV, 128>(k, dtype_out, batch, st);
+  return bn == 256 ? launch_glds_out<OP_PLAIN, 256>(k, dtype_out, batch, st) : launch_glds_out<OP_PLAIN, 128>(k, dtype_out, batch, st);
+}
+
+}  // namespace gpvk
+
+extern "C" int gpv_set_option(int option, int value) {
+  if (option == GPV_OPT_GLDS) {
+    const int prev = gpvk::g_glds_mode;
+    gpvk::g_glds_mode = value;
+    return prev;
+  }
+  if (option == GPV_OPT_GLDS_LAUNCHES) {
+    const long prev = gpvk::g_glds_launches;
+    gpvk::g_glds_launches = value;
+    return (int)prev;
+  }
+  return -1;
+}

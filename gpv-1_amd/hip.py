@@ -27,7 +27,7 @@ class GemmArgs(C.Structure):
                 ('res', C.c_void_p), ('ldr', C.c_int64), ('sR', C.c_int64),
                 ('relu_mask', C.c_void_p), ('ldm', C.c_int64),
                 ('act', C.c_int), ('drop_p', C.c_float), ('seed', C.c_uint64),
-                ('accumulate', C.c_int), ('split_k', C.c_int)]
+                ('accumulate', C.c_int), ('split_k', C.c_int), ('a_rowsum', C.c_void_p)]
 
 
 class ConvArgs(C.Structure):
@@ -66,11 +66,19 @@ def lib():
     return _LIB
 
 
-EXPORTS = ['gpv_abi_version', 'gpv_gemm', 'gpv_conv2d', 'gpv_image_to_nhwc4', 'gpv_maxpool3x3s2',
+EXPORTS = ['gpv_abi_version', 'gpv_set_option', 'gpv_gemm', 'gpv_conv2d', 'gpv_image_to_nhwc4', 'gpv_maxpool3x3s2',
            'gpv_attention_fwd', 'gpv_attention_bwd', 'gpv_layernorm_fwd', 'gpv_layernorm_bwd',
            'gpv_softmax_ce', 'gpv_roi_weights', 'gpv_add', 'gpv_add_rowbcast', 'gpv_colsum', 'gpv_cast',
            'gpv_cast_rowscale_t', 'gpv_prep_conv_weight', 'gpv_embedding', 'gpv_dropout',
            'gpv_relevance_condition', 'gpv_adamw', 'gpv_sumsq', 'gpv_act_fwd', 'gpv_act_bwd']
+
+
+OPT_GLDS, OPT_GLDS_LAUNCHES = 0, 1
+
+
+def set_option(option, value):
+    """gpv_set_option: kernel-selection knob (tests / tuning); returns the previous value"""
+    return lib().gpv_set_option(C.c_int(option), C.c_int(value))
 
 
 def dcode(t):
@@ -106,7 +114,7 @@ def _f32(t):
 
 def gemm(A, B, Cm, M, N, K, lda, ldb, ldc, layoutA=KMAJOR, layoutB=KMAJOR, batch=1, sA=0, sB=0, sC=0,
          alpha=1.0, rowscale=None, bias=None, res=None, ldr=0, sR=0, relu_mask=None, ldm=0, act=ACT_NONE,
-         drop_p=0.0, seed=0, accumulate=False, split_k=1):
+         drop_p=0.0, seed=0, accumulate=False, split_k=1, a_rowsum=None):
     a = GemmArgs()
     a.A, a.B, a.C = _p(A), _p(B), _p(Cm)
     a.M, a.N, a.K, a.batch = M, N, K, batch
@@ -125,6 +133,7 @@ def gemm(A, B, Cm, M, N, K, lda, ldb, ldc, layoutA=KMAJOR, layoutB=KMAJOR, batch
     a.relu_mask, a.ldm = _p(relu_mask), ldm
     a.act, a.drop_p, a.seed = act, drop_p, seed
     a.accumulate, a.split_k = int(accumulate), split_k
+    a.a_rowsum = _p(_f32(a_rowsum))
     _chk(lib().gpv_gemm(C.byref(a), _stream()), 'gpv_gemm')
 
 
@@ -274,8 +283,8 @@ def act_bwd(dy, ref, dx, n, act, alpha=1.0):
 
 
 def _install_debug_sync():
-    """GPV_DEBUG_SYNC=1: print every entry-point call (tensor shapes, scalars) and synchronise after it, so that
-    an asynchronous GPU fault is attributed to the launch that caused it.  Debug aid only."""
+    """GPV_DEBUG_SYNC=1: time (HIP events) and print every entry-point call (tensor shapes, scalars) and synchronise
+    after it: per-call timings, and an asynchronous GPU fault dies right after the launch that caused it.  Debug aid only."""
     import functools
     import sys
     g = globals()
@@ -290,10 +299,13 @@ def _install_debug_sync():
     def wrap(name, fn):
         @functools.wraps(fn)
         def inner(*a, **k):
-            print('[gpv-hip]', name, ' '.join(desc(x) for x in a), ' '.join(f'{n}={desc(x)}' for n, x in k.items()),
-                  file=sys.stderr, flush=True)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
             r = fn(*a, **k)
+            e1.record()
             torch.cuda.synchronize()
+            print('[gpv-hip] %8.1f us' % (e0.elapsed_time(e1) * 1e3), name, ' '.join(desc(x) for x in a),
+                  ' '.join(f'{n}={desc(x)}' for n, x in k.items()), file=sys.stderr, flush=True)
             return r
         return inner
     for name, fn in list(g.items()):

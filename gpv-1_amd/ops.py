@@ -177,10 +177,12 @@ class LinearFn(Function):
             t = torch.empty_like(dz)
             hip.act_bwd(dz, _as_compute(z), t, M * N, ACT_GELU, 1.0)
             dz = t
+        need_b = w.bias is not None and w.bias.requires_grad
         if w.weight.requires_grad:
+            # dW += dz^T x ; the bias gradient (column sums of dz) rides along in the same launch (a_rowsum)
             hip.gemm(dz, x2, w.wgrad(), N, K, M, N, K, K, layoutA=hip.TRANS, layoutB=hip.TRANS, accumulate=True,
-                     split_k=_split_k(N, K, M))
-        if w.bias is not None and w.bias.requires_grad:
+                     split_k=_split_k(N, K, M), a_rowsum=w.bgrad() if need_b else None)
+        elif need_b:
             hip.colsum(dz, w.bgrad(), M, N, N)
         dx = None
         if ctx.needs_input_grad[0]:

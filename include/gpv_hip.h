@@ -37,6 +37,14 @@ extern "C" {
 
 int gpv_abi_version(void); /* = 1 */
 
+/* Kernel-selection knob (process-wide; tests and tuning only; never changes results beyond fp32 summation order).
+ *   option GPV_OPT_GLDS: 0 = 4-wave register-staged GEMM/conv kernel only, 1 (default) = use the 8-wave
+ *   direct-to-LDS kernel where it is expected to win, 2 = wherever it is legal.  Returns the previous value,
+ *   or -1 for an unknown option.  (No reference counterpart: the reference delegates kernel choice to cuDNN/cuBLAS.) */
+#define GPV_OPT_GLDS 0
+#define GPV_OPT_GLDS_LAUNCHES 1 /* returns the number of 8-wave launches so far, then sets the counter to value */
+int gpv_set_option(int option, int value);
+
 /* ---------------------------------------------------------------------------------------------
  * GEMM with fused epilogue:   C[b] = epi( alpha * A[b] x B[b]^T )        b = 0..batch-1
  *   A: M x K (layoutA), B: N x K (layoutB), C: M x N row-major (ldc), dtype_out.
@@ -63,6 +71,9 @@ typedef struct {
   int act;
   float drop_p; uint64_t seed;    /* inverted dropout after act; drop_p = 0 disables */
   int accumulate, split_k;
+  float* a_rowsum;                /* layoutA = layoutB = GPV_TRANS only, or NULL: a_rowsum[m] += sum_k A[m,k]  (atomic).
+                                     Weight-gradient GEMMs pass dY as A, so this is the bias gradient
+                                     (sum over tokens), fused instead of a separate gpv_colsum launch. */
 } gpv_gemm_args;
 int gpv_gemm(const gpv_gemm_args* a, void* stream);
 

@@ -95,6 +95,21 @@ def test_gemm_trans_layouts_and_splitk(dtype):
     assert rel(dF, Wg[:, :, :Pn].float().transpose(1, 2) @ dO.float()) < TOL[dtype]
 
 
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('N,K,M,split', [(256, 256, 9600, 8), (768, 3072, 640, 1), (2, 256, 3200, 4), (100, 72, 333, 3), (2048, 256, 3200, 2)])
+def test_gemm_wgrad_with_fused_bias_grad(dtype, N, K, M, split):
+    """dW[N,K] += dY^T X and db[N] += colsum(dY) in one launch (a_rowsum), split-K and single-pass variants"""
+    h = hip()
+    dy, x = rnd(M, N, dtype=dtype, seed=40), rnd(M, K, dtype=dtype, seed=41)
+    dw0, db0 = rnd(N, K, seed=42), rnd(N, seed=43)
+    dw, db = dw0.clone(), db0.clone()
+    h.gemm(dy, x, dw, N, K, M, N, K, K, layoutA=h.TRANS, layoutB=h.TRANS, accumulate=True, split_k=split, a_rowsum=db)
+    refw = dw0 + dy.float().t() @ x.float()
+    refb = db0 + dy.float().sum(0)
+    assert rel(dw, refw) < (3e-5 if dtype == torch.float32 else 3e-3)
+    assert rel(db, refb) < 1e-5                                      # exact fp32 sums of the stored values
+
+
 def test_gemm_dropout_epilogue():
     h = hip()
     M, N, K = 512, 512, 64
@@ -187,6 +202,70 @@ def test_stem_conv_image_prep_and_maxpool(dtype):
     z = torch.empty(Bn, PH, PW, 64, device=DEV, dtype=dtype)
     h.maxpool3x3s2(y, z, Bn, OH, OW, 64, PH, PW)
     assert torch.equal(z.float(), nhwc(F.max_pool2d(y.float().permute(0, 3, 1, 2), 3, 2, 1)))
+
+
+# ------------------------------------------------------------- 8-wave direct-to-LDS kernel (gemm_glds.hip)
+@pytest.fixture()
+def glds():
+    """force the 8-wave kernel wherever it is legal (by default it only takes the large launches) and count its launches"""
+    h = hip()
+    prev = h.set_option(h.OPT_GLDS, 2)
+    h.set_option(h.OPT_GLDS_LAUNCHES, 0)
+    yield h
+    h.set_option(h.OPT_GLDS, prev)
+
+
+@pytest.mark.parametrize('M,N,K', [(300, 256, 256), (2048, 512, 768), (1000, 128, 192), (257, 130, 64), (9600, 256, 2048),
+                                   (70, 384, 128), (513, 100, 320)])
+def test_glds_gemm_plain(glds, M, N, K):
+    A, B = rnd(M, K, dtype=torch.bfloat16, seed=1), rnd(N, K, dtype=torch.bfloat16, seed=2)
+    Cm = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    glds.gemm(A, B, Cm, M, N, K, K, K, N)
+    assert glds.set_option(glds.OPT_GLDS_LAUNCHES, 0) == 1
+    assert rel(Cm, A.float() @ B.float().t()) < TOL[torch.bfloat16]
+    Cf = torch.zeros(M, N + 8, device=DEV)                         # fp32 output, strided C
+    glds.gemm(A, B, Cf, M, N, K, K, K, N + 8)
+    assert glds.set_option(glds.OPT_GLDS_LAUNCHES, 0) == 1
+    assert rel(Cf[:, :N], A.float() @ B.float().t()) < 1e-5
+    assert Cf[:, N:].abs().max() == 0
+
+
+def test_glds_gemm_epilogue_and_batch(glds):
+    h, dtype = glds, torch.bfloat16
+    Bt, M, N, K = 3, 200, 192, 192
+    A, B = rnd(Bt, M, K, dtype=dtype, seed=3), rnd(Bt, N, K, dtype=dtype, seed=4)
+    bias, rs = rnd(N, seed=5), rnd(M, seed=6)
+    res = rnd(Bt, M, N, dtype=dtype, seed=7)
+    mask = rnd(M, N, dtype=dtype, seed=8)
+    for act, fn in ((h.ACT_NONE, lambda x: x), (h.ACT_RELU, F.relu), (h.ACT_GELU, lambda x: F.gelu(x))):
+        Cm = torch.empty(Bt, M, N, device=DEV, dtype=dtype)
+        h.gemm(A, B, Cm, M, N, K, K, K, N, batch=Bt, sA=M * K, sB=N * K, sC=M * N, alpha=0.5, rowscale=rs, bias=bias,
+               res=res, ldr=N, sR=M * N, relu_mask=mask, ldm=N, act=act)
+        ref = fn(0.5 * (A.float() @ B.float().transpose(1, 2)) * rs[None, :, None] + bias + res.float())
+        ref = ref * (mask.float() > 0)
+        assert rel(Cm, ref) < TOL[dtype], act
+    assert h.set_option(h.OPT_GLDS_LAUNCHES, 0) == 3
+    # dropout epilogue: same keep pattern as the 4-wave kernel (counter-hash of the element index)
+    M, N, K = 512, 256, 128
+    A, B = rnd(M, K, dtype=dtype, seed=9), rnd(N, K, dtype=dtype, seed=10)
+    c1, c2 = torch.empty(M, N, device=DEV, dtype=dtype), torch.empty(M, N, device=DEV, dtype=dtype)
+    h.gemm(A, B, c1, M, N, K, K, K, N, drop_p=0.25, seed=77)
+    h.set_option(h.OPT_GLDS, 0)
+    h.gemm(A, B, c2, M, N, K, K, K, N, drop_p=0.25, seed=77)
+    h.set_option(h.OPT_GLDS, 2)
+    assert torch.equal(c1 == 0, c2 == 0) and rel(c1, c2.float()) < 1e-2
+
+
+GCONVS = [  # Cin, Cout, k, stride, pad, H, W   (Cin % 64 == 0 both ways, Cout > 64)
+    (64, 128, 1, 1, 0, 24, 32), (256, 128, 3, 2, 1, 24, 32), (128, 128, 3, 1, 1, 15, 20), (256, 512, 1, 2, 0, 30, 40),
+    (512, 2048, 1, 1, 0, 15, 20), (128, 256, 3, 2, 1, 17, 23), (128, 192, 3, 2, 1, 32, 32)]
+
+
+@pytest.mark.parametrize('Cin,Cout,k,s,p,H,W', GCONVS)
+def test_glds_conv_fwd_dgrad(glds, Cin, Cout, k, s, p, H, W):
+    test_conv_fwd_dgrad_wgrad(torch.bfloat16, Cin, Cout, k, s, p, H, W)
+    # forward (N = Cout) + dgrad (N = Cin); N <= 64 and the wgrad stay on the 4-wave kernel
+    assert glds.set_option(glds.OPT_GLDS_LAUNCHES, 0) == int(Cout > 64) + int(Cin > 64)
 
 
 # ----------------------------------------------------------------------------------------- attention

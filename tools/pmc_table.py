@@ -1,0 +1,14 @@
+"""pivot a rocprofv3 --pmc counter_collection.csv: mean counter value per (kernel, grid) over the last dispatches"""
+import csv, glob, sys, collections
+rows = []
+for f in glob.glob(sys.argv[1] + '/**/*counter_collection.csv', recursive=True):
+    rows += list(csv.DictReader(open(f)))
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for r in rows:
+    k = (r['Kernel_Name'].replace('(anonymous namespace)::', '')[:70], r.get('Grid_Size', ''), r.get('LDS_Block_Size', ''))
+    agg[k][r['Counter_Name']].append(float(r['Counter_Value']))
+names = sorted({c for v in agg.values() for c in v})
+print('kernel | grid | ' + ' | '.join(names))
+for k, v in agg.items():
+    if 'gemm_kernel' not in k[0]: continue
+    print(k[0][-40:], '|', k[1], '| ' + ' | '.join('%.4g' % (sum(v[c]) / len(v[c])) if c in v else '-' for c in names))
