@@ -69,27 +69,37 @@ def ensure_grad(p):
 # --------------------------------------------------------------------------------------------
 # weight references
 # --------------------------------------------------------------------------------------------
-def _lp_pair(p):
-    """(W [N,K], W^T [K,N]) of a 2-D (or [N,K,1,1]) parameter in the compute dtype, cached per epoch."""
+def _lp(p):
+    """W [N,K] of a 2-D (or [N,K,1,1]) parameter in the compute dtype.
+
+    precise mode: the fp32 parameter itself.  bf16 mode: parameters a FlatTrainer manages carry ``_gpv_lp`` -- a view
+    into the trainer's flat bf16 mirror that the AdamW kernel rewrites in the same pass as the fp32 master weight (no
+    cast launches per step); everything else (frozen weights, inference without a trainer) is cast once per epoch.
+    No transposed copy exists: backward-data GEMMs read W as a reduction-major operand (GPV_TRANS), which the kernel
+    stages with the LDS transpose read at the same speed (tools/bench_dx_layout.py)."""
+    N = p.shape[0]
+    K = p.numel() // N
+    if RT.dtype == torch.float32:
+        src = p.detach().reshape(N, K)
+        return src if src.is_contiguous() else src.contiguous()
+    lp = getattr(p, '_gpv_lp', None)
+    if lp is not None:
+        if p._gpv_lp_static != RT.static_epoch:          # load_state_dict / manual edit since the mirror was written
+            hip.cast(p._gpv_flat, lp, lp.numel())
+            p._gpv_lp_static = RT.static_epoch
+        return lp.view(N, K)
     key = ('lin', id(p), RT.dtype)
     hit = RT.cache.get(key)
     ep = RT.epoch_of(p)
     if hit is not None and hit[0] == ep:
-        return hit[1], hit[2]
-    N = p.shape[0]
-    K = p.numel() // N
+        return hit[1]
     src = p.detach().reshape(N, K)
     if not src.is_contiguous():
         src = src.contiguous()
-    wt = torch.empty(K, N, device=p.device, dtype=RT.dtype)
-    if RT.dtype == torch.float32:
-        w = src
-        hip.cast_rowscale_t(src, None, None, wt, N, K)
-    else:
-        w = torch.empty(N, K, device=p.device, dtype=RT.dtype)
-        hip.cast_rowscale_t(src, None, w, wt, N, K)
-    RT.cache[key] = (ep, w, wt)
-    return w, wt
+    w = torch.empty(N, K, device=p.device, dtype=RT.dtype)
+    hip.cast(src, w, N * K)
+    RT.cache[key] = (ep, w)
+    return w
 
 
 class W:
@@ -104,12 +114,7 @@ class W:
         self.K = weight.numel() // weight.shape[0]
 
     def lp(self):
-        w, _ = _lp_pair(self.weight)
-        return w[self.r0:self.r1]                     # [N, K] contiguous rows, ld = K
-
-    def lpT(self):
-        _, wt = _lp_pair(self.weight)
-        return wt[:, self.r0:self.r1]                 # [K, N] view, ld = Ntot
+        return _lp(self.weight)[self.r0:self.r1]      # [N, K] contiguous rows, ld = K
 
     def bias_f32(self):
         return None if self.bias is None else self.bias.detach()[self.r0:self.r1]
@@ -187,7 +192,7 @@ class LinearFn(Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(M, K, device=dz.device, dtype=RT.dtype)
-            hip.gemm(dz, w.lpT(), dx, M, K, N, N, w.Ntot, K)
+            hip.gemm(dz, w.lp(), dx, M, K, N, N, K, K, layoutB=hip.TRANS)      # dx = dz W, W read reduction-major
             dx = dx.reshape(ctx.xshape)
         return dx, None, None, None, None, None
 

@@ -69,6 +69,7 @@ class FlatTrainer:
         self.G = torch.zeros_like(self.P)
         self.M = torch.zeros_like(self.P)
         self.V = torch.zeros_like(self.P)
+        self.Pb = torch.zeros(off, device=dev, dtype=torch.bfloat16)      # bf16 mirror of P, rewritten by the AdamW kernel
         self.touched = torch.zeros(len(self.entries), dtype=torch.bool)
         self._touched_dev = torch.zeros(len(self.entries), device=dev, dtype=torch.int32)
         for i, (n, p, g, o, k) in enumerate(self.entries):
@@ -77,6 +78,8 @@ class FlatTrainer:
             p.data = pv
             p.grad = gv
             p._gpv_managed = True                                                  # compute copies follow weights_epoch
+            p._gpv_flat, p._gpv_lp = self.P[o:o + k], self.Pb[o:o + k]            # fp32 master / bf16 mirror segments
+            p._gpv_lp_static = -1                                                  # mirror not yet written (ops._lp casts on first use)
             p._gpv_touch = (lambda i=i: self._mark(i))                            # kernel-accumulated gradients
             p.register_hook(lambda grad, i=i: self._mark(i))                       # autograd-delivered gradients
         self.gsq = torch.zeros(1, device=dev, dtype=torch.float32)
@@ -142,7 +145,7 @@ class FlatTrainer:
         bc1, bc2 = 1 - b1 ** t, 1 - b2 ** t
         for g, s, e in self._ranges(lambda g: True):
             clip_here = use_clip and g in ('detr_backbone', 'detr_head')
-            hip.adamw(self.P[s:e], self.G[s:e], self.M[s:e], self.V[s:e], None, e - s, self.lr[g] * sched, b1, b2,
+            hip.adamw(self.P[s:e], self.G[s:e], self.M[s:e], self.V[s:e], self.Pb[s:e], e - s, self.lr[g] * sched, b1, b2,
                       self.eps, self.wd, bc1, bc2, self.gscale if clip_here else None)
         RT.bump_weights(everything=False)
 

@@ -200,3 +200,30 @@ def test_kv_cached_graph_decode_equals_full_prefix_decode(rt, precise):
             assert rel(a1, b.float().cpu()) < (1e-4 if precise else 2e-2)
             if precise:
                 assert torch.equal(a1[-1].topk(1, -1).indices, b[-1].topk(1, -1).indices)
+
+
+def test_trainer_bf16_weight_mirror_tracks_master_weights(rt):
+    """bf16 compute weights are written by the AdamW kernel next to the fp32 master copy (no cast launches per step);
+    they must equal bf16(master) after optimizer steps and after an external edit of the weights."""
+    import gpv1_amd.ops as ops
+    from gpv1_amd.train import FlatTrainer
+    rt.set_precise(False)
+    model, _ = build_small()
+    model.to(DEV).train()
+    tr = FlatTrainer(model, lr=1e-3, lr_backbone=1e-4)
+    images, mask, ids, attn = batch()
+    for _ in range(2):
+        model.bert.model.p = 0.0
+        loss = tr.train_step(nested(images, mask), (ids, attn), gpu_targets())
+        assert torch.isfinite(loss)
+    checked = 0
+    for n, p in model.named_parameters():
+        if getattr(p, '_gpv_lp', None) is not None and p.dim() == 2:
+            assert torch.equal(ops._lp(p), p.detach().to(torch.bfloat16)), n
+            checked += 1
+    assert checked > 50, checked
+    p0 = model.text_decoder.layers[0].linear1.weight
+    with torch.no_grad():
+        p0.mul_(2.0)
+    ops.RT.bump_weights()                        # what load_state_dict / .to() do
+    assert torch.equal(ops._lp(p0), p0.detach().to(torch.bfloat16))
