@@ -148,6 +148,19 @@ class BertModel(nn.Module):
             if isinstance(m, LinearP) and m.bias is not None:
                 nn.init.zeros_(m.bias)
 
+    @staticmethod
+    def _qkv(sa):
+        """packed query/key/value projection of one layer in the compute dtype (BERT is frozen: cached per static epoch)"""
+        RT = ops.RT
+        key = ('bert_qkv', id(sa), RT.dtype)
+        hit = RT.cache.get(key)
+        if hit is not None and hit[0] == RT.static_epoch:
+            return hit[1], hit[2]
+        w = torch.cat([sa.query.weight, sa.key.weight, sa.value.weight]).detach().to(RT.dtype).contiguous()
+        b = torch.cat([sa.query.bias, sa.key.bias, sa.value.bias]).detach().float().contiguous()
+        RT.cache[key] = (RT.static_epoch, w, b)
+        return w, b
+
     @torch.no_grad()
     def forward(self, input_ids, attention_mask):
         B, T = input_ids.shape
@@ -165,8 +178,10 @@ class BertModel(nn.Module):
         kpm = (attention_mask == 0).to(torch.uint8).contiguous()
         for l in self.encoder.layer:
             sa = l.attention.self
-            q, k, v = sa.query(x), sa.key(x), sa.value(x)
-            a = ops.attention([q, k, v], ((0, 0), (1, 0), (2, 0)), B, H, T, T, D // H, kpm=kpm, drop_p=p)
+            wqkv, bqkv = self._qkv(sa)                     # one [3D, D] GEMM instead of three (frozen weights: cached)
+            qkv = torch.empty(B * T, 3 * D, device=x.device, dtype=ops.RT.dtype)
+            hip.gemm(x, wqkv, qkv, B * T, 3 * D, D, D, D, 3 * D, bias=bqkv)
+            a = ops.attention([qkv], ((0, 0), (0, D), (0, 2 * D)), B, H, T, T, D // H, kpm=kpm, drop_p=p)
             x = l.attention.output.LayerNorm(x, l.attention.output.dense(a), p)
             h = l.intermediate.dense(x, ops.ACT_GELU)
             x = l.output.LayerNorm(x, l.output.dense(h), p)
