@@ -486,6 +486,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmK p) {
   }
 
   TOut* Cp = reinterpret_cast<TOut*>(p.C) + (int64_t)batch * p.sC;
+  int64_t ldc = p.ldc;
+  if (p.ws != nullptr) {            // split reduction through a workspace: this split's partial product is a dense [M,N] slab
+    Cp = reinterpret_cast<TOut*>(p.ws) + (int64_t)ksplit * p.M * p.N;
+    ldc = p.N;
+  }
   const TOut* Rp = p.res ? reinterpret_cast<const TOut*>(p.res) + (int64_t)batch * p.sR : nullptr;
   const TOut* Mp = reinterpret_cast<const TOut*>(p.mask);
 
@@ -503,7 +508,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmK p) {
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
           const int n = col0 + wn * (BN / 2) + j * 16 + (lane >> 4) * 4;
-          float* dst = reinterpret_cast<float*>(Cp) + (int64_t)m * p.ldc + n;
+          float* dst = reinterpret_cast<float*>(Cp) + (int64_t)m * ldc + n;
 #pragma unroll
           for (int r = 0; r < 4; ++r)
             if (n + r < p.N) atomicAdd(dst + r, acc[i][j][r] * rs);
@@ -521,7 +526,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmK p) {
   constexpr int HR = BM / 2;
   constexpr int CH = BN / 8;
   constexpr int NCH = (HR * CH) / 256;
-  const bool v_st = (p.ldc % 8 == 0) && ((reinterpret_cast<uintptr_t>(Cp) & 15) == 0);
+  const bool v_st = (ldc % 8 == 0) && ((reinterpret_cast<uintptr_t>(Cp) & 15) == 0);
   const bool v_res = Rp && (p.ldr % 8 == 0) && ((reinterpret_cast<uintptr_t>(Rp) & 15) == 0);
   const bool v_msk = Mp && (p.ldm % 8 == 0) && ((reinterpret_cast<uintptr_t>(Mp) & 15) == 0);
   // every chunk this thread finishes covers the SAME 8 columns (256 % CH == 0): fetch their bias once
@@ -615,13 +620,39 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmK p) {
           v[e] = x;
         }
         const int64_t mp = (AMODE == OP_CONV && p.cg.cm && m < p.M) ? s_rowpix[m - row0] : m;
-        TOut* dst = Cp + mp * p.ldc + n;
+        TOut* dst = Cp + mp * ldc + n;
         if (v_st && full) Vec8IO<TOut>::st(dst, v);
         else {
 #pragma unroll
           for (int e = 0; e < 8; ++e)
             if (n + e < p.N) dst[e] = (TOut)v[e];
         }
+      }
+    }
+  }
+}
+
+// C[m, n] += sum_s ws[s][m][n]   (second pass of a workspace split reduction; 4 columns per thread)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int nsplit, int M, int N, float* __restrict__ C,
+                                                            int64_t ldc) {
+  const int64_t slab = (int64_t)M * N;
+  const int nq = (N + 3) / 4;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < (int64_t)M * nq; i += (int64_t)gridDim.x * blockDim.x) {
+    const int m = (int)(i / nq), n = (int)(i - (int64_t)m * nq) * 4;
+    const float* src = ws + (int64_t)m * N + n;
+    float* dst = C + (int64_t)m * ldc + n;
+    if (n + 4 <= N && (N & 3) == 0 && (ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0) {
+      float4 a = *reinterpret_cast<const float4*>(dst);
+      for (int s = 0; s < nsplit; ++s) {
+        const float4 v = *reinterpret_cast<const float4*>(src + s * slab);
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+      }
+      *reinterpret_cast<float4*>(dst) = a;
+    } else {
+      for (int e = 0; e < 4 && n + e < N; ++e) {
+        float a = dst[e];
+        for (int s = 0; s < nsplit; ++s) a += src[s * slab + e];
+        dst[e] = a;
       }
     }
   }
@@ -639,6 +670,17 @@ int launch_cfg_v(const GemmK& k, int batch, hipStream_t st) {
   if (split > kt_total) split = kt_total;
   p.kt_per_split = (kt_total + split - 1) / split;
   split = (kt_total + p.kt_per_split - 1) / p.kt_per_split;
+  // Split reduction without atomics when the caller lent a workspace: every split writes its partial [M,N] product
+  // with the normal coalesced epilogue, a second tiny kernel adds the slabs to C.  fp32 atomics on C cost
+  // outputs x splits / ~94e9 s (67 us for the 128x512 gradient of a layer2 1x1 conv at its best split of 96).
+  p.ws = nullptr;
+  bool two_pass = false;
+  if (p.accumulate && split > 1 && batch == 1 && k.ws_base != nullptr && sizeof(TOut) == 4 &&
+      (int64_t)split * p.M * p.N * 4 <= k.ws_bytes) {
+    two_pass = true;
+    p.ws = reinterpret_cast<float*>(k.ws_base);
+    p.accumulate = 0; p.res = nullptr; p.mask = nullptr; p.bias = nullptr; p.act = 0; p.dthresh = 0;
+  }
   auto fn = gemm_kernel<TIn, TOut, AMODE, BMODE, BM, BN, VEC>;
   static bool attr_done = false;
   if (lds > 64 * 1024 && !attr_done) {
@@ -649,6 +691,13 @@ int launch_cfg_v(const GemmK& k, int batch, hipStream_t st) {
   dim3 grid(tilesM * p.tilesN, split, batch);
   hipLaunchKernelGGL(fn, grid, dim3(256), lds, st, p);
   GPV_CHECK_LAUNCH();
+  if (two_pass) {
+    const int64_t quads = (int64_t)p.M * ((p.N + 3) / 4);
+    const int blocks = (int)((quads + 255) / 256 < 2048 ? (quads + 255) / 256 : 2048);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, p.ws, split, p.M, p.N,
+                       reinterpret_cast<float*>(p.C), p.ldc);
+    GPV_CHECK_LAUNCH();
+  }
   return 0;
 }
 
@@ -705,6 +754,7 @@ extern "C" int gpv_gemm(const gpv_gemm_args* a, void* stream) {
   k.dscale = a->drop_p > 0.f ? 1.0f / (1.0f - a->drop_p) : 1.0f;
   k.accumulate = a->accumulate; k.split_k = a->split_k;
   k.a_rowsum = a->a_rowsum;
+  k.ws_base = a->workspace; k.ws_bytes = a->workspace ? a->workspace_bytes : 0;
   if (k.a_rowsum && !(a->layoutA == GPV_TRANS && a->layoutB == GPV_TRANS && a->batch == 1)) return (int)hipErrorInvalidValue;
   if (a->accumulate && a->split_k <= 1 && !a->res) {
     // one block owns every output element: C += acc as a coalesced read-modify-write through the LDS epilogue
@@ -776,14 +826,25 @@ extern "C" int gpv_conv2d(const gpv_conv_args* a, void* stream) {
     k.accumulate = 1;
     int split = a->split_k;
     if (split < 1) {
-      int64_t tiles = (int64_t)((k.M + 63) / 64) * ((k.N + 63) / 64);
-      int64_t want = 1536 / (tiles > 0 ? tiles : 1);
-      int kt = (k.K + BK - 1) / BK;
+      const int kt = (k.K + BK - 1) / BK;
+      int64_t want;
+      if (a->workspace && a->Cin % 128 == 0 && k.M >= 128) {
+        // two-pass reduction (no atomics): ~2 blocks of 128x128 per CU is the measured optimum on the layer2-4 shapes
+        // (tools/bench_split_conv.py: 64..96 / 64 / 32 / 16 / 8 / 4 splits for 4 / 9 / 16 / 36 / 64 / 144 tiles)
+        const int64_t t128 = (int64_t)((k.M + 127) / 128) * (k.N / 128);
+        want = (544 + t128 / 2) / t128;
+        if (want > 96) want = 96;
+        while (want > 1 && want * (int64_t)k.M * k.N * 4 > a->workspace_bytes) --want;
+      } else {
+        const int64_t tiles = (int64_t)((k.M + 63) / 64) * ((k.N + 63) / 64);
+        want = 1536 / (tiles > 0 ? tiles : 1);
+      }
       if (want > kt / 8) want = kt / 8;
       split = want < 1 ? 1 : (int)want;
     }
     k.split_k = split;
     if (split <= 1) { k.accumulate = 0; k.res = a->y; k.ldr = k.ldc; }
+    k.ws_base = a->workspace; k.ws_bytes = a->workspace ? a->workspace_bytes : 0;
     k.vecA = aligned16(a->w) && (a->Cout % vecel == 0) ? 1 : 0;
     k.vecB = aligned16(a->x) && (a->Cs % vecel == 0) ? 1 : 0;
     // CONVT needs every N tile inside one tap: BN divides Cin (64 always does here; 128 when Cin % 128 == 0)

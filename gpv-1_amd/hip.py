@@ -27,7 +27,8 @@ class GemmArgs(C.Structure):
                 ('res', C.c_void_p), ('ldr', C.c_int64), ('sR', C.c_int64),
                 ('relu_mask', C.c_void_p), ('ldm', C.c_int64),
                 ('act', C.c_int), ('drop_p', C.c_float), ('seed', C.c_uint64),
-                ('accumulate', C.c_int), ('split_k', C.c_int), ('a_rowsum', C.c_void_p)]
+                ('accumulate', C.c_int), ('split_k', C.c_int), ('workspace', C.c_void_p), ('workspace_bytes', C.c_int64),
+                ('a_rowsum', C.c_void_p)]
 
 
 class ConvArgs(C.Structure):
@@ -37,7 +38,7 @@ class ConvArgs(C.Structure):
                 ('KH', C.c_int), ('KW', C.c_int), ('SH', C.c_int), ('SW', C.c_int), ('PH', C.c_int), ('PW', C.c_int),
                 ('dtype_in', C.c_int), ('dtype_out', C.c_int),
                 ('rowscale', C.c_void_p), ('bias', C.c_void_p), ('res', C.c_void_p), ('relu_mask', C.c_void_p),
-                ('act', C.c_int), ('split_k', C.c_int)]
+                ('act', C.c_int), ('split_k', C.c_int), ('workspace', C.c_void_p), ('workspace_bytes', C.c_int64)]
 
 
 class AttnArgs(C.Structure):
@@ -112,6 +113,21 @@ def _f32(t):
     return t
 
 
+_WS = {}
+WS_MAX = 256 << 20
+
+
+def _workspace(device, nbytes):
+    """split-reduction scratch (include/gpv_hip.h, gpv_gemm_args.workspace): one buffer per device, grown on demand up
+    to WS_MAX, shared by all launches of the (single) compute stream.  A launch that would need more gets the buffer as
+    it is and the library falls back to fp32 atomics for it."""
+    need = min(nbytes, WS_MAX)
+    ws = _WS.get(device)
+    if ws is None or ws.numel() < need:
+        ws = _WS[device] = torch.empty(max(need, 64 << 20), device=device, dtype=torch.uint8)
+    return ws
+
+
 def gemm(A, B, Cm, M, N, K, lda, ldb, ldc, layoutA=KMAJOR, layoutB=KMAJOR, batch=1, sA=0, sB=0, sC=0,
          alpha=1.0, rowscale=None, bias=None, res=None, ldr=0, sR=0, relu_mask=None, ldm=0, act=ACT_NONE,
          drop_p=0.0, seed=0, accumulate=False, split_k=1, a_rowsum=None):
@@ -134,6 +150,9 @@ def gemm(A, B, Cm, M, N, K, lda, ldb, ldc, layoutA=KMAJOR, layoutB=KMAJOR, batch
     a.act, a.drop_p, a.seed = act, drop_p, seed
     a.accumulate, a.split_k = int(accumulate), split_k
     a.a_rowsum = _p(_f32(a_rowsum))
+    if accumulate and split_k > 1 and batch == 1:
+        ws = _workspace(A.device, split_k * M * N * 4)
+        a.workspace, a.workspace_bytes = _p(ws), ws.numel()
     _chk(lib().gpv_gemm(C.byref(a), _stream()), 'gpv_gemm')
 
 
@@ -153,6 +172,9 @@ def conv2d(mode, x, w, y, B, IH, IW, Cs, Cin, OH, OW, Cout, KH, KW, SH, SW, PH, 
             raise TypeError('conv2d: res/mask dtype must equal output dtype')
     a.res, a.relu_mask = _p(res), _p(relu_mask)
     a.act, a.split_k = act, split_k
+    if mode == 2:                                      # wgrad: the library picks the split; lend it the shared scratch
+        ws = _workspace(x.device, WS_MAX)
+        a.workspace, a.workspace_bytes = _p(ws), ws.numel()
     _chk(lib().gpv_conv2d(C.byref(a), _stream()), 'gpv_conv2d')
 
 

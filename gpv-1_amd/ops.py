@@ -128,12 +128,13 @@ class W:
 
 
 def _split_k(out_rows, out_cols, red):
-    """split of the reduction for wgrad GEMMs.  fp32 atomics cost ~ outputs x split / 70e9 s, so: just enough
-    blocks to fill the chip (~512), never more than 8 splits, never fewer than 16 k-tiles per split
-    (tools/bench_split.py sweep); split 1 is a non-atomic read-modify-write."""
+    """split of the reduction for wgrad GEMMs.  The splits are summed through a workspace (two-pass, no atomics on the
+    gradient), so the split only trades parallelism against 8 bytes of scratch traffic per output and split:
+    ~768 blocks of 64x64, never more than 8 splits, never fewer than 16 k-tiles per split
+    (tools/bench_lin_wgrad.py sweep); split 1 is a read-modify-write epilogue."""
     tiles = ((out_rows + 63) // 64) * ((out_cols + 63) // 64)
     kt = (red + 31) // 32
-    return max(1, min(-(-512 // max(tiles, 1)), 8, kt // 16))
+    return max(1, min(-(-768 // max(tiles, 1)), 8, kt // 16))
 
 
 def _c(x):

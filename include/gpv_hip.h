@@ -71,6 +71,10 @@ typedef struct {
   int act;
   float drop_p; uint64_t seed;    /* inverted dropout after act; drop_p = 0 disables */
   int accumulate, split_k;
+  void* workspace; int64_t workspace_bytes; /* optional scratch for accumulate != 0 with split_k > 1: when it holds
+                                     split_k * M * N * 4 bytes the splits write partial products there and a second
+                                     pass adds them to C (no fp32 atomics on C).  Contents are don't-care before and
+                                     after; one workspace may be shared by all launches of ONE stream. */
   float* a_rowsum;                /* layoutA = layoutB = GPV_TRANS only, or NULL: a_rowsum[m] += sum_k A[m,k]  (atomic).
                                      Weight-gradient GEMMs pass dY as A, so this is the bias gradient
                                      (sum over tokens), fused instead of a separate gpv_colsum launch. */
@@ -101,6 +105,7 @@ typedef struct {
   const void* res; const void* relu_mask;  /* same shape as y */
   int act;
   int split_k;                             /* wgrad only */
+  void* workspace; int64_t workspace_bytes; /* wgrad only, optional: split reduction scratch, same contract as gpv_gemm_args */
 } gpv_conv_args;
 int gpv_conv2d(const gpv_conv_args* a, void* stream);
 
