@@ -833,7 +833,7 @@ extern "C" int gpv_conv2d(const gpv_conv_args* a, void* stream) {
         // (tools/bench_split_conv.py: 64..96 / 64 / 32 / 16 / 8 / 4 splits for 4 / 9 / 16 / 36 / 64 / 144 tiles)
         const int64_t t128 = (int64_t)((k.M + 127) / 128) * (k.N / 128);
         want = (544 + t128 / 2) / t128;
-        if (want > 96) want = 96;
+        if (want > 288) want = 288;
         while (want > 1 && want * (int64_t)k.M * k.N * 4 > a->workspace_bytes) --want;
       } else {
         const int64_t tiles = (int64_t)((k.M + 63) / 64) * ((k.N + 63) / 64);

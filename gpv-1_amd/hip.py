@@ -98,7 +98,14 @@ def _p(t):
     return C.c_void_p(t.data_ptr())
 
 
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
+
 def _stream():
+    # current HIP stream of the current device (honours torch.cuda.stream(...) / graph capture).  The raw getter
+    # costs 0.3 us, torch.cuda.current_stream().cuda_stream 2.6 us -- per launch, 1500 launches per step.
+    if _raw_stream is not None:
+        return C.c_void_p(_raw_stream(torch.cuda.current_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 

@@ -152,7 +152,8 @@ class FlatTrainer:
     def train_step(self, images, queries, targets):
         """one iteration of train_distr.py:399-428; returns the loss tensor (or None: no applicable target)"""
         model = self.model
-        model.train()
+        if not model.training:                      # nn.Module.train() walks ~600 modules (0.66 ms): only when needed
+            model.train()
         _, answer_token_ids = model.encode_answers(targets)
         for i, t in enumerate(targets):
             t['answer_token_ids'] = answer_token_ids[i, 1:]

@@ -11,7 +11,7 @@ for name, ci, co, k, s, p, H, W in SH:
     x = torch.randn(B, H, W, ci, device=dev).to(torch.bfloat16); dy = torch.randn(B, OH, OW, co, device=dev).to(torch.bfloat16)
     dw = torch.zeros(co, k * k, ci, device=dev); sc = torch.ones(co, device=dev)
     res = []
-    for split in (0, 1, 2, 4, 8, 16, 32, 64):
+    for split in (0, 4, 8, 16, 32, 64, 96, 128, 192, 256):
         def run():
             hip.conv2d(2, x, dy, dw, B, H, W, ci, ci, OH, OW, co, k, k, s, s, p, p, rowscale=sc, split_k=split)
         for _ in range(2): run()
