@@ -1,0 +1,36 @@
+"""HBM traffic of the implicit-GEMM conv kernels from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of bench.py.
+usage (on the GPU box): python tools/pmc_traffic.py <dir pass FETCH_SIZE> <dir pass WRITE_SIZE> <steps profiled> > profiles/xxx.json
+Units and corrections follow /opt/skills/guides/MI355X_MICROARCH.md (HBM section): rocprofv3 reports both counters in KB;
+on gfx950 FETCH_SIZE counts 128-byte requests at 64 B -> doubled; WRITE_SIZE is taken as reported (uncalibrated)."""
+import csv, glob, json, os, sys
+
+def load(d, counter):
+    out = {}
+    for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r['Counter_Name'] != counter:
+                continue
+            k = r['Kernel_Name']
+            v = out.setdefault(k, [0.0, 0])
+            v[0] += float(r['Counter_Value']); v[1] += 1
+    return out
+
+def is_conv(name):
+    n = name.replace('(anonymous namespace)::', '')
+    return ('gemm_kernel' in n and 'Li2ELi0E' in n) or ('gemm_kernel<' in n and ', 1, 2, ' in n) or 'glds_kernelILi2E' in n
+
+fd, wd, steps = sys.argv[1], sys.argv[2], int(sys.argv[3])
+F, Wr = load(fd, 'FETCH_SIZE'), load(wd, 'WRITE_SIZE')
+fetch_kb = sum(v[0] for k, v in F.items() if is_conv(k)); nf = sum(v[1] for k, v in F.items() if is_conv(k))
+write_kb = sum(v[0] for k, v in Wr.items() if is_conv(k)); nw = sum(v[1] for k, v in Wr.items() if is_conv(k))
+res = {
+    'what': 'gemm_kernel<OP_CONV,...> / wgrad <OP_TRANS,OP_CONV> / glds_kernel<OP_CONV> launches of `python bench.py` (B=32 train step)',
+    'steps_profiled': steps, 'conv_launches_fetch_pass': nf, 'conv_launches_write_pass': nw,
+    'FETCH_SIZE_KB_raw': fetch_kb, 'WRITE_SIZE_KB_raw': write_kb,
+    'fetch_bytes_corrected_x2': fetch_kb * 1024 * 2, 'write_bytes': write_kb * 1024,
+    'traffic_bytes_per_step': (fetch_kb * 2 + write_kb) * 1024 / steps,
+    'traffic_bytes_per_launch': (fetch_kb * 2 * 1024 / max(nf, 1)) + (write_kb * 1024 / max(nw, 1)),
+    'by_kernel_KB': {k.replace('(anonymous namespace)::', '')[:90]: {'fetch_raw': F.get(k, [0, 0])[0], 'write': Wr.get(k, [0, 0])[0], 'launches': F.get(k, [0, 0])[1]}
+                     for k in F if is_conv(k)},
+}
+print(json.dumps(res, indent=1))
