@@ -120,6 +120,8 @@ class GPV(nn.Module):
         self.detr_joiner = LinearP(cfg.detr_joiner.detr_dim, cfg.detr_joiner.out_dim)
         self.init_detr_params = []
         self.bert = Bert(num_layers=cfg.get('bert_layers', 12) if isinstance(cfg, dict) else 12)
+        if isinstance(cfg, dict) and cfg.get('bert_dropout') is not None:          # test knob; the reference keeps HF's 0.1
+            self.bert.model.p = float(cfg.get('bert_dropout'))
         self.bert_joiner = LinearP(cfg.bert_joiner.bert_dim, cfg.bert_joiner.out_dim)
         layer = BertConnectionLayer(cfg.co_att)
         self.co_att_transformer = nn.ModuleList([copy.deepcopy(layer) for _ in range(cfg.co_att.num_layers)])

@@ -149,6 +149,30 @@ class FlatTrainer:
                       self.eps, self.wd, bc1, bc2, self.gscale if clip_here else None)
         RT.bump_weights(everything=False)
 
+    # ---- checkpointing (train_distr.py:381-389 saves optimizer.state_dict() + the warm-up scheduler's) ----
+    def state_dict(self):
+        """optimizer + schedule state, keyed by parameter NAME so that it survives a different flattening order"""
+        st = {}
+        for i, (n, p, g, o, k) in enumerate(self.entries):
+            st[n] = {'exp_avg': self.M[o:o + k].detach().cpu().clone(), 'exp_avg_sq': self.V[o:o + k].detach().cpu().clone(),
+                     'touched': bool(self.touched[i])}
+        return {'state': st, 'step': self.step_count, 'warmup_steps': self.warmup_steps, 't_total': self.t_total,
+                'lr': dict(self.lr), 'weight_decay': self.wd, 'betas': tuple(self.betas), 'eps': self.eps}
+
+    def load_state_dict(self, sd):
+        self.step_count = int(sd['step'])
+        for i, (n, p, g, o, k) in enumerate(self.entries):
+            e = sd['state'].get(n)
+            if e is None or e['exp_avg'].numel() != k:
+                continue
+            self.M[o:o + k].copy_(e['exp_avg'])
+            self.V[o:o + k].copy_(e['exp_avg_sq'])
+            self.touched[i] = bool(e['touched'])
+
+    def current_lrs(self):
+        sched = warmup_linear(self.step_count, self.warmup_steps, self.t_total) if self.t_total > 0 else 1.0
+        return {g: lr * sched for g, lr in self.lr.items()}
+
     def train_step(self, images, queries, targets):
         """one iteration of train_distr.py:399-428; returns the loss tensor (or None: no applicable target)"""
         model = self.model

@@ -1,0 +1,143 @@
+"""SURVEY §8(f) rows on CPU: Hydra-compatible config loading, the training driver (checkpoint layout, resume,
+phase-1 freeze, sharding) and the inference harness (checkpoint prefix, box ordering, answer cut).
+The kernels are emulated by tests/cpu_shim.py; the drivers are the product code."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests import synth, cpu_shim
+from tests.test_model_cpu import build_small, V
+
+
+@pytest.fixture(scope='module')
+def shim():
+    import gpv1_amd.ops as ops
+    undo = cpu_shim.install()
+    ops.RT.set_precise(True)
+    yield
+    ops.RT.set_precise(False)
+    undo()
+
+
+def test_config_interpolation_overrides_and_float_parsing(tmp_path):
+    from gpv1_amd.config import load_config
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = load_config(os.path.join(here, 'configs', 'exp', 'gpv.yaml'),
+                      ['exp_name=run7', 'output_dir=/tmp/out', 'training.freeze=True', 'training.lr=2e-4', 'model.detr.num_queries=50',
+                       'training.lr_milestones=[3,4]', 'training.ckpt=null', '+inputs.query=what is this?'])
+    assert cfg.ckpt_dir == '/tmp/out/run7/ckpts' and cfg.eval.ckpt == '/tmp/out/run7/ckpts/model.pth'
+    assert cfg.training.freeze is True and cfg.training.lr == 2e-4 and cfg.training.ckpt is None
+    assert cfg.model.detr.num_queries == 50 and cfg.training.lr_milestones == [3, 4]
+    assert cfg.batch_size == 120 and cfg.inputs.query == 'what is this?'
+    assert isinstance(cfg.model.losses.CaptionLoss.loss_wts.loss_caption, float)
+    assert [k for k, _ in cfg.model.losses.items()] == ['CaptionLoss', 'VqaLoss', 'ClsLoss', 'Localization']
+    with pytest.raises(KeyError):
+        load_config(os.path.join(here, 'configs', 'exp', 'gpv.yaml'), ['training.no_such_key=1'])
+    # the shapes the reference's own YAML uses: top-level group referenced from inside `model`, PyYAML-hostile floats
+    y = tmp_path / 'ref_style.yaml'
+    y.write_text('data_dir: /d\nmodel:\n  vocab: ${data_dir}/vocab.json\n  hidden_dim: 768\n  losses: ${losses}\n  detr:\n    dropout: 0.1\n'
+                 '  text_decoder:\n    dropout: ${model.detr.dropout}\n    hidden_dim: ${model.hidden_dim}\nlosses:\n  CaptionLoss:\n    loss_wts:\n      loss_caption: 5e-2\n'
+                 'training:\n  lr: 1e-4\n  freeze: False\n')
+    c = load_config(str(y), ['model.detr.dropout=0.2'])
+    assert c.model.vocab == '/d/vocab.json' and c.model.text_decoder.dropout == 0.2 and c.model.text_decoder.hidden_dim == 768
+    assert c.model.losses.CaptionLoss.loss_wts.loss_caption == 0.05 and c.training.lr == 1e-4 and c.training.freeze is False
+
+
+def _driver_cfg(tmp_path, **training):
+    from gpv1_amd.config import from_dict
+    m = synth.small_cfg(dropout=0.0)
+    m['vocab'] = synth.make_vocab(V)
+    m['vocab_embed'] = synth.synth_tensor('answer_head.vocab_embed', (V, 768))
+    m['bert_layers'] = 2
+    m['bert_dropout'] = 0.0                                   # the CPU shim has no dropout
+    tr = {'ckpt': None, 'freeze': False, 'frozen_epochs': 1, 'frozen_batch_size': 2, 'num_epochs': 2, 'batch_size': 2, 'log_step': 1,
+          'ckpt_step': 1000, 'lr': 1e-3, 'lr_backbone': 1e-4, 'weight_decay': 1e-4, 'lr_warmup': True, 'lr_linear_decay': True,
+          'lr_warmup_fraction': 0.25, 'clip_max_norm': 0.1}
+    tr.update(training)
+    return from_dict({'ckpt_dir': str(tmp_path / 'ckpts'), 'model': m, 'training': tr, 'synthetic_samples': 4})
+
+
+def _dataset(model_vocab):
+    from gpv1_amd.train_distr import SyntheticCocoDataset
+    return SyntheticCocoDataset(4, model_vocab, image_size=(64, 96), query_len=5)
+
+
+def test_train_driver_checkpoint_layout_and_resume(shim, tmp_path):
+    from gpv1_amd import train_distr as td
+    vocab = synth.make_vocab(V)
+    logs = []
+    torch.manual_seed(0)
+    cfg = _driver_cfg(tmp_path / 'a')
+    model, tr, step = td.train_worker(cfg, dataset=_dataset(vocab), device='cpu', log=logs.append)
+    assert step == 4 and len(logs) == 4 and 'loss' in logs[0]
+    ck = torch.load(os.path.join(cfg.ckpt_dir, 'model.pth'), weights_only=False)
+    assert set(ck) == {'model', 'optimizer', 'epoch', 'step', 'lr', 'model_selection_metric', 'warmup_scheduler'}
+    assert ck['epoch'] == 1 and ck['step'] == 4
+    assert all(k.startswith('module.') for k in ck['model']) and len(ck['model']) == len(model.state_dict())
+    # interrupted after epoch 0, resumed from its checkpoint: same weights as the uninterrupted run
+    torch.manual_seed(0)
+    cfg1 = _driver_cfg(tmp_path / 'b')
+    cfg1['max_steps'] = 2
+    td.train_worker(cfg1, dataset=_dataset(vocab), device='cpu', log=lambda s: None)
+    torch.manual_seed(0)
+    cfg2 = _driver_cfg(tmp_path / 'b', ckpt=os.path.join(cfg1.ckpt_dir, 'model.pth'))
+    m2, tr2, step2 = td.train_worker(cfg2, dataset=_dataset(vocab), device='cpu', log=logs.append)
+    assert step2 == 4 and 'resumed' in logs[-3]
+    a, b = model.state_dict(), m2.state_dict()
+    worst = max(float((a[k].float() - b[k].float()).abs().max()) for k in a if a[k].is_floating_point())
+    assert worst < 1e-6, worst
+    assert tr2.step_count == tr.step_count == 4
+
+
+def test_phase1_freeze_and_sharding(shim, tmp_path):
+    from gpv1_amd import train_distr as td
+    from gpv1_amd.gpv import GPV
+    cfg = _driver_cfg(tmp_path, freeze=True)
+    model = GPV(cfg.model)
+    model.init_detr_params = [n for n, _ in model.named_parameters() if n.startswith('detr.transformer.encoder')]
+    td.freeze_detr_params(model)
+    assert all(not p.requires_grad for n, p in model.named_parameters() if n in model.init_detr_params)
+    assert any(p.requires_grad for n, p in model.named_parameters() if n.startswith('detr.transformer.decoder'))
+    # DistributedSampler semantics: disjoint cover (with wrap-around padding), reshuffled per epoch
+    s0, s1 = td.shard_indices(10, 0, 0, 4), td.shard_indices(10, 0, 1, 4)
+    allr = sum((td.shard_indices(10, 0, r, 4) for r in range(4)), [])
+    assert len(s0) == len(s1) == 3 and set(allr) == set(range(10)) and len(allr) == 12
+    assert td.shard_indices(10, 1, 0, 4) != s0
+
+
+def test_inference_harness(shim, tmp_path):
+    from gpv1_amd import inference as inf
+    from gpv1_amd import train_distr as td
+    from gpv1_amd.train import FlatTrainer
+    model, _ = build_small()
+    model.eval()
+    path = str(tmp_path / 'model.pth')
+    td.save_checkpoint(path, model, FlatTrainer(model), epoch=0, step=1)
+    fresh, _ = build_small()
+    with torch.no_grad():
+        for p in fresh.parameters():
+            p.add_(1.0)
+    inf.load_model_state(fresh, path)                                   # 'module.' prefixed checkpoint
+    assert all(torch.equal(a, b) for a, b in zip(fresh.state_dict().values(), model.state_dict().values()))
+    # decode: boxes by relevance descending, cut; answer up to __stop__
+    out = {'pred_relevance_logits': torch.tensor([[[0.0, 1.0], [3.0, 0.0], [1.0, 0.0]]]),
+           'pred_boxes': torch.tensor([[[0.1] * 4, [0.2] * 4, [0.3] * 4]]),
+           'answer_logits': torch.zeros(1, 1, 4, V)}
+    ids = [model.word_to_idx['w3'], model.word_to_idx['w7'], model.word_to_idx['__stop__'], model.word_to_idx['w1']]
+    for t, i in enumerate(ids):
+        out['answer_logits'][0, 0, t, i] = 5.0
+    d = inf.decode_outputs(out, model, num_output_boxes=2)[0]
+    assert d['answer'] == 'w3 w7' and d['boxes'].shape == (2, 4)
+    assert np.allclose(d['boxes'][:, 0], [0.2, 0.3]) and d['relevance'][0] > d['relevance'][1]
+    assert inf.detokenize(['it', 'is', "n't", 'a', 'cat', ',', 'is', 'it', '?']) == "it isn't a cat, is it?"
+    img = (np.random.RandomState(0).rand(64, 96, 3) * 255).astype(np.uint8)
+    x = inf.preprocess_image(img)
+    assert x.shape == (3, 64, 96) and abs(float(x[0].mean()) - (img[..., 0].mean() / 255 - 0.485) / 0.229) < 1e-4
+    g = torch.Generator().manual_seed(0)
+    q = (torch.randint(1000, 30000, (1, 5), generator=g), torch.ones(1, 5, dtype=torch.long))
+    p = inf.predict(model, [img], q, num_output_boxes=3)[0]
+    assert p['boxes'].shape == (3, 4) and isinstance(p['answer'], str)
+    pb = inf.predict(model, [img], q, beam_size=2, num_output_boxes=3)[0]
+    assert 'answer_prob' in pb and 0.0 <= pb['answer_prob'] <= 1.0

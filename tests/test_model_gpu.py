@@ -227,3 +227,28 @@ def test_trainer_bf16_weight_mirror_tracks_master_weights(rt):
         p0.mul_(2.0)
     ops.RT.bump_weights()                        # what load_state_dict / .to() do
     assert torch.equal(ops._lp(p0), p0.detach().to(torch.bfloat16))
+
+
+def test_training_driver_and_inference_harness_on_gpu(rt, tmp_path):
+    """the Hydra-style training driver (2 epochs, checkpoint, resume) and the inference harness, bf16, on the HIP path"""
+    from tests.test_drivers_cpu import _driver_cfg, _dataset
+    from gpv1_amd import train_distr as td, inference as inf
+    rt.set_precise(False)
+    vocab = synth.make_vocab(V)
+    cfg = _driver_cfg(tmp_path)
+    cfg.model['bert_dropout'] = None                     # keep the reference's active BERT dropout
+    logs = []
+    model, tr, step = td.train_worker(cfg, dataset=_dataset(vocab), device=DEV, log=logs.append)
+    assert step == 4 and all(torch.isfinite(p).all() for p in model.parameters())
+    cfg2 = _driver_cfg(tmp_path, ckpt=os.path.join(cfg.ckpt_dir, 'model.pth'), num_epochs=3)
+    cfg2.model['bert_dropout'] = None
+    m2, tr2, step2 = td.train_worker(cfg2, dataset=_dataset(vocab), device=DEV, log=logs.append)
+    assert step2 == 6 and tr2.step_count == 6
+    m2.eval()
+    img = (np.random.RandomState(0).rand(64, 96, 3) * 255).astype(np.uint8)
+    g = torch.Generator().manual_seed(0)
+    q = (torch.randint(1000, 30000, (1, 5), generator=g).to(DEV), torch.ones(1, 5, dtype=torch.long, device=DEV))
+    p = inf.predict(m2, [img], q, num_output_boxes=3)[0]
+    assert p['boxes'].shape == (3, 4) and np.all(np.diff(p['relevance']) <= 0)
+    pb = inf.predict(m2, [img], q, beam_size=2, num_output_boxes=3)[0]
+    assert 0.0 <= pb['answer_prob'] <= 1.0
