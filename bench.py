@@ -132,7 +132,7 @@ def greedy_decode_bench(model, dev):
     from gpv1_amd.misc import NestedTensor
     model.eval()
     if os.environ.get('GPV_DEBUG_SYNC') == '1' or os.environ.get('GPV_NO_GRAPHS') == '1':
-        model.cfg['kv_graphs'] = False                           # debug aids (hip.py): no capture while synchronising per call
+        model.cfg['kv_graphs'] = model.cfg['graph_inference'] = False   # debug aids (hip.py): no capture while synchronising per call
     res = {}
     with torch.no_grad():
         for Bd, iters in ((1, 10), (64, 5)):
@@ -146,7 +146,7 @@ def greedy_decode_bench(model, dev):
             torch.cuda.synchronize()
             ms = (time.perf_counter() - t0) / iters * 1e3
             res[f'bs{Bd}'] = {'ms_per_batch': ms, 'ms_per_image': ms / Bd}
-    res['what'] = 'GPV.forward(images, queries, None): max_text_len=20 greedy, KV cache + hipGraph decode step, bf16'
+    res['what'] = 'GPV.forward(images, queries, None): max_text_len=20 greedy, KV cache, whole inference replayed as one hipGraph, bf16'
     model.train()
     return res
 

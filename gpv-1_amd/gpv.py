@@ -148,6 +148,7 @@ class GPV(nn.Module):
         self.relevance_tokens = nn.Parameter(0.1 * torch.randn([2, cfg.hidden_dim]))
         self.criterion = GPVCriterion(cfg.losses)
         self._kvdec = {}
+        self._igraphs = {}
         self.pos_enc = nn.Parameter(positionalencoding1d(cfg.text_decoder.hidden_dim, cfg.max_pos_enc_len)
                                     .view(1, cfg.max_pos_enc_len, -1), requires_grad=False)
 
@@ -213,6 +214,53 @@ class GPV(nn.Module):
 
     # ------------------------------------------------------------------ reference API
     def forward(self, images, queries, answer_token_ids, targets=None, vocab_mask=None):
+        if (answer_token_ids is None and targets is None and not self.training and torch.is_grad_enabled() is False
+                and self.cfg.get('graph_inference', True) and self.cfg.get('kv_decode', True)):
+            g = self._graphed_greedy(images, queries, vocab_mask)
+            if g is not None:
+                return g
+        return self._forward_impl(images, queries, answer_token_ids, targets, vocab_mask)
+
+    # ---- whole greedy inference as ONE hipGraph ---------------------------------------------------------------
+    def _graphed_greedy(self, images, queries, vocab_mask):
+        """Greedy inference (gpv.py:178-196) has static shapes for a fixed batch: ~1000 encoder launches + 20 decode
+        steps are captured once into a single HIP graph (torch.cuda.CUDAGraph; our kernels are launched on the
+        capturing stream through the C ABI) and replayed.  At batch 1 the eager path is bound by ~20 us of Python per
+        launch (20 ms per image for ~6 ms of GPU work).  Returns None when the call does not qualify (host-side
+        tokenisation, CPU tensors, nested capture): the caller then runs the eager path."""
+        from .misc import NestedTensor
+        if not isinstance(images, NestedTensor) or not isinstance(queries, (tuple, list)) or len(queries) != 2 \
+                or not all(torch.is_tensor(q) for q in queries):
+            return None
+        x, m = images.tensors, images.mask
+        ids, attn = queries
+        if not x.is_cuda or torch.cuda.is_current_stream_capturing():
+            return None
+        key = (tuple(x.shape), tuple(ids.shape), x.dtype, RT.dtype, vocab_mask is not None, RT.weights_epoch, RT.static_epoch)
+        ent = self._igraphs.get(key)
+        if ent is None:
+            for k in [k for k in self._igraphs if k[-2:] != key[-2:]]:          # weights changed: those graphs hold stale copies
+                del self._igraphs[k]
+            sx, sm, sids, sattn = x.clone(), m.clone(), ids.clone(), attn.clone()
+            svm = vocab_mask.clone().float() if vocab_mask is not None else None
+            run = lambda: self._forward_impl(NestedTensor(sx, sm), (sids, sattn), None, None, svm, kv_graphs=False)
+            for _ in range(2):                                                    # warm-up: weight copies, kernel attributes, decoder buffers
+                run()
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = run()
+            ent = self._igraphs[key] = (graph, (sx, sm, sids, sattn, svm), out)
+        graph, (sx, sm, sids, sattn, svm), out = ent
+        sx.copy_(x); sm.copy_(m); sids.copy_(ids); sattn.copy_(attn)
+        if svm is not None:
+            svm.copy_(vocab_mask)
+        graph.replay()
+        res = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in out.items()}     # the graph's outputs are overwritten by the next replay
+        torch.cuda.current_stream().synchronize()       # see decode.py: graph launches are not left queued behind a busy GPU
+        return res
+
+    def _forward_impl(self, images, queries, answer_token_ids, targets=None, vocab_mask=None, kv_graphs=None):
         outputs, memory = self._encode(images, queries)
         B = memory.shape[0]
         dev = memory.device
@@ -220,10 +268,11 @@ class GPV(nn.Module):
             if not self.training and self.cfg.get('kv_decode', True):
                 # KV-cached, hipGraph-captured decode step (decode.py): same outputs, 1/20th of the decoder work
                 from .decode import GreedyKVDecoder
-                key = (B, memory.shape[1], str(dev), RT.dtype)
+                use_graphs = self.cfg.get('kv_graphs', True) if kv_graphs is None else kv_graphs
+                key = (B, memory.shape[1], str(dev), RT.dtype, use_graphs)
                 dec = self._kvdec.get(key)
                 if dec is None:
-                    dec = self._kvdec[key] = GreedyKVDecoder(self, B, memory.shape[1], use_graphs=self.cfg.get('kv_graphs', True))
+                    dec = self._kvdec[key] = GreedyKVDecoder(self, B, memory.shape[1], use_graphs=use_graphs)
                 outputs['answer_logits'], _ = dec.decode(memory, vocab_mask)
             else:
                 outputs['answer_logits'] = self.greedy_full_prefix(memory, vocab_mask)

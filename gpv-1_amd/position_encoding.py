@@ -41,6 +41,8 @@ class PositionEmbeddingSine(nn.Module):
         mask = tensor_list.mask
         assert mask is not None
         B, h, w = mask.shape
+        if mask.is_cuda and torch.cuda.is_current_stream_capturing():        # no host round trip inside a graph capture
+            return self.compute(mask).reshape(B, h * w, -1).to(RT.dtype).contiguous()
         plain = not bool(mask.any())
         key = (B, h, w, str(mask.device), RT.dtype)
         if plain and key in self._cache:

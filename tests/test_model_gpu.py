@@ -190,16 +190,26 @@ def test_kv_cached_graph_decode_equals_full_prefix_decode(rt, precise):
     vm = torch.zeros(V, device=DEV)
     vm[::3] = -10000.0
     with torch.no_grad():
-        for vocab_mask in (None, vm):
-            model.cfg['kv_decode'] = True
-            a1 = model(nested(images, mask), (ids, attn), None, None, vocab_mask=vocab_mask)['answer_logits']
-            a2 = model(nested(images, mask), (ids, attn), None, None, vocab_mask=vocab_mask)['answer_logits']   # graph replay
-            model.cfg['kv_decode'] = False
-            b = model(nested(images, mask), (ids, attn), None, None, vocab_mask=vocab_mask)['answer_logits']
-            assert torch.equal(a1, a2)
-            assert rel(a1, b.float().cpu()) < (1e-4 if precise else 2e-2)
-            if precise:
-                assert torch.equal(a1[-1].topk(1, -1).indices, b[-1].topk(1, -1).indices)
+        for whole in (True, False):                 # whole inference as one hipGraph / eager encoder + one graph per decode step
+            model.cfg['graph_inference'] = whole
+            for vocab_mask in (None, vm):
+                model.cfg['kv_decode'] = True
+                o1 = model(nested(images, mask), (ids, attn), None, None, vocab_mask=vocab_mask)
+                a1 = o1['answer_logits']
+                a2 = model(nested(images, mask), (ids, attn), None, None, vocab_mask=vocab_mask)['answer_logits']   # graph replay
+                model.cfg['kv_decode'] = False
+                ob = model(nested(images, mask), (ids, attn), None, None, vocab_mask=vocab_mask)
+                b = ob['answer_logits']
+                assert torch.equal(a1, a2)
+                assert rel(a1, b.float().cpu()) < (1e-4 if precise else 2e-2)
+                assert rel(o1['pred_boxes'], ob['pred_boxes'].float().cpu()) < 1e-6
+                if precise:
+                    assert torch.equal(a1[-1].topk(1, -1).indices, b[-1].topk(1, -1).indices)
+        # replay with different inputs of the same shape: the static input buffers are refreshed
+        model.cfg['graph_inference'], model.cfg['kv_decode'] = True, True
+        im2 = torch.roll(images, 1, 0)
+        o3 = model(nested(im2, torch.roll(mask, 1, 0)), (torch.roll(ids, 1, 0), torch.roll(attn, 1, 0)), None, None)
+        assert rel(torch.roll(o3['pred_boxes'], -1, 0), o1['pred_boxes'].float().cpu()) < (1e-5 if precise else 2e-2)
 
 
 def test_trainer_bf16_weight_mirror_tracks_master_weights(rt):
