@@ -632,29 +632,45 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmK p) {
   }
 }
 
-// C[m, n] += sum_s ws[s][m][n]   (second pass of a workspace split reduction; 4 columns per thread)
+// C[m, n] += sum_s ws[s][m][n]   (second pass of a workspace split reduction).  A group of G threads shares one run
+// of 4 columns and strides over the splits (a layer2 1x1 wgrad has 96 slabs of 64K outputs: one thread per output
+// quad walking 96 slabs was 64 blocks of serial latency), partial sums meet in LDS.
+template <int G>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int nsplit, int M, int N, float* __restrict__ C,
                                                             int64_t ldc) {
+  constexpr int QB = 256 / G;                      // quads per block
+  __shared__ float4 part[G > 1 ? 256 : 1];
   const int64_t slab = (int64_t)M * N;
-  const int nq = (N + 3) / 4;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < (int64_t)M * nq; i += (int64_t)gridDim.x * blockDim.x) {
-    const int m = (int)(i / nq), n = (int)(i - (int64_t)m * nq) * 4;
+  const int nq = N >> 2;                           // host guarantees N % 4 == 0, ldc % 4 == 0, C 16-byte aligned
+  const int64_t total = (int64_t)M * nq;
+  const int ql = threadIdx.x % QB, g = threadIdx.x / QB;
+  const int64_t i = (int64_t)blockIdx.x * QB + ql;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  int m = 0, n = 0;
+  if (i < total) {
+    m = (int)(i / nq); n = (int)(i - (int64_t)m * nq) * 4;
     const float* src = ws + (int64_t)m * N + n;
-    float* dst = C + (int64_t)m * ldc + n;
-    if (n + 4 <= N && (N & 3) == 0 && (ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0) {
-      float4 a = *reinterpret_cast<const float4*>(dst);
-      for (int s = 0; s < nsplit; ++s) {
-        const float4 v = *reinterpret_cast<const float4*>(src + s * slab);
+    for (int s = g; s < nsplit; s += G) {
+      const float4 v = *reinterpret_cast<const float4*>(src + s * slab);
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+  }
+  if constexpr (G > 1) {
+    part[threadIdx.x] = a;
+    __syncthreads();
+    if (g == 0) {
+#pragma unroll
+      for (int k = 1; k < G; ++k) {
+        const float4 v = part[k * QB + ql];
         a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
       }
-      *reinterpret_cast<float4*>(dst) = a;
-    } else {
-      for (int e = 0; e < 4 && n + e < N; ++e) {
-        float a = dst[e];
-        for (int s = 0; s < nsplit; ++s) a += src[s * slab + e];
-        dst[e] = a;
-      }
     }
+  }
+  if (g == 0 && i < total) {
+    float4* dst = reinterpret_cast<float4*>(C + (int64_t)m * ldc + n);
+    float4 c = *dst;
+    c.x += a.x; c.y += a.y; c.z += a.z; c.w += a.w;
+    *dst = c;
   }
 }
 
@@ -676,7 +692,8 @@ int launch_cfg_v(const GemmK& k, int batch, hipStream_t st) {
   p.ws = nullptr;
   bool two_pass = false;
   if (p.accumulate && split > 1 && batch == 1 && k.ws_base != nullptr && sizeof(TOut) == 4 &&
-      (int64_t)split * p.M * p.N * 4 <= k.ws_bytes) {
+      (int64_t)split * p.M * p.N * 4 <= k.ws_bytes && p.N % 4 == 0 && p.ldc % 4 == 0 &&
+      (reinterpret_cast<uintptr_t>(p.C) & 15) == 0) {
     two_pass = true;
     p.ws = reinterpret_cast<float*>(k.ws_base);
     p.accumulate = 0; p.res = nullptr; p.mask = nullptr; p.bias = nullptr; p.act = 0; p.dthresh = 0;
@@ -692,10 +709,15 @@ int launch_cfg_v(const GemmK& k, int batch, hipStream_t st) {
   hipLaunchKernelGGL(fn, grid, dim3(256), lds, st, p);
   GPV_CHECK_LAUNCH();
   if (two_pass) {
-    const int64_t quads = (int64_t)p.M * ((p.N + 3) / 4);
-    const int blocks = (int)((quads + 255) / 256 < 2048 ? (quads + 255) / 256 : 2048);
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, p.ws, split, p.M, p.N,
-                       reinterpret_cast<float*>(p.C), p.ldc);
+    const int64_t quads = (int64_t)p.M * (p.N / 4);
+    float* Cf = reinterpret_cast<float*>(p.C);
+    if (split >= 32) {
+      hipLaunchKernelGGL(splitk_reduce_kernel<16>, dim3((unsigned)((quads + 15) / 16)), dim3(256), 0, st, p.ws, split, p.M, p.N, Cf, p.ldc);
+    } else if (split >= 4) {
+      hipLaunchKernelGGL(splitk_reduce_kernel<4>, dim3((unsigned)((quads + 63) / 64)), dim3(256), 0, st, p.ws, split, p.M, p.N, Cf, p.ldc);
+    } else {
+      hipLaunchKernelGGL(splitk_reduce_kernel<1>, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, st, p.ws, split, p.M, p.N, Cf, p.ldc);
+    }
     GPV_CHECK_LAUNCH();
   }
   return 0;
