@@ -94,7 +94,7 @@ __device__ __forceinline__ bf16x8 ld_pair64(const bf16* p0, const bf16* p1) {
 
 // MODE 0: forward (writes o, lse).  MODE 1: dQ (reads dout, o, lse; writes dq)
 template <typename T, int DHK, int DHV, int NT, int MODE>
-__global__ __launch_bounds__(256) void attn_q_kernel(AttnK p) {
+__global__ __launch_bounds__(256, DHK < 96 ? 2 : 1) void attn_q_kernel(AttnK p) {
   constexpr bool PRECISE = sizeof(T) == 4;
   constexpr int KP = DHK + 8;
   constexpr int KC = DHK / 32;
@@ -148,6 +148,93 @@ __global__ __launch_bounds__(256) void attn_q_kernel(AttnK p) {
     if (MODE) { delta += __shfl_xor(delta, 16); delta += __shfl_xor(delta, 32); }
   }
 
+  if constexpr (MODE == 1) {
+    // ---- dQ, streamed over pairs of 16-key tiles: the probabilities are recomputed from the saved log-sum-exp, so
+    // nothing needs all Sk scores at once.  (Holding them -- as the forward must for its max/sum -- cost 256+ VGPRs:
+    // one wave per SIMD, 159 us for the encoder shape; two live tiles fit 3-4 waves per SIMD.) ----
+    const uint8_t* kpm1 = p.kpm ? p.kpm + (int64_t)b * p.Sk : nullptr;
+    const float lse1 = qok ? p.lse[((int64_t)b * p.H + h) * p.Sq + q] : 0.f;
+    const uint64_t rng1 = (((uint64_t)b * p.H + h) * p.Sq + q) * (uint64_t)p.Sk;
+    f32x4 dq[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+    for (int kb = 0; kb < NT / 2; ++kb) {
+      if (kb * 2 >= ntr) break;
+      f32x4 sj[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int j = 2 * kb + t;
+        f32x4 sc = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (j < ntr) {
+#pragma unroll
+          for (int kc = 0; kc < KC; ++kc) {
+            const int off = (j * 16 + (lane & 15)) * KP + kc * 32 + g * 8;
+            const bf16x8 kh = *reinterpret_cast<const bf16x8*>(Kh + off);
+            const bf16x8 vh = *reinterpret_cast<const bf16x8*>(Vh + off);
+            sc = mfma16(kh, qh[kc], sc);
+            dp = mfma16(vh, doh[kc], dp);
+            if (PRECISE) {
+              const bf16x8 kl = *reinterpret_cast<const bf16x8*>(Kl + off);
+              const bf16x8 vl = *reinterpret_cast<const bf16x8*>(Vl + off);
+              sc = mfma16(kl, qh[kc], sc);
+              sc = mfma16(kh, ql[kc], sc);
+              dp = mfma16(vl, doh[kc], dp);
+              dp = mfma16(vh, dol[kc], dp);
+            }
+          }
+        }
+        uint32_t km1 = 0u;
+        if (kpm1) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) km1 |= (uint32_t)kpm1[min(j * 16 + g * 4 + i, p.Sk - 1)] << (8 * i);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int key = j * 16 + g * 4 + i;
+          const bool dead = key >= p.Sk || (p.causal && key > q) || ((km1 >> (8 * i)) & 0xffu) != 0u;
+          const float pr = dead ? 0.f : __expf(sc[i] * p.scale - lse1);      // normalised P
+          float d = dp[i];
+          if (p.dthresh) d = drop_keep(p.seed, rng1 + key, p.dthresh) ? d * p.dscale : 0.f;
+          sj[t][i] = pr * (d - delta) * p.scale;
+        }
+      }
+      bf16x8 ph, pl;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float a = sj[0][i], c = sj[1][i];
+        ph[i] = (bf16)a; ph[4 + i] = (bf16)c;
+        pl[i] = (bf16)(a - (float)ph[i]); pl[4 + i] = (bf16)(c - (float)ph[4 + i]);
+      }
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        const int off = (dt * 16 + (lane & 15)) * vtp + kb * 32 + g * 4;
+        const bf16x8 xh = ld_pair64(Th + off, Th + off + 16);
+        dq[dt] = mfma16(xh, ph, dq[dt]);
+        if (PRECISE) {
+          const bf16x8 xl = ld_pair64(Tl + off, Tl + off + 16);
+          dq[dt] = mfma16(xl, ph, dq[dt]);
+          dq[dt] = mfma16(xh, pl, dq[dt]);
+        }
+      }
+    }
+    if (!qok) return;
+    T* outp1 = reinterpret_cast<T*>(p.dq) + b * p.q_bs + (int64_t)q * p.q_rs + h * p.dh;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      const int d = dt * 16 + g * 4;
+      if (sizeof(T) == 4) {
+        *reinterpret_cast<float4*>(reinterpret_cast<float*>(outp1) + d) = make_float4(dq[dt][0], dq[dt][1], dq[dt][2], dq[dt][3]);
+      } else {
+        bf16x4 o4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o4[i] = (bf16)dq[dt][i];
+        *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(outp1) + d) = o4;
+      }
+    }
+    return;
+  }
+
   // ---- scores S^T[key][q] for all key tiles ----
   f32x4 s[NT];
 #pragma unroll
@@ -168,14 +255,26 @@ __global__ __launch_bounds__(256) void attn_q_kernel(AttnK p) {
     }
   }
   const uint8_t* kpm = p.kpm ? p.kpm + (int64_t)b * p.Sk : nullptr;
+  // key-padding bytes of this lane's 4 keys per tile, fetched up front WITHOUT per-element branches: the former
+  // `if (!dead && kpm) dead = kpm[key]` was 80 exec-masked branches, each waiting for its own byte load -- serial L2
+  // latency that made up most of the kernel's 35 k cycles per wave (and 160 SGPRs of live lane masks, spilled).
+  uint32_t km[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) km[j] = 0u;
+  if (kpm) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) km[j] |= (uint32_t)kpm[min(j * 16 + g * 4 + i, p.Sk - 1)] << (8 * i);
+    }
+  }
   float mx = -INFINITY;
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int key = j * 16 + g * 4 + i;
-      bool dead = key >= p.Sk || (p.causal && key > q);
-      if (!dead && kpm) dead = kpm[key] != 0;
+      const bool dead = key >= p.Sk || (p.causal && key > q) || ((km[j] >> (8 * i)) & 0xffu) != 0u;
       float x = dead ? -INFINITY : s[j][i] * p.scale;
       s[j][i] = x;
       mx = fmaxf(mx, x);

@@ -31,13 +31,18 @@ __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
-// counter-based RNG for dropout: one 32-bit hash per element index (murmur3 fmix64 of seed ^ idx).
+// counter-based RNG for dropout: one 32-bit hash per element index.  32-bit arithmetic only: the previous fmix64
+// (three 64x64 multiplies = 12 quarter-rate v_mul_lo/hi_u32 per element) made every dropout consumer VALU-bound --
+// the encoder attention kernels spent 54 % of their wave cycles issuing ~3700 VALU instructions per wave for 20 MFMAs
+// (PMC, tools/pmc_attn.py), the FFN GEMM epilogue hashes 19.6 M elements per layer.  This is the 2-multiply
+// "lowbias32" finalizer on (index low word ^ seed), the high words folded in with one more multiply.
 __device__ __forceinline__ uint32_t hash_u32(uint64_t seed, uint64_t idx) {
-  uint64_t z = seed + idx * 0x9E3779B97F4A7C15ull;
-  z ^= z >> 33; z *= 0xff51afd7ed558ccdull;
-  z ^= z >> 33; z *= 0xc4ceb9fe1a85ec53ull;
-  z ^= z >> 33;
-  return (uint32_t)z;
+  uint32_t x = (uint32_t)idx ^ (uint32_t)seed;
+  x ^= ((uint32_t)(idx >> 32) ^ (uint32_t)(seed >> 32)) * 0x9E3779B9u;
+  x ^= x >> 16; x *= 0x7feb352du;
+  x ^= x >> 15; x *= 0x846ca68bu;
+  x ^= x >> 16;
+  return x;
 }
 // keep-probability (1-p): element kept iff hash >= p * 2^32
 __device__ __forceinline__ bool drop_keep(uint64_t seed, uint64_t idx, uint32_t thresh) {
