@@ -125,13 +125,14 @@ WS_MAX = 256 << 20
 
 
 def _workspace(device, nbytes):
-    """split-reduction scratch (include/gpv_hip.h, gpv_gemm_args.workspace): one buffer per device, grown on demand up
-    to WS_MAX, shared by all launches of the (single) compute stream.  A launch that would need more gets the buffer as
-    it is and the library falls back to fp32 atomics for it."""
+    """split-reduction scratch (include/gpv_hip.h, gpv_gemm_args.workspace): one buffer per (device, stream), grown on
+    demand up to WS_MAX, shared by all launches of that stream.  A launch that would need more gets the buffer as it is
+    and the library falls back to fp32 atomics for it."""
     need = min(nbytes, WS_MAX)
-    ws = _WS.get(device)
+    key = (device, _raw_stream(torch.cuda.current_device()) if _raw_stream is not None else 0)
+    ws = _WS.get(key)
     if ws is None or ws.numel() < need:
-        ws = _WS[device] = torch.empty(max(need, 64 << 20), device=device, dtype=torch.uint8)
+        ws = _WS[key] = torch.empty(max(need, 64 << 20), device=device, dtype=torch.uint8)
     return ws
 
 
