@@ -2,6 +2,7 @@
 // image layout conversion, RoI separable weights, casts / weight prep, element-wise helpers,
 // fused AdamW.  All use 16-byte vector accesses where the layout allows (gfx950 HBM-bound rules).
 #include "common.h"
+#include <cstdlib>
 #include "../../include/gpv_hip.h"
 
 namespace {
@@ -497,7 +498,8 @@ extern "C" int gpv_layernorm_bwd(const void* dy, const void* x, const void* s, c
   if (cols % 8 != 0 || cols > 4096 || rows <= 0) return (int)hipErrorInvalidValue;
   const uint32_t th = drop_p > 0.f ? drop_thresh(drop_p) : 0u;
   const float sc = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
-  int rpb = (rows + 1023) / 1024;
+  static const int rpb_div = [] { const char* e = getenv("GPV_LN_BWD_BLOCKS"); return e ? atoi(e) : 1024; }();   // tuning only
+  int rpb = (rows + rpb_div - 1) / rpb_div;
   if (rpb < 8) rpb = 8;
   dim3 grid((rows + rpb - 1) / rpb), block(256);
   const size_t lds = dgamma ? 2 * (size_t)cols * sizeof(float) : 0;

@@ -1,0 +1,84 @@
+"""C-ABI checks that need no GPU: the shared library loads, exports exactly the entry points include/gpv_hip.h declares,
+and the ctypes mirrors in gpv-1_amd/hip.py have the C layout (sizes and field offsets, via a gcc-compiled probe)."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, 'include', 'gpv_hip.h')
+
+
+def declared():
+    src = open(HEADER).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\bint\s+(gpv_\w+)\s*\(', src)))
+
+
+def lib_path():
+    sys.path.insert(0, ROOT)
+    import gpv1_amd.hip as hip
+    if not os.path.exists(hip._LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    return hip._LIB_PATH
+
+
+def test_library_exports_every_declared_entry_point():
+    import gpv1_amd.hip as hip
+    names = declared()
+    assert len(names) == 25, names
+    assert sorted(hip.EXPORTS) == names
+    lib = ctypes.CDLL(lib_path())
+    for n in names:
+        assert hasattr(lib, n), f'{n} declared in include/gpv_hip.h but not exported'
+    lib.gpv_abi_version.restype = ctypes.c_int
+    assert lib.gpv_abi_version() == 1
+    # every other exported gpv_* symbol is declared
+    out = subprocess.run(['nm', '-D', '--defined-only', lib_path()], capture_output=True, text=True).stdout
+    exported = sorted({l.split()[-1] for l in out.splitlines() if l.split() and l.split()[-1].startswith('gpv_')})
+    assert exported == names, set(exported) ^ set(names)
+
+
+def test_ctypes_structs_match_the_c_layout(tmp_path):
+    import gpv1_amd.hip as hip
+    pairs = (('gpv_gemm_args', hip.GemmArgs), ('gpv_conv_args', hip.ConvArgs), ('gpv_attn_args', hip.AttnArgs))
+    prog = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', 'int main(void) {']
+    for cname, cls in pairs:
+        prog.append(f'  printf("{cname} %zu", sizeof({cname}));')
+        for f, _ in cls._fields_:
+            prog.append(f'  printf(" %zu", offsetof({cname}, {f}));')
+        prog.append('  printf("\\n");')
+    prog += ['  return 0;', '}']
+    c = tmp_path / 'probe.c'
+    c.write_text('\n'.join(prog))
+    exe = tmp_path / 'probe'
+    subprocess.run(['gcc', '-std=c99', '-o', str(exe), str(c)], check=True)
+    lines = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.strip().splitlines()
+    for (cname, cls), line in zip(pairs, lines):
+        vals = line.split()
+        assert vals[0] == cname
+        assert int(vals[1]) == ctypes.sizeof(cls), (cname, vals[1], ctypes.sizeof(cls))
+        offs = [int(v) for v in vals[2:]]
+        assert offs == [getattr(cls, f).offset for f, _ in cls._fields_], cname
+
+
+def test_product_refuses_to_run_without_the_library(monkeypatch, tmp_path):
+    """no CPU / eager fallback: a missing library or a CPU tensor is an error, not a silent detour"""
+    import importlib
+    import torch
+    import gpv1_amd.hip as hip
+    monkeypatch.setattr(hip, '_LIB', None)
+    monkeypatch.setattr(hip, '_LIB_PATH', str(tmp_path / 'nope.so'))
+    try:
+        hip.lib()
+        raise AssertionError('expected RuntimeError')
+    except RuntimeError as e:
+        assert 'no CPU/eager fallback' in str(e)
+    monkeypatch.undo()
+    try:
+        hip._p(torch.zeros(4))
+        raise AssertionError('expected RuntimeError')
+    except RuntimeError as e:
+        assert 'GPU' in str(e)
