@@ -260,6 +260,8 @@ class ResNetFn(Function):
 
     @staticmethod
     def backward(ctx, dc5):
+        if RT.backward_milestone is not None:          # everything downstream of the backbone has finished its backward
+            RT.backward_milestone('backbone')
         ev = _prof('conv_bwd')
         ctx.body.backward_nhwc(ctx.keep, dc5.to(RT.dtype))
         if ev is not None:

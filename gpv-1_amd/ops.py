@@ -30,6 +30,7 @@ class Runtime:
         self.seed = 0x5EED
         self._ctr = 0
         self.cache = {}
+        self.backward_milestone = None   # set by train.FlatTrainer for the duration of a backward pass (gradient-exchange overlap)
 
     def set_precise(self, on=True):
         self.dtype = torch.float32 if on else torch.bfloat16

@@ -15,6 +15,8 @@ MI355X-first choices
   * torch-1.6 optimizer semantics kept: a parameter is only updated (incl. weight decay) once it has
     received a gradient at least once; the touched set is agreed across ranks (MAX all-reduce).
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -85,7 +87,12 @@ class FlatTrainer:
         self.gsq = torch.zeros(1, device=dev, dtype=torch.float32)
         self.gscale = torch.ones(1, device=dev, dtype=torch.float32)
         b = bucket_mb * 1024 * 1024 // 4
-        self.buckets = [(s, min(off, s + b)) for s in range(0, off, b)]
+        self.backbone_end = max([o + (k + 7) // 8 * 8 for (n, p, g, o, k) in self.entries if g == 'detr_backbone'], default=0)
+        self.buckets = [(s, min(self.backbone_end, s + b)) for s in range(0, self.backbone_end, b)] + \
+                       [(s, min(off, s + b)) for s in range(self.backbone_end, off, b)]      # no bucket straddles the backbone boundary
+        self.overlap = self.world > 1 and os.environ.get('GPV_OVERLAP', '1') != '0'
+        self.dry_overlap = False             # tests: run the milestone / guard logic without communicating
+        self._closed_from, self._works, self.late_touch, self.milestones = None, [], None, 0
         if self.world > 1:
             dist.broadcast(self.P, src=0, group=self.pg)
         RT.bump_weights()
@@ -99,15 +106,45 @@ class FlatTrainer:
 
     def _mark(self, i):
         self.touched[i] = True
+        if self._closed_from is not None and self.entries[i][3] >= self._closed_from:
+            # a gradient kernel was issued for a parameter whose bucket is already being all-reduced: its contribution
+            # would stay rank-local.  Never observed (see _on_milestone); if the autograd order ever changes, fail loudly.
+            self.late_touch = self.entries[i][0]
+            if not self.dry_overlap:
+                raise RuntimeError(f'gpv1_amd.FlatTrainer: gradient of {self.entries[i][0]} written after its bucket was '
+                                   f'handed to the all-reduce (set GPV_OVERLAP=0 to disable the overlap)')
 
     def zero_grad(self):
         self.G.zero_()
 
-    # ---- gradient exchange: average over ranks, a few large buckets, async ----
+    # ---- gradient exchange: average over ranks, a few large buckets, async, overlapped with the backbone backward ----
+    # Flat order = [detr_backbone | detr_head | others]; the backward pass runs the other way round, and when autograd
+    # reaches ResNetFn.backward every node created after the backbone in the forward (transformer, heads, co-attention,
+    # text decoder: 350 MB of the 444 MB) has already run -- the engine orders ready nodes by creation sequence.  At
+    # that milestone the buckets behind the backbone segment are all-reduced on RCCL's stream while the backbone
+    # backward (8 of the ~22 ms) computes; the backbone segment follows after the pass.  _mark() guards the assumption.
+    def _on_milestone(self, what):
+        if what != 'backbone' or self._closed_from is not None or not (self.overlap or self.dry_overlap):
+            return
+        self._closed_from = self.backbone_end
+        self.milestones += 1
+        if self.overlap:
+            self._works = [dist.all_reduce(self.G[s:e], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+                           for s, e in self.buckets if s >= self.backbone_end]
+
+    def begin_backward(self):
+        self._closed_from, self._works, self.late_touch, self.milestones = None, [], None, 0
+        RT.backward_milestone = self._on_milestone
+
     def allreduce_grads(self):
+        RT.backward_milestone = None
+        closed = self._closed_from
+        self._closed_from = None
         if self.world == 1:
             return
-        works = [dist.all_reduce(self.G[s:e], op=dist.ReduceOp.SUM, group=self.pg, async_op=True) for s, e in self.buckets]
+        works = self._works + [dist.all_reduce(self.G[s:e], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+                               for s, e in self.buckets if closed is None or s < closed]
+        self._works = []
         t = self._touched_dev
         t.copy_(self.touched.to(torch.int32), non_blocking=False)
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.pg)
@@ -184,6 +221,7 @@ class FlatTrainer:
         loss = model(images, queries, answer_token_ids, targets)
         if loss is not None:
             self.zero_grad()
+            self.begin_backward()
             loss.backward()
             self.allreduce_grads()
             self.step()

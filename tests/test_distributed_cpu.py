@@ -64,18 +64,29 @@ def _worker(rank, world, port, out):
     for _ in range(1):
         tr.model.bert.model.p = 0.0
         tr.train_step(nested(images, mask), (ids, attn), _targets(rank, V))
+    # train_step overlaps the exchange of everything behind the backbone segment with the backbone's backward
+    res['milestones'], res['late_touch'], res['overlap'] = tr.milestones, tr.late_touch, tr.overlap
     res['P'] = tr.P.clone()
     res['names'] = [e[0] for e in tr.entries]
     torch.save(res, os.path.join(out, f'rank{rank}.pt'))
     dist.destroy_process_group()
 
 
-@pytest.mark.timeout(900)
+@pytest.mark.timeout(1800)
 def test_two_rank_gradient_exchange(tmp_path):
-    port = _free_port()
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
-    r0 = torch.load(os.path.join(tmp_path, 'rank0.pt'))
-    r1 = torch.load(os.path.join(tmp_path, 'rank1.pt'))
+    runs = {}
+    for overlap in ('1', '0'):                      # exchange overlapped with the backbone backward / after the pass
+        os.environ['GPV_OVERLAP'] = overlap
+        out = tmp_path / f'overlap{overlap}'
+        out.mkdir()
+        mp.spawn(_worker, args=(2, _free_port(), str(out)), nprocs=2, join=True)
+        runs[overlap] = [torch.load(os.path.join(out, f'rank{r}.pt')) for r in range(2)]
+    os.environ.pop('GPV_OVERLAP')
+    r0, r1 = runs['1']
+    assert r0['overlap'] and r0['milestones'] == 1 and r0['late_touch'] is None and r1['late_touch'] is None
+    assert not runs['0'][0]['overlap'] and runs['0'][0]['milestones'] == 0
+    # same parameters after the steps whichever way the gradients were exchanged (same sums, same order per bucket)
+    assert torch.equal(r0['P'], runs['0'][0]['P'])
     # exchanged gradient = average of the two local gradients, identical on both ranks
     avg = (r0['local'] + r1['local']) / 2
     assert torch.equal(r0['avg'], r1['avg'])

@@ -168,12 +168,14 @@ def test_full_size_properties(rt):
             assert rel(o16[k], o32[k].cpu()) < 8e-2, (k, rel(o16[k], o32[k].cpu()))
     # training with dropout on (bf16): gradients finite, loss goes down on a fixed batch
     tr = FlatTrainer(model, lr=1e-4, lr_backbone=1e-5)
+    tr.dry_overlap = True
     losses = []
     for it in range(4):
         targets = [{'task': 'CocoCaptioning', 'answer': ' '.join(f'w{(7 * i + j) % (Vf - 4)}' for j in range(6))} for i in range(Bf)]
         targets[1] = {'task': 'CocoDetection', 'boxes': torch.tensor([[0.5, 0.5, 0.2, 0.3], [0.3, 0.6, 0.1, 0.1]], device=DEV),
                       'labels': torch.zeros(2, dtype=torch.long, device=DEV)}
         loss = tr.train_step(nested(images, mask), (ids, attn), targets)
+        assert tr.milestones == 1 and tr.late_touch is None, tr.late_touch
         assert torch.isfinite(loss)
         assert torch.isfinite(tr.G).all()
         losses.append(float(loss))
@@ -302,10 +304,12 @@ def test_baseline_config2_multitask_and_config4_detection_only_steps(rt):
         return out
     for det_only in (False, True):
         tr = FlatTrainer(model, lr=1e-4, lr_backbone=1e-5)
-        tg = targets(det_only)
+        tr.dry_overlap = True                    # run the multi-GPU overlap bookkeeping: no gradient may be written
+        tg = targets(det_only)                   # after its bucket was handed to the all-reduce (FlatTrainer._mark)
         losses = []
         for it in range(4):
             loss = tr.train_step(nested(images, mask), (ids, attn), [dict(t) for t in tg])
+            assert tr.milestones == 1 and tr.late_touch is None, tr.late_touch
             assert torch.isfinite(loss) and torch.isfinite(tr.G).all()
             losses.append(float(loss.detach()))
             ind = model.criterion.localization_criterion.set_criterion.last_indices
