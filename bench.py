@@ -129,7 +129,7 @@ def cpu_baseline(model, seconds_budget=25.0):
 def greedy_decode_bench(model, dev):
     """second half of BASELINE.json's metric: greedy-decode ms/image (whole inference: backbone -> DETR -> BERT ->
     co-attention -> 20-token KV-cached decode, one hipGraph per step), eval mode, bf16, inputs resident in HBM."""
-    from gpv1_amd.misc import NestedTensor
+    from gpv1_amd.misc import nested_tensor_from_tensor_list
     model.eval()
     if os.environ.get('GPV_DEBUG_SYNC') == '1' or os.environ.get('GPV_NO_GRAPHS') == '1':
         model.cfg['kv_graphs'] = model.cfg['graph_inference'] = False   # debug aids (hip.py): no capture while synchronising per call
@@ -137,12 +137,13 @@ def greedy_decode_bench(model, dev):
     with torch.no_grad():
         for Bd, iters in ((1, 10), (64, 5)):
             images, mask, ids, attn, _ = make_batch(7, Bd, dev)
+            samples_d = nested_tensor_from_tensor_list(images)
             for _ in range(2):                                   # warm-up: captures the 20 step graphs for this batch size
-                model(NestedTensor(images, mask), (ids, attn), None, None)
+                model(samples_d, (ids, attn), None, None)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(iters):
-                o = model(NestedTensor(images, mask), (ids, attn), None, None)
+                o = model(samples_d, (ids, attn), None, None)
             torch.cuda.synchronize()
             ms = (time.perf_counter() - t0) / iters * 1e3
             res[f'bs{Bd}'] = {'ms_per_batch': ms, 'ms_per_image': ms / Bd}
@@ -174,7 +175,7 @@ def main():
     import gpv1_amd.hip as hip
     import gpv1_amd.backbone as bbm
     from gpv1_amd.gpv import GPV
-    from gpv1_amd.misc import NestedTensor
+    from gpv1_amd.misc import nested_tensor_from_tensor_list
     from gpv1_amd.train import FlatTrainer
     from gpv1_amd.ops import RT
     hip.lib()
@@ -189,7 +190,7 @@ def main():
     tr = FlatTrainer(model, lr=1e-4, lr_backbone=1e-5, weight_decay=1e-4, clip_max_norm=0.1,
                      warmup_steps=int(0.1 * total_steps), t_total=total_steps)
     images, mask, ids, attn, targets = make_batch(rank, args.batch, dev)
-    samples = NestedTensor(images, mask)
+    samples = nested_tensor_from_tensor_list(images)           # the reference's collate (detr_misc.py:267-299): same-size images, no padding
 
     def step():
         tg = [dict(t) for t in targets]

@@ -293,7 +293,7 @@ class BackboneBase(nn.Module):
         iy = torch.div(torch.arange(h, device=m.device) * H, h, rounding_mode='floor')   # F.interpolate nearest
         ix = torch.div(torch.arange(w, device=m.device) * Wd, w, rounding_mode='floor')
         mask = m[:, iy][:, :, ix]
-        return {'0': NestedTensor(c5, mask)}
+        return {'0': NestedTensor(c5, mask, getattr(tensor_list, 'all_valid', None))}
 
 
 class Backbone(BackboneBase):

@@ -153,7 +153,9 @@ class AnswerClassification(nn.Module):
         sel = [i for i, t in enumerate(targets) if 'answer' in t and (self.task is None or t['task'] == self.task)]
         if not sel:
             return {self.key: None}
-        logits = outputs['answer_logits'][:, sel]
+        logits = outputs['answer_logits']
+        if len(sel) != logits.shape[1]:                         # indexing with a host list = H2D copy + sync: only when a subset
+            logits = logits[:, sel]
         return {self.key: self.compute_ce_loss(logits, [targets[i]['answer_token_ids'] for i in sel])}
 
 

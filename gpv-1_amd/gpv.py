@@ -355,7 +355,8 @@ class GPV(nn.Module):
             toks.extend(['__pad__'] * (S - len(toks)))
             ids.append([self.word_to_idx.get(w, self.word_to_idx['__unk__']) for w in toks][:self.cfg.max_text_len])
         dev = self.vision_token.device
-        return padded_inputs, torch.tensor(ids, dtype=torch.long, device=dev)
+        from .misc import STAGER
+        return padded_inputs, STAGER.to_device(ids, torch.long, dev)          # no host<->device sync (misc.PinnedStager)
 
     def token_ids_to_words(self, token_ids):
         B, S = token_ids.shape

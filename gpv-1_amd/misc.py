@@ -7,13 +7,16 @@ import torch
 class NestedTensor(object):
     """detr_misc.py:302-322"""
 
-    def __init__(self, tensors, mask: Optional[torch.Tensor]):
+    def __init__(self, tensors, mask: Optional[torch.Tensor], all_valid: Optional[bool] = None):
         self.tensors = tensors
         self.mask = mask
+        # host-side knowledge that no pixel is padding (all images the same size): lets the position encoding use its
+        # cached constant without asking the device (`mask.any()` is a host<->device sync per step).  None = unknown.
+        self.all_valid = all_valid
 
     def to(self, device):
         mask = self.mask.to(device) if self.mask is not None else None
-        return NestedTensor(self.tensors.to(device), mask)
+        return NestedTensor(self.tensors.to(device), mask, self.all_valid)
 
     def decompose(self):
         return self.tensors, self.mask
@@ -37,7 +40,41 @@ def nested_tensor_from_tensor_list(tensor_list: List[torch.Tensor]):
     for img, pad_img, m in zip(tensor_list, tensor, mask):
         pad_img[:img.shape[0], :img.shape[1], :img.shape[2]].copy_(img)
         m[:img.shape[1], :img.shape[2]] = False
-    return NestedTensor(tensor, mask)
+    return NestedTensor(tensor, mask, all(img.shape[1] == h and img.shape[2] == w for img in tensor_list))
+
+
+class PinnedStager:
+    """small host->device transfers without a host<->device synchronisation: a pageable-memory copy
+    (`torch.tensor(list, device='cuda')`) waits for everything queued on the stream, i.e. the previous training step.
+    A ring of pinned staging buffers + non_blocking copies keeps the host free to run ahead; the ring is deep enough
+    (8 slots, each protected by the event of its last copy) that a slot is never rewritten while its copy is pending."""
+
+    def __init__(self, slots=8, nbytes=1 << 16):
+        self.slots, self.nbytes, self.bufs, self.events, self.i = slots, nbytes, None, None, 0
+
+    def to_device(self, data, dtype, device):
+        t = torch.as_tensor(data, dtype=dtype)
+        dev = torch.device(device)
+        if dev.type != 'cuda' or t.numel() * t.element_size() > self.nbytes:
+            return t.to(dev)
+        if self.bufs is None:
+            self.bufs = [torch.empty(self.nbytes, dtype=torch.uint8).pin_memory() for _ in range(self.slots)]
+            self.events = [None] * self.slots
+        k = self.i
+        self.i = (k + 1) % self.slots
+        if self.events[k] is not None:
+            self.events[k].synchronize()                      # only ever waits when the host is 8 transfers ahead
+        n = t.numel() * t.element_size()
+        host = self.bufs[k][:n].view(dtype).view(t.shape)
+        host.copy_(t)
+        out = host.to(dev, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))
+        self.events[k] = ev
+        return out
+
+
+STAGER = PinnedStager()
 
 
 def collate_fn(batch):

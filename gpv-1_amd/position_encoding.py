@@ -43,7 +43,8 @@ class PositionEmbeddingSine(nn.Module):
         B, h, w = mask.shape
         if mask.is_cuda and torch.cuda.is_current_stream_capturing():        # no host round trip inside a graph capture
             return self.compute(mask).reshape(B, h * w, -1).to(RT.dtype).contiguous()
-        plain = not bool(mask.any())
+        hint = getattr(tensor_list, 'all_valid', None)
+        plain = hint if hint is not None else not bool(mask.any())      # the device round trip only when nothing is known on the host
         key = (B, h, w, str(mask.device), RT.dtype)
         if plain and key in self._cache:
             return self._cache[key]
