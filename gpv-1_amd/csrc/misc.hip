@@ -449,9 +449,11 @@ __global__ void act_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ r
 
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                              bf16* __restrict__ plow, int64_t n, float lr, float b1, float b2, float eps, float wd, float bc1,
-                             float bc2, const float* __restrict__ gscale) {
+                             float bc2, const float* __restrict__ gscale, const uint16_t* __restrict__ seg_id,
+                             const int32_t* __restrict__ seg_live) {
   const float gs = gscale ? *gscale : 1.f;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    if (seg_id && !seg_live[seg_id[i >> 3]]) continue;          // parameter never received a gradient: untouched, like torch 1.6
     float gi = g[i] * gs;
     float pi = p[i] * (1.f - lr * wd);
     float mi = b1 * m[i] + (1.f - b1) * gi;
@@ -651,8 +653,10 @@ extern "C" int gpv_act_bwd(const void* dy, const void* ref, void* dx, int64_t n,
 }
 
 extern "C" int gpv_adamw(float* p, const float* g, float* m, float* v, void* p_lowp, int64_t n, float lr, float beta1, float beta2,
-                         float eps, float wd, float bc1, float bc2, const float* gscale, void* stream) {
-  hipLaunchKernelGGL(adamw_kernel, dim3(grid1d(n, 256)), dim3(256), 0, ST(stream), p, g, m, v, (bf16*)p_lowp, n, lr, beta1, beta2, eps, wd, bc1, bc2, gscale);
+                         float eps, float wd, float bc1, float bc2, const float* gscale, const uint16_t* seg_id,
+                         const int32_t* seg_live, void* stream) {
+  if ((seg_id == nullptr) != (seg_live == nullptr)) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid1d(n, 256)), dim3(256), 0, ST(stream), p, g, m, v, (bf16*)p_lowp, n, lr, beta1, beta2, eps, wd, bc1, bc2, gscale, seg_id, seg_live);
   GPV_CHECK_LAUNCH();
   return 0;
 }

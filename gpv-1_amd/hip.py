@@ -293,10 +293,10 @@ def relevance_condition(x, logits, tokens, y, rows, dim):
                                        _stream()), 'gpv_relevance_condition')
 
 
-def adamw(p, g, m, v, p_lowp, n, lr, beta1, beta2, eps, wd, bc1, bc2, gscale=None):
+def adamw(p, g, m, v, p_lowp, n, lr, beta1, beta2, eps, wd, bc1, bc2, gscale=None, seg_id=None, seg_live=None):
     _chk(lib().gpv_adamw(_p(p), _p(g), _p(m), _p(v), _p(p_lowp), C.c_int64(n), C.c_float(lr), C.c_float(beta1),
                          C.c_float(beta2), C.c_float(eps), C.c_float(wd), C.c_float(bc1), C.c_float(bc2),
-                         _p(gscale), _stream()), 'gpv_adamw')
+                         _p(gscale), _p(seg_id), _p(seg_live), _stream()), 'gpv_adamw')
 
 
 def sumsq(x, n, out):

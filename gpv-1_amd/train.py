@@ -72,8 +72,18 @@ class FlatTrainer:
         self.M = torch.zeros_like(self.P)
         self.V = torch.zeros_like(self.P)
         self.Pb = torch.zeros(off, device=dev, dtype=torch.bfloat16)      # bf16 mirror of P, rewritten by the AdamW kernel
-        self.touched = torch.zeros(len(self.entries), dtype=torch.bool)
-        self._touched_dev = torch.zeros(len(self.entries), device=dev, dtype=torch.int32)
+        self.touched = torch.zeros(len(self.entries), dtype=torch.bool)           # host: which parameters THIS rank's kernels wrote
+        # device: which parameters any rank has ever written (torch-1.6 optimizers skip the rest).  The AdamW kernel reads
+        # it through seg_id (parameter index of every 8-element chunk), so no host round trip is needed to pick ranges.
+        self.live = torch.zeros(len(self.entries), device=dev, dtype=torch.int32)
+        sid = torch.zeros(off // 8, dtype=torch.int16)
+        for i, (n, p, g, o, k) in enumerate(self.entries):
+            sid[o // 8:(o + k + 7) // 8] = i
+        self.seg_id = sid.to(dev)
+        self.group_range = {}
+        for (n, p, g, o, k) in self.entries:
+            lo, hi = self.group_range.get(g, (o, o))
+            self.group_range[g] = (min(lo, o), max(hi, o + (k + 7) // 8 * 8))
         for i, (n, p, g, o, k) in enumerate(self.entries):
             pv, gv = self._view(self.P, p, o, k), self._view(self.G, p, o, k)
             pv.copy_(p.data)
@@ -145,13 +155,20 @@ class FlatTrainer:
         works = self._works + [dist.all_reduce(self.G[s:e], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
                                for s, e in self.buckets if closed is None or s < closed]
         self._works = []
-        t = self._touched_dev
-        t.copy_(self.touched.to(torch.int32), non_blocking=False)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.pg)
-        self.touched |= t.cpu().bool()
+        self._publish_touched()
+        dist.all_reduce(self.live, op=dist.ReduceOp.MAX, group=self.pg)          # stays on the device: no host sync
         for w in works:
             w.wait()
         self.G.mul_(1.0 / self.world)
+
+    def _publish_touched(self):
+        """host-side 'touched' marks of this step -> device flags (idempotent; pinned staging, asynchronous)"""
+        from .misc import STAGER
+        loc = STAGER.to_device(self.touched.to(torch.int32), torch.int32, self.live.device)
+        torch.maximum(self.live, loc, out=self.live)
+
+    def live_host(self):
+        return self.live.cpu().bool()
 
     def _ranges(self, pred):
         """contiguous flat ranges of touched entries satisfying pred(group), merged per group"""
@@ -170,29 +187,34 @@ class FlatTrainer:
         """clip_grad_norm_(detr params) + AdamW + schedule (train_distr.py:423-428,468-469)"""
         sched = warmup_linear(self.step_count, self.warmup_steps, self.t_total) if self.t_total > 0 else 1.0
         use_clip = self.clip is not None and self.clip > 0
+        self._publish_touched()
         if use_clip:
             self.gsq.zero_()
-            for g, s, e in self._ranges(lambda g: g in ('detr_backbone', 'detr_head')):
-                hip.sumsq(self.G[s:e], e - s, self.gsq)
+            for g in ('detr_backbone', 'detr_head'):                         # untouched gradients are zero: whole groups
+                if g in self.group_range:
+                    s, e = self.group_range[g]
+                    hip.sumsq(self.G[s:e], e - s, self.gsq)
             # scale = min(1, max_norm / (norm + 1e-6)) on device, no host sync
             torch.clamp(self.clip / (self.gsq.sqrt() + 1e-6), max=1.0, out=self.gscale)
         self.step_count += 1
         t = self.step_count
         b1, b2 = self.betas
         bc1, bc2 = 1 - b1 ** t, 1 - b2 ** t
-        for g, s, e in self._ranges(lambda g: True):
+        for g, (s, e) in self.group_range.items():                           # one launch per group; the kernel skips dead parameters
             clip_here = use_clip and g in ('detr_backbone', 'detr_head')
             hip.adamw(self.P[s:e], self.G[s:e], self.M[s:e], self.V[s:e], self.Pb[s:e], e - s, self.lr[g] * sched, b1, b2,
-                      self.eps, self.wd, bc1, bc2, self.gscale if clip_here else None)
+                      self.eps, self.wd, bc1, bc2, self.gscale if clip_here else None,
+                      seg_id=self.seg_id[s // 8:e // 8], seg_live=self.live)
         RT.bump_weights(everything=False)
 
     # ---- checkpointing (train_distr.py:381-389 saves optimizer.state_dict() + the warm-up scheduler's) ----
     def state_dict(self):
         """optimizer + schedule state, keyed by parameter NAME so that it survives a different flattening order"""
         st = {}
+        live = self.live_host()
         for i, (n, p, g, o, k) in enumerate(self.entries):
             st[n] = {'exp_avg': self.M[o:o + k].detach().cpu().clone(), 'exp_avg_sq': self.V[o:o + k].detach().cpu().clone(),
-                     'touched': bool(self.touched[i])}
+                     'touched': bool(live[i])}
         return {'state': st, 'step': self.step_count, 'warmup_steps': self.warmup_steps, 't_total': self.t_total,
                 'lr': dict(self.lr), 'weight_decay': self.wd, 'betas': tuple(self.betas), 'eps': self.eps}
 
@@ -205,6 +227,7 @@ class FlatTrainer:
             self.M[o:o + k].copy_(e['exp_avg'])
             self.V[o:o + k].copy_(e['exp_avg_sq'])
             self.touched[i] = bool(e['touched'])
+        self._publish_touched()
 
     def current_lrs(self):
         sched = warmup_linear(self.step_count, self.warmup_steps, self.t_total) if self.t_total > 0 else 1.0

@@ -196,7 +196,12 @@ int gpv_relevance_condition(const void* x, const float* logits, const float* tok
  * optionally writing the bf16 compute copy; grad is multiplied by *gscale (device scalar, clip factor)
  * when gscale != NULL. */
 int gpv_adamw(float* p, const float* g, float* m, float* v, void* p_lowp, int64_t n, float lr, float beta1,
-              float beta2, float eps, float wd, float bc1, float bc2, const float* gscale, void* stream);
+              float beta2, float eps, float wd, float bc1, float bc2, const float* gscale,
+              const uint16_t* seg_id, const int32_t* seg_live, void* stream);
+/* seg_id / seg_live (both or neither): element i belongs to parameter seg_id[i / 8] (parameters start on multiples of 8
+ * elements) and is updated only if seg_live[that id] != 0.  The set of parameters that have ever received a gradient
+ * (torch-1.6 optimizers skip the others, train_distr.py:423-428) then lives on the DEVICE: it can be MAX-all-reduced
+ * across ranks and consumed by the update without a host round trip. */
 int gpv_sumsq(const float* x, int64_t n, float* out /* += */, void* stream);
 
 #ifdef __cplusplus

@@ -257,12 +257,16 @@ def relevance_condition(x, logits, tokens, y, rows, dim):
     y.copy_((x.float() + logits.softmax(-1) @ tokens).to(y.dtype))
 
 
-def adamw(p, g, m, v, p_lowp, n, lr, beta1, beta2, eps, wd, bc1, bc2, gscale=None):
+def adamw(p, g, m, v, p_lowp, n, lr, beta1, beta2, eps, wd, bc1, bc2, gscale=None, seg_id=None, seg_live=None):
     gi = g * (gscale if gscale is not None else 1.0)
-    p.mul_(1 - lr * wd)
-    m.mul_(beta1).add_(gi, alpha=1 - beta1)
-    v.mul_(beta2).addcmul_(gi, gi, value=1 - beta2)
-    p.addcdiv_(m, v.sqrt() / math.sqrt(bc2) + eps, value=-lr / bc1)
+    p2 = p * (1 - lr * wd)
+    m2 = m * beta1 + gi * (1 - beta1)
+    v2 = v * beta2 + gi * gi * (1 - beta2)
+    p2 = p2 - (lr / bc1) * m2 / (v2.sqrt() / math.sqrt(bc2) + eps)
+    if seg_id is not None:
+        live = seg_live[seg_id[:(n + 7) // 8].long()].bool().repeat_interleave(8)[:n]
+        p2, m2, v2 = torch.where(live, p2, p), torch.where(live, m2, m), torch.where(live, v2, v)
+    p.copy_(p2); m.copy_(m2); v.copy_(v2)
     if p_lowp is not None:
         p_lowp.copy_(p.to(p_lowp.dtype))
 

@@ -479,3 +479,21 @@ def test_adamw_matches_torch():
     acc = torch.zeros(1, device=DEV)
     h.sumsq(g, n, acc)
     assert rel(acc, (g * g).sum().view(1)) < 1e-5
+    # per-parameter liveness on the device: chunks of 8 elements map to a parameter id, dead parameters are left alone
+    n2 = 4096
+    bounds = [0, 40, 1000, 1008, 3000, n2]                      # 5 parameters, starts on multiples of 8
+    sid = torch.zeros(n2 // 8, dtype=torch.int16)
+    for i in range(5):
+        sid[bounds[i] // 8:bounds[i + 1] // 8] = i
+    live = torch.tensor([1, 0, 1, 0, 1], dtype=torch.int32, device=DEV)
+    p0, g = rnd(n2, seed=92), rnd(n2, seed=93)
+    p, m, v = p0.clone(), torch.zeros(n2, device=DEV), torch.zeros(n2, device=DEV)
+    pr, mr, vr = p0.clone(), torch.zeros(n2, device=DEV), torch.zeros(n2, device=DEV)
+    h.adamw(p, g, m, v, None, n2, 1e-3, 0.9, 0.999, 1e-8, 1e-2, 0.1, 0.001, seg_id=sid.to(DEV), seg_live=live)
+    h.adamw(pr, g, mr, vr, None, n2, 1e-3, 0.9, 0.999, 1e-8, 1e-2, 0.1, 0.001)
+    for i in range(5):
+        sl = slice(bounds[i], bounds[i + 1])
+        if live[i]:
+            assert torch.equal(p[sl], pr[sl]) and torch.equal(m[sl], mr[sl])
+        else:
+            assert torch.equal(p[sl], p0[sl]) and m[sl].abs().max() == 0 and v[sl].abs().max() == 0
