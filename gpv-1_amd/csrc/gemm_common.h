@@ -46,4 +46,9 @@ __device__ __forceinline__ int conv_row_to_pixel(int m, const ConvGeom& g) {
 // (caller falls back to the 4-wave kernel), > 0 = hipError_t.
 int glds_try_launch(const GemmK& k, int amode, int dtype_in, int dtype_out, int batch, hipStream_t st);
 
+// gemm_skinny.hip: 64x64 tiles with the reduction split across the block's four waves, for GEMMs whose tiles cannot
+// fill the chip (M = 192..640 rows).  Same return convention.
+int skinny_try_launch(const GemmK& k, int dtype_in, int dtype_out, int batch, hipStream_t st);
+extern int g_skinny_mode;
+
 }  // namespace gpvk

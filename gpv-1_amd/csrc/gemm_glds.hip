@@ -358,6 +358,11 @@ extern "C" int gpv_set_option(int option, int value) {
     gpvk::g_glds_mode = value;
     return prev;
   }
+  if (option == GPV_OPT_SKINNY) {
+    const int prev = gpvk::g_skinny_mode;
+    gpvk::g_skinny_mode = value;
+    return prev;
+  }
   if (option == GPV_OPT_GLDS_LAUNCHES) {
     const long prev = gpvk::g_glds_launches;
     gpvk::g_glds_launches = value;

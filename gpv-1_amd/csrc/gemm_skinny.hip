@@ -1,0 +1,186 @@
+// Small-M GEMM with the reduction split across the four waves of a workgroup (gfx950).
+//
+//   C[M,N] = epilogue( A[M,K] x B[N,K]^T ),  bf16, both operands K-major, 64x64 output tile per 256-thread block.
+//
+// The frozen BERT encoder runs at M = B*T_l = 192 rows and the text decoder at 640: 36..144 tiles of 64x64 cannot fill
+// 256 CUs, so gemm.hip's kernel spends its time in the serial k-loop of a few resident blocks (K = 768: 24 steps of 32,
+// ~0.5 us each: 11.9 us; K = 3072: 34 us).  Here one k-step is 128 deep: every wave multiplies the WHOLE 64x64 tile
+// over its own 32-deep quarter (4x fewer serial steps, 16 MFMAs per wave and step), and the four partial tiles are
+// summed through LDS once at the end.  Same epilogue contract as gpv_gemm (alpha, rowscale, bias, residual, ReLU/GELU,
+// dropout, ReLU mask).
+#include "gemm_common.h"
+
+namespace gpvk {
+
+int g_skinny_mode = 1;        // gpv_set_option(GPV_OPT_SKINNY, .): 0 never, 1 heuristic, 2 wherever legal
+
+namespace {
+
+constexpr int SBM = 64, SBN = 64, SBK = 128, SPITCH = SBK + 8;     // LDS row pitch 272 B: 16 rows cover all 64 banks
+
+template <typename TOut>
+__global__ __launch_bounds__(256) void skinny_kernel(GemmK p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  bf16* lds = reinterpret_cast<bf16*>(smem);
+  constexpr int TILE = SBM * SPITCH;                  // elements per operand tile
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tn = blockIdx.x % p.tilesN, tm = blockIdx.x / p.tilesN;
+  const int row0 = tm * SBM, col0 = tn * SBN;
+  const bf16* A = reinterpret_cast<const bf16*>(p.A);
+  const bf16* B = reinterpret_cast<const bf16*>(p.B);
+  const int nk = (p.K + SBK - 1) / SBK;
+
+  // loader: 64 rows x 16 chunks of 16 B per operand = 1024 chunks -> 4 per thread (same chunk column, rows +16)
+  const int lc = tid & 15, lr = tid >> 4;
+  const bf16* ap[4];
+  const bf16* bp[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    ap[i] = A + (int64_t)min(row0 + lr + 16 * i, p.M - 1) * p.lda + lc * 8;
+    bp[i] = B + (int64_t)min(col0 + lr + 16 * i, p.N - 1) * p.ldb + lc * 8;
+  }
+  uint4 ra[4], rb[4];
+  auto load = [&](int kt) {
+    const int k = kt * SBK + lc * 8;
+    const bool ok = k < p.K;                           // K % 8 == 0 (host): a chunk is entirely inside or outside
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ra[i] = *reinterpret_cast<const uint4*>(ok ? ap[i] + kt * SBK : ap[i]);
+      rb[i] = *reinterpret_cast<const uint4*>(ok ? bp[i] + kt * SBK : bp[i]);
+      if (!ok) { ra[i] = make_uint4(0, 0, 0, 0); rb[i] = make_uint4(0, 0, 0, 0); }
+    }
+  };
+  auto store = [&](int stage) {
+    bf16* sa = lds + stage * 2 * TILE;
+    bf16* sb = sa + TILE;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *reinterpret_cast<uint4*>(sa + (lr + 16 * i) * SPITCH + lc * 8) = ra[i];
+      *reinterpret_cast<uint4*>(sb + (lr + 16 * i) * SPITCH + lc * 8) = rb[i];
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int foff = (lane & 15) * SPITCH + wave * 32 + (lane >> 4) * 8;      // this wave's quarter of the k-step
+
+  load(0);
+  store(0);
+  __syncthreads();
+  for (int t = 0; t < nk; ++t) {
+    if (t + 1 < nk) load(t + 1);                       // in flight while tile t is multiplied
+    const bf16* sa = lds + (t & 1) * 2 * TILE;
+    const bf16* sb = sa + TILE;
+    bf16x8 af[4], bfr[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      af[i] = *reinterpret_cast<const bf16x8*>(sa + i * 16 * SPITCH + foff);
+      bfr[i] = *reinterpret_cast<const bf16x8*>(sb + i * 16 * SPITCH + foff);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(bfr[j], af[i], acc[i][j]);    // swapped: lane holds 4 consecutive columns
+    if (t + 1 < nk) store((t + 1) & 1);
+    __syncthreads();
+  }
+
+  // ---- sum the four waves' partial tiles through LDS (fragment-native order: every access is lane-contiguous) ----
+  float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      *reinterpret_cast<f32x4*>(red + wave * (SBM * SBN) + (i * 4 + j) * 256 + lane * 4) = acc[i][j];
+  __syncthreads();
+
+  TOut* Cp = reinterpret_cast<TOut*>(p.C);
+  const TOut* Rp = reinterpret_cast<const TOut*>(p.res);
+  const TOut* Mp = reinterpret_cast<const TOut*>(p.mask);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int q = tid + 256 * r;
+    const int ij = q >> 6, l = q & 63;
+    f32x4 v = *reinterpret_cast<const f32x4*>(red + ij * 256 + l * 4);
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      const f32x4 u = *reinterpret_cast<const f32x4*>(red + w * (SBM * SBN) + ij * 256 + l * 4);
+      v[0] += u[0]; v[1] += u[1]; v[2] += u[2]; v[3] += u[3];
+    }
+    const int m = row0 + (ij >> 2) * 16 + (l & 15);
+    const int n = col0 + (ij & 3) * 16 + (l >> 4) * 4;
+    if (m >= p.M || n >= p.N) continue;
+    const float rs = p.rowscale ? p.rowscale[m] * p.alpha : p.alpha;
+    float o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (n + e >= p.N) { o[e] = 0.f; continue; }
+      float x = v[e] * rs;
+      if (p.bias) x += p.bias[n + e];
+      if (Rp) x += (float)Rp[(int64_t)m * p.ldr + n + e];
+      if (p.act == GPV_ACT_RELU) x = fmaxf(x, 0.f);
+      else if (p.act == GPV_ACT_GELU) x = gelu_erf(x);
+      if (p.dthresh) x = drop_keep(p.seed, (uint64_t)m * (uint64_t)p.N + (n + e), p.dthresh) ? x * p.dscale : 0.f;
+      if (Mp) x = (float)Mp[(int64_t)m * p.ldm + n + e] > 0.f ? x : 0.f;
+      o[e] = x;
+    }
+    TOut* dst = Cp + (int64_t)m * p.ldc + n;
+    if (n + 4 <= p.N && (p.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(Cp) & 7) == 0) {
+      if constexpr (sizeof(TOut) == 2) {
+        bf16x4 o4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o4[e] = (bf16)o[e];
+        *reinterpret_cast<bf16x4*>(dst) = o4;
+      } else {
+        if ((reinterpret_cast<uintptr_t>(Cp) & 15) == 0) *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+        else { dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2]; dst[3] = o[3]; }
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (n + e < p.N) dst[e] = (TOut)o[e];
+    }
+  }
+}
+
+template <typename TOut>
+int launch_skinny(const GemmK& k, hipStream_t st) {
+  constexpr size_t stage = (size_t)2 * 2 * SBM * SPITCH * 2;         // two stages x (A, B) tiles
+  constexpr size_t redb = (size_t)4 * SBM * SBN * 4;
+  constexpr size_t lds = stage > redb ? stage : redb;
+  GemmK p = k;
+  p.tilesN = (p.N + SBN - 1) / SBN;
+  const int tilesM = (p.M + SBM - 1) / SBM;
+  auto fn = skinny_kernel<TOut>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(fn, dim3(tilesM * p.tilesN), dim3(256), lds, st, p);
+  GPV_CHECK_LAUNCH();
+  return 0;
+}
+
+inline bool al16s(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
+
+}  // namespace
+
+// returns 0 = launched, -1 = not applicable, > 0 = hipError_t
+int skinny_try_launch(const GemmK& k, int dtype_in, int dtype_out, int batch, hipStream_t st) {
+  if (g_skinny_mode == 0 || dtype_in != GPV_BF16 || batch != 1 || k.accumulate || k.split_k > 1) return -1;
+  if (k.K % 8 != 0 || k.lda % 8 != 0 || k.ldb % 8 != 0 || !al16s(k.A) || !al16s(k.B)) return -1;
+  if (g_skinny_mode == 1) {
+    // worth it when the 64x64 tiles cannot fill the chip and the reduction is long enough to be the cost
+    const int64_t tiles = (int64_t)((k.M + SBM - 1) / SBM) * ((k.N + SBN - 1) / SBN);
+    if (tiles > 320 || k.K < 512) return -1;
+  }
+  if (dtype_out == GPV_BF16) return launch_skinny<bf16>(k, st);
+  return launch_skinny<float>(k, st);
+}
+
+}  // namespace gpvk

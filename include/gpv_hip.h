@@ -42,6 +42,7 @@ int gpv_abi_version(void); /* = 1 */
  *   direct-to-LDS kernel where it is expected to win, 2 = wherever it is legal.  Returns the previous value,
  *   or -1 for an unknown option.  (No reference counterpart: the reference delegates kernel choice to cuDNN/cuBLAS.) */
 #define GPV_OPT_GLDS 0
+#define GPV_OPT_SKINNY 2 /* small-M GEMM kernel (reduction split over the block's waves): 0 never, 1 (default) heuristic, 2 wherever legal */
 #define GPV_OPT_GLDS_LAUNCHES 1 /* returns the number of 8-wave launches so far, then sets the counter to value */
 int gpv_set_option(int option, int value);
 

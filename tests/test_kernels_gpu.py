@@ -210,9 +210,11 @@ def glds():
     """force the 8-wave kernel wherever it is legal (by default it only takes the large launches) and count its launches"""
     h = hip()
     prev = h.set_option(h.OPT_GLDS, 2)
+    prevs = h.set_option(h.OPT_SKINNY, 0)
     h.set_option(h.OPT_GLDS_LAUNCHES, 0)
     yield h
     h.set_option(h.OPT_GLDS, prev)
+    h.set_option(h.OPT_SKINNY, prevs)
 
 
 @pytest.mark.parametrize('M,N,K', [(300, 256, 256), (2048, 512, 768), (1000, 128, 192), (257, 130, 64), (9600, 256, 2048),
@@ -254,6 +256,49 @@ def test_glds_gemm_epilogue_and_batch(glds):
     h.gemm(A, B, c2, M, N, K, K, K, N, drop_p=0.25, seed=77)
     h.set_option(h.OPT_GLDS, 2)
     assert torch.equal(c1 == 0, c2 == 0) and rel(c1, c2.float()) < 1e-2
+
+
+@pytest.fixture()
+def skinny():
+    """force the small-M kernel (gemm_skinny.hip: reduction split over the block's four waves) wherever it is legal"""
+    h = hip()
+    prev = h.set_option(h.OPT_SKINNY, 2)
+    prevg = h.set_option(h.OPT_GLDS, 0)
+    yield h
+    h.set_option(h.OPT_SKINNY, prev)
+    h.set_option(h.OPT_GLDS, prevg)
+
+
+@pytest.mark.parametrize('M,N,K', [(192, 768, 768), (192, 768, 3072), (640, 2304, 768), (70, 130, 200), (1, 768, 768), (640, 768, 10000),
+                                   (65, 64, 128), (300, 100, 8)])
+def test_skinny_gemm(skinny, M, N, K):
+    h, dtype = skinny, torch.bfloat16
+    A, B = rnd(M, K, dtype=dtype, seed=1), rnd(N, K, dtype=dtype, seed=2)
+    ref = A.float() @ B.float().t()
+    Cm = torch.empty(M, N, device=DEV, dtype=dtype)
+    h.gemm(A, B, Cm, M, N, K, K, K, N)
+    assert rel(Cm, ref) < TOL[dtype]
+    h.set_option(h.OPT_SKINNY, 0)                                  # the 4-wave kernel on the same problem
+    C0 = torch.empty(M, N, device=DEV, dtype=dtype)
+    h.gemm(A, B, C0, M, N, K, K, K, N)
+    h.set_option(h.OPT_SKINNY, 2)
+    assert rel(Cm, C0.float()) < 8e-3                              # same math, different fp32 summation order + one bf16 rounding
+    bias, rs = rnd(N, seed=5), rnd(M, seed=6)
+    res, mask = rnd(M, N, dtype=dtype, seed=7), rnd(M, N, dtype=dtype, seed=8)
+    for act, fn in ((h.ACT_NONE, lambda x: x), (h.ACT_RELU, F.relu), (h.ACT_GELU, lambda x: F.gelu(x))):
+        h.gemm(A, B, Cm, M, N, K, K, K, N, alpha=0.5, rowscale=rs, bias=bias, res=res, ldr=N, relu_mask=mask, ldm=N, act=act)
+        r2 = fn(0.5 * ref * rs[:, None] + bias + res.float()) * (mask.float() > 0)
+        assert rel(Cm, r2) < TOL[dtype], act
+    Cf = torch.zeros(M, N + 8, device=DEV)                         # fp32 output, strided C
+    h.gemm(A, B, Cf, M, N, K, K, K, N + 8)
+    assert rel(Cf[:, :N], ref) < 1e-5 and Cf[:, N:].abs().max() == 0
+    if K >= 64:
+        c1, c2 = torch.empty(M, N, device=DEV, dtype=dtype), torch.empty(M, N, device=DEV, dtype=dtype)
+        h.gemm(A, B, c1, M, N, K, K, K, N, drop_p=0.25, seed=77)  # same keep pattern as the 4-wave kernel
+        h.set_option(h.OPT_SKINNY, 0)
+        h.gemm(A, B, c2, M, N, K, K, K, N, drop_p=0.25, seed=77)
+        h.set_option(h.OPT_SKINNY, 2)
+        assert torch.equal(c1 == 0, c2 == 0)
 
 
 GCONVS = [  # Cin, Cout, k, stride, pad, H, W   (Cin % 64 == 0 both ways, Cout > 64)
