@@ -175,9 +175,10 @@ int skinny_try_launch(const GemmK& k, int dtype_in, int dtype_out, int batch, hi
   if (g_skinny_mode == 0 || dtype_in != GPV_BF16 || batch != 1 || k.accumulate || k.split_k > 1) return -1;
   if (k.K % 8 != 0 || k.lda % 8 != 0 || k.ldb % 8 != 0 || !al16s(k.A) || !al16s(k.B)) return -1;
   if (g_skinny_mode == 1) {
-    // worth it when the 64x64 tiles cannot fill the chip and the reduction is long enough to be the cost
+    // measured on every forward GEMM shape of the step (tools/bench_step_gemms.py, SK=0 vs 2): it wins whenever the
+    // 64x64 tiles cannot fill the chip (<= ~1.4 per CU), and up to 2.5 per CU when the reduction is long
     const int64_t tiles = (int64_t)((k.M + SBM - 1) / SBM) * ((k.N + SBN - 1) / SBN);
-    if (tiles > 320 || k.K < 512) return -1;
+    if (!((tiles <= 360 && k.K >= 128) || (tiles <= 640 && k.K >= 2048))) return -1;
   }
   if (dtype_out == GPV_BF16) return launch_skinny<bf16>(k, st);
   return launch_skinny<float>(k, st);

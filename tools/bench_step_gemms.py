@@ -5,6 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import gpv1_amd.hip as hip
 import gpv1_amd.ops as ops
 dev = 'cuda'
+if 'SK' in os.environ: hip.set_option(hip.OPT_SKINNY, int(os.environ['SK']))
 shapes = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'gemm_shapes_step.json')))
 rows = []
 for (M, N, K, la, lb, batch, acc), count in shapes:
@@ -25,6 +26,6 @@ for (M, N, K, la, lb, batch, acc), count in shapes:
 rows.sort(reverse=True)
 tot = sum(r[0] for r in rows)
 print('total %.2f ms over %d calls' % (tot / 1e3, sum(r[2] for r in rows)))
-for r in rows[:40]:
+for r in sorted(rows, key=lambda r: (r[3], r[4], r[5], r[6], r[7]))  if os.environ.get('SORT') else rows[:40]:
     t, us, c, M, N, K, la, lb, acc = r
     print('%7.0f us = %3d x %6.1f us  M=%5d N=%5d K=%5d  %s%s %s  %5.0f TF/s' % (t, c, us, M, N, K, 'T' if la else 'K', 'T' if lb else 'K', 'wgrad' if acc else '', 2.0 * M * N * K / us / 1e6))
