@@ -796,13 +796,17 @@ extern "C" int gpv_gemm(const gpv_gemm_args* a, void* stream) {
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int la = a->layoutA, lb = a->layoutB;
   if (la == GPV_KMAJOR && lb == GPV_KMAJOR) {
-    const int sk = skinny_try_launch(k, a->dtype_in, a->dtype_out, a->batch, st);             // few tiles, long reduction (BERT, text decoder)
+    const int sk = skinny_try_launch(k, 0, a->dtype_in, a->dtype_out, a->batch, st);             // few tiles, long reduction (BERT, text decoder)
     if (sk >= 0) return sk;
     const int g = glds_try_launch(k, OP_PLAIN, a->dtype_in, a->dtype_out, a->batch, st);      // 8-wave direct-to-LDS kernel when it qualifies
     if (g >= 0) return g;
     return launch_dtype<OP_PLAIN, OP_PLAIN>(k, a->batch, a->dtype_in, a->dtype_out, st);
   }
-  if (la == GPV_KMAJOR && lb == GPV_TRANS) return launch_dtype<OP_PLAIN, OP_TRANS>(k, a->batch, a->dtype_in, a->dtype_out, st);
+  if (la == GPV_KMAJOR && lb == GPV_TRANS) {
+    const int sk = skinny_try_launch(k, 1, a->dtype_in, a->dtype_out, a->batch, st);             // small backward-data GEMMs
+    if (sk >= 0) return sk;
+    return launch_dtype<OP_PLAIN, OP_TRANS>(k, a->batch, a->dtype_in, a->dtype_out, st);
+  }
   if (la == GPV_TRANS && lb == GPV_TRANS) return launch_dtype<OP_TRANS, OP_TRANS>(k, a->batch, a->dtype_in, a->dtype_out, st);
   return (int)hipErrorInvalidValue;
 }

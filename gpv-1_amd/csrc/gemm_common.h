@@ -48,7 +48,7 @@ int glds_try_launch(const GemmK& k, int amode, int dtype_in, int dtype_out, int 
 
 // gemm_skinny.hip: 64x64 tiles with the reduction split across the block's four waves, for GEMMs whose tiles cannot
 // fill the chip (M = 192..640 rows).  Same return convention.
-int skinny_try_launch(const GemmK& k, int dtype_in, int dtype_out, int batch, hipStream_t st);
+int skinny_try_launch(const GemmK& k, int b_trans, int dtype_in, int dtype_out, int batch, hipStream_t st);
 extern int g_skinny_mode;
 
 }  // namespace gpvk

@@ -17,12 +17,29 @@ int g_skinny_mode = 1;        // gpv_set_option(GPV_OPT_SKINNY, .): 0 never, 1 h
 namespace {
 
 constexpr int SBM = 64, SBN = 64, SBK = 128, SPITCH = SBK + 8;     // LDS row pitch 272 B: 16 rows cover all 64 banks
+constexpr int TPITCH = SBN + 16;      // reduction-major B tile [128 red][64 cols]: pitch 160 B (the transpose-read rule of gemm.hip)
 
-template <typename TOut>
+// fragment of a reduction-major tile for the 16 columns starting at cbase: lane (col = lane&15, g = lane>>4) receives the
+// reduction rows 8g..8g+7 of its column (two ds_read_b64_tr_b16, see gemm.hip TStage::frag)
+__device__ __forceinline__ bf16x8 tr_frag(const bf16* tile, int cbase, int lane) {
+  typedef short __attribute__((ext_vector_type(4))) s16x4;
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  const int g = lane >> 4, i = lane & 15;
+  const bf16* p0 = tile + (8 * g + (i >> 2)) * TPITCH + cbase + (i & 3) * 4;
+  s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0));
+  s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0 + 4 * TPITCH));
+  typedef short __attribute__((ext_vector_type(8))) s16x8;
+  s16x8 r = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  return __builtin_bit_cast(bf16x8, r);
+}
+
+template <typename TOut, bool BT>
 __global__ __launch_bounds__(256) void skinny_kernel(GemmK p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   bf16* lds = reinterpret_cast<bf16*>(smem);
-  constexpr int TILE = SBM * SPITCH;                  // elements per operand tile
+  constexpr int TILE = SBM * SPITCH;                  // elements of a K-major operand tile
+  constexpr int BTILE = BT ? SBK * TPITCH : TILE;      // reduction-major B tile is [128][80]
+  constexpr int STAGE = TILE + BTILE;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tn = blockIdx.x % p.tilesN, tm = blockIdx.x / p.tilesN;
   const int row0 = tm * SBM, col0 = tn * SBN;
@@ -34,10 +51,14 @@ __global__ __launch_bounds__(256) void skinny_kernel(GemmK p) {
   const int lc = tid & 15, lr = tid >> 4;
   const bf16* ap[4];
   const bf16* bp[4];
+  // reduction-major B (BT): tile rows are reduction indices, a row is 64 output columns = 8 chunks -> thread (row tr + 32 i, chunk tc)
+  const int tc = tid & 7, tr = tid >> 3;
+  const bool bcol_ok = col0 + tc * 8 < p.N;            // N % 8 == 0 (host)
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     ap[i] = A + (int64_t)min(row0 + lr + 16 * i, p.M - 1) * p.lda + lc * 8;
-    bp[i] = B + (int64_t)min(col0 + lr + 16 * i, p.N - 1) * p.ldb + lc * 8;
+    if constexpr (BT) bp[i] = B + (int64_t)(tr + 32 * i) * p.ldb + (bcol_ok ? col0 + tc * 8 : 0);
+    else bp[i] = B + (int64_t)min(col0 + lr + 16 * i, p.N - 1) * p.ldb + lc * 8;
   }
   uint4 ra[4], rb[4];
   auto load = [&](int kt) {
@@ -46,17 +67,25 @@ __global__ __launch_bounds__(256) void skinny_kernel(GemmK p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       ra[i] = *reinterpret_cast<const uint4*>(ok ? ap[i] + kt * SBK : ap[i]);
-      rb[i] = *reinterpret_cast<const uint4*>(ok ? bp[i] + kt * SBK : bp[i]);
-      if (!ok) { ra[i] = make_uint4(0, 0, 0, 0); rb[i] = make_uint4(0, 0, 0, 0); }
+      if (!ok) ra[i] = make_uint4(0, 0, 0, 0);
+      if constexpr (BT) {
+        const bool okb = bcol_ok && kt * SBK + tr + 32 * i < p.K;
+        rb[i] = *reinterpret_cast<const uint4*>(okb ? bp[i] + (int64_t)kt * SBK * p.ldb : B);
+        if (!okb) rb[i] = make_uint4(0, 0, 0, 0);
+      } else {
+        rb[i] = *reinterpret_cast<const uint4*>(ok ? bp[i] + kt * SBK : bp[i]);
+        if (!ok) rb[i] = make_uint4(0, 0, 0, 0);
+      }
     }
   };
   auto store = [&](int stage) {
-    bf16* sa = lds + stage * 2 * TILE;
+    bf16* sa = lds + stage * STAGE;
     bf16* sb = sa + TILE;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       *reinterpret_cast<uint4*>(sa + (lr + 16 * i) * SPITCH + lc * 8) = ra[i];
-      *reinterpret_cast<uint4*>(sb + (lr + 16 * i) * SPITCH + lc * 8) = rb[i];
+      if constexpr (BT) *reinterpret_cast<uint4*>(sb + (tr + 32 * i) * TPITCH + tc * 8) = rb[i];
+      else *reinterpret_cast<uint4*>(sb + (lr + 16 * i) * SPITCH + lc * 8) = rb[i];
     }
   };
 
@@ -72,13 +101,14 @@ __global__ __launch_bounds__(256) void skinny_kernel(GemmK p) {
   __syncthreads();
   for (int t = 0; t < nk; ++t) {
     if (t + 1 < nk) load(t + 1);                       // in flight while tile t is multiplied
-    const bf16* sa = lds + (t & 1) * 2 * TILE;
+    const bf16* sa = lds + (t & 1) * STAGE;
     const bf16* sb = sa + TILE;
     bf16x8 af[4], bfr[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       af[i] = *reinterpret_cast<const bf16x8*>(sa + i * 16 * SPITCH + foff);
-      bfr[i] = *reinterpret_cast<const bf16x8*>(sb + i * 16 * SPITCH + foff);
+      if constexpr (BT) bfr[i] = tr_frag(sb + wave * 32 * TPITCH, i * 16, lane);
+      else bfr[i] = *reinterpret_cast<const bf16x8*>(sb + i * 16 * SPITCH + foff);
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -146,15 +176,15 @@ __global__ __launch_bounds__(256) void skinny_kernel(GemmK p) {
   }
 }
 
-template <typename TOut>
+template <typename TOut, bool BT>
 int launch_skinny(const GemmK& k, hipStream_t st) {
-  constexpr size_t stage = (size_t)2 * 2 * SBM * SPITCH * 2;         // two stages x (A, B) tiles
+  constexpr size_t stage = (size_t)2 * (SBM * SPITCH + (BT ? SBK * TPITCH : SBM * SPITCH)) * 2;      // two stages x (A, B) tiles
   constexpr size_t redb = (size_t)4 * SBM * SBN * 4;
   constexpr size_t lds = stage > redb ? stage : redb;
   GemmK p = k;
   p.tilesN = (p.N + SBN - 1) / SBN;
   const int tilesM = (p.M + SBM - 1) / SBM;
-  auto fn = skinny_kernel<TOut>;
+  auto fn = skinny_kernel<TOut, BT>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -170,18 +200,19 @@ inline bool al16s(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) 
 
 }  // namespace
 
-// returns 0 = launched, -1 = not applicable, > 0 = hipError_t
-int skinny_try_launch(const GemmK& k, int dtype_in, int dtype_out, int batch, hipStream_t st) {
+// returns 0 = launched, -1 = not applicable, > 0 = hipError_t.  b_trans: B is reduction-major (GPV_TRANS): dX = dY W.
+int skinny_try_launch(const GemmK& k, int b_trans, int dtype_in, int dtype_out, int batch, hipStream_t st) {
   if (g_skinny_mode == 0 || dtype_in != GPV_BF16 || batch != 1 || k.accumulate || k.split_k > 1) return -1;
   if (k.K % 8 != 0 || k.lda % 8 != 0 || k.ldb % 8 != 0 || !al16s(k.A) || !al16s(k.B)) return -1;
+  if (b_trans && k.N % 8 != 0) return -1;
   if (g_skinny_mode == 1) {
     // measured on every forward GEMM shape of the step (tools/bench_step_gemms.py, SK=0 vs 2): it wins whenever the
     // 64x64 tiles cannot fill the chip (<= ~1.4 per CU), and up to 2.5 per CU when the reduction is long
     const int64_t tiles = (int64_t)((k.M + SBM - 1) / SBM) * ((k.N + SBN - 1) / SBN);
     if (!((tiles <= 360 && k.K >= 128) || (tiles <= 640 && k.K >= 2048))) return -1;
   }
-  if (dtype_out == GPV_BF16) return launch_skinny<bf16>(k, st);
-  return launch_skinny<float>(k, st);
+  if (b_trans) return dtype_out == GPV_BF16 ? launch_skinny<bf16, true>(k, st) : launch_skinny<float, true>(k, st);
+  return dtype_out == GPV_BF16 ? launch_skinny<bf16, false>(k, st) : launch_skinny<float, false>(k, st);
 }
 
 }  // namespace gpvk

@@ -301,6 +301,29 @@ def test_skinny_gemm(skinny, M, N, K):
         assert torch.equal(c1 == 0, c2 == 0)
 
 
+@pytest.mark.parametrize('M,N,K', [(3200, 256, 2048), (640, 768, 768), (3200, 256, 256), (70, 136, 200), (1, 768, 2048), (300, 64, 72)])
+def test_skinny_gemm_reduction_major_b(skinny, M, N, K):
+    """dX[M,N] = dY[M,K] W[K,N] with W read reduction-major (GPV_TRANS), the backward-data form of a Linear"""
+    h, dtype = skinny, torch.bfloat16
+    A, W = rnd(M, K, dtype=dtype, seed=11), rnd(K, N, dtype=dtype, seed=12)
+    ref = A.float() @ W.float()
+    Cm = torch.empty(M, N, device=DEV, dtype=dtype)
+    h.gemm(A, W, Cm, M, N, K, K, N, N, layoutB=h.TRANS)
+    assert rel(Cm, ref) < TOL[dtype]
+    h.set_option(h.OPT_SKINNY, 0)
+    C0 = torch.empty(M, N, device=DEV, dtype=dtype)
+    h.gemm(A, W, C0, M, N, K, K, N, N, layoutB=h.TRANS)
+    h.set_option(h.OPT_SKINNY, 2)
+    assert rel(Cm, C0.float()) < 8e-3
+    res = rnd(M, N, dtype=dtype, seed=13)
+    h.gemm(A, W, Cm, M, N, K, K, N, N, layoutB=h.TRANS, res=res, ldr=N, alpha=2.0)
+    assert rel(Cm, 2.0 * ref + res.float()) < TOL[dtype]
+    Wp = torch.zeros(K, N + 8, device=DEV, dtype=dtype)              # strided W
+    Wp[:, :N] = W
+    h.gemm(A, Wp, Cm, M, N, K, K, N + 8, N, layoutB=h.TRANS)
+    assert rel(Cm, ref) < TOL[dtype]
+
+
 GCONVS = [  # Cin, Cout, k, stride, pad, H, W   (Cin % 64 == 0 both ways, Cout > 64)
     (64, 128, 1, 1, 0, 24, 32), (256, 128, 3, 2, 1, 24, 32), (128, 128, 3, 1, 1, 15, 20), (256, 512, 1, 2, 0, 30, 40),
     (512, 2048, 1, 1, 0, 15, 20), (128, 256, 3, 2, 1, 17, 23), (128, 192, 3, 2, 1, 32, 32)]
