@@ -674,6 +674,26 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   }
 }
 
+}  // namespace
+
+namespace gpvk {
+// C[m,n] += sum over `split` dense [M,N] slabs of ws (N % 4 == 0, ldc % 4 == 0, C 16-byte aligned)
+int launch_splitk_reduce(const float* ws, int split, int M, int N, float* C, int64_t ldc, hipStream_t st) {
+  const int64_t quads = (int64_t)M * (N / 4);
+  if (split >= 32) {
+    hipLaunchKernelGGL(splitk_reduce_kernel<16>, dim3((unsigned)((quads + 15) / 16)), dim3(256), 0, st, ws, split, M, N, C, ldc);
+  } else if (split >= 4) {
+    hipLaunchKernelGGL(splitk_reduce_kernel<4>, dim3((unsigned)((quads + 63) / 64)), dim3(256), 0, st, ws, split, M, N, C, ldc);
+  } else {
+    hipLaunchKernelGGL(splitk_reduce_kernel<1>, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, st, ws, split, M, N, C, ldc);
+  }
+  GPV_CHECK_LAUNCH();
+  return 0;
+}
+}  // namespace gpvk
+
+namespace {
+
 template <typename TIn, typename TOut, int AMODE, int BMODE, int BM, int BN, bool VEC>
 int launch_cfg_v(const GemmK& k, int batch, hipStream_t st) {
   constexpr bool PRECISE = sizeof(TIn) == 4;
@@ -709,16 +729,8 @@ int launch_cfg_v(const GemmK& k, int batch, hipStream_t st) {
   hipLaunchKernelGGL(fn, grid, dim3(256), lds, st, p);
   GPV_CHECK_LAUNCH();
   if (two_pass) {
-    const int64_t quads = (int64_t)p.M * (p.N / 4);
-    float* Cf = reinterpret_cast<float*>(p.C);
-    if (split >= 32) {
-      hipLaunchKernelGGL(splitk_reduce_kernel<16>, dim3((unsigned)((quads + 15) / 16)), dim3(256), 0, st, p.ws, split, p.M, p.N, Cf, p.ldc);
-    } else if (split >= 4) {
-      hipLaunchKernelGGL(splitk_reduce_kernel<4>, dim3((unsigned)((quads + 63) / 64)), dim3(256), 0, st, p.ws, split, p.M, p.N, Cf, p.ldc);
-    } else {
-      hipLaunchKernelGGL(splitk_reduce_kernel<1>, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, st, p.ws, split, p.M, p.N, Cf, p.ldc);
-    }
-    GPV_CHECK_LAUNCH();
+    const int e = launch_splitk_reduce(p.ws, split, p.M, p.N, reinterpret_cast<float*>(p.C), p.ldc, st);
+    if (e) return e;
   }
   return 0;
 }
@@ -807,7 +819,15 @@ extern "C" int gpv_gemm(const gpv_gemm_args* a, void* stream) {
     if (sk >= 0) return sk;
     return launch_dtype<OP_PLAIN, OP_TRANS>(k, a->batch, a->dtype_in, a->dtype_out, st);
   }
-  if (la == GPV_TRANS && lb == GPV_TRANS) return launch_dtype<OP_TRANS, OP_TRANS>(k, a->batch, a->dtype_in, a->dtype_out, st);
+  if (la == GPV_TRANS && lb == GPV_TRANS) {
+    if (a->accumulate) {                                  // small weight gradients: reduction split over the block's waves
+      GemmK kk = k;
+      kk.accumulate = 1; kk.res = nullptr; kk.ldr = 0; kk.sR = 0;      // (the split==1 rewrite above turned C += into res = C)
+      const int sk = skinny_tt_try_launch(kk, a->dtype_in, a->dtype_out, a->batch, st);
+      if (sk >= 0) return sk;
+    }
+    return launch_dtype<OP_TRANS, OP_TRANS>(k, a->batch, a->dtype_in, a->dtype_out, st);
+  }
   return (int)hipErrorInvalidValue;
 }
 

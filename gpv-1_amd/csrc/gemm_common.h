@@ -51,4 +51,9 @@ int glds_try_launch(const GemmK& k, int amode, int dtype_in, int dtype_out, int 
 int skinny_try_launch(const GemmK& k, int b_trans, int dtype_in, int dtype_out, int batch, hipStream_t st);
 extern int g_skinny_mode;
 
+// gemm.hip: second pass of a workspace split reduction, C[m,n] += sum_s ws[s][m][n]
+int launch_splitk_reduce(const float* ws, int split, int M, int N, float* C, int64_t ldc, hipStream_t st);
+// gemm_skinny.hip: weight-gradient form (both operands reduction-major), fp32 accumulate into C, optional a_rowsum
+int skinny_tt_try_launch(const GemmK& k, int dtype_in, int dtype_out, int batch, hipStream_t st);
+
 }  // namespace gpvk

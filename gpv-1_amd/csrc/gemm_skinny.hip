@@ -196,6 +196,119 @@ int launch_skinny(const GemmK& k, hipStream_t st) {
   return 0;
 }
 
+// ---- weight-gradient form: C[M,N] (+)= A^T B with A [K][M], B [K][N] both reduction-major (dW = dY^T X) -------------
+// grid = (tiles, splits): split s covers k-steps [s*per, (s+1)*per) of 128 and writes its partial product to the
+// workspace slab s (or, with one split, adds straight into C); a_rowsum: column sums of the A tile (bias gradient),
+// accumulated by the loader threads of the tn == 0 blocks.
+__global__ __launch_bounds__(256) void skinny_tt_kernel(GemmK p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  bf16* lds = reinterpret_cast<bf16*>(smem);
+  constexpr int TT = SBK * TPITCH;                    // [128 red][64 cols + 16]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tn = blockIdx.x % p.tilesN, tm = blockIdx.x / p.tilesN;
+  const int row0 = tm * SBM, col0 = tn * SBN;
+  const bf16* A = reinterpret_cast<const bf16*>(p.A);
+  const bf16* B = reinterpret_cast<const bf16*>(p.B);
+  const int nk_total = (p.K + SBK - 1) / SBK;
+  const int kt0 = blockIdx.y * p.kt_per_split, kt1 = min(nk_total, kt0 + p.kt_per_split);
+  const int tc = tid & 7, tr = tid >> 3;
+  const bool a_ok = row0 + tc * 8 < p.M, b_ok = col0 + tc * 8 < p.N;      // M % 8 == 0, N % 8 == 0 (host)
+  const bf16* ap = A + (a_ok ? row0 + tc * 8 : 0);
+  const bf16* bp = B + (b_ok ? col0 + tc * 8 : 0);
+  const bool do_sum = p.a_rowsum != nullptr && tn == 0;
+  float csum[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) csum[e] = 0.f;
+  uint4 ra[4], rb[4];
+  auto load = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t k = (int64_t)kt * SBK + tr + 32 * i;
+      const bool ok = k < p.K;
+      ra[i] = *reinterpret_cast<const uint4*>(ok && a_ok ? ap + k * p.lda : A);
+      rb[i] = *reinterpret_cast<const uint4*>(ok && b_ok ? bp + k * p.ldb : B);
+      if (!(ok && a_ok)) ra[i] = make_uint4(0, 0, 0, 0);
+      if (!(ok && b_ok)) rb[i] = make_uint4(0, 0, 0, 0);
+    }
+  };
+  auto store = [&](int stage) {
+    bf16* sa = lds + stage * 2 * TT;
+    bf16* sb = sa + TT;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *reinterpret_cast<uint4*>(sa + (tr + 32 * i) * TPITCH + tc * 8) = ra[i];
+      *reinterpret_cast<uint4*>(sb + (tr + 32 * i) * TPITCH + tc * 8) = rb[i];
+      if (do_sum) {
+        const uint32_t w[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          csum[2 * e] += __builtin_bit_cast(float, w[e] << 16);
+          csum[2 * e + 1] += __builtin_bit_cast(float, w[e] & 0xffff0000u);
+        }
+      }
+    }
+  };
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  load(kt0);
+  store(0);
+  __syncthreads();
+  for (int t = kt0; t < kt1; ++t) {
+    if (t + 1 < kt1) load(t + 1);
+    const bf16* sa = lds + ((t - kt0) & 1) * 2 * TT + wave * 32 * TPITCH;
+    const bf16* sb = sa + TT;
+    bf16x8 af[4], bfr[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { af[i] = tr_frag(sa, i * 16, lane); bfr[i] = tr_frag(sb, i * 16, lane); }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(bfr[j], af[i], acc[i][j]);
+    if (t + 1 < kt1) store(((t + 1 - kt0) & 1));
+    __syncthreads();
+  }
+  if (do_sum) {                                       // threads with equal tc hold partial sums of the same 8 rows of dW
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float v = csum[e];
+      v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+      const int m = row0 + tc * 8 + e;
+      if (lane < 8 && m < p.M) atomicAdd(p.a_rowsum + m, v);
+    }
+  }
+  float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      *reinterpret_cast<f32x4*>(red + wave * (SBM * SBN) + (i * 4 + j) * 256 + lane * 4) = acc[i][j];
+  __syncthreads();
+  float* Cp = p.ws ? p.ws + (int64_t)blockIdx.y * p.M * p.N : reinterpret_cast<float*>(p.C);
+  const int64_t ldc = p.ws ? p.N : p.ldc;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int q = tid + 256 * r;
+    const int ij = q >> 6, l = q & 63;
+    f32x4 v = *reinterpret_cast<const f32x4*>(red + ij * 256 + l * 4);
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      const f32x4 u = *reinterpret_cast<const f32x4*>(red + w * (SBM * SBN) + ij * 256 + l * 4);
+      v[0] += u[0]; v[1] += u[1]; v[2] += u[2]; v[3] += u[3];
+    }
+    const int m = row0 + (ij >> 2) * 16 + (l & 15);
+    const int n = col0 + (ij & 3) * 16 + (l >> 4) * 4;
+    if (m >= p.M || n >= p.N) continue;
+    const float rs = p.rowscale ? p.rowscale[m] * p.alpha : p.alpha;
+    float4* dst = reinterpret_cast<float4*>(Cp + (int64_t)m * ldc + n);     // N % 8 == 0, ldc % 4 == 0, 16-byte aligned (host)
+    float4 o = make_float4(v[0] * rs, v[1] * rs, v[2] * rs, v[3] * rs);
+    if (!p.ws) { const float4 c = *dst; o.x += c.x; o.y += c.y; o.z += c.z; o.w += c.w; }      // single split: C += ...
+    *dst = o;
+  }
+}
+
 inline bool al16s(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 
 }  // namespace
@@ -213,6 +326,39 @@ int skinny_try_launch(const GemmK& k, int b_trans, int dtype_in, int dtype_out, 
   }
   if (b_trans) return dtype_out == GPV_BF16 ? launch_skinny<bf16, true>(k, st) : launch_skinny<float, true>(k, st);
   return dtype_out == GPV_BF16 ? launch_skinny<bf16, false>(k, st) : launch_skinny<float, false>(k, st);
+}
+
+// weight-gradient form; returns 0 = launched, -1 = not applicable
+int skinny_tt_try_launch(const GemmK& k, int dtype_in, int dtype_out, int batch, hipStream_t st) {
+  if (g_skinny_mode == 0 || dtype_in != GPV_BF16 || dtype_out != GPV_F32 || batch != 1 || !k.accumulate) return -1;
+  if (k.M % 8 != 0 || k.N % 8 != 0 || k.lda % 8 != 0 || k.ldb % 8 != 0 || k.ldc % 4 != 0) return -1;
+  if (!al16s(k.A) || !al16s(k.B) || !al16s(k.C) || k.res || k.mask || k.bias || k.act || k.dthresh) return -1;
+  const int64_t tiles = (int64_t)((k.M + SBM - 1) / SBM) * ((k.N + SBN - 1) / SBN);
+  const int nk = (k.K + SBK - 1) / SBK;
+  if (g_skinny_mode == 1 && (tiles > 256 || nk < 4)) return -1;
+  // enough splits for ~512 blocks, at least 3 k-steps of 128 each, within the lent workspace
+  int split = (int)((512 + tiles - 1) / tiles);
+  if (split > nk / 3) split = nk / 3;
+  if (split < 1) split = 1;
+  while (split > 1 && (k.ws_base == nullptr || (int64_t)split * k.M * k.N * 4 > k.ws_bytes)) --split;
+  GemmK p = k;
+  p.tilesN = (p.N + SBN - 1) / SBN;
+  p.kt_per_split = (nk + split - 1) / split;
+  split = (nk + p.kt_per_split - 1) / p.kt_per_split;
+  p.ws = split > 1 ? reinterpret_cast<float*>(k.ws_base) : nullptr;
+  constexpr size_t stage = (size_t)2 * 2 * SBK * TPITCH * 2;
+  constexpr size_t redb = (size_t)4 * SBM * SBN * 4;
+  constexpr size_t lds = stage > redb ? stage : redb;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(skinny_tt_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(skinny_tt_kernel, dim3((unsigned)tiles, split), dim3(256), lds, st, p);
+  GPV_CHECK_LAUNCH();
+  if (split > 1) return launch_splitk_reduce(p.ws, split, p.M, p.N, reinterpret_cast<float*>(p.C), p.ldc, st);
+  return 0;
 }
 
 }  // namespace gpvk

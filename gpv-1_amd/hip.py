@@ -158,8 +158,8 @@ def gemm(A, B, Cm, M, N, K, lda, ldb, ldc, layoutA=KMAJOR, layoutB=KMAJOR, batch
     a.act, a.drop_p, a.seed = act, drop_p, seed
     a.accumulate, a.split_k = int(accumulate), split_k
     a.a_rowsum = _p(_f32(a_rowsum))
-    if accumulate and split_k > 1 and batch == 1:
-        ws = _workspace(A.device, split_k * M * N * 4)
+    if accumulate and batch == 1:                      # the library may split the reduction (further) when it has scratch
+        ws = _workspace(A.device, max(split_k, 8) * M * N * 4)
         a.workspace, a.workspace_bytes = _p(ws), ws.numel()
     _chk(lib().gpv_gemm(C.byref(a), _stream()), 'gpv_gemm')
 
