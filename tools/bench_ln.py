@@ -17,5 +17,7 @@ for rows, cols, dt in [(9600, 256, torch.bfloat16), (3200, 256, torch.bfloat16),
     dx = torch.empty_like(x); ds = torch.empty_like(x); dg = torch.zeros(cols, device=dev); db = torch.zeros(cols, device=dev)
     f = t(lambda: hip.layernorm_fwd(x, s, g, b, y, mean, rstd, rows, cols, 1e-5, 0.1, 7))
     bw = t(lambda: hip.layernorm_bwd(dy, x, s, g, mean, rstd, dx, ds, dg, db, rows, cols, 0.1, 7))
+    bw0 = t(lambda: hip.layernorm_bwd(dy, x, s, g, mean, rstd, dx, ds, None, None, rows, cols, 0.1, 7))
+    bw1 = t(lambda: hip.layernorm_bwd(dy, x, s, g, mean, rstd, dx, ds, dg, db, rows, cols, 0.0, 7))
     byt = rows * cols * x.element_size()
-    print('rows %5d cols %4d %-8s fwd %6.1f us (%4.0f GB/s)  bwd %6.1f us (%4.0f GB/s)' % (rows, cols, str(dt)[6:], f, 3 * byt / f / 1e3, bw, 5 * byt / bw / 1e3))
+    print('rows %5d cols %4d %-8s fwd %6.1f us (%4.0f GB/s)  bwd %6.1f us (%4.0f GB/s)  bwd no-dgamma %6.1f  bwd no-dropout %6.1f' % (rows, cols, str(dt)[6:], f, 3 * byt / f / 1e3, bw, 5 * byt / bw / 1e3, bw0, bw1))
