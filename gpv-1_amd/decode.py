@@ -57,7 +57,7 @@ class GreedyKVDecoder:
         self.wc.copy_(m.answer_head.classifiers())                                         # [V, D]
 
     # ---- one decoding step (static shapes for a fixed t) ------------------------------------
-    def _step(self, t):
+    def _step_core(self, t):
         m, B, D, H, T, Tm = self.m, self.B, self.D, self.H, self.T, self.Tm
         dh = D // H
         x = m.answer_input_embedings(self.tok)                                              # [B, D]
@@ -83,12 +83,21 @@ class GreedyKVDecoder:
             hip.attention_fwd(q, kvm, kvm[:, D:], o, st, B, H, 1, Tm, dh, 1.0 / dh ** 0.5)
             x = layer.norm2(x, ca.out_proj(o))
             x = layer.norm3(x, layer.linear2(layer.linear1(x, ops.ACT_RELU)))
-        lg = ops.matmul_nt(x, self.wc)                                                      # [B, V]
+        return ops.matmul_nt(x, self.wc)                                                    # [B, V] logits of position t
+
+    def _step(self, t):
+        lg = self._step_core(t)
         self.logits[:, t].copy_(lg)
         nxt = torch.topk(lg.float() + self.vocab_mask, k=1, dim=-1).indices[:, 0]
         self.tok.copy_(nxt)
-        if t + 1 < T:
+        if t + 1 < self.T:
             self.ids[:, t + 1].copy_(nxt)
+
+    def reorder(self, perm, upto):
+        """beam search: sequence i continues the hypothesis that lived in slot perm[i]; positions < upto are valid"""
+        for l in range(self.L):
+            self.kc[l][:, :upto].copy_(self.kc[l][:, :upto].index_select(0, perm))
+            self.vc[l][:, :upto].copy_(self.vc[l][:, :upto].index_select(0, perm))
 
     @torch.no_grad()
     def decode(self, memory, vocab_mask=None):

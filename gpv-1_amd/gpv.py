@@ -223,6 +223,10 @@ class GPV(nn.Module):
 
     # ---- whole greedy inference as ONE hipGraph ---------------------------------------------------------------
     def _graphed_greedy(self, images, queries, vocab_mask):
+        return self._graphed(('greedy',), lambda im, q, vm: self._forward_impl(im, q, None, None, vm, kv_graphs=False),
+                             images, queries, vocab_mask)
+
+    def _graphed(self, kind, fn, images, queries, vocab_mask):
         """Greedy inference (gpv.py:178-196) has static shapes for a fixed batch: ~1000 encoder launches + 20 decode
         steps are captured once into a single HIP graph (torch.cuda.CUDAGraph; our kernels are launched on the
         capturing stream through the C ABI) and replayed.  At batch 1 the eager path is bound by ~20 us of Python per
@@ -236,14 +240,14 @@ class GPV(nn.Module):
         ids, attn = queries
         if not x.is_cuda or torch.cuda.is_current_stream_capturing():
             return None
-        key = (tuple(x.shape), tuple(ids.shape), x.dtype, RT.dtype, vocab_mask is not None, RT.weights_epoch, RT.static_epoch)
+        key = kind + (tuple(x.shape), tuple(ids.shape), x.dtype, RT.dtype, vocab_mask is not None, RT.weights_epoch, RT.static_epoch)
         ent = self._igraphs.get(key)
         if ent is None:
             for k in [k for k in self._igraphs if k[-2:] != key[-2:]]:          # weights changed: those graphs hold stale copies
                 del self._igraphs[k]
             sx, sm, sids, sattn = x.clone(), m.clone(), ids.clone(), attn.clone()
             svm = vocab_mask.clone().float() if vocab_mask is not None else None
-            run = lambda: self._forward_impl(NestedTensor(sx, sm), (sids, sattn), None, None, svm, kv_graphs=False)
+            run = lambda: fn(NestedTensor(sx, sm, getattr(images, 'all_valid', None)), (sids, sattn), svm)
             for _ in range(2):                                                    # warm-up: weight copies, kernel attributes, decoder buffers
                 run()
             torch.cuda.synchronize()
@@ -301,30 +305,16 @@ class GPV(nn.Module):
     def forward_beam_search(self, images, queries, beam_size=1):
         """gpv.py:209-362, quirks preserved (no length normalisation, finished beams keep extending --
         the reference's `is True` test never fires --, last seqs slot never written, stable tie order)."""
-        outputs, memory = self._encode(images, queries)
-        B, K, T = memory.shape[0], beam_size, self.cfg.max_text_len
-        dev = memory.device
-        tok = torch.full((K, B, 1), self.word_to_idx['__cls__'], dtype=torch.long, device=dev)
-        seq_lp = torch.zeros(B, K, device=dev)
-        seqs = torch.zeros(K, B, T, dtype=torch.long, device=dev)
-        memK = memory.repeat(K, 1, 1)                                              # all K beams in ONE decoder pass
-        for t in range(T - 1):
-            logits = self.decode_text(self.answer_input_embedings(tok.reshape(K * B, -1)), memK)[:, -1].float()
-            top = torch.log_softmax(logits, -1).topk(K, -1)                        # [K*B, K]
-            vals, last = top.values.view(K, B, K), top.indices.view(K, B, K)
-            scores = (seq_lp.t().unsqueeze(-1) + vals).permute(1, 0, 2).contiguous()   # [B, K1, K2]
-            if t == 0:
-                scores[:, 1:] = scores[:, 1:] * 0 - 1e9
-            flat = scores.view(B, K * K)
-            order = torch.sort(flat, dim=1, descending=True, stable=True).indices[:, :K]   # [B,K]
-            k1, k2 = order // K, order % K
-            bi = torch.arange(B, device=dev).unsqueeze(1).expand(B, K)
-            w = last[k1, bi, k2]                                                   # [B,K]
-            seq_lp = flat.gather(1, order)
-            new_tok = torch.cat((tok[k1, bi], w.unsqueeze(-1)), -1).permute(1, 0, 2).contiguous()
-            new_seqs = seqs[k1, bi].permute(1, 0, 2).contiguous()
-            new_seqs[:, :, t] = w.t()
-            tok, seqs = new_tok, new_seqs
+        outputs = None
+        if (not self.training and not torch.is_grad_enabled() and self.cfg.get('graph_inference', True)
+                and self.cfg.get('kv_decode', True)):
+            # the whole beam search (encoder + 19 KV-cached steps with their top-k / sort / cache reordering) has static
+            # shapes: one hipGraph, like the greedy path
+            outputs = self._graphed(('beam', beam_size), lambda im, q, vm: self._beam_device(im, q, beam_size), images, queries, None)
+        if outputs is None:
+            outputs = self._beam_device(images, queries, beam_size)
+        seqs, seq_lp = outputs.pop('_beam_seqs'), outputs.pop('_beam_lp')
+        K, B, T = seqs.shape
         seqs_c, lp = seqs.cpu(), seq_lp.exp().cpu()
         answers, probs = [], []
         for b in range(B):
@@ -340,6 +330,52 @@ class GPV(nn.Module):
                 answers[b].append(words)
                 probs[b].append(float(lp[b, k]))
         outputs['answers'], outputs['answer_probs'] = answers, probs
+        return outputs
+
+    def _beam_device(self, images, queries, beam_size):
+        """device part of the beam search: outputs dict + '_beam_seqs' [K,B,T] + '_beam_lp' [B,K] (no host round trip)"""
+        outputs, memory = self._encode(images, queries)
+        B, K, T = memory.shape[0], beam_size, self.cfg.max_text_len
+        dev = memory.device
+        tok = torch.full((K, B, 1), self.word_to_idx['__cls__'], dtype=torch.long, device=dev)
+        seq_lp = torch.zeros(B, K, device=dev)
+        seqs = torch.zeros(K, B, T, dtype=torch.long, device=dev)
+        memK = memory.repeat(K, 1, 1)                                              # all K beams in ONE decoder pass
+        kv = None
+        if not self.training and not torch.is_grad_enabled() and self.cfg.get('kv_decode', True):
+            # KV-cached decode step (decode.py) instead of the reference's full-prefix pass per token: the decoder is
+            # causal, so the logits of the newest position are the same; the caches follow the beams (reorder below)
+            from .decode import GreedyKVDecoder
+            key = (K * B, memK.shape[1], str(dev), RT.dtype, 'beam')
+            kv = self._kvdec.get(key)
+            if kv is None:
+                kv = self._kvdec[key] = GreedyKVDecoder(self, K * B, memK.shape[1], use_graphs=False)
+            kv.memory.copy_(memK.reshape(K * B * memK.shape[1], -1))
+            kv._prepare()
+        for t in range(T - 1):
+            if kv is not None:
+                kv.tok.copy_(tok[:, :, -1].reshape(K * B))
+                logits = kv._step_core(t).float()
+            else:
+                logits = self.decode_text(self.answer_input_embedings(tok.reshape(K * B, -1)), memK)[:, -1].float()
+            top = torch.log_softmax(logits, -1).topk(K, -1)                        # [K*B, K]
+            vals, last = top.values.view(K, B, K), top.indices.view(K, B, K)
+            scores = (seq_lp.t().unsqueeze(-1) + vals).permute(1, 0, 2).contiguous()   # [B, K1, K2]
+            if t == 0:
+                scores[:, 1:] = scores[:, 1:] * 0 - 1e9
+            flat = scores.view(B, K * K)
+            order = torch.sort(flat, dim=1, descending=True, stable=True).indices[:, :K]   # [B,K]
+            k1, k2 = order // K, order % K
+            bi = torch.arange(B, device=dev).unsqueeze(1).expand(B, K)
+            w = last[k1, bi, k2]                                                   # [B,K]
+            seq_lp = flat.gather(1, order)
+            new_tok = torch.cat((tok[k1, bi], w.unsqueeze(-1)), -1).permute(1, 0, 2).contiguous()
+            new_seqs = seqs[k1, bi].permute(1, 0, 2).contiguous()
+            new_seqs[:, :, t] = w.t()
+            tok, seqs = new_tok, new_seqs
+            if kv is not None:                                                     # slot (k, b) continues parent (k1[b,k], b)
+                kv.reorder((k1.t() * B + bi.t()).reshape(K * B), t + 1)
+        outputs['_beam_seqs'], outputs['_beam_lp'] = seqs, seq_lp
         return outputs
 
     def encode_answers(self, targets):
