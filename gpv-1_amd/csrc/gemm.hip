@@ -305,7 +305,7 @@ template <> struct Vec8IO<float> {
 };
 
 template <typename TIn, typename TOut, int AMODE, int BMODE, int BM, int BN, bool VEC>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmK p) {
+__device__ __forceinline__ void gemm_body(const GemmK& p) {
   constexpr bool PRECISE = sizeof(TIn) == 4;
   constexpr int FM = BM / 32, FN = BN / 32;
   constexpr int A_ELEMS = BM * LDK, B_ELEMS = BN * LDK;
@@ -632,6 +632,17 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmK p) {
   }
 }
 
+template <typename TIn, typename TOut, int AMODE, int BMODE, int BM, int BN, bool VEC>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmK p) {
+  gemm_body<TIn, TOut, AMODE, BMODE, BM, BN, VEC>(p);
+}
+// the same body under its own name for the backbone's 1x1 stride-1 convolutions (plain GEMMs over the pixel rows):
+// profiles and PMC passes can then tell them from the transformer's Linear layers
+template <typename TIn, typename TOut, int BM, int BN, bool VEC>
+__global__ __launch_bounds__(256) void conv1x1_kernel(GemmK p) {
+  gemm_body<TIn, TOut, OP_PLAIN, OP_PLAIN, BM, BN, VEC>(p);
+}
+
 // C[m, n] += sum_s ws[s][m][n]   (second pass of a workspace split reduction).  A group of G threads shares one run
 // of 4 columns and strides over the splits (a layer2 1x1 wgrad has 96 slabs of 64K outputs: one thread per output
 // quad walking 96 slabs was 64 blocks of serial latency), partial sums meet in LDS.
@@ -719,11 +730,14 @@ int launch_cfg_v(const GemmK& k, int batch, hipStream_t st) {
     p.accumulate = 0; p.res = nullptr; p.mask = nullptr; p.bias = nullptr; p.act = 0; p.dthresh = 0;
   }
   auto fn = gemm_kernel<TIn, TOut, AMODE, BMODE, BM, BN, VEC>;
-  static bool attr_done = false;
-  if (lds > 64 * 1024 && !attr_done) {
+  if constexpr (AMODE == OP_PLAIN && BMODE == OP_PLAIN) {
+    if (k.conv1x1) fn = conv1x1_kernel<TIn, TOut, BM, BN, VEC>;
+  }
+  static bool attr_done[2] = {false, false};
+  if (lds > 64 * 1024 && !attr_done[k.conv1x1 ? 1 : 0]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    attr_done = true;
+    attr_done[k.conv1x1 ? 1 : 0] = true;
   }
   dim3 grid(tilesM * p.tilesN, split, batch);
   hipLaunchKernelGGL(fn, grid, dim3(256), lds, st, p);
@@ -860,6 +874,18 @@ extern "C" int gpv_conv2d(const gpv_conv_args* a, void* stream) {
     // the stem reads 16-B runs at pixel granularity (Cs = 4 bf16 = 8 B): require 16-B aligned runs
     if ((a->Cs % vecel) != 0) k.vecA = ((a->SW * a->Cs) % vecel == 0 && (a->IW * a->Cs) % vecel == 0 && a->PW == 0) ? k.vecA : 0;
     k.vecB = aligned16(a->w) && (k.K % 8 == 0) ? 1 : 0;
+    if (a->KH == 1 && a->KW == 1 && a->SH == 1 && a->SW == 1 && a->PH == 0 && a->PW == 0 && a->IH == a->OH && a->IW == a->OW) {
+      // a 1x1 stride-1 convolution IS a GEMM over the pixel rows (row pitch Cs): no tap / pixel decoding per thread
+      // (three integer divisions per staged row -- a third of the instructions of a K = 64 tile), and the GEMM-side
+      // kernel choices apply
+      k.lda = a->Cs;
+      k.cg = ConvGeom{};
+      k.conv1x1 = 1;
+      k.vecA = aligned16(a->x) && (a->Cs % vecel == 0) ? 1 : 0;
+      const int g = glds_try_launch(k, OP_PLAIN, a->dtype_in, a->dtype_out, 1, st);
+      if (g >= 0) return g;
+      return launch_dtype<OP_PLAIN, OP_PLAIN>(k, 1, a->dtype_in, a->dtype_out, st);
+    }
     if (k.vecA && k.vecB) {
       const int g = glds_try_launch(k, OP_CONV, a->dtype_in, a->dtype_out, 1, st);
       if (g >= 0) return g;
