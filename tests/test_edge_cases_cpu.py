@@ -1,0 +1,95 @@
+"""Edge cases of the host logic (CPU, kernels emulated by tests/cpu_shim.py), following what the reference does:
+empty / missing targets, ragged image lists, zero ground-truth boxes, answer truncation and out-of-vocabulary words,
+matcher tie cases."""
+import numpy as np
+import pytest
+import torch
+
+from tests import synth, cpu_shim
+from tests.test_model_cpu import build_small, nested, V, H, W, Tl
+
+
+@pytest.fixture(scope='module')
+def shim():
+    import gpv1_amd.ops as ops
+    undo = cpu_shim.install()
+    ops.RT.set_precise(True)
+    yield
+    ops.RT.set_precise(False)
+    undo()
+
+
+def _inputs(Bn, sizes=None, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    sizes = sizes or [(H, W)] * Bn
+    imgs = [torch.randn(3, h, w, generator=g) for h, w in sizes]
+    ids = torch.randint(1000, 30000, (Bn, Tl), generator=g)
+    attn = torch.ones(Bn, Tl, dtype=torch.long)
+    return imgs, ids, attn
+
+
+def test_ragged_image_list_equals_explicit_padding(shim):
+    """gpv.py / detr_roi_head.py:72-73: a list of differently sized images is zero-padded to the batch maximum with a mask"""
+    from gpv1_amd.misc import NestedTensor, nested_tensor_from_tensor_list
+    model, _ = build_small()
+    model.eval()
+    imgs, ids, attn = _inputs(3, [(96, 128), (64, 96), (80, 100)])
+    nt = nested_tensor_from_tensor_list(imgs)
+    assert nt.tensors.shape == (3, 3, 96, 128) and nt.all_valid is False
+    assert bool(nt.mask[1, 64:, :].all()) and bool(nt.mask[1, :, 96:].all()) and not bool(nt.mask[1, :64, :96].any())
+    with torch.no_grad():
+        a = model(imgs, (ids, attn), None, None)                       # raw list: the model builds the NestedTensor
+        b = model(NestedTensor(nt.tensors, nt.mask), (ids, attn), None, None)
+    for k in ('pred_boxes', 'pred_relevance_logits', 'answer_logits'):
+        assert torch.equal(a[k], b[k]), k
+    same = nested_tensor_from_tensor_list([imgs[0], imgs[0].clone()])
+    assert same.all_valid is True and not bool(same.mask.any())
+
+
+def test_no_applicable_target_and_empty_boxes(shim):
+    """losses.py:155-176: a loss whose task has no sample contributes nothing; a batch nobody can score returns None
+    (train_distr.py:414 skips the step); a detection sample with zero boxes matches nothing and only pays the
+    no-object term"""
+    from gpv1_amd.train import FlatTrainer
+    model, _ = build_small()
+    model.train()
+    model.bert.model.p = 0.0
+    imgs, ids, attn = _inputs(2)
+    tr = FlatTrainer(model, lr=1e-4, lr_backbone=1e-5)
+    none = tr.train_step(nested(torch.stack(imgs), torch.zeros(2, H, W, dtype=torch.bool)), (ids, attn),
+                         [{'task': 'SomethingElse'}, {'task': 'SomethingElse'}])
+    assert none is None and tr.step_count == 0
+    tg = [{'task': 'CocoDetection', 'boxes': torch.zeros(0, 4), 'labels': torch.zeros(0, dtype=torch.long)},
+          {'task': 'CocoDetection', 'boxes': torch.tensor([[0.5, 0.5, 0.2, 0.2]]), 'labels': torch.zeros(1, dtype=torch.long)}]
+    loss = tr.train_step(nested(torch.stack(imgs), torch.zeros(2, H, W, dtype=torch.bool)), (ids, attn), tg)
+    assert torch.isfinite(loss) and tr.step_count == 1
+    ind = model.criterion.localization_criterion.set_criterion.last_indices
+    assert len(ind) == 2 and len(ind[0][0]) == 0 and len(ind[1][0]) == 1
+
+
+def test_encode_answers_truncation_oov_and_padding(shim):
+    """gpv.py:377-430: '__cls__ answer __stop__', lower-cased, OOV -> __unk__, padded with __pad__ to the batch maximum,
+    cut at max_text_len (6 in the small configuration)"""
+    model, _ = build_small()
+    w2i = model.word_to_idx
+    toks, ids = model.encode_answers([{'answer': 'W3 w5'}, {'answer': ''}, {'answer': 'w1 zzz w2 w3 w4 w5 w6 w7'}, {}])
+    assert ids.shape == (4, 6)
+    assert ids[0].tolist() == [w2i['__cls__'], w2i['w3'], w2i['w5'], w2i['__stop__'], w2i['__pad__'], w2i['__pad__']]
+    assert ids[1].tolist()[:2] == [w2i['__cls__'], w2i['__stop__']] and ids[3].tolist() == ids[1].tolist()
+    assert ids[2].tolist() == [w2i['__cls__'], w2i['w1'], w2i['__unk__'], w2i['w2'], w2i['w3'], w2i['w4']]   # truncated, no __stop__
+    assert model.token_ids_to_words(ids[:1])[0][1:3] == ['w3', 'w5']
+
+
+def test_matcher_ties_and_more_targets_than_queries():
+    """matcher.py:32-77 via scipy LSAP: identical predictions tie -> lowest index wins (scipy's rule, pinned by the golden
+    matcher fixture); more ground-truth boxes than queries -> min(Q, n) pairs"""
+    from gpv1_amd.criterion import HungarianMatcher
+    m = HungarianMatcher(cost_class=1, cost_bbox=5, cost_giou=2)
+    logits = torch.zeros(1, 3, 2)
+    boxes = torch.tensor([[[0.5, 0.5, 0.2, 0.2]] * 3])
+    tgt = [{'boxes': torch.tensor([[0.5, 0.5, 0.2, 0.2], [0.3, 0.3, 0.1, 0.1]]), 'labels': torch.zeros(2, dtype=torch.long)}]
+    (pi, ti), = m({'pred_relevance_logits': logits, 'pred_boxes': boxes}, tgt)
+    assert sorted(ti.tolist()) == [0, 1] and len(set(pi.tolist())) == 2
+    many = [{'boxes': torch.rand(5, 4) * 0.3 + 0.3, 'labels': torch.zeros(5, dtype=torch.long)}]
+    (pi, ti), = m({'pred_relevance_logits': logits, 'pred_boxes': boxes}, many)
+    assert len(pi) == 3 and len(set(ti.tolist())) == 3
