@@ -9,7 +9,7 @@ What the reference's drivers use from Hydra/OmegaConf and what is reproduced her
   * attribute access, ``.items()``, real bools (the model reads ``cfg.roi_head is True`` style flags).
 The ``defaults:`` list (dataset / task groups) selects data-loading YAMLs, which are out of scope here (BASELINE uses
 synthetic COCO-shaped tensors); it is kept in the tree untouched.
-This file can load the reference's own ``configs/exp/gpv.yaml`` as well as ``configs/exp/gpv.yaml`` of this repo.
+This loads the reference's own ``configs/exp/gpv.yaml``; the drivers' built-in tree is gpv1_amd/default_config.py.
 """
 import re
 
@@ -96,8 +96,8 @@ def load_config(path, overrides=(), strict=True):
     return AttrDict.wrap(_resolve(tree, tree))
 
 
-def from_dict(tree, overrides=()):
+def from_dict(tree, overrides=(), strict=True):
     import copy
     tree = copy.deepcopy(dict(tree))
-    apply_overrides(tree, overrides)
+    apply_overrides(tree, overrides, strict)
     return AttrDict.wrap(_resolve(tree, tree))

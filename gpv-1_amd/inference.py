@@ -9,7 +9,7 @@ Out of scope: image decoding (skimage / cv2 in the reference).  The image is a `
 float in [0,1], or an already normalised 3xHxW float32 tensor; nltk's Treebank detokenizer is replaced by its
 punctuation-attachment rules (a join that glues ``, . ! ? ; : ' n't 's %`` to the previous token).
 
-usage: python -m gpv1_amd.inference --config configs/exp/gpv.yaml ckpt=... inputs.img=img.npy inputs.query="what is this?"
+usage: python -m gpv1_amd.inference [--config some.yaml] ckpt=... inputs.img=img.npy inputs.query="what is this?"
                                       [beam_size=5] [num_output_boxes=5]
 """
 import argparse
@@ -20,7 +20,8 @@ import sys
 import numpy as np
 import torch
 
-from .config import load_config
+from .config import from_dict, load_config
+from .default_config import default_tree
 from .gpv import GPV
 from .misc import nested_tensor_from_tensor_list
 
@@ -107,10 +108,11 @@ def predict(model, images, queries, beam_size=None, num_output_boxes=None):
 
 def main(argv=None):
     ap = argparse.ArgumentParser(description=__doc__.split('\n')[0])
-    ap.add_argument('--config', default=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'configs', 'exp', 'gpv.yaml'))
+    ap.add_argument('--config', default=None, help='YAML file (e.g. the reference configs/exp/gpv.yaml); default: gpv1_amd.default_config')
     ap.add_argument('overrides', nargs='*')
     args = ap.parse_args(argv)
-    cfg = load_config(args.config, args.overrides, strict=False)     # ckpt= inputs.img= inputs.query= beam_size= are added keys
+    # ckpt= inputs.img= inputs.query= beam_size= are added keys
+    cfg = load_config(args.config, args.overrides, strict=False) if args.config else from_dict(default_tree(), args.overrides, strict=False)
     model = GPV(cfg.model).cuda().eval()
     load_model_state(model, cfg.get('ckpt', cfg.eval.ckpt), map_location='cuda:0')
     img = np.load(cfg.inputs.img)

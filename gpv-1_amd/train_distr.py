@@ -2,7 +2,7 @@
 
 Reference: exp/gpv/train_distr.py (``train_worker`` :150-474, ``main`` :478-495) launched by scripts/train.sh.
 What is reproduced -- everything between the data loader and the checkpoint file:
-  * Hydra-style invocation: ``python -m gpv1_amd.train_distr [--config configs/exp/gpv.yaml] key=value ...``
+  * Hydra-style invocation: ``python -m gpv1_amd.train_distr [--config some.yaml] key=value ...``
     (config.py; the reference's own YAML loads too);
   * model construction ``GPV(cfg.model)``, optional ``load_pretr_detr()`` (:182-183), phase-1 freeze of the DETR
     parameters that came from the checkpoint (``freeze_detr_params`` :136-140, ``training.freeze`` -> ``frozen_epochs`` /
@@ -27,7 +27,8 @@ import time
 import torch
 import torch.distributed as dist
 
-from .config import load_config
+from .config import from_dict, load_config
+from .default_config import default_tree
 from .gpv import GPV
 from .misc import nested_tensor_from_tensor_list
 from .train import FlatTrainer
@@ -181,10 +182,10 @@ def train_worker(cfg, dataset=None, device=None, log=print):
 
 def main(argv=None):
     ap = argparse.ArgumentParser(description=__doc__.split('\n')[0])
-    ap.add_argument('--config', default=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'configs', 'exp', 'gpv.yaml'))
+    ap.add_argument('--config', default=None, help='YAML file (e.g. the reference configs/exp/gpv.yaml); default: gpv1_amd.default_config')
     ap.add_argument('overrides', nargs='*', help='Hydra-style key=value overrides')
     args = ap.parse_args(argv)
-    cfg = load_config(args.config, args.overrides)
+    cfg = load_config(args.config, args.overrides) if args.config else from_dict(default_tree(), args.overrides)
     train_worker(cfg)
 
 

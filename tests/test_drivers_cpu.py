@@ -22,11 +22,11 @@ def shim():
 
 
 def test_config_interpolation_overrides_and_float_parsing(tmp_path):
-    from gpv1_amd.config import load_config
-    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    cfg = load_config(os.path.join(here, 'configs', 'exp', 'gpv.yaml'),
-                      ['exp_name=run7', 'output_dir=/tmp/out', 'training.freeze=True', 'training.lr=2e-4', 'model.detr.num_queries=50',
-                       'training.lr_milestones=[3,4]', 'training.ckpt=null', '+inputs.query=what is this?'])
+    from gpv1_amd.config import load_config, from_dict
+    from gpv1_amd.default_config import default_tree
+    cfg = from_dict(default_tree(),
+                    ['exp_name=run7', 'output_dir=/tmp/out', 'training.freeze=True', 'training.lr=2e-4', 'model.detr.num_queries=50',
+                     'training.lr_milestones=[3,4]', 'training.ckpt=null', '+inputs.query=what is this?'])
     assert cfg.ckpt_dir == '/tmp/out/run7/ckpts' and cfg.eval.ckpt == '/tmp/out/run7/ckpts/model.pth'
     assert cfg.training.freeze is True and cfg.training.lr == 2e-4 and cfg.training.ckpt is None
     assert cfg.model.detr.num_queries == 50 and cfg.training.lr_milestones == [3, 4]
@@ -34,7 +34,7 @@ def test_config_interpolation_overrides_and_float_parsing(tmp_path):
     assert isinstance(cfg.model.losses.CaptionLoss.loss_wts.loss_caption, float)
     assert [k for k, _ in cfg.model.losses.items()] == ['CaptionLoss', 'VqaLoss', 'ClsLoss', 'Localization']
     with pytest.raises(KeyError):
-        load_config(os.path.join(here, 'configs', 'exp', 'gpv.yaml'), ['training.no_such_key=1'])
+        from_dict(default_tree(), ['training.no_such_key=1'])
     # the shapes the reference's own YAML uses: top-level group referenced from inside `model`, PyYAML-hostile floats
     y = tmp_path / 'ref_style.yaml'
     y.write_text('data_dir: /d\nmodel:\n  vocab: ${data_dir}/vocab.json\n  hidden_dim: 768\n  losses: ${losses}\n  detr:\n    dropout: 0.1\n'
