@@ -189,11 +189,16 @@ class FlatTrainer:
         use_clip = self.clip is not None and self.clip > 0
         self._publish_touched()
         if use_clip:
+            # ||g||^2 over the DETR groups (untouched gradients are zero: whole groups).  Every rank must get the SAME bits
+            # from the same all-reduced gradient, or the replicas drift apart one ulp of the clip factor per step:
+            # torch's norm is a fixed-order tree reduction; gpv_sumsq accumulates its blocks with float atomics, whose
+            # order differs from run to run (found by tests/test_distributed_gpu.py).
             self.gsq.zero_()
-            for g in ('detr_backbone', 'detr_head'):                         # untouched gradients are zero: whole groups
+            for g in ('detr_backbone', 'detr_head'):
                 if g in self.group_range:
                     s, e = self.group_range[g]
-                    hip.sumsq(self.G[s:e], e - s, self.gsq)
+                    n = torch.linalg.vector_norm(self.G[s:e])
+                    self.gsq.addcmul_(n, n)
             # scale = min(1, max_norm / (norm + 1e-6)) on device, no host sync
             torch.clamp(self.clip / (self.gsq.sqrt() + 1e-6), max=1.0, out=self.gscale)
         self.step_count += 1
