@@ -165,12 +165,17 @@ def main():
     local = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    local = local % max(torch.cuda.device_count(), 1)   # (only differs on a box with fewer GPUs than ranks: the gloo dry run below)
     torch.cuda.set_device(local)
     dev = f'cuda:{local}'
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29511')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device(dev))
+        backend = os.environ.get('GPV_DIST_BACKEND', 'nccl')     # 'gloo': dry run of the N > 1 path with ranks sharing one GPU
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device(dev))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import gpv1_amd.hip as hip
     import gpv1_amd.backbone as bbm
@@ -253,7 +258,7 @@ def main():
            'config': {'workload': 'GPV-1 (ResNet-50 + 6+6 DETR layers, 100 queries, RoI head, BERT-base, 3 co-attention, '
                                   '3 text-decoder layers, V=10000) CocoCaptioning-only train step, dropout 0.1, AdamW',
                       'global_batch': world * args.batch, 'image': '480x640', 'caption_tokens': 20,
-                      'parallelism': f'dp{world}', 'final_loss': float(loss)},
+                      'parallelism': f'dp{world}', 'final_loss': float(loss.detach())},
            'roofline': roof}
     if world == 1 and not args.no_decode:
         out['greedy_decode'] = greedy_decode_bench(model, dev)
