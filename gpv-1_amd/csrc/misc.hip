@@ -91,13 +91,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
                                                      const float* __restrict__ rstd, T* __restrict__ dx, T* __restrict__ ds,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, int rows, int cols,
                                                      int rows_per_block, uint32_t dthresh, float dscale, uint64_t seed) {
-  extern __shared__ float lds[];   // [2][cols]
-  float* sg = lds;
-  float* sb = lds + cols;
-  if (dgamma) {
-    for (int c = threadIdx.x; c < 2 * cols; c += 256) lds[c] = 0.f;
-    __syncthreads();
-  }
+  extern __shared__ float lds[];   // [4 waves][2][cols]: every wave parks its partial dgamma | dbeta, no LDS atomics
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float ag[NV][8], ab[NV][8];
 #pragma unroll
@@ -161,16 +155,22 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
     }
   }
   if (dgamma) {
+    float* wg = lds + wave * 2 * cols;               // this wave's [dgamma | dbeta] partials (plain 16-byte stores)
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int c = (i * 64 + lane) * 8;
       if (c < cols) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { atomicAdd(&sg[c + e], ag[i][e]); atomicAdd(&sb[c + e], ab[i][e]); }
+        *reinterpret_cast<float4*>(wg + c) = make_float4(ag[i][0], ag[i][1], ag[i][2], ag[i][3]);
+        *reinterpret_cast<float4*>(wg + c + 4) = make_float4(ag[i][4], ag[i][5], ag[i][6], ag[i][7]);
+        *reinterpret_cast<float4*>(wg + cols + c) = make_float4(ab[i][0], ab[i][1], ab[i][2], ab[i][3]);
+        *reinterpret_cast<float4*>(wg + cols + c + 4) = make_float4(ab[i][4], ab[i][5], ab[i][6], ab[i][7]);
       }
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < cols; c += 256) { atomicAdd(&dgamma[c], sg[c]); atomicAdd(&dbeta[c], sb[c]); }
+    for (int c = threadIdx.x; c < 2 * cols; c += 256) {
+      const float v = lds[c] + lds[2 * cols + c] + lds[4 * cols + c] + lds[6 * cols + c];
+      atomicAdd(c < cols ? dgamma + c : dbeta + (c - cols), v);
+    }
   }
 }
 
@@ -500,11 +500,11 @@ extern "C" int gpv_layernorm_bwd(const void* dy, const void* x, const void* s, c
   if (cols % 8 != 0 || cols > 4096 || rows <= 0) return (int)hipErrorInvalidValue;
   const uint32_t th = drop_p > 0.f ? drop_thresh(drop_p) : 0u;
   const float sc = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
-  static const int rpb_div = [] { const char* e = getenv("GPV_LN_BWD_BLOCKS"); return e ? atoi(e) : 1024; }();   // tuning only
+  static const int rpb_div = [] { const char* e = getenv("GPV_LN_BWD_BLOCKS"); return e ? atoi(e) : 512; }();   // tuning only (512: fewer same-address global atomics on dgamma)
   int rpb = (rows + rpb_div - 1) / rpb_div;
   if (rpb < 8) rpb = 8;
   dim3 grid((rows + rpb - 1) / rpb), block(256);
-  const size_t lds = dgamma ? 2 * (size_t)cols * sizeof(float) : 0;
+  const size_t lds = dgamma ? 8 * (size_t)cols * sizeof(float) : 0;       // 4 waves x [dgamma | dbeta]; cols <= 4096 -> <= 128 KB
 #define LN_B(T, NV) hipLaunchKernelGGL((ln_bwd_kernel<T, NV>), grid, block, lds, ST(stream), (const T*)dy, (const T*)x, (const T*)s, gamma, mean, rstd, (T*)dx, (T*)ds, dgamma, dbeta, rows, cols, rpb, th, sc, seed)
   const int nv = (cols + 511) / 512;
   if (dtype == GPV_BF16) { if (nv <= 1) LN_B(bf16, 1); else if (nv <= 2) LN_B(bf16, 2); else if (nv <= 5) LN_B(bf16, 5); else LN_B(bf16, 8); }
