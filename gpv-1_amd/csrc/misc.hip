@@ -71,11 +71,12 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
   for (int i = 0; i < NV; ++i) {
     const int c = (i * 64 + lane) * 8;
     if (c < cols) {
-      float o[8];
+      float o[8], gm[8], bt[8];
+      if (gamma) { Ld8<float>::ld(gamma + c, gm); Ld8<float>::ld(beta + c, bt); }      // cols % 8 == 0: two 16-byte loads each
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         float n = (v[i][e] - mu) * rs;
-        o[e] = gamma ? n * gamma[c + e] + beta[c + e] : n;
+        o[e] = gamma ? n * gm[e] + bt[e] : n;
       }
       Ld8<T>::st(yr + c, o);
     }
@@ -122,10 +123,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
             xv[e] += sv;
           }
         }
+        float gm[8];
+        if (gamma) Ld8<float>::ld(gamma + c, gm);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           zh[i][e] = (xv[e] - mu) * rs;
-          float g = gamma ? gamma[c + e] : 1.f;
+          float g = gamma ? gm[e] : 1.f;
           gy[i][e] = dv[e] * g;
           s1 += gy[i][e];
           s2 += gy[i][e] * zh[i][e];
