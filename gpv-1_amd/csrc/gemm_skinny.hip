@@ -144,17 +144,47 @@ __global__ __launch_bounds__(256) void skinny_kernel(GemmK p) {
     const int n = col0 + (ij & 3) * 16 + (l >> 4) * 4;
     if (m >= p.M || n >= p.N) continue;
     const float rs = p.rowscale ? p.rowscale[m] * p.alpha : p.alpha;
+    // the 4 columns' bias / residual / mask as one vector load each when they are whole and aligned (per-element global
+    // loads in an epilogue loop are what made the LayerNorm forward 2x too slow)
+    const bool full = n + 4 <= p.N;
+    float bv[4] = {0.f, 0.f, 0.f, 0.f}, rv[4] = {0.f, 0.f, 0.f, 0.f}, mv[4] = {1.f, 1.f, 1.f, 1.f};
+    if (p.bias) {
+      if (full && (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0) {
+        const float4 b4 = *reinterpret_cast<const float4*>(p.bias + n);
+        bv[0] = b4.x; bv[1] = b4.y; bv[2] = b4.z; bv[3] = b4.w;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bv[e] = n + e < p.N ? p.bias[n + e] : 0.f;
+      }
+    }
+    auto ld4 = [&](const TOut* base, int64_t ld, float* out) {
+      const TOut* q = base + (int64_t)m * ld + n;
+      if (full && (ld & 3) == 0 && (reinterpret_cast<uintptr_t>(base) & (4 * sizeof(TOut) - 1)) == 0) {
+        if constexpr (sizeof(TOut) == 2) {
+          const bf16x4 t = *reinterpret_cast<const bf16x4*>(q);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) out[e] = (float)t[e];
+        } else {
+          const float4 t = *reinterpret_cast<const float4*>(q);
+          out[0] = t.x; out[1] = t.y; out[2] = t.z; out[3] = t.w;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) out[e] = n + e < p.N ? (float)q[e] : 0.f;
+      }
+    };
+    if (Rp) ld4(Rp, p.ldr, rv);
+    if (Mp) ld4(Mp, p.ldm, mv);
     float o[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       if (n + e >= p.N) { o[e] = 0.f; continue; }
-      float x = v[e] * rs;
-      if (p.bias) x += p.bias[n + e];
-      if (Rp) x += (float)Rp[(int64_t)m * p.ldr + n + e];
+      float x = v[e] * rs + bv[e];
+      if (Rp) x += rv[e];
       if (p.act == GPV_ACT_RELU) x = fmaxf(x, 0.f);
       else if (p.act == GPV_ACT_GELU) x = gelu_erf(x);
       if (p.dthresh) x = drop_keep(p.seed, (uint64_t)m * (uint64_t)p.N + (n + e), p.dthresh) ? x * p.dscale : 0.f;
-      if (Mp) x = (float)Mp[(int64_t)m * p.ldm + n + e] > 0.f ? x : 0.f;
+      if (Mp) x = mv[e] > 0.f ? x : 0.f;
       o[e] = x;
     }
     TOut* dst = Cp + (int64_t)m * p.ldc + n;
