@@ -15,6 +15,7 @@ MI355X-first choices
   * torch-1.6 optimizer semantics kept: a parameter is only updated (incl. weight decay) once it has
     received a gradient at least once; the touched set is agreed across ranks (MAX all-reduce).
 """
+import gc
 import os
 
 import torch
@@ -50,8 +51,13 @@ def warmup_linear(step, warmup_steps, t_total):
 
 class FlatTrainer:
     def __init__(self, model, lr=1e-4, lr_backbone=1e-5, weight_decay=1e-4, clip_max_norm=0.1, warmup_steps=0,
-                 t_total=0, betas=(0.9, 0.999), eps=1e-8, bucket_mb=128, process_group=None):
+                 t_total=0, betas=(0.9, 0.999), eps=1e-8, bucket_mb=128, process_group=None, manual_gc=True, gc_interval=200):
         self.model = model
+        # Python's cyclic collector costs 1-3 ms per step once it has a few hundred thousand module / tensor objects to
+        # walk (measured: 970-1020 vs 1062-1070 images/s over 20 steps), while a step leaves ~17 small cycles and no
+        # device memory behind (tools/gc_growth.py).  With manual_gc the trainer freezes the long-lived objects, turns
+        # the automatic collector off and collects every gc_interval steps itself (Megatron-style).
+        self.manual_gc, self.gc_interval, self._gc_armed = manual_gc, gc_interval, False
         self.lr = {'detr_backbone': lr_backbone, 'detr_head': lr, 'bert': lr, 'others': lr}
         self.wd, self.clip, self.betas, self.eps = weight_decay, clip_max_norm, betas, eps
         self.warmup_steps, self.t_total = warmup_steps, t_total
@@ -241,6 +247,12 @@ class FlatTrainer:
     def train_step(self, images, queries, targets):
         """one iteration of train_distr.py:399-428; returns the loss tensor (or None: no applicable target)"""
         model = self.model
+        if self.manual_gc:
+            if not self._gc_armed:
+                gc.collect(); gc.freeze(); gc.disable()
+                self._gc_armed = True
+            elif self.step_count % self.gc_interval == self.gc_interval - 1:
+                gc.collect()
         if not model.training:                      # nn.Module.train() walks ~600 modules (0.66 ms): only when needed
             model.train()
         _, answer_token_ids = model.encode_answers(targets)
