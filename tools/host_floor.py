@@ -3,7 +3,7 @@ import os, sys, time, torch, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from gpv1_amd.gpv import GPV
-from gpv1_amd.misc import NestedTensor
+from gpv1_amd.misc import NestedTensor, nested_tensor_from_tensor_list
 from gpv1_amd.train import FlatTrainer
 import gpv1_amd.hip as hip
 dev = 'cuda:0'
@@ -11,7 +11,8 @@ torch.manual_seed(0)
 model = GPV(bench.make_cfg()).to(dev)
 tr = FlatTrainer(model, lr=1e-4, lr_backbone=1e-5)
 images, mask, ids, attn, targets = bench.make_batch(0, 32, dev)
-step = lambda: tr.train_step(NestedTensor(images, mask), (ids, attn), [dict(t) for t in targets])
+samples = nested_tensor_from_tensor_list(images)
+step = lambda: tr.train_step(samples, (ids, attn), [dict(t) for t in targets])
 for _ in range(3): step()
 torch.cuda.synchronize()
 t0 = time.perf_counter()
@@ -37,7 +38,7 @@ def fwd_only():
     tg = [dict(t) for t in targets]
     _, a = model.encode_answers(tg)
     for i, t in enumerate(tg): t['answer_token_ids'] = a[i, 1:]
-    return model(NestedTensor(images, mask), (ids, attn), a, tg)
+    return model(samples, (ids, attn), a, tg)
 t0 = time.perf_counter()
 for _ in range(5): loss = fwd_only()
 t1 = time.perf_counter()
