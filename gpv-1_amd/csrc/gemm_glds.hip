@@ -1,7 +1,11 @@
-// 8-wave direct-to-LDS bf16 GEMM / implicit-GEMM convolution (forward and dgrad) for gfx950.
+// Direct-to-LDS bf16 GEMM / implicit-GEMM convolution (forward and dgrad) for gfx950, in two shapes:
 //
-//   C[M,N] = epilogue( A[M,K] x B[N,K]^T ),   256 x BN (256 | 128) x 64 tiles, 512 threads = 8 waves,
-//   wave tile 128x64 (BN=256, waves 2x4) or 64x64 (BN=128, waves 4x2), mfma_f32_16x16x32_bf16.
+//   C[M,N] = epilogue( A[M,K] x B[N,K]^T ),  k-tiles of 64, mfma_f32_16x16x32_bf16
+//   * 8 waves, 256 x BN (256 | 128) tiles, wave tile 128x64 (waves 2x4) or 64x64 (waves 4x2), one block per CU:
+//     the launches that fill the chip several times over (960-985 TFLOP/s on 4096^3 / 8192^3);
+//   * 4 waves, 128 x 128 tiles, wave tile 64x64 (waves 2x2), 64 KB of LDS -> two blocks per CU: the B=32 ResNet-50 /
+//     transformer launches with K >= 512..1024 (150-1200 tiles), where a second resident block hides the other's
+//     prologue/epilogue and the tail is finer (layer4 3x3 fwd 150 -> 76 us, 9600x256x2048 54 -> 30 us).
 //
 // Why a second kernel next to gemm.hip: the 4-wave 128x128x32 register-staged kernel tops out at ~550-650 TFLOP/s on
 // large GEMMs (tools/bench_gemm_sq.py): a barrier and a ds_read restart every 32-deep step, 8 LDS fragment reads per
@@ -39,14 +43,14 @@ __device__ __forceinline__ void glds16(const void* g, unsigned char* l) {
   __builtin_amdgcn_global_load_lds((glb_void_t*)g, (lds_void_t*)l, 16, 0, 0);
 }
 
-template <int AMODE, int BN, typename TOut>
-__global__ __launch_bounds__(512) void glds_kernel(GemmK p) {
-  constexpr int BM = GBM;
-  constexpr int WN = BN / 64, WM = 8 / WN;
+template <int AMODE, int BM, int BN, typename TOut>
+__device__ __forceinline__ void glds_body(const GemmK& p) {
+  constexpr int NT = BM * 2, NW = NT / 64;     // 512 threads = 8 waves (BM 256) | 256 threads = 4 waves (BM 128, two blocks per CU)
+  constexpr int WN = BN / 64, WM = NW / WN;
   constexpr int WTM = BM / WM;                 // 128 | 64
   constexpr int FM = WTM / 16, FN = 4;
   constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
-  constexpr int AI = BM / 64, BI = BN / 64;    // global_load_lds instructions per wave and k-tile (8 rows each)
+  constexpr int AI = BM / (8 * NW), BI = BN / (8 * NW);    // global_load_lds instructions per wave and k-tile (8 rows each)
   extern __shared__ __attribute__((aligned(128))) unsigned char smem[];
   __shared__ int s_rowpix[AMODE == OP_CONV ? BM : 1];
 
@@ -90,13 +94,6 @@ __global__ __launch_bounds__(512) void glds_kernel(GemmK p) {
       }
     }
   }
-  auto kmap = [&](int kt) -> int {
-    if (!cm_on) return kt * GBK;
-    const int t = kt / cm_cpt, c = kt - t * cm_cpt;
-    const int ri = t / cm_nS, si = t - ri * cm_nS;
-    return ((cm_r0 + 2 * ri) * p.cg.KW + cm_s0 + 2 * si) * p.cg.Cin + c * GBK;
-  };
-
   // ---- loader state: this lane's rows and its (swizzled) 16-byte chunk ----
   const int lrow = lane >> 3;
   const int lchunk = (lane & 7) ^ lrow;                 // logical chunk fetched into slot (lane & 7) of row lrow
@@ -129,31 +126,50 @@ __global__ __launch_bounds__(512) void glds_kernel(GemmK p) {
   }
   const bf16* zero_src = reinterpret_cast<const bf16*>(g_zero_line) + (lane & 7) * 8;
 
+  // conv gather state: k-tiles walk (tap, channel block) with the channel block innermost, so the per-row source address and
+  // its bounds check are recomputed once per TAP (Cin/64 k-tiles), not per k-tile; the loop itself only adds the channel offset.
+  int it_c0 = 0, it_tr = cm_on ? cm_r0 : 0, it_ts = cm_on ? cm_s0 : 0;
+  const bf16* tap_src[AI];
+  unsigned tap_ok = 0;
+#pragma unroll
+  for (int j = 0; j < AI; ++j) tap_src[j] = a_ptr[j];
+
   auto issue = [&](int kt, int stage) {
-    const int k0 = kmap(kt);
     unsigned char* sa = smem + stage * STAGE + wave * (AI * 1024);
     unsigned char* sb = smem + stage * STAGE + A_BYTES + wave * (BI * 1024);
+    int k0;
     if constexpr (AMODE == OP_CONV) {
       const ConvGeom& g = p.cg;
-      const int tap = k0 / g.Cin, c0 = k0 - tap * g.Cin;
-      const int tr = tap / g.KW, ts = tap - tr * g.KW;
+      if (it_c0 == 0) {                              // new tap (uniform branch)
+        tap_ok = 0;
 #pragma unroll
-      for (int j = 0; j < AI; ++j) {
-        int ih, iw;
-        bool ok = !cm_empty;
-        if (g.dgrad) {                               // strides are 1 or 2 (checked on the host)
-          const int th = a_oh[j] + g.PH - tr, tw = a_ow[j] + g.PW - ts;
-          const int sh = g.SH - 1, sw = g.SW - 1;
-          ih = th >> sh; iw = tw >> sw;
-          ok = ok && th >= 0 && tw >= 0 && ((th & sh) == 0) && ((tw & sw) == 0) && ih < g.IH && iw < g.IW;
-        } else {
-          ih = a_oh[j] * g.SH + tr - g.PH; iw = a_ow[j] * g.SW + ts - g.PW;
-          ok = ok && ih >= 0 && iw >= 0 && ih < g.IH && iw < g.IW;
+        for (int j = 0; j < AI; ++j) {
+          int ih, iw;
+          bool ok = !cm_empty;
+          if (g.dgrad) {                             // strides are 1 or 2 (checked on the host)
+            const int th = a_oh[j] + g.PH - it_tr, tw = a_ow[j] + g.PW - it_ts;
+            const int sh = g.SH - 1, sw = g.SW - 1;
+            ih = th >> sh; iw = tw >> sw;
+            ok = ok && th >= 0 && tw >= 0 && ((th & sh) == 0) && ((tw & sw) == 0) && ih < g.IH && iw < g.IW;
+          } else {
+            ih = a_oh[j] * g.SH + it_tr - g.PH; iw = a_ow[j] * g.SW + it_ts - g.PW;
+            ok = ok && ih >= 0 && iw >= 0 && ih < g.IH && iw < g.IW;
+          }
+          tap_src[j] = a_ptr[j] + (int64_t)(ih * g.IW + iw) * g.Cs;
+          tap_ok |= (ok ? 1u : 0u) << j;
         }
-        const bf16* src = a_ptr[j] + (int64_t)(ih * g.IW + iw) * g.Cs + c0;
-        glds16(ok ? src : zero_src, sa + j * 1024);
+      }
+      k0 = (it_tr * g.KW + it_ts) * g.Cin + it_c0;
+#pragma unroll
+      for (int j = 0; j < AI; ++j) glds16(((tap_ok >> j) & 1u) ? tap_src[j] + it_c0 : zero_src, sa + j * 1024);
+      it_c0 += GBK;
+      if (it_c0 == g.Cin) {                          // next tap; a class-uniform stride-2 dgrad tile steps by 2
+        it_c0 = 0;
+        if (cm_on) { it_ts += 2; if (it_ts >= g.KW) { it_ts = cm_s0; it_tr += 2; } }
+        else { ++it_ts; if (it_ts == g.KW) { it_ts = 0; ++it_tr; } }
       }
     } else {
+      k0 = kt * GBK;
 #pragma unroll
       for (int j = 0; j < AI; ++j) glds16(a_ptr[j] + k0, sa + j * 1024);
     }
@@ -200,15 +216,15 @@ __global__ __launch_bounds__(512) void glds_kernel(GemmK p) {
   const TOut* Mp = reinterpret_cast<const TOut*>(p.mask);
   float* ep = reinterpret_cast<float*>(smem);
   constexpr int EPITCH = BN + 4;
-  constexpr int HR = 128;
+  constexpr int HR = BM / 2;                     // rows staged at a time: the fp32 image must fit the two operand stages
   constexpr int CH = BN / 8;
-  constexpr int NCH = (HR * CH) / 512;           // 8 | 4 chunks of 8 columns per thread and half
+  constexpr int NCH = (HR * CH) / NT;            // chunks of 8 columns per thread and half
   const bool v_st = (p.ldc % 8 == 0) && ((reinterpret_cast<uintptr_t>(Cp) & 15) == 0);
   const bool v_res = Rp && (p.ldr % 8 == 0) && ((reinterpret_cast<uintptr_t>(Rp) & 15) == 0);
   const bool v_msk = Mp && (p.ldm % 8 == 0) && ((reinterpret_cast<uintptr_t>(Mp) & 15) == 0);
   float bv[8];
   {
-    const int nb = col0 + (tid % CH) * 8;          // 512 % CH == 0: a thread always finishes the same 8 columns
+    const int nb = col0 + (tid % CH) * 8;          // NT % CH == 0: a thread always finishes the same 8 columns
     const bool vb = p.bias && nb + 8 <= p.N && ((reinterpret_cast<uintptr_t>(p.bias) & 15) == 0);
     if (vb) {
       const float4 b0 = *reinterpret_cast<const float4*>(p.bias + nb);
@@ -234,7 +250,7 @@ __global__ __launch_bounds__(512) void glds_kernel(GemmK p) {
     __syncthreads();
 #pragma unroll
     for (int g = 0; g < NCH; ++g) {
-      const int idx = tid + g * 512;
+      const int idx = tid + g * NT;
       const int r = idx / CH, c8 = idx - r * CH;
       const int m = row0 + half * HR + r;
       const int n = col0 + c8 * 8;
@@ -288,32 +304,41 @@ __global__ __launch_bounds__(512) void glds_kernel(GemmK p) {
   }
 }
 
-template <int AMODE, int BN, typename TOut>
+template <int AMODE, int BM, int BN, typename TOut>
+__global__ __launch_bounds__(BM * 2) void glds_kernel(GemmK p) { glds_body<AMODE, BM, BN, TOut>(p); }
+
+// 1x1 stride-1 convolutions are plain GEMMs over the NHWC rows; their own kernel name keeps them attributable to the
+// backbone in rocprofv3 traces and PMC passes (like conv1x1_kernel in gemm.hip)
+template <int BM, int BN, typename TOut>
+__global__ __launch_bounds__(BM * 2) void glds_conv1x1_kernel(GemmK p) { glds_body<OP_PLAIN, BM, BN, TOut>(p); }
+
+template <int AMODE, int BM, int BN, typename TOut>
 int launch_glds(const GemmK& k, int batch, hipStream_t st) {
-  constexpr size_t stage = (size_t)2 * (GBM + BN) * ROWB;
-  constexpr size_t epi = (size_t)128 * (BN + 4) * 4;
+  constexpr size_t stage = (size_t)2 * (BM + BN) * ROWB;
+  constexpr size_t epi = (size_t)(BM / 2) * (BN + 4) * 4;
   constexpr size_t lds = stage > epi ? stage : epi;
   GemmK p = k;
-  const int tilesM = (p.M + GBM - 1) / GBM;
+  const int tilesM = (p.M + BM - 1) / BM;
   p.tilesN = (p.N + BN - 1) / BN;
-  auto fn = glds_kernel<AMODE, BN, TOut>;
-  static bool attr_done = false;
-  if (!attr_done) {
+  const bool c11 = AMODE == OP_PLAIN && p.conv1x1;
+  auto fn = c11 ? glds_conv1x1_kernel<BM, BN, TOut> : glds_kernel<AMODE, BM, BN, TOut>;
+  static bool attr_done[2] = {false, false};
+  if (!attr_done[c11]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    attr_done = true;
+    attr_done[c11] = true;
   }
   dim3 grid(tilesM * p.tilesN, 1, batch);
   ++g_glds_launches;
-  hipLaunchKernelGGL(fn, grid, dim3(512), lds, st, p);
+  hipLaunchKernelGGL(fn, grid, dim3(BM * 2), lds, st, p);
   GPV_CHECK_LAUNCH();
   return 0;
 }
 
-template <int AMODE, int BN>
+template <int AMODE, int BM, int BN>
 int launch_glds_out(const GemmK& k, int dtype_out, int batch, hipStream_t st) {
-  if (dtype_out == GPV_BF16) return launch_glds<AMODE, BN, bf16>(k, batch, st);
-  return launch_glds<AMODE, BN, float>(k, batch, st);
+  if (dtype_out == GPV_BF16) return launch_glds<AMODE, BM, BN, bf16>(k, batch, st);
+  return launch_glds<AMODE, BM, BN, float>(k, batch, st);
 }
 
 int g_glds_mode = [] { const char* e = getenv("GPV_GLDS"); return e ? atoi(e) : 1; }();   // gpv_set_option(GPV_OPT_GLDS, .)
@@ -323,7 +348,7 @@ inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) =
 }  // namespace
 
 int glds_try_launch(const GemmK& k, int amode, int dtype_in, int dtype_out, int batch, hipStream_t st) {
-  const int mode = g_glds_mode;     // 0 = never, 1 (default) = where it is expected to win, 2 = wherever it is legal
+  const int mode = g_glds_mode;     // 0 = never, 1 (default) = where it is expected to win, 2 / 3 = the 8-wave / 4-wave variant wherever legal
   if (mode == 0 || dtype_in != GPV_BF16) return -1;
   if (k.accumulate || k.split_k > 1) return -1;
   if (k.K % GBK != 0 || k.K < GBK || k.N <= 64) return -1;
@@ -336,18 +361,23 @@ int glds_try_launch(const GemmK& k, int amode, int dtype_in, int dtype_out, int 
     return -1;
   }
   const int bn = k.N > 128 ? 256 : 128;
+  bool small_tiles = mode == 3;
   if (mode == 1) {
-    // one 8-wave block per CU: worth it when there is at least ~a chip of 256-row tiles and a real reduction
-    // Measured on the ResNet-50 / transformer shapes at B=32 (tools/bench_conv.py, bench_dgrad.py, bench_gemm_sq.py,
-    // GPV_GLDS=0 vs 2): with 1-2 tiles per CU the 4-wave kernel (3 blocks/CU, epilogues overlapped with other
-    // blocks' main loops) wins unless the reduction is long; stride-2 dgrad classes are too unbalanced for 1 block/CU.
+    // Measured per shape on the ResNet-50 / transformer launches at B=32 (tools/bench_conv.py, bench_dgrad.py,
+    // bench_gemm_sq.py with GPV_GLDS=0/2/3).  At 1-2 256-row tiles per CU the 8-wave kernel loses to kernels with 2-3
+    // co-resident blocks (epilogues overlapped with other blocks' main loops, finer tail); it keeps the launches that fill the
+    // chip several times over.  The 4-wave 128x128 variant wins wherever the reduction is long enough to amortise its
+    // prologue/epilogue: every K >= 1024 conv / GEMM (layer3/4 3x3 fwd 94->82 / 150->76 us, their stride-2 dgrads
+    // 194->139 / 161->101 us) and the K = 512 forward 1x1s; ReLU-mask (dgrad) epilogues need K >= 1024.
     const int64_t tiles = (int64_t)((k.M + GBM - 1) / GBM) * ((k.N + bn - 1) / bn) * batch;
-    const bool deep = k.K >= 2048 && tiles >= 128;
-    const bool huge = tiles >= 1024 && k.K >= 512;
-    if (!(deep || huge) || (amode == OP_CONV && k.cg.cm)) return -1;
+    const bool huge = tiles >= 1024 && k.K >= 512 && !(amode == OP_CONV && k.cg.cm);   // parity classes: too unbalanced for 1 block/CU
+    small_tiles = !huge && (k.K >= 1024 || (k.K >= 512 && !k.mask));
+    if (!huge && !small_tiles) return -1;
   }
-  if (amode == OP_CONV) return bn == 256 ? launch_glds_out<OP_CONV, 256>(k, dtype_out, batch, st) : launch_glds_out<OP_CONV, 128>(k, dtype_out, batch, st);
-  return bn == 256 ? launch_glds_out<OP_PLAIN, 256>(k, dtype_out, batch, st) : launch_glds_out<OP_PLAIN, 128>(k, dtype_out, batch, st);
+  if (small_tiles)   // 4-wave 128x128 variant, two blocks per CU
+    return amode == OP_CONV ? launch_glds_out<OP_CONV, 128, 128>(k, dtype_out, batch, st) : launch_glds_out<OP_PLAIN, 128, 128>(k, dtype_out, batch, st);
+  if (amode == OP_CONV) return bn == 256 ? launch_glds_out<OP_CONV, 256, 256>(k, dtype_out, batch, st) : launch_glds_out<OP_CONV, 256, 128>(k, dtype_out, batch, st);
+  return bn == 256 ? launch_glds_out<OP_PLAIN, 256, 256>(k, dtype_out, batch, st) : launch_glds_out<OP_PLAIN, 256, 128>(k, dtype_out, batch, st);
 }
 
 }  // namespace gpvk

@@ -352,7 +352,9 @@ int skinny_try_launch(const GemmK& k, int b_trans, int dtype_in, int dtype_out, 
     // measured on every forward GEMM shape of the step (tools/bench_step_gemms.py, SK=0 vs 2): it wins whenever the
     // 64x64 tiles cannot fill the chip (<= ~1.4 per CU), and up to 2.5 per CU when the reduction is long
     const int64_t tiles = (int64_t)((k.M + SBM - 1) / SBM) * ((k.N + SBN - 1) / SBN);
-    if (!((tiles <= 360 && k.K >= 128) || (tiles <= 640 && k.K >= 2048))) return -1;
+    // (the 360..640-tile, K >= 2048 launches -- 9600x256x2048, 3200x768x3072 -- go to the 4-wave direct-to-LDS kernel when B
+    // is k-major: 54 -> 30 us, 52 -> 40 us; that kernel has no reduction-major B form, so dX = dY W keeps them here)
+    if (!((tiles <= 360 && k.K >= 128) || (b_trans && tiles <= 640 && k.K >= 2048))) return -1;
   }
   if (b_trans) return dtype_out == GPV_BF16 ? launch_skinny<bf16, true>(k, st) : launch_skinny<float, true>(k, st);
   return dtype_out == GPV_BF16 ? launch_skinny<bf16, false>(k, st) : launch_skinny<float, false>(k, st);

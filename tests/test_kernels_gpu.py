@@ -205,11 +205,12 @@ def test_stem_conv_image_prep_and_maxpool(dtype):
 
 
 # ------------------------------------------------------------- 8-wave direct-to-LDS kernel (gemm_glds.hip)
-@pytest.fixture()
-def glds():
-    """force the 8-wave kernel wherever it is legal (by default it only takes the large launches) and count its launches"""
+@pytest.fixture(params=[2, 3], ids=['8wave', '4wave128'])
+def glds(request):
+    """force the direct-to-LDS kernel wherever it is legal (by default it only takes the launches it wins) and count its
+    launches; 2 = the 8-wave 256-row tiles, 3 = the 4-wave 128x128 variant"""
     h = hip()
-    prev = h.set_option(h.OPT_GLDS, 2)
+    prev = h.set_option(h.OPT_GLDS, request.param)
     prevs = h.set_option(h.OPT_SKINNY, 0)
     h.set_option(h.OPT_GLDS_LAUNCHES, 0)
     yield h
