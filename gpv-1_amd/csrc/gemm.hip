@@ -924,6 +924,10 @@ extern "C" int gpv_conv2d(const gpv_conv_args* a, void* stream) {
     k.vecA = aligned16(a->w) && (a->Cout % vecel == 0) ? 1 : 0;
     k.vecB = aligned16(a->x) && (a->Cs % vecel == 0) ? 1 : 0;
     // CONVT needs every N tile inside one tap: BN divides Cin (64 always does here; 128 when Cin % 128 == 0)
+    {   // direct-to-LDS kernel (gemm_glds_tt.hip): 128-multiples of Cout / Cin with a workspace split reduction
+      const int gw = glds_wgrad_try_launch(k, a->dtype_in, a->dtype_out, st);
+      if (gw >= 0) return gw;
+    }
     static const int wforce = [] { const char* e = getenv("GPV_FORCE_WGRAD_TILE"); return e ? atoi(e) : 0; }();   // tuning only
     if (a->dtype_in == GPV_BF16) {
       const bool can128 = (a->Cin % 128 == 0) && k.M >= 128;

@@ -57,4 +57,8 @@ int launch_splitk_reduce(const float* ws, int split, int M, int N, float* C, int
 // gemm_skinny.hip: weight-gradient form (both operands reduction-major), fp32 accumulate into C, optional a_rowsum
 int skinny_tt_try_launch(const GemmK& k, int dtype_in, int dtype_out, int batch, hipStream_t st);
 
+// gemm_glds_tt.hip: direct-to-LDS conv weight gradient (two-pass split reduction through k.ws_base).  Same return convention.
+int glds_wgrad_try_launch(const GemmK& k, int dtype_in, int dtype_out, hipStream_t st);
+extern int g_wgrad_mode;
+
 }  // namespace gpvk

@@ -393,6 +393,11 @@ extern "C" int gpv_set_option(int option, int value) {
     gpvk::g_skinny_mode = value;
     return prev;
   }
+  if (option == GPV_OPT_GLDS_WGRAD) {
+    const int prev = gpvk::g_wgrad_mode;
+    gpvk::g_wgrad_mode = value;
+    return prev;
+  }
   if (option == GPV_OPT_GLDS_LAUNCHES) {
     const long prev = gpvk::g_glds_launches;
     gpvk::g_glds_launches = value;

@@ -1,0 +1,246 @@
+// Direct-to-LDS convolution weight gradient for gfx950 (bf16 operands, fp32 partial products).
+//
+//   dW[Cout][tap*Cin + c] += sum over pixels k of  dY[k][Cout]  *  X[pixel k shifted by tap][c]
+//   M = Cout, N = taps*Cin, reduction K = B*OH*OW output pixels; both operands are REDUCTION-major in memory
+//   (a row of dY / of the NHWC input is one pixel), so a k-tile is [64 pixels][128 columns] = 256 B per pixel and operand.
+//
+// Same idea as gemm_glds.hip, for the operand form gemm.hip's register-staged TRANS x CONV kernel handles:
+//   * 128 x 128 tiles, 4 waves (2x2, wave tile 64x64), k-tiles of 64 pixels, two LDS stages of 32 KB -> two blocks per CU;
+//   * pixel rows go L2 -> LDS with global_load_lds_dwordx4 (a wave instruction = 4 pixel rows x 256 B, lane-linear in LDS):
+//     no staging VGPRs, no zero-masking pass, no ds_write;
+//   * MFMA operand fragments come out of the pixel-major LDS image with ds_read_b64_tr_b16 (one read = 4 consecutive pixels
+//     of the lane's column).  A pixel row is exactly 64 banks wide, so the 8 rows a 32-lane phase touches (r, r+8; r = 0..3)
+//     would all hit the same banks: the 32-byte column pairs of row r are stored at pair index P ^ q(r),
+//     q(r) = (r & 3) | ((r >> 3) & 1) << 2, applied when the lane picks its SOURCE chunk and again in the fragment address;
+//   * the gather arithmetic (pixel -> (image, oh, ow) -> input offset, bounds) is done ONCE per pixel row and k-tile: lane l
+//     owns row l of the k-tile and advances its (oh, ow, image) state by 64 pixels without divisions; the four loads a lane
+//     issues fetch their row's offset from the owning lane with a wave shuffle.  (The register-staged kernel recomputes it
+//     for every 16-byte load: ~100 VALU instructions per 16 MFMAs and wave; here ~60 per 32.)
+// The reduction is split over gridDim.y; every split writes its partial [M,N] product (alpha, per-row BN scale applied)
+// to its slab of the caller's workspace, gemm.hip's splitk_reduce_kernel adds the slabs to dW (two-pass, no atomics).
+#include "gemm_common.h"
+
+namespace gpvk {
+namespace {
+
+constexpr int TBM = 128, TBN = 128, TBK = 64;
+constexpr int ROWBYTES = 256;                      // one pixel row of a 128-column operand tile
+constexpr int OP_BYTES = TBK * ROWBYTES;           // 16 KB
+constexpr int TSTAGE = 2 * OP_BYTES;
+
+__device__ __attribute__((aligned(256))) unsigned char g_zero_row[256];   // zero-initialised
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void glb_void_t;
+
+__device__ __forceinline__ void glds16(const void* g, unsigned char* l) {
+  __builtin_amdgcn_global_load_lds((glb_void_t*)g, (lds_void_t*)l, 16, 0, 0);
+}
+
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned char* p) {
+  typedef short __attribute__((ext_vector_type(4))) s16x4;
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
+  s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 4 * ROWBYTES));
+  typedef short __attribute__((ext_vector_type(8))) s16x8;
+  s16x8 r = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  return __builtin_bit_cast(bf16x8, r);
+}
+
+__global__ __launch_bounds__(256) void glds_wgrad_kernel(GemmK p) {
+  extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const ConvGeom& g = p.cg;
+
+  // (tile, split) plane, split-major, contiguous range per XCD (see gemm.hip): an XCD runs all tiles of one reduction slice
+  int tile, ksplit;
+  {
+    const int gx = gridDim.x, nwg = gx * (int)gridDim.y, bid = (int)blockIdx.x + gx * (int)blockIdx.y;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+    const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    ksplit = v / gx;
+    tile = v - ksplit * gx;
+  }
+  const int tm = tile / p.tilesN, tn = tile - tm * p.tilesN;
+  const int row0 = tm * TBM, col0 = tn * TBN;
+  const int kt_total = (p.K + TBK - 1) / TBK;
+  const int kt0 = ksplit * p.kt_per_split;
+  const int kt1 = min(kt_total, kt0 + p.kt_per_split);
+  if (kt0 >= kt1) return;                            // (the host sizes the split so that this does not happen)
+
+  // this tile's tap and channel block (TBN divides Cin: checked on the host)
+  const int tap = col0 / g.Cin, c0 = col0 - tap * g.Cin;
+  const int tap_r = tap / g.KW, tap_s = tap - tap_r * g.KW;
+  const int dh = tap_r - g.PH, dw = tap_s - g.PW;
+
+  // ---- pixel-row state: lane l owns reduction row l of every k-tile ----
+  int px_b, px_oh, px_ow;
+  {
+    const int k = kt0 * TBK + lane;
+    px_b = k / (g.OH * g.OW);
+    const int rem = k - px_b * (g.OH * g.OW);
+    px_oh = rem / g.OW;
+    px_ow = rem - px_oh * g.OW;
+  }
+  const int adv_q = TBK / g.OW, adv_r = TBK - adv_q * g.OW;      // 64 pixels = adv_q rows + adv_r columns (OH*OW >= 64: host)
+
+  // ---- loader: instruction j of this wave covers rows wave*16 + j*4 + (lane >> 4), slot lane & 15 ----
+  const int lrow = lane >> 4;
+  const int chunk01 = (lane & 15) ^ (2 * lrow);                  // logical 16-B chunk for j = 0, 1; j = 2, 3: ^ 8
+  const bf16* Xp = reinterpret_cast<const bf16*>(p.B) + c0;
+  const bf16* a_ptr[4];
+  {
+    const bf16* Ap = reinterpret_cast<const bf16*>(p.A) + row0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = wave * 16 + j * 4 + lrow;
+      a_ptr[j] = Ap + (int64_t)(kt0 * TBK + r) * p.lda + (chunk01 ^ ((j >> 1) * 8)) * 8;
+    }
+  }
+  const int64_t a_step = (int64_t)TBK * p.lda;
+  const bf16* zero_src = reinterpret_cast<const bf16*>(g_zero_row) + (lane & 15) * 8;
+
+  auto issue = [&](int kt, int stage) {
+    unsigned char* sa = smem + stage * TSTAGE + wave * (4 * 1024);
+    unsigned char* sb = sa + OP_BYTES;
+    // my row's gather offset (elements from Xp), or -1 when the tap falls outside the input / beyond the last pixel
+    int off;
+    {
+      const int ih = px_oh * g.SH + dh, iw = px_ow * g.SW + dw;
+      const bool ok = (unsigned)ih < (unsigned)g.IH && (unsigned)iw < (unsigned)g.IW && kt * TBK + lane < p.K;
+      off = ok ? ((px_b * g.IH + ih) * g.IW + iw) * g.Cs : -1;
+      px_ow += adv_r;
+      const int c = px_ow >= g.OW ? 1 : 0;
+      px_ow -= c ? g.OW : 0;
+      px_oh += adv_q + c;
+      const int c2 = px_oh >= g.OH ? 1 : 0;
+      px_oh -= c2 ? g.OH : 0;
+      px_b += c2;
+    }
+    const bool full = (kt + 1) * TBK <= p.K;                     // uniform
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = wave * 16 + j * 4 + lrow;
+      const int o = __shfl(off, r);
+      const bf16* src = Xp + o + (chunk01 ^ ((j >> 1) * 8)) * 8;
+      glds16(o >= 0 ? src : zero_src, sb + j * 1024);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bool ok = full || kt * TBK + wave * 16 + j * 4 + lrow < p.K;
+      glds16(ok ? a_ptr[j] : zero_src, sa + j * 1024);
+      a_ptr[j] += a_step;
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // fragment addresses: lane (li = lane & 15, fg = lane >> 4) points at row 8*fg + (li >> 2), 8 bytes (li & 1) of logical
+  // chunk 2*P + ((li & 3) >> 1), P = 16-column group; stored pair index = P ^ q, q = (li >> 2) | (fg & 1) << 2
+  const int li = lane & 15, fg = lane >> 4;
+  const int fq = (li >> 2) | ((fg & 1) << 2);
+  const int f_row = (8 * fg + (li >> 2)) * ROWBYTES + ((li & 3) >> 1) * 16 + (li & 1) * 8;
+  int a_sl[4], b_sl[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    a_sl[i] = f_row + (((wm * 4 + i) ^ fq) << 5);
+    b_sl[i] = OP_BYTES + f_row + (((wn * 4 + i) ^ fq) << 5);
+  }
+
+  issue(kt0, 0);
+  for (int kt = kt0; kt < kt1; ++kt) {
+    const int t = kt - kt0;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (kt + 1 < kt1) issue(kt + 1, (t + 1) & 1);
+    const unsigned char* st = smem + (t & 1) * TSTAGE;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 af[4], bfr[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bfr[j] = tr_frag(st + b_sl[j] + kk * 32 * ROWBYTES);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = tr_frag(st + a_sl[i] + kk * 32 * ROWBYTES);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(bfr[j], af[i], acc[i][j]);   // swapped: lane holds 4 consecutive columns
+    }
+  }
+
+  // ---------------- epilogue: fragments -> LDS (fp32, 64 rows at a time) -> whole rows of this split's slab ----------------
+  float* Cp = p.ws + (int64_t)ksplit * p.M * p.N;
+  float* ep = reinterpret_cast<float*>(smem);
+  constexpr int EPITCH = TBN + 4;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    __syncthreads();
+    if (wm == half) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          *reinterpret_cast<f32x4*>(ep + (i * 16 + li) * EPITCH + wn * 64 + j * 16 + fg * 4) = acc[i][j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {                    // 64 rows x 32 quads / 256 threads
+      const int idx = tid + q * 256;
+      const int r = idx >> 5, c4 = idx & 31;
+      const int m = row0 + half * 64 + r;
+      if (m >= p.M) continue;
+      const float rs = p.rowscale ? p.rowscale[m] * p.alpha : p.alpha;
+      float4 v = *reinterpret_cast<const float4*>(ep + r * EPITCH + c4 * 4);
+      v.x *= rs; v.y *= rs; v.z *= rs; v.w *= rs;
+      *reinterpret_cast<float4*>(Cp + (int64_t)m * p.N + col0 + c4 * 4) = v;
+    }
+  }
+}
+
+}  // namespace
+
+int g_wgrad_mode = [] { const char* e = getenv("GPV_GLDS_WGRAD"); return e ? atoi(e) : 1; }();   // gpv_set_option(GPV_OPT_GLDS_WGRAD, .)
+
+// conv weight gradient (k as prepared by gpv_conv2d mode 2: A = dy [K][M], B = x NHWC, C = dw [M][N] fp32, split chosen).
+// returns 0 = launched (partial products + reduction), -1 = not applicable, > 0 = hipError_t
+int glds_wgrad_try_launch(const GemmK& k, int dtype_in, int dtype_out, hipStream_t st) {
+  if (g_wgrad_mode == 0 || dtype_in != GPV_BF16 || dtype_out != GPV_F32) return -1;
+  const ConvGeom& g = k.cg;
+  if (k.M % TBM != 0 || g.Cin % TBN != 0 || k.N % TBN != 0) return -1;
+  if (g.Cs % 8 != 0 || k.lda % 8 != 0 || (reinterpret_cast<uintptr_t>(k.A) & 15) || (reinterpret_cast<uintptr_t>(k.B) & 15)) return -1;
+  if (TBK / g.OW + 2 > g.OH || (int64_t)g.IH * g.IW * g.Cs * (k.K / (g.OH * g.OW)) >= (1ll << 31)) return -1;
+  if (!k.accumulate || k.ws_base == nullptr || (reinterpret_cast<uintptr_t>(k.C) & 15) || k.ldc % 4 != 0) return -1;
+  GemmK p = k;
+  const int kt_total = (p.K + TBK - 1) / TBK;
+  // two 64 KB blocks per CU = 512 resident blocks: size the split so that (tiles x splits) fills them once -- the 544 the
+  // register-staged kernel (three blocks per CU) is tuned for would leave a second, almost empty round
+  static const int target = [] { const char* e = getenv("GPV_WGRAD_TARGET"); return e ? atoi(e) : 512; }();
+  const int tiles = (p.M / TBM) * (p.N / TBN);
+  int split = target / tiles;
+  if (split > kt_total / 4) split = kt_total / 4;
+  if (split < 2) return -1;
+  while (split > 2 && (int64_t)split * p.M * p.N * 4 > k.ws_bytes) --split;
+  p.kt_per_split = (kt_total + split - 1) / split;
+  split = (kt_total + p.kt_per_split - 1) / p.kt_per_split;
+  if ((int64_t)split * p.M * p.N * 4 > k.ws_bytes) return -1;
+  p.ws = reinterpret_cast<float*>(k.ws_base);
+  p.tilesN = p.N / TBN;
+  constexpr int lds = 2 * TSTAGE;                    // 64 KB (the fp32 epilogue image needs 33 KB)
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(glds_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return (int)e;
+    attr_done = true;
+  }
+  dim3 grid((p.M / TBM) * p.tilesN, split, 1);
+  hipLaunchKernelGGL(glds_wgrad_kernel, grid, dim3(256), lds, st, p);
+  GPV_CHECK_LAUNCH();
+  return launch_splitk_reduce(p.ws, split, p.M, p.N, reinterpret_cast<float*>(p.C), p.ldc, st);
+}
+
+}  // namespace gpvk

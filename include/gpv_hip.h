@@ -38,12 +38,13 @@ extern "C" {
 int gpv_abi_version(void); /* = 1 */
 
 /* Kernel-selection knob (process-wide; tests and tuning only; never changes results beyond fp32 summation order).
- *   option GPV_OPT_GLDS: 0 = 4-wave register-staged GEMM/conv kernel only, 1 (default) = use the 8-wave
- *   direct-to-LDS kernel where it is expected to win, 2 = wherever it is legal.  Returns the previous value,
- *   or -1 for an unknown option.  (No reference counterpart: the reference delegates kernel choice to cuDNN/cuBLAS.) */
+ *   option GPV_OPT_GLDS: 0 = 4-wave register-staged GEMM/conv kernel only, 1 (default) = use the direct-to-LDS
+ *   kernels where they are expected to win, 2 / 3 = the 8-wave 256-row / 4-wave 128x128 variant wherever it is legal.
+ *   Returns the previous value, or -1 for an unknown option.  (No reference counterpart: the reference delegates kernel choice to cuDNN/cuBLAS.) */
 #define GPV_OPT_GLDS 0
 #define GPV_OPT_SKINNY 2 /* small-M GEMM kernel (reduction split over the block's waves): 0 never, 1 (default) heuristic, 2 wherever legal */
-#define GPV_OPT_GLDS_LAUNCHES 1 /* returns the number of 8-wave launches so far, then sets the counter to value */
+#define GPV_OPT_GLDS_LAUNCHES 1 /* returns the number of direct-to-LDS GEMM/conv launches so far, then sets the counter to value */
+#define GPV_OPT_GLDS_WGRAD 3 /* direct-to-LDS conv weight-gradient kernel: 0 never, 1 (default) wherever it is legal */
 int gpv_set_option(int option, int value);
 
 /* ---------------------------------------------------------------------------------------------

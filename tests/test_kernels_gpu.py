@@ -175,6 +175,34 @@ def test_conv_fwd_dgrad_wgrad(dtype, Cin, Cout, k, s, p, H, W):
     assert rel(dw, refw) < (3e-5 if dtype == torch.float32 else 3e-3)
 
 
+@pytest.mark.parametrize('Cin,Cout,k,s,p,H,W,Bn', [
+    (128, 128, 3, 1, 1, 30, 40, 4),      # 3x3, every tap incl. the padded border
+    (256, 256, 3, 2, 1, 30, 40, 4),      # stride 2
+    (512, 128, 1, 1, 0, 15, 20, 5),      # 1x1, B*OH*OW = 1500: ragged last k-tile of 64 pixels
+    (256, 512, 1, 2, 0, 30, 40, 3),      # strided 1x1 (downsample)
+    (128, 256, 3, 1, 1, 8, 24, 6)])      # short rows: a 64-pixel k-tile spans 3 image rows and crosses images
+def test_conv_wgrad_direct_to_lds_vs_register_staged(Cin, Cout, k, s, p, H, W, Bn):
+    """gemm_glds_tt.hip against gemm.hip's TRANS x CONV kernel (same split, same reduction kernel) and against autograd"""
+    h, dtype = hip(), torch.bfloat16
+    x = rnd(Bn, Cin, H, W, dtype=dtype, seed=40)
+    OH, OW = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    dy = rnd(Bn, Cout, OH, OW, dtype=dtype, seed=41)
+    scale = rnd(Cout, seed=42).abs() + 0.5
+    xn, dyn = nhwc(x), nhwc(dy)
+    outs = []
+    for mode in (0, 1):
+        prev = h.set_option(h.OPT_GLDS_WGRAD, mode)
+        dw = torch.full((Cout, k, k, Cin), 0.25, device=DEV)           # accumulates into what is there
+        h.conv2d(2, xn, dyn, dw, Bn, H, W, Cin, Cin, OH, OW, Cout, k, k, s, s, p, p, rowscale=scale)
+        h.set_option(h.OPT_GLDS_WGRAD, prev)
+        outs.append(dw)
+    wf = torch.zeros(Cout, Cin, k, k, device=DEV, requires_grad=True)
+    gw, = torch.autograd.grad(F.conv2d(x.float(), wf, stride=s, padding=p), wf, dy.float())
+    ref = (gw * scale.view(-1, 1, 1, 1)).permute(0, 2, 3, 1) + 0.25
+    assert rel(outs[1], ref) < 3e-3
+    assert rel(outs[1], outs[0]) < 1e-5                                # same bf16 products, fp32 sums in a different order
+
+
 @pytest.mark.parametrize('dtype', DTYPES)
 def test_stem_conv_image_prep_and_maxpool(dtype):
     h = hip()

@@ -17,14 +17,14 @@ def load(d, counter):
 
 def is_conv(name):
     n = name.replace('(anonymous namespace)::', '')
-    return ('gemm_kernel' in n and 'Li2ELi0E' in n) or ('gemm_kernel<' in n and ', 1, 2, ' in n) or 'glds_kernelILi2E' in n or 'conv1x1_kernel' in n
+    return ('gemm_kernel' in n and 'Li2ELi0E' in n) or ('gemm_kernel<' in n and ', 1, 2, ' in n) or 'glds_kernelILi2E' in n or 'conv1x1_kernel' in n or 'glds_wgrad_kernel' in n
 
 fd, wd, steps = sys.argv[1], sys.argv[2], int(sys.argv[3])
 F, Wr = load(fd, 'FETCH_SIZE'), load(wd, 'WRITE_SIZE')
 fetch_kb = sum(v[0] for k, v in F.items() if is_conv(k)); nf = sum(v[1] for k, v in F.items() if is_conv(k))
 write_kb = sum(v[0] for k, v in Wr.items() if is_conv(k)); nw = sum(v[1] for k, v in Wr.items() if is_conv(k))
 res = {
-    'what': 'gemm_kernel<OP_CONV,...> / conv1x1_kernel / wgrad <OP_TRANS,OP_CONV> / glds_kernel<OP_CONV> launches of `python bench.py` (B=32 train step)',
+    'what': 'gemm_kernel<OP_CONV,...> / conv1x1_kernel / wgrad <OP_TRANS,OP_CONV> / glds_wgrad_kernel / glds_kernel<OP_CONV> / glds_conv1x1_kernel launches of `python bench.py` (B=32 train step)',
     'steps_profiled': steps, 'conv_launches_fetch_pass': nf, 'conv_launches_write_pass': nw,
     'FETCH_SIZE_KB_raw': fetch_kb, 'WRITE_SIZE_KB_raw': write_kb,
     'fetch_bytes_corrected_x2': fetch_kb * 1024 * 2, 'write_bytes': write_kb * 1024,
