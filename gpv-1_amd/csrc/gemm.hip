@@ -839,6 +839,8 @@ extern "C" int gpv_gemm(const gpv_gemm_args* a, void* stream) {
     if (a->accumulate) {                                  // small weight gradients: reduction split over the block's waves
       GemmK kk = k;
       kk.accumulate = 1; kk.res = nullptr; kk.ldr = 0; kk.sR = 0;      // (the split==1 rewrite above turned C += into res = C)
+      const int gt = glds_tt_try_launch(kk, a->dtype_in, a->dtype_out, a->batch, st);        // 128-multiples, long reduction
+      if (gt >= 0) return gt;
       const int sk = skinny_tt_try_launch(kk, a->dtype_in, a->dtype_out, a->batch, st);
       if (sk >= 0) return sk;
     }

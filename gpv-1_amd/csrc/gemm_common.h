@@ -59,6 +59,7 @@ int skinny_tt_try_launch(const GemmK& k, int dtype_in, int dtype_out, int batch,
 
 // gemm_glds_tt.hip: direct-to-LDS conv weight gradient (two-pass split reduction through k.ws_base).  Same return convention.
 int glds_wgrad_try_launch(const GemmK& k, int dtype_in, int dtype_out, hipStream_t st);
+int glds_tt_try_launch(const GemmK& k, int dtype_in, int dtype_out, int batch, hipStream_t st);   // linear form (+ a_rowsum)
 extern int g_wgrad_mode;
 
 }  // namespace gpvk

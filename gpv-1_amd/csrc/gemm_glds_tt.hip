@@ -47,7 +47,8 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* p) {
   return __builtin_bit_cast(bf16x8, r);
 }
 
-__global__ __launch_bounds__(256) void glds_wgrad_kernel(GemmK p) {
+template <bool CONV>
+__device__ __forceinline__ void glds_tt_body(const GemmK& p) {
   extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -69,62 +70,78 @@ __global__ __launch_bounds__(256) void glds_wgrad_kernel(GemmK p) {
   const int kt1 = min(kt_total, kt0 + p.kt_per_split);
   if (kt0 >= kt1) return;                            // (the host sizes the split so that this does not happen)
 
-  // this tile's tap and channel block (TBN divides Cin: checked on the host)
-  const int tap = col0 / g.Cin, c0 = col0 - tap * g.Cin;
-  const int tap_r = tap / g.KW, tap_s = tap - tap_r * g.KW;
-  const int dh = tap_r - g.PH, dw = tap_s - g.PW;
+  // CONV: this tile's tap and channel block (TBN divides Cin: checked on the host)
+  int c0 = 0, dh = 0, dw = 0;
+  if constexpr (CONV) {
+    const int tap = col0 / g.Cin;
+    c0 = col0 - tap * g.Cin;
+    const int tap_r = tap / g.KW, tap_s = tap - tap_r * g.KW;
+    dh = tap_r - g.PH; dw = tap_s - g.PW;
+  }
 
-  // ---- pixel-row state: lane l owns reduction row l of every k-tile ----
-  int px_b, px_oh, px_ow;
-  {
+  // ---- CONV pixel-row state: lane l owns reduction row l of every k-tile ----
+  int px_b = 0, px_oh = 0, px_ow = 0, adv_q = 0, adv_r = 0;
+  if constexpr (CONV) {
     const int k = kt0 * TBK + lane;
     px_b = k / (g.OH * g.OW);
     const int rem = k - px_b * (g.OH * g.OW);
     px_oh = rem / g.OW;
     px_ow = rem - px_oh * g.OW;
+    adv_q = TBK / g.OW; adv_r = TBK - adv_q * g.OW;              // 64 pixels = adv_q rows + adv_r columns (adv_q + 2 <= OH: host)
   }
-  const int adv_q = TBK / g.OW, adv_r = TBK - adv_q * g.OW;      // 64 pixels = adv_q rows + adv_r columns (OH*OW >= 64: host)
 
   // ---- loader: instruction j of this wave covers rows wave*16 + j*4 + (lane >> 4), slot lane & 15 ----
   const int lrow = lane >> 4;
   const int chunk01 = (lane & 15) ^ (2 * lrow);                  // logical 16-B chunk for j = 0, 1; j = 2, 3: ^ 8
   const bf16* Xp = reinterpret_cast<const bf16*>(p.B) + c0;
   const bf16* a_ptr[4];
+  const bf16* b_ptr[CONV ? 1 : 4];
   {
     const bf16* Ap = reinterpret_cast<const bf16*>(p.A) + row0;
+    const bf16* Bp = reinterpret_cast<const bf16*>(p.B) + col0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int r = wave * 16 + j * 4 + lrow;
       a_ptr[j] = Ap + (int64_t)(kt0 * TBK + r) * p.lda + (chunk01 ^ ((j >> 1) * 8)) * 8;
+      if constexpr (!CONV) b_ptr[j] = Bp + (int64_t)(kt0 * TBK + r) * p.ldb + (chunk01 ^ ((j >> 1) * 8)) * 8;
     }
   }
-  const int64_t a_step = (int64_t)TBK * p.lda;
+  const int64_t a_step = (int64_t)TBK * p.lda, b_step = (int64_t)TBK * p.ldb;
   const bf16* zero_src = reinterpret_cast<const bf16*>(g_zero_row) + (lane & 15) * 8;
 
   auto issue = [&](int kt, int stage) {
     unsigned char* sa = smem + stage * TSTAGE + wave * (4 * 1024);
     unsigned char* sb = sa + OP_BYTES;
-    // my row's gather offset (elements from Xp), or -1 when the tap falls outside the input / beyond the last pixel
-    int off;
-    {
-      const int ih = px_oh * g.SH + dh, iw = px_ow * g.SW + dw;
-      const bool ok = (unsigned)ih < (unsigned)g.IH && (unsigned)iw < (unsigned)g.IW && kt * TBK + lane < p.K;
-      off = ok ? ((px_b * g.IH + ih) * g.IW + iw) * g.Cs : -1;
-      px_ow += adv_r;
-      const int c = px_ow >= g.OW ? 1 : 0;
-      px_ow -= c ? g.OW : 0;
-      px_oh += adv_q + c;
-      const int c2 = px_oh >= g.OH ? 1 : 0;
-      px_oh -= c2 ? g.OH : 0;
-      px_b += c2;
-    }
     const bool full = (kt + 1) * TBK <= p.K;                     // uniform
+    if constexpr (CONV) {
+      // my row's gather offset (elements from Xp), or -1 when the tap falls outside the input / beyond the last pixel
+      int off;
+      {
+        const int ih = px_oh * g.SH + dh, iw = px_ow * g.SW + dw;
+        const bool ok = (unsigned)ih < (unsigned)g.IH && (unsigned)iw < (unsigned)g.IW && kt * TBK + lane < p.K;
+        off = ok ? ((px_b * g.IH + ih) * g.IW + iw) * g.Cs : -1;
+        px_ow += adv_r;
+        const int c = px_ow >= g.OW ? 1 : 0;
+        px_ow -= c ? g.OW : 0;
+        px_oh += adv_q + c;
+        const int c2 = px_oh >= g.OH ? 1 : 0;
+        px_oh -= c2 ? g.OH : 0;
+        px_b += c2;
+      }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int r = wave * 16 + j * 4 + lrow;
-      const int o = __shfl(off, r);
-      const bf16* src = Xp + o + (chunk01 ^ ((j >> 1) * 8)) * 8;
-      glds16(o >= 0 ? src : zero_src, sb + j * 1024);
+      for (int j = 0; j < 4; ++j) {
+        const int r = wave * 16 + j * 4 + lrow;
+        const int o = __shfl(off, r);
+        const bf16* src = Xp + o + (chunk01 ^ ((j >> 1) * 8)) * 8;
+        glds16(o >= 0 ? src : zero_src, sb + j * 1024);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bool ok = full || kt * TBK + wave * 16 + j * 4 + lrow < p.K;
+        glds16(ok ? b_ptr[j] : zero_src, sb + j * 1024);
+        b_ptr[j] += b_step;
+      }
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -152,6 +169,17 @@ __global__ __launch_bounds__(256) void glds_wgrad_kernel(GemmK p) {
     b_sl[i] = OP_BYTES + f_row + (((wn * 4 + i) ^ fq) << 5);
   }
 
+  // plain form, bias gradient: a_rowsum[m] += sum_k A[k][m].  The A fragments are already in registers: one more MFMA per
+  // fragment against an all-ones operand gives every lane the column sum of ITS m (lane & 15), on the waves of the first
+  // column tile only
+  const bool do_sum = !CONV && p.a_rowsum != nullptr && tn == 0 && wn == 0;
+  f32x4 sacc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) sacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  bf16x8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
+
   issue(kt0, 0);
   for (int kt = kt0; kt < kt1; ++kt) {
     const int t = kt - kt0;
@@ -170,6 +198,18 @@ __global__ __launch_bounds__(256) void glds_wgrad_kernel(GemmK p) {
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(bfr[j], af[i], acc[i][j]);   // swapped: lane holds 4 consecutive columns
+      if constexpr (!CONV) {
+        if (do_sum) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) sacc[i] = mfma16(ones, af[i], sacc[i]);
+        }
+      }
+    }
+  }
+  if constexpr (!CONV) {
+    if (do_sum && fg == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) atomicAdd(p.a_rowsum + row0 + wm * 64 + i * 16 + li, sacc[i][0]);
     }
   }
 
@@ -202,19 +242,12 @@ __global__ __launch_bounds__(256) void glds_wgrad_kernel(GemmK p) {
   }
 }
 
-}  // namespace
+__global__ __launch_bounds__(256) void glds_wgrad_kernel(GemmK p) { glds_tt_body<true>(p); }       // conv: B gathered from NHWC x
+__global__ __launch_bounds__(256) void glds_tt_kernel(GemmK p) { glds_tt_body<false>(p); }         // linear: B = x [K][N]
 
-int g_wgrad_mode = [] { const char* e = getenv("GPV_GLDS_WGRAD"); return e ? atoi(e) : 1; }();   // gpv_set_option(GPV_OPT_GLDS_WGRAD, .)
-
-// conv weight gradient (k as prepared by gpv_conv2d mode 2: A = dy [K][M], B = x NHWC, C = dw [M][N] fp32, split chosen).
-// returns 0 = launched (partial products + reduction), -1 = not applicable, > 0 = hipError_t
-int glds_wgrad_try_launch(const GemmK& k, int dtype_in, int dtype_out, hipStream_t st) {
-  if (g_wgrad_mode == 0 || dtype_in != GPV_BF16 || dtype_out != GPV_F32) return -1;
-  const ConvGeom& g = k.cg;
-  if (k.M % TBM != 0 || g.Cin % TBN != 0 || k.N % TBN != 0) return -1;
-  if (g.Cs % 8 != 0 || k.lda % 8 != 0 || (reinterpret_cast<uintptr_t>(k.A) & 15) || (reinterpret_cast<uintptr_t>(k.B) & 15)) return -1;
-  if (TBK / g.OW + 2 > g.OH || (int64_t)g.IH * g.IW * g.Cs * (k.K / (g.OH * g.OW)) >= (1ll << 31)) return -1;
-  if (!k.accumulate || k.ws_base == nullptr || (reinterpret_cast<uintptr_t>(k.C) & 15) || k.ldc % 4 != 0) return -1;
+// shared launch tail: split sizing, workspace slabs, kernel, reduction
+template <typename F>
+int launch_tt(F fn, const GemmK& k, bool& attr_done, hipStream_t st) {
   GemmK p = k;
   const int kt_total = (p.K + TBK - 1) / TBK;
   // two 64 KB blocks per CU = 512 resident blocks: size the split so that (tiles x splits) fills them once -- the 544 the
@@ -227,20 +260,54 @@ int glds_wgrad_try_launch(const GemmK& k, int dtype_in, int dtype_out, hipStream
   while (split > 2 && (int64_t)split * p.M * p.N * 4 > k.ws_bytes) --split;
   p.kt_per_split = (kt_total + split - 1) / split;
   split = (kt_total + p.kt_per_split - 1) / p.kt_per_split;
-  if ((int64_t)split * p.M * p.N * 4 > k.ws_bytes) return -1;
+  if (split < 2 || (int64_t)split * p.M * p.N * 4 > k.ws_bytes) return -1;
   p.ws = reinterpret_cast<float*>(k.ws_base);
   p.tilesN = p.N / TBN;
   constexpr int lds = 2 * TSTAGE;                    // 64 KB (the fp32 epilogue image needs 33 KB)
-  static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(glds_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return (int)e;
     attr_done = true;
   }
   dim3 grid((p.M / TBM) * p.tilesN, split, 1);
-  hipLaunchKernelGGL(glds_wgrad_kernel, grid, dim3(256), lds, st, p);
+  hipLaunchKernelGGL(fn, grid, dim3(256), lds, st, p);
   GPV_CHECK_LAUNCH();
   return launch_splitk_reduce(p.ws, split, p.M, p.N, reinterpret_cast<float*>(p.C), p.ldc, st);
+}
+
+inline bool al16t(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
+
+}  // namespace
+
+int g_wgrad_mode = [] { const char* e = getenv("GPV_GLDS_WGRAD"); return e ? atoi(e) : 1; }();   // gpv_set_option(GPV_OPT_GLDS_WGRAD, .)
+
+// conv weight gradient (k as prepared by gpv_conv2d mode 2: A = dy [K][M], B = x NHWC, C = dw [M][N] fp32, split chosen).
+// returns 0 = launched (partial products + reduction), -1 = not applicable, > 0 = hipError_t
+int glds_wgrad_try_launch(const GemmK& k, int dtype_in, int dtype_out, hipStream_t st) {
+  if (g_wgrad_mode == 0 || dtype_in != GPV_BF16 || dtype_out != GPV_F32) return -1;
+  const ConvGeom& g = k.cg;
+  if (k.M % TBM != 0 || g.Cin % TBN != 0 || k.N % TBN != 0) return -1;
+  if (g.Cs % 8 != 0 || k.lda % 8 != 0 || !al16t(k.A) || !al16t(k.B)) return -1;
+  if (TBK / g.OW + 2 > g.OH || (int64_t)g.IH * g.IW * g.Cs * (k.K / (g.OH * g.OW)) >= (1ll << 31)) return -1;
+  if (!k.accumulate || k.ws_base == nullptr || !al16t(k.C) || k.ldc % 4 != 0) return -1;
+  static bool attr_done = false;
+  return launch_tt(glds_wgrad_kernel, k, attr_done, st);
+}
+
+// linear weight gradient dW[M][N] += dY^T X (A = dy [K][M], B = x [K][N], both reduction-major), optional a_rowsum (bias
+// gradient).  Same return convention.
+int glds_tt_try_launch(const GemmK& k, int dtype_in, int dtype_out, int batch, hipStream_t st) {
+  if (g_wgrad_mode == 0 || dtype_in != GPV_BF16 || dtype_out != GPV_F32 || batch != 1) return -1;
+  if (k.M % TBM != 0 || k.N % TBN != 0 || k.K < 8 * TBK) return -1;
+  // measured on every linear weight-gradient shape of the step (tools/bench_step_gemms.py, GPV_GLDS_WGRAD=0 vs 2): it wins
+  // once there is enough work to fill the chip -- 768x3072 / 3072x768 over 3200 rows 52 -> 35 us, 1536x768 36 -> 26 us,
+  // 2048x256 over 9600 rows 33 -> 27 us -- and loses on the 4..36-tile gradients of short reductions (skinny_tt's territory)
+  if (g_wgrad_mode == 1 && (int64_t)(k.M / TBM) * (k.N / TBN) * ((k.K + TBK - 1) / TBK) < 3000) return -1;
+  if (k.lda % 8 != 0 || k.ldb % 8 != 0 || !al16t(k.A) || !al16t(k.B)) return -1;
+  if (!k.accumulate || k.ws_base == nullptr || !al16t(k.C) || k.ldc % 4 != 0) return -1;
+  if (k.res || k.mask || k.bias || k.act || k.dthresh) return -1;
+  static bool attr_done = false;
+  return launch_tt(glds_tt_kernel, k, attr_done, st);
 }
 
 }  // namespace gpvk

@@ -44,7 +44,7 @@ int gpv_abi_version(void); /* = 1 */
 #define GPV_OPT_GLDS 0
 #define GPV_OPT_SKINNY 2 /* small-M GEMM kernel (reduction split over the block's waves): 0 never, 1 (default) heuristic, 2 wherever legal */
 #define GPV_OPT_GLDS_LAUNCHES 1 /* returns the number of direct-to-LDS GEMM/conv launches so far, then sets the counter to value */
-#define GPV_OPT_GLDS_WGRAD 3 /* direct-to-LDS conv weight-gradient kernel: 0 never, 1 (default) wherever it is legal */
+#define GPV_OPT_GLDS_WGRAD 3 /* direct-to-LDS weight-gradient kernel: 0 never, 1 (default) conv wherever legal + linear where it wins, 2 both wherever legal */
 int gpv_set_option(int option, int value);
 
 /* ---------------------------------------------------------------------------------------------

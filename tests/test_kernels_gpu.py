@@ -127,6 +127,27 @@ def test_gemm_dropout_epilogue():
     assert torch.equal(C1, C2)            # counter-based RNG: same seed -> same mask
 
 
+@pytest.mark.parametrize('N,K,M', [(256, 256, 9600), (768, 3072, 3200), (2048, 256, 3200), (256, 2048, 9600), (1536, 768, 3392),
+                                   (768, 768, 10000), (128, 384, 1000)])
+def test_gemm_wgrad_direct_to_lds(N, K, M):
+    """gemm_glds_tt.hip (linear form, bias gradient through a ones-operand MFMA) vs the default kernels and vs fp32 torch;
+    M = 10000 / 1000 rows: ragged last k-tile of 64"""
+    h, dtype = hip(), torch.bfloat16
+    dy, x = rnd(M, N, dtype=dtype, seed=50), rnd(M, K, dtype=dtype, seed=51)
+    dw0, db0 = rnd(N, K, seed=52), rnd(N, seed=53)
+    outs = []
+    for mode in (0, 2):
+        prev = h.set_option(h.OPT_GLDS_WGRAD, mode)
+        dw, db = dw0.clone(), db0.clone()
+        h.gemm(dy, x, dw, N, K, M, N, K, K, layoutA=h.TRANS, layoutB=h.TRANS, accumulate=True, split_k=8, a_rowsum=db)
+        h.set_option(h.OPT_GLDS_WGRAD, prev)
+        outs.append((dw, db))
+    refw = dw0 + dy.float().t() @ x.float()
+    refb = db0 + dy.float().sum(0)
+    assert rel(outs[1][0], refw) < 3e-3 and rel(outs[1][1], refb) < 1e-5
+    assert rel(outs[1][0], outs[0][0]) < 1e-5 and rel(outs[1][1], outs[0][1]) < 1e-5
+
+
 # ----------------------------------------------------------------------------------------- conv
 def nhwc(x):
     return x.permute(0, 2, 3, 1).contiguous()
