@@ -159,7 +159,8 @@ def gemm(A, B, Cm, M, N, K, lda, ldb, ldc, layoutA=KMAJOR, layoutB=KMAJOR, batch
     a.accumulate, a.split_k = int(accumulate), split_k
     a.a_rowsum = _p(_f32(a_rowsum))
     if accumulate and batch == 1:                      # the library may split the reduction (further) when it has scratch
-        ws = _workspace(A.device, max(split_k, 8) * M * N * 4)
+        # (the direct-to-LDS weight-gradient kernel sizes its own split: 512 blocks of 128x128 fp32 partials = 32 MiB)
+        ws = _workspace(A.device, max(max(split_k, 8) * M * N * 4, 512 * 128 * 128 * 4))
         a.workspace, a.workspace_bytes = _p(ws), ws.numel()
     _chk(lib().gpv_gemm(C.byref(a), _stream()), 'gpv_gemm')
 
