@@ -815,8 +815,11 @@ extern "C" int gpv_gemm(const gpv_gemm_args* a, void* stream) {
   const int64_t vecel = 16 / esz;  // elements per 16 B
   auto vec_ok = [&](const void* ptr, int64_t ld, int64_t bs, int layout, int extent_contig) {
     bool ok = aligned16(ptr) && (ld % vecel == 0) && (a->batch == 1 || bs % vecel == 0);
-    if (layout == GPV_KMAJOR) ok = ok && (a->K % 8 == 0);
-    else ok = ok && (extent_contig % 8 == 0);
+    // 16-byte chunks: the contiguous extent must be a multiple of 8, or end inside the row pitch -- a reduction-major
+    // operand's last chunk then only feeds outputs beyond M / N (discarded); a k-major operand's last chunk multiplies
+    // masked rows of the other operand, so its padding must be finite (caller's promise: GPV_GEMM_KPAD_FINITE)
+    if (layout == GPV_KMAJOR) ok = ok && (a->K % 8 == 0 || ((a->flags & GPV_GEMM_KPAD_FINITE) && ld >= ((int64_t)a->K + 7) / 8 * 8));
+    else ok = ok && (extent_contig % 8 == 0 || ld >= ((int64_t)extent_contig + 7) / 8 * 8);
     return ok ? 1 : 0;
   };
   k.vecA = vec_ok(a->A, a->lda, a->sA, a->layoutA, a->M);

@@ -28,7 +28,7 @@ class GemmArgs(C.Structure):
                 ('relu_mask', C.c_void_p), ('ldm', C.c_int64),
                 ('act', C.c_int), ('drop_p', C.c_float), ('seed', C.c_uint64),
                 ('accumulate', C.c_int), ('split_k', C.c_int), ('workspace', C.c_void_p), ('workspace_bytes', C.c_int64),
-                ('a_rowsum', C.c_void_p)]
+                ('a_rowsum', C.c_void_p), ('flags', C.c_int)]
 
 
 class ConvArgs(C.Structure):
@@ -138,7 +138,7 @@ def _workspace(device, nbytes):
 
 def gemm(A, B, Cm, M, N, K, lda, ldb, ldc, layoutA=KMAJOR, layoutB=KMAJOR, batch=1, sA=0, sB=0, sC=0,
          alpha=1.0, rowscale=None, bias=None, res=None, ldr=0, sR=0, relu_mask=None, ldm=0, act=ACT_NONE,
-         drop_p=0.0, seed=0, accumulate=False, split_k=1, a_rowsum=None):
+         drop_p=0.0, seed=0, accumulate=False, split_k=1, a_rowsum=None, kpad_finite=False):
     a = GemmArgs()
     a.A, a.B, a.C = _p(A), _p(B), _p(Cm)
     a.M, a.N, a.K, a.batch = M, N, K, batch
@@ -158,6 +158,7 @@ def gemm(A, B, Cm, M, N, K, lda, ldb, ldc, layoutA=KMAJOR, layoutB=KMAJOR, batch
     a.act, a.drop_p, a.seed = act, drop_p, seed
     a.accumulate, a.split_k = int(accumulate), split_k
     a.a_rowsum = _p(_f32(a_rowsum))
+    a.flags = 1 if kpad_finite else 0                   # GPV_GEMM_KPAD_FINITE
     if accumulate and batch == 1:                      # the library may split the reduction (further) when it has scratch
         # (the direct-to-LDS weight-gradient kernel sizes its own split: 512 blocks of 128x128 fp32 partials = 32 MiB)
         ws = _workspace(A.device, max(max(split_k, 8) * M * N * 4, 512 * 128 * 128 * 4))

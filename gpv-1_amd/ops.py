@@ -474,7 +474,8 @@ class RoiPoolFn(Function):
         hip.roi_weights(_c(boxes.detach().float().reshape(-1, 4)), wgt, B * Q, H, Wd, ldw)
         f = _c(_as_compute(feat))
         out = torch.empty(B, Q, Cc, device=feat.device, dtype=RT.dtype)
-        hip.gemm(wgt, f, out, Q, Cc, Pn, ldw, Cc, Cc, layoutB=hip.TRANS, batch=B, sA=Q * ldw, sB=Pn * Cc, sC=Q * Cc)
+        hip.gemm(wgt, f, out, Q, Cc, Pn, ldw, Cc, Cc, layoutB=hip.TRANS, batch=B, sA=Q * ldw, sB=Pn * Cc, sC=Q * Cc,
+                 kpad_finite=True)               # roi_weights zero-fills [Pn, ldw)
         ctx.dims = (B, Pn, Cc, Q, ldw)
         ctx.save_for_backward(wgt)
         return out

@@ -80,7 +80,11 @@ typedef struct {
   float* a_rowsum;                /* layoutA = layoutB = GPV_TRANS only, or NULL: a_rowsum[m] += sum_k A[m,k]  (atomic).
                                      Weight-gradient GEMMs pass dY as A, so this is the bias gradient
                                      (sum over tokens), fused instead of a separate gpv_colsum launch. */
+  int flags;                      /* GPV_GEMM_KPAD_FINITE: every row of a GPV_KMAJOR operand is readable and holds finite values
+                                     (zero padding) up to the next multiple of 8 elements of K -- lets a K that is not a multiple
+                                     of 8 (RoI pooling: K = H*W = 300 of a 320-pitch weight row) use the 16-byte load path */
 } gpv_gemm_args;
+#define GPV_GEMM_KPAD_FINITE 1
 int gpv_gemm(const gpv_gemm_args* a, void* stream);
 
 /* ---------------------------------------------------------------------------------------------

@@ -34,7 +34,7 @@ def _act(x, act):
 
 def gemm(A, B, Cm, M, N, K, lda, ldb, ldc, layoutA=0, layoutB=0, batch=1, sA=0, sB=0, sC=0, alpha=1.0, rowscale=None,
          bias=None, res=None, ldr=0, sR=0, relu_mask=None, ldm=0, act=0, drop_p=0.0, seed=0, accumulate=False, split_k=1,
-         a_rowsum=None):
+         a_rowsum=None, kpad_finite=False):
     assert drop_p == 0.0, 'cpu shim: dropout unsupported'
     a = _mat(A, M, K, lda, layoutA, batch, sA).float()
     if a_rowsum is not None:
