@@ -43,6 +43,23 @@ def load_model_state(model, path, map_location='cpu'):
     return model
 
 
+def resize_image(img, size=(480, 640)):
+    """``skimage.transform.resize(img, (imh, imw), anti_aliasing=True)`` of datasets/coco_datasets.py:174 (the reference's
+    images are resized to ``task_configs.image_size`` = 480x640 before normalisation): float image in [0,1], Gaussian
+    pre-filter with sigma = (scale - 1) / 2 on the axes that shrink, then order-1 interpolation on the pixel-area grid,
+    mirrored borders.  Restated from scikit-image's published algorithm with scipy.ndimage (scikit-image is not in this
+    image, so this step is NOT pinned against it); HxWx3 uint8 or float array in, float32 HxWx3 in [0,1] out."""
+    from scipy import ndimage as ndi
+    a = np.asarray(img)
+    a = a.astype(np.float64) / (255.0 if a.dtype == np.uint8 else 1.0)
+    factors = np.array([a.shape[0] / size[0], a.shape[1] / size[1], 1.0])
+    sigma = np.maximum(0.0, (factors - 1.0) / 2.0)
+    if sigma.max() > 0:
+        a = ndi.gaussian_filter(a, sigma, mode='mirror')
+    out = ndi.zoom(a, 1.0 / factors, order=1, mode='mirror', grid_mode=True)
+    return np.clip(out, 0.0, 1.0).astype(np.float32)
+
+
 def preprocess_image(img):
     """ToPILImage -> ToTensor -> Normalize of inference.py:64-67 for the array forms documented above"""
     if torch.is_tensor(img) and img.dim() == 3 and img.shape[0] == 3 and img.is_floating_point():
@@ -95,9 +112,12 @@ def decode_outputs(outputs, model, num_output_boxes=None):
 
 
 @torch.no_grad()
-def predict(model, images, queries, beam_size=None, num_output_boxes=None):
-    """images: list of arrays/tensors (see preprocess_image); queries: list[str] or (ids, mask) tensors"""
+def predict(model, images, queries, beam_size=None, num_output_boxes=None, size=None):
+    """images: list of arrays/tensors (see preprocess_image); queries: list[str] or (ids, mask) tensors;
+    size: (H, W) to resize HxWx3 arrays to first (the data loader's 480x640), None = as they are (inference.py)"""
     dev = model.vision_token.device
+    if size is not None:
+        images = [resize_image(i, size) if not torch.is_tensor(i) else i for i in images]
     imgs = nested_tensor_from_tensor_list([preprocess_image(i).to(dev) for i in images])
     if beam_size:
         out = model.forward_beam_search(imgs, queries, beam_size=beam_size)

@@ -141,3 +141,50 @@ def test_inference_harness(shim, tmp_path):
     assert p['boxes'].shape == (3, 4) and isinstance(p['answer'], str)
     pb = inf.predict(model, [img], q, beam_size=2, num_output_boxes=3)[0]
     assert 'answer_prob' in pb and 0.0 <= pb['answer_prob'] <= 1.0
+
+
+def test_compute_predictions_files_and_vocab_mask(shim, tmp_path):
+    """compute_predictions.py:30-109 -- vocabulary mask, prediction JSON, boxes file layout"""
+    import json
+    from gpv1_amd import compute_predictions as cp
+    from gpv1_amd import inference as inf
+    model, _ = build_small()
+    model.eval()
+    # mask: 0 on class-name tokens present in the vocabulary and on __stop__/__pad__, -10000 elsewhere
+    tokens, mask = cp.create_vocab_mask(model, classes=('w3', 'w5 w9', 'not-a-word'), synonyms={'w3': ['w3', 'w4'], 'w5 w9': ['w5 w9'], 'not-a-word': ['w1']}, use_syns=True)
+    on = sorted(int(i) for i in np.nonzero(mask == 0)[0])
+    assert on == sorted(model.word_to_idx[t] for t in ('w3', 'w4', 'w5', 'w9', 'w1', '__stop__', '__pad__'))
+    assert set(tokens) == {'w3', 'w4', 'w5', 'w9', 'w1', '__stop__', '__pad__'} and float(mask.min()) == -10000.0 and mask.dtype == np.float32
+    assert cp.word_tokenize('hot dog') == ['hot', 'dog'] and len(cp.COCO_CLASSES) == 80
+    # three batches of two; num_eval_batches = 1 keeps batches 0 and 1 (the reference's `i > num_eval_batches`)
+    rs = np.random.RandomState(1)
+    g = torch.Generator().manual_seed(3)
+
+    def batches():
+        for b in range(3):
+            imgs = [inf.preprocess_image(inf.resize_image((rs.rand(50, 70, 3) * 255).astype(np.uint8), (32, 48))) for _ in range(2)]
+            q = (torch.randint(1000, 30000, (2, 5), generator=g), torch.ones(2, 5, dtype=torch.long))
+            yield imgs, q, [f'{b}_{k}' for k in range(2)]
+    _, vm = cp.create_vocab_mask(model, classes=('w2', 'w6'))
+    preds, jpath, bpath = cp.make_predictions(model, batches(), str(tmp_path / 'eval'), 'CocoClassification', subset='val',
+                                              data_split='gpv_split', num_eval_batches=1, vocab_mask=vm)
+    assert os.path.basename(jpath) == 'CocoClassification_gpv_split_val_predictions.json'
+    assert sorted(preds) == ['0_0', '0_1', '1_0', '1_1'] and json.load(open(jpath)) == preds
+    assert all(set(p['answer'].split()) <= {'w2', 'w6'} for p in preds.values())          # the mask confines the answers
+    if bpath.endswith('.npz'):
+        z = np.load(bpath)
+        boxes, rel = z['1_0/boxes'], z['1_0/relevance']
+    else:
+        import h5py
+        with h5py.File(bpath, 'r') as f:
+            boxes, rel = f['1_0']['boxes'][()], f['1_0']['relevance'][()]
+    Q = model.cfg.detr.num_queries if hasattr(model, 'cfg') else boxes.shape[0]
+    assert boxes.shape == (Q, 4) and rel.shape == (Q,) and boxes.dtype == np.float32 and rel.dtype == np.float32
+    assert np.all(np.diff(rel) <= 0)                                                      # sorted by relevance, all boxes kept
+    # anti-aliased resize: constant images stay constant, means are preserved, sizes are exact
+    c = np.full((50, 70, 3), 0.25, np.float32)
+    assert np.abs(inf.resize_image(c, (20, 30)) - 0.25).max() < 1e-6
+    img = (rs.rand(97, 131, 3) * 255).astype(np.uint8)
+    r = inf.resize_image(img, (48, 64))
+    assert r.shape == (48, 64, 3) and r.dtype == np.float32 and abs(float(r.mean()) - img.mean() / 255) < 2e-3
+    assert r.std() < (img / 255.0).std()                                                  # low-pass before subsampling

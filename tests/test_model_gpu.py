@@ -264,6 +264,16 @@ def test_training_driver_and_inference_harness_on_gpu(rt, tmp_path):
     assert p['boxes'].shape == (3, 4) and np.all(np.diff(p['relevance']) <= 0)
     pb = inf.predict(m2, [img], q, beam_size=2, num_output_boxes=3)[0]
     assert 0.0 <= pb['answer_prob'] <= 1.0
+    # prediction files (compute_predictions.py): classification vocabulary mask confines the answers, boxes file layout
+    from gpv1_amd import compute_predictions as cp
+    _, vm = cp.create_vocab_mask(m2, classes=('w2', 'w6'))
+    rs = np.random.RandomState(1)
+    batches = [([inf.preprocess_image(inf.resize_image((rs.rand(50, 70, 3) * 255).astype(np.uint8), (64, 96))) for _ in range(2)],
+                (torch.randint(1000, 30000, (2, 5), generator=g).to(DEV), torch.ones(2, 5, dtype=torch.long, device=DEV)),
+                [f'{b}_{k}' for k in range(2)]) for b in range(2)]
+    preds, jpath, bpath = cp.make_predictions(m2, batches, str(tmp_path / 'eval'), 'CocoClassification', vocab_mask=vm)
+    assert sorted(preds) == ['0_0', '0_1', '1_0', '1_1'] and all(set(v['answer'].split()) <= {'w2', 'w6'} for v in preds.values())
+    assert os.path.exists(jpath) and os.path.exists(bpath)
 
 
 def _full_batch(Bf, Vf, tl=6, seed=11):
