@@ -21,7 +21,7 @@ from .ops import W, RT
 from .detr import create_detr, create_detr_roi_head
 from .bert import Bert
 from .vilbert import BertConnectionLayer
-from .transformer import LinearP, LayerNormP, MultiheadAttention
+from .transformer import LinearP, LayerNormP, MultiheadAttention, ffn
 from .criterion import GPVCriterion
 from .misc import AttrDict, NestedTensor
 
@@ -60,8 +60,7 @@ class TextDecoderLayer(nn.Module):
         p = self.p if self.training else 0.0
         tgt = self.norm1(tgt, self.self_attn(tgt, tgt, tgt, B, Tt, Tt, causal=True), p)
         tgt = self.norm2(tgt, self.multihead_attn(tgt, memory, memory, B, Tt, Tm), p)   # no memory padding mask
-        h = self.linear1(tgt, ops.ACT_RELU, p)
-        return self.norm3(tgt, self.linear2(h), p)
+        return self.norm3(tgt, ffn(tgt, self.linear1, self.linear2, p), p)
 
 
 class TextDecoder(nn.Module):

@@ -27,6 +27,11 @@ class LinearP(nn.Module):
         return ops.linear(x, W(self.weight, self.bias), act, drop_p, out_f32)
 
 
+def ffn(x, l1, l2, drop_p):
+    """linear2(dropout(relu(linear1(x)))) of two LinearP modules as one autograd node (ops.FFNFn)"""
+    return ops.ffn(x, W(l1.weight, l1.bias), W(l2.weight, l2.bias), drop_p)
+
+
 class LayerNormP(nn.Module):
     def __init__(self, dim, eps=1e-5):
         super().__init__()
@@ -87,8 +92,7 @@ class TransformerEncoderLayer(nn.Module):
         p = self.p if self.training else 0.0
         qk = ops.add(src, pos)
         src = self.norm1(src, self.self_attn(qk, qk, src, B, S, S, kpm), p)
-        h = self.linear1(src, ops.ACT_RELU, p)
-        return self.norm2(src, self.linear2(h), p)
+        return self.norm2(src, ffn(src, self.linear1, self.linear2, p), p)
 
 
 class TransformerDecoderLayer(nn.Module):
@@ -110,8 +114,7 @@ class TransformerDecoderLayer(nn.Module):
         tgt = self.norm1(tgt, self.self_attn(qk, qk, tgt, B, Q, Q), p)
         a = self.multihead_attn(ops.add(tgt, query_pos), mem_pos, memory, B, Q, S, kpm)
         tgt = self.norm2(tgt, a, p)
-        h = self.linear1(tgt, ops.ACT_RELU, p)
-        return self.norm3(tgt, self.linear2(h), p)
+        return self.norm3(tgt, ffn(tgt, self.linear1, self.linear2, p), p)
 
 
 class TransformerEncoder(nn.Module):
