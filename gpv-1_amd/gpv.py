@@ -21,7 +21,7 @@ from .ops import W, RT
 from .detr import create_detr, create_detr_roi_head
 from .bert import Bert
 from .vilbert import BertConnectionLayer
-from .transformer import LinearP, LayerNormP, MultiheadAttention, ffn
+from .transformer import LinearP, LayerNormP, MultiheadAttention, ffn_block
 from .criterion import GPVCriterion
 from .misc import AttrDict, NestedTensor
 
@@ -60,7 +60,7 @@ class TextDecoderLayer(nn.Module):
         p = self.p if self.training else 0.0
         tgt = self.norm1(tgt, self.self_attn(tgt, tgt, tgt, B, Tt, Tt, causal=True), p)
         tgt = self.norm2(tgt, self.multihead_attn(tgt, memory, memory, B, Tt, Tm), p)   # no memory padding mask
-        return self.norm3(tgt, ffn(tgt, self.linear1, self.linear2, p), p)
+        return ffn_block(tgt, self.linear1, self.linear2, self.norm3, p)
 
 
 class TextDecoder(nn.Module):

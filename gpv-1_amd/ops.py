@@ -199,56 +199,6 @@ class LinearFn(Function):
         return dx, None, None, None, None, None
 
 
-class FFNFn(Function):
-    """y = W2 . dropout(relu(W1 x + b1)) + b2 as ONE autograd node (DETR encoder/decoder layers transformer.py:156-158,
-    226-229, text decoder).  Same two forward GEMMs as linear(linear(x, relu, p)); in backward the ReLU / dropout derivative is
-    applied in the EPILOGUE of the dX = dY W2 GEMM (alpha = 1/(1-p), ReLU mask = the saved hidden activation, which is zero
-    exactly where the unit was dropped or inactive) instead of a separate pass over the [M, 2048] gradient."""
-
-    @staticmethod
-    def forward(ctx, x, w1, w2, drop_p, dummy=None):
-        K, Fh, N = w1.K, w1.N, w2.N
-        x2 = _c(_as_compute(x)).reshape(-1, K)
-        M = x2.shape[0]
-        h = torch.empty(M, Fh, device=x.device, dtype=RT.dtype)
-        seed = RT.next_seed() if drop_p > 0 else 0
-        hip.gemm(x2, w1.lp(), h, M, Fh, K, K, K, Fh, bias=w1.bias_f32(), act=ACT_RELU, drop_p=drop_p, seed=seed)
-        y = torch.empty(M, N, device=x.device, dtype=RT.dtype)
-        hip.gemm(h, w2.lp(), y, M, N, Fh, Fh, Fh, N, bias=w2.bias_f32())
-        ctx.w1, ctx.w2, ctx.drop_p, ctx.xshape = w1, w2, drop_p, x.shape
-        ctx.save_for_backward(x2, h)
-        return y.reshape(*x.shape[:-1], N)
-
-    @staticmethod
-    def backward(ctx, dy):
-        w1, w2 = ctx.w1, ctx.w2
-        x2, h = ctx.saved_tensors
-        K, Fh, N = w1.K, w1.N, w2.N
-        M = x2.shape[0]
-        dy2 = _c(_as_compute(dy)).reshape(M, N)
-        nb2 = w2.bias is not None and w2.bias.requires_grad
-        if w2.weight.requires_grad:
-            hip.gemm(dy2, h, w2.wgrad(), N, Fh, M, N, Fh, Fh, layoutA=hip.TRANS, layoutB=hip.TRANS, accumulate=True,
-                     split_k=_split_k(N, Fh, M), a_rowsum=w2.bgrad() if nb2 else None)
-        elif nb2:
-            hip.colsum(dy2, w2.bgrad(), M, N, N)
-        dz = torch.empty(M, Fh, device=dy2.device, dtype=RT.dtype)
-        hip.gemm(dy2, w2.lp(), dz, M, Fh, N, N, Fh, Fh, layoutB=hip.TRANS, relu_mask=h, ldm=Fh,
-                 alpha=1.0 / (1.0 - ctx.drop_p) if ctx.drop_p > 0 else 1.0)
-        nb1 = w1.bias is not None and w1.bias.requires_grad
-        if w1.weight.requires_grad:
-            hip.gemm(dz, x2, w1.wgrad(), Fh, K, M, Fh, K, K, layoutA=hip.TRANS, layoutB=hip.TRANS, accumulate=True,
-                     split_k=_split_k(Fh, K, M), a_rowsum=w1.bgrad() if nb1 else None)
-        elif nb1:
-            hip.colsum(dz, w1.bgrad(), M, Fh, Fh)
-        dx = None
-        if ctx.needs_input_grad[0]:
-            dx = torch.empty(M, K, device=dz.device, dtype=RT.dtype)
-            hip.gemm(dz, w1.lp(), dx, M, K, Fh, Fh, K, K, layoutB=hip.TRANS)
-            dx = dx.reshape(ctx.xshape)
-        return dx, None, None, None, None
-
-
 _DUMMY = {}
 
 
@@ -267,16 +217,6 @@ def linear(x, w, act=ACT_NONE, drop_p=0.0, out_f32=False):
     if torch.is_grad_enabled() and not x.requires_grad and (w.weight.requires_grad or (w.bias is not None and w.bias.requires_grad)):
         dummy = _dummy(x.device)
     return LinearFn.apply(x, w, act, drop_p, out_f32, dummy)
-
-
-def ffn(x, w1, w2, drop_p=0.0):
-    """linear(linear(x, w1, relu, drop_p), w2) with the activation derivative fused into the backward-data GEMM"""
-    if not torch.is_grad_enabled():
-        return linear(linear(x, w1, ACT_RELU, drop_p), w2)
-    dummy = None
-    if not x.requires_grad and any(q is not None and q.requires_grad for q in (w1.weight, w1.bias, w2.weight, w2.bias)):
-        dummy = _dummy(x.device)
-    return FFNFn.apply(x, w1, w2, drop_p, dummy)
 
 
 # y = a @ b^T with both operands activations (answer head: h x Wc^T)
@@ -350,6 +290,73 @@ class AddLayerNormFn(Function):
         if ctx.has_s:
             dsr = (ds if ds is not None else dx).reshape(ctx.shape)
         return (dxr if ctx.needs_input_grad[0] else None), (dsr if ctx.needs_input_grad[1] else None), None, None, None, None
+
+
+class FFNBlockFn(Function):
+    """out = LayerNorm(x + dropout(W2 . dropout(relu(W1 x + b1)) + b2)): the whole post-norm feed-forward sub-layer
+    (transformer.py:156-160, 226-231) as ONE autograd node.  x has two consumers (FFN input, residual); as separate nodes
+    autograd sums their gradients with an extra elementwise pass -- here the residual gradient from the LayerNorm backward is
+    the `res` operand of the last backward-data GEMM (dx = dz W1 + dx_res), and the ReLU/dropout derivative sits in the epilogue
+    of dz = dy W2: alpha = 1/(1-p), ReLU mask = the saved hidden activation, which is zero exactly where the unit was
+    dropped or inactive (no separate pass over the [M, 2048] gradient)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, w2, gamma, beta, eps, drop_p):
+        K, Fh = w1.K, w1.N
+        x2 = _c(_as_compute(x)).reshape(-1, K)
+        M = x2.shape[0]
+        h = torch.empty(M, Fh, device=x.device, dtype=RT.dtype)
+        seed1 = RT.next_seed() if drop_p > 0 else 0
+        hip.gemm(x2, w1.lp(), h, M, Fh, K, K, K, Fh, bias=w1.bias_f32(), act=ACT_RELU, drop_p=drop_p, seed=seed1)
+        y = torch.empty(M, K, device=x.device, dtype=RT.dtype)
+        hip.gemm(h, w2.lp(), y, M, K, Fh, Fh, Fh, K, bias=w2.bias_f32())
+        out = torch.empty_like(x2)
+        mean = torch.empty(M, device=x.device, dtype=torch.float32)
+        rstd = torch.empty_like(mean)
+        seed2 = RT.next_seed() if drop_p > 0 else 0
+        hip.layernorm_fwd(x2, y, gamma.detach(), beta.detach(), out, mean, rstd, M, K, eps, drop_p, seed2)
+        ctx.w1, ctx.w2, ctx.gamma, ctx.beta, ctx.drop_p, ctx.seed2, ctx.xshape = w1, w2, gamma, beta, drop_p, seed2, x.shape
+        ctx.save_for_backward(x2, h, y, mean, rstd)
+        return out.reshape(x.shape)
+
+    @staticmethod
+    def backward(ctx, dout):
+        w1, w2, gamma, beta = ctx.w1, ctx.w2, ctx.gamma, ctx.beta
+        x2, h, y, mean, rstd = ctx.saved_tensors
+        M, K = x2.shape
+        Fh = w1.N
+        d2 = _c(_as_compute(dout)).reshape(M, K)
+        dx_res = torch.empty_like(x2)
+        ds = torch.empty_like(x2) if ctx.drop_p > 0 else None
+        need_g = gamma.requires_grad
+        hip.layernorm_bwd(d2, x2, y, gamma.detach(), mean, rstd, dx_res, ds, ensure_grad(gamma) if need_g else None,
+                          ensure_grad(beta) if need_g else None, M, K, ctx.drop_p, ctx.seed2)
+        dy2 = ds if ds is not None else dx_res
+        nb2 = w2.bias is not None and w2.bias.requires_grad
+        if w2.weight.requires_grad:
+            hip.gemm(dy2, h, w2.wgrad(), K, Fh, M, K, Fh, Fh, layoutA=hip.TRANS, layoutB=hip.TRANS, accumulate=True,
+                     split_k=_split_k(K, Fh, M), a_rowsum=w2.bgrad() if nb2 else None)
+        elif nb2:
+            hip.colsum(dy2, w2.bgrad(), M, K, K)
+        dz = torch.empty(M, Fh, device=d2.device, dtype=RT.dtype)
+        hip.gemm(dy2, w2.lp(), dz, M, Fh, K, K, Fh, Fh, layoutB=hip.TRANS, relu_mask=h, ldm=Fh,
+                 alpha=1.0 / (1.0 - ctx.drop_p) if ctx.drop_p > 0 else 1.0)
+        nb1 = w1.bias is not None and w1.bias.requires_grad
+        if w1.weight.requires_grad:
+            hip.gemm(dz, x2, w1.wgrad(), Fh, K, M, Fh, K, K, layoutA=hip.TRANS, layoutB=hip.TRANS, accumulate=True,
+                     split_k=_split_k(Fh, K, M), a_rowsum=w1.bgrad() if nb1 else None)
+        elif nb1:
+            hip.colsum(dz, w1.bgrad(), M, Fh, Fh)
+        dx = torch.empty(M, K, device=dz.device, dtype=RT.dtype)
+        hip.gemm(dz, w1.lp(), dx, M, K, Fh, Fh, K, K, layoutB=hip.TRANS, res=dx_res, ldr=K)
+        return dx.reshape(ctx.xshape), None, None, None, None, None, None
+
+
+def ffn_block(x, w1, w2, gamma, beta, eps, drop_p=0.0):
+    """LayerNorm(x + dropout(ffn(x))) -- one node when gradients flow, the plain composition otherwise"""
+    if not (torch.is_grad_enabled() and x.requires_grad):
+        return add_layernorm(x, linear(linear(x, w1, ACT_RELU, drop_p), w2), gamma, beta, eps, drop_p)
+    return FFNBlockFn.apply(x, w1, w2, gamma, beta, eps, drop_p)
 
 
 def add_layernorm(x, s, gamma, beta, eps, drop_p=0.0):

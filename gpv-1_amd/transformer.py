@@ -27,9 +27,9 @@ class LinearP(nn.Module):
         return ops.linear(x, W(self.weight, self.bias), act, drop_p, out_f32)
 
 
-def ffn(x, l1, l2, drop_p):
-    """linear2(dropout(relu(linear1(x)))) of two LinearP modules as one autograd node (ops.FFNFn)"""
-    return ops.ffn(x, W(l1.weight, l1.bias), W(l2.weight, l2.bias), drop_p)
+def ffn_block(x, l1, l2, norm, drop_p):
+    """norm(x + dropout(linear2(dropout(relu(linear1(x)))))) as one autograd node (ops.FFNBlockFn)"""
+    return ops.ffn_block(x, W(l1.weight, l1.bias), W(l2.weight, l2.bias), norm.weight, norm.bias, norm.eps, drop_p)
 
 
 class LayerNormP(nn.Module):
@@ -92,7 +92,7 @@ class TransformerEncoderLayer(nn.Module):
         p = self.p if self.training else 0.0
         qk = ops.add(src, pos)
         src = self.norm1(src, self.self_attn(qk, qk, src, B, S, S, kpm), p)
-        return self.norm2(src, ffn(src, self.linear1, self.linear2, p), p)
+        return ffn_block(src, self.linear1, self.linear2, self.norm2, p)
 
 
 class TransformerDecoderLayer(nn.Module):
@@ -114,7 +114,7 @@ class TransformerDecoderLayer(nn.Module):
         tgt = self.norm1(tgt, self.self_attn(qk, qk, tgt, B, Q, Q), p)
         a = self.multihead_attn(ops.add(tgt, query_pos), mem_pos, memory, B, Q, S, kpm)
         tgt = self.norm2(tgt, a, p)
-        return self.norm3(tgt, ffn(tgt, self.linear1, self.linear2, p), p)
+        return ffn_block(tgt, self.linear1, self.linear2, self.norm3, p)
 
 
 class TransformerEncoder(nn.Module):
