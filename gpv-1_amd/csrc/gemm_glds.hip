@@ -54,7 +54,8 @@ __device__ __forceinline__ void glds_body(const GemmK& p) {
   extern __shared__ __attribute__((aligned(128))) unsigned char smem[];
   __shared__ int s_rowpix[AMODE == OP_CONV ? BM : 1];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform, but only provably so this way: LDS-DMA bases (M0) in SGPRs
   const int wm = wave / WN, wn = wave - wm * WN;
   // XCD-aware tile order (see gemm.hip): contiguous tile range per XCD
   int tile;
@@ -63,7 +64,7 @@ __device__ __forceinline__ void glds_body(const GemmK& p) {
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
     tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
   }
-  int tm = tile / p.tilesN;
+  int tm = __builtin_amdgcn_readfirstlane(tile / p.tilesN);      // (the division is done on the VALU)
   const int tn = tile - tm * p.tilesN;
   if constexpr (AMODE == OP_CONV) {
     if (p.cg.cm && p.cg.cls_rows % BM == 0) {           // cycle the stride-2 dgrad parity classes through the row panels
@@ -81,14 +82,15 @@ __device__ __forceinline__ void glds_body(const GemmK& p) {
   if constexpr (AMODE == OP_CONV) {
     if (p.cg.cm) {
       if (tid < BM) s_rowpix[tid] = conv_row_to_pixel(min(row0 + tid, p.M - 1), p.cg);
-      const int c_lo = row0 / p.cg.cls_rows, c_hi = min(row0 + BM - 1, p.M - 1) / p.cg.cls_rows;
+      const int c_lo = __builtin_amdgcn_readfirstlane(row0 / p.cg.cls_rows);
+      const int c_hi = __builtin_amdgcn_readfirstlane(min(row0 + BM - 1, p.M - 1) / p.cg.cls_rows);
       if (c_lo == c_hi) {
         cm_on = true;
         cm_r0 = ((c_lo >> 1) + p.cg.PH) & 1;
         cm_s0 = ((c_lo & 1) + p.cg.PW) & 1;
         const int nR = (p.cg.KH - cm_r0 + 1) / 2;
         cm_nS = (p.cg.KW - cm_s0 + 1) / 2;
-        cm_cpt = p.cg.Cin / GBK;
+        cm_cpt = __builtin_amdgcn_readfirstlane(p.cg.Cin / GBK);
         nk = nR * cm_nS * cm_cpt;
         if (nk == 0) { cm_empty = true; nk = 1; }       // no tap reaches this class: one all-zero k-tile, dx = res * mask
       }
