@@ -34,14 +34,8 @@ constexpr int ROWB = 128;     // bytes per staged operand row
 constexpr int GBM = 256;
 long g_glds_launches = 0;     // gpv_set_option(GPV_OPT_GLDS_LAUNCHES, .)
 
-__device__ __attribute__((aligned(128))) unsigned char g_zero_line[128];   // device globals are zero-initialised
-
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void glb_void_t;
-
-__device__ __forceinline__ void glds16(const void* g, unsigned char* l) {
-  __builtin_amdgcn_global_load_lds((glb_void_t*)g, (lds_void_t*)l, 16, 0, 0);
-}
 
 template <int AMODE, int BM, int BN, typename TOut>
 __device__ __forceinline__ void glds_body(const GemmK& p) {
@@ -97,13 +91,20 @@ __device__ __forceinline__ void glds_body(const GemmK& p) {
     }
   }
   // ---- loader state: this lane's rows and its (swizzled) 16-byte chunk ----
+  // Operands are fetched with buffer_load_dwordx4 ... lds through one descriptor per operand: the per-lane part of an address
+  // is a 32-bit byte offset fixed for the whole tile (conv: for a whole tap), the k-tile offset rides in the scalar soffset,
+  // and an out-of-range voffset (padding tap, empty parity class) makes the hardware deliver zeros -- no 64-bit address
+  // arithmetic and no zero-line select per load in the loop (PMC: the loop issued 4.9 VALU instructions per MFMA).
+  constexpr int OOB = 0x7ffffff0;                      // == num_records: voffset + 16 > num_records -> zeros
   const int lrow = lane >> 3;
   const int lchunk = (lane & 7) ^ lrow;                 // logical chunk fetched into slot (lane & 7) of row lrow
-  const bf16* a_ptr[AI];
+  int a_vo[AI];                                        // plain: row * lda bytes ; conv: image base bytes
   int a_oh[AI], a_ow[AI];
-  const bf16* b_ptr[BI];
+  int b_vo[BI];
   const bf16* Ab = reinterpret_cast<const bf16*>(p.A) + (int64_t)batch * p.sA;
   const bf16* Bb = reinterpret_cast<const bf16*>(p.B) + (int64_t)batch * p.sB;
+  const auto rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(Ab), (short)0, OOB, 0x00020000);
+  const auto rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(Bb), (short)0, OOB, 0x00020000);
 #pragma unroll
   for (int j = 0; j < AI; ++j) {
     const int r = wave * (AI * 8) + j * 8 + lrow;
@@ -114,27 +115,29 @@ __device__ __forceinline__ void glds_body(const GemmK& p) {
       const int rem = pix - b * (p.cg.OH * p.cg.OW);
       a_oh[j] = rem / p.cg.OW;
       a_ow[j] = rem - a_oh[j] * p.cg.OW;
-      a_ptr[j] = Ab + (int64_t)b * p.cg.IH * p.cg.IW * p.cg.Cs + lchunk * 8;
+      a_vo[j] = (b * p.cg.IH * p.cg.IW * p.cg.Cs + lchunk * 8) * 2;
     } else {
       a_oh[j] = a_ow[j] = 0;
-      a_ptr[j] = Ab + (int64_t)m * p.lda + lchunk * 8;
+      a_vo[j] = (m * (int)p.lda + lchunk * 8) * 2;
     }
   }
+  const bool bz = (AMODE == OP_CONV) && cm_empty;
 #pragma unroll
   for (int j = 0; j < BI; ++j) {
     const int r = wave * (BI * 8) + j * 8 + lrow;
     const int n = min(col0 + r, p.N - 1);
-    b_ptr[j] = Bb + (int64_t)n * p.ldb + lchunk * 8;
+    b_vo[j] = bz ? OOB : (n * (int)p.ldb + lchunk * 8) * 2;
   }
-  const bf16* zero_src = reinterpret_cast<const bf16*>(g_zero_line) + (lane & 7) * 8;
+  auto bload = [&](const decltype(rsA)& rs, int voff, int soff, unsigned char* l) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)l, 16, voff, soff, 0, 0);
+  };
 
-  // conv gather state: k-tiles walk (tap, channel block) with the channel block innermost, so the per-row source address and
-  // its bounds check are recomputed once per TAP (Cin/64 k-tiles), not per k-tile; the loop itself only adds the channel offset.
+  // conv gather state: k-tiles walk (tap, channel block) with the channel block innermost, so the per-row source offset and
+  // its bounds check are recomputed once per TAP (Cin/64 k-tiles), not per k-tile; the loop itself only changes soffset.
   int it_c0 = 0, it_tr = cm_on ? cm_r0 : 0, it_ts = cm_on ? cm_s0 : 0;
-  const bf16* tap_src[AI];
-  unsigned tap_ok = 0;
+  int tap_off[AI];
 #pragma unroll
-  for (int j = 0; j < AI; ++j) tap_src[j] = a_ptr[j];
+  for (int j = 0; j < AI; ++j) tap_off[j] = OOB;
 
   auto issue = [&](int kt, int stage) {
     unsigned char* sa = smem + stage * STAGE + wave * (AI * 1024);
@@ -143,7 +146,6 @@ __device__ __forceinline__ void glds_body(const GemmK& p) {
     if constexpr (AMODE == OP_CONV) {
       const ConvGeom& g = p.cg;
       if (it_c0 == 0) {                              // new tap (uniform branch)
-        tap_ok = 0;
 #pragma unroll
         for (int j = 0; j < AI; ++j) {
           int ih, iw;
@@ -157,13 +159,12 @@ __device__ __forceinline__ void glds_body(const GemmK& p) {
             ih = a_oh[j] * g.SH + it_tr - g.PH; iw = a_ow[j] * g.SW + it_ts - g.PW;
             ok = ok && ih >= 0 && iw >= 0 && ih < g.IH && iw < g.IW;
           }
-          tap_src[j] = a_ptr[j] + (int64_t)(ih * g.IW + iw) * g.Cs;
-          tap_ok |= (ok ? 1u : 0u) << j;
+          tap_off[j] = ok ? a_vo[j] + (ih * g.IW + iw) * g.Cs * 2 : OOB;
         }
       }
       k0 = (it_tr * g.KW + it_ts) * g.Cin + it_c0;
 #pragma unroll
-      for (int j = 0; j < AI; ++j) glds16(((tap_ok >> j) & 1u) ? tap_src[j] + it_c0 : zero_src, sa + j * 1024);
+      for (int j = 0; j < AI; ++j) bload(rsA, tap_off[j], it_c0 * 2, sa + j * 1024);
       it_c0 += GBK;
       if (it_c0 == g.Cin) {                          // next tap; a class-uniform stride-2 dgrad tile steps by 2
         it_c0 = 0;
@@ -173,11 +174,10 @@ __device__ __forceinline__ void glds_body(const GemmK& p) {
     } else {
       k0 = kt * GBK;
 #pragma unroll
-      for (int j = 0; j < AI; ++j) glds16(a_ptr[j] + k0, sa + j * 1024);
+      for (int j = 0; j < AI; ++j) bload(rsA, a_vo[j], k0 * 2, sa + j * 1024);
     }
-    const bool bz = (AMODE == OP_CONV) && cm_empty;
 #pragma unroll
-    for (int j = 0; j < BI; ++j) glds16(bz ? zero_src : b_ptr[j] + k0, sb + j * 1024);
+    for (int j = 0; j < BI; ++j) bload(rsB, b_vo[j], k0 * 2, sb + j * 1024);
   };
 
   f32x4 acc[FM][FN];
@@ -355,10 +355,14 @@ int glds_try_launch(const GemmK& k, int amode, int dtype_in, int dtype_out, int 
   if (k.accumulate || k.split_k > 1) return -1;
   if (k.K % GBK != 0 || k.K < GBK || k.N <= 64) return -1;
   if (!al16(k.A) || !al16(k.B) || k.ldb % 8 != 0 || (batch > 1 && (k.sA % 8 != 0 || k.sB % 8 != 0))) return -1;
+  // 32-bit byte offsets into each operand (one buffer descriptor per operand and batch element)
+  const int64_t lim = 0x7ffffff0ll / 2;
+  if ((int64_t)k.N * k.ldb >= lim) return -1;
   if (amode == OP_CONV) {
+    if ((int64_t)k.cg.IH * k.cg.IW * k.cg.Cs * ((int64_t)k.M / ((int64_t)k.cg.OH * k.cg.OW) + 1) >= lim) return -1;
     if (k.cg.Cin % GBK != 0 || k.cg.Cs % 8 != 0) return -1;
   } else if (amode == OP_PLAIN) {
-    if (k.lda % 8 != 0) return -1;
+    if (k.lda % 8 != 0 || (int64_t)k.M * k.lda >= lim) return -1;
   } else {
     return -1;
   }
