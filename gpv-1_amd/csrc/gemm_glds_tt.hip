@@ -28,14 +28,8 @@ constexpr int ROWBYTES = 256;                      // one pixel row of a 128-col
 constexpr int OP_BYTES = TBK * ROWBYTES;           // 16 KB
 constexpr int TSTAGE = 2 * OP_BYTES;
 
-__device__ __attribute__((aligned(256))) unsigned char g_zero_row[256];   // zero-initialised
-
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void glb_void_t;
-
-__device__ __forceinline__ void glds16(const void* g, unsigned char* l) {
-  __builtin_amdgcn_global_load_lds((glb_void_t*)g, (lds_void_t*)l, 16, 0, 0);
-}
 
 __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* p) {
   typedef short __attribute__((ext_vector_type(4))) s16x4;
@@ -91,35 +85,36 @@ __device__ __forceinline__ void glds_tt_body(const GemmK& p) {
   }
 
   // ---- loader: instruction j of this wave covers rows wave*16 + j*4 + (lane >> 4), slot lane & 15 ----
+  // buffer_load_dwordx4 ... lds through one descriptor per operand: per-lane 32-bit byte offsets fixed for the whole split, the
+  // k-tile offset in the scalar soffset, an out-of-range voffset (tap outside the input, row beyond the last pixel) = zeros.
+  constexpr int OOB = 0x7ffffff0;                                // == num_records
   const int lrow = lane >> 4;
   const int chunk01 = (lane & 15) ^ (2 * lrow);                  // logical 16-B chunk for j = 0, 1; j = 2, 3: ^ 8
-  const bf16* Xp = reinterpret_cast<const bf16*>(p.B) + c0;
-  const bf16* a_ptr[4];
-  const bf16* b_ptr[CONV ? 1 : 4];
-  {
-    const bf16* Ap = reinterpret_cast<const bf16*>(p.A) + row0;
-    const bf16* Bp = reinterpret_cast<const bf16*>(p.B) + col0;
+  const auto rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), (short)0, OOB, 0x00020000);
+  const auto rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), (short)0, OOB, 0x00020000);
+  int a_vo[4], b_vo[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int r = wave * 16 + j * 4 + lrow;
-      a_ptr[j] = Ap + (int64_t)(kt0 * TBK + r) * p.lda + (chunk01 ^ ((j >> 1) * 8)) * 8;
-      if constexpr (!CONV) b_ptr[j] = Bp + (int64_t)(kt0 * TBK + r) * p.ldb + (chunk01 ^ ((j >> 1) * 8)) * 8;
-    }
+  for (int j = 0; j < 4; ++j) {
+    const int r = wave * 16 + j * 4 + lrow;
+    const int ch = chunk01 ^ ((j >> 1) * 8);
+    a_vo[j] = (r * (int)p.lda + row0 + ch * 8) * 2;
+    b_vo[j] = CONV ? (c0 + ch * 8) * 2 : (r * (int)p.ldb + col0 + ch * 8) * 2;
   }
-  const int64_t a_step = (int64_t)TBK * p.lda, b_step = (int64_t)TBK * p.ldb;
-  const bf16* zero_src = reinterpret_cast<const bf16*>(g_zero_row) + (lane & 15) * 8;
+  auto bload = [&](const decltype(rsA)& rs, int voff, int soff, unsigned char* l) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)l, 16, voff, soff, 0, 0);
+  };
 
   auto issue = [&](int kt, int stage) {
     unsigned char* sa = smem + stage * TSTAGE + wave * (4 * 1024);
     unsigned char* sb = sa + OP_BYTES;
     const bool full = (kt + 1) * TBK <= p.K;                     // uniform
     if constexpr (CONV) {
-      // my row's gather offset (elements from Xp), or -1 when the tap falls outside the input / beyond the last pixel
+      // my row's gather offset (bytes into x), or OOB when the tap falls outside the input / beyond the last pixel
       int off;
       {
         const int ih = px_oh * g.SH + dh, iw = px_ow * g.SW + dw;
         const bool ok = (unsigned)ih < (unsigned)g.IH && (unsigned)iw < (unsigned)g.IW && kt * TBK + lane < p.K;
-        off = ok ? ((px_b * g.IH + ih) * g.IW + iw) * g.Cs : -1;
+        off = ok ? ((px_b * g.IH + ih) * g.IW + iw) * g.Cs * 2 : OOB;
         px_ow += adv_r;
         const int c = px_ow >= g.OW ? 1 : 0;
         px_ow -= c ? g.OW : 0;
@@ -129,25 +124,19 @@ __device__ __forceinline__ void glds_tt_body(const GemmK& p) {
         px_b += c2;
       }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int r = wave * 16 + j * 4 + lrow;
-        const int o = __shfl(off, r);
-        const bf16* src = Xp + o + (chunk01 ^ ((j >> 1) * 8)) * 8;
-        glds16(o >= 0 ? src : zero_src, sb + j * 1024);
-      }
+      for (int j = 0; j < 4; ++j)                                  // (OOB + a chunk offset is still out of range)
+        bload(rsB, __shfl(off, wave * 16 + j * 4 + lrow) + b_vo[j], 0, sb + j * 1024);
     } else {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const bool ok = full || kt * TBK + wave * 16 + j * 4 + lrow < p.K;
-        glds16(ok ? b_ptr[j] : zero_src, sb + j * 1024);
-        b_ptr[j] += b_step;
+        bload(rsB, ok ? b_vo[j] : OOB, kt * TBK * (int)p.ldb * 2, sb + j * 1024);
       }
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const bool ok = full || kt * TBK + wave * 16 + j * 4 + lrow < p.K;
-      glds16(ok ? a_ptr[j] : zero_src, sa + j * 1024);
-      a_ptr[j] += a_step;
+      bload(rsA, ok ? a_vo[j] : OOB, kt * TBK * (int)p.lda * 2, sa + j * 1024);
     }
   };
 
@@ -288,7 +277,8 @@ int glds_wgrad_try_launch(const GemmK& k, int dtype_in, int dtype_out, hipStream
   const ConvGeom& g = k.cg;
   if (k.M % TBM != 0 || g.Cin % TBN != 0 || k.N % TBN != 0) return -1;
   if (g.Cs % 8 != 0 || k.lda % 8 != 0 || !al16t(k.A) || !al16t(k.B)) return -1;
-  if (TBK / g.OW + 2 > g.OH || (int64_t)g.IH * g.IW * g.Cs * (k.K / (g.OH * g.OW)) >= (1ll << 31)) return -1;
+  if (TBK / g.OW + 2 > g.OH || (int64_t)g.IH * g.IW * g.Cs * (k.K / (g.OH * g.OW)) >= (1ll << 30) ||
+      (int64_t)k.K * k.lda >= (1ll << 30)) return -1;
   if (!k.accumulate || k.ws_base == nullptr || !al16t(k.C) || k.ldc % 4 != 0) return -1;
   static bool attr_done = false;
   return launch_tt(glds_wgrad_kernel, k, attr_done, st);
@@ -299,6 +289,7 @@ int glds_wgrad_try_launch(const GemmK& k, int dtype_in, int dtype_out, hipStream
 int glds_tt_try_launch(const GemmK& k, int dtype_in, int dtype_out, int batch, hipStream_t st) {
   if (g_wgrad_mode == 0 || dtype_in != GPV_BF16 || dtype_out != GPV_F32 || batch != 1) return -1;
   if (k.M % TBM != 0 || k.N % TBN != 0 || k.K < 8 * TBK) return -1;
+  if ((int64_t)k.K * k.lda >= (1ll << 30) || (int64_t)k.K * k.ldb >= (1ll << 30)) return -1;
   // measured on every linear weight-gradient shape of the step (tools/bench_step_gemms.py, GPV_GLDS_WGRAD=0 vs 2): it wins
   // once there is enough work to fill the chip -- 768x3072 / 3072x768 over 3200 rows 52 -> 35 us, 1536x768 36 -> 26 us,
   // 2048x256 over 9600 rows 33 -> 27 us -- and loses on the 4..36-tile gradients of short reductions (skinny_tt's territory)
