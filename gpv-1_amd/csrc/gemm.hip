@@ -95,14 +95,29 @@ template <typename T, int ROWS, int MODE, bool VEC>
 struct KStage {
   static constexpr int NIT = ROWS / 64;
   struct Buf { Raw8<T> raw[NIT]; bool okf[NIT]; };
+  // bf16 16-byte path of the plain operand: buffer loads -- the per-lane byte offset is fixed for the tile (row * ld + slot),
+  // the k-tile offset rides in the scalar soffset, rows beyond the operand get an out-of-range offset = hardware zeros
+  // (no 64-bit address add, no safe-address select per load, no zero-masking pass before the LDS write)
+  static constexpr bool BUF = VEC && MODE == OP_PLAIN && sizeof(T) == 2;
+  static constexpr int OOB = 0x7ffffff0;
   const T* base[NIT];
   const T* safe;
   int oh[NIT], ow[NIT];
   bool rowok[NIT];
+  __amdgpu_buffer_rsrc_t rs;
+  int vo[NIT];
 
   __device__ __forceinline__ void init(const T* ptr, int64_t ld, int row0, int nrows, int k_begin, const ConvGeom& g) {
     const int tid = threadIdx.x;
     safe = ptr;
+    if constexpr (BUF) {
+      rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(ptr), (short)0, OOB, 0x00020000);
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int row = (tid + it * 256) >> 2, slot = (tid + it * 256) & 3;
+        vo[it] = row0 + row < nrows ? ((row0 + row) * (int)ld + slot * 8) * 2 : OOB;
+      }
+    }
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       int row = (tid + it * 256) >> 2;
@@ -124,6 +139,18 @@ struct KStage {
   __device__ __forceinline__ void load(int k0, int K, const ConvGeom& g, Buf& bf) {
     Raw8<T>(&raw)[NIT] = bf.raw; bool(&okf)[NIT] = bf.okf;
     const int tid = threadIdx.x;
+    if constexpr (BUF) {
+      typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+      const bool full = k0 + BK <= K;                      // uniform; K % 8 == 0 or finite padding (host): whole chunks
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int slot = (tid + it * 256) & 3;
+        const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, (full || k0 + slot * 8 < K) ? vo[it] : OOB, k0 * 2, 0);
+        raw[it].w[0] = t[0]; raw[it].w[1] = t[1]; raw[it].w[2] = t[2]; raw[it].w[3] = t[3];
+        okf[it] = true;
+      }
+      return;
+    }
     int tr = 0, ts = 0, c0 = k0;
     if (MODE == OP_CONV) {
       int tap = k0 / g.Cin;
@@ -186,6 +213,10 @@ struct TStage {
   static constexpr int NIT = (BK * CHK) / 256;    // chunks per thread
   static constexpr int PITCH = COLS + 16;         // elements; (PITCH/2) % 64 in {8, 40}: 8 rows hit distinct bank octets
   struct Buf { Raw8<T> raw[NIT]; bool okf[NIT]; };
+  static constexpr bool BUF = VEC && MODE == OP_PLAIN && sizeof(T) == 2;    // see KStage
+  static constexpr int OOB = 0x7ffffff0;
+  __amdgpu_buffer_rsrc_t rs;
+  int vo[NIT];
   const T* ptr; int64_t ld; int col0, ncols;
   int tap_r, tap_s, c0;
   int pb[NIT], poh[NIT], pow_[NIT];      // CONVT: (batch, oh, ow) of this thread's reduction rows, advanced per k-tile
@@ -196,6 +227,15 @@ struct TStage {
     ptr = p; ld = ld_; col0 = col0_; ncols = ncols_;
     tap_r = tap_s = c0 = 0;
     do_sum = false;
+    if constexpr (BUF) {
+      rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(p), (short)0, OOB, 0x00020000);
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int idx = threadIdx.x + it * 256;
+        const int kr = idx / CHK, ch = idx - kr * CHK;
+        vo[it] = col0 + ch * 8 < ncols ? (kr * (int)ld + col0 + ch * 8) * 2 : OOB;
+      }
+    }
     if constexpr (SUM) {
 #pragma unroll
       for (int it = 0; it < NIT; ++it)
@@ -219,6 +259,19 @@ struct TStage {
   }
   __device__ __forceinline__ void load(int k0, int K, const ConvGeom& g, Buf& bf) {
     Raw8<T>(&raw)[NIT] = bf.raw; bool(&okf)[NIT] = bf.okf;
+    if constexpr (BUF) {
+      typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+      const bool full = k0 + BK <= K;                      // uniform
+      const int soff = k0 * (int)ld * 2;
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int kr = (threadIdx.x + it * 256) / CHK;
+        const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, (full || k0 + kr < K) ? vo[it] : OOB, soff, 0);
+        raw[it].w[0] = t[0]; raw[it].w[1] = t[1]; raw[it].w[2] = t[2]; raw[it].w[3] = t[3];
+        okf[it] = true;
+      }
+      return;
+    }
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int idx = threadIdx.x + it * 256;
@@ -824,6 +877,11 @@ extern "C" int gpv_gemm(const gpv_gemm_args* a, void* stream) {
   };
   k.vecA = vec_ok(a->A, a->lda, a->sA, a->layoutA, a->M);
   k.vecB = vec_ok(a->B, a->ldb, a->sB, a->layoutB, a->N);
+  {   // the 16-byte path addresses an operand (one batch element) with 32-bit byte offsets
+    const int64_t lim = 0x7ffffff0ll / esz;
+    if ((int64_t)(a->layoutA == GPV_KMAJOR ? a->M : a->K) * a->lda >= lim) k.vecA = 0;
+    if ((int64_t)(a->layoutB == GPV_KMAJOR ? a->N : a->K) * a->ldb >= lim) k.vecB = 0;
+  }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int la = a->layoutA, lb = a->layoutB;
   if (la == GPV_KMAJOR && lb == GPV_KMAJOR) {
@@ -886,7 +944,7 @@ extern "C" int gpv_conv2d(const gpv_conv_args* a, void* stream) {
       k.lda = a->Cs;
       k.cg = ConvGeom{};
       k.conv1x1 = 1;
-      k.vecA = aligned16(a->x) && (a->Cs % vecel == 0) ? 1 : 0;
+      k.vecA = aligned16(a->x) && (a->Cs % vecel == 0) && (int64_t)k.M * a->Cs * esz < 0x7ffffff0ll ? 1 : 0;
       const int g = glds_try_launch(k, OP_PLAIN, a->dtype_in, a->dtype_out, 1, st);
       if (g >= 0) return g;
       return launch_dtype<OP_PLAIN, OP_PLAIN>(k, 1, a->dtype_in, a->dtype_out, st);
