@@ -49,33 +49,36 @@ __global__ __launch_bounds__(256) void skinny_kernel(GemmK p) {
 
   // loader: 64 rows x 16 chunks of 16 B per operand = 1024 chunks -> 4 per thread (same chunk column, rows +16)
   const int lc = tid & 15, lr = tid >> 4;
-  const bf16* ap[4];
-  const bf16* bp[4];
+  // operands through buffer loads: per-thread 32-bit byte offsets fixed for the tile, the k-step offset in the scalar soffset,
+  // an out-of-range offset (reduction tail, columns beyond N) = hardware zeros -- no 64-bit address add, no safe-address
+  // select and no zeroing selects per load (this loader issued ~64 VALU instructions per 16 MFMAs)
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  constexpr int OOB = 0x7ffffff0;
+  const auto rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(A), (short)0, OOB, 0x00020000);
+  const auto rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(B), (short)0, OOB, 0x00020000);
+  int avo[4], bvo[4];
   // reduction-major B (BT): tile rows are reduction indices, a row is 64 output columns = 8 chunks -> thread (row tr + 32 i, chunk tc)
   const int tc = tid & 7, tr = tid >> 3;
   const bool bcol_ok = col0 + tc * 8 < p.N;            // N % 8 == 0 (host)
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    ap[i] = A + (int64_t)min(row0 + lr + 16 * i, p.M - 1) * p.lda + lc * 8;
-    if constexpr (BT) bp[i] = B + (int64_t)(tr + 32 * i) * p.ldb + (bcol_ok ? col0 + tc * 8 : 0);
-    else bp[i] = B + (int64_t)min(col0 + lr + 16 * i, p.N - 1) * p.ldb + lc * 8;
+    avo[i] = (min(row0 + lr + 16 * i, p.M - 1) * (int)p.lda + lc * 8) * 2;
+    if constexpr (BT) bvo[i] = bcol_ok ? ((tr + 32 * i) * (int)p.ldb + col0 + tc * 8) * 2 : OOB;
+    else bvo[i] = (min(col0 + lr + 16 * i, p.N - 1) * (int)p.ldb + lc * 8) * 2;
   }
   uint4 ra[4], rb[4];
+  auto bl = [&](const decltype(rsA)& rs, int vo, int so) {
+    const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, so, 0);
+    return make_uint4(t[0], t[1], t[2], t[3]);
+  };
   auto load = [&](int kt) {
-    const int k = kt * SBK + lc * 8;
-    const bool ok = k < p.K;                           // K % 8 == 0 (host): a chunk is entirely inside or outside
+    const bool full = (kt + 1) * SBK <= p.K;           // uniform
+    const bool ok = full || kt * SBK + lc * 8 < p.K;   // K % 8 == 0 (host): a chunk is entirely inside or outside
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      ra[i] = *reinterpret_cast<const uint4*>(ok ? ap[i] + kt * SBK : ap[i]);
-      if (!ok) ra[i] = make_uint4(0, 0, 0, 0);
-      if constexpr (BT) {
-        const bool okb = bcol_ok && kt * SBK + tr + 32 * i < p.K;
-        rb[i] = *reinterpret_cast<const uint4*>(okb ? bp[i] + (int64_t)kt * SBK * p.ldb : B);
-        if (!okb) rb[i] = make_uint4(0, 0, 0, 0);
-      } else {
-        rb[i] = *reinterpret_cast<const uint4*>(ok ? bp[i] + kt * SBK : bp[i]);
-        if (!ok) rb[i] = make_uint4(0, 0, 0, 0);
-      }
+      ra[i] = bl(rsA, ok ? avo[i] : OOB, kt * SBK * 2);
+      if constexpr (BT) rb[i] = bl(rsB, (full || kt * SBK + tr + 32 * i < p.K) ? bvo[i] : OOB, kt * SBK * (int)p.ldb * 2);
+      else rb[i] = bl(rsB, ok ? bvo[i] : OOB, kt * SBK * 2);
     }
   };
   auto store = [&](int stage) {
@@ -243,22 +246,31 @@ __global__ __launch_bounds__(256) void skinny_tt_kernel(GemmK p) {
   const int kt0 = blockIdx.y * p.kt_per_split, kt1 = min(nk_total, kt0 + p.kt_per_split);
   const int tc = tid & 7, tr = tid >> 3;
   const bool a_ok = row0 + tc * 8 < p.M, b_ok = col0 + tc * 8 < p.N;      // M % 8 == 0, N % 8 == 0 (host)
-  const bf16* ap = A + (a_ok ? row0 + tc * 8 : 0);
-  const bf16* bp = B + (b_ok ? col0 + tc * 8 : 0);
+  // buffer loads (see skinny_kernel): fixed per-thread offsets, the k-step offset in soffset, out-of-range = zeros
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  constexpr int OOB = 0x7ffffff0;
+  const auto rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(A), (short)0, OOB, 0x00020000);
+  const auto rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(B), (short)0, OOB, 0x00020000);
+  int avo[4], bvo[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    avo[i] = a_ok ? ((tr + 32 * i) * (int)p.lda + row0 + tc * 8) * 2 : OOB;
+    bvo[i] = b_ok ? ((tr + 32 * i) * (int)p.ldb + col0 + tc * 8) * 2 : OOB;
+  }
   const bool do_sum = p.a_rowsum != nullptr && tn == 0;
   float csum[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) csum[e] = 0.f;
   uint4 ra[4], rb[4];
   auto load = [&](int kt) {
+    const bool full = (kt + 1) * SBK <= p.K;           // uniform
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int64_t k = (int64_t)kt * SBK + tr + 32 * i;
-      const bool ok = k < p.K;
-      ra[i] = *reinterpret_cast<const uint4*>(ok && a_ok ? ap + k * p.lda : A);
-      rb[i] = *reinterpret_cast<const uint4*>(ok && b_ok ? bp + k * p.ldb : B);
-      if (!(ok && a_ok)) ra[i] = make_uint4(0, 0, 0, 0);
-      if (!(ok && b_ok)) rb[i] = make_uint4(0, 0, 0, 0);
+      const bool ok = full || kt * SBK + tr + 32 * i < p.K;
+      const u32x4 ta = __builtin_amdgcn_raw_buffer_load_b128(rsA, ok ? avo[i] : OOB, kt * SBK * (int)p.lda * 2, 0);
+      const u32x4 tb = __builtin_amdgcn_raw_buffer_load_b128(rsB, ok ? bvo[i] : OOB, kt * SBK * (int)p.ldb * 2, 0);
+      ra[i] = make_uint4(ta[0], ta[1], ta[2], ta[3]);
+      rb[i] = make_uint4(tb[0], tb[1], tb[2], tb[3]);
     }
   };
   auto store = [&](int stage) {
@@ -348,6 +360,10 @@ int skinny_try_launch(const GemmK& k, int b_trans, int dtype_in, int dtype_out, 
   if (g_skinny_mode == 0 || dtype_in != GPV_BF16 || batch != 1 || k.accumulate || k.split_k > 1) return -1;
   if (k.K % 8 != 0 || k.lda % 8 != 0 || k.ldb % 8 != 0 || !al16s(k.A) || !al16s(k.B)) return -1;
   if (b_trans && k.N % 8 != 0) return -1;
+  {   // 32-bit byte offsets into each operand
+    const int64_t lim = 0x7ffffff0ll / 2;
+    if ((int64_t)k.M * k.lda >= lim || (int64_t)(b_trans ? k.K : k.N) * k.ldb >= lim) return -1;
+  }
   if (g_skinny_mode == 1) {
     // measured on every forward GEMM shape of the step (tools/bench_step_gemms.py, SK=0 vs 2): it wins whenever the
     // 64x64 tiles cannot fill the chip (<= ~1.4 per CU), and up to 2.5 per CU when the reduction is long
@@ -365,6 +381,7 @@ int skinny_tt_try_launch(const GemmK& k, int dtype_in, int dtype_out, int batch,
   if (g_skinny_mode == 0 || dtype_in != GPV_BF16 || dtype_out != GPV_F32 || batch != 1 || !k.accumulate) return -1;
   if (k.M % 8 != 0 || k.N % 8 != 0 || k.lda % 8 != 0 || k.ldb % 8 != 0 || k.ldc % 4 != 0) return -1;
   if (!al16s(k.A) || !al16s(k.B) || !al16s(k.C) || k.res || k.mask || k.bias || k.act || k.dthresh) return -1;
+  if ((int64_t)k.K * k.lda >= 0x7ffffff0ll / 2 || (int64_t)k.K * k.ldb >= 0x7ffffff0ll / 2) return -1;   // 32-bit byte offsets
   const int64_t tiles = (int64_t)((k.M + SBM - 1) / SBM) * ((k.N + SBN - 1) / SBN);
   const int nk = (k.K + SBK - 1) / SBK;
   if (g_skinny_mode == 1 && (tiles > 256 || nk < 4)) return -1;
