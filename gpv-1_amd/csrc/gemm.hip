@@ -816,8 +816,9 @@ int launch_tiles(const GemmK& k, int batch, hipStream_t st) {
   static const int force = [] { const char* e = getenv("GPV_FORCE_TILE"); return e ? atoi(e) : 0; }();   // tuning only
   int cfg;   // 0: 128x128, 1: 128x64, 2: 64x64
   if (force) cfg = force - 1;
-  else if (k.K <= 256) cfg = (k.N >= 1024 && t128 >= 384) ? 0 : 2;   // <= 8 k-tiles: HBM/latency bound, 64x64 keeps more bytes in flight
-                                                                      // (tools/bench_c3.py); wide outputs amortise the A tile better at 128x128
+  else if (k.K <= 256) cfg = (k.N >= 1024 && t128 >= 384 && !k.conv1x1) ? 0 : 2;   // <= 8 k-tiles: HBM/latency bound, 64x64 keeps more bytes in flight
+                                                                      // (tools/bench_c3.py); the wide Linear outputs (FFN expansion) stay at 128x128, the
+                                                                      // 1x1 convs since the buffer-load loaders do not: layer3 conv3 66 -> 61, conv1 dgrad 78 -> 65 us
   else if (k.N <= 64 && t12864 >= 384) cfg = 1;                       // N = 64 (layer1): 128x64, measured 100 vs 105 / 144 vs 151 us
   else if (k.N > 64 && t128 >= 384) cfg = 0;
   else if (t12864 >= 384) cfg = 1;
