@@ -79,6 +79,14 @@ def test_gemm_trans_layouts_and_splitk(dtype):
     Cm = torch.empty(M, N, device=DEV, dtype=dtype)
     h.gemm(A, Bm, Cm, M, N, K, 320, N, N, layoutB=h.TRANS)
     assert rel(Cm, A[:, :K].float() @ Bm.float()) < TOL[dtype]
+    # same with the caller's promise that the row padding [K, 320) is finite (zero): 16-byte load path (GPV_GEMM_KPAD_FINITE),
+    # batched like RoI pooling; the padding columns and the rows k >= K of the other operand must not leak into the result
+    Ab = A.unsqueeze(0).repeat(2, 1, 1).contiguous()
+    Bb = torch.stack([Bm, rnd(K, N, dtype=dtype, seed=15)]).contiguous()
+    Cb = torch.empty(2, M, N, device=DEV, dtype=dtype)
+    h.gemm(Ab, Bb, Cb, M, N, K, 320, N, N, layoutB=h.TRANS, batch=2, sA=M * 320, sB=K * N, sC=M * N, kpad_finite=True)
+    assert rel(Cb, Ab[:, :, :K].float() @ Bb.float()) < TOL[dtype]
+    assert torch.equal(Cb[0], Cm) or rel(Cb[0], Cm.float()) < 1e-6
     # (TRANS, TRANS) wgrad form: dW[N,K] += dY[Mr,N]^T X[Mr,K], split-K atomics into fp32
     for (Mr, Nn, Kk, split) in [(9600, 256, 2048, 8), (3200, 768, 768, 1), (777, 72, 136, 3), (192, 2304, 768, 4)]:
         dY, X = rnd(Mr, Nn, dtype=dtype, seed=11), rnd(Mr, Kk, dtype=dtype, seed=12)
