@@ -888,6 +888,8 @@ extern "C" int gpv_gemm(const gpv_gemm_args* a, void* stream) {
   if (la == GPV_KMAJOR && lb == GPV_KMAJOR) {
     const int sk = skinny_try_launch(k, 0, a->dtype_in, a->dtype_out, a->batch, st);             // few tiles, long reduction (BERT, text decoder)
     if (sk >= 0) return sk;
+    const int pp = pipe_try_launch(k, OP_PLAIN, a->dtype_in, a->dtype_out, a->batch, st);     // three-stage pipelined direct-to-LDS kernel
+    if (pp >= 0) return pp;
     const int g = glds_try_launch(k, OP_PLAIN, a->dtype_in, a->dtype_out, a->batch, st);      // 8-wave direct-to-LDS kernel when it qualifies
     if (g >= 0) return g;
     return launch_dtype<OP_PLAIN, OP_PLAIN>(k, a->batch, a->dtype_in, a->dtype_out, st);
@@ -946,11 +948,15 @@ extern "C" int gpv_conv2d(const gpv_conv_args* a, void* stream) {
       k.cg = ConvGeom{};
       k.conv1x1 = 1;
       k.vecA = aligned16(a->x) && (a->Cs % vecel == 0) && (int64_t)k.M * a->Cs * esz < 0x7ffffff0ll ? 1 : 0;
+      const int pp = pipe_try_launch(k, OP_PLAIN, a->dtype_in, a->dtype_out, 1, st);
+      if (pp >= 0) return pp;
       const int g = glds_try_launch(k, OP_PLAIN, a->dtype_in, a->dtype_out, 1, st);
       if (g >= 0) return g;
       return launch_dtype<OP_PLAIN, OP_PLAIN>(k, 1, a->dtype_in, a->dtype_out, st);
     }
     if (k.vecA && k.vecB) {
+      const int pp = pipe_try_launch(k, OP_CONV, a->dtype_in, a->dtype_out, 1, st);
+      if (pp >= 0) return pp;
       const int g = glds_try_launch(k, OP_CONV, a->dtype_in, a->dtype_out, 1, st);
       if (g >= 0) return g;
     }

@@ -47,6 +47,12 @@ __device__ __forceinline__ int conv_row_to_pixel(int m, const ConvGeom& g) {
 // (caller falls back to the 4-wave kernel), > 0 = hipError_t.
 int glds_try_launch(const GemmK& k, int amode, int dtype_in, int dtype_out, int batch, hipStream_t st);
 
+// gemm_pipe.hip: three-stage pipelined direct-to-LDS kernel, 8 waves, one block per CU, tile height picked per problem (bf16 -> bf16).
+// Same return convention; tried before glds_try_launch.
+int pipe_try_launch(const GemmK& k, int amode, int dtype_in, int dtype_out, int batch, hipStream_t st);
+int pipe_set_mode(int v);
+long pipe_launches(long set);
+
 // gemm_skinny.hip: 64x64 tiles with the reduction split across the block's four waves, for GEMMs whose tiles cannot
 // fill the chip (M = 192..640 rows).  Same return convention.
 int skinny_try_launch(const GemmK& k, int b_trans, int dtype_in, int dtype_out, int batch, hipStream_t st);

@@ -109,8 +109,22 @@ class FlatTrainer:
         self.overlap = self.world > 1 and os.environ.get('GPV_OVERLAP', '1') != '0'
         self.dry_overlap = False             # tests: run the milestone / guard logic without communicating
         self._closed_from, self._works, self.late_touch, self.milestones = None, [], None, 0
+        self.host_pg = None
         if self.world > 1:
             dist.broadcast(self.P, src=0, group=self.pg)
+            # DDP broadcasts every parameter AND buffer from rank 0 at construction; the tensors this trainer does not manage
+            # (frozen BERT, vocabulary embedding, FrozenBN statistics, the frozen stem / layer1) must not depend on each rank's seed
+            for t in list(model.buffers()) + [p.data for n, p in model.named_parameters() if not getattr(p, '_gpv_managed', False)]:
+                if t.numel() == 0:
+                    continue
+                if t.is_contiguous():
+                    dist.broadcast(t, src=0, group=self.pg)
+                else:                                                                 # channels_last conv weights
+                    c = t.contiguous()
+                    dist.broadcast(c, src=0, group=self.pg)
+                    t.copy_(c)
+            # host-side agreement channel (train_step): gloo, so that no device synchronisation is involved
+            self.host_pg = self.pg if dist.get_backend(self.pg) == 'gloo' else dist.new_group(backend='gloo')
         RT.bump_weights()
 
     @staticmethod
@@ -158,8 +172,14 @@ class FlatTrainer:
         self._closed_from = None
         if self.world == 1:
             return
-        works = self._works + [dist.all_reduce(self.G[s:e], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
-                               for s, e in self.buckets if closed is None or s < closed]
+        # Every rank issues the buckets in the SAME order -- [behind the backbone segment] then [backbone segment] -- whether or
+        # not its backward reached the milestone (a rank without an applicable target runs no backward at all, see train_step).
+        works = list(self._works)
+        if closed is None:
+            works += [dist.all_reduce(self.G[s:e], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+                      for s, e in self.buckets if s >= self.backbone_end]
+        works += [dist.all_reduce(self.G[s:e], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+                  for s, e in self.buckets if s < self.backbone_end]
         self._works = []
         self._publish_touched()
         dist.all_reduce(self.live, op=dist.ReduceOp.MAX, group=self.pg)          # stays on the device: no host sync
@@ -259,10 +279,23 @@ class FlatTrainer:
         for i, t in enumerate(targets):
             t['answer_token_ids'] = answer_token_ids[i, 1:]
         loss = model(images, queries, answer_token_ids, targets)
+        # The reference skips the update when no criterion applies to the batch (losses.py:163-169, train_distr.py:420); under
+        # its DDP a rank-local skip leaves the other ranks waiting in the gradient all-reduce forever.  Here the ranks agree on
+        # the host (one int through gloo, issued while the GPU still runs the forward): nobody has a loss -> everyone skips
+        # like the reference; somebody has -> the ranks without one contribute zero gradients, enter every collective and step.
+        if not self._any_rank_has_loss(loss is not None):
+            return None
+        self.zero_grad()
+        self.begin_backward()
         if loss is not None:
-            self.zero_grad()
-            self.begin_backward()
             loss.backward()
-            self.allreduce_grads()
-            self.step()
+        self.allreduce_grads()
+        self.step()
         return loss
+
+    def _any_rank_has_loss(self, has):
+        if self.world == 1:
+            return has
+        t = torch.tensor([1 if has else 0], dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.host_pg)
+        return bool(int(t))

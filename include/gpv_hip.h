@@ -45,6 +45,8 @@ int gpv_abi_version(void); /* = 1 */
 #define GPV_OPT_SKINNY 2 /* small-M GEMM kernel (reduction split over the block's waves): 0 never, 1 (default) heuristic, 2 wherever legal */
 #define GPV_OPT_GLDS_LAUNCHES 1 /* returns the number of direct-to-LDS GEMM/conv launches so far, then sets the counter to value */
 #define GPV_OPT_GLDS_WGRAD 3 /* direct-to-LDS weight-gradient kernel: 0 never, 1 (default) conv wherever legal + linear where it wins, 2 both wherever legal */
+#define GPV_OPT_PIPE 4 /* three-stage pipelined direct-to-LDS GEMM/conv kernel (gemm_pipe.hip): 0 never, 1 (default) heuristic, 100 + i = tile configuration i wherever legal */
+#define GPV_OPT_PIPE_LAUNCHES 5 /* returns the number of pipelined-kernel launches so far, then sets the counter to value */
 int gpv_set_option(int option, int value);
 
 /* ---------------------------------------------------------------------------------------------

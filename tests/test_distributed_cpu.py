@@ -99,3 +99,48 @@ def test_two_rank_gradient_exchange(tmp_path):
     assert torch.equal(r0['touched'], r1['touched']) and r0['touched'][ib].all()
     # parameters were broadcast from rank 0 at construction and stay bit-identical after two steps
     assert torch.equal(r0['P'], r1['P'])
+
+
+def _worker_noloss(rank, world, port, out):
+    """rank 1 never has an applicable target (losses.py:163-169 returns None): it must still enter every collective."""
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from tests import synth, cpu_shim
+    from tests.test_model_cpu import build_small, nested, V, B, H, W, Tl, PAD
+    import gpv1_amd.ops as ops
+    from gpv1_amd.train import FlatTrainer
+    cpu_shim.install()
+    ops.RT.set_precise(True)
+    torch.manual_seed(5 + rank)
+    model, _ = build_small()
+    model.train()
+    model.bert.model.p = 0.0
+    tr = FlatTrainer(model, lr=1e-4, lr_backbone=1e-5, bucket_mb=8)
+    images, mask, ids, attn = synth.synth_batch(B, H, W, Tl, V, seed=1234 + rank, pad_to=PAD)
+    none_t = [{'task': 'SomethingElse'} for _ in range(B)]
+    res = {'ret': []}
+    # step 1: nobody has a loss -> every rank skips (the reference's behaviour), no optimizer step
+    res['ret'].append(tr.train_step(nested(images, mask), (ids, attn), [dict(t) for t in none_t]) is None)
+    res['steps_after_all_none'] = tr.step_count
+    P0 = tr.P.clone()
+    # steps 2-3: rank 0 has targets, rank 1 has none: rank 1 contributes zeros and steps with the others
+    for _ in range(2):
+        tg = synth.synth_targets(B, V, S=6) if rank == 0 else [dict(t) for t in none_t]
+        res['ret'].append(tr.train_step(nested(images, mask), (ids, attn), tg) is None)
+    res['steps'] = tr.step_count
+    res['P'] = tr.P.clone()
+    res['moved'] = bool((tr.P != P0).any())
+    torch.save(res, os.path.join(out, f'rank{rank}.pt'))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(1800)
+def test_rank_without_applicable_target_stays_in_step(tmp_path):
+    mp.spawn(_worker_noloss, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = [torch.load(os.path.join(tmp_path, f'rank{r}.pt')) for r in range(2)]
+    assert r0['ret'] == [True, False, False] and r1['ret'] == [True, True, True]
+    assert r0['steps_after_all_none'] == 0 and r1['steps_after_all_none'] == 0
+    assert r0['steps'] == 2 and r1['steps'] == 2
+    assert r0['moved'] and torch.equal(r0['P'], r1['P'])
