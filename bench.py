@@ -11,7 +11,9 @@ random-init weights; inputs are resident in HBM before the timed region.
 
 Prints ONE JSON line (rank 0) with the contract fields + "roofline" (dominant kernel: the implicit-GEMM
 convolution of the backbone, timed live with HIP events on the launch stream inside the timed region)
-+ "cpu_baseline" (the CPU oracle's forward+backward on this host, bounded sample, N=1 only).
++ "roofline_attention" (encoder attention core against the dense bf16 MFMA peak) + "cpu_baseline" (the CPU
+oracle's forward+backward and greedy decode on this host, bounded sample, N=1 only).
+--gpus N without a launcher starts the N ranks itself (torch.distributed.run on 127.0.0.1).
 """
 import argparse
 import json
@@ -33,9 +35,9 @@ CAP_WORDS = 18           # + __cls__ + __stop__ = 20 tokens = max_text_len
 
 
 def make_cfg():
-    from tests import synth
+    from gpv1_amd import synthetic
     g = torch.Generator().manual_seed(0)
-    return synth.model_cfg(vocab=synth.make_vocab(V), vocab_embed=0.1 * torch.randn(V, 768, generator=g))
+    return synthetic.model_cfg(vocab=synthetic.make_vocab(V), vocab_embed=0.1 * torch.randn(V, 768, generator=g))
 
 
 def make_batch(rank, B, dev):
@@ -91,14 +93,15 @@ def conv_algorithmic(model, B):
     return {'fwd_bytes': fb, 'fwd_flops': ff, 'bwd_bytes': bb, 'bwd_flops': bf, 'fwd_launches': n_f, 'bwd_launches': n_b}
 
 
-def cpu_baseline(model, seconds_budget=25.0):
-    """CPU oracle (oracle/gpv_oracle.py, the pinned restatement of the reference) forward+loss+backward
-    on the host cores, B=2 at full size -- a reported baseline, not the target."""
+def cpu_baseline(model, seconds_budget=40.0):
+    """CPU oracle (oracle/gpv_oracle.py, the pinned restatement of the reference) on the host cores, SURVEY 8(d) protocol:
+    forward+loss+backward at B=4, full size, median of 5 after 2 warm-ups; greedy decode at B=1, median of 3 after 1 warm-up.
+    A reported baseline, not the target.  (tools/time_reference_cpu.py times the imported reference itself in the build
+    container: BASELINE.md.)"""
     from oracle import gpv_oracle as O
-    from tests import synth
     # 256 OpenMP threads on ~1e4 small ops is far slower than 32 (barrier cost): use min(cores, 32) and say so
     torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
-    Bc = 2
+    Bc = 4
     cfg = make_cfg()
     cfg['_cls_id'] = V - 3
     Pm = {k: v.detach().float().cpu().contiguous() for k, v in model.state_dict().items()}
@@ -110,7 +113,8 @@ def cpu_baseline(model, seconds_budget=25.0):
     train_keys = [n for n, p in model.named_parameters() if p.requires_grad and not n.startswith('bert.')]
     times = []
     t_start = time.time()
-    for it in range(3):
+    warm = 2
+    for it in range(warm + 5):
         leaves = {k: Pm[k].clone().requires_grad_(True) for k in train_keys}
         Pg = dict(Pm)
         Pg.update(leaves)
@@ -118,12 +122,84 @@ def cpu_baseline(model, seconds_budget=25.0):
         out = O.gpv_forward(Pg, cfg, images, mask, ids, attn, tok, training=True)
         loss, _ = O.gpv_criterion(out, targets, cfg['losses'])
         loss.backward()
-        times.append(time.time() - t0)
-        if time.time() - t_start > seconds_budget:
+        if it >= warm:
+            times.append(time.time() - t0)
+        if time.time() - t_start > seconds_budget and len(times) >= 1:
             break
-    t = sorted(times[1:] or times)[len(times[1:] or times) // 2]
+    t = sorted(times)[len(times) // 2]
+    gt = []
+    with torch.no_grad():
+        for it in range(4):
+            t0 = time.time()
+            O.gpv_forward(Pm, cfg, images[:1], mask[:1], ids[:1], attn[:1], None, training=False)
+            if it >= 1:
+                gt.append(time.time() - t0)
+            if time.time() - t_start > 2 * seconds_budget and gt:
+                break
+    g = sorted(gt)[len(gt) // 2]
     return {'value': Bc / t, 'unit': 'images/sec', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': f'oracle fwd+loss+bwd (no optimizer), B={Bc}, 480x640, V={V}, fp32, median of {len(times[1:] or times)} after 1 warm-up'}
+            'sample': f'oracle fwd+loss+bwd (no optimizer), B={Bc}, 480x640, V={V}, fp32, median of {len(times)} after {warm} warm-ups; '
+                      f'greedy decode B=1: median of {len(gt)} after 1 warm-up',
+            'greedy_ms_per_image': g * 1e3}
+
+
+def attention_roofline(dev, B):
+    """north_star's second roofline: MFMA utilisation on the encoder attention path.  The attention core of one DETR encoder
+    layer at the workload shape (B x 8 heads, 300 x 300 scores, dh = 32, dropout 0.1, operands = column slices of the fused
+    q|k and v projection buffers exactly as the model passes them), timed live with HIP events on the launch stream.
+    Algorithmic flops of the fused core = 4*B*h*S^2*dh forward (QK^T + PV), x2.5 backward."""
+    import math
+    import gpv1_amd.hip as hip
+    H, S, dh = 8, 300, 32
+    D = H * dh
+    g = torch.Generator().manual_seed(5)
+    qk = torch.randn(B * S, 2 * D, generator=g).to(dev).to(torch.bfloat16)
+    v = torch.randn(B * S, D, generator=g).to(dev).to(torch.bfloat16)
+    do = torch.randn(B * S, D, generator=g).to(dev).to(torch.bfloat16)
+    o = torch.empty(B * S, D, device=dev, dtype=torch.bfloat16)
+    lse = torch.empty(B, H, S, device=dev, dtype=torch.float32)
+    dqk, dv = torch.empty_like(qk), torch.empty_like(v)
+    st = ((S * 2 * D, 2 * D), (S * 2 * D, 2 * D), (S * D, D), (S * D, D))
+    scale = 1.0 / math.sqrt(dh)
+
+    def fwd():
+        hip.attention_fwd(qk[:, :D], qk[:, D:], v, o, st, B, H, S, S, dh, scale, drop_p=0.1, seed=11, lse=lse)
+
+    def bwd():
+        hip.attention_bwd(qk[:, :D], qk[:, D:], v, o, do, dqk[:, :D], dqk[:, D:], dv, st, (S * D, D), B, H, S, S, dh, scale,
+                          drop_p=0.1, seed=11, lse=lse)
+    out = {}
+    for name, fn in (('fwd', fwd), ('bwd', bwd)):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        out[name] = e0.elapsed_time(e1) / 20 * 1e3
+    fl = 4.0 * B * H * S * S * dh
+    tf = fl / (out['fwd'] * 1e-6) / 1e12
+    return {'bound': 'mfma', 'achieved': tf, 'peak': 2500.0, 'unit': 'TFLOP/s', 'frac': tf / 2500.0,
+            'kernel': 'attn_q_kernel<bf16,32,32,20,0> (DETR encoder self-attention core, forward; B x 8 heads, 300x300, dh 32, dropout on)',
+            'flops_per_launch': fl, 'avg_launch_us': out['fwd'], 'bwd_us': out['bwd'],
+            'bwd_tflops': 2.5 * fl / (out['bwd'] * 1e-6) / 1e12,
+            'note': 'dh = 32: 2 MFMAs per 256 scores against ~12 VALU instructions per score -- the core is VALU-bound, see DESIGN.md'}
+
+
+def self_launch(args):
+    """python bench.py --gpus N without a launcher: start N ranks on this node (the reference spawns its own ranks too,
+    exp/gpv/train_distr.py:488-493) through torch.distributed.run and pass its exit code on"""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd).returncode
 
 
 def greedy_decode_bench(model, dev):
@@ -161,9 +237,14 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-decode', action='store_true')
     args = ap.parse_args()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(self_launch(args))
     rank = int(os.environ.get('RANK', 0))
     local = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
+    if world != args.gpus:
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU '
+                         f'(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)')
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     local = local % max(torch.cuda.device_count(), 1)   # (only differs on a box with fewer GPUs than ranks: the gloo dry run below)
     torch.cuda.set_device(local)
@@ -260,6 +341,7 @@ def main():
                       'global_batch': world * args.batch, 'image': '480x640', 'caption_tokens': 20,
                       'parallelism': f'dp{world}', 'final_loss': float(loss.detach())},
            'roofline': roof}
+    out['roofline_attention'] = attention_roofline(dev, args.batch)
     if world == 1 and not args.no_decode:
         out['greedy_decode'] = greedy_decode_bench(model, dev)
     if world == 1 and not args.no_cpu_baseline:

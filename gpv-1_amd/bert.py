@@ -191,11 +191,42 @@ class BertModel(nn.Module):
 class Bert(nn.Module):
     """bert.py:5-22.  ``forward(sentences, device)`` -> (last hidden state B x T x 768, token_inputs)."""
 
-    def __init__(self, cfg=None, vocab_file=None, num_layers=12):
+    def __init__(self, cfg=None, vocab_file=None, num_layers=12, weights=None):
         super().__init__()
         vocab_file = vocab_file or os.environ.get('GPV_BERT_VOCAB')
         self.tokenizer = WordPieceTokenizer(vocab_file) if vocab_file and os.path.exists(vocab_file) else None
         self.model = BertModel(layers=num_layers)
+        weights = weights or os.environ.get('GPV_BERT_WEIGHTS')
+        self.pretrained = False
+        if weights:
+            self.load_pretrained(weights)
+
+    def load_pretrained(self, path):
+        """bert.py:8-9 `BertModel.from_pretrained('bert-base-uncased')`: the reference downloads the weights; here they come
+        from a local file -- a torch-saved HF state dict (pytorch_model.bin), a directory holding one, or a .safetensors file.
+        Key names are HF's (with or without the 'bert.' prefix); LayerNorm gamma/beta of old checkpoints are renamed."""
+        if os.path.isdir(path):
+            cands = [os.path.join(path, f) for f in ('model.safetensors', 'pytorch_model.bin')]
+            path = next((c for c in cands if os.path.exists(c)), None)
+            if path is None:
+                raise FileNotFoundError(f'Bert.load_pretrained: none of {cands} exists')
+        if path.endswith('.safetensors'):
+            from safetensors.torch import load_file
+            sd = load_file(path)
+        else:
+            sd = torch.load(path, map_location='cpu', weights_only=True)
+        ren = {}
+        for k, v in sd.items():
+            k = k[len('bert.'):] if k.startswith('bert.') else k
+            k = k.replace('LayerNorm.gamma', 'LayerNorm.weight').replace('LayerNorm.beta', 'LayerNorm.bias')
+            ren[k] = v
+        own = self.model.state_dict()
+        missing = [k for k in own if k not in ren and 'position_ids' not in k]
+        if missing:
+            raise RuntimeError(f'Bert.load_pretrained: {len(missing)} tensors missing from {path}, e.g. {missing[:3]}')
+        self.model.load_state_dict({k: ren[k] for k in own if k in ren}, strict=False)
+        self.pretrained = True
+        ops.RT.bump_weights()
 
     def forward(self, sentences, device=None):
         if isinstance(sentences, (tuple, list)) and len(sentences) == 2 and torch.is_tensor(sentences[0]):

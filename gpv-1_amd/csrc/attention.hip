@@ -22,11 +22,28 @@ struct AttnK {
   int B, H, Sq, Sk, dh, skp;
   float scale;
   const uint8_t* kpm; int causal;
-  uint32_t dthresh; float dscale; uint64_t seed;
+  uint32_t dthresh; float dscale; uint64_t seed; const uint64_t* seed_dev;
   float* lse;
   const void* dout; int64_t do_bs, do_rs;
   void* dq; void* dk; void* dv;
 };
+
+// Attention dropout: the keep decisions of a (batch, head, query) row come from one 32-bit word per PAIR of keys, 16 bits per
+// element (drop probability floor(p * 65536) / 65536), mixed from the row's seed with full-rate VALU only (shifts, xors, 24-bit
+// multiplies).  The 64-bit counter hash of common.h per SCORE (three quarter-rate 32-bit multiplies) made the dh = 32 kernels
+// spend more on the mask than on the softmax; forward, dQ and dK/dV kernels must agree on this function.
+constexpr uint32_t ATTN_PAIR_STEP = 0x9E3779B9u;
+__device__ __forceinline__ uint32_t attn_row_seed(uint64_t seed, uint64_t row) { return hash_u32(seed, row); }
+__device__ __forceinline__ uint32_t attn_pair_bits(uint32_t x) {     // x = row seed + pair index * ATTN_PAIR_STEP
+  x ^= x >> 16; x = __umul24(x, 0x85EBCBu);
+  x ^= x >> 13; x = __umul24(x, 0xC2B2AFu);
+  x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ bool attn_keep(uint32_t row_seed, int key, uint32_t t16) {
+  const uint32_t w = attn_pair_bits(row_seed + (uint32_t)(key >> 1) * ATTN_PAIR_STEP);
+  return ((key & 1) ? (w >> 16) : (w & 0xffffu)) >= t16;
+}
 
 template <typename T> struct R8 {  // 8 staged values as floats
   float v[8];
@@ -95,6 +112,7 @@ __device__ __forceinline__ bf16x8 ld_pair64(const bf16* p0, const bf16* p1) {
 // MODE 0: forward (writes o, lse).  MODE 1: dQ (reads dout, o, lse; writes dq)
 template <typename T, int DHK, int DHV, int NT, int MODE>
 __global__ __launch_bounds__(256, DHK < 96 ? 2 : 1) void attn_q_kernel(AttnK p) {
+  if (p.dthresh) p.seed = eff_seed(p.seed, p.seed_dev);
   constexpr bool PRECISE = sizeof(T) == 4;
   constexpr int KP = DHK + 8;
   constexpr int KC = DHK / 32;
@@ -153,8 +171,11 @@ __global__ __launch_bounds__(256, DHK < 96 ? 2 : 1) void attn_q_kernel(AttnK p) 
     // nothing needs all Sk scores at once.  (Holding them -- as the forward must for its max/sum -- cost 256+ VGPRs:
     // one wave per SIMD, 159 us for the encoder shape; two live tiles fit 3-4 waves per SIMD.) ----
     const uint8_t* kpm1 = p.kpm ? p.kpm + (int64_t)b * p.Sk : nullptr;
-    const float lse1 = qok ? p.lse[((int64_t)b * p.H + h) * p.Sq + q] : 0.f;
-    const uint64_t rng1 = (((uint64_t)b * p.H + h) * p.Sq + q) * (uint64_t)p.Sk;
+    const float c2q = p.scale * 1.4426950408889634f;
+    const float lse1 = qok ? -p.lse[((int64_t)b * p.H + h) * p.Sq + q] * 1.4426950408889634f : 0.f;   // exp(s*scale - lse) = exp2(s*c2 + lse1)
+    const uint32_t rs1 = p.dthresh ? attn_row_seed(p.seed, ((uint64_t)b * p.H + h) * p.Sq + q) : 0u;
+    const uint32_t t16 = p.dthresh >> 16;
+    const bool masked1 = kpm1 != nullptr || p.causal;
     f32x4 dq[DT];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -189,13 +210,24 @@ __global__ __launch_bounds__(256, DHK < 96 ? 2 : 1) void attn_q_kernel(AttnK p) 
 #pragma unroll
           for (int i = 0; i < 4; ++i) km1 |= (uint32_t)kpm1[min(j * 16 + g * 4 + i, p.Sk - 1)] << (8 * i);
         }
+        uint32_t w01 = 0u, w23 = 0u;
+        if (p.dthresh) {
+          const uint32_t pb = rs1 + (uint32_t)(j * 8 + g * 2) * ATTN_PAIR_STEP;
+          w01 = attn_pair_bits(pb); w23 = attn_pair_bits(pb + ATTN_PAIR_STEP);
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int key = j * 16 + g * 4 + i;
-          const bool dead = key >= p.Sk || (p.causal && key > q) || ((km1 >> (8 * i)) & 0xffu) != 0u;
-          const float pr = dead ? 0.f : __expf(sc[i] * p.scale - lse1);      // normalised P
+          float pr = __builtin_amdgcn_exp2f(fmaf(sc[i], c2q, lse1));         // normalised P
+          if (masked1 || j * 16 + 16 > p.Sk) {
+            const bool dead = key >= p.Sk || (p.causal && key > q) || ((km1 >> (8 * i)) & 0xffu) != 0u;
+            pr = dead ? 0.f : pr;
+          }
           float d = dp[i];
-          if (p.dthresh) d = drop_keep(p.seed, rng1 + key, p.dthresh) ? d * p.dscale : 0.f;
+          if (p.dthresh) {
+            const uint32_t w = i < 2 ? w01 : w23;
+            d = ((i & 1) ? (w >> 16) : (w & 0xffffu)) >= t16 ? d * p.dscale : 0.f;
+          }
           sj[t][i] = pr * (d - delta) * p.scale;
         }
       }
@@ -235,7 +267,10 @@ __global__ __launch_bounds__(256, DHK < 96 ? 2 : 1) void attn_q_kernel(AttnK p) 
     return;
   }
 
-  // ---- scores S^T[key][q] for all key tiles ----
+  // ---- forward: scores S^T[key][q] for all key tiles, softmax over the registers, out^T = V^T P^T ----
+  // The core is VALU-bound at dh = 32 (2 MFMAs per 256 scores against every per-score VALU instruction): what is spent per
+  // score is one max, one fma + v_exp (scale and max folded into the fma, base-2 exponent), one add, the dropout select and
+  // the bf16 pack.  Masks cost nothing when there are none (no key-padding mask, not causal): only the tail tiles test keys.
   f32x4 s[NT];
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
@@ -255,86 +290,72 @@ __global__ __launch_bounds__(256, DHK < 96 ? 2 : 1) void attn_q_kernel(AttnK p) 
     }
   }
   const uint8_t* kpm = p.kpm ? p.kpm + (int64_t)b * p.Sk : nullptr;
-  // key-padding bytes of this lane's 4 keys per tile, fetched up front WITHOUT per-element branches: the former
-  // `if (!dead && kpm) dead = kpm[key]` was 80 exec-masked branches, each waiting for its own byte load -- serial L2
-  // latency that made up most of the kernel's 35 k cycles per wave (and 160 SGPRs of live lane masks, spilled).
-  uint32_t km[NT];
+  if (kpm != nullptr || p.causal) {
+    // key-padding bytes of this lane's 4 keys per tile, fetched up front WITHOUT per-element branches
+    uint32_t km[NT];
 #pragma unroll
-  for (int j = 0; j < NT; ++j) km[j] = 0u;
-  if (kpm) {
+    for (int j = 0; j < NT; ++j) km[j] = 0u;
+    if (kpm) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) km[j] |= (uint32_t)kpm[min(j * 16 + g * 4 + i, p.Sk - 1)] << (8 * i);
+      }
+    }
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) km[j] |= (uint32_t)kpm[min(j * 16 + g * 4 + i, p.Sk - 1)] << (8 * i);
+      for (int i = 0; i < 4; ++i) {
+        const int key = j * 16 + g * 4 + i;
+        const bool dead = key >= p.Sk || (p.causal && key > q) || ((km[j] >> (8 * i)) & 0xffu) != 0u;
+        s[j][i] = dead ? -INFINITY : s[j][i];
+      }
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      if (j * 16 + 16 > p.Sk) {                      // (uniform) tail tiles only
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s[j][i] = (j * 16 + g * 4 + i >= p.Sk) ? -INFINITY : s[j][i];
+      }
     }
   }
   float mx = -INFINITY;
 #pragma unroll
-  for (int j = 0; j < NT; ++j) {
+  for (int j = 0; j < NT; ++j)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int key = j * 16 + g * 4 + i;
-      const bool dead = key >= p.Sk || (p.causal && key > q) || ((km[j] >> (8 * i)) & 0xffu) != 0u;
-      float x = dead ? -INFINITY : s[j][i] * p.scale;
-      s[j][i] = x;
-      mx = fmaxf(mx, x);
-    }
-  }
-  float lsum = 0.f, lse_q = 0.f;
-  if (MODE == 0) {
-    mx = fmaxf(mx, __shfl_xor(mx, 16));
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
-    const float mref = mx == -INFINITY ? 0.f : mx;
+    for (int i = 0; i < 4; ++i) mx = fmaxf(mx, s[j][i]);
+  mx = fmaxf(mx, __shfl_xor(mx, 16));
+  mx = fmaxf(mx, __shfl_xor(mx, 32));
+  const float c2 = p.scale * 1.4426950408889634f;           // exp(scale * (s - mx)) = exp2(s * c2 - mx * c2)
+  const float nm = mx == -INFINITY ? 0.f : -mx * c2;
+  float lsum = 0.f;
 #pragma unroll
-    for (int j = 0; j < NT; ++j)
+  for (int j = 0; j < NT; ++j)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { float e = __expf(s[j][i] - mref); s[j][i] = e; lsum += e; }
-    lsum += __shfl_xor(lsum, 16);
-    lsum += __shfl_xor(lsum, 32);
-    if (g == 0 && qok && p.lse) p.lse[((int64_t)b * p.H + h) * p.Sq + q] = mref + logf(lsum);
-  } else {
-    lse_q = qok ? p.lse[((int64_t)b * p.H + h) * p.Sq + q] : 0.f;
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) s[j][i] = __expf(s[j][i] - lse_q);   // normalised P (masked -> 0)
-  }
+    for (int i = 0; i < 4; ++i) { const float e = __builtin_amdgcn_exp2f(fmaf(s[j][i], c2, nm)); s[j][i] = e; lsum += e; }
+  lsum += __shfl_xor(lsum, 16);
+  lsum += __shfl_xor(lsum, 32);
+  if (g == 0 && qok && p.lse) p.lse[((int64_t)b * p.H + h) * p.Sq + q] = (mx == -INFINITY ? 0.f : mx * p.scale) + logf(lsum);
 
-  const uint64_t rng_row = (((uint64_t)b * p.H + h) * p.Sq + q) * (uint64_t)p.Sk;
-  if (MODE == 1) {
-    // dP^T[key][q] = sum_d V[key][d] dO[q][d] ; dS = P * (dPd - delta) * scale
+  if (p.dthresh) {
+    const uint32_t rs = attn_row_seed(p.seed, ((uint64_t)b * p.H + h) * p.Sq + q);
+    const uint32_t t16 = p.dthresh >> 16;
+    const uint32_t gb = rs + (uint32_t)(g * 2) * ATTN_PAIR_STEP;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-      f32x4 dp = f32x4{0.f, 0.f, 0.f, 0.f};
       if (j < ntr) {
-#pragma unroll
-        for (int kc = 0; kc < KC; ++kc) {
-          const int off = (j * 16 + (lane & 15)) * KP + kc * 32 + g * 8;
-          bf16x8 vh = *reinterpret_cast<const bf16x8*>(Vh + off);
-          dp = mfma16(vh, doh[kc], dp);
-          if (PRECISE) {
-            bf16x8 vl = *reinterpret_cast<const bf16x8*>(Vl + off);
-            dp = mfma16(vl, doh[kc], dp);
-            dp = mfma16(vh, dol[kc], dp);
-          }
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        float d = dp[i];
-        if (p.dthresh) d = drop_keep(p.seed, rng_row + (j * 16 + g * 4 + i), p.dthresh) ? d * p.dscale : 0.f;
-        s[j][i] = s[j][i] * (d - delta) * p.scale;
+        const uint32_t w0 = attn_pair_bits(gb + (uint32_t)(j * 8) * ATTN_PAIR_STEP);
+        const uint32_t w1 = attn_pair_bits(gb + (uint32_t)(j * 8 + 1) * ATTN_PAIR_STEP);
+        s[j][0] = (w0 & 0xffffu) >= t16 ? s[j][0] * p.dscale : 0.f;
+        s[j][1] = (w0 >> 16) >= t16 ? s[j][1] * p.dscale : 0.f;
+        s[j][2] = (w1 & 0xffffu) >= t16 ? s[j][2] * p.dscale : 0.f;
+        s[j][3] = (w1 >> 16) >= t16 ? s[j][3] * p.dscale : 0.f;
       }
     }
-  } else if (p.dthresh) {
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        s[j][i] = drop_keep(p.seed, rng_row + (j * 16 + g * 4 + i), p.dthresh) ? s[j][i] * p.dscale : 0.f;
   }
 
-  // ---- out^T[d][q] = sum_key X^T[d][key] * s[key][q]   (X = V forward, K for dQ) ----
+  // ---- out^T[d][q] = sum_key V^T[d][key] * P^T[key][q] ----
   f32x4 oacc[DT];
 #pragma unroll
   for (int dt = 0; dt < DT; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -346,7 +367,7 @@ __global__ __launch_bounds__(256, DHK < 96 ? 2 : 1) void attn_q_kernel(AttnK p) 
       for (int i = 0; i < 4; ++i) {
         float a = s[2 * kb][i], c = s[2 * kb + 1][i];
         ph[i] = (bf16)a; ph[4 + i] = (bf16)c;
-        pl[i] = (bf16)(a - (float)ph[i]); pl[4 + i] = (bf16)(c - (float)ph[4 + i]);
+        if (PRECISE) { pl[i] = (bf16)(a - (float)ph[i]); pl[4 + i] = (bf16)(c - (float)ph[4 + i]); }
       }
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) {
@@ -362,9 +383,8 @@ __global__ __launch_bounds__(256, DHK < 96 ? 2 : 1) void attn_q_kernel(AttnK p) 
     }
   }
   if (!qok) return;
-  T* outp = (MODE == 0 ? reinterpret_cast<T*>(p.o) + b * p.o_bs + (int64_t)q * p.o_rs
-                       : reinterpret_cast<T*>(p.dq) + b * p.q_bs + (int64_t)q * p.q_rs) + h * p.dh;
-  const float inv = MODE == 0 ? (lsum > 0.f ? 1.f / lsum : 0.f) : 1.f;
+  T* outp = reinterpret_cast<T*>(p.o) + b * p.o_bs + (int64_t)q * p.o_rs + h * p.dh;
+  const float inv = lsum > 0.f ? 1.f / lsum : 0.f;
 #pragma unroll
   for (int dt = 0; dt < DT; ++dt) {
     const int d = dt * 16 + g * 4;
@@ -383,6 +403,7 @@ __global__ __launch_bounds__(256, DHK < 96 ? 2 : 1) void attn_q_kernel(AttnK p) 
 // dK / dV: workgroup = 64 keys of one (b,h); wave = 16 keys; queries streamed in chunks of 64.
 template <typename T, int DHK, int DHV>
 __global__ __launch_bounds__(256) void attn_kv_kernel(AttnK p) {
+  if (p.dthresh) p.seed = eff_seed(p.seed, p.seed_dev);
   constexpr bool PRECISE = sizeof(T) == 4;
   constexpr int KP = DHK + 8, KC = DHK / 32, DT = DHV / 16, QC = 64, QTP = QC + 8;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -393,6 +414,7 @@ __global__ __launch_bounds__(256) void attn_kv_kernel(AttnK p) {
   bf16* DTh = QTl + DHV * QTP;   bf16* DTl = DTh + (PRECISE ? DHV * QTP : 0);
   float* lse_s = reinterpret_cast<float*>(DTl + DHV * QTP);
   float* del_s = lse_s + QC;
+  uint32_t* rs_s = reinterpret_cast<uint32_t*>(del_s + QC);       // dropout row seeds of the staged queries
 
   const int b = blockIdx.z, h = blockIdx.y, k0 = blockIdx.x * 64;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
@@ -400,6 +422,8 @@ __global__ __launch_bounds__(256) void attn_kv_kernel(AttnK p) {
   const bool kok = key < p.Sk;
   bool kdead = !kok;
   if (kok && p.kpm) kdead = p.kpm[(int64_t)b * p.Sk + key] != 0;
+  const float c2k = p.scale * 1.4426950408889634f;
+  const uint32_t kpair = (uint32_t)(key >> 1) * ATTN_PAIR_STEP, kshift = (key & 1) * 16, t16 = p.dthresh >> 16;
 
   bf16x8 kh[KC], kl[KC], vh[KC], vl[KC];
   {
@@ -442,7 +466,8 @@ __global__ __launch_bounds__(256) void attn_kv_kernel(AttnK p) {
         }
         ls = p.lse[((int64_t)b * p.H + h) * p.Sq + qc0 + r];
       }
-      lse_s[r] = ls; del_s[r] = dl;
+      lse_s[r] = -ls * 1.4426950408889634f; del_s[r] = dl;
+      rs_s[r] = p.dthresh ? attn_row_seed(p.seed, ((uint64_t)b * p.H + h) * p.Sq + qc0 + r) : 0u;
     }
     __syncthreads();
 #pragma unroll
@@ -472,16 +497,23 @@ __global__ __launch_bounds__(256) void attn_kv_kernel(AttnK p) {
         const int qr = qb * 32 + t * 16 + g * 4;   // local query row of element i = qr + i
         const float4 l4 = *reinterpret_cast<const float4*>(lse_s + qr);
         const float4 d4 = *reinterpret_cast<const float4*>(del_s + qr);
-        const float ls[4] = {l4.x, l4.y, l4.z, l4.w};
+        const float ls[4] = {l4.x, l4.y, l4.z, l4.w};             // -lse * log2(e); -inf for padded queries -> P = 0
         const float dl[4] = {d4.x, d4.y, d4.z, d4.w};
+        uint32_t rsd[4] = {0u, 0u, 0u, 0u};
+        if (p.dthresh) {
+          const uint4 r4 = *reinterpret_cast<const uint4*>(rs_s + qr);
+          rsd[0] = r4.x; rsd[1] = r4.y; rsd[2] = r4.z; rsd[3] = r4.w;
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int qq = qc0 + qr + i;
-          bool dead = kdead || (p.causal && key > qq);
-          float pv = dead ? 0.f : __expf(sa[i] * p.scale - ls[i]);   // ls = +inf for padded queries -> 0
+          const bool dead = kdead || (p.causal && key > qq);
+          float pv = __builtin_amdgcn_exp2f(fmaf(sa[i], c2k, ls[i]));
+          pv = dead ? 0.f : pv;
           float d = dp[i], pd = pv;
           if (p.dthresh) {
-            const bool keep = drop_keep(p.seed, (((uint64_t)b * p.H + h) * p.Sq + qq) * (uint64_t)p.Sk + key, p.dthresh);
+            const uint32_t w = attn_pair_bits(rsd[i] + kpair);
+            const bool keep = ((w >> kshift) & 0xffffu) >= t16;
             d = keep ? d * p.dscale : 0.f;
             pd = keep ? pv * p.dscale : 0.f;
           }
@@ -547,7 +579,7 @@ template <typename T, int DHK, int DHV>
 int launch_kv(const AttnK& p, hipStream_t st) {
   constexpr bool PRECISE = sizeof(T) == 4;
   constexpr int KP = DHK + 8, QC = 64, QTP = QC + 8;
-  size_t lds = ((size_t)2 * QC * KP + (size_t)2 * DHV * QTP) * 2 * (PRECISE ? 2 : 1) + 2 * QC * sizeof(float);
+  size_t lds = ((size_t)2 * QC * KP + (size_t)2 * DHV * QTP) * 2 * (PRECISE ? 2 : 1) + 3 * QC * sizeof(float);
   auto fn = attn_kv_kernel<T, DHK, DHV>;
   static size_t attr = 0;
   if (lds > 64 * 1024 && lds > attr) {
@@ -595,7 +627,7 @@ int fill(const gpv_attn_args* a, AttnK& p) {
   p.scale = a->scale; p.kpm = a->kpm; p.causal = a->causal;
   p.dthresh = a->drop_p > 0.f ? drop_thresh(a->drop_p) : 0u;
   p.dscale = a->drop_p > 0.f ? 1.f / (1.f - a->drop_p) : 1.f;
-  p.seed = a->seed; p.lse = a->lse;
+  p.seed = a->seed; p.seed_dev = gpvk::g_seed_dev; p.lse = a->lse;
   p.dout = a->dout; p.do_bs = a->do_bs; p.do_rs = a->do_rs; p.dq = a->dq; p.dk = a->dk; p.dv = a->dv;
   return 0;
 }

@@ -48,6 +48,13 @@ __device__ __forceinline__ uint32_t hash_u32(uint64_t seed, uint64_t idx) {
 __device__ __forceinline__ bool drop_keep(uint64_t seed, uint64_t idx, uint32_t thresh) {
   return hash_u32(seed, idx) >= thresh;
 }
+// Device-resident seed epoch (gpv_set_seed_device): when a caller replays captured launches (hipGraph) the `seed` argument of a
+// launch is frozen in the graph; the effective seed of every dropout consumer is then seed ^ mix(*epoch), the caller bumps the
+// word once per step, and the forward / backward launches of one step see the same value.  NULL = the seed argument as given.
+namespace gpvk { extern const uint64_t* g_seed_dev; }
+__device__ __forceinline__ uint64_t eff_seed(uint64_t seed, const uint64_t* epoch) {
+  return epoch ? seed ^ (*epoch * 0x9E3779B97F4A7C15ull) : seed;
+}
 __host__ __device__ __forceinline__ uint32_t drop_thresh(float p) {
   double t = (double)p * 4294967296.0;
   if (t < 0) t = 0;

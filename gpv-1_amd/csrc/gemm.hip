@@ -687,12 +687,14 @@ __device__ __forceinline__ void gemm_body(const GemmK& p) {
 
 template <typename TIn, typename TOut, int AMODE, int BMODE, int BM, int BN, bool VEC>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmK p) {
+  if (p.dthresh) p.seed = eff_seed(p.seed, p.seed_dev);
   gemm_body<TIn, TOut, AMODE, BMODE, BM, BN, VEC>(p);
 }
 // the same body under its own name for the backbone's 1x1 stride-1 convolutions (plain GEMMs over the pixel rows):
 // profiles and PMC passes can then tell them from the transformer's Linear layers
 template <typename TIn, typename TOut, int BM, int BN, bool VEC>
 __global__ __launch_bounds__(256) void conv1x1_kernel(GemmK p) {
+  if (p.dthresh) p.seed = eff_seed(p.seed, p.seed_dev);
   gemm_body<TIn, TOut, OP_PLAIN, OP_PLAIN, BM, BN, VEC>(p);
 }
 
@@ -853,7 +855,7 @@ extern "C" int gpv_gemm(const gpv_gemm_args* a, void* stream) {
   k.lda = a->lda; k.ldb = a->ldb; k.ldc = a->ldc; k.sA = a->sA; k.sB = a->sB; k.sC = a->sC;
   k.alpha = a->alpha; k.rowscale = a->rowscale; k.bias = a->bias;
   k.res = a->res; k.ldr = a->ldr; k.sR = a->sR; k.mask = a->relu_mask; k.ldm = a->ldm;
-  k.act = a->act; k.seed = a->seed;
+  k.act = a->act; k.seed = a->seed; k.seed_dev = gpvk::g_seed_dev;
   k.dthresh = a->drop_p > 0.f ? drop_thresh(a->drop_p) : 0u;
   k.dscale = a->drop_p > 0.f ? 1.0f / (1.0f - a->drop_p) : 1.0f;
   k.accumulate = a->accumulate; k.split_k = a->split_k;

@@ -22,7 +22,7 @@ struct GemmK {
   const float* rowscale; const float* bias;
   const void* res; int64_t ldr, sR;
   const void* mask; int64_t ldm;
-  int act; uint32_t dthresh; float dscale; uint64_t seed;
+  int act; uint32_t dthresh; float dscale; uint64_t seed; const uint64_t* seed_dev;
   int accumulate, split_k, kt_per_split, tilesN;
   int vecA, vecB;
   int conv1x1;         // launched from gpv_conv2d as a plain GEMM: use the conv1x1_kernel name

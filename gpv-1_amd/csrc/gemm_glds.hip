@@ -307,12 +307,18 @@ __device__ __forceinline__ void glds_body(const GemmK& p) {
 }
 
 template <int AMODE, int BM, int BN, typename TOut>
-__global__ __launch_bounds__(BM * 2) void glds_kernel(GemmK p) { glds_body<AMODE, BM, BN, TOut>(p); }
+__global__ __launch_bounds__(BM * 2) void glds_kernel(GemmK p) {
+  if (p.dthresh) p.seed = eff_seed(p.seed, p.seed_dev);
+  glds_body<AMODE, BM, BN, TOut>(p);
+}
 
 // 1x1 stride-1 convolutions are plain GEMMs over the NHWC rows; their own kernel name keeps them attributable to the
 // backbone in rocprofv3 traces and PMC passes (like conv1x1_kernel in gemm.hip)
 template <int BM, int BN, typename TOut>
-__global__ __launch_bounds__(BM * 2) void glds_conv1x1_kernel(GemmK p) { glds_body<OP_PLAIN, BM, BN, TOut>(p); }
+__global__ __launch_bounds__(BM * 2) void glds_conv1x1_kernel(GemmK p) {
+  if (p.dthresh) p.seed = eff_seed(p.seed, p.seed_dev);
+  glds_body<OP_PLAIN, BM, BN, TOut>(p);
+}
 
 template <int AMODE, int BM, int BN, typename TOut>
 int launch_glds(const GemmK& k, int batch, hipStream_t st) {

@@ -335,10 +335,16 @@ __device__ __forceinline__ void pipe_body(const GemmK& p) {
 }
 
 template <int AMODE, int BM, int BN, int WM, typename TOut>
-__global__ __launch_bounds__(NT) void pipe_kernel(GemmK p) { pipe_body<AMODE, BM, BN, WM, TOut>(p); }
+__global__ __launch_bounds__(NT) void pipe_kernel(GemmK p) {
+  if (p.dthresh) p.seed = eff_seed(p.seed, p.seed_dev);
+  pipe_body<AMODE, BM, BN, WM, TOut>(p);
+}
 // 1x1 stride-1 convolutions launched as plain GEMMs keep a name of their own (rocprofv3 attribution to the backbone)
 template <int BM, int BN, int WM, typename TOut>
-__global__ __launch_bounds__(NT) void pipe_conv1x1_kernel(GemmK p) { pipe_body<OP_PLAIN, BM, BN, WM, TOut>(p); }
+__global__ __launch_bounds__(NT) void pipe_conv1x1_kernel(GemmK p) {
+  if (p.dthresh) p.seed = eff_seed(p.seed, p.seed_dev);
+  pipe_body<OP_PLAIN, BM, BN, WM, TOut>(p);
+}
 
 template <int AMODE, int BM, int BN, int WM>
 int launch_pipe(const GemmK& k, int batch, hipStream_t st) {
@@ -427,7 +433,14 @@ int pipe_try_launch(const GemmK& k, int amode, int dtype_in, int dtype_out, int 
     idx = mode - 100;
     if (idx >= kNumCfgs || k.N % kCfgs[idx].bn != 0) return -1;
   } else {
-    if (k.K < 512 || k.M < 2048) return -1;         // short reductions / few rows: the other kernels (measured per shape)
+    // Where it wins (tools/bench_pipe.py, B=32 shapes, round 2): reductions of >= 512 over 256..768-wide outputs of <= 40 k rows
+    // (layer3/4 3x3 and long-K 1x1 convs fwd + dgrad, the DETR / co-attention GEMMs) and any width below 9600 rows.  N = 128
+    // (layer2) and the >= 1024-wide outputs of >= 9600 rows stay on the two-blocks-per-CU 128x128 kernel (its 600-2400 tiles
+    // balance better than 256-row rounds); the stride-2 dgrad parity classes are too uneven for one block per CU.
+    if (k.K < 512 || k.M < 2048 || k.M > 40000 || k.N < 256) return -1;
+    if (amode == OP_CONV && k.cg.cm) return -1;
+    if (k.N >= 1024 && k.M >= 9600) return -1;
+    if ((int64_t)k.M * k.N * batch > (int64_t)24 << 20) return -1;          // >= 1024 tiles of 256x256: the 8-wave 256x256 kernel (128 flop per operand byte)
     idx = pick_cfg(k, batch);
     if (idx < 0) return -1;
   }

@@ -35,6 +35,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const bf16* tile, int cbase, int lane)
 
 template <typename TOut, bool BT>
 __global__ __launch_bounds__(256) void skinny_kernel(GemmK p) {
+  if (p.dthresh) p.seed = eff_seed(p.seed, p.seed_dev);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   bf16* lds = reinterpret_cast<bf16*>(smem);
   constexpr int TILE = SBM * SPITCH;                  // elements of a K-major operand tile

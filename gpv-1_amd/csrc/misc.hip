@@ -22,7 +22,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      T* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd,
                                                      int rows, int cols, float eps, uint32_t dthresh, float dscale,
-                                                     uint64_t seed) {
+                                                     uint64_t seed, const uint64_t* seed_dev) {
+  if (dthresh) seed = eff_seed(seed, seed_dev);
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -91,7 +92,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, T* __restrict__ dx, T* __restrict__ ds,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, int rows, int cols,
-                                                     int rows_per_block, uint32_t dthresh, float dscale, uint64_t seed) {
+                                                     int rows_per_block, uint32_t dthresh, float dscale, uint64_t seed,
+                                                     const uint64_t* seed_dev) {
+  if (dthresh) seed = eff_seed(seed, seed_dev);
   extern __shared__ float lds[];   // [4 waves][2][cols]: every wave parks its partial dgamma | dbeta, no LDS atomics
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float ag[NV][8], ab[NV][8];
@@ -398,7 +401,9 @@ __global__ void embedding_kernel(const TT* __restrict__ table, const int64_t* __
 }
 
 template <typename T>
-__global__ void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n, uint32_t dthresh, float dscale, uint64_t seed) {
+__global__ void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n, uint32_t dthresh, float dscale, uint64_t seed,
+                               const uint64_t* seed_dev) {
+  seed = eff_seed(seed, seed_dev);
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
     y[i] = (T)(drop_keep(seed, (uint64_t)i, dthresh) ? (float)x[i] * dscale : 0.f);
 }
@@ -455,8 +460,17 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
                              float bc2, const float* __restrict__ gscale, const uint16_t* __restrict__ seg_id,
                              const int32_t* __restrict__ seg_live) {
   const float gs = gscale ? *gscale : 1.f;
+  const float l1 = logf(b1), l2 = logf(b2);
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    if (seg_id && !seg_live[seg_id[i >> 3]]) continue;          // parameter never received a gradient: untouched, like torch 1.6
+    if (seg_id) {
+      // seg_live[parameter] = the parameter's own Adam step count INCLUDING this step, 0 = it never received a gradient
+      // (untouched, like torch 1.6).  torch keeps `step` per parameter, starting at its first gradient: a head that is first
+      // touched at global step 100 takes its first update with the bias corrections of step 1.
+      const int t = seg_live[seg_id[i >> 3]];
+      if (!t) continue;
+      bc1 = -expm1f((float)t * l1);
+      bc2 = -expm1f((float)t * l2);
+    }
     float gi = g[i] * gs;
     float pi = p[i] * (1.f - lr * wd);
     float mi = b1 * m[i] + (1.f - b1) * gi;
@@ -488,7 +502,7 @@ extern "C" int gpv_layernorm_fwd(const void* x, const void* s, const float* gamm
   const uint32_t th = drop_p > 0.f ? drop_thresh(drop_p) : 0u;
   const float sc = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
   dim3 grid((rows + 3) / 4), block(256);
-#define LN_F(T, NV) hipLaunchKernelGGL((ln_fwd_kernel<T, NV>), grid, block, 0, ST(stream), (const T*)x, (const T*)s, gamma, beta, (T*)y, mean, rstd, rows, cols, eps, th, sc, seed)
+#define LN_F(T, NV) hipLaunchKernelGGL((ln_fwd_kernel<T, NV>), grid, block, 0, ST(stream), (const T*)x, (const T*)s, gamma, beta, (T*)y, mean, rstd, rows, cols, eps, th, sc, seed, gpvk::g_seed_dev)
   const int nv = (cols + 511) / 512;
   if (dtype == GPV_BF16) { if (nv <= 1) LN_F(bf16, 1); else if (nv <= 2) LN_F(bf16, 2); else if (nv <= 5) LN_F(bf16, 5); else LN_F(bf16, 8); }
   else { if (nv <= 1) LN_F(float, 1); else if (nv <= 2) LN_F(float, 2); else if (nv <= 5) LN_F(float, 5); else LN_F(float, 8); }
@@ -508,7 +522,7 @@ extern "C" int gpv_layernorm_bwd(const void* dy, const void* x, const void* s, c
   if (rpb < 8) rpb = 8;
   dim3 grid((rows + rpb - 1) / rpb), block(256);
   const size_t lds = dgamma ? 8 * (size_t)cols * sizeof(float) : 0;       // 4 waves x [dgamma | dbeta]; cols <= 4096 -> <= 128 KB
-#define LN_B(T, NV) hipLaunchKernelGGL((ln_bwd_kernel<T, NV>), grid, block, lds, ST(stream), (const T*)dy, (const T*)x, (const T*)s, gamma, mean, rstd, (T*)dx, (T*)ds, dgamma, dbeta, rows, cols, rpb, th, sc, seed)
+#define LN_B(T, NV) hipLaunchKernelGGL((ln_bwd_kernel<T, NV>), grid, block, lds, ST(stream), (const T*)dy, (const T*)x, (const T*)s, gamma, mean, rstd, (T*)dx, (T*)ds, dgamma, dbeta, rows, cols, rpb, th, sc, seed, gpvk::g_seed_dev)
   const int nv = (cols + 511) / 512;
   if (dtype == GPV_BF16) { if (nv <= 1) LN_B(bf16, 1); else if (nv <= 2) LN_B(bf16, 2); else if (nv <= 5) LN_B(bf16, 5); else LN_B(bf16, 8); }
   else { if (nv <= 1) LN_B(float, 1); else if (nv <= 2) LN_B(float, 2); else if (nv <= 5) LN_B(float, 5); else LN_B(float, 8); }
@@ -618,12 +632,18 @@ extern "C" int gpv_embedding(const void* table, const int64_t* ids, void* out, i
   return 0;
 }
 
+namespace gpvk { const uint64_t* g_seed_dev = nullptr; }
+extern "C" int gpv_set_seed_device(const uint64_t* epoch) {
+  gpvk::g_seed_dev = epoch;
+  return 0;
+}
+
 extern "C" int gpv_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, int dtype, void* stream) {
   const uint32_t th = drop_thresh(p);
   const float sc = 1.f / (1.f - p);
   dim3 g(grid1d(n, 256)), b(256);
-  if (dtype == GPV_BF16) hipLaunchKernelGGL((dropout_kernel<bf16>), g, b, 0, ST(stream), (const bf16*)x, (bf16*)y, n, th, sc, seed);
-  else hipLaunchKernelGGL((dropout_kernel<float>), g, b, 0, ST(stream), (const float*)x, (float*)y, n, th, sc, seed);
+  if (dtype == GPV_BF16) hipLaunchKernelGGL((dropout_kernel<bf16>), g, b, 0, ST(stream), (const bf16*)x, (bf16*)y, n, th, sc, seed, gpvk::g_seed_dev);
+  else hipLaunchKernelGGL((dropout_kernel<float>), g, b, 0, ST(stream), (const float*)x, (float*)y, n, th, sc, seed, gpvk::g_seed_dev);
   GPV_CHECK_LAUNCH();
   return 0;
 }

@@ -139,5 +139,7 @@ class GreedyKVDecoder:
             # launches never fault, event waits do not help, a stream sync every <=4 decodes does).  The sync costs
             # no GPU time: the next call's encoder is host-issued in ~20 ms either way.
             torch.cuda.current_stream().synchronize()
-        out = self.logits.float() + self.vocab_mask if vocab_mask is not None else self.logits
+        # fresh tensors like the reference returns: self.logits is this decoder's persistent buffer, the next decode of
+        # the same (batch, memory length) overwrites it
+        out = self.logits.float() + self.vocab_mask if vocab_mask is not None else self.logits.clone()
         return out.unsqueeze(0), self.ids.clone()

@@ -118,7 +118,8 @@ class GPV(nn.Module):
         self.detr = create_detr_roi_head(cfg.detr) if cfg.roi_head is True else create_detr(cfg.detr)
         self.detr_joiner = LinearP(cfg.detr_joiner.detr_dim, cfg.detr_joiner.out_dim)
         self.init_detr_params = []
-        self.bert = Bert(num_layers=cfg.get('bert_layers', 12) if isinstance(cfg, dict) else 12)
+        self.bert = Bert(num_layers=cfg.get('bert_layers', 12) if isinstance(cfg, dict) else 12,
+                         weights=cfg.get('bert_weights') if isinstance(cfg, dict) else None)    # model.bert_weights: local bert-base-uncased
         if isinstance(cfg, dict) and cfg.get('bert_dropout') is not None:          # test knob; the reference keeps HF's 0.1
             self.bert.model.p = float(cfg.get('bert_dropout'))
         self.bert_joiner = LinearP(cfg.bert_joiner.bert_dim, cfg.bert_joiner.out_dim)

@@ -71,7 +71,7 @@ EXPORTS = ['gpv_abi_version', 'gpv_set_option', 'gpv_gemm', 'gpv_conv2d', 'gpv_i
            'gpv_attention_fwd', 'gpv_attention_bwd', 'gpv_layernorm_fwd', 'gpv_layernorm_bwd',
            'gpv_softmax_ce', 'gpv_roi_weights', 'gpv_add', 'gpv_add_rowbcast', 'gpv_colsum', 'gpv_cast',
            'gpv_cast_rowscale_t', 'gpv_prep_conv_weight', 'gpv_embedding', 'gpv_dropout',
-           'gpv_relevance_condition', 'gpv_adamw', 'gpv_sumsq', 'gpv_act_fwd', 'gpv_act_bwd']
+           'gpv_relevance_condition', 'gpv_adamw', 'gpv_sumsq', 'gpv_act_fwd', 'gpv_act_bwd', 'gpv_set_seed_device']
 
 
 OPT_GLDS, OPT_GLDS_LAUNCHES, OPT_SKINNY, OPT_GLDS_WGRAD, OPT_PIPE, OPT_PIPE_LAUNCHES = 0, 1, 2, 3, 4, 5
@@ -80,6 +80,19 @@ OPT_GLDS, OPT_GLDS_LAUNCHES, OPT_SKINNY, OPT_GLDS_WGRAD, OPT_PIPE, OPT_PIPE_LAUN
 def set_option(option, value):
     """gpv_set_option: kernel-selection knob (tests / tuning); returns the previous value"""
     return lib().gpv_set_option(C.c_int(option), C.c_int(value))
+
+
+_SEED_DEV = None
+
+
+def set_seed_device(t):
+    """gpv_set_seed_device: lend the library one device int64 word as the dropout seed epoch (None: back to plain seeds).
+    The tensor is kept alive here for as long as it is installed."""
+    global _SEED_DEV
+    if t is not None and (t.dtype != torch.int64 or t.numel() != 1 or not t.is_cuda):
+        raise TypeError('seed epoch must be a 1-element int64 device tensor')
+    _chk(lib().gpv_set_seed_device(_p(t)), 'gpv_set_seed_device')
+    _SEED_DEV = t
 
 
 def dcode(t):

@@ -31,10 +31,22 @@ class Runtime:
         self._ctr = 0
         self.cache = {}
         self.backward_milestone = None   # set by train.FlatTrainer for the duration of a backward pass (gradient-exchange overlap)
+        self.split = None                # set by train.GraphedBody while it captures / replays: the backbone runs outside autograd
+        self.seed_dev = None             # device int64 word lent to the library as the dropout seed epoch (hipGraph replays)
 
     def set_precise(self, on=True):
         self.dtype = torch.float32 if on else torch.bfloat16
         self.cache.clear()
+        # the compute copies just freed are baked into every captured graph (GPV._igraphs, GreedyKVDecoder.graphs,
+        # train.GraphedBody): their keys carry the epochs, so bumping them retires those graphs
+        self.bump_weights()
+
+    def enable_seed_epoch(self, device):
+        """install the device-resident seed epoch (include/gpv_hip.h: gpv_set_seed_device); idempotent"""
+        if self.seed_dev is None or self.seed_dev.device != torch.device(device):
+            self.seed_dev = torch.zeros(1, dtype=torch.int64, device=device)
+            hip.set_seed_device(self.seed_dev)
+        return self.seed_dev
 
     def bump_weights(self, everything=True):
         """call after parameters changed.  everything=False: only the parameters a trainer manages changed

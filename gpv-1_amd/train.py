@@ -49,10 +49,168 @@ def warmup_linear(step, warmup_steps, t_total):
     return max(0.0, float(t_total - step) / float(max(1.0, t_total - warmup_steps)))
 
 
+class GraphedBody:
+    """Forward and backward of the model body (everything of train_distr.py:413-421 between the host-side tokenisation and
+    the criterion) as hipGraphs, for one static input signature (image / query / answer-token shapes).
+
+    Why: a training step is ~1500 kernel launches issued from Python at ~12 us each -- 18 ms of host work per step
+    (tools/host_floor.py) against < 26 ms of GPU work; below that the host is the bound.  Replayed graphs cost ~15 us each.
+
+    Shape of the capture (torch.cuda.CUDAGraph; our kernels are launched on the capturing stream through the C ABI):
+      F1  backbone forward            images -> c5                      (called outside autograd: ops.RT.split)
+      F2  rest of the forward         c5 (autograd leaf) -> outputs dict
+      --  criterion: EAGER (Hungarian matcher + set criterion stay on the host by north_star; the text cross-entropy
+          is one kernel); its tiny autograd graph ends at detached copies of the outputs
+      B1  backward of F2              d(outputs) -> parameter gradients (accumulated by the kernels) + d(c5)
+      B2  backbone backward           d(c5) -> backbone parameter gradients
+    B1 exists once per set of outputs that carry a gradient (answer logits / box + relevance outputs): a caption-only batch
+    must leave the box head untouched (torch-1.6 optimizer semantics), so its B1 never visits it.
+    F1 | F2 and B1 | B2 are separate graphs because the trainer hands the gradient buckets behind the backbone segment to
+    RCCL between B1 and B2 (the overlap of train_distr.py's DDP), and bench.py brackets F1 / B2 with HIP events.
+    Dropout: the seed argument of a captured launch is frozen, the device-resident seed epoch (gpv_set_seed_device) is
+    bumped once per replayed step; forward and backward of a step read the same value.
+    Optimizer, gradient exchange and clip stay eager (a dozen launches; their scalars change every step)."""
+
+    GRAD_KEYS = ('answer_logits', 'pred_relevance_logits', 'pred_boxes')
+
+    def __init__(self, trainer, images, queries, tok):
+        from .misc import NestedTensor
+        self.tr = trainer
+        model = trainer.model
+        dev = images.tensors.device
+        self.s_img, self.s_mask = images.tensors.clone(), images.mask.clone()
+        self.all_valid = getattr(images, 'all_valid', None)
+        self.s_ids, self.s_attn = queries[0].clone(), queries[1].clone()
+        self.s_tok = tok.clone()
+        self.epochs = (RT.static_epoch, RT.dtype)
+        self.keep, self.c5, self.c5_leaf = None, None, None
+        self.variants = {}
+        RT.enable_seed_epoch(dev)
+        torch.cuda.synchronize()
+        gc.collect()
+        self.pool = torch.cuda.graph_pool_handle()
+        self.f1, self.f2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        saved = trainer.touched.clone()
+        assert torch.cuda.current_stream(dev) == trainer.stream            # captures run on the trainer's side stream
+        RT.split = self
+        try:
+            self.f1.capture_begin(pool=self.pool)
+            self.outs = model._forward_impl(NestedTensor(self.s_img, self.s_mask, self.all_valid), (self.s_ids, self.s_attn),
+                                            self.s_tok, None)
+            self.f2.capture_end()
+        finally:
+            RT.split = None
+        self.fwd_touched = trainer.touched.clone()            # (forward kernels never write gradients: stays empty)
+        trainer.touched |= saved
+
+    # called by backbone.BackboneBase.forward while this body is being captured (ops.RT.split)
+    def backbone_forward(self, body, x):
+        self.keep = []
+        c5 = body.forward_nhwc(x, self.keep)
+        self.f1.capture_end()
+        self.f2.capture_begin(pool=self.pool)
+        self.c5 = c5
+        self.c5_leaf = c5.detach().requires_grad_(True)
+        self.body = body
+        return self.c5_leaf
+
+    def stale(self):
+        return self.epochs != (RT.static_epoch, RT.dtype)
+
+    def forward(self, images, queries, tok):
+        """replay F1 + F2 on the current stream; returns the outputs dict as fresh autograd leaves"""
+        from . import backbone as bbm
+        self.s_img.copy_(images.tensors, non_blocking=True)
+        self.s_mask.copy_(images.mask, non_blocking=True)
+        self.s_ids.copy_(queries[0], non_blocking=True)
+        self.s_attn.copy_(queries[1], non_blocking=True)
+        self.s_tok.copy_(tok, non_blocking=True)
+        RT.seed_dev.add_(1)
+        ev = bbm._prof('conv_fwd')
+        self.f1.replay()
+        if ev is not None:
+            ev.record()
+        self.f2.replay()
+        leaves = {}
+        for k, v in self.outs.items():
+            if torch.is_tensor(v):
+                leaves[k] = v.detach().requires_grad_(v.requires_grad and k in self.GRAD_KEYS)
+            elif k == 'aux_outputs':
+                leaves[k] = [{kk: vv.detach().requires_grad_(vv.requires_grad) for kk, vv in a.items()} for a in v]
+            else:
+                leaves[k] = v
+        return leaves
+
+    def _roots(self, leaves):
+        """(static output, gradient of its leaf) pairs for every output the criterion reached"""
+        pairs = []
+        for k in self.GRAD_KEYS:
+            if k in leaves and leaves[k].grad is not None:
+                pairs.append((k, self.outs[k], leaves[k].grad))
+        for i, a in enumerate(leaves.get('aux_outputs', ())):
+            for kk, vv in a.items():
+                if vv.grad is not None:
+                    pairs.append((('aux', i, kk), self.outs['aux_outputs'][i][kk], vv.grad))
+        return pairs
+
+    def backward(self, leaves):
+        """d(outputs) = the .grad of the leaves forward() returned -> replay B1 (+ the trainer's milestone) + B2"""
+        from . import backbone as bbm
+        tr = self.tr
+        pairs = self._roots(leaves)
+        if not pairs:
+            return
+        vkey = tuple(k for k, _, _ in pairs)
+        var = self.variants.get(vkey)
+        if var is None:
+            var = self.variants[vkey] = self._capture_backward(pairs)
+        for (k, _, g), sg in zip(pairs, var['grads']):
+            sg.copy_(g, non_blocking=True)
+        tr.touched |= var['touched']
+        var['b1'].replay()
+        if RT.backward_milestone is not None:
+            RT.backward_milestone('backbone')
+        ev = bbm._prof('conv_bwd')
+        var['b2'].replay()
+        if ev is not None:
+            ev.record()
+
+    def _capture_backward(self, pairs):
+        tr = self.tr
+        torch.cuda.synchronize()
+        gc.collect()
+        grads = [torch.zeros_like(g) for _, _, g in pairs]
+        b1, b2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        saved = tr.touched.clone()
+        tr.touched.zero_()
+        milestone, RT.backward_milestone = RT.backward_milestone, None
+        self.c5_leaf.grad = None
+        from .ops import _DUMMY
+        for d in _DUMMY.values():
+            d.grad = None
+        b1.capture_begin(pool=self.pool)
+        torch.autograd.backward([o for _, o, _ in pairs], grads, retain_graph=True)
+        b1.capture_end()
+        dc5 = self.c5_leaf.grad
+        b2.capture_begin(pool=self.pool)
+        self.body.backward_nhwc(self.keep, dc5.to(RT.dtype))
+        b2.capture_end()
+        RT.backward_milestone = milestone
+        var = {'b1': b1, 'b2': b2, 'grads': grads, 'touched': tr.touched.clone(), 'dc5': dc5}
+        tr.touched |= saved
+        return var
+
+
 class FlatTrainer:
     def __init__(self, model, lr=1e-4, lr_backbone=1e-5, weight_decay=1e-4, clip_max_norm=0.1, warmup_steps=0,
-                 t_total=0, betas=(0.9, 0.999), eps=1e-8, bucket_mb=128, process_group=None, manual_gc=True, gc_interval=200):
+                 t_total=0, betas=(0.9, 0.999), eps=1e-8, bucket_mb=128, process_group=None, manual_gc=True, gc_interval=200,
+                 graphs=None, lr_milestones=None, lr_drop=0.1, warmup_iters=0):
         self.model = model
+        self.milestones, self.lr_drop, self.warmup_iters = (list(lr_milestones) if lr_milestones is not None else None), lr_drop, warmup_iters
+        self.epoch, self.it_in_epoch = 0, 0
+        # hipGraph replay of the model body (GraphedBody): default on for bf16 on the GPU; GPV_TRAIN_GRAPHS=0 turns it off
+        self.graphs = (os.environ.get('GPV_TRAIN_GRAPHS', '1') != '0') if graphs is None else bool(graphs)
+        self._bodies, self._seen, self.stream = {}, {}, None
         # Python's cyclic collector costs 1-3 ms per step once it has a few hundred thousand module / tensor objects to
         # walk (measured: 970-1020 vs 1062-1070 images/s over 20 steps), while a step leaves ~17 small cycles and no
         # device memory behind (tools/gc_growth.py).  With manual_gc the trainer freezes the long-lived objects, turns
@@ -73,6 +231,8 @@ class FlatTrainer:
             off += (p.numel() + 7) // 8 * 8                                          # keep every segment 32-B aligned
         self.total = off
         dev = named[0][1].device
+        if self.graphs and dev.type == 'cuda':
+            self.stream = torch.cuda.Stream(device=dev)
         self.P = torch.zeros(off, device=dev, dtype=torch.float32)
         self.G = torch.zeros_like(self.P)
         self.M = torch.zeros_like(self.P)
@@ -82,6 +242,8 @@ class FlatTrainer:
         # device: which parameters any rank has ever written (torch-1.6 optimizers skip the rest).  The AdamW kernel reads
         # it through seg_id (parameter index of every 8-element chunk), so no host round trip is needed to pick ranges.
         self.live = torch.zeros(len(self.entries), device=dev, dtype=torch.int32)
+        # per-parameter Adam step counts (torch keeps `step` per parameter, starting at its first gradient): += live per step
+        self.pstep = torch.zeros(len(self.entries), device=dev, dtype=torch.int32)
         sid = torch.zeros(off // 8, dtype=torch.int16)
         for i, (n, p, g, o, k) in enumerate(self.entries):
             sid[o // 8:(o + k + 7) // 8] = i
@@ -211,7 +373,7 @@ class FlatTrainer:
 
     def step(self):
         """clip_grad_norm_(detr params) + AdamW + schedule (train_distr.py:423-428,468-469)"""
-        sched = warmup_linear(self.step_count, self.warmup_steps, self.t_total) if self.t_total > 0 else 1.0
+        sched = self.lr_factor()
         use_clip = self.clip is not None and self.clip > 0
         self._publish_touched()
         if use_clip:
@@ -230,42 +392,139 @@ class FlatTrainer:
         self.step_count += 1
         t = self.step_count
         b1, b2 = self.betas
-        bc1, bc2 = 1 - b1 ** t, 1 - b2 ** t
+        bc1, bc2 = 1 - b1 ** t, 1 - b2 ** t                                   # (unused by the kernel when the per-parameter counts are given)
+        self.pstep.add_(self.live)
         for g, (s, e) in self.group_range.items():                           # one launch per group; the kernel skips dead parameters
             clip_here = use_clip and g in ('detr_backbone', 'detr_head')
             hip.adamw(self.P[s:e], self.G[s:e], self.M[s:e], self.V[s:e], self.Pb[s:e], e - s, self.lr[g] * sched, b1, b2,
                       self.eps, self.wd, bc1, bc2, self.gscale if clip_here else None,
-                      seg_id=self.seg_id[s // 8:e // 8], seg_live=self.live)
+                      seg_id=self.seg_id[s // 8:e // 8], seg_live=self.pstep)
         RT.bump_weights(everything=False)
 
     # ---- checkpointing (train_distr.py:381-389 saves optimizer.state_dict() + the warm-up scheduler's) ----
-    def state_dict(self):
-        """optimizer + schedule state, keyed by parameter NAME so that it survives a different flattening order"""
-        st = {}
-        live = self.live_host()
-        for i, (n, p, g, o, k) in enumerate(self.entries):
-            st[n] = {'exp_avg': self.M[o:o + k].detach().cpu().clone(), 'exp_avg_sq': self.V[o:o + k].detach().cpu().clone(),
-                     'touched': bool(live[i])}
-        return {'state': st, 'step': self.step_count, 'warmup_steps': self.warmup_steps, 't_total': self.t_total,
-                'lr': dict(self.lr), 'weight_decay': self.wd, 'betas': tuple(self.betas), 'eps': self.eps}
+    def _torch_param_order(self):
+        """the reference's optimizer parameter numbering: four groups (train_distr.py:228-253) filled in
+        model.named_parameters() order -- EVERY parameter, trainable or not -- numbered consecutively group after group"""
+        groups = {g: [] for g in GROUPS}
+        for n, p in self.model.named_parameters():
+            groups[param_group_of(n)].append(n)
+        order, idx = [], 0
+        for g in GROUPS:
+            order.append((g, list(range(idx, idx + len(groups[g]))), groups[g]))
+            idx += len(groups[g])
+        return order
 
-    def load_state_dict(self, sd):
-        self.step_count = int(sd['step'])
-        for i, (n, p, g, o, k) in enumerate(self.entries):
-            e = sd['state'].get(n)
-            if e is None or e['exp_avg'].numel() != k:
-                continue
-            self.M[o:o + k].copy_(e['exp_avg'])
-            self.V[o:o + k].copy_(e['exp_avg_sq'])
-            self.touched[i] = bool(e['touched'])
+    def state_dict(self):
+        """optimizer state in torch.optim.AdamW.state_dict() layout (what the reference's checkpoints hold,
+        train_distr.py:381-389): {'state': {param index: {'step', 'exp_avg', 'exp_avg_sq'}}, 'param_groups': [4 groups]}
+        with the reference's parameter numbering; only parameters that have taken a step have state, like torch's.
+        Extra keys ('gpv1_amd': names, schedule position) make it self-describing; torch ignores them."""
+        by_name = {n: (p, o, k, i) for i, (n, p, g, o, k) in enumerate(self.entries)}
+        pstep = self.pstep.cpu()
+        state, groups, names = {}, [], {}
+        b1, b2 = self.betas
+        sched = self.lr_factor()
+        for g, ids, ns in self._torch_param_order():
+            for pid, n in zip(ids, ns):
+                names[pid] = n
+                e = by_name.get(n)
+                if e is None or int(pstep[e[3]]) == 0:
+                    continue
+                p, o, k, i = e
+                shape = p.shape
+                state[pid] = {'step': torch.tensor(float(pstep[i])),
+                              'exp_avg': self._view(self.M, p, o, k).detach().cpu().clone().contiguous().view(shape),
+                              'exp_avg_sq': self._view(self.V, p, o, k).detach().cpu().clone().contiguous().view(shape)}
+            groups.append({'params': ids, 'lr': self.lr[g] * sched, 'initial_lr': self.lr[g], 'betas': (b1, b2), 'eps': self.eps,
+                           'weight_decay': self.wd, 'amsgrad': False, 'maximize': False, 'foreach': None, 'capturable': False,
+                           'differentiable': False, 'fused': None})
+        return {'state': state, 'param_groups': groups,
+                'gpv1_amd': {'names': names, 'step': self.step_count, 'warmup_steps': self.warmup_steps, 't_total': self.t_total,
+                             'epoch': self.epoch}}
+
+    def load_state_dict(self, sd, step=None):
+        """accepts a torch.optim.AdamW state dict with the reference's parameter numbering (a reference checkpoint's
+        'optimizer', or state_dict() above) and the name-keyed format this trainer wrote in round 1.  `step`: the global
+        step of the checkpoint (ckpt['step'], train_distr.py:275) when the dict itself does not carry it."""
+        if 'param_groups' not in sd:                                          # round-1 format: {'state': {name: ...}, 'step': ...}
+            self.step_count = int(sd['step'])
+            pstep = torch.zeros(len(self.entries), dtype=torch.int32)
+            for i, (n, p, g, o, k) in enumerate(self.entries):
+                e = sd['state'].get(n)
+                if e is None or e['exp_avg'].numel() != k:
+                    continue
+                self.M[o:o + k].copy_(e['exp_avg'].reshape(-1))
+                self.V[o:o + k].copy_(e['exp_avg_sq'].reshape(-1))
+                if e.get('touched'):
+                    self.touched[i] = True
+                    pstep[i] = self.step_count
+            self.pstep.copy_(pstep)
+            self._publish_touched()
+            return
+        extra = sd.get('gpv1_amd', {})
+        self.step_count = int(extra.get('step', step if step is not None else 0))
+        if 'epoch' in extra:
+            self.epoch = int(extra['epoch'])
+        by_name = {n: (p, o, k, i) for i, (n, p, g, o, k) in enumerate(self.entries)}
+        pstep = torch.zeros(len(self.entries), dtype=torch.int32)
+        taken = 0
+        for g, ids, ns in self._torch_param_order():
+            for pid, n in zip(ids, ns):
+                st = sd['state'].get(pid, sd['state'].get(str(pid)))
+                e = by_name.get(n)
+                if st is None or e is None:
+                    continue
+                p, o, k, i = e
+                if st['exp_avg'].numel() != k:
+                    continue
+                self._view(self.M, p, o, k).copy_(st['exp_avg'].view(p.shape))
+                self._view(self.V, p, o, k).copy_(st['exp_avg_sq'].view(p.shape))
+                pstep[i] = int(float(st['step']))
+                self.touched[i] = True
+                taken += 1
+        self.pstep.copy_(pstep)
         self._publish_touched()
+        return taken
+
+    def lr_factor(self):
+        """multiplier on every group's base learning rate for the NEXT optimizer step.
+        lr_linear_decay (configs/exp/gpv.yaml:142, the shipped setting): WarmupLinearSchedule stepped per iteration
+        (train_distr.py:298-302,468-469).  Otherwise (train_distr.py:288-292,303-308,470-474): MultiStepLR(lr_milestones,
+        lr_drop) stepped per EPOCH times GradualWarmupScheduler(multiplier=1, total_epoch=iterations of epoch 0) during epoch 0."""
+        if self.t_total > 0:
+            return warmup_linear(self.step_count, self.warmup_steps, self.t_total)
+        f = 1.0
+        if self.milestones is not None:
+            f = self.lr_drop ** sum(1 for m in self.milestones if self.epoch >= m)
+        if self.warmup_iters > 0 and self.epoch == 0 and self.it_in_epoch < self.warmup_iters:
+            f *= float(self.it_in_epoch) / float(self.warmup_iters)
+        return f
+
+    def set_epoch(self, epoch, it_in_epoch=0):
+        """position inside the run for the MultiStepLR / GradualWarmup schedule (train_distr.train_worker calls it per iteration)"""
+        self.epoch, self.it_in_epoch = int(epoch), int(it_in_epoch)
 
     def current_lrs(self):
-        sched = warmup_linear(self.step_count, self.warmup_steps, self.t_total) if self.t_total > 0 else 1.0
+        sched = self.lr_factor()
         return {g: lr * sched for g, lr in self.lr.items()}
 
     def train_step(self, images, queries, targets):
-        """one iteration of train_distr.py:399-428; returns the loss tensor (or None: no applicable target)"""
+        """one iteration of train_distr.py:399-428; returns the (detached) loss tensor, or None: no applicable target.
+
+        With graphs on, the whole step -- eager warm-up steps, captures, replays, optimizer -- runs on ONE dedicated side
+        stream: hipGraph capture needs a non-default stream, and autograd's AccumulateGrad nodes remember the stream they
+        were created on (a node made on the default stream by an earlier eager step and kept alive by a stashed loss would
+        make the captured backward synchronise with the legacy stream, which is illegal during capture)."""
+        if self.stream is None:
+            return self._train_step_impl(images, queries, targets)
+        cur = torch.cuda.current_stream(self.stream.device)
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            loss = self._train_step_impl(images, queries, targets)
+        cur.wait_stream(self.stream)
+        return loss
+
+    def _train_step_impl(self, images, queries, targets):
         model = self.model
         if self.manual_gc:
             if not self._gc_armed:
@@ -278,6 +537,9 @@ class FlatTrainer:
         _, answer_token_ids = model.encode_answers(targets)
         for i, t in enumerate(targets):
             t['answer_token_ids'] = answer_token_ids[i, 1:]
+        body = self._graphed_body(images, queries, answer_token_ids)
+        if body is not None:
+            return self._train_step_graphed(body, images, queries, answer_token_ids, targets)
         loss = model(images, queries, answer_token_ids, targets)
         # The reference skips the update when no criterion applies to the batch (losses.py:163-169, train_distr.py:420); under
         # its DDP a rank-local skip leaves the other ranks waiting in the gradient all-reduce forever.  Here the ranks agree on
@@ -291,7 +553,47 @@ class FlatTrainer:
             loss.backward()
         self.allreduce_grads()
         self.step()
-        return loss
+        return None if loss is None else loss.detach()     # (a stashed loss would keep the step's autograd graph alive)
+
+    # ---- hipGraph path ----
+    def _graphed_body(self, images, queries, tok):
+        """the GraphedBody for this batch signature, captured the second time the signature is seen (the first, eager,
+        step is the warm-up: weight copies, kernel attributes, workspaces); None -> eager step"""
+        from .misc import NestedTensor
+        if not self.graphs or not isinstance(images, NestedTensor) or not torch.is_tensor(images.tensors) \
+                or not images.tensors.is_cuda or images.mask is None or RT.dtype != torch.bfloat16 \
+                or not isinstance(queries, (tuple, list)) or len(queries) != 2 or not all(torch.is_tensor(q) for q in queries) \
+                or torch.cuda.is_current_stream_capturing():
+            return None
+        key = (tuple(images.tensors.shape), images.tensors.dtype, getattr(images, 'all_valid', None), tuple(queries[0].shape),
+               tuple(tok.shape))
+        body = self._bodies.get(key)
+        if body is not None and body.stale():
+            del self._bodies[key]
+            body = None
+        if body is None:
+            n = self._seen.get(key, 0)
+            self._seen[key] = n + 1
+            if n < 1:
+                return None
+            if len(self._bodies) >= int(os.environ.get('GPV_TRAIN_GRAPH_SLOTS', '4')):       # each body pins its activations
+                return None
+            body = self._bodies[key] = GraphedBody(self, images, queries, tok)
+        return body
+
+    def _train_step_graphed(self, body, images, queries, tok, targets):
+        outs = body.forward(images, queries, tok)
+        loss = self.model.criterion(outs, targets)[0]
+        if not self._any_rank_has_loss(loss is not None):
+            return None
+        self.zero_grad()
+        self.begin_backward()
+        if loss is not None:
+            loss.backward()
+            body.backward(outs)
+        self.allreduce_grads()
+        self.step()
+        return None if loss is None else loss.detach()
 
     def _any_rank_has_loss(self, has):
         if self.world == 1:

@@ -114,7 +114,7 @@ def load_checkpoint(path, model, trainer=None, map_location='cpu'):
             taken += 1
     model.load_state_dict(cur)
     if trainer is not None and ckpt.get('optimizer') is not None:
-        trainer.load_state_dict(ckpt['optimizer'])
+        trainer.load_state_dict(ckpt['optimizer'], step=ckpt.get('step'))      # torch.optim.AdamW layout (reference checkpoints) or round-1 layout
     return ckpt, taken
 
 
@@ -146,11 +146,23 @@ def train_worker(cfg, dataset=None, device=None, log=print):
         dataset = SyntheticCocoDataset(int(cfg.get('synthetic_samples', 4 * batch_size)), model.vocab)
     steps_per_epoch = (-(-len(dataset) // world)) // per_rank
     t_total = steps_per_epoch * epochs if tr_cfg.lr_linear_decay else 0
+    have_ckpt = tr_cfg.ckpt is not None and os.path.exists(str(tr_cfg.ckpt))
+    if not model.bert.pretrained and not have_ckpt:
+        # the reference's query encoder is BertModel.from_pretrained('bert-base-uncased') (bert.py:8-9), frozen: training against
+        # a random-init BERT is only meaningful for throughput / plumbing runs
+        log(f'[rank {rank}] WARNING: BERT has random weights (no model.bert_weights / GPV_BERT_WEIGHTS and no checkpoint): '
+            f'the frozen query encoder is NOT bert-base-uncased')
+        if cfg.get('require_pretrained_bert', False):
+            raise RuntimeError('training.require_pretrained_bert is set and no BERT weights were given')
+    sched = {}
+    if not tr_cfg.lr_linear_decay:                         # MultiStepLR per epoch x GradualWarmup over epoch 0 (train_distr.py:288-308)
+        sched = {'lr_milestones': list(tr_cfg.get('lr_milestones', []) or []), 'lr_drop': tr_cfg.get('lr_drop', 0.1),
+                 'warmup_iters': steps_per_epoch if tr_cfg.lr_warmup else 0}
     trainer = FlatTrainer(model, lr=tr_cfg.lr, lr_backbone=tr_cfg.lr_backbone, weight_decay=tr_cfg.weight_decay,
                           clip_max_norm=tr_cfg.clip_max_norm,
-                          warmup_steps=int(tr_cfg.lr_warmup_fraction * t_total) if tr_cfg.lr_warmup else 0, t_total=t_total)
+                          warmup_steps=int(tr_cfg.lr_warmup_fraction * t_total) if tr_cfg.lr_warmup else 0, t_total=t_total, **sched)
     step, last_epoch = 0, -1
-    if tr_cfg.ckpt is not None and os.path.exists(str(tr_cfg.ckpt)):
+    if have_ckpt:
         ckpt, taken = load_checkpoint(tr_cfg.ckpt, model, trainer, map_location=device)
         step, last_epoch = ckpt['step'], ckpt['epoch']
         log(f'[rank {rank}] resumed {tr_cfg.ckpt}: {taken} tensors, end of epoch {last_epoch}, step {step}')
@@ -161,19 +173,24 @@ def train_worker(cfg, dataset=None, device=None, log=print):
     t0 = time.time()
     for epoch in range(last_epoch + 1, epochs):
         idx = shard_indices(len(dataset), epoch, rank, world)
-        for imgs, queries, targets in batches(dataset, idx, per_rank, device):
+        for it, (imgs, queries, targets) in enumerate(batches(dataset, idx, per_rank, device)):
+            trainer.set_epoch(epoch, it)
             loss = trainer.train_step(imgs, queries, targets)
             step += 1
             if rank == 0 and step % tr_cfg.log_step == 0:
                 log(f'epoch {epoch} step {step} loss {float(loss.detach()) if loss is not None else float("nan"):.4f} '
                     f'lr {trainer.current_lrs()["others"]:.3e} {time.time() - t0:.1f}s')
             if rank == 0 and step % tr_cfg.ckpt_step == 0:
+                # like the reference's mid-epoch save (train_distr.py:372-389: 'epoch': epoch-1 next to the CURRENT step): a
+                # resume re-runs this epoch from its start while the schedule continues from `step` -- the reference's behaviour,
+                # kept as is (with lr_linear_decay the tail of such a run sits at lr 0 once step passes t_total)
                 save_checkpoint(ckpt_path, model, trainer, epoch - 1, step)
             if max_steps is not None and step >= max_steps:
                 break
+        stopped = max_steps is not None and step >= max_steps
         if rank == 0:
-            save_checkpoint(ckpt_path, model, trainer, epoch, step)
-        if max_steps is not None and step >= max_steps:
+            save_checkpoint(ckpt_path, model, trainer, epoch - 1 if stopped and it + 1 < steps_per_epoch else epoch, step)
+        if stopped:
             break
     if world > 1:
         dist.barrier()

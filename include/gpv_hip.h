@@ -196,6 +196,13 @@ int gpv_embedding(const void* table, const int64_t* ids, void* out, int64_t n_id
 int gpv_act_fwd(const void* x, void* y, int64_t n, int act, int dtype, void* stream);
 int gpv_act_bwd(const void* dy, const void* ref, void* dx, int64_t n, int act, float alpha, int dtype, void* stream);
 int gpv_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, int dtype, void* stream);
+/* Device-resident seed epoch for captured launches (process-wide, like gpv_set_option).  The reference draws fresh dropout masks
+ * from torch's device RNG state on every step (nn.Dropout / F.dropout in exp/gpv/models/transformer.py:156-160, vilbert.py);
+ * a launch recorded in a hipGraph has its `seed` argument frozen, so the caller lends ONE device word: every dropout consumer
+ * (gpv_gemm epilogue, gpv_attention_*, gpv_layernorm_*, gpv_dropout) then uses seed ^ mix(*epoch), read at kernel run time.
+ * The caller bumps the word once per step, before the forward; forward and backward of a step see the same value.
+ * epoch == NULL (default) restores the plain `seed` argument.  The pointer must stay valid while launches can run. */
+int gpv_set_seed_device(const uint64_t* epoch);
 /* relevance conditioning gpv.py:364-375: y = x + softmax(logits)[.,0]*tok[0] + softmax(logits)[.,1]*tok[1] */
 int gpv_relevance_condition(const void* x, const float* logits, const float* tokens, void* y, int rows,
                             int dim, int dtype, void* stream);
@@ -207,9 +214,11 @@ int gpv_adamw(float* p, const float* g, float* m, float* v, void* p_lowp, int64_
               float beta2, float eps, float wd, float bc1, float bc2, const float* gscale,
               const uint16_t* seg_id, const int32_t* seg_live, void* stream);
 /* seg_id / seg_live (both or neither): element i belongs to parameter seg_id[i / 8] (parameters start on multiples of 8
- * elements) and is updated only if seg_live[that id] != 0.  The set of parameters that have ever received a gradient
- * (torch-1.6 optimizers skip the others, train_distr.py:423-428) then lives on the DEVICE: it can be MAX-all-reduced
- * across ranks and consumed by the update without a host round trip. */
+ * elements); seg_live[that id] is the parameter's OWN Adam step count including this step, 0 = it has never received a
+ * gradient and is left untouched (torch-1.6 optimizers skip parameters whose .grad is None, incl. their weight decay).
+ * When given, the bias corrections are computed per parameter from that count (torch keeps `step` per parameter, starting
+ * at its first gradient) and bc1 / bc2 are ignored.  The counts live on the device (agreed across ranks with a MAX
+ * all-reduce of the "ever touched" flags), so picking the live parameters costs no host round trip. */
 int gpv_sumsq(const float* x, int64_t n, float* out /* += */, void* stream);
 
 #ifdef __cplusplus

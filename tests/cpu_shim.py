@@ -262,10 +262,15 @@ def adamw(p, g, m, v, p_lowp, n, lr, beta1, beta2, eps, wd, bc1, bc2, gscale=Non
     p2 = p * (1 - lr * wd)
     m2 = m * beta1 + gi * (1 - beta1)
     v2 = v * beta2 + gi * gi * (1 - beta2)
-    p2 = p2 - (lr / bc1) * m2 / (v2.sqrt() / math.sqrt(bc2) + eps)
-    if seg_id is not None:
-        live = seg_live[seg_id[:(n + 7) // 8].long()].bool().repeat_interleave(8)[:n]
+    if seg_id is not None:           # seg_live = per-parameter Adam step count (0 = never touched): per-parameter bias corrections
+        t = seg_live[seg_id[:(n + 7) // 8].long()].repeat_interleave(8)[:n].double()
+        live = t > 0
+        c1 = (1 - beta1 ** t.clamp(min=1)).float()
+        c2 = (1 - beta2 ** t.clamp(min=1)).float()
+        p2 = p2 - (lr / c1) * m2 / (v2.sqrt() / c2.sqrt() + eps)
         p2, m2, v2 = torch.where(live, p2, p), torch.where(live, m2, m), torch.where(live, v2, v)
+    else:
+        p2 = p2 - (lr / bc1) * m2 / (v2.sqrt() / math.sqrt(bc2) + eps)
     p.copy_(p2); m.copy_(m2); v.copy_(v2)
     if p_lowp is not None:
         p_lowp.copy_(p.to(p_lowp.dtype))

@@ -269,10 +269,12 @@ def glds(request):
     h = hip()
     prev = h.set_option(h.OPT_GLDS, request.param)
     prevs = h.set_option(h.OPT_SKINNY, 0)
+    prevp = h.set_option(h.OPT_PIPE, 0)                  # (the pipelined kernel is tried first: off for these cases)
     h.set_option(h.OPT_GLDS_LAUNCHES, 0)
     yield h
     h.set_option(h.OPT_GLDS, prev)
     h.set_option(h.OPT_SKINNY, prevs)
+    h.set_option(h.OPT_PIPE, prevp)
 
 
 @pytest.mark.parametrize('M,N,K', [(300, 256, 256), (2048, 512, 768), (1000, 128, 192), (257, 130, 64), (9600, 256, 2048),
@@ -314,6 +316,56 @@ def test_glds_gemm_epilogue_and_batch(glds):
     h.gemm(A, B, c2, M, N, K, K, K, N, drop_p=0.25, seed=77)
     h.set_option(h.OPT_GLDS, 2)
     assert torch.equal(c1 == 0, c2 == 0) and rel(c1, c2.float()) < 1e-2
+
+
+PIPE_CFGS = [(256, 128), (192, 128), (128, 128), (160, 256), (128, 256), (96, 256)]     # gemm_pipe.hip: kCfgs
+
+
+@pytest.fixture(params=range(len(PIPE_CFGS)), ids=['%dx%d' % c for c in PIPE_CFGS])
+def pipe(request):
+    """force tile configuration i of the three-stage pipelined direct-to-LDS kernel (gemm_pipe.hip) wherever it is legal"""
+    h = hip()
+    prev = h.set_option(h.OPT_PIPE, 100 + request.param)
+    prevs = h.set_option(h.OPT_SKINNY, 0)
+    h.set_option(h.OPT_PIPE_LAUNCHES, 0)
+    h.bn = PIPE_CFGS[request.param][1]
+    yield h
+    h.set_option(h.OPT_PIPE, prev)
+    h.set_option(h.OPT_SKINNY, prevs)
+
+
+@pytest.mark.parametrize('M,N,K', [(300, 256, 256), (2048, 512, 768), (1000, 128, 192), (9600, 256, 2048), (70, 384, 128), (257, 768, 64)])
+def test_pipe_gemm_plain_epilogue_batch(pipe, M, N, K):
+    h, dtype = pipe, torch.bfloat16
+    A, B = rnd(M, K, dtype=dtype, seed=1), rnd(N, K, dtype=dtype, seed=2)
+    ref = A.float() @ B.float().t()
+    Cm = torch.empty(M, N, device=DEV, dtype=dtype)
+    h.gemm(A, B, Cm, M, N, K, K, K, N)
+    legal = N % h.bn == 0 and K >= 128                               # (a k-loop of >= 2 tiles, whole column tiles)
+    assert h.set_option(h.OPT_PIPE_LAUNCHES, 0) == int(legal)
+    assert rel(Cm, ref) < TOL[dtype]
+    bias, rs = rnd(N, seed=5), rnd(M, seed=6)
+    res, mask = rnd(M, N, dtype=dtype, seed=7), rnd(M, N, dtype=dtype, seed=8)
+    for act, fn in ((h.ACT_NONE, lambda x: x), (h.ACT_RELU, F.relu), (h.ACT_GELU, lambda x: F.gelu(x))):
+        h.gemm(A, B, Cm, M, N, K, K, K, N, alpha=0.5, rowscale=rs, bias=bias, res=res, ldr=N, relu_mask=mask, ldm=N, act=act)
+        r2 = fn(0.5 * ref * rs[:, None] + bias + res.float()) * (mask.float() > 0)
+        assert rel(Cm, r2) < TOL[dtype], act
+    assert h.set_option(h.OPT_PIPE_LAUNCHES, 0) == 3 * int(legal)
+    # dropout epilogue: same keep pattern as the 4-wave kernel (counter-hash of the element index)
+    c1, c2 = torch.empty(M, N, device=DEV, dtype=dtype), torch.empty(M, N, device=DEV, dtype=dtype)
+    h.gemm(A, B, c1, M, N, K, K, K, N, drop_p=0.25, seed=77)
+    mode = h.set_option(h.OPT_PIPE, 0)
+    g = h.set_option(h.OPT_GLDS, 0)
+    h.gemm(A, B, c2, M, N, K, K, K, N, drop_p=0.25, seed=77)
+    h.set_option(h.OPT_PIPE, mode)
+    h.set_option(h.OPT_GLDS, g)
+    assert torch.equal(c1 == 0, c2 == 0) and rel(c1, c2.float()) < 1e-2
+    if M <= 2048:                                                    # batched, strided batch elements
+        Bt = 3
+        Ab, Bb = rnd(Bt, M, K, dtype=dtype, seed=3), rnd(Bt, N, K, dtype=dtype, seed=4)
+        Cb = torch.empty(Bt, M, N, device=DEV, dtype=dtype)
+        h.gemm(Ab, Bb, Cb, M, N, K, K, K, N, batch=Bt, sA=M * K, sB=N * K, sC=M * N, bias=bias)
+        assert rel(Cb, Ab.float() @ Bb.float().transpose(1, 2) + bias) < TOL[dtype]
 
 
 @pytest.fixture()
@@ -385,6 +437,16 @@ def test_skinny_gemm_reduction_major_b(skinny, M, N, K):
 GCONVS = [  # Cin, Cout, k, stride, pad, H, W   (Cin % 64 == 0 both ways, Cout > 64)
     (64, 128, 1, 1, 0, 24, 32), (256, 128, 3, 2, 1, 24, 32), (128, 128, 3, 1, 1, 15, 20), (256, 512, 1, 2, 0, 30, 40),
     (512, 2048, 1, 1, 0, 15, 20), (128, 256, 3, 2, 1, 17, 23), (128, 192, 3, 2, 1, 32, 32)]
+
+
+@pytest.mark.parametrize('Cin,Cout,k,s,p,H,W', GCONVS)
+def test_pipe_conv_fwd_dgrad(pipe, Cin, Cout, k, s, p, H, W):
+    """implicit-GEMM conv forward / backward-data through every tile configuration of the pipelined kernel, incl. the stride-2
+    dgrad parity classes, ragged last row tiles, image-crossing tiles and the 160- / 96-row tiles with uneven piece counts"""
+    test_conv_fwd_dgrad_wgrad(torch.bfloat16, Cin, Cout, k, s, p, H, W)
+    bn = pipe.bn
+    want = int(Cout % bn == 0 and k * k * Cin >= 128) + int(Cin % bn == 0 and k * k * Cout >= 128)
+    assert pipe.set_option(pipe.OPT_PIPE_LAUNCHES, 0) == want
 
 
 @pytest.mark.parametrize('Cin,Cout,k,s,p,H,W', GCONVS)

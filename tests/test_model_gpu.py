@@ -355,3 +355,57 @@ def test_baseline_config3_beam_search_and_config0_single_image(rt):
         assert rel(one['pred_boxes'][0], full['pred_boxes'][0].float().cpu()) < 2e-2
         d = inf.decode_outputs(one, model, num_output_boxes=5)[0]
         assert d['boxes'].shape == (5, 4) and isinstance(d['answer'], str)
+
+
+def test_graphed_train_step_equals_eager(rt):
+    """train.GraphedBody (forward / backward of the model body replayed as hipGraphs, criterion + optimizer eager)
+    against the eager step: dropout off, identical batches; caption-only, multitask and detection-only batches in turn
+    (one backward graph per set of outputs that carry a gradient); the box head stays untouched by caption-only steps."""
+    from gpv1_amd.train import FlatTrainer
+    rt.set_precise(False)
+    images, mask, ids, attn = batch()
+    cap = [{'task': 'CocoCaptioning', 'answer': ' '.join(f'w{(3 * i + j) % (V - 4)}' for j in range(4))} for i in range(B)]
+    det = [{'task': 'CocoDetection', 'boxes': torch.tensor([[0.5, 0.5, 0.2, 0.3], [0.3, 0.6, 0.1, 0.1]], device=DEV)[: 1 + i % 2],
+            'labels': torch.zeros(1 + i % 2, dtype=torch.long, device=DEV)} for i in range(B)]
+    mixed = [cap[i] if i % 2 == 0 else det[i] for i in range(B)]
+    schedule = [cap, cap, cap, mixed, mixed, det, cap]
+    res = {}
+    for graphs in (False, True):
+        model, _ = build_small()
+        model.to(DEV).train()
+        model.bert.model.p = 0.0
+        tr = FlatTrainer(model, lr=1e-3, lr_backbone=1e-4, graphs=graphs)
+        losses, live_after_cap = [], None
+        for it, tg in enumerate(schedule):
+            loss = tr.train_step(nested(images, mask), (ids, attn), [dict(t) for t in tg])
+            losses.append(float(loss))
+            if it == 2:
+                live_after_cap = tr.live_host().clone()
+        res[graphs] = (losses, tr.P.clone(), live_after_cap, tr.live_host().clone(), len(tr._bodies), [e[0] for e in tr.entries])
+    (l0, p0, c0, v0, n0, names), (l1, p1, c1, v1, n1, _) = res[False], res[True]
+    assert n0 == 0 and n1 >= 1, (n0, n1)                          # the graphed trainer captured; signatures: S differs between cap / det answers
+    assert torch.equal(c0, c1) and torch.equal(v0, v1)            # same touched sets, step by step
+    ib = [i for i, n in enumerate(names) if 'bbox_embed' in n]
+    assert not c1[ib].any() and v1[ib].all()                      # box head: untouched by caption-only steps, live after detection
+    for a, b_ in zip(l0, l1):
+        assert abs(a - b_) <= 2e-2 * max(abs(a), 1.0), (l0, l1)
+    assert rel(p1, p0.cpu()) < 1e-2, rel(p1, p0.cpu())        # 7 Adam steps at lr 1e-3: sign flips of noise-level gradients (fp32 atomics order)
+
+
+def test_graphed_train_step_draws_fresh_dropout_masks(rt):
+    """the seed of a captured launch is frozen in the graph; the device-resident seed epoch (gpv_set_seed_device) must
+    give every replayed step its own masks -- and the backward of a step the masks of its forward (loss keeps falling)"""
+    from gpv1_amd.train import FlatTrainer
+    import gpv1_amd.ops as ops
+    rt.set_precise(False)
+    model, _ = build_small(dropout=0.3)
+    model.to(DEV).train()
+    model.bert.model.p = 0.0
+    tr = FlatTrainer(model, lr=0.0, lr_backbone=0.0, graphs=True)          # lr 0: the weights never move, only the masks do
+    images, mask, ids, attn = batch()
+    cap = [{'task': 'CocoCaptioning', 'answer': ' '.join(f'w{(3 * i + j) % (V - 4)}' for j in range(4))} for i in range(B)]
+    losses = [float(tr.train_step(nested(images, mask), (ids, attn), [dict(t) for t in cap])) for _ in range(6)]
+    assert len(tr._bodies) == 1
+    replayed = losses[2:]
+    assert len(set(replayed)) == len(replayed), losses          # different masks -> different losses at identical weights
+    assert int(ops.RT.seed_dev) >= 4
