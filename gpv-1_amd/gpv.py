@@ -178,11 +178,14 @@ class GPV(nn.Module):
         self.load_state_dict(cur)
 
     # ------------------------------------------------------------------ encoder shared by all branches
-    def _encode(self, images, queries):
+    def _encode(self, images, queries, query_encodings=None):
+        """query_encodings: BERT features computed by the caller (train.GraphedBody runs the frozen, no_grad BERT as a
+        parallel branch of the backbone's hipGraph: 110 launches of <= 144 workgroups hide under the convolutions)"""
         outputs = self.detr(images)
         outputs['detr_hs'] = self.detr_joiner(outputs['detr_hs'])                  # [L,B,Q,768]
-        with torch.no_grad():
-            query_encodings, _ = self.bert(queries)
+        if query_encodings is None:
+            with torch.no_grad():
+                query_encodings, _ = self.bert(queries)
         lv = self.bert_joiner(query_encodings.detach())                            # [B,Tl,768]
         B, Tl, D = lv.shape
         vl = outputs['detr_hs'][-1]
@@ -264,8 +267,8 @@ class GPV(nn.Module):
         torch.cuda.current_stream().synchronize()       # see decode.py: graph launches are not left queued behind a busy GPU
         return res
 
-    def _forward_impl(self, images, queries, answer_token_ids, targets=None, vocab_mask=None, kv_graphs=None):
-        outputs, memory = self._encode(images, queries)
+    def _forward_impl(self, images, queries, answer_token_ids, targets=None, vocab_mask=None, kv_graphs=None, query_encodings=None):
+        outputs, memory = self._encode(images, queries, query_encodings)
         B = memory.shape[0]
         dev = memory.device
         if answer_token_ids is None:                                               # greedy, gpv.py:178-196

@@ -33,6 +33,7 @@ class Runtime:
         self.backward_milestone = None   # set by train.FlatTrainer for the duration of a backward pass (gradient-exchange overlap)
         self.split = None                # set by train.GraphedBody while it captures / replays: the backbone runs outside autograd
         self.seed_dev = None             # device int64 word lent to the library as the dropout seed epoch (hipGraph replays)
+        self.defer_list = None           # set by train.GraphedBody while it captures a backward: deferred weight-gradient launches
 
     def set_precise(self, on=True):
         self.dtype = torch.float32 if on else torch.bfloat16
@@ -67,6 +68,19 @@ class Runtime:
 
 
 RT = Runtime()
+
+
+def off_critical_path(fn, *tensors):
+    """Weight gradients are needed by nobody until the optimizer.  While train.GraphedBody captures the backward of the model
+    body (single GPU) the weight-gradient GEMMs of the transformer / co-attention / text-decoder layers -- ~140 launches of
+    36-600 workgroups, latency-bound -- are not launched in place: they are collected and captured as ONE parallel branch
+    of the backbone's backward graph (fork at its start, join at its end), where they fill the tails of the convolution
+    launches.  A fork per gradient was measured and lost: every cross-branch edge costs more than the overlap wins.
+    Outside such a capture fn() simply runs in place.  `tensors` keep the operands fn reads alive with the closure."""
+    if RT.defer_list is None:
+        fn()
+        return
+    RT.defer_list.append((fn, tensors))
 
 
 def ensure_grad(p):
@@ -199,8 +213,9 @@ class LinearFn(Function):
         need_b = w.bias is not None and w.bias.requires_grad
         if w.weight.requires_grad:
             # dW += dz^T x ; the bias gradient (column sums of dz) rides along in the same launch (a_rowsum)
-            hip.gemm(dz, x2, w.wgrad(), N, K, M, N, K, K, layoutA=hip.TRANS, layoutB=hip.TRANS, accumulate=True,
-                     split_k=_split_k(N, K, M), a_rowsum=w.bgrad() if need_b else None)
+            wg, bg = w.wgrad(), (w.bgrad() if need_b else None)
+            off_critical_path(lambda: hip.gemm(dz, x2, wg, N, K, M, N, K, K, layoutA=hip.TRANS, layoutB=hip.TRANS, accumulate=True,
+                                               split_k=_split_k(N, K, M), a_rowsum=bg), dz, x2)
         elif need_b:
             hip.colsum(dz, w.bgrad(), M, N, N)
         dx = None
@@ -346,8 +361,9 @@ class FFNBlockFn(Function):
         dy2 = ds if ds is not None else dx_res
         nb2 = w2.bias is not None and w2.bias.requires_grad
         if w2.weight.requires_grad:
-            hip.gemm(dy2, h, w2.wgrad(), K, Fh, M, K, Fh, Fh, layoutA=hip.TRANS, layoutB=hip.TRANS, accumulate=True,
-                     split_k=_split_k(K, Fh, M), a_rowsum=w2.bgrad() if nb2 else None)
+            wg2, bg2 = w2.wgrad(), (w2.bgrad() if nb2 else None)
+            off_critical_path(lambda: hip.gemm(dy2, h, wg2, K, Fh, M, K, Fh, Fh, layoutA=hip.TRANS, layoutB=hip.TRANS, accumulate=True,
+                                               split_k=_split_k(K, Fh, M), a_rowsum=bg2), dy2, h)
         elif nb2:
             hip.colsum(dy2, w2.bgrad(), M, K, K)
         dz = torch.empty(M, Fh, device=d2.device, dtype=RT.dtype)
@@ -355,8 +371,9 @@ class FFNBlockFn(Function):
                  alpha=1.0 / (1.0 - ctx.drop_p) if ctx.drop_p > 0 else 1.0)
         nb1 = w1.bias is not None and w1.bias.requires_grad
         if w1.weight.requires_grad:
-            hip.gemm(dz, x2, w1.wgrad(), Fh, K, M, Fh, K, K, layoutA=hip.TRANS, layoutB=hip.TRANS, accumulate=True,
-                     split_k=_split_k(Fh, K, M), a_rowsum=w1.bgrad() if nb1 else None)
+            wg1, bg1 = w1.wgrad(), (w1.bgrad() if nb1 else None)
+            off_critical_path(lambda: hip.gemm(dz, x2, wg1, Fh, K, M, Fh, K, K, layoutA=hip.TRANS, layoutB=hip.TRANS, accumulate=True,
+                                               split_k=_split_k(Fh, K, M), a_rowsum=bg1), dz, x2)
         elif nb1:
             hip.colsum(dz, w1.bgrad(), M, Fh, Fh)
         dx = torch.empty(M, K, device=dz.device, dtype=RT.dtype)

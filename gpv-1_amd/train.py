@@ -92,11 +92,21 @@ class GraphedBody:
         self.f1, self.f2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         saved = trainer.touched.clone()
         assert torch.cuda.current_stream(dev) == trainer.stream            # captures run on the trainer's side stream
+        # the frozen BERT (no_grad, ~110 launches of 36-144 workgroups) only needs the query ids: it is captured as a parallel
+        # branch of F1 (fork / join on a second stream) and runs under the backbone's convolutions
+        self.side = torch.cuda.Stream(device=dev) if os.environ.get('GPV_BERT_BRANCH', '1') != '0' else None
+        self.wside = torch.cuda.Stream(device=dev)
         RT.split = self
         try:
             self.f1.capture_begin(pool=self.pool)
+            q_enc = None
+            if self.side is not None:
+                self.side.wait_stream(trainer.stream)
+                with torch.cuda.stream(self.side), torch.no_grad():
+                    q_enc, _ = model.bert((self.s_ids, self.s_attn))
+            self.q_enc = q_enc
             self.outs = model._forward_impl(NestedTensor(self.s_img, self.s_mask, self.all_valid), (self.s_ids, self.s_attn),
-                                            self.s_tok, None)
+                                            self.s_tok, None, query_encodings=q_enc)
             self.f2.capture_end()
         finally:
             RT.split = None
@@ -107,6 +117,8 @@ class GraphedBody:
     def backbone_forward(self, body, x):
         self.keep = []
         c5 = body.forward_nhwc(x, self.keep)
+        if self.side is not None:
+            torch.cuda.current_stream(x.device).wait_stream(self.side)         # join the BERT branch before F1 ends
         self.f1.capture_end()
         self.f2.capture_begin(pool=self.pool)
         self.c5 = c5
@@ -160,7 +172,7 @@ class GraphedBody:
         pairs = self._roots(leaves)
         if not pairs:
             return
-        vkey = tuple(k for k, _, _ in pairs)
+        vkey = (tuple(k for k, _, _ in pairs), bool(tr.defer_wgrad))
         var = self.variants.get(vkey)
         if var is None:
             var = self.variants[vkey] = self._capture_backward(pairs)
@@ -188,15 +200,33 @@ class GraphedBody:
         from .ops import _DUMMY
         for d in _DUMMY.values():
             d.grad = None
-        b1.capture_begin(pool=self.pool)
-        torch.autograd.backward([o for _, o, _ in pairs], grads, retain_graph=True)
-        b1.capture_end()
-        dc5 = self.c5_leaf.grad
-        b2.capture_begin(pool=self.pool)
-        self.body.backward_nhwc(self.keep, dc5.to(RT.dtype))
-        b2.capture_end()
+        # Single GPU: the weight-gradient GEMMs of the model body are collected during B1 (ops.off_critical_path) and captured
+        # as one parallel branch of B2, under the backbone's convolutions.  With more ranks they stay in B1, so that the
+        # buckets behind the backbone segment are complete when the trainer hands them to RCCL between B1 and B2.
+        dev = self.s_img.device
+        defer = bool(tr.defer_wgrad)
+        deferred = []
+        try:
+            b1.capture_begin(pool=self.pool)
+            RT.defer_list = deferred if defer else None
+            torch.autograd.backward([o for _, o, _ in pairs], grads, retain_graph=True)
+            RT.defer_list = None
+            b1.capture_end()
+            dc5 = self.c5_leaf.grad
+            b2.capture_begin(pool=self.pool)
+            if deferred:
+                self.wside.wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(self.wside):
+                    for fn, _ in deferred:
+                        fn()
+            self.body.backward_nhwc(self.keep, dc5.to(RT.dtype))
+            if deferred:
+                torch.cuda.current_stream(dev).wait_stream(self.wside)
+            b2.capture_end()
+        finally:
+            RT.defer_list = None
         RT.backward_milestone = milestone
-        var = {'b1': b1, 'b2': b2, 'grads': grads, 'touched': tr.touched.clone(), 'dc5': dc5}
+        var = {'b1': b1, 'b2': b2, 'grads': grads, 'touched': tr.touched.clone(), 'dc5': dc5, 'deferred': deferred}
         tr.touched |= saved
         return var
 
@@ -206,11 +236,12 @@ class FlatTrainer:
                  t_total=0, betas=(0.9, 0.999), eps=1e-8, bucket_mb=128, process_group=None, manual_gc=True, gc_interval=200,
                  graphs=None, lr_milestones=None, lr_drop=0.1, warmup_iters=0):
         self.model = model
-        self.milestones, self.lr_drop, self.warmup_iters = (list(lr_milestones) if lr_milestones is not None else None), lr_drop, warmup_iters
+        self.lr_milestones, self.lr_drop, self.warmup_iters = (list(lr_milestones) if lr_milestones is not None else None), lr_drop, warmup_iters
         self.epoch, self.it_in_epoch = 0, 0
         # hipGraph replay of the model body (GraphedBody): default on for bf16 on the GPU; GPV_TRAIN_GRAPHS=0 turns it off
         self.graphs = (os.environ.get('GPV_TRAIN_GRAPHS', '1') != '0') if graphs is None else bool(graphs)
         self._bodies, self._seen, self.stream = {}, {}, None
+        self.defer_wgrad = None          # decided below (single rank only): model-body weight gradients as a branch of the backbone backward graph
         # Python's cyclic collector costs 1-3 ms per step once it has a few hundred thousand module / tensor objects to
         # walk (measured: 970-1020 vs 1062-1070 images/s over 20 steps), while a step leaves ~17 small cycles and no
         # device memory behind (tools/gc_growth.py).  With manual_gc the trainer freezes the long-lived objects, turns
@@ -271,6 +302,7 @@ class FlatTrainer:
         self.overlap = self.world > 1 and os.environ.get('GPV_OVERLAP', '1') != '0'
         self.dry_overlap = False             # tests: run the milestone / guard logic without communicating
         self._closed_from, self._works, self.late_touch, self.milestones = None, [], None, 0
+        self.defer_wgrad = self.world == 1 and os.environ.get('GPV_DEFER_WGRAD', '1') != '0'
         self.host_pg = None
         if self.world > 1:
             dist.broadcast(self.P, src=0, group=self.pg)
@@ -494,8 +526,8 @@ class FlatTrainer:
         if self.t_total > 0:
             return warmup_linear(self.step_count, self.warmup_steps, self.t_total)
         f = 1.0
-        if self.milestones is not None:
-            f = self.lr_drop ** sum(1 for m in self.milestones if self.epoch >= m)
+        if self.lr_milestones is not None:
+            f = self.lr_drop ** sum(1 for m in self.lr_milestones if self.epoch >= m)
         if self.warmup_iters > 0 and self.epoch == 0 and self.it_in_epoch < self.warmup_iters:
             f *= float(self.it_in_epoch) / float(self.warmup_iters)
         return f
