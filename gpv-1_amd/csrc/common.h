@@ -44,9 +44,42 @@ __device__ __forceinline__ uint32_t hash_u32(uint64_t seed, uint64_t idx) {
   x ^= x >> 16;
   return x;
 }
-// keep-probability (1-p): element kept iff hash >= p * 2^32
+// Dropout keep decisions come in PAIRS of consecutive flat element indices: one 32-bit mix per pair, 16 bits per element
+// (drop probability = floor(p * 65536) / 65536), and only one quarter-rate 32-bit multiply per pair -- the rest is shifts, xors
+// and full-rate 24-bit multiplies.  (Round 1 hashed the 64-bit index of every element with three 32-bit multiplies: the
+// LayerNorm kernels and the K = 256 FFN GEMM epilogues spent more on the mask than on their arithmetic.)  Every consumer of an
+// (seed, flat index) mask -- GEMM epilogues, LayerNorm forward / backward, gpv_dropout -- uses these, so a mask drawn by one
+// kernel is the mask another one reconstructs.
+__device__ __forceinline__ uint32_t drop_pair_bits(uint64_t seed, uint64_t pair) {
+  uint32_t x = (uint32_t)pair * 0x9E3779B9u + (uint32_t)seed;
+  x += ((uint32_t)(pair >> 32) ^ (uint32_t)(seed >> 32)) * 0x85EBCA6Bu;
+  x ^= x >> 16; x = __umul24(x, 0x85EBCBu);
+  x ^= x >> 13; x = __umul24(x, 0xC2B2AFu);
+  x ^= x >> 16;
+  return x;
+}
+// element kept iff its 16 bits >= p * 2^16
 __device__ __forceinline__ bool drop_keep(uint64_t seed, uint64_t idx, uint32_t thresh) {
-  return hash_u32(seed, idx) >= thresh;
+  const uint32_t w = drop_pair_bits(seed, idx >> 1);
+  return ((idx & 1) ? (w >> 16) : (w & 0xffffu)) >= (thresh >> 16);
+}
+// keep bits of the N (4 or 8) consecutive elements base .. base+N-1 (bit e = element base + e); N/2 mixes when base is even
+template <int N>
+__device__ __forceinline__ uint32_t drop_mask(uint64_t seed, uint64_t base, uint32_t thresh) {
+  const uint32_t t16 = thresh >> 16;
+  uint32_t m = 0u;
+  if ((base & 1) == 0) {
+#pragma unroll
+    for (int q = 0; q < N / 2; ++q) {
+      const uint32_t w = drop_pair_bits(seed, (base >> 1) + q);
+      m |= ((w & 0xffffu) >= t16 ? 1u : 0u) << (2 * q);
+      m |= ((w >> 16) >= t16 ? 1u : 0u) << (2 * q + 1);
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < N; ++e) m |= (drop_keep(seed, base + e, thresh) ? 1u : 0u) << e;
+  }
+  return m;
 }
 // Device-resident seed epoch (gpv_set_seed_device): when a caller replays captured launches (hipGraph) the `seed` argument of a
 // launch is frozen in the graph; the effective seed of every dropout consumer is then seed ^ mix(*epoch), the caller bumps the

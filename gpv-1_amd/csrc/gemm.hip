@@ -658,6 +658,7 @@ __device__ __forceinline__ void gemm_body(const GemmK& p) {
         }
         const float rs = p.rowscale ? p.rowscale[m] * p.alpha : p.alpha;
         const bool full = n + 8 <= p.N;
+        const uint32_t keep8 = p.dthresh ? drop_mask<8>(p.seed, ((uint64_t)batch * p.M + m) * (uint64_t)p.N + n, p.dthresh) : 0xffu;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           float x = v[e] * rs;
@@ -665,10 +666,7 @@ __device__ __forceinline__ void gemm_body(const GemmK& p) {
           if (Rp) x += rv[g][e];
           if (p.act == GPV_ACT_RELU) x = fmaxf(x, 0.f);
           else if (p.act == GPV_ACT_GELU) x = gelu_erf(x);
-          if (p.dthresh) {
-            uint64_t di = ((uint64_t)batch * p.M + m) * (uint64_t)p.N + (n + e);
-            x = drop_keep(p.seed, di, p.dthresh) ? x * p.dscale : 0.f;
-          }
+          if (p.dthresh) x = ((keep8 >> e) & 1u) ? x * p.dscale : 0.f;
           if (Mp) x = mv[g][e] > 0.f ? x : 0.f;
           v[e] = x;
         }

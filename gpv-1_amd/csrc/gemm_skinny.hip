@@ -180,6 +180,7 @@ __global__ __launch_bounds__(256) void skinny_kernel(GemmK p) {
     if (Rp) ld4(Rp, p.ldr, rv);
     if (Mp) ld4(Mp, p.ldm, mv);
     float o[4];
+    const uint32_t keep4 = p.dthresh ? drop_mask<4>(p.seed, (uint64_t)m * (uint64_t)p.N + n, p.dthresh) : 0xfu;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       if (n + e >= p.N) { o[e] = 0.f; continue; }
@@ -187,7 +188,7 @@ __global__ __launch_bounds__(256) void skinny_kernel(GemmK p) {
       if (Rp) x += rv[e];
       if (p.act == GPV_ACT_RELU) x = fmaxf(x, 0.f);
       else if (p.act == GPV_ACT_GELU) x = gelu_erf(x);
-      if (p.dthresh) x = drop_keep(p.seed, (uint64_t)m * (uint64_t)p.N + (n + e), p.dthresh) ? x * p.dscale : 0.f;
+      if (p.dthresh) x = ((keep4 >> e) & 1u) ? x * p.dscale : 0.f;
       if (Mp) x = mv[e] > 0.f ? x : 0.f;
       o[e] = x;
     }

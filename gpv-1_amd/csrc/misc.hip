@@ -16,16 +16,28 @@ inline int grid1d(int64_t n, int per_block) {
 // ------------------------------------------------------------------------------------------
 // LayerNorm forward: one wave per row (cols <= 8*64*MAXV), values kept in registers.
 // y = LN(x + drop(s)) * g + b
+// HALF (cols <= 256, the DETR width): a row is 32 lanes x 8 elements, so a wave takes TWO rows -- with one row per wave half
+// the lanes of every DETR LayerNorm (9600 x 256, 3200 x 256) sat idle and a wave had half the bytes in flight.
 // ------------------------------------------------------------------------------------------
-template <typename T, int NV>   // NV = number of 8-element vectors per lane (cols <= NV*512)
+template <bool HALF> __device__ __forceinline__ float row_sum(float v) {
+  if (HALF) {
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+  }
+  return wave_sum(v);
+}
+
+template <typename T, int NV, bool HALF>   // NV = number of 8-element vectors per lane (cols <= NV*512)
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const T* __restrict__ s,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      T* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd,
                                                      int rows, int cols, float eps, uint32_t dthresh, float dscale,
                                                      uint64_t seed, const uint64_t* seed_dev) {
   if (dthresh) seed = eff_seed(seed, seed_dev);
-  const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  constexpr int LW = HALF ? 32 : 64;                       // lanes per row
+  const int lane = threadIdx.x & (LW - 1);
+  const int row = HALF ? blockIdx.x * 8 + (threadIdx.x >> 5) : blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   const T* xr = x + (int64_t)row * cols;
   const T* sr = s ? s + (int64_t)row * cols : nullptr;
@@ -33,16 +45,17 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
   float sum = 0.f;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
-    const int c = (i * 64 + lane) * 8;
+    const int c = (i * LW + lane) * 8;
     if (c < cols) {
       Ld8<T>::ld(xr + c, v[i]);
       if (sr) {
         float t[8];
         Ld8<T>::ld(sr + c, t);
+        const uint32_t keep8 = dthresh ? drop_mask<8>(seed, (uint64_t)row * cols + c, dthresh) : 0xffu;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           float sv = t[e];
-          if (dthresh) sv = drop_keep(seed, (uint64_t)row * cols + c + e, dthresh) ? sv * dscale : 0.f;
+          if (dthresh) sv = ((keep8 >> e) & 1u) ? sv * dscale : 0.f;
           v[i][e] += sv;
         }
       }
@@ -53,24 +66,24 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
       for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
     }
   }
-  sum = wave_sum(sum);
+  sum = row_sum<HALF>(sum);
   const float mu = sum / cols;
   float var = 0.f;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
-    const int c = (i * 64 + lane) * 8;
+    const int c = (i * LW + lane) * 8;
     if (c < cols) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) { float d = v[i][e] - mu; var += d * d; }
     }
   }
-  var = wave_sum(var) / cols;
+  var = row_sum<HALF>(var) / cols;
   const float rs = rsqrtf(var + eps);
   if (lane == 0) { if (mean) mean[row] = mu; if (rstd) rstd[row] = rs; }
   T* yr = y + (int64_t)row * cols;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
-    const int c = (i * 64 + lane) * 8;
+    const int c = (i * LW + lane) * 8;
     if (c < cols) {
       float o[8], gm[8], bt[8];
       if (gamma) { Ld8<float>::ld(gamma + c, gm); Ld8<float>::ld(beta + c, bt); }      // cols % 8 == 0: two 16-byte loads each
@@ -84,10 +97,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
   }
 }
 
-// LayerNorm backward: one wave per row. z = x + drop(s) is recomputed.
+// LayerNorm backward: one wave (HALF: half a wave) per row. z = x + drop(s) is recomputed.
 // dz = rstd * (g*dy - mean(g*dy) - zhat*mean(g*dy*zhat)); dx = dz ; ds = dz * dropmask
 // dgamma/dbeta accumulated per block in LDS then atomics.
-template <typename T, int NV>
+template <typename T, int NV, bool HALF>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ s,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, T* __restrict__ dx, T* __restrict__ ds,
@@ -96,7 +109,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
                                                      const uint64_t* seed_dev) {
   if (dthresh) seed = eff_seed(seed, seed_dev);
   extern __shared__ float lds[];   // [4 waves][2][cols]: every wave parks its partial dgamma | dbeta, no LDS atomics
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int LW = HALF ? 32 : 64, RPI = HALF ? 8 : 4;      // lanes per row, rows per block iteration
+  const int lane = threadIdx.x & (LW - 1), wave = threadIdx.x >> 6;
+  const int slot = HALF ? threadIdx.x >> 5 : wave;            // which of the block's RPI concurrent rows
   float ag[NV][8], ab[NV][8];
 #pragma unroll
   for (int i = 0; i < NV; ++i)
@@ -105,24 +120,27 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
 
   const int r_begin = blockIdx.x * rows_per_block;
   const int r_end = min(rows, r_begin + rows_per_block);
-  for (int row = r_begin + wave; row < r_end; row += 4) {
-    const float mu = mean[row], rs = rstd[row];
+  for (int row = r_begin + slot; row < r_end; row += RPI) {      // (HALF: the two halves of a wave may run one iteration apart;
+    const float mu = mean[row], rs = rstd[row];                  //  every shuffle below stays inside a half)
     float zh[NV][8], gy[NV][8];
+    uint32_t keep[NV];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int c = (i * 64 + lane) * 8;
+      const int c = (i * LW + lane) * 8;
+      keep[i] = 0xffu;
       if (c < cols) {
         float xv[8], dv[8];
         Ld8<T>::ld(x + (int64_t)row * cols + c, xv);
         Ld8<T>::ld(dy + (int64_t)row * cols + c, dv);
+        if (dthresh) keep[i] = drop_mask<8>(seed, (uint64_t)row * cols + c, dthresh);
         if (s) {
           float t[8];
           Ld8<T>::ld(s + (int64_t)row * cols + c, t);
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             float sv = t[e];
-            if (dthresh) sv = drop_keep(seed, (uint64_t)row * cols + c + e, dthresh) ? sv * dscale : 0.f;
+            if (dthresh) sv = ((keep[i] >> e) & 1u) ? sv * dscale : 0.f;
             xv[e] += sv;
           }
         }
@@ -143,17 +161,17 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
         for (int e = 0; e < 8; ++e) zh[i][e] = gy[i][e] = 0.f;
       }
     }
-    s1 = wave_sum(s1) / cols;
-    s2 = wave_sum(s2) / cols;
+    s1 = row_sum<HALF>(s1) / cols;
+    s2 = row_sum<HALF>(s2) / cols;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int c = (i * 64 + lane) * 8;
+      const int c = (i * LW + lane) * 8;
       if (c < cols) {
         float o[8], o2[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           o[e] = rs * (gy[i][e] - s1 - zh[i][e] * s2);
-          if (dthresh) o2[e] = drop_keep(seed, (uint64_t)row * cols + c + e, dthresh) ? o[e] * dscale : 0.f;
+          if (dthresh) o2[e] = ((keep[i] >> e) & 1u) ? o[e] * dscale : 0.f;
         }
         Ld8<T>::st(dx + (int64_t)row * cols + c, o);
         if (dthresh && ds) Ld8<T>::st(ds + (int64_t)row * cols + c, o2);
@@ -161,11 +179,17 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
     }
   }
   if (dgamma) {
+    if (HALF) {                                        // the two halves of a wave hold partials of the same columns
+#pragma unroll
+      for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { ag[i][e] += __shfl_xor(ag[i][e], 32); ab[i][e] += __shfl_xor(ab[i][e], 32); }
+    }
     float* wg = lds + wave * 2 * cols;               // this wave's [dgamma | dbeta] partials (plain 16-byte stores)
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int c = (i * 64 + lane) * 8;
-      if (c < cols) {
+      const int c = (i * LW + lane) * 8;
+      if (c < cols && (!HALF || (threadIdx.x & 32) == 0)) {
         *reinterpret_cast<float4*>(wg + c) = make_float4(ag[i][0], ag[i][1], ag[i][2], ag[i][3]);
         *reinterpret_cast<float4*>(wg + c + 4) = make_float4(ag[i][4], ag[i][5], ag[i][6], ag[i][7]);
         *reinterpret_cast<float4*>(wg + cols + c) = make_float4(ab[i][0], ab[i][1], ab[i][2], ab[i][3]);
@@ -501,11 +525,12 @@ extern "C" int gpv_layernorm_fwd(const void* x, const void* s, const float* gamm
   if (cols % 8 != 0 || cols > 4096 || rows <= 0) return (int)hipErrorInvalidValue;
   const uint32_t th = drop_p > 0.f ? drop_thresh(drop_p) : 0u;
   const float sc = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
-  dim3 grid((rows + 3) / 4), block(256);
-#define LN_F(T, NV) hipLaunchKernelGGL((ln_fwd_kernel<T, NV>), grid, block, 0, ST(stream), (const T*)x, (const T*)s, gamma, beta, (T*)y, mean, rstd, rows, cols, eps, th, sc, seed, gpvk::g_seed_dev)
+  const bool half = cols <= 256;                         // two rows per wave (see ln_fwd_kernel)
+  dim3 grid(half ? (rows + 7) / 8 : (rows + 3) / 4), block(256);
+#define LN_F(T, NV, H) hipLaunchKernelGGL((ln_fwd_kernel<T, NV, H>), grid, block, 0, ST(stream), (const T*)x, (const T*)s, gamma, beta, (T*)y, mean, rstd, rows, cols, eps, th, sc, seed, gpvk::g_seed_dev)
   const int nv = (cols + 511) / 512;
-  if (dtype == GPV_BF16) { if (nv <= 1) LN_F(bf16, 1); else if (nv <= 2) LN_F(bf16, 2); else if (nv <= 5) LN_F(bf16, 5); else LN_F(bf16, 8); }
-  else { if (nv <= 1) LN_F(float, 1); else if (nv <= 2) LN_F(float, 2); else if (nv <= 5) LN_F(float, 5); else LN_F(float, 8); }
+  if (dtype == GPV_BF16) { if (half) LN_F(bf16, 1, true); else if (nv <= 1) LN_F(bf16, 1, false); else if (nv <= 2) LN_F(bf16, 2, false); else if (nv <= 5) LN_F(bf16, 5, false); else LN_F(bf16, 8, false); }
+  else { if (half) LN_F(float, 1, true); else if (nv <= 1) LN_F(float, 1, false); else if (nv <= 2) LN_F(float, 2, false); else if (nv <= 5) LN_F(float, 5, false); else LN_F(float, 8, false); }
 #undef LN_F
   GPV_CHECK_LAUNCH();
   return 0;
@@ -522,10 +547,11 @@ extern "C" int gpv_layernorm_bwd(const void* dy, const void* x, const void* s, c
   if (rpb < 8) rpb = 8;
   dim3 grid((rows + rpb - 1) / rpb), block(256);
   const size_t lds = dgamma ? 8 * (size_t)cols * sizeof(float) : 0;       // 4 waves x [dgamma | dbeta]; cols <= 4096 -> <= 128 KB
-#define LN_B(T, NV) hipLaunchKernelGGL((ln_bwd_kernel<T, NV>), grid, block, lds, ST(stream), (const T*)dy, (const T*)x, (const T*)s, gamma, mean, rstd, (T*)dx, (T*)ds, dgamma, dbeta, rows, cols, rpb, th, sc, seed, gpvk::g_seed_dev)
+#define LN_B(T, NV, H) hipLaunchKernelGGL((ln_bwd_kernel<T, NV, H>), grid, block, lds, ST(stream), (const T*)dy, (const T*)x, (const T*)s, gamma, mean, rstd, (T*)dx, (T*)ds, dgamma, dbeta, rows, cols, rpb, th, sc, seed, gpvk::g_seed_dev)
   const int nv = (cols + 511) / 512;
-  if (dtype == GPV_BF16) { if (nv <= 1) LN_B(bf16, 1); else if (nv <= 2) LN_B(bf16, 2); else if (nv <= 5) LN_B(bf16, 5); else LN_B(bf16, 8); }
-  else { if (nv <= 1) LN_B(float, 1); else if (nv <= 2) LN_B(float, 2); else if (nv <= 5) LN_B(float, 5); else LN_B(float, 8); }
+  const bool half = cols <= 256;
+  if (dtype == GPV_BF16) { if (half) LN_B(bf16, 1, true); else if (nv <= 1) LN_B(bf16, 1, false); else if (nv <= 2) LN_B(bf16, 2, false); else if (nv <= 5) LN_B(bf16, 5, false); else LN_B(bf16, 8, false); }
+  else { if (half) LN_B(float, 1, true); else if (nv <= 1) LN_B(float, 1, false); else if (nv <= 2) LN_B(float, 2, false); else if (nv <= 5) LN_B(float, 5, false); else LN_B(float, 8, false); }
 #undef LN_B
   GPV_CHECK_LAUNCH();
   return 0;

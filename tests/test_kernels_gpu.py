@@ -667,21 +667,35 @@ def test_adamw_matches_torch():
     acc = torch.zeros(1, device=DEV)
     h.sumsq(g, n, acc)
     assert rel(acc, (g * g).sum().view(1)) < 1e-5
-    # per-parameter liveness on the device: chunks of 8 elements map to a parameter id, dead parameters are left alone
+    # per-parameter step counts on the device: chunks of 8 elements map to a parameter id; count 0 = the parameter never
+    # received a gradient and is left alone; otherwise the count is the parameter's OWN Adam step (torch keeps `step` per
+    # parameter) and sets its bias corrections -- parameters first touched at different times take different first updates
     n2 = 4096
     bounds = [0, 40, 1000, 1008, 3000, n2]                      # 5 parameters, starts on multiples of 8
     sid = torch.zeros(n2 // 8, dtype=torch.int16)
     for i in range(5):
         sid[bounds[i] // 8:bounds[i + 1] // 8] = i
-    live = torch.tensor([1, 0, 1, 0, 1], dtype=torch.int32, device=DEV)
-    p0, g = rnd(n2, seed=92), rnd(n2, seed=93)
+    first = [1, 0, 2, 0, 1]                                      # global step at which each parameter gets its first gradient (0: never)
+    p0 = rnd(n2, seed=92)
     p, m, v = p0.clone(), torch.zeros(n2, device=DEV), torch.zeros(n2, device=DEV)
-    pr, mr, vr = p0.clone(), torch.zeros(n2, device=DEV), torch.zeros(n2, device=DEV)
-    h.adamw(p, g, m, v, None, n2, 1e-3, 0.9, 0.999, 1e-8, 1e-2, 0.1, 0.001, seg_id=sid.to(DEV), seg_live=live)
-    h.adamw(pr, g, mr, vr, None, n2, 1e-3, 0.9, 0.999, 1e-8, 1e-2, 0.1, 0.001)
+    refs = [torch.nn.Parameter(p0[bounds[i]:bounds[i + 1]].clone()) for i in range(5)]
+    opt = torch.optim.AdamW(refs, lr=1e-3, weight_decay=1e-2)
+    pstep = torch.zeros(5, dtype=torch.int32, device=DEV)
+    for step in range(1, 4):
+        g = rnd(n2, seed=93 + step)
+        live = torch.tensor([1 if f and step >= f else 0 for f in first], dtype=torch.int32, device=DEV)
+        pstep += live
+        for i in range(5):
+            refs[i].grad = g[bounds[i]:bounds[i + 1]].clone() if live[i] else None
+        opt.step()
+        gm = g.clone()
+        for i in range(5):
+            if not live[i]:
+                gm[bounds[i]:bounds[i + 1]] = 0
+        h.adamw(p, gm, m, v, None, n2, 1e-3, 0.9, 0.999, 1e-8, 1e-2, 0.5, 0.5, seg_id=sid.to(DEV), seg_live=pstep)   # (bc1/bc2 ignored)
     for i in range(5):
         sl = slice(bounds[i], bounds[i + 1])
-        if live[i]:
-            assert torch.equal(p[sl], pr[sl]) and torch.equal(m[sl], mr[sl])
+        if first[i]:
+            assert rel(p[sl], refs[i].data) < 2e-6, i
         else:
             assert torch.equal(p[sl], p0[sl]) and m[sl].abs().max() == 0 and v[sl].abs().max() == 0
