@@ -886,10 +886,10 @@ extern "C" int gpv_gemm(const gpv_gemm_args* a, void* stream) {
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int la = a->layoutA, lb = a->layoutB;
   if (la == GPV_KMAJOR && lb == GPV_KMAJOR) {
-    const int sk = skinny_try_launch(k, 0, a->dtype_in, a->dtype_out, a->batch, st);             // few tiles, long reduction (BERT, text decoder)
-    if (sk >= 0) return sk;
-    const int pp = pipe_try_launch(k, OP_PLAIN, a->dtype_in, a->dtype_out, a->batch, st);     // three-stage pipelined direct-to-LDS kernel
+    const int pp = pipe_try_launch(k, OP_PLAIN, a->dtype_in, a->dtype_out, a->batch, st);     // pipelined direct-to-LDS kernel (big tiles, and the small-M 6-8 stage tiles)
     if (pp >= 0) return pp;
+    const int sk = skinny_try_launch(k, 0, a->dtype_in, a->dtype_out, a->batch, st);             // few tiles, long reduction: what the pipelined kernel does not take (fp32 outputs, ragged N)
+    if (sk >= 0) return sk;
     const int g = glds_try_launch(k, OP_PLAIN, a->dtype_in, a->dtype_out, a->batch, st);      // 8-wave direct-to-LDS kernel when it qualifies
     if (g >= 0) return g;
     return launch_dtype<OP_PLAIN, OP_PLAIN>(k, a->batch, a->dtype_in, a->dtype_out, st);

@@ -26,7 +26,7 @@ namespace {
 
 constexpr int GBK = 64;
 constexpr int ROWB = 128;
-constexpr int NW = 8, NT = 512, NS = 3;
+constexpr int NW = 8, NT = 512;
 long g_pipe_launches = 0;
 
 typedef __attribute__((address_space(3))) void lds_void_t;
@@ -48,11 +48,17 @@ __device__ __forceinline__ void wait_vm(int n) {
     case 10: wait_vm_c<10>(); break;
     case 11: wait_vm_c<11>(); break;
     case 12: wait_vm_c<12>(); break;
+    case 13: wait_vm_c<13>(); break;
+    case 14: wait_vm_c<14>(); break;
+    case 15: wait_vm_c<15>(); break;
+    case 16: wait_vm_c<16>(); break;
+    case 17: wait_vm_c<17>(); break;
+    case 18: wait_vm_c<18>(); break;
     default: wait_vm_c<0>(); break;
   }
 }
 
-template <int AMODE, int BM, int BN, int WM, typename TOut>
+template <int AMODE, int BM, int BN, int WM, int NS, typename TOut>
 __device__ __forceinline__ void pipe_body(const GemmK& p) {
   constexpr int WN = NW / WM;
   constexpr int WTM = BM / WM, WTN = BN / WN;
@@ -210,15 +216,17 @@ __device__ __forceinline__ void pipe_body(const GemmK& p) {
   if constexpr (AMODE == OP_CONV) {
     if (p.cg.cm) __syncthreads();          // s_rowpix visible before anything is in flight (a plain barrier: no LDS-DMA outstanding yet)
   }
-  issue(0);
-  if (nk > 1) issue(1);
-  int sc = 0, si = 2;
+#pragma unroll
+  for (int s0 = 0; s0 < NS - 1; ++s0)
+    if (s0 < nk) issue(s0);                 // NS-1 tiles in flight before the first MFMA (NS = 3 for the big tiles; 6-8 for the
+  int sc = 0, si = NS - 1;                  // small-M tiles, whose whole cost is the latency of their short k-loop)
   for (int t = 0; t < nk; ++t) {
-    // tile t has landed once at most the pieces of tile t+1 are still outstanding for this wave ...
-    if (t + 1 < nk) wait_vm(nl); else wait_vm_c<0>();
-    __builtin_amdgcn_s_barrier();           // ... for every wave; and everyone is done reading stage (t+2)%3 (= tile t-1's)
+    // tile t has landed once at most the tiles issued after it are still outstanding for this wave ...
+    const int ahead = min(nk, t + NS - 1) - (t + 1);
+    wait_vm(ahead * nl);
+    __builtin_amdgcn_s_barrier();           // ... for every wave; and everyone is done reading stage (t-1)%NS (tile t-1's)
     asm volatile("" ::: "memory");
-    if (t + 2 < nk) issue(si);
+    if (t + NS - 1 < nk) issue(si);
     const unsigned char* st = smem + sc * STAGE;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
@@ -243,12 +251,12 @@ __device__ __forceinline__ void pipe_body(const GemmK& p) {
   const TOut* Mp = reinterpret_cast<const TOut*>(p.mask);
   float* ep = reinterpret_cast<float*>(smem);
   constexpr int EPITCH = BN + 4;
-  constexpr int HR = BM / 2;
+  constexpr int NHALF = (BM * BN >= 2 * NT * 8) ? 2 : 1;      // small tiles: the whole fp32 image in one pass
+  constexpr int HR = BM / NHALF;
   constexpr int CH = BN / 8;
-  static_assert((HR * CH) % NT == 0, "epilogue chunking");
   static_assert(HR % WTM == 0 || WTM % HR == 0, "a wave's rows lie in one half");
   static_assert((size_t)HR * EPITCH * 4 <= (size_t)NS * STAGE, "epilogue image fits the stages");
-  constexpr int NCH = (HR * CH) / NT;
+  constexpr int NCH = (HR * CH + NT - 1) / NT;
   const bool v_st = (p.ldc % 8 == 0) && ((reinterpret_cast<uintptr_t>(Cp) & 15) == 0);
   const bool v_res = Rp && (p.ldr % 8 == 0) && ((reinterpret_cast<uintptr_t>(Rp) & 15) == 0);
   const bool v_msk = Mp && (p.ldm % 8 == 0) && ((reinterpret_cast<uintptr_t>(Mp) & 15) == 0);
@@ -266,7 +274,7 @@ __device__ __forceinline__ void pipe_body(const GemmK& p) {
     }
   }
 #pragma unroll
-  for (int half = 0; half < 2; ++half) {
+  for (int half = 0; half < NHALF; ++half) {
     __syncthreads();
     if ((wm * WTM) / HR == half) {
 #pragma unroll
@@ -281,6 +289,7 @@ __device__ __forceinline__ void pipe_body(const GemmK& p) {
 #pragma unroll
     for (int g = 0; g < NCH; ++g) {
       const int idx = tid + g * NT;
+      if ((HR * CH) % NT != 0 && idx >= HR * CH) continue;
       const int r = idx / CH, c8 = idx - r * CH;
       const int m = row0 + half * HR + r;
       const int n = col0 + c8 * 8;
@@ -332,19 +341,19 @@ __device__ __forceinline__ void pipe_body(const GemmK& p) {
   }
 }
 
-template <int AMODE, int BM, int BN, int WM, typename TOut>
+template <int AMODE, int BM, int BN, int WM, int NS, typename TOut>
 __global__ __launch_bounds__(NT) void pipe_kernel(GemmK p) {
   if (p.dthresh) p.seed = eff_seed(p.seed, p.seed_dev);
-  pipe_body<AMODE, BM, BN, WM, TOut>(p);
+  pipe_body<AMODE, BM, BN, WM, NS, TOut>(p);
 }
 // 1x1 stride-1 convolutions launched as plain GEMMs keep a name of their own (rocprofv3 attribution to the backbone)
-template <int BM, int BN, int WM, typename TOut>
+template <int BM, int BN, int WM, int NS, typename TOut>
 __global__ __launch_bounds__(NT) void pipe_conv1x1_kernel(GemmK p) {
   if (p.dthresh) p.seed = eff_seed(p.seed, p.seed_dev);
-  pipe_body<OP_PLAIN, BM, BN, WM, TOut>(p);
+  pipe_body<OP_PLAIN, BM, BN, WM, NS, TOut>(p);
 }
 
-template <int AMODE, int BM, int BN, int WM>
+template <int AMODE, int BM, int BN, int WM, int NS>
 int launch_pipe(const GemmK& k, int batch, hipStream_t st) {
   constexpr size_t stages = (size_t)NS * (BM + BN) * ROWB;
   constexpr size_t lds = stages + (AMODE == OP_CONV ? (size_t)BM * 4 : 0);
@@ -354,8 +363,8 @@ int launch_pipe(const GemmK& k, int batch, hipStream_t st) {
   p.tilesN = (p.N + BN - 1) / BN;
   const bool c11 = AMODE == OP_PLAIN && p.conv1x1;
   void (*fn)(GemmK);
-  if constexpr (AMODE == OP_PLAIN) fn = c11 ? pipe_conv1x1_kernel<BM, BN, WM, bf16> : pipe_kernel<AMODE, BM, BN, WM, bf16>;
-  else fn = pipe_kernel<AMODE, BM, BN, WM, bf16>;
+  if constexpr (AMODE == OP_PLAIN) fn = c11 ? pipe_conv1x1_kernel<BM, BN, WM, NS, bf16> : pipe_kernel<AMODE, BM, BN, WM, NS, bf16>;
+  else fn = pipe_kernel<AMODE, BM, BN, WM, NS, bf16>;
   static bool attr_done[2] = {false, false};
   if (!attr_done[c11]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -371,18 +380,24 @@ int launch_pipe(const GemmK& k, int batch, hipStream_t st) {
 
 // tile configurations: index -> (BM, BN, WM)
 struct PipeCfg { int bm, bn; };
-constexpr PipeCfg kCfgs[] = {{256, 128}, {192, 128}, {128, 128}, {160, 256}, {128, 256}, {96, 256}};
+constexpr PipeCfg kCfgs[] = {{256, 128}, {192, 128}, {128, 128}, {160, 256}, {128, 256}, {96, 256},
+                             {64, 64}, {32, 64}};     // the last two: small-M tiles, 6 / 8 stages, plain GEMMs only
+constexpr int kNumBig = 6;
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
 template <int AMODE>
 int launch_cfg_idx(int idx, const GemmK& k, int batch, hipStream_t st) {
   switch (idx) {
-    case 0: return launch_pipe<AMODE, 256, 128, 4>(k, batch, st);
-    case 1: return launch_pipe<AMODE, 192, 128, 4>(k, batch, st);
-    case 2: return launch_pipe<AMODE, 128, 128, 2>(k, batch, st);
-    case 3: return launch_pipe<AMODE, 160, 256, 2>(k, batch, st);
-    case 4: return launch_pipe<AMODE, 128, 256, 2>(k, batch, st);
-    case 5: return launch_pipe<AMODE, 96, 256, 2>(k, batch, st);
+    case 0: return launch_pipe<AMODE, 256, 128, 4, 3>(k, batch, st);
+    case 1: return launch_pipe<AMODE, 192, 128, 4, 3>(k, batch, st);
+    case 2: return launch_pipe<AMODE, 128, 128, 2, 3>(k, batch, st);
+    case 3: return launch_pipe<AMODE, 160, 256, 2, 3>(k, batch, st);
+    case 4: return launch_pipe<AMODE, 128, 256, 2, 3>(k, batch, st);
+    case 5: return launch_pipe<AMODE, 96, 256, 2, 3>(k, batch, st);
+  }
+  if constexpr (AMODE == OP_PLAIN) {
+    if (idx == 6) return launch_pipe<OP_PLAIN, 64, 64, 2, 6>(k, batch, st);
+    if (idx == 7) return launch_pipe<OP_PLAIN, 32, 64, 2, 8>(k, batch, st);
   }
   return -1;
 }
@@ -395,7 +410,7 @@ inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) =
 int pick_cfg(const GemmK& k, int batch) {
   double best = 1e300;
   int bi = -1;
-  for (int i = 0; i < kNumCfgs; ++i) {
+  for (int i = 0; i < kNumBig; ++i) {
     const int bm = kCfgs[i].bm, bn = kCfgs[i].bn;
     if (k.N % bn != 0) continue;
     const int64_t tiles = (int64_t)((k.M + bm - 1) / bm) * (k.N / bn) * batch;
@@ -414,7 +429,7 @@ int pipe_try_launch(const GemmK& k, int amode, int dtype_in, int dtype_out, int 
   const int mode = g_pipe_mode;
   if (mode == 0 || dtype_in != GPV_BF16 || dtype_out != GPV_BF16) return -1;
   if (k.accumulate || k.split_k > 1) return -1;
-  if (k.K % GBK != 0 || k.K < 2 * GBK || k.N % 128 != 0) return -1;
+  if (k.K % GBK != 0 || k.K < 2 * GBK || k.N % 64 != 0) return -1;
   if (!al16(k.A) || !al16(k.B) || k.ldb % 8 != 0 || (batch > 1 && (k.sA % 8 != 0 || k.sB % 8 != 0))) return -1;
   const int64_t lim = 0x7ffffff0ll / 2;
   if ((int64_t)k.N * k.ldb >= lim) return -1;
@@ -429,7 +444,17 @@ int pipe_try_launch(const GemmK& k, int amode, int dtype_in, int dtype_out, int 
   int idx;
   if (mode >= 100) {
     idx = mode - 100;
-    if (idx >= kNumCfgs || k.N % kCfgs[idx].bn != 0) return -1;
+    if (idx >= kNumCfgs || k.N % kCfgs[idx].bn != 0 || (idx >= kNumBig && amode != OP_PLAIN)) return -1;
+  } else if (amode == OP_PLAIN && !k.conv1x1 && k.K >= 256 &&
+             (int64_t)((k.M + 63) / 64) * (k.N / 64) * batch <= 250 &&
+             ((int64_t)((k.M + 63) / 64) * (k.N / 64) * batch >= 100 || k.K <= 1024)) {
+    // small-M GEMMs (BERT and the co-attention text stream at M = 192, the text decoder at 640 rows): too few 64x64 tiles to
+    // fill the chip.  6-8 k-tiles in flight through LDS-DMA instead of gemm_skinny.hip's one register-staged tile of
+    // look-ahead: 9.0 -> 8.4 us (192x768x768), 10.6 -> 8.8 (192x2304x768), 19.0 -> 16.5 (3200x256x2048) -- modest: what
+    // bounds these launches is the ~35 GB/s per CU of the operand path times the few CUs they occupy, not the look-ahead
+    // (tools/bench_pipe.py small).  Very few tiles with a long reduction (192x768x3072) keep the in-block k-split of gemm_skinny.
+    const int64_t t64 = (int64_t)((k.M + 63) / 64) * (k.N / 64) * batch;
+    idx = t64 < 128 ? 7 : 6;
   } else {
     // Where it wins (tools/bench_pipe.py, B=32 shapes, round 2): reductions of >= 512 over 256..768-wide outputs of <= 40 k rows
     // (layer3/4 3x3 and long-K 1x1 convs fwd + dgrad, the DETR / co-attention GEMMs) and any width below 9600 rows.  N = 128

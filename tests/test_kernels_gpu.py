@@ -318,23 +318,34 @@ def test_glds_gemm_epilogue_and_batch(glds):
     assert torch.equal(c1 == 0, c2 == 0) and rel(c1, c2.float()) < 1e-2
 
 
-PIPE_CFGS = [(256, 128), (192, 128), (128, 128), (160, 256), (128, 256), (96, 256)]     # gemm_pipe.hip: kCfgs
+PIPE_CFGS = [(256, 128), (192, 128), (128, 128), (160, 256), (128, 256), (96, 256), (64, 64), (32, 64)]     # gemm_pipe.hip: kCfgs
 
 
-@pytest.fixture(params=range(len(PIPE_CFGS)), ids=['%dx%d' % c for c in PIPE_CFGS])
-def pipe(request):
-    """force tile configuration i of the three-stage pipelined direct-to-LDS kernel (gemm_pipe.hip) wherever it is legal"""
+def _pipe_fixture(idx):
     h = hip()
-    prev = h.set_option(h.OPT_PIPE, 100 + request.param)
+    prev = h.set_option(h.OPT_PIPE, 100 + idx)
     prevs = h.set_option(h.OPT_SKINNY, 0)
     h.set_option(h.OPT_PIPE_LAUNCHES, 0)
-    h.bn = PIPE_CFGS[request.param][1]
+    h.bn = PIPE_CFGS[idx][1]
     yield h
     h.set_option(h.OPT_PIPE, prev)
     h.set_option(h.OPT_SKINNY, prevs)
 
 
-@pytest.mark.parametrize('M,N,K', [(300, 256, 256), (2048, 512, 768), (1000, 128, 192), (9600, 256, 2048), (70, 384, 128), (257, 768, 64)])
+@pytest.fixture(params=range(len(PIPE_CFGS)), ids=['%dx%d' % c for c in PIPE_CFGS])
+def pipe(request):
+    """force tile configuration i of the pipelined direct-to-LDS kernel (gemm_pipe.hip) wherever it is legal; the last two are
+    the small-M tiles (6 / 8 LDS stages, plain GEMMs only)"""
+    yield from _pipe_fixture(request.param)
+
+
+@pytest.fixture(params=range(6), ids=['%dx%d' % c for c in PIPE_CFGS[:6]])
+def pipe_big(request):
+    yield from _pipe_fixture(request.param)
+
+
+@pytest.mark.parametrize('M,N,K', [(300, 256, 256), (2048, 512, 768), (1000, 128, 192), (9600, 256, 2048), (70, 384, 128), (257, 768, 64),
+                                   (192, 768, 768), (640, 2304, 768), (1, 768, 3072)])
 def test_pipe_gemm_plain_epilogue_batch(pipe, M, N, K):
     h, dtype = pipe, torch.bfloat16
     A, B = rnd(M, K, dtype=dtype, seed=1), rnd(N, K, dtype=dtype, seed=2)
@@ -440,7 +451,8 @@ GCONVS = [  # Cin, Cout, k, stride, pad, H, W   (Cin % 64 == 0 both ways, Cout >
 
 
 @pytest.mark.parametrize('Cin,Cout,k,s,p,H,W', GCONVS)
-def test_pipe_conv_fwd_dgrad(pipe, Cin, Cout, k, s, p, H, W):
+def test_pipe_conv_fwd_dgrad(pipe_big, Cin, Cout, k, s, p, H, W):
+    pipe = pipe_big
     """implicit-GEMM conv forward / backward-data through every tile configuration of the pipelined kernel, incl. the stride-2
     dgrad parity classes, ragged last row tiles, image-crossing tiles and the 160- / 96-row tiles with uneven piece counts"""
     test_conv_fwd_dgrad_wgrad(torch.bfloat16, Cin, Cout, k, s, p, H, W)

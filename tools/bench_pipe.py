@@ -11,8 +11,8 @@ import gpv1_amd.hip as hip
 
 B = 32
 dev = 'cuda'
-NCFG = 6
-CFG = ['256x128', '192x128', '128x128', '160x256', '128x256', '96x256']
+NCFG = 8
+CFG = ['256x128', '192x128', '128x128', '160x256', '128x256', '96x256', '64x64s6', '32x64s8']
 FWD = [  # name, Cin, Cout, k, s, p, H, W, with_res
     ('l2.c1', 512, 128, 1, 1, 0, 60, 80, 0), ('l2.c2', 128, 128, 3, 1, 1, 60, 80, 0), ('l2.c3', 128, 512, 1, 1, 0, 60, 80, 1),
     ('l2.0c1', 256, 128, 1, 1, 0, 120, 160, 0), ('l2.0c2s2', 128, 128, 3, 2, 1, 120, 160, 0),
@@ -26,6 +26,9 @@ DGRAD = [('l2.c3', 128, 512, 1, 1, 0, 60, 80), ('l2.c2', 128, 128, 3, 1, 1, 60, 
          ('l3.0c2s2', 256, 256, 3, 2, 1, 60, 80), ('l3.0ds', 512, 1024, 1, 2, 0, 60, 80),
          ('l4.c3', 512, 2048, 1, 1, 0, 15, 20), ('l4.c2', 512, 512, 3, 1, 1, 15, 20), ('l4.c1', 2048, 512, 1, 1, 0, 15, 20),
          ('l4.0c2s2', 512, 512, 3, 2, 1, 30, 40), ('l4.0ds', 1024, 2048, 1, 2, 0, 30, 40)]
+SMALL = [(192, 768, 768), (192, 2304, 768), (192, 3072, 768), (192, 768, 3072), (640, 768, 768), (640, 2304, 768), (640, 2048, 768),
+         (640, 768, 2048), (3392, 1536, 768), (3200, 768, 768), (3200, 768, 2304), (3200, 256, 256), (3200, 512, 256), (3200, 256, 2048),
+         (3200, 2048, 256), (9600, 256, 256), (9600, 512, 256)]
 GEMMS = [(9600, 2048, 256), (9600, 256, 2048), (9600, 256, 256), (9600, 512, 256), (3200, 768, 2304), (3200, 3072, 768), (3200, 768, 3072),
          (3200, 768, 768), (640, 10000, 768), (4096, 4096, 4096), (8192, 8192, 8192)]
 
@@ -121,5 +124,26 @@ def main():
         sweep('g', M, N, K, run, c, 2.0 * M * N * K)
 
 
+def small():
+    print('configs:', CFG)
+    print('--- small-M GEMMs (NT): old = skinny / 4-wave kernels')
+    tot = [0.0, 0.0, 0.0]
+    for (M, N, K) in SMALL:
+        a = torch.randn(M, K, device=dev).to(torch.bfloat16)
+        b = (torch.randn(N, K, device=dev) / K ** 0.5).to(torch.bfloat16)
+        c = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+        bias = torch.randn(N, device=dev)
+
+        def run():
+            hip.gemm(a, b, c, M, N, K, K, K, N, bias=bias)
+        r = sweep('s', M, N, K, run, c, 2.0 * M * N * K)
+        for i in range(3):
+            tot[i] += r[i]
+    print('small sums: old %.1f best %.1f auto %.1f' % tuple(tot))
+
+
 if __name__ == '__main__':
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == 'small':
+        small()
+    else:
+        main()
