@@ -28,6 +28,7 @@ class WordPieceTokenizer:
         with open(vocab_file, encoding='utf-8') as f:
             self.vocab = {w.rstrip('\n'): i for i, w in enumerate(f)}
         self.unk, self.cls, self.sep, self.pad = (self.vocab[t] for t in ('[UNK]', '[CLS]', '[SEP]', '[PAD]'))
+        self.SPECIALS = tuple(t for t in self.SPECIALS if t in self.vocab)
 
     @staticmethod
     def _is_punct(ch):
@@ -36,8 +37,34 @@ class WordPieceTokenizer:
             return True
         return unicodedata.category(ch).startswith('P')
 
+    SPECIALS = ('[UNK]', '[SEP]', '[PAD]', '[CLS]', '[MASK]')
+
+    @staticmethod
+    def _is_cjk(cp):
+        return (0x4E00 <= cp <= 0x9FFF or 0x3400 <= cp <= 0x4DBF or 0x20000 <= cp <= 0x2A6DF or 0x2A700 <= cp <= 0x2B73F or
+                0x2B740 <= cp <= 0x2B81F or 0x2B820 <= cp <= 0x2CEAF or 0xF900 <= cp <= 0xFAFF or 0x2F800 <= cp <= 0x2FA1F)
+
     def basic(self, text):
-        text = unicodedata.normalize('NFD', text.lower())
+        """HF BasicTokenizer(do_lower_case=True): clean (drop NUL / U+FFFD / control characters, any whitespace -> space), put
+        spaces around CJK characters, lower-case, NFD + strip combining marks, split on whitespace and punctuation"""
+        cleaned = []
+        for ch in text:
+            cp = ord(ch)
+            if cp == 0 or cp == 0xFFFD:
+                continue
+            if ch in '\t\n\r':
+                cleaned.append(' ')
+                continue
+            cat = unicodedata.category(ch)
+            if cat.startswith('C'):
+                continue
+            if cat == 'Zs':
+                cleaned.append(' ')
+            elif self._is_cjk(cp):
+                cleaned.append(' ' + ch + ' ')
+            else:
+                cleaned.append(ch)
+        text = unicodedata.normalize('NFD', ''.join(cleaned).lower())
         out, cur = [], ''
         for ch in text:
             if unicodedata.category(ch) == 'Mn':
@@ -56,6 +83,17 @@ class WordPieceTokenizer:
         if cur:
             out.append(cur)
         return out
+
+    def tokenize_ids(self, text):
+        """special tokens written in the text are kept whole (HF splits the text on them before anything else)"""
+        import re
+        ids = []
+        for part in re.split('(' + '|'.join(re.escape(t) for t in self.SPECIALS) + ')', text):
+            if part in self.SPECIALS:
+                ids.append(self.vocab[part])
+            elif part:
+                ids.extend(i for w in self.basic(part) for i in self.wordpiece(w))
+        return ids
 
     def wordpiece(self, word):
         if len(word) > 100:
@@ -76,7 +114,7 @@ class WordPieceTokenizer:
         return ids
 
     def __call__(self, sentences):
-        seqs = [[self.cls] + [i for w in self.basic(s) for i in self.wordpiece(w)] + [self.sep] for s in sentences]
+        seqs = [[self.cls] + self.tokenize_ids(s) + [self.sep] for s in sentences]
         T = max(len(s) for s in seqs)
         ids = torch.full((len(seqs), T), self.pad, dtype=torch.long)
         attn = torch.zeros(len(seqs), T, dtype=torch.long)

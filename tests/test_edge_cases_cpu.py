@@ -93,3 +93,44 @@ def test_matcher_ties_and_more_targets_than_queries():
     many = [{'boxes': torch.rand(5, 4) * 0.3 + 0.3, 'labels': torch.zeros(5, dtype=torch.long)}]
     (pi, ti), = m({'pred_relevance_logits': logits, 'pred_boxes': boxes}, many)
     assert len(pi) == 3 and len(set(ti.tolist())) == 3
+
+
+def test_load_pretr_detr_and_phase1_freeze(shim, tmp_path):
+    """gpv.py:122-135 + train_distr.py:136-140: a DETR checkpoint ({'model': keys without the 'detr.' prefix}) initialises
+    the matching tensors only -- same name AND same size --, remembers them in init_detr_params, leaves everything else
+    alone; phase 1 of the reference's schedule (training.freeze) then freezes exactly that list."""
+    from gpv1_amd.train_distr import freeze_detr_params
+    model, _ = build_small()
+    before = {k: v.clone() for k, v in model.state_dict().items()}
+    g = torch.Generator().manual_seed(7)
+    ckpt = {}
+    take = ['backbone.0.body.layer2.0.conv1.weight', 'backbone.0.body.layer2.0.bn1.running_var', 'transformer.encoder.layers.0.linear1.weight',
+            'transformer.decoder.layers.1.norm3.bias', 'input_proj.bias', 'bbox_embed.layers.2.weight']
+    for k in take:
+        ckpt[k] = torch.randn(before['detr.' + k].shape, generator=g)
+    ckpt['class_embed.weight'] = torch.randn(92, 256, generator=g)          # COCO DETR head: 92 classes -> size mismatch, skipped
+    ckpt['class_embed.bias'] = torch.randn(92, generator=g)
+    ckpt['query_embed.weight'] = torch.randn(100, 256, generator=g)         # 100 queries vs the fixture's 10 -> skipped
+    ckpt['not_in_the_model.weight'] = torch.randn(3, 3, generator=g)        # unknown name -> ignored
+    path = tmp_path / 'detr.pth'
+    torch.save({'model': ckpt}, path)
+    model.cfg['pretr_detr'] = str(path)
+    model.load_pretr_detr()
+    assert sorted(model.init_detr_params) == sorted('detr.' + k for k in take)
+    after = model.state_dict()
+    for k, v in after.items():
+        lk = k[len('detr.'):] if k.startswith('detr.') else None
+        if lk in take:
+            assert torch.equal(v, ckpt[lk]), k
+        else:
+            assert torch.equal(v, before[k]), k                              # incl. the size-mismatched class_embed / query_embed
+    # phase 1: exactly the loaded tensors that are parameters stop training (buffers such as running_var are not parameters)
+    rg_before = {n: p.requires_grad for n, p in model.named_parameters()}
+    freeze_detr_params(model)
+    for n, p in model.named_parameters():
+        if n in model.init_detr_params:
+            assert p.requires_grad is False, n
+        else:
+            assert p.requires_grad == rg_before[n], n
+    freeze_detr_params(model, requires_grad=True)                           # phase 2 (finetune): released again
+    assert all(p.requires_grad for n, p in model.named_parameters() if n in model.init_detr_params)
