@@ -110,7 +110,7 @@ __device__ __forceinline__ bf16x8 ld_pair64(const bf16* p0, const bf16* p1) {
 }
 
 // MODE 0: forward (writes o, lse).  MODE 1: dQ (reads dout, o, lse; writes dq)
-template <typename T, int DHK, int DHV, int NT, int MODE>
+template <typename T, int DHK, int DHV, int NT, int MODE, bool MASKED>
 __global__ __launch_bounds__(256, DHK < 96 ? 2 : 1) void attn_q_kernel(AttnK p) {
   if (p.dthresh) p.seed = eff_seed(p.seed, p.seed_dev);
   constexpr bool PRECISE = sizeof(T) == 4;
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256, DHK < 96 ? 2 : 1) void attn_q_kernel(AttnK p) 
   bf16* Vh = Tl + DHV * vtp;
   bf16* Vl = Vh + (PRECISE ? skp * KP : 0);
 
-  const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64;
+  const int b = blockIdx.z, h = blockIdx.y;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
   const T* kg = reinterpret_cast<const T*>(p.k) + b * p.k_bs + h * p.dh;
   const T* vg = reinterpret_cast<const T*>(p.v) + b * p.v_bs + h * p.dh;
@@ -140,262 +140,274 @@ __global__ __launch_bounds__(256, DHK < 96 ? 2 : 1) void attn_q_kernel(AttnK p) 
   }
   __syncthreads();
 
-  const int q = q0 + wave * 16 + (lane & 15);
-  const bool qok = q < p.Sq;
-  // Q (and dO, O) fragments straight from global: lane (q, g) holds d = kc*32 + g*8 .. +7
-  bf16x8 qh[KC], ql[KC], doh[KC], dol[KC];
-  float delta = 0.f;
-  {
-    const T* qp = reinterpret_cast<const T*>(p.q) + b * p.q_bs + (int64_t)q * p.q_rs + h * p.dh;
-    const T* dop = MODE ? reinterpret_cast<const T*>(p.dout) + b * p.do_bs + (int64_t)q * p.do_rs + h * p.dh : nullptr;
-    const T* op = MODE ? reinterpret_cast<const T*>(p.o) + b * p.o_bs + (int64_t)q * p.o_rs + h * p.dh : nullptr;
-#pragma unroll
-    for (int kc = 0; kc < KC; ++kc) {
-      const int d0 = kc * 32 + g * 8;
-      R8<T> x;
-      if (qok && d0 < p.dh) x.load(qp + d0); else x.zero();
-      qh[kc] = x.hi(); ql[kc] = x.lo();
-      if (MODE) {
-        R8<T> y, z;
-        if (qok && d0 < p.dh) { y.load(dop + d0); z.load(op + d0); } else { y.zero(); z.zero(); }
-        doh[kc] = y.hi(); dol[kc] = y.lo();
-#pragma unroll
-        for (int e = 0; e < 8; ++e) delta += y.v[e] * z.v[e];
+  // One block serves `per` consecutive 16-query tiles of its (batch, head): K and V are staged ONCE and every wave walks its
+  // share of the tiles.  (Round 1 staged them once per 64 queries: 5 blocks per head re-staged the same 38 KB, and the waves
+  // spent 61 % of their cycles waiting on that staging -- PMC, profiles/r02_pmc_attention.txt.)
+  const int nqt = (p.Sq + 15) >> 4;
+  const int per = (nqt + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int qt_end = min(nqt, ((int)blockIdx.x + 1) * per);
+  for (int qt = (int)blockIdx.x * per + wave; qt < qt_end; qt += 4) {
+    const int q = qt * 16 + (lane & 15);
+    const bool qok = q < p.Sq;
+    // Q (and dO, O) fragments straight from global: lane (q, g) holds d = kc*32 + g*8 .. +7
+    bf16x8 qh[KC], ql[KC], doh[KC], dol[KC];
+    float delta = 0.f;
+    {
+      const T* qp = reinterpret_cast<const T*>(p.q) + b * p.q_bs + (int64_t)q * p.q_rs + h * p.dh;
+      const T* dop = MODE ? reinterpret_cast<const T*>(p.dout) + b * p.do_bs + (int64_t)q * p.do_rs + h * p.dh : nullptr;
+      const T* op = MODE ? reinterpret_cast<const T*>(p.o) + b * p.o_bs + (int64_t)q * p.o_rs + h * p.dh : nullptr;
+  #pragma unroll
+      for (int kc = 0; kc < KC; ++kc) {
+        const int d0 = kc * 32 + g * 8;
+        R8<T> x;
+        if (qok && d0 < p.dh) x.load(qp + d0); else x.zero();
+        qh[kc] = x.hi(); ql[kc] = x.lo();
+        if (MODE) {
+          R8<T> y, z;
+          if (qok && d0 < p.dh) { y.load(dop + d0); z.load(op + d0); } else { y.zero(); z.zero(); }
+          doh[kc] = y.hi(); dol[kc] = y.lo();
+  #pragma unroll
+          for (int e = 0; e < 8; ++e) delta += y.v[e] * z.v[e];
+        }
       }
+      if (MODE) { delta += __shfl_xor(delta, 16); delta += __shfl_xor(delta, 32); }
     }
-    if (MODE) { delta += __shfl_xor(delta, 16); delta += __shfl_xor(delta, 32); }
-  }
 
-  if constexpr (MODE == 1) {
-    // ---- dQ, streamed over pairs of 16-key tiles: the probabilities are recomputed from the saved log-sum-exp, so
-    // nothing needs all Sk scores at once.  (Holding them -- as the forward must for its max/sum -- cost 256+ VGPRs:
-    // one wave per SIMD, 159 us for the encoder shape; two live tiles fit 3-4 waves per SIMD.) ----
-    const uint8_t* kpm1 = p.kpm ? p.kpm + (int64_t)b * p.Sk : nullptr;
-    const float c2q = p.scale * 1.4426950408889634f;
-    const float lse1 = qok ? -p.lse[((int64_t)b * p.H + h) * p.Sq + q] * 1.4426950408889634f : 0.f;   // exp(s*scale - lse) = exp2(s*c2 + lse1)
-    const uint32_t rs1 = p.dthresh ? attn_row_seed(p.seed, ((uint64_t)b * p.H + h) * p.Sq + q) : 0u;
-    const uint32_t t16 = p.dthresh >> 16;
-    const bool masked1 = kpm1 != nullptr || p.causal;
-    f32x4 dq[DT];
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
-    for (int kb = 0; kb < NT / 2; ++kb) {
-      if (kb * 2 >= ntr) break;
-      f32x4 sj[2];
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const int j = 2 * kb + t;
-        f32x4 sc = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (j < ntr) {
-#pragma unroll
-          for (int kc = 0; kc < KC; ++kc) {
-            const int off = (j * 16 + (lane & 15)) * KP + kc * 32 + g * 8;
-            const bf16x8 kh = *reinterpret_cast<const bf16x8*>(Kh + off);
-            const bf16x8 vh = *reinterpret_cast<const bf16x8*>(Vh + off);
-            sc = mfma16(kh, qh[kc], sc);
-            dp = mfma16(vh, doh[kc], dp);
-            if (PRECISE) {
-              const bf16x8 kl = *reinterpret_cast<const bf16x8*>(Kl + off);
-              const bf16x8 vl = *reinterpret_cast<const bf16x8*>(Vl + off);
-              sc = mfma16(kl, qh[kc], sc);
-              sc = mfma16(kh, ql[kc], sc);
-              dp = mfma16(vl, doh[kc], dp);
-              dp = mfma16(vh, dol[kc], dp);
+    if constexpr (MODE == 1) {
+      // ---- dQ, streamed over pairs of 16-key tiles: the probabilities are recomputed from the saved log-sum-exp, so
+      // nothing needs all Sk scores at once.  (Holding them -- as the forward must for its max/sum -- cost 256+ VGPRs:
+      // one wave per SIMD, 159 us for the encoder shape; two live tiles fit 3-4 waves per SIMD.) ----
+      const uint8_t* kpm1 = p.kpm ? p.kpm + (int64_t)b * p.Sk : nullptr;
+      const float c2q = p.scale * 1.4426950408889634f;
+      const float lse1 = qok ? -p.lse[((int64_t)b * p.H + h) * p.Sq + q] * 1.4426950408889634f : 0.f;   // exp(s*scale - lse) = exp2(s*c2 + lse1)
+      const uint32_t rs1 = p.dthresh ? attn_row_seed(p.seed, ((uint64_t)b * p.H + h) * p.Sq + q) : 0u;
+      const uint32_t t16 = p.dthresh >> 16;
+      constexpr bool masked1 = MASKED;
+      f32x4 dq[DT];
+  #pragma unroll
+      for (int dt = 0; dt < DT; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  #pragma unroll 2
+      for (int kb = 0; kb < NT / 2; ++kb) {
+        if (kb * 2 >= ntr) break;
+        f32x4 sj[2];
+  #pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int j = 2 * kb + t;
+          f32x4 sc = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (j < ntr) {
+  #pragma unroll
+            for (int kc = 0; kc < KC; ++kc) {
+              const int off = (j * 16 + (lane & 15)) * KP + kc * 32 + g * 8;
+              const bf16x8 kh = *reinterpret_cast<const bf16x8*>(Kh + off);
+              const bf16x8 vh = *reinterpret_cast<const bf16x8*>(Vh + off);
+              sc = mfma16(kh, qh[kc], sc);
+              dp = mfma16(vh, doh[kc], dp);
+              if (PRECISE) {
+                const bf16x8 kl = *reinterpret_cast<const bf16x8*>(Kl + off);
+                const bf16x8 vl = *reinterpret_cast<const bf16x8*>(Vl + off);
+                sc = mfma16(kl, qh[kc], sc);
+                sc = mfma16(kh, ql[kc], sc);
+                dp = mfma16(vl, doh[kc], dp);
+                dp = mfma16(vh, dol[kc], dp);
+              }
             }
           }
-        }
-        uint32_t km1 = 0u;
-        if (kpm1) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) km1 |= (uint32_t)kpm1[min(j * 16 + g * 4 + i, p.Sk - 1)] << (8 * i);
-        }
-        uint32_t w01 = 0u, w23 = 0u;
-        if (p.dthresh) {
-          const uint32_t pb = rs1 + (uint32_t)(j * 8 + g * 2) * ATTN_PAIR_STEP;
-          w01 = attn_pair_bits(pb); w23 = attn_pair_bits(pb + ATTN_PAIR_STEP);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int key = j * 16 + g * 4 + i;
-          float pr = __builtin_amdgcn_exp2f(fmaf(sc[i], c2q, lse1));         // normalised P
-          if (masked1 || j * 16 + 16 > p.Sk) {
-            const bool dead = key >= p.Sk || (p.causal && key > q) || ((km1 >> (8 * i)) & 0xffu) != 0u;
-            pr = dead ? 0.f : pr;
+          uint32_t km1 = 0u;
+          if (MASKED && kpm1) {
+  #pragma unroll
+            for (int i = 0; i < 4; ++i) km1 |= (uint32_t)kpm1[min(j * 16 + g * 4 + i, p.Sk - 1)] << (8 * i);
           }
-          float d = dp[i];
+          uint32_t w01 = 0u, w23 = 0u;
           if (p.dthresh) {
-            const uint32_t w = i < 2 ? w01 : w23;
-            d = ((i & 1) ? (w >> 16) : (w & 0xffffu)) >= t16 ? d * p.dscale : 0.f;
+            const uint32_t pb = rs1 + (uint32_t)(j * 8 + g * 2) * ATTN_PAIR_STEP;
+            w01 = attn_pair_bits(pb); w23 = attn_pair_bits(pb + ATTN_PAIR_STEP);
           }
-          sj[t][i] = pr * (d - delta) * p.scale;
+  #pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int key = j * 16 + g * 4 + i;
+            float pr = __builtin_amdgcn_exp2f(fmaf(sc[i], c2q, lse1));         // normalised P
+            if (masked1 || j * 16 + 16 > p.Sk) {
+              const bool dead = key >= p.Sk || (p.causal && key > q) || ((km1 >> (8 * i)) & 0xffu) != 0u;
+              pr = dead ? 0.f : pr;
+            }
+            float d = dp[i];
+            if (p.dthresh) {
+              const uint32_t w = i < 2 ? w01 : w23;
+              d = ((i & 1) ? (w >> 16) : (w & 0xffffu)) >= t16 ? d * p.dscale : 0.f;
+            }
+            sj[t][i] = pr * (d - delta) * p.scale;
+          }
+        }
+        bf16x8 ph, pl;
+  #pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float a = sj[0][i], c = sj[1][i];
+          ph[i] = (bf16)a; ph[4 + i] = (bf16)c;
+          pl[i] = (bf16)(a - (float)ph[i]); pl[4 + i] = (bf16)(c - (float)ph[4 + i]);
+        }
+  #pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          const int off = (dt * 16 + (lane & 15)) * vtp + kb * 32 + g * 4;
+          const bf16x8 xh = ld_pair64(Th + off, Th + off + 16);
+          dq[dt] = mfma16(xh, ph, dq[dt]);
+          if (PRECISE) {
+            const bf16x8 xl = ld_pair64(Tl + off, Tl + off + 16);
+            dq[dt] = mfma16(xl, ph, dq[dt]);
+            dq[dt] = mfma16(xh, pl, dq[dt]);
+          }
         }
       }
-      bf16x8 ph, pl;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float a = sj[0][i], c = sj[1][i];
-        ph[i] = (bf16)a; ph[4 + i] = (bf16)c;
-        pl[i] = (bf16)(a - (float)ph[i]); pl[4 + i] = (bf16)(c - (float)ph[4 + i]);
-      }
-#pragma unroll
+      if (!qok) continue;
+      T* outp1 = reinterpret_cast<T*>(p.dq) + b * p.q_bs + (int64_t)q * p.q_rs + h * p.dh;
+  #pragma unroll
       for (int dt = 0; dt < DT; ++dt) {
-        const int off = (dt * 16 + (lane & 15)) * vtp + kb * 32 + g * 4;
-        const bf16x8 xh = ld_pair64(Th + off, Th + off + 16);
-        dq[dt] = mfma16(xh, ph, dq[dt]);
-        if (PRECISE) {
-          const bf16x8 xl = ld_pair64(Tl + off, Tl + off + 16);
-          dq[dt] = mfma16(xl, ph, dq[dt]);
-          dq[dt] = mfma16(xh, pl, dq[dt]);
+        const int d = dt * 16 + g * 4;
+        if (sizeof(T) == 4) {
+          *reinterpret_cast<float4*>(reinterpret_cast<float*>(outp1) + d) = make_float4(dq[dt][0], dq[dt][1], dq[dt][2], dq[dt][3]);
+        } else {
+          bf16x4 o4;
+  #pragma unroll
+          for (int i = 0; i < 4; ++i) o4[i] = (bf16)dq[dt][i];
+          *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(outp1) + d) = o4;
+        }
+      }
+      continue;
+    }
+
+    // ---- forward: scores S^T[key][q] for all key tiles, softmax over the registers, out^T = V^T P^T ----
+    // The core is VALU-bound at dh = 32 (2 MFMAs per 256 scores against every per-score VALU instruction): what is spent per
+    // score is one max, one fma + v_exp (scale and max folded into the fma, base-2 exponent), one add, the dropout select and
+    // the bf16 pack.  Masks cost nothing when there are none (no key-padding mask, not causal): only the tail tiles test keys.
+    f32x4 s[NT];
+  #pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      s[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (j < ntr) {
+  #pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {
+          const int off = (j * 16 + (lane & 15)) * KP + kc * 32 + g * 8;
+          bf16x8 kh = *reinterpret_cast<const bf16x8*>(Kh + off);
+          s[j] = mfma16(kh, qh[kc], s[j]);
+          if (PRECISE) {
+            bf16x8 kl = *reinterpret_cast<const bf16x8*>(Kl + off);
+            s[j] = mfma16(kl, qh[kc], s[j]);
+            s[j] = mfma16(kh, ql[kc], s[j]);
+          }
         }
       }
     }
-    if (!qok) return;
-    T* outp1 = reinterpret_cast<T*>(p.dq) + b * p.q_bs + (int64_t)q * p.q_rs + h * p.dh;
-#pragma unroll
+    const uint8_t* kpm = p.kpm ? p.kpm + (int64_t)b * p.Sk : nullptr;
+    if constexpr (MASKED) {
+      // key-padding bytes of this lane's 4 keys per tile, fetched up front WITHOUT per-element branches
+      uint32_t km[NT];
+  #pragma unroll
+      for (int j = 0; j < NT; ++j) km[j] = 0u;
+      if (kpm) {
+  #pragma unroll
+        for (int j = 0; j < NT; ++j) {
+  #pragma unroll
+          for (int i = 0; i < 4; ++i) km[j] |= (uint32_t)kpm[min(j * 16 + g * 4 + i, p.Sk - 1)] << (8 * i);
+        }
+      }
+  #pragma unroll
+      for (int j = 0; j < NT; ++j) {
+  #pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int key = j * 16 + g * 4 + i;
+          const bool dead = key >= p.Sk || (p.causal && key > q) || ((km[j] >> (8 * i)) & 0xffu) != 0u;
+          s[j][i] = dead ? -INFINITY : s[j][i];
+        }
+      }
+    } else {
+  #pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        if (j * 16 + 16 > p.Sk) {                      // (uniform) tail tiles only
+  #pragma unroll
+          for (int i = 0; i < 4; ++i) s[j][i] = (j * 16 + g * 4 + i >= p.Sk) ? -INFINITY : s[j][i];
+        }
+      }
+    }
+    float mx = -INFINITY;
+  #pragma unroll
+    for (int j = 0; j < NT; ++j)
+  #pragma unroll
+      for (int i = 0; i < 4; ++i) mx = fmaxf(mx, s[j][i]);
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float c2 = p.scale * 1.4426950408889634f;           // exp(scale * (s - mx)) = exp2(s * c2 - mx * c2)
+    const float nm = mx == -INFINITY ? 0.f : -mx * c2;
+    float lsum = 0.f;
+  #pragma unroll
+    for (int j = 0; j < NT; ++j)
+  #pragma unroll
+      for (int i = 0; i < 4; ++i) { const float e = __builtin_amdgcn_exp2f(fmaf(s[j][i], c2, nm)); s[j][i] = e; lsum += e; }
+    lsum += __shfl_xor(lsum, 16);
+    lsum += __shfl_xor(lsum, 32);
+    if (g == 0 && qok && p.lse) p.lse[((int64_t)b * p.H + h) * p.Sq + q] = (mx == -INFINITY ? 0.f : mx * p.scale) + logf(lsum);
+
+    if (p.dthresh) {
+      const uint32_t rs = attn_row_seed(p.seed, ((uint64_t)b * p.H + h) * p.Sq + q);
+      const uint32_t t16 = p.dthresh >> 16;
+      const uint32_t gb = rs + (uint32_t)(g * 2) * ATTN_PAIR_STEP;
+  #pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        if (j < ntr) {
+          const uint32_t w0 = attn_pair_bits(gb + (uint32_t)(j * 8) * ATTN_PAIR_STEP);
+          const uint32_t w1 = attn_pair_bits(gb + (uint32_t)(j * 8 + 1) * ATTN_PAIR_STEP);
+          s[j][0] = (w0 & 0xffffu) >= t16 ? s[j][0] * p.dscale : 0.f;
+          s[j][1] = (w0 >> 16) >= t16 ? s[j][1] * p.dscale : 0.f;
+          s[j][2] = (w1 & 0xffffu) >= t16 ? s[j][2] * p.dscale : 0.f;
+          s[j][3] = (w1 >> 16) >= t16 ? s[j][3] * p.dscale : 0.f;
+        }
+      }
+    }
+
+    // ---- out^T[d][q] = sum_key V^T[d][key] * P^T[key][q] ----
+    // (scheduling fences: left alone, hipcc hoists the V^T fragment reads of all ten key blocks above the softmax -- 80 more live
+    //  registers on top of the 80 scores: 256 VGPRs and 106 spilled to scratch in round 1's build of this kernel)
+    f32x4 oacc[DT];
+  #pragma unroll
+    for (int dt = 0; dt < DT; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    __builtin_amdgcn_sched_barrier(0);
+  #pragma unroll
+    for (int kb = 0; kb < NT / 2; ++kb) {
+      if (kb & 1) __builtin_amdgcn_sched_barrier(0);
+      if (kb * 2 < ntr) {
+        bf16x8 ph, pl;
+  #pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float a = s[2 * kb][i], c = s[2 * kb + 1][i];
+          ph[i] = (bf16)a; ph[4 + i] = (bf16)c;
+          if (PRECISE) { pl[i] = (bf16)(a - (float)ph[i]); pl[4 + i] = (bf16)(c - (float)ph[4 + i]); }
+        }
+  #pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          const int off = (dt * 16 + (lane & 15)) * vtp + kb * 32 + g * 4;
+          bf16x8 xh = ld_pair64(Th + off, Th + off + 16);
+          oacc[dt] = mfma16(xh, ph, oacc[dt]);
+          if (PRECISE) {
+            bf16x8 xl = ld_pair64(Tl + off, Tl + off + 16);
+            oacc[dt] = mfma16(xl, ph, oacc[dt]);
+            oacc[dt] = mfma16(xh, pl, oacc[dt]);
+          }
+        }
+      }
+    }
+    if (!qok) continue;
+    T* outp = reinterpret_cast<T*>(p.o) + b * p.o_bs + (int64_t)q * p.o_rs + h * p.dh;
+    const float inv = lsum > 0.f ? 1.f / lsum : 0.f;
+  #pragma unroll
     for (int dt = 0; dt < DT; ++dt) {
       const int d = dt * 16 + g * 4;
       if (sizeof(T) == 4) {
-        *reinterpret_cast<float4*>(reinterpret_cast<float*>(outp1) + d) = make_float4(dq[dt][0], dq[dt][1], dq[dt][2], dq[dt][3]);
+        *reinterpret_cast<float4*>(reinterpret_cast<float*>(outp) + d) =
+            make_float4(oacc[dt][0] * inv, oacc[dt][1] * inv, oacc[dt][2] * inv, oacc[dt][3] * inv);
       } else {
         bf16x4 o4;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) o4[i] = (bf16)dq[dt][i];
-        *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(outp1) + d) = o4;
+  #pragma unroll
+        for (int i = 0; i < 4; ++i) o4[i] = (bf16)(oacc[dt][i] * inv);
+        *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(outp) + d) = o4;
       }
-    }
-    return;
-  }
-
-  // ---- forward: scores S^T[key][q] for all key tiles, softmax over the registers, out^T = V^T P^T ----
-  // The core is VALU-bound at dh = 32 (2 MFMAs per 256 scores against every per-score VALU instruction): what is spent per
-  // score is one max, one fma + v_exp (scale and max folded into the fma, base-2 exponent), one add, the dropout select and
-  // the bf16 pack.  Masks cost nothing when there are none (no key-padding mask, not causal): only the tail tiles test keys.
-  f32x4 s[NT];
-#pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    s[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (j < ntr) {
-#pragma unroll
-      for (int kc = 0; kc < KC; ++kc) {
-        const int off = (j * 16 + (lane & 15)) * KP + kc * 32 + g * 8;
-        bf16x8 kh = *reinterpret_cast<const bf16x8*>(Kh + off);
-        s[j] = mfma16(kh, qh[kc], s[j]);
-        if (PRECISE) {
-          bf16x8 kl = *reinterpret_cast<const bf16x8*>(Kl + off);
-          s[j] = mfma16(kl, qh[kc], s[j]);
-          s[j] = mfma16(kh, ql[kc], s[j]);
-        }
-      }
-    }
-  }
-  const uint8_t* kpm = p.kpm ? p.kpm + (int64_t)b * p.Sk : nullptr;
-  if (kpm != nullptr || p.causal) {
-    // key-padding bytes of this lane's 4 keys per tile, fetched up front WITHOUT per-element branches
-    uint32_t km[NT];
-#pragma unroll
-    for (int j = 0; j < NT; ++j) km[j] = 0u;
-    if (kpm) {
-#pragma unroll
-      for (int j = 0; j < NT; ++j) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) km[j] |= (uint32_t)kpm[min(j * 16 + g * 4 + i, p.Sk - 1)] << (8 * i);
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int key = j * 16 + g * 4 + i;
-        const bool dead = key >= p.Sk || (p.causal && key > q) || ((km[j] >> (8 * i)) & 0xffu) != 0u;
-        s[j][i] = dead ? -INFINITY : s[j][i];
-      }
-    }
-  } else {
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      if (j * 16 + 16 > p.Sk) {                      // (uniform) tail tiles only
-#pragma unroll
-        for (int i = 0; i < 4; ++i) s[j][i] = (j * 16 + g * 4 + i >= p.Sk) ? -INFINITY : s[j][i];
-      }
-    }
-  }
-  float mx = -INFINITY;
-#pragma unroll
-  for (int j = 0; j < NT; ++j)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) mx = fmaxf(mx, s[j][i]);
-  mx = fmaxf(mx, __shfl_xor(mx, 16));
-  mx = fmaxf(mx, __shfl_xor(mx, 32));
-  const float c2 = p.scale * 1.4426950408889634f;           // exp(scale * (s - mx)) = exp2(s * c2 - mx * c2)
-  const float nm = mx == -INFINITY ? 0.f : -mx * c2;
-  float lsum = 0.f;
-#pragma unroll
-  for (int j = 0; j < NT; ++j)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { const float e = __builtin_amdgcn_exp2f(fmaf(s[j][i], c2, nm)); s[j][i] = e; lsum += e; }
-  lsum += __shfl_xor(lsum, 16);
-  lsum += __shfl_xor(lsum, 32);
-  if (g == 0 && qok && p.lse) p.lse[((int64_t)b * p.H + h) * p.Sq + q] = (mx == -INFINITY ? 0.f : mx * p.scale) + logf(lsum);
-
-  if (p.dthresh) {
-    const uint32_t rs = attn_row_seed(p.seed, ((uint64_t)b * p.H + h) * p.Sq + q);
-    const uint32_t t16 = p.dthresh >> 16;
-    const uint32_t gb = rs + (uint32_t)(g * 2) * ATTN_PAIR_STEP;
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      if (j < ntr) {
-        const uint32_t w0 = attn_pair_bits(gb + (uint32_t)(j * 8) * ATTN_PAIR_STEP);
-        const uint32_t w1 = attn_pair_bits(gb + (uint32_t)(j * 8 + 1) * ATTN_PAIR_STEP);
-        s[j][0] = (w0 & 0xffffu) >= t16 ? s[j][0] * p.dscale : 0.f;
-        s[j][1] = (w0 >> 16) >= t16 ? s[j][1] * p.dscale : 0.f;
-        s[j][2] = (w1 & 0xffffu) >= t16 ? s[j][2] * p.dscale : 0.f;
-        s[j][3] = (w1 >> 16) >= t16 ? s[j][3] * p.dscale : 0.f;
-      }
-    }
-  }
-
-  // ---- out^T[d][q] = sum_key V^T[d][key] * P^T[key][q] ----
-  f32x4 oacc[DT];
-#pragma unroll
-  for (int dt = 0; dt < DT; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int kb = 0; kb < NT / 2; ++kb) {
-    if (kb * 2 < ntr) {
-      bf16x8 ph, pl;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        float a = s[2 * kb][i], c = s[2 * kb + 1][i];
-        ph[i] = (bf16)a; ph[4 + i] = (bf16)c;
-        if (PRECISE) { pl[i] = (bf16)(a - (float)ph[i]); pl[4 + i] = (bf16)(c - (float)ph[4 + i]); }
-      }
-#pragma unroll
-      for (int dt = 0; dt < DT; ++dt) {
-        const int off = (dt * 16 + (lane & 15)) * vtp + kb * 32 + g * 4;
-        bf16x8 xh = ld_pair64(Th + off, Th + off + 16);
-        oacc[dt] = mfma16(xh, ph, oacc[dt]);
-        if (PRECISE) {
-          bf16x8 xl = ld_pair64(Tl + off, Tl + off + 16);
-          oacc[dt] = mfma16(xl, ph, oacc[dt]);
-          oacc[dt] = mfma16(xh, pl, oacc[dt]);
-        }
-      }
-    }
-  }
-  if (!qok) return;
-  T* outp = reinterpret_cast<T*>(p.o) + b * p.o_bs + (int64_t)q * p.o_rs + h * p.dh;
-  const float inv = lsum > 0.f ? 1.f / lsum : 0.f;
-#pragma unroll
-  for (int dt = 0; dt < DT; ++dt) {
-    const int d = dt * 16 + g * 4;
-    if (sizeof(T) == 4) {
-      *reinterpret_cast<float4*>(reinterpret_cast<float*>(outp) + d) =
-          make_float4(oacc[dt][0] * inv, oacc[dt][1] * inv, oacc[dt][2] * inv, oacc[dt][3] * inv);
-    } else {
-      bf16x4 o4;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) o4[i] = (bf16)(oacc[dt][i] * inv);
-      *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(outp) + d) = o4;
     }
   }
 }
@@ -556,24 +568,39 @@ __global__ __launch_bounds__(256) void attn_kv_kernel(AttnK p) {
   }
 }
 
-template <typename T, int DHK, int DHV, int NT, int MODE>
-int launch_q(const AttnK& p, hipStream_t st) {
+template <typename T, int DHK, int DHV, int NT, int MODE, bool MASKED>
+int launch_q_m(const AttnK& p, hipStream_t st) {
   constexpr bool PRECISE = sizeof(T) == 4;
   constexpr int KP = DHK + 8;
   const int vtp = p.skp + 8;
   size_t elems = (size_t)p.skp * KP + (size_t)DHV * vtp + (MODE ? (size_t)p.skp * KP : 0);
   size_t lds = elems * 2 * (PRECISE ? 2 : 1);
-  auto fn = attn_q_kernel<T, DHK, DHV, NT, MODE>;
+  auto fn = attn_q_kernel<T, DHK, DHV, NT, MODE, MASKED>;
   static size_t attr = 0;
   if (lds > 64 * 1024 && lds > attr) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     attr = lds;
   }
-  dim3 grid((p.Sq + 63) / 64, p.H, p.B);
+  // q-tiles of 16 per block: ~10 when there are enough (batch, head) pairs to fill the chip, fewer (down to 4 = one per wave) otherwise
+  const int nqt = (p.Sq + 15) / 16;
+  const int bh = p.B * p.H;
+  int nsplit = (nqt + 9) / 10;
+  const int want = (512 + bh - 1) / bh;
+  if (nsplit < want) nsplit = want;
+  if (nsplit > (nqt + 3) / 4) nsplit = (nqt + 3) / 4;
+  if (nsplit < 1) nsplit = 1;
+  dim3 grid(nsplit, p.H, p.B);
   hipLaunchKernelGGL(fn, grid, dim3(256), lds, st, p);
   GPV_CHECK_LAUNCH();
   return 0;
+}
+template <typename T, int DHK, int DHV, int NT, int MODE>
+int launch_q(const AttnK& p, hipStream_t st) {
+  // masks are a template parameter: the key-padding / causal bookkeeping (20 packed mask words, lane-mask SGPRs) pushed the
+  // mask-free encoder / decoder launches into scratch when both forms shared one body
+  if (p.kpm != nullptr || p.causal) return launch_q_m<T, DHK, DHV, NT, MODE, true>(p, st);
+  return launch_q_m<T, DHK, DHV, NT, MODE, false>(p, st);
 }
 template <typename T, int DHK, int DHV>
 int launch_kv(const AttnK& p, hipStream_t st) {
