@@ -42,21 +42,11 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* p) {
 }
 
 template <bool CONV>
-__device__ __forceinline__ void glds_tt_body(const GemmK& p) {
+__device__ __forceinline__ void glds_tt_core(const GemmK& p, int tile, int ksplit) {
   extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const ConvGeom& g = p.cg;
-
-  // (tile, split) plane, split-major, contiguous range per XCD (see gemm.hip): an XCD runs all tiles of one reduction slice
-  int tile, ksplit;
-  {
-    const int gx = gridDim.x, nwg = gx * (int)gridDim.y, bid = (int)blockIdx.x + gx * (int)blockIdx.y;
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
-    const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-    ksplit = v / gx;
-    tile = v - ksplit * gx;
-  }
   const int tm = tile / p.tilesN, tn = tile - tm * p.tilesN;
   const int row0 = tm * TBM, col0 = tn * TBN;
   const int kt_total = (p.K + TBK - 1) / TBK;
@@ -203,7 +193,11 @@ __device__ __forceinline__ void glds_tt_body(const GemmK& p) {
   }
 
   // ---------------- epilogue: fragments -> LDS (fp32, 64 rows at a time) -> whole rows of this split's slab ----------------
-  float* Cp = p.ws + (int64_t)ksplit * p.M * p.N;
+  // p.ws: this split's slab of the workspace (two-pass reduction); NULL (grouped launch, one block owns the whole reduction of
+  // its tile): C += acc as a coalesced read-modify-write
+  const bool direct = p.ws == nullptr;
+  float* Cp = direct ? reinterpret_cast<float*>(p.C) : p.ws + (int64_t)ksplit * p.M * p.N;
+  const int64_t cpitch = direct ? p.ldc : p.N;
   float* ep = reinterpret_cast<float*>(smem);
   constexpr int EPITCH = TBN + 4;
 #pragma unroll
@@ -226,13 +220,51 @@ __device__ __forceinline__ void glds_tt_body(const GemmK& p) {
       const float rs = p.rowscale ? p.rowscale[m] * p.alpha : p.alpha;
       float4 v = *reinterpret_cast<const float4*>(ep + r * EPITCH + c4 * 4);
       v.x *= rs; v.y *= rs; v.z *= rs; v.w *= rs;
-      *reinterpret_cast<float4*>(Cp + (int64_t)m * p.N + col0 + c4 * 4) = v;
+      float4* dst = reinterpret_cast<float4*>(Cp + (int64_t)m * cpitch + col0 + c4 * 4);
+      if (direct) { const float4 c = *dst; v.x += c.x; v.y += c.y; v.z += c.z; v.w += c.w; }
+      *dst = v;
     }
   }
 }
 
+template <bool CONV>
+__device__ __forceinline__ void glds_tt_body(const GemmK& p) {
+  // (tile, split) plane, split-major, contiguous range per XCD (see gemm.hip): an XCD runs all tiles of one reduction slice
+  const int gx = gridDim.x, nwg = gx * (int)gridDim.y, bid = (int)blockIdx.x + gx * (int)blockIdx.y;
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+  const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  const int ksplit = v / gx;
+  glds_tt_core<CONV>(p, v - ksplit * gx, ksplit);
+}
 __global__ __launch_bounds__(256) void glds_wgrad_kernel(GemmK p) { glds_tt_body<true>(p); }       // conv: B gathered from NHWC x
 __global__ __launch_bounds__(256) void glds_tt_kernel(GemmK p) { glds_tt_body<false>(p); }         // linear: B = x [K][N]
+
+// ---- grouped launch: many independent linear weight gradients in ONE grid ---------------------------------------------------
+// The model body's ~140 weight-gradient GEMMs (0.44 TFLOP in all) are independent of each other and of everything else until
+// the optimizer; launched one by one they cost 3.2 ms (17 us each: launch, first load, a 3-50-step k-loop on 4-144 blocks, a
+// split reduction).  Here up to GPV_TT_GROUP_MAX problems travel in the kernel argument, every 128x128 tile of every problem is
+// one workgroup that walks its whole reduction and adds its tile into the gradient (no split, no workspace, no second pass):
+// tens of thousands of workgroups, the chip stays full.
+struct GroupK {
+  int n;
+  int tile_start[GPV_TT_GROUP_MAX + 1];           // prefix sums of the problems' tile counts
+  gpv_tt_problem prob[GPV_TT_GROUP_MAX];
+};
+static_assert(sizeof(GroupK) <= 4096, "kernel argument segment");
+
+__global__ __launch_bounds__(256) void glds_tt_group_kernel(GroupK g) {
+  const int bid = blockIdx.x;
+  int pi = 0;
+  while (pi + 1 < g.n && bid >= g.tile_start[pi + 1]) ++pi;          // uniform scalar walk (<= 48 steps)
+  const gpv_tt_problem& q = g.prob[pi];
+  GemmK p{};
+  p.A = q.A; p.B = q.B; p.C = q.C; p.a_rowsum = q.a_rowsum;
+  p.M = q.M; p.N = q.N; p.K = q.K; p.lda = q.lda; p.ldb = q.ldb; p.ldc = q.ldc;
+  p.alpha = 1.0f; p.ws = nullptr;
+  p.tilesN = q.N / TBN;
+  p.kt_per_split = (q.K + TBK - 1) / TBK;
+  glds_tt_core<false>(p, bid - g.tile_start[pi], 0);
+}
 
 // shared launch tail: split sizing, workspace slabs, kernel, reduction
 template <typename F>
@@ -302,3 +334,35 @@ int glds_tt_try_launch(const GemmK& k, int dtype_in, int dtype_out, int batch, h
 }
 
 }  // namespace gpvk
+
+extern "C" int gpv_gemm_tt_group(const gpv_tt_problem* problems, int n, void* stream) {
+  using namespace gpvk;
+  if (!problems || n <= 0) return (int)hipErrorInvalidValue;
+  static bool attr_done = false;
+  constexpr int lds = 2 * TSTAGE;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(glds_tt_group_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return (int)e;
+    attr_done = true;
+  }
+  for (int i0 = 0; i0 < n; i0 += GPV_TT_GROUP_MAX) {
+    GroupK g{};
+    g.n = n - i0 < GPV_TT_GROUP_MAX ? n - i0 : GPV_TT_GROUP_MAX;
+    int tiles = 0;
+    for (int i = 0; i < g.n; ++i) {
+      const gpv_tt_problem& q = problems[i0 + i];
+      if (!q.A || !q.B || !q.C || q.M <= 0 || q.N <= 0 || q.K <= 0 || q.M % TBM != 0 || q.N % TBN != 0 || q.lda % 8 != 0 ||
+          q.ldb % 8 != 0 || q.ldc % 4 != 0 || !al16t(q.A) || !al16t(q.B) || !al16t(q.C) ||
+          (int64_t)q.K * q.lda >= (1ll << 30) || (int64_t)q.K * q.ldb >= (1ll << 30))
+        return (int)hipErrorInvalidValue;
+      g.prob[i] = q;
+      g.tile_start[i] = tiles;
+      tiles += (q.M / TBM) * (q.N / TBN);
+    }
+    g.tile_start[g.n] = tiles;
+    hipLaunchKernelGGL(glds_tt_group_kernel, dim3(tiles), dim3(256), lds, reinterpret_cast<hipStream_t>(stream), g);
+    GPV_CHECK_LAUNCH();
+  }
+  return 0;
+}
+

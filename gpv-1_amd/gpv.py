@@ -182,7 +182,8 @@ class GPV(nn.Module):
         """query_encodings: BERT features computed by the caller (train.GraphedBody runs the frozen, no_grad BERT as a
         parallel branch of the backbone's hipGraph: 110 launches of <= 144 workgroups hide under the convolutions)"""
         outputs = self.detr(images)
-        outputs['detr_hs'] = self.detr_joiner(outputs['detr_hs'])                  # [L,B,Q,768]
+        # (backward: everything downstream of the DETR stream -- text decoder, answer head, co-attention -- is done when this fires)
+        outputs['detr_hs'] = self.detr_joiner(ops.boundary(outputs['detr_hs'], 'detr'))     # [L,B,Q,768]
         if query_encodings is None:
             with torch.no_grad():
                 query_encodings, _ = self.bert(queries)

@@ -52,6 +52,11 @@ class AttnArgs(C.Structure):
                 ('dq', C.c_void_p), ('dk', C.c_void_p), ('dv', C.c_void_p)]
 
 
+class TTProblem(C.Structure):
+    _fields_ = [('A', C.c_void_p), ('B', C.c_void_p), ('C', C.c_void_p), ('a_rowsum', C.c_void_p),
+                ('M', C.c_int), ('N', C.c_int), ('K', C.c_int), ('lda', C.c_int), ('ldb', C.c_int), ('ldc', C.c_int)]
+
+
 def lib():
     global _LIB
     if _LIB is None:
@@ -71,7 +76,8 @@ EXPORTS = ['gpv_abi_version', 'gpv_set_option', 'gpv_gemm', 'gpv_conv2d', 'gpv_i
            'gpv_attention_fwd', 'gpv_attention_bwd', 'gpv_layernorm_fwd', 'gpv_layernorm_bwd',
            'gpv_softmax_ce', 'gpv_roi_weights', 'gpv_add', 'gpv_add_rowbcast', 'gpv_colsum', 'gpv_cast',
            'gpv_cast_rowscale_t', 'gpv_prep_conv_weight', 'gpv_embedding', 'gpv_dropout',
-           'gpv_relevance_condition', 'gpv_adamw', 'gpv_sumsq', 'gpv_act_fwd', 'gpv_act_bwd', 'gpv_set_seed_device']
+           'gpv_relevance_condition', 'gpv_adamw', 'gpv_sumsq', 'gpv_act_fwd', 'gpv_act_bwd', 'gpv_set_seed_device',
+           'gpv_gemm_tt_group']
 
 
 OPT_GLDS, OPT_GLDS_LAUNCHES, OPT_SKINNY, OPT_GLDS_WGRAD, OPT_PIPE, OPT_PIPE_LAUNCHES = 0, 1, 2, 3, 4, 5
@@ -177,6 +183,27 @@ def gemm(A, B, Cm, M, N, K, lda, ldb, ldc, layoutA=KMAJOR, layoutB=KMAJOR, batch
         ws = _workspace(A.device, max(max(split_k, 8) * M * N * 4, 512 * 128 * 128 * 4))
         a.workspace, a.workspace_bytes = _p(ws), ws.numel()
     _chk(lib().gpv_gemm(C.byref(a), _stream()), 'gpv_gemm')
+
+
+def tt_group_ok(dy, x, dw, M, N, K, lda, ldb, ldc):
+    """can this weight gradient (dW[M,N] += dy[K,M]^T x[K,N], bf16 operands, fp32 dW) ride in a grouped launch?"""
+    return (dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and dw.dtype == torch.float32 and M % 128 == 0 and N % 128 == 0
+            and lda % 8 == 0 and ldb % 8 == 0 and ldc % 4 == 0 and dy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0
+            and dw.data_ptr() % 16 == 0 and K * max(lda, ldb) < (1 << 30))
+
+
+def gemm_tt_group(problems):
+    """gpv_gemm_tt_group: problems = [(dy, x, dw, bias_grad | None, M, N, K, lda, ldb, ldc), ...]; longest reductions first so that
+    the grid's tail is made of short workgroups"""
+    if not problems:
+        return
+    problems = sorted(problems, key=lambda q: -q[6])
+    arr = (TTProblem * len(problems))()
+    for i, (dy, x, dw, bg, M, N, K, lda, ldb, ldc) in enumerate(problems):
+        a = arr[i]
+        a.A, a.B, a.C, a.a_rowsum = dy.data_ptr(), x.data_ptr(), dw.data_ptr(), (bg.data_ptr() if bg is not None else None)
+        a.M, a.N, a.K, a.lda, a.ldb, a.ldc = M, N, K, lda, ldb, ldc
+    _chk(lib().gpv_gemm_tt_group(arr, C.c_int(len(problems)), _stream()), 'gpv_gemm_tt_group')
 
 
 def conv2d(mode, x, w, y, B, IH, IW, Cs, Cin, OH, OW, Cout, KH, KW, SH, SW, PH, PW, rowscale=None, bias=None,

@@ -34,6 +34,7 @@ class Runtime:
         self.split = None                # set by train.GraphedBody while it captures / replays: the backbone runs outside autograd
         self.seed_dev = None             # device int64 word lent to the library as the dropout seed epoch (hipGraph replays)
         self.defer_list = None           # set by train.GraphedBody while it captures a backward: deferred weight-gradient launches
+        self.backward_boundary = None    # callback(tag) from ops.BoundaryFn.backward (same capture)
 
     def set_precise(self, on=True):
         self.dtype = torch.float32 if on else torch.bfloat16
@@ -80,7 +81,41 @@ def off_critical_path(fn, *tensors):
     if RT.defer_list is None:
         fn()
         return
-    RT.defer_list.append((fn, tensors))
+    RT.defer_list.append((fn, tensors, None))
+
+
+def wgrad_linear(dz, x2, wg, bg, N, K, M, split):
+    """dW[N,K] += dz[M,N]^T x2[M,K] (+ bias gradient = column sums of dz): in place, or -- while a backward is being captured --
+    handed to the deferred list as a PROBLEM (train.GraphedBody groups the eligible ones into gpv_gemm_tt_group launches)"""
+    def run():
+        hip.gemm(dz, x2, wg, N, K, M, N, K, K, layoutA=hip.TRANS, layoutB=hip.TRANS, accumulate=True, split_k=split, a_rowsum=bg)
+    if RT.defer_list is None:
+        run()
+        return
+    prob = None
+    if wg.stride(1) == 1 and hip.tt_group_ok(dz, x2, wg, N, K, M, N, K, wg.stride(0)):
+        prob = (dz, x2, wg, bg, N, K, M, N, K, wg.stride(0))
+    RT.defer_list.append((run, (dz, x2), prob))
+
+
+class BoundaryFn(Function):
+    """identity in the forward; its backward tells the runtime that every node created after this point has run
+    (autograd orders ready nodes by creation sequence) -- a place where train.GraphedBody forks work onto a side branch"""
+
+    @staticmethod
+    def forward(ctx, x, tag):
+        ctx.tag = tag
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        if RT.backward_boundary is not None:
+            RT.backward_boundary(ctx.tag)
+        return g, None
+
+
+def boundary(x, tag):
+    return BoundaryFn.apply(x, tag) if (torch.is_grad_enabled() and x.requires_grad) else x
 
 
 def ensure_grad(p):
@@ -213,9 +248,7 @@ class LinearFn(Function):
         need_b = w.bias is not None and w.bias.requires_grad
         if w.weight.requires_grad:
             # dW += dz^T x ; the bias gradient (column sums of dz) rides along in the same launch (a_rowsum)
-            wg, bg = w.wgrad(), (w.bgrad() if need_b else None)
-            off_critical_path(lambda: hip.gemm(dz, x2, wg, N, K, M, N, K, K, layoutA=hip.TRANS, layoutB=hip.TRANS, accumulate=True,
-                                               split_k=_split_k(N, K, M), a_rowsum=bg), dz, x2)
+            wgrad_linear(dz, x2, w.wgrad(), w.bgrad() if need_b else None, N, K, M, _split_k(N, K, M))
         elif need_b:
             hip.colsum(dz, w.bgrad(), M, N, N)
         dx = None
@@ -361,9 +394,7 @@ class FFNBlockFn(Function):
         dy2 = ds if ds is not None else dx_res
         nb2 = w2.bias is not None and w2.bias.requires_grad
         if w2.weight.requires_grad:
-            wg2, bg2 = w2.wgrad(), (w2.bgrad() if nb2 else None)
-            off_critical_path(lambda: hip.gemm(dy2, h, wg2, K, Fh, M, K, Fh, Fh, layoutA=hip.TRANS, layoutB=hip.TRANS, accumulate=True,
-                                               split_k=_split_k(K, Fh, M), a_rowsum=bg2), dy2, h)
+            wgrad_linear(dy2, h, w2.wgrad(), w2.bgrad() if nb2 else None, K, Fh, M, _split_k(K, Fh, M))
         elif nb2:
             hip.colsum(dy2, w2.bgrad(), M, K, K)
         dz = torch.empty(M, Fh, device=d2.device, dtype=RT.dtype)
@@ -371,9 +402,7 @@ class FFNBlockFn(Function):
                  alpha=1.0 / (1.0 - ctx.drop_p) if ctx.drop_p > 0 else 1.0)
         nb1 = w1.bias is not None and w1.bias.requires_grad
         if w1.weight.requires_grad:
-            wg1, bg1 = w1.wgrad(), (w1.bgrad() if nb1 else None)
-            off_critical_path(lambda: hip.gemm(dz, x2, wg1, Fh, K, M, Fh, K, K, layoutA=hip.TRANS, layoutB=hip.TRANS, accumulate=True,
-                                               split_k=_split_k(Fh, K, M), a_rowsum=bg1), dz, x2)
+            wgrad_linear(dz, x2, w1.wgrad(), w1.bgrad() if nb1 else None, Fh, K, M, _split_k(Fh, K, M))
         elif nb1:
             hip.colsum(dz, w1.bgrad(), M, Fh, Fh)
         dx = torch.empty(M, K, device=dz.device, dtype=RT.dtype)

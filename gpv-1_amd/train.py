@@ -187,6 +187,19 @@ class GraphedBody:
         if ev is not None:
             ev.record()
 
+    @staticmethod
+    def _flush(deferred):
+        """launch the collected weight gradients: every problem the grouped kernel takes (128-multiples, bf16) in
+        gpv_gemm_tt_group launches of up to 48 problems, the rest (2- and 4-wide heads, ragged shapes) one by one"""
+        group = [prob for _, _, prob in deferred if prob is not None]
+        if os.environ.get('GPV_WGRAD_GROUP', '1') == '0':
+            group = []
+        if group:
+            hip.gemm_tt_group(group)
+        for fn, _, prob in deferred:
+            if prob is None or not group:
+                fn()
+
     def _capture_backward(self, pairs):
         tr = self.tr
         torch.cuda.synchronize()
@@ -206,27 +219,45 @@ class GraphedBody:
         dev = self.s_img.device
         defer = bool(tr.defer_wgrad)
         deferred = []
+        side_a = []
+
+        def at_boundary(tag):
+            # The model body's backward is a latency-bound chain of small kernels.  When it reaches the DETR stream, the weight
+            # gradients collected so far (text decoder, answer head, co-attention: the big 768-wide ones) start on a side branch
+            # and run beside the DETR decoder / encoder backward; those of the DETR layers follow under the backbone (B2).
+            if tag != 'detr' or not deferred or not defer:
+                return
+            cur = torch.cuda.current_stream(dev)
+            self.wside.wait_stream(cur)
+            with torch.cuda.stream(self.wside):
+                self._flush(deferred)
+            side_a.extend(deferred)
+            del deferred[:]
         try:
             b1.capture_begin(pool=self.pool)
             RT.defer_list = deferred if defer else None
+            RT.backward_boundary = at_boundary if os.environ.get('GPV_WGRAD_SPLIT', '1') != '0' else None
             torch.autograd.backward([o for _, o, _ in pairs], grads, retain_graph=True)
             RT.defer_list = None
+            RT.backward_boundary = None
+            if side_a:
+                torch.cuda.current_stream(dev).wait_stream(self.wside)
             b1.capture_end()
             dc5 = self.c5_leaf.grad
             b2.capture_begin(pool=self.pool)
             if deferred:
                 self.wside.wait_stream(torch.cuda.current_stream(dev))
                 with torch.cuda.stream(self.wside):
-                    for fn, _ in deferred:
-                        fn()
+                    self._flush(deferred)
             self.body.backward_nhwc(self.keep, dc5.to(RT.dtype))
             if deferred:
                 torch.cuda.current_stream(dev).wait_stream(self.wside)
             b2.capture_end()
         finally:
             RT.defer_list = None
+            RT.backward_boundary = None
         RT.backward_milestone = milestone
-        var = {'b1': b1, 'b2': b2, 'grads': grads, 'touched': tr.touched.clone(), 'dc5': dc5, 'deferred': deferred}
+        var = {'b1': b1, 'b2': b2, 'grads': grads, 'touched': tr.touched.clone(), 'dc5': dc5, 'deferred': deferred + side_a}
         tr.touched |= saved
         return var
 

@@ -37,6 +37,22 @@ extern "C" {
 
 int gpv_abi_version(void); /* = 1 */
 
+/* ---------------------------------------------------------------------------------------------
+ * Grouped weight-gradient GEMM:  for every problem i:  C_i[M_i, N_i] += A_i^T B_i   (fp32 accumulate into C)
+ *   A_i: K_i x M_i (dY rows, row pitch lda), B_i: K_i x N_i (layer input rows, row pitch ldb), both bf16 and reduction-major;
+ *   a_rowsum_i (optional): += column sums of A_i (the bias gradient).  M_i, N_i multiples of 128; lda, ldb multiples of 8;
+ *   ldc multiple of 4; 16-byte aligned bases.  One launch per GPV_TT_GROUP_MAX problems, one workgroup per 128x128 output
+ *   tile walking the whole reduction: no split, no workspace.  `problems` is HOST memory (copied into the kernel arguments).
+ *   Replaces the per-layer weight-gradient halves of loss.backward() (exp/gpv/train_distr.py:421: every nn.Linear of the DETR
+ *   transformer, the co-attention layers and the text decoder) where the caller has all their operands at once. */
+#define GPV_TT_GROUP_MAX 48
+typedef struct {
+  const void* A; const void* B; float* C; float* a_rowsum;
+  int M, N, K;
+  int lda, ldb, ldc;
+} gpv_tt_problem;
+int gpv_gemm_tt_group(const gpv_tt_problem* problems, int n, void* stream);
+
 /* Kernel-selection knob (process-wide; tests and tuning only; never changes results beyond fp32 summation order).
  *   option GPV_OPT_GLDS: 0 = 4-wave register-staged GEMM/conv kernel only, 1 (default) = use the direct-to-LDS
  *   kernels where they are expected to win, 2 / 3 = the 8-wave 256-row / 4-wave 128x128 variant wherever it is legal.

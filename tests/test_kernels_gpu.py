@@ -711,3 +711,28 @@ def test_adamw_matches_torch():
             assert rel(p[sl], refs[i].data) < 2e-6, i
         else:
             assert torch.equal(p[sl], p0[sl]) and m[sl].abs().max() == 0 and v[sl].abs().max() == 0
+
+
+def test_grouped_weight_gradient_gemm():
+    """gpv_gemm_tt_group: many independent dW_i += dY_i^T X_i (+ bias gradients) in one grid, no split / workspace; problems of
+    different shapes and reduction lengths (incl. ragged last k-tiles and strided gradient slices), > 48 of them (two launches)"""
+    h = hip()
+    shapes = [(192, 768, 768), (640, 768, 2048), (3200, 256, 256), (3200, 2048, 256), (100, 128, 384), (1000, 384, 128), (64, 128, 128),
+              (3392, 1536, 768)]
+    probs, refs = [], []
+    for rep in range(7):                                      # 56 problems
+        for i, (K, M, N) in enumerate(shapes):
+            dy = rnd(K, M, dtype=torch.bfloat16, seed=100 + 10 * rep + i)
+            x = rnd(K, N, dtype=torch.bfloat16, seed=500 + 10 * rep + i)
+            big = rnd(M + 128, N, seed=900 + 10 * rep + i)     # dW is a row slice of a larger gradient buffer (packed in_proj)
+            dw = big[64:64 + M]
+            bg = rnd(M, seed=1300 + 10 * rep + i) if i % 2 == 0 else None
+            refs.append((dw.clone() + dy.float().t() @ x.float(), None if bg is None else bg.clone() + dy.float().sum(0), big.clone()))
+            probs.append((dy, x, dw, bg, M, N, K, M, N, N))
+            assert h.tt_group_ok(dy, x, dw, M, N, K, M, N, N)
+    h.gemm_tt_group(probs)
+    for (dy, x, dw, bg, M, N, K, *_), (rw, rb, big0) in zip(probs, refs):
+        assert rel(dw, rw) < 3e-3, (M, N, K, rel(dw, rw))
+        if bg is not None:
+            assert rel(bg, rb) < 3e-3
+    assert not h.tt_group_ok(probs[0][0], probs[0][1], probs[0][2], 100, 768, 192, 768, 768, 768)      # M not a multiple of 128
