@@ -343,13 +343,15 @@ def main():
     ach_gbs = bytes_step / (conv_ms * 1e-3) / 1e9
     # HBM traffic per launch from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, MI355X_MICROARCH.md): cannot be collected
     # inside a timed run, so it is the committed measurement of this same command (tools/pmc_traffic.py ->
-    # profiles/r01_pmc_conv_traffic.json); null if that file is missing or was taken for another launch count.
+    # profiles/r02_pmc_conv_traffic.json); null if that file is missing or was taken for another launch count.
     traffic = None
     try:
-        pm = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_conv_traffic.json')))
-        if pm['conv_launches_fetch_pass'] == launches * pm['steps_profiled'] and args.batch == BATCH:
+        import glob
+        latest = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r*_pmc_conv_traffic.json')))[-1]
+        pm = json.load(open(latest))
+        if pm['conv_launches_fetch_pass'] % launches == 0 and pm['conv_launches_fetch_pass'] == pm['conv_launches_write_pass'] and args.batch == BATCH:
             traffic = pm['traffic_bytes_per_launch']
-    except (OSError, KeyError, ValueError):
+    except (OSError, KeyError, ValueError, IndexError):
         pass
     roof = {'bound': 'hbm', 'achieved': ach_gbs, 'peak': 8000.0, 'unit': 'GB/s', 'frac': ach_gbs / 8000.0, 'traffic': traffic,
             'kernel': 'glds_kernel<OP_CONV> / glds_wgrad_kernel / conv1x1_kernel / gemm_kernel<OP_CONV> (NHWC implicit-GEMM conv fwd/dgrad/wgrad, ResNet-50 body)',

@@ -1,5 +1,6 @@
 """HBM traffic of the implicit-GEMM conv kernels from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of bench.py.
-usage (on the GPU box): python tools/pmc_traffic.py <dir pass FETCH_SIZE> <dir pass WRITE_SIZE> <steps profiled> > profiles/xxx.json
+usage (on the GPU box): python tools/pmc_traffic.py <dir pass FETCH_SIZE> <dir pass WRITE_SIZE> > profiles/xxx.json
+(every training step and every isolated conv pass of bench.py issues the same 135 conv launches: passes profiled = launches / 135)
 Units and corrections follow /opt/skills/guides/MI355X_MICROARCH.md (HBM section): rocprofv3 reports both counters in KB;
 on gfx950 FETCH_SIZE counts 128-byte requests at 64 B -> doubled; WRITE_SIZE is taken as reported (uncalibrated)."""
 import csv, glob, json, os, sys
@@ -17,14 +18,17 @@ def load(d, counter):
 
 def is_conv(name):
     n = name.replace('(anonymous namespace)::', '')
-    return ('gemm_kernel' in n and 'Li2ELi0E' in n) or ('gemm_kernel<' in n and ', 1, 2, ' in n) or 'glds_kernelILi2E' in n or 'conv1x1_kernel' in n or 'glds_wgrad_kernel' in n
+    return (('gemm_kernel' in n and 'Li2ELi0E' in n) or ('gemm_kernel<' in n and ', 1, 2, ' in n) or 'glds_kernelILi2E' in n or 'conv1x1_kernel' in n
+            or 'glds_wgrad_kernel' in n or 'pipe_kernelILi2E' in n)
 
-fd, wd, steps = sys.argv[1], sys.argv[2], int(sys.argv[3])
+fd, wd = sys.argv[1], sys.argv[2]
+LAUNCHES_PER_PASS = 135          # conv launches of one forward + backward of the body (bench.py conv_algorithmic)
 F, Wr = load(fd, 'FETCH_SIZE'), load(wd, 'WRITE_SIZE')
 fetch_kb = sum(v[0] for k, v in F.items() if is_conv(k)); nf = sum(v[1] for k, v in F.items() if is_conv(k))
 write_kb = sum(v[0] for k, v in Wr.items() if is_conv(k)); nw = sum(v[1] for k, v in Wr.items() if is_conv(k))
+steps = nf / LAUNCHES_PER_PASS
 res = {
-    'what': 'gemm_kernel<OP_CONV,...> / conv1x1_kernel / wgrad <OP_TRANS,OP_CONV> / glds_wgrad_kernel / glds_kernel<OP_CONV> / glds_conv1x1_kernel launches of `python bench.py` (B=32 train step)',
+    'what': 'gemm_kernel<OP_CONV,...> / conv1x1_kernel / pipe_kernel<OP_CONV> / pipe_conv1x1_kernel / glds_kernel<OP_CONV> / glds_conv1x1_kernel / glds_wgrad_kernel launches of `python bench.py` (B=32 train step)',
     'steps_profiled': steps, 'conv_launches_fetch_pass': nf, 'conv_launches_write_pass': nw,
     'FETCH_SIZE_KB_raw': fetch_kb, 'WRITE_SIZE_KB_raw': write_kb,
     'fetch_bytes_corrected_x2': fetch_kb * 1024 * 2, 'write_bytes': write_kb * 1024,
