@@ -49,6 +49,11 @@ def warmup_linear(step, warmup_steps, t_total):
     return max(0.0, float(t_total - step) / float(max(1.0, t_total - warmup_steps)))
 
 
+# Stream captures prohibit "unsafe" runtime calls (event queries, allocations).  'thread_local' restricts that to the capturing
+# thread: RCCL's watchdog thread polls the events of the in-flight bucket all-reduces while B2 is being captured.
+CAPTURE_MODE = os.environ.get('GPV_CAPTURE_MODE', 'thread_local')
+
+
 class GraphedBody:
     """Forward and backward of the model body (everything of train_distr.py:413-421 between the host-side tokenisation and
     the criterion) as hipGraphs, for one static input signature (image / query / answer-token shapes).
@@ -98,7 +103,7 @@ class GraphedBody:
         self.wside = torch.cuda.Stream(device=dev)
         RT.split = self
         try:
-            self.f1.capture_begin(pool=self.pool)
+            self.f1.capture_begin(pool=self.pool, capture_error_mode=CAPTURE_MODE)
             q_enc = None
             if self.side is not None:
                 self.side.wait_stream(trainer.stream)
@@ -120,7 +125,7 @@ class GraphedBody:
         if self.side is not None:
             torch.cuda.current_stream(x.device).wait_stream(self.side)         # join the BERT branch before F1 ends
         self.f1.capture_end()
-        self.f2.capture_begin(pool=self.pool)
+        self.f2.capture_begin(pool=self.pool, capture_error_mode=CAPTURE_MODE)
         self.c5 = c5
         self.c5_leaf = c5.detach().requires_grad_(True)
         self.body = body
@@ -213,9 +218,10 @@ class GraphedBody:
         from .ops import _DUMMY
         for d in _DUMMY.values():
             d.grad = None
-        # Single GPU: the weight-gradient GEMMs of the model body are collected during B1 (ops.off_critical_path) and captured
-        # as one parallel branch of B2, under the backbone's convolutions.  With more ranks they stay in B1, so that the
-        # buckets behind the backbone segment are complete when the trainer hands them to RCCL between B1 and B2.
+        # The weight-gradient GEMMs of the model body are collected during B1 (ops.wgrad_linear) and launched as grouped kernels:
+        # the text / co-attention group on a branch beside the DETR backward, the DETR group on a branch of B2 under the
+        # backbone's convolutions (single GPU) or at the end of B1 (several ranks: the buckets behind the backbone segment
+        # must be complete when the trainer hands them to RCCL between B1 and B2).
         dev = self.s_img.device
         defer = bool(tr.defer_wgrad)
         deferred = []
@@ -234,17 +240,23 @@ class GraphedBody:
             side_a.extend(deferred)
             del deferred[:]
         try:
-            b1.capture_begin(pool=self.pool)
+            b1.capture_begin(pool=self.pool, capture_error_mode=CAPTURE_MODE)
             RT.defer_list = deferred if defer else None
             RT.backward_boundary = at_boundary if os.environ.get('GPV_WGRAD_SPLIT', '1') != '0' else None
             torch.autograd.backward([o for _, o, _ in pairs], grads, retain_graph=True)
             RT.defer_list = None
             RT.backward_boundary = None
+            if deferred and tr.world > 1:
+                # more than one rank: the DETR layers' group runs here, at the end of B1, so that every gradient behind the
+                # backbone segment is complete when the trainer hands those buckets to RCCL (overlapped with B2)
+                self._flush(deferred)
+                side_a.extend(deferred)
+                del deferred[:]
             if side_a:
                 torch.cuda.current_stream(dev).wait_stream(self.wside)
             b1.capture_end()
             dc5 = self.c5_leaf.grad
-            b2.capture_begin(pool=self.pool)
+            b2.capture_begin(pool=self.pool, capture_error_mode=CAPTURE_MODE)
             if deferred:
                 self.wside.wait_stream(torch.cuda.current_stream(dev))
                 with torch.cuda.stream(self.wside):
@@ -333,7 +345,7 @@ class FlatTrainer:
         self.overlap = self.world > 1 and os.environ.get('GPV_OVERLAP', '1') != '0'
         self.dry_overlap = False             # tests: run the milestone / guard logic without communicating
         self._closed_from, self._works, self.late_touch, self.milestones = None, [], None, 0
-        self.defer_wgrad = self.world == 1 and os.environ.get('GPV_DEFER_WGRAD', '1') != '0'
+        self.defer_wgrad = os.environ.get('GPV_DEFER_WGRAD', '1') != '0'       # (with several ranks the groups stay inside B1)
         self.host_pg = None
         if self.world > 1:
             dist.broadcast(self.P, src=0, group=self.pg)
