@@ -138,6 +138,12 @@ __global__ __launch_bounds__(256, DHK < 96 ? 2 : 1) void attn_q_kernel(AttnK p) 
     stage_cols<T, PRECISE, DHV>(kg, p.k_rs, p.Sk, skp, vtp, Th, Tl);
     stage_rows<T, PRECISE, DHK>(vg, p.v_rs, p.Sk, skp, p.dh, Vh, Vl);
   }
+  // Dead keys (index >= Sk, key-padding mask set) are an additive -inf per key, staged once per block: it rides in as the initial
+  // value of the score accumulators (an LDS read in place of the zeroing moves), so neither the forward nor dQ spends a
+  // per-score instruction on padding.  Only the causal mask, which depends on the query, is tested per score.
+  float* kbias = reinterpret_cast<float*>(MODE ? Vl + skp * KP : Vh);
+  for (int idx = threadIdx.x; idx < skp; idx += 256)
+    kbias[idx] = (idx >= p.Sk || (p.kpm && p.kpm[(int64_t)b * p.Sk + idx])) ? -INFINITY : 0.f;
   __syncthreads();
 
   // One block serves `per` consecutive 16-query tiles of its (batch, head): K and V are staged ONCE and every wave walks its
@@ -177,12 +183,11 @@ __global__ __launch_bounds__(256, DHK < 96 ? 2 : 1) void attn_q_kernel(AttnK p) 
       // ---- dQ, streamed over pairs of 16-key tiles: the probabilities are recomputed from the saved log-sum-exp, so
       // nothing needs all Sk scores at once.  (Holding them -- as the forward must for its max/sum -- cost 256+ VGPRs:
       // one wave per SIMD, 159 us for the encoder shape; two live tiles fit 3-4 waves per SIMD.) ----
-      const uint8_t* kpm1 = p.kpm ? p.kpm + (int64_t)b * p.Sk : nullptr;
       const float c2q = p.scale * 1.4426950408889634f;
-      const float lse1 = qok ? -p.lse[((int64_t)b * p.H + h) * p.Sq + q] * 1.4426950408889634f : 0.f;   // exp(s*scale - lse) = exp2(s*c2 + lse1)
+      const float lse0 = qok ? p.lse[((int64_t)b * p.H + h) * p.Sq + q] : 0.f;
+      const float lse1 = lse0 > -INFINITY ? -lse0 * 1.4426950408889634f : 0.f;   // exp(s*scale - lse) = exp2(s*c2 + lse1); a row with no live key: P = 0
       const uint32_t rs1 = p.dthresh ? attn_row_seed(p.seed, ((uint64_t)b * p.H + h) * p.Sq + q) : 0u;
       const uint32_t t16 = p.dthresh >> 16;
-      constexpr bool masked1 = MASKED;
       f32x4 dq[DT];
   #pragma unroll
       for (int dt = 0; dt < DT; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -193,8 +198,8 @@ __global__ __launch_bounds__(256, DHK < 96 ? 2 : 1) void attn_q_kernel(AttnK p) 
   #pragma unroll
         for (int t = 0; t < 2; ++t) {
           const int j = 2 * kb + t;
-          f32x4 sc = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
-          if (j < ntr) {
+          f32x4 sc = *reinterpret_cast<const f32x4*>(kbias + j * 16 + g * 4), dp = f32x4{0.f, 0.f, 0.f, 0.f};
+          {                                            // (ntr is a multiple of 4: a pair is never half empty)
   #pragma unroll
             for (int kc = 0; kc < KC; ++kc) {
               const int off = (j * 16 + (lane & 15)) * KP + kc * 32 + g * 8;
@@ -212,11 +217,6 @@ __global__ __launch_bounds__(256, DHK < 96 ? 2 : 1) void attn_q_kernel(AttnK p) 
               }
             }
           }
-          uint32_t km1 = 0u;
-          if (MASKED && kpm1) {
-  #pragma unroll
-            for (int i = 0; i < 4; ++i) km1 |= (uint32_t)kpm1[min(j * 16 + g * 4 + i, p.Sk - 1)] << (8 * i);
-          }
           uint32_t w01 = 0u, w23 = 0u;
           if (p.dthresh) {
             const uint32_t pb = rs1 + (uint32_t)(j * 8 + g * 2) * ATTN_PAIR_STEP;
@@ -225,11 +225,8 @@ __global__ __launch_bounds__(256, DHK < 96 ? 2 : 1) void attn_q_kernel(AttnK p) 
   #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const int key = j * 16 + g * 4 + i;
-            float pr = __builtin_amdgcn_exp2f(fmaf(sc[i], c2q, lse1));         // normalised P
-            if (masked1 || j * 16 + 16 > p.Sk) {
-              const bool dead = key >= p.Sk || (p.causal && key > q) || ((km1 >> (8 * i)) & 0xffu) != 0u;
-              pr = dead ? 0.f : pr;
-            }
+            float pr = __builtin_amdgcn_exp2f(fmaf(sc[i], c2q, lse1));         // normalised P (0 for dead keys: sc = -inf)
+            if (MASKED && p.causal) pr = key > q ? 0.f : pr;
             float d = dp[i];
             if (p.dthresh) {
               const uint32_t w = i < 2 ? w01 : w23;
@@ -278,53 +275,39 @@ __global__ __launch_bounds__(256, DHK < 96 ? 2 : 1) void attn_q_kernel(AttnK p) 
     // The core is VALU-bound at dh = 32 (2 MFMAs per 256 scores against every per-score VALU instruction): what is spent per
     // score is one max, one fma + v_exp (scale and max folded into the fma, base-2 exponent), one add, the dropout select and
     // the bf16 pack.  Masks cost nothing when there are none (no key-padding mask, not causal): only the tail tiles test keys.
+    // Key tiles are handled in groups of four (skp is a multiple of 64, zero padded): ONE uniform test per group.  (A test per
+    // tile -- round 2's first build -- made every QK MFMA its own basic block behind a full s_waitcnt, and the twenty 64-bit
+    // conditions were spilled to VGPR lanes: 242 v_readlane per query tile.)
     f32x4 s[NT];
   #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      s[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (j < ntr) {
+    for (int j0 = 0; j0 < NT; j0 += 4) {
+      if (j0 < ntr) {
   #pragma unroll
-        for (int kc = 0; kc < KC; ++kc) {
-          const int off = (j * 16 + (lane & 15)) * KP + kc * 32 + g * 8;
-          bf16x8 kh = *reinterpret_cast<const bf16x8*>(Kh + off);
-          s[j] = mfma16(kh, qh[kc], s[j]);
-          if (PRECISE) {
-            bf16x8 kl = *reinterpret_cast<const bf16x8*>(Kl + off);
-            s[j] = mfma16(kl, qh[kc], s[j]);
-            s[j] = mfma16(kh, ql[kc], s[j]);
+        for (int j = j0; j < j0 + 4; ++j) {
+          s[j] = *reinterpret_cast<const f32x4*>(kbias + j * 16 + g * 4);
+  #pragma unroll
+          for (int kc = 0; kc < KC; ++kc) {
+            const int off = (j * 16 + (lane & 15)) * KP + kc * 32 + g * 8;
+            bf16x8 kh = *reinterpret_cast<const bf16x8*>(Kh + off);
+            s[j] = mfma16(kh, qh[kc], s[j]);
+            if (PRECISE) {
+              bf16x8 kl = *reinterpret_cast<const bf16x8*>(Kl + off);
+              s[j] = mfma16(kl, qh[kc], s[j]);
+              s[j] = mfma16(kh, ql[kc], s[j]);
+            }
           }
         }
+      } else {
+  #pragma unroll
+        for (int j = j0; j < j0 + 4; ++j) s[j] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
       }
     }
-    const uint8_t* kpm = p.kpm ? p.kpm + (int64_t)b * p.Sk : nullptr;
     if constexpr (MASKED) {
-      // key-padding bytes of this lane's 4 keys per tile, fetched up front WITHOUT per-element branches
-      uint32_t km[NT];
+      if (p.causal) {
   #pragma unroll
-      for (int j = 0; j < NT; ++j) km[j] = 0u;
-      if (kpm) {
+        for (int j = 0; j < NT; ++j)
   #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-  #pragma unroll
-          for (int i = 0; i < 4; ++i) km[j] |= (uint32_t)kpm[min(j * 16 + g * 4 + i, p.Sk - 1)] << (8 * i);
-        }
-      }
-  #pragma unroll
-      for (int j = 0; j < NT; ++j) {
-  #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int key = j * 16 + g * 4 + i;
-          const bool dead = key >= p.Sk || (p.causal && key > q) || ((km[j] >> (8 * i)) & 0xffu) != 0u;
-          s[j][i] = dead ? -INFINITY : s[j][i];
-        }
-      }
-    } else {
-  #pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        if (j * 16 + 16 > p.Sk) {                      // (uniform) tail tiles only
-  #pragma unroll
-          for (int i = 0; i < 4; ++i) s[j][i] = (j * 16 + g * 4 + i >= p.Sk) ? -INFINITY : s[j][i];
-        }
+          for (int i = 0; i < 4; ++i) s[j][i] = (j * 16 + g * 4 + i > q) ? -INFINITY : s[j][i];
       }
     }
     float mx = -INFINITY;
@@ -338,9 +321,14 @@ __global__ __launch_bounds__(256, DHK < 96 ? 2 : 1) void attn_q_kernel(AttnK p) 
     const float nm = mx == -INFINITY ? 0.f : -mx * c2;
     float lsum = 0.f;
   #pragma unroll
-    for (int j = 0; j < NT; ++j)
+    for (int j0 = 0; j0 < NT; j0 += 4) {
+      if (j0 < ntr) {
   #pragma unroll
-      for (int i = 0; i < 4; ++i) { const float e = __builtin_amdgcn_exp2f(fmaf(s[j][i], c2, nm)); s[j][i] = e; lsum += e; }
+        for (int j = j0; j < j0 + 4; ++j)
+  #pragma unroll
+          for (int i = 0; i < 4; ++i) { const float e = __builtin_amdgcn_exp2f(fmaf(s[j][i], c2, nm)); s[j][i] = e; lsum += e; }
+      }
+    }
     lsum += __shfl_xor(lsum, 16);
     lsum += __shfl_xor(lsum, 32);
     if (g == 0 && qok && p.lse) p.lse[((int64_t)b * p.H + h) * p.Sq + q] = (mx == -INFINITY ? 0.f : mx * p.scale) + logf(lsum);
@@ -350,14 +338,17 @@ __global__ __launch_bounds__(256, DHK < 96 ? 2 : 1) void attn_q_kernel(AttnK p) 
       const uint32_t t16 = p.dthresh >> 16;
       const uint32_t gb = rs + (uint32_t)(g * 2) * ATTN_PAIR_STEP;
   #pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        if (j < ntr) {
-          const uint32_t w0 = attn_pair_bits(gb + (uint32_t)(j * 8) * ATTN_PAIR_STEP);
-          const uint32_t w1 = attn_pair_bits(gb + (uint32_t)(j * 8 + 1) * ATTN_PAIR_STEP);
-          s[j][0] = (w0 & 0xffffu) >= t16 ? s[j][0] * p.dscale : 0.f;
-          s[j][1] = (w0 >> 16) >= t16 ? s[j][1] * p.dscale : 0.f;
-          s[j][2] = (w1 & 0xffffu) >= t16 ? s[j][2] * p.dscale : 0.f;
-          s[j][3] = (w1 >> 16) >= t16 ? s[j][3] * p.dscale : 0.f;
+      for (int j0 = 0; j0 < NT; j0 += 4) {
+        if (j0 < ntr) {
+  #pragma unroll
+          for (int j = j0; j < j0 + 4; ++j) {
+            const uint32_t w0 = attn_pair_bits(gb + (uint32_t)(j * 8) * ATTN_PAIR_STEP);
+            const uint32_t w1 = attn_pair_bits(gb + (uint32_t)(j * 8 + 1) * ATTN_PAIR_STEP);
+            s[j][0] = (w0 & 0xffffu) >= t16 ? s[j][0] : 0.f;      // (the 1/(1-p) of the kept ones is applied to the output row)
+            s[j][1] = (w0 >> 16) >= t16 ? s[j][1] : 0.f;
+            s[j][2] = (w1 & 0xffffu) >= t16 ? s[j][2] : 0.f;
+            s[j][3] = (w1 >> 16) >= t16 ? s[j][3] : 0.f;
+          }
         }
       }
     }
@@ -370,32 +361,35 @@ __global__ __launch_bounds__(256, DHK < 96 ? 2 : 1) void attn_q_kernel(AttnK p) 
     for (int dt = 0; dt < DT; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     __builtin_amdgcn_sched_barrier(0);
   #pragma unroll
-    for (int kb = 0; kb < NT / 2; ++kb) {
-      if (kb & 1) __builtin_amdgcn_sched_barrier(0);
-      if (kb * 2 < ntr) {
-        bf16x8 ph, pl;
+    for (int j0 = 0; j0 < NT; j0 += 4) {
+      __builtin_amdgcn_sched_barrier(0);
+      if (j0 < ntr) {
   #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          float a = s[2 * kb][i], c = s[2 * kb + 1][i];
-          ph[i] = (bf16)a; ph[4 + i] = (bf16)c;
-          if (PRECISE) { pl[i] = (bf16)(a - (float)ph[i]); pl[4 + i] = (bf16)(c - (float)ph[4 + i]); }
-        }
+        for (int kb = j0 / 2; kb < j0 / 2 + 2; ++kb) {
+          bf16x8 ph, pl;
   #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
-          const int off = (dt * 16 + (lane & 15)) * vtp + kb * 32 + g * 4;
-          bf16x8 xh = ld_pair64(Th + off, Th + off + 16);
-          oacc[dt] = mfma16(xh, ph, oacc[dt]);
-          if (PRECISE) {
-            bf16x8 xl = ld_pair64(Tl + off, Tl + off + 16);
-            oacc[dt] = mfma16(xl, ph, oacc[dt]);
-            oacc[dt] = mfma16(xh, pl, oacc[dt]);
+          for (int i = 0; i < 4; ++i) {
+            float a = s[2 * kb][i], c = s[2 * kb + 1][i];
+            ph[i] = (bf16)a; ph[4 + i] = (bf16)c;
+            if (PRECISE) { pl[i] = (bf16)(a - (float)ph[i]); pl[4 + i] = (bf16)(c - (float)ph[4 + i]); }
+          }
+  #pragma unroll
+          for (int dt = 0; dt < DT; ++dt) {
+            const int off = (dt * 16 + (lane & 15)) * vtp + kb * 32 + g * 4;
+            bf16x8 xh = ld_pair64(Th + off, Th + off + 16);
+            oacc[dt] = mfma16(xh, ph, oacc[dt]);
+            if (PRECISE) {
+              bf16x8 xl = ld_pair64(Tl + off, Tl + off + 16);
+              oacc[dt] = mfma16(xl, ph, oacc[dt]);
+              oacc[dt] = mfma16(xh, pl, oacc[dt]);
+            }
           }
         }
       }
     }
     if (!qok) continue;
     T* outp = reinterpret_cast<T*>(p.o) + b * p.o_bs + (int64_t)q * p.o_rs + h * p.dh;
-    const float inv = lsum > 0.f ? 1.f / lsum : 0.f;
+    const float inv = lsum > 0.f ? (p.dthresh ? p.dscale : 1.f) / lsum : 0.f;
   #pragma unroll
     for (int dt = 0; dt < DT; ++dt) {
       const int d = dt * 16 + g * 4;
@@ -574,7 +568,7 @@ int launch_q_m(const AttnK& p, hipStream_t st) {
   constexpr int KP = DHK + 8;
   const int vtp = p.skp + 8;
   size_t elems = (size_t)p.skp * KP + (size_t)DHV * vtp + (MODE ? (size_t)p.skp * KP : 0);
-  size_t lds = elems * 2 * (PRECISE ? 2 : 1);
+  size_t lds = elems * 2 * (PRECISE ? 2 : 1) + (size_t)p.skp * sizeof(float);
   auto fn = attn_q_kernel<T, DHK, DHV, NT, MODE, MASKED>;
   static size_t attr = 0;
   if (lds > 64 * 1024 && lds > attr) {
@@ -590,6 +584,10 @@ int launch_q_m(const AttnK& p, hipStream_t st) {
   if (nsplit < want) nsplit = want;
   if (nsplit > (nqt + 3) / 4) nsplit = (nqt + 3) / 4;
   if (nsplit < 1) nsplit = 1;
+  {
+    static const int force = [] { const char* e = getenv("GPV_ATTN_SPLIT"); return e ? atoi(e) : 0; }();
+    if (force > 0) nsplit = force < nqt ? force : nqt;
+  }
   dim3 grid(nsplit, p.H, p.B);
   hipLaunchKernelGGL(fn, grid, dim3(256), lds, st, p);
   GPV_CHECK_LAUNCH();
@@ -597,9 +595,9 @@ int launch_q_m(const AttnK& p, hipStream_t st) {
 }
 template <typename T, int DHK, int DHV, int NT, int MODE>
 int launch_q(const AttnK& p, hipStream_t st) {
-  // masks are a template parameter: the key-padding / causal bookkeeping (20 packed mask words, lane-mask SGPRs) pushed the
-  // mask-free encoder / decoder launches into scratch when both forms shared one body
-  if (p.kpm != nullptr || p.causal) return launch_q_m<T, DHK, DHV, NT, MODE, true>(p, st);
+  // the causal mask is a template parameter (its per-score tests are compiled out of the encoder / decoder / co-attention
+  // launches); key padding costs nothing per score (the kbias row in LDS), so masked and unmasked batches share one kernel
+  if (p.causal) return launch_q_m<T, DHK, DHV, NT, MODE, true>(p, st);
   return launch_q_m<T, DHK, DHV, NT, MODE, false>(p, st);
 }
 template <typename T, int DHK, int DHV>
@@ -650,7 +648,7 @@ int fill(const gpv_attn_args* a, AttnK& p) {
   p.q_bs = a->q_bs; p.q_rs = a->q_rs; p.k_bs = a->k_bs; p.k_rs = a->k_rs; p.v_bs = a->v_bs; p.v_rs = a->v_rs;
   p.o_bs = a->o_bs; p.o_rs = a->o_rs;
   p.B = a->B; p.H = a->H; p.Sq = a->Sq; p.Sk = a->Sk; p.dh = a->dh;
-  p.skp = ((a->Sk + 31) / 32) * 32;
+  p.skp = ((a->Sk + 63) / 64) * 64;      // key tiles come in groups of four (one uniform test per group in the kernels)
   p.scale = a->scale; p.kpm = a->kpm; p.causal = a->causal;
   p.dthresh = a->drop_p > 0.f ? drop_thresh(a->drop_p) : 0u;
   p.dscale = a->drop_p > 0.f ? 1.f / (1.f - a->drop_p) : 1.f;
