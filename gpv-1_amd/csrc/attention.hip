@@ -19,7 +19,7 @@ namespace {
 struct AttnK {
   const void* q; const void* k; const void* v; void* o;
   int64_t q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs;
-  int B, H, Sq, Sk, dh, skp;
+  int B, H, Sq, Sk, dh, skp, nsplit;
   float scale;
   const uint8_t* kpm; int causal;
   uint32_t dthresh; float dscale; uint64_t seed; const uint64_t* seed_dev;
@@ -66,12 +66,101 @@ template <typename T> struct R8 {  // 8 staged values as floats
   }
 };
 
+// 8 consecutive elements as loaded (16 bytes of bf16, 32 of fp32): what a thread holds while a batch of staging loads is in flight
+template <typename T> struct Raw8;
+template <> struct Raw8<bf16> {
+  bf16x8 r;
+  __device__ __forceinline__ void zero() { r = bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; }
+  __device__ __forceinline__ void load(const bf16* p) { r = *reinterpret_cast<const bf16x8*>(p); }
+  __device__ __forceinline__ R8<bf16> get() const {
+    R8<bf16> x;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x.v[i] = (float)r[i];
+    return x;
+  }
+};
+template <> struct Raw8<float> {
+  float v[8];
+  __device__ __forceinline__ void zero() {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = 0.f;
+  }
+  __device__ __forceinline__ void load(const float* p) { Ld8<float>::ld(p, v); }
+  __device__ __forceinline__ R8<float> get() const {
+    R8<float> x;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x.v[i] = v[i];
+    return x;
+  }
+};
+
+// The K / V staging of the per-(batch, head) kernels, all loads first: with run-time loop bounds hipcc kept one load in flight
+// per thread and iteration (8 dependent round trips to L2/HBM before the first MFMA: the waves spent 57 % of their life in
+// s_waitcnt, PMC in profiles/r02_pmc_attention.txt).  MAXR bounds the rows at compile time, so the loops unroll and every
+// load of the block's staging is issued before the first LDS store.
+template <typename T, int DH, int MAXR, int NTHR> struct RowBatch {      // [rows][DH] row-major -> LDS [rows_pad][DH + 8]
+  static constexpr int SL = DH / 8, IT = (MAXR * SL + NTHR - 1) / NTHR;
+  Raw8<T> x[IT];
+  __device__ __forceinline__ void load(const T* g, int64_t rs, int rows_valid, int rows_pad, int dh) {
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int idx = threadIdx.x + it * NTHR, r = idx / SL, sl = idx - r * SL;
+      if (idx < rows_pad * SL && r < rows_valid && sl * 8 < dh) x[it].load(g + (int64_t)r * rs + sl * 8); else x[it].zero();
+    }
+  }
+  template <bool PRECISE> __device__ __forceinline__ void store(int rows_pad, bf16* hi, bf16* lo) const {
+    constexpr int PITCH = DH + 8;
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int idx = threadIdx.x + it * NTHR, r = idx / SL, sl = idx - r * SL;
+      if (idx < rows_pad * SL) {
+        const R8<T> v = x[it].get();
+        *reinterpret_cast<bf16x8*>(hi + r * PITCH + sl * 8) = v.hi();
+        if (PRECISE) *reinterpret_cast<bf16x8*>(lo + r * PITCH + sl * 8) = v.lo();
+      }
+    }
+  }
+};
+template <typename T, int DH, int MAXR, int NTHR> struct ColBatch {      // transposed: LDS [DH][pitch], element (d, r) = g[r][d]
+  static constexpr int DG = DH / 8, IT = ((MAXR / 2) * DG + NTHR - 1) / NTHR;
+  Raw8<T> a[IT], b[IT];
+  __device__ __forceinline__ void load(const T* g, int64_t rs, int rows_valid, int rows_pad) {
+    const int np = rows_pad / 2;
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int idx = threadIdx.x + it * NTHR, dg = idx / np, rp = idx - dg * np;
+      const bool in = idx < np * DG;
+      if (in && 2 * rp < rows_valid) a[it].load(g + (int64_t)(2 * rp) * rs + dg * 8); else a[it].zero();
+      if (in && 2 * rp + 1 < rows_valid) b[it].load(g + (int64_t)(2 * rp + 1) * rs + dg * 8); else b[it].zero();
+    }
+  }
+  template <bool PRECISE> __device__ __forceinline__ void store(int rows_pad, int pitch, bf16* hi, bf16* lo) const {
+    const int np = rows_pad / 2;
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int idx = threadIdx.x + it * NTHR, dg = idx / np, rp = idx - dg * np;
+      if (idx < np * DG) {
+        const R8<T> u = a[it].get(), w = b[it].get();
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          bf16x2 h; h[0] = (bf16)u.v[c]; h[1] = (bf16)w.v[c];
+          *reinterpret_cast<bf16x2*>(hi + (dg * 8 + c) * pitch + 2 * rp) = h;
+          if (PRECISE) {
+            bf16x2 l; l[0] = (bf16)(u.v[c] - (float)h[0]); l[1] = (bf16)(w.v[c] - (float)h[1]);
+            *reinterpret_cast<bf16x2*>(lo + (dg * 8 + c) * pitch + 2 * rp) = l;
+          }
+        }
+      }
+    }
+  }
+};
+
 // stage a [rows_valid x dh] row-major global tile into LDS [rows_pad][PITCH] (k-contiguous), zero padded
-template <typename T, bool PRECISE, int DHK>
+template <typename T, bool PRECISE, int DHK, int NTHR = 256>
 __device__ __forceinline__ void stage_rows(const T* g, int64_t rs, int rows_valid, int rows_pad, int dh, bf16* hi, bf16* lo) {
   constexpr int PITCH = DHK + 8;
   constexpr int SL = DHK / 8;
-  for (int idx = threadIdx.x; idx < rows_pad * SL; idx += 256) {
+  for (int idx = threadIdx.x; idx < rows_pad * SL; idx += NTHR) {
     int r = idx / SL, sl = idx - r * SL;
     R8<T> x;
     if (r < rows_valid && sl * 8 < dh) x.load(g + (int64_t)r * rs + sl * 8); else x.zero();
@@ -80,11 +169,11 @@ __device__ __forceinline__ void stage_rows(const T* g, int64_t rs, int rows_vali
   }
 }
 // stage transposed: LDS [DHV][pitch] with element (d, r) = g[r][d]; rows_pad even
-template <typename T, bool PRECISE, int DHV>
+template <typename T, bool PRECISE, int DHV, int NTHR = 256>
 __device__ __forceinline__ void stage_cols(const T* g, int64_t rs, int rows_valid, int rows_pad, int pitch, bf16* hi, bf16* lo) {
   constexpr int DG = DHV / 8;
   const int np = rows_pad / 2;
-  for (int idx = threadIdx.x; idx < np * DG; idx += 256) {
+  for (int idx = threadIdx.x; idx < np * DG; idx += NTHR) {
     int dg = idx / np, rp = idx - dg * np;
     R8<T> a, b;
     if (2 * rp < rows_valid) a.load(g + (int64_t)(2 * rp) * rs + dg * 8); else a.zero();
@@ -110,8 +199,12 @@ __device__ __forceinline__ bf16x8 ld_pair64(const bf16* p0, const bf16* p1) {
 }
 
 // MODE 0: forward (writes o, lse).  MODE 1: dQ (reads dout, o, lse; writes dq)
-template <typename T, int DHK, int DHV, int NT, int MODE, bool MASKED>
-__global__ __launch_bounds__(256, DHK < 96 ? 2 : 1) void attn_q_kernel(AttnK p) {
+// Workgroup = 8 waves on one (batch, head) [x one of gridDim-derived query splits]; FULL: every one of the NT key tiles is live
+// (skp == 16 NT: the encoder's 300 keys, the decoder's 100), which makes the tile loops branch-free -- hipcc then overlaps the LDS
+// reads of a tile group with the MFMAs of the one before.
+constexpr int QW = 8, QTHR = QW * 64;
+template <typename T, int DHK, int DHV, int NT, int MODE, bool MASKED, bool FULL>
+__global__ __launch_bounds__(QTHR) void attn_q_kernel(AttnK p) {
   if (p.dthresh) p.seed = eff_seed(p.seed, p.seed_dev);
   constexpr bool PRECISE = sizeof(T) == 4;
   constexpr int KP = DHK + 8;
@@ -119,7 +212,7 @@ __global__ __launch_bounds__(256, DHK < 96 ? 2 : 1) void attn_q_kernel(AttnK p) 
   constexpr int DT = DHV / 16;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   bf16* sm = reinterpret_cast<bf16*>(smem_raw);
-  const int skp = p.skp, ntr = skp / 16, vtp = skp + 8;
+  const int skp = FULL ? NT * 16 : p.skp, ntr = FULL ? NT : skp / 16, vtp = skp + 8;
   // LDS carve: K[skp][KP] (hi,lo) | X^T[DHV][vtp] (hi,lo)  (X = V fwd, K for dQ) | (dQ only) V[skp][KP] (hi,lo)
   bf16* Kh = sm;
   bf16* Kl = Kh + (PRECISE ? skp * KP : 0);
@@ -128,63 +221,104 @@ __global__ __launch_bounds__(256, DHK < 96 ? 2 : 1) void attn_q_kernel(AttnK p) 
   bf16* Vh = Tl + DHV * vtp;
   bf16* Vl = Vh + (PRECISE ? skp * KP : 0);
 
-  const int b = blockIdx.z, h = blockIdx.y;
+  // XCD-aware block order (workgroup i runs on XCD i % 8, used for speed only): every XCD gets a CONTIGUOUS range of
+  // (batch, head, split) triples, so the eight heads of one batch element -- interleaved 64-byte slices of the same K / V / Q
+  // rows -- and the query splits of one head share one L2 instead of pulling every 128-byte line into several.
+  int b, h, xs;
+  {
+    const int nsp = p.nsplit, total = (int)gridDim.x;
+    const int qd = total >> 3, r = total & 7, xcd = (int)blockIdx.x & 7, loc = (int)blockIdx.x >> 3;
+    const int v = (xcd < r ? xcd * (qd + 1) : r * (qd + 1) + (xcd - r) * qd) + loc;
+    xs = v % nsp;
+    const int bh = v / nsp;
+    h = bh % p.H; b = bh / p.H;
+  }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
   const T* kg = reinterpret_cast<const T*>(p.k) + b * p.k_bs + h * p.dh;
   const T* vg = reinterpret_cast<const T*>(p.v) + b * p.v_bs + h * p.dh;
-  stage_rows<T, PRECISE, DHK>(kg, p.k_rs, p.Sk, skp, p.dh, Kh, Kl);
-  if (MODE == 0) stage_cols<T, PRECISE, DHV>(vg, p.v_rs, p.Sk, skp, vtp, Th, Tl);
-  else {
-    stage_cols<T, PRECISE, DHV>(kg, p.k_rs, p.Sk, skp, vtp, Th, Tl);
-    stage_rows<T, PRECISE, DHK>(vg, p.v_rs, p.Sk, skp, p.dh, Vh, Vl);
+  // One block serves `per` consecutive 16-query tiles of its (batch, head): K and V are staged ONCE and every wave walks its
+  // share of the tiles.  The per-tile operands (Q rows; dO, O, lse for dQ) are fetched one tile ahead -- the first before the
+  // staging -- so that their L2 / HBM round trip (1-2 us, once per tile) overlaps the previous tile's softmax.
+  const int nqt = (p.Sq + 15) >> 4;
+  const int per = (nqt + p.nsplit - 1) / p.nsplit;
+  const int qt_end = min(nqt, (xs + 1) * per);
+  const int qt_first = xs * per + wave;
+  Raw8<T> nq[KC], nd[MODE ? KC : 1], no[MODE ? KC : 1];
+  float nlse = 0.f;
+  auto fetch = [&](int qt_) {
+    const int q_ = qt_ * 16 + (lane & 15);
+    const bool ok = qt_ < qt_end && q_ < p.Sq;
+    const T* qp = reinterpret_cast<const T*>(p.q) + b * p.q_bs + (int64_t)q_ * p.q_rs + h * p.dh;
+  #pragma unroll
+    for (int kc = 0; kc < KC; ++kc) {
+      const int d0 = kc * 32 + g * 8;
+      if (ok && d0 < p.dh) nq[kc].load(qp + d0); else nq[kc].zero();
+      if constexpr (MODE == 1) {
+        const T* dop = reinterpret_cast<const T*>(p.dout) + b * p.do_bs + (int64_t)q_ * p.do_rs + h * p.dh;
+        const T* op = reinterpret_cast<const T*>(p.o) + b * p.o_bs + (int64_t)q_ * p.o_rs + h * p.dh;
+        if (ok && d0 < p.dh) { nd[kc].load(dop + d0); no[kc].load(op + d0); } else { nd[kc].zero(); no[kc].zero(); }
+      }
+    }
+    if constexpr (MODE == 1) nlse = ok ? p.lse[((int64_t)b * p.H + h) * p.Sq + q_] : 0.f;
+  };
+  fetch(qt_first);
+  if constexpr (PRECISE) {            // (fp32 test path: the plain loops)
+    stage_rows<T, PRECISE, DHK, QTHR>(kg, p.k_rs, p.Sk, skp, p.dh, Kh, Kl);
+    if (MODE == 0) stage_cols<T, PRECISE, DHV, QTHR>(vg, p.v_rs, p.Sk, skp, vtp, Th, Tl);
+    else {
+      stage_cols<T, PRECISE, DHV, QTHR>(kg, p.k_rs, p.Sk, skp, vtp, Th, Tl);
+      stage_rows<T, PRECISE, DHK, QTHR>(vg, p.v_rs, p.Sk, skp, p.dh, Vh, Vl);
+    }
+  } else {
+    RowBatch<T, DHK, NT * 16, QTHR> kr;
+    ColBatch<T, DHV, NT * 16, QTHR> xc;
+    kr.load(kg, p.k_rs, p.Sk, skp, p.dh);
+    xc.load(MODE == 0 ? vg : kg, MODE == 0 ? p.v_rs : p.k_rs, p.Sk, skp);
+    if constexpr (MODE == 0) {
+      kr.template store<PRECISE>(skp, Kh, Kl);
+      xc.template store<PRECISE>(skp, vtp, Th, Tl);
+    } else {
+      RowBatch<T, DHK, NT * 16, QTHR> vr;
+      vr.load(vg, p.v_rs, p.Sk, skp, p.dh);
+      kr.template store<PRECISE>(skp, Kh, Kl);
+      xc.template store<PRECISE>(skp, vtp, Th, Tl);
+      vr.template store<PRECISE>(skp, Vh, Vl);
+    }
   }
   // Dead keys (index >= Sk, key-padding mask set) are an additive -inf per key, staged once per block: it rides in as the initial
   // value of the score accumulators (an LDS read in place of the zeroing moves), so neither the forward nor dQ spends a
   // per-score instruction on padding.  Only the causal mask, which depends on the query, is tested per score.
   float* kbias = reinterpret_cast<float*>(MODE ? Vl + skp * KP : Vh);
-  for (int idx = threadIdx.x; idx < skp; idx += 256)
+  for (int idx = threadIdx.x; idx < skp; idx += QTHR)
     kbias[idx] = (idx >= p.Sk || (p.kpm && p.kpm[(int64_t)b * p.Sk + idx])) ? -INFINITY : 0.f;
   __syncthreads();
 
-  // One block serves `per` consecutive 16-query tiles of its (batch, head): K and V are staged ONCE and every wave walks its
-  // share of the tiles.  (Round 1 staged them once per 64 queries: 5 blocks per head re-staged the same 38 KB, and the waves
-  // spent 61 % of their cycles waiting on that staging -- PMC, profiles/r02_pmc_attention.txt.)
-  const int nqt = (p.Sq + 15) >> 4;
-  const int per = (nqt + (int)gridDim.x - 1) / (int)gridDim.x;
-  const int qt_end = min(nqt, ((int)blockIdx.x + 1) * per);
-  for (int qt = (int)blockIdx.x * per + wave; qt < qt_end; qt += 4) {
+  for (int qt = qt_first; qt < qt_end; qt += QW) {
     const int q = qt * 16 + (lane & 15);
     const bool qok = q < p.Sq;
-    // Q (and dO, O) fragments straight from global: lane (q, g) holds d = kc*32 + g*8 .. +7
+    // Q (and dO, O) fragments come straight from global, lane (q, g) holds d = kc*32 + g*8 .. +7 -- fetched one tile ahead
     bf16x8 qh[KC], ql[KC], doh[KC], dol[KC];
     float delta = 0.f;
-    {
-      const T* qp = reinterpret_cast<const T*>(p.q) + b * p.q_bs + (int64_t)q * p.q_rs + h * p.dh;
-      const T* dop = MODE ? reinterpret_cast<const T*>(p.dout) + b * p.do_bs + (int64_t)q * p.do_rs + h * p.dh : nullptr;
-      const T* op = MODE ? reinterpret_cast<const T*>(p.o) + b * p.o_bs + (int64_t)q * p.o_rs + h * p.dh : nullptr;
+    const float lse0 = nlse;
   #pragma unroll
-      for (int kc = 0; kc < KC; ++kc) {
-        const int d0 = kc * 32 + g * 8;
-        R8<T> x;
-        if (qok && d0 < p.dh) x.load(qp + d0); else x.zero();
-        qh[kc] = x.hi(); ql[kc] = x.lo();
-        if (MODE) {
-          R8<T> y, z;
-          if (qok && d0 < p.dh) { y.load(dop + d0); z.load(op + d0); } else { y.zero(); z.zero(); }
-          doh[kc] = y.hi(); dol[kc] = y.lo();
+    for (int kc = 0; kc < KC; ++kc) {
+      const R8<T> x = nq[kc].get();
+      qh[kc] = x.hi(); ql[kc] = x.lo();
+      if (MODE) {
+        const R8<T> y = nd[kc].get(), z = no[kc].get();
+        doh[kc] = y.hi(); dol[kc] = y.lo();
   #pragma unroll
-          for (int e = 0; e < 8; ++e) delta += y.v[e] * z.v[e];
-        }
+        for (int e = 0; e < 8; ++e) delta += y.v[e] * z.v[e];
       }
-      if (MODE) { delta += __shfl_xor(delta, 16); delta += __shfl_xor(delta, 32); }
     }
+    if (MODE) { delta += __shfl_xor(delta, 16); delta += __shfl_xor(delta, 32); }
+    fetch(qt + QW);
 
     if constexpr (MODE == 1) {
       // ---- dQ, streamed over pairs of 16-key tiles: the probabilities are recomputed from the saved log-sum-exp, so
       // nothing needs all Sk scores at once.  (Holding them -- as the forward must for its max/sum -- cost 256+ VGPRs:
       // one wave per SIMD, 159 us for the encoder shape; two live tiles fit 3-4 waves per SIMD.) ----
       const float c2q = p.scale * 1.4426950408889634f;
-      const float lse0 = qok ? p.lse[((int64_t)b * p.H + h) * p.Sq + q] : 0.f;
       const float lse1 = lse0 > -INFINITY ? -lse0 * 1.4426950408889634f : 0.f;   // exp(s*scale - lse) = exp2(s*c2 + lse1); a row with no live key: P = 0
       const uint32_t rs1 = p.dthresh ? attn_row_seed(p.seed, ((uint64_t)b * p.H + h) * p.Sq + q) : 0u;
       const uint32_t t16 = p.dthresh >> 16;
@@ -562,34 +696,32 @@ __global__ __launch_bounds__(256) void attn_kv_kernel(AttnK p) {
   }
 }
 
-template <typename T, int DHK, int DHV, int NT, int MODE, bool MASKED>
-int launch_q_m(const AttnK& p, hipStream_t st) {
+template <typename T, int DHK, int DHV, int NT, int MODE, bool MASKED, bool FULL>
+int launch_q_f(AttnK p, hipStream_t st) {
   constexpr bool PRECISE = sizeof(T) == 4;
   constexpr int KP = DHK + 8;
   const int vtp = p.skp + 8;
   size_t elems = (size_t)p.skp * KP + (size_t)DHV * vtp + (MODE ? (size_t)p.skp * KP : 0);
   size_t lds = elems * 2 * (PRECISE ? 2 : 1) + (size_t)p.skp * sizeof(float);
-  auto fn = attn_q_kernel<T, DHK, DHV, NT, MODE, MASKED>;
+  auto fn = attn_q_kernel<T, DHK, DHV, NT, MODE, MASKED, FULL>;
   static size_t attr = 0;
   if (lds > 64 * 1024 && lds > attr) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     attr = lds;
   }
-  // q-tiles of 16 per block: ~10 when there are enough (batch, head) pairs to fill the chip, fewer (down to 4 = one per wave) otherwise
+  // one block of 8 waves per (batch, head) when those fill the chip; fewer query tiles per block (down to one per wave) otherwise
   const int nqt = (p.Sq + 15) / 16;
   const int bh = p.B * p.H;
-  int nsplit = (nqt + 9) / 10;
-  const int want = (512 + bh - 1) / bh;
-  if (nsplit < want) nsplit = want;
-  if (nsplit > (nqt + 3) / 4) nsplit = (nqt + 3) / 4;
+  int nsplit = (256 + bh - 1) / bh;
+  if (nsplit > (nqt + QW - 1) / QW) nsplit = (nqt + QW - 1) / QW;
   if (nsplit < 1) nsplit = 1;
   {
     static const int force = [] { const char* e = getenv("GPV_ATTN_SPLIT"); return e ? atoi(e) : 0; }();
     if (force > 0) nsplit = force < nqt ? force : nqt;
   }
-  dim3 grid(nsplit, p.H, p.B);
-  hipLaunchKernelGGL(fn, grid, dim3(256), lds, st, p);
+  p.nsplit = nsplit;
+  hipLaunchKernelGGL(fn, dim3(nsplit * bh), dim3(QTHR), lds, st, p);
   GPV_CHECK_LAUNCH();
   return 0;
 }
@@ -597,8 +729,9 @@ template <typename T, int DHK, int DHV, int NT, int MODE>
 int launch_q(const AttnK& p, hipStream_t st) {
   // the causal mask is a template parameter (its per-score tests are compiled out of the encoder / decoder / co-attention
   // launches); key padding costs nothing per score (the kbias row in LDS), so masked and unmasked batches share one kernel
-  if (p.causal) return launch_q_m<T, DHK, DHV, NT, MODE, true>(p, st);
-  return launch_q_m<T, DHK, DHV, NT, MODE, false>(p, st);
+  const bool full = p.skp == NT * 16;
+  if (p.causal) return full ? launch_q_f<T, DHK, DHV, NT, MODE, true, true>(p, st) : launch_q_f<T, DHK, DHV, NT, MODE, true, false>(p, st);
+  return full ? launch_q_f<T, DHK, DHV, NT, MODE, false, true>(p, st) : launch_q_f<T, DHK, DHV, NT, MODE, false, false>(p, st);
 }
 template <typename T, int DHK, int DHV>
 int launch_kv(const AttnK& p, hipStream_t st) {
