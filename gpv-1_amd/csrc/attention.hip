@@ -32,6 +32,7 @@ struct AttnK {
 // element (drop probability floor(p * 65536) / 65536), mixed from the row's seed with full-rate VALU only (shifts, xors, 24-bit
 // multiplies).  The 64-bit counter hash of common.h per SCORE (three quarter-rate 32-bit multiplies) made the dh = 32 kernels
 // spend more on the mask than on the softmax; forward, dQ and dK/dV kernels must agree on this function.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 constexpr uint32_t ATTN_PAIR_STEP = 0x9E3779B9u;
 __device__ __forceinline__ uint32_t attn_row_seed(uint64_t seed, uint64_t row) { return hash_u32(seed, row); }
 __device__ __forceinline__ uint32_t attn_pair_bits(uint32_t x) {     // x = row seed + pair index * ATTN_PAIR_STEP
@@ -40,9 +41,16 @@ __device__ __forceinline__ uint32_t attn_pair_bits(uint32_t x) {     // x = row 
   x ^= x >> 16;
   return x;
 }
-__device__ __forceinline__ bool attn_keep(uint32_t row_seed, int key, uint32_t t16) {
-  const uint32_t w = attn_pair_bits(row_seed + (uint32_t)(key >> 1) * ATTN_PAIR_STEP);
-  return ((key & 1) ? (w >> 16) : (w & 0xffffu)) >= t16;
+// An element is kept when its 16 bits, read as a SIGNED halfword, are >= ts = floor(p * 65536) - 32768 (same rate as an unsigned
+// test against floor(p * 65536); the signed form lets the forward mask a packed pair of bf16 probabilities with three packed-math
+// instructions -- saturating subtract, arithmetic shift, and-not -- instead of two compares and two selects on the floats).
+__device__ __forceinline__ int attn_ts(uint32_t dthresh) { return (int)(dthresh >> 16) - 32768; }
+__device__ __forceinline__ bool attn_keep_lo(uint32_t w, int ts) { return (int)(short)(w & 0xffffu) >= ts; }
+__device__ __forceinline__ bool attn_keep_hi(uint32_t w, int ts) { return ((int)w >> 16) >= ts; }
+__device__ __forceinline__ uint32_t attn_drop_bits(uint32_t w, uint32_t ts2) {       // 0xffff in every DROPPED half; ts2 = ts | ts << 16
+  typedef short s16x2 __attribute__((ext_vector_type(2)));
+  const s16x2 d = __builtin_elementwise_sub_sat(__builtin_bit_cast(s16x2, w), __builtin_bit_cast(s16x2, ts2));
+  return __builtin_bit_cast(uint32_t, (s16x2)(d >> (s16x2){15, 15}));
 }
 
 template <typename T> struct R8 {  // 8 staged values as floats
@@ -321,7 +329,7 @@ __global__ __launch_bounds__(QTHR) void attn_q_kernel(AttnK p) {
       const float c2q = p.scale * 1.4426950408889634f;
       const float lse1 = lse0 > -INFINITY ? -lse0 * 1.4426950408889634f : 0.f;   // exp(s*scale - lse) = exp2(s*c2 + lse1); a row with no live key: P = 0
       const uint32_t rs1 = p.dthresh ? attn_row_seed(p.seed, ((uint64_t)b * p.H + h) * p.Sq + q) : 0u;
-      const uint32_t t16 = p.dthresh >> 16;
+      const int ts = attn_ts(p.dthresh);
       f32x4 dq[DT];
   #pragma unroll
       for (int dt = 0; dt < DT; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -364,7 +372,7 @@ __global__ __launch_bounds__(QTHR) void attn_q_kernel(AttnK p) {
             float d = dp[i];
             if (p.dthresh) {
               const uint32_t w = i < 2 ? w01 : w23;
-              d = ((i & 1) ? (w >> 16) : (w & 0xffffu)) >= t16 ? d * p.dscale : 0.f;
+              d = ((i & 1) ? attn_keep_hi(w, ts) : attn_keep_lo(w, ts)) ? d * p.dscale : 0.f;
             }
             sj[t][i] = pr * (d - delta) * p.scale;
           }
@@ -467,10 +475,12 @@ __global__ __launch_bounds__(QTHR) void attn_q_kernel(AttnK p) {
     lsum += __shfl_xor(lsum, 32);
     if (g == 0 && qok && p.lse) p.lse[((int64_t)b * p.H + h) * p.Sq + q] = (mx == -INFINITY ? 0.f : mx * p.scale) + logf(lsum);
 
-    if (p.dthresh) {
-      const uint32_t rs = attn_row_seed(p.seed, ((uint64_t)b * p.H + h) * p.Sq + q);
-      const uint32_t t16 = p.dthresh >> 16;
-      const uint32_t gb = rs + (uint32_t)(g * 2) * ATTN_PAIR_STEP;
+    // dropout: the 1/(1-p) of the kept probabilities is applied to the output row; the drops themselves are and-ed out of the
+    // packed bf16 pairs below (fp32 path: selected on the floats here, its low-order split needs the masked value)
+    const uint32_t gb = p.dthresh ? attn_row_seed(p.seed, ((uint64_t)b * p.H + h) * p.Sq + q) + (uint32_t)(g * 2) * ATTN_PAIR_STEP : 0u;
+    const int ts = attn_ts(p.dthresh);
+    const uint32_t ts2 = ((uint32_t)ts & 0xffffu) * 0x10001u;
+    if (PRECISE && p.dthresh) {
   #pragma unroll
       for (int j0 = 0; j0 < NT; j0 += 4) {
         if (j0 < ntr) {
@@ -478,10 +488,10 @@ __global__ __launch_bounds__(QTHR) void attn_q_kernel(AttnK p) {
           for (int j = j0; j < j0 + 4; ++j) {
             const uint32_t w0 = attn_pair_bits(gb + (uint32_t)(j * 8) * ATTN_PAIR_STEP);
             const uint32_t w1 = attn_pair_bits(gb + (uint32_t)(j * 8 + 1) * ATTN_PAIR_STEP);
-            s[j][0] = (w0 & 0xffffu) >= t16 ? s[j][0] : 0.f;      // (the 1/(1-p) of the kept ones is applied to the output row)
-            s[j][1] = (w0 >> 16) >= t16 ? s[j][1] : 0.f;
-            s[j][2] = (w1 & 0xffffu) >= t16 ? s[j][2] : 0.f;
-            s[j][3] = (w1 >> 16) >= t16 ? s[j][3] : 0.f;
+            s[j][0] = attn_keep_lo(w0, ts) ? s[j][0] : 0.f;
+            s[j][1] = attn_keep_hi(w0, ts) ? s[j][1] : 0.f;
+            s[j][2] = attn_keep_lo(w1, ts) ? s[j][2] : 0.f;
+            s[j][3] = attn_keep_hi(w1, ts) ? s[j][3] : 0.f;
           }
         }
       }
@@ -506,6 +516,16 @@ __global__ __launch_bounds__(QTHR) void attn_q_kernel(AttnK p) {
             float a = s[2 * kb][i], c = s[2 * kb + 1][i];
             ph[i] = (bf16)a; ph[4 + i] = (bf16)c;
             if (PRECISE) { pl[i] = (bf16)(a - (float)ph[i]); pl[4 + i] = (bf16)(c - (float)ph[4 + i]); }
+          }
+          if (!PRECISE && p.dthresh) {
+            u32x4 pw = __builtin_bit_cast(u32x4, ph);       // words: keys (0,1), (2,3) of tile 2kb, then of tile 2kb+1
+  #pragma unroll
+            for (int t = 0; t < 2; ++t) {
+              const uint32_t pb = gb + (uint32_t)((2 * kb + t) * 8) * ATTN_PAIR_STEP;
+              pw[2 * t] &= ~attn_drop_bits(attn_pair_bits(pb), ts2);
+              pw[2 * t + 1] &= ~attn_drop_bits(attn_pair_bits(pb + ATTN_PAIR_STEP), ts2);
+            }
+            ph = __builtin_bit_cast(bf16x8, pw);
           }
   #pragma unroll
           for (int dt = 0; dt < DT; ++dt) {
@@ -563,7 +583,8 @@ __global__ __launch_bounds__(256) void attn_kv_kernel(AttnK p) {
   bool kdead = !kok;
   if (kok && p.kpm) kdead = p.kpm[(int64_t)b * p.Sk + key] != 0;
   const float c2k = p.scale * 1.4426950408889634f;
-  const uint32_t kpair = (uint32_t)(key >> 1) * ATTN_PAIR_STEP, kshift = (key & 1) * 16, t16 = p.dthresh >> 16;
+  const uint32_t kpair = (uint32_t)(key >> 1) * ATTN_PAIR_STEP, kshift = (key & 1) * 16;
+  const int ts = attn_ts(p.dthresh);
 
   bf16x8 kh[KC], kl[KC], vh[KC], vl[KC];
   {
@@ -653,7 +674,7 @@ __global__ __launch_bounds__(256) void attn_kv_kernel(AttnK p) {
           float d = dp[i], pd = pv;
           if (p.dthresh) {
             const uint32_t w = attn_pair_bits(rsd[i] + kpair);
-            const bool keep = ((w >> kshift) & 0xffffu) >= t16;
+            const bool keep = (int)(short)((w >> kshift) & 0xffffu) >= ts;
             d = keep ? d * p.dscale : 0.f;
             pd = keep ? pv * p.dscale : 0.f;
           }
