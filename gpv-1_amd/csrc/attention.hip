@@ -19,7 +19,7 @@ namespace {
 struct AttnK {
   const void* q; const void* k; const void* v; void* o;
   int64_t q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs;
-  int B, H, Sq, Sk, dh, skp, nsplit;
+  int B, H, Sq, Sk, dh, skp, nsplit, sqp;
   float scale;
   const uint8_t* kpm; int causal;
   uint32_t dthresh; float dscale; uint64_t seed; const uint64_t* seed_dev;
@@ -717,6 +717,176 @@ __global__ __launch_bounds__(256) void attn_kv_kernel(AttnK p) {
   }
 }
 
+// dK / dV, bf16, all queries of one (batch, head) resident: workgroup = 8 waves on one (batch, head) [x a split of the key tiles],
+// Q and dO staged ONCE (row-major for the score MFMAs, transposed for the dK / dV MFMAs) together with every query's
+// -lse*log2(e), delta = dO.O and dropout row seed; a wave then owns 16 keys at a time and walks all queries in pairs of tiles.
+// (attn_kv_kernel above re-staged each 64-query chunk in every 64-key block behind two barriers: five dependent load ->
+//  LDS -> barrier round trips per block, 65 us on the encoder shape with the MFMAs idle 90 % of the time.)
+// NQT = query tiles the loops are unrolled for; CAUSAL compiles the per-score query test in.
+template <int DHK, int DHV, int NQT, bool CAUSAL>
+__global__ __launch_bounds__(QTHR) void attn_kv2_kernel(AttnK p) {
+  using T = bf16;
+  if (p.dthresh) p.seed = eff_seed(p.seed, p.seed_dev);
+  constexpr int KP = DHK + 8, KC = DHK / 32, DT = DHV / 16;
+  const int sqp = p.sqp, QTP = sqp + 8;              // sqp: Sq rounded up to 32
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  bf16* Qh = reinterpret_cast<bf16*>(smem_raw);
+  bf16* Dh = Qh + sqp * KP;
+  bf16* QTh = Dh + sqp * KP;
+  bf16* DTh = QTh + DHV * QTP;
+  float* lse_s = reinterpret_cast<float*>(DTh + DHV * QTP);
+  float* del_s = lse_s + sqp;
+  uint32_t* rs_s = reinterpret_cast<uint32_t*>(del_s + sqp);
+
+  int b, h, xs;
+  {
+    const int nsp = p.nsplit, total = (int)gridDim.x;
+    const int qd = total >> 3, r = total & 7, xcd = (int)blockIdx.x & 7, loc = (int)blockIdx.x >> 3;
+    const int v = (xcd < r ? xcd * (qd + 1) : r * (qd + 1) + (xcd - r) * qd) + loc;
+    xs = v % nsp;
+    const int bh = v / nsp;
+    h = bh % p.H; b = bh / p.H;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
+  const int nkt = (p.Sk + 15) >> 4;
+  const int per = (nkt + p.nsplit - 1) / p.nsplit;
+  const int kt_end = min(nkt, (xs + 1) * per);
+  const int kt_first = xs * per + wave;
+  // this wave's K / V rows (MFMA B operands), fetched one key tile ahead
+  Raw8<T> nk[KC], nv[KC];
+  bool ndead = true;
+  auto fetch = [&](int kt_) {
+    const int key_ = kt_ * 16 + (lane & 15);
+    const bool ok = kt_ < kt_end && key_ < p.Sk;
+    const T* kp_ = reinterpret_cast<const T*>(p.k) + b * p.k_bs + (int64_t)key_ * p.k_rs + h * p.dh;
+    const T* vp_ = reinterpret_cast<const T*>(p.v) + b * p.v_bs + (int64_t)key_ * p.v_rs + h * p.dh;
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) {
+      const int d0 = kc * 32 + g * 8;
+      if (ok && d0 < p.dh) { nk[kc].load(kp_ + d0); nv[kc].load(vp_ + d0); } else { nk[kc].zero(); nv[kc].zero(); }
+    }
+    ndead = !ok || (p.kpm && p.kpm[(int64_t)b * p.Sk + key_] != 0);
+  };
+  fetch(kt_first);
+
+  const T* qg = reinterpret_cast<const T*>(p.q) + b * p.q_bs + h * p.dh;
+  const T* dog = reinterpret_cast<const T*>(p.dout) + b * p.do_bs + h * p.dh;
+  const T* og = reinterpret_cast<const T*>(p.o) + b * p.o_bs + h * p.dh;
+  {
+    RowBatch<T, DHK, NQT * 16, QTHR> qr, dr;
+    ColBatch<T, DHV, NQT * 16, QTHR> qc, dc;
+    qr.load(qg, p.q_rs, p.Sq, sqp, p.dh);
+    dr.load(dog, p.do_rs, p.Sq, sqp, p.dh);
+    qc.load(qg, p.q_rs, p.Sq, sqp);
+    dc.load(dog, p.do_rs, p.Sq, sqp);
+    qr.template store<false>(sqp, Qh, nullptr);
+    dr.template store<false>(sqp, Dh, nullptr);
+    qc.template store<false>(sqp, QTP, QTh, nullptr);
+    dc.template store<false>(sqp, QTP, DTh, nullptr);
+  }
+  for (int r = threadIdx.x; r < sqp; r += QTHR) {
+    float dl = 0.f, ls = INFINITY;                   // padded queries: -lse = -inf -> P = 0
+    if (r < p.Sq) {
+      const T* a = dog + (int64_t)r * p.do_rs;
+      const T* c = og + (int64_t)r * p.o_rs;
+      for (int d = 0; d < p.dh; d += 8) {
+        float u[8], w[8];
+        Ld8<T>::ld(a + d, u); Ld8<T>::ld(c + d, w);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dl += u[e] * w[e];
+      }
+      ls = p.lse[((int64_t)b * p.H + h) * p.Sq + r];
+    }
+    lse_s[r] = -ls * 1.4426950408889634f; del_s[r] = dl;
+    rs_s[r] = p.dthresh ? attn_row_seed(p.seed, ((uint64_t)b * p.H + h) * p.Sq + r) : 0u;
+  }
+  __syncthreads();
+
+  const float c2k = p.scale * 1.4426950408889634f;
+  const int ts = attn_ts(p.dthresh);
+  const int nqb = sqp >> 5;                          // pairs of query tiles
+  for (int kt = kt_first; kt < kt_end; kt += QW) {
+    const int key = kt * 16 + (lane & 15);
+    const bool kok = key < p.Sk;
+    const bool kdead = ndead;
+    bf16x8 kh[KC], vh[KC];
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) { kh[kc] = nk[kc].get().hi(); vh[kc] = nv[kc].get().hi(); }
+    fetch(kt + QW);
+    const uint32_t kpair = (uint32_t)(key >> 1) * ATTN_PAIR_STEP, kshift = (key & 1) * 16;
+    f32x4 dkacc[DT], dvacc[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) { dkacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dvacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int qb = 0; qb < NQT / 2; ++qb) {
+      if (qb >= nqb) break;
+      f32x4 pr[2], ds[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        f32x4 sa = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {
+          const int off = (qb * 32 + t * 16 + (lane & 15)) * KP + kc * 32 + g * 8;
+          sa = mfma16(*reinterpret_cast<const bf16x8*>(Qh + off), kh[kc], sa);
+          dp = mfma16(*reinterpret_cast<const bf16x8*>(Dh + off), vh[kc], dp);
+        }
+        const int qr = qb * 32 + t * 16 + g * 4;     // query row of element i = qr + i
+        const float4 l4 = *reinterpret_cast<const float4*>(lse_s + qr);
+        const float4 d4 = *reinterpret_cast<const float4*>(del_s + qr);
+        const float ls[4] = {l4.x, l4.y, l4.z, l4.w};
+        const float dl[4] = {d4.x, d4.y, d4.z, d4.w};
+        uint32_t rsd[4] = {0u, 0u, 0u, 0u};
+        if (p.dthresh) {
+          const uint4 r4 = *reinterpret_cast<const uint4*>(rs_s + qr);
+          rsd[0] = r4.x; rsd[1] = r4.y; rsd[2] = r4.z; rsd[3] = r4.w;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float pv = __builtin_amdgcn_exp2f(fmaf(sa[i], c2k, ls[i]));
+          bool dead = kdead;
+          if (CAUSAL) dead = dead || (p.causal && key > qr + i);
+          pv = dead ? 0.f : pv;
+          float d = dp[i], pd = pv;
+          if (p.dthresh) {
+            const uint32_t w = attn_pair_bits(rsd[i] + kpair);
+            const bool keep = (int)(short)((w >> kshift) & 0xffffu) >= ts;
+            d = keep ? d * p.dscale : 0.f;
+            pd = keep ? pv * p.dscale : 0.f;
+          }
+          pr[t][i] = pd;
+          ds[t][i] = pv * (d - dl[i]) * p.scale;
+        }
+      }
+      bf16x8 ph, sh;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        ph[i] = (bf16)pr[0][i]; ph[4 + i] = (bf16)pr[1][i];
+        sh[i] = (bf16)ds[0][i]; sh[4 + i] = (bf16)ds[1][i];
+      }
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        const int off = (dt * 16 + (lane & 15)) * QTP + qb * 32 + g * 4;
+        dvacc[dt] = mfma16(ld_pair64(DTh + off, DTh + off + 16), ph, dvacc[dt]);
+        dkacc[dt] = mfma16(ld_pair64(QTh + off, QTh + off + 16), sh, dkacc[dt]);
+      }
+    }
+    if (!kok) continue;
+    T* dkp = reinterpret_cast<T*>(p.dk) + b * p.k_bs + (int64_t)key * p.k_rs + h * p.dh;
+    T* dvp = reinterpret_cast<T*>(p.dv) + b * p.v_bs + (int64_t)key * p.v_rs + h * p.dh;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      const int d = dt * 16 + g * 4;
+      if (d < p.dh) {
+        bf16x4 k4, v4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { k4[i] = (bf16)dkacc[dt][i]; v4[i] = (bf16)dvacc[dt][i]; }
+        *reinterpret_cast<bf16x4*>(dkp + d) = k4;
+        *reinterpret_cast<bf16x4*>(dvp + d) = v4;
+      }
+    }
+  }
+}
+
 template <typename T, int DHK, int DHV, int NT, int MODE, bool MASKED, bool FULL>
 int launch_q_f(AttnK p, hipStream_t st) {
   constexpr bool PRECISE = sizeof(T) == 4;
@@ -772,6 +942,38 @@ int launch_kv(const AttnK& p, hipStream_t st) {
   return 0;
 }
 
+// resident-queries dK/dV (bf16): returns -1 when the shape does not fit (Sq > 320, or the staged queries exceed the LDS)
+template <int DHK, int DHV, int NQT, bool CAUSAL>
+int launch_kv2_c(AttnK p, hipStream_t st) {
+  constexpr int KP = DHK + 8;
+  const int QTP = p.sqp + 8;
+  const size_t lds = ((size_t)2 * p.sqp * KP + (size_t)2 * DHV * QTP) * 2 + (size_t)3 * p.sqp * sizeof(float);
+  if (lds > 160 * 1024) return -1;
+  auto fn = attn_kv2_kernel<DHK, DHV, NQT, CAUSAL>;
+  static size_t attr = 0;
+  if (lds > 64 * 1024 && lds > attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    attr = lds;
+  }
+  const int nkt = (p.Sk + 15) / 16;
+  const int bh = p.B * p.H;
+  int nsplit = (256 + bh - 1) / bh;
+  if (nsplit > (nkt + QW - 1) / QW) nsplit = (nkt + QW - 1) / QW;
+  if (nsplit < 1) nsplit = 1;
+  p.nsplit = nsplit;
+  hipLaunchKernelGGL(fn, dim3(nsplit * bh), dim3(QTHR), lds, st, p);
+  GPV_CHECK_LAUNCH();
+  return 0;
+}
+template <int DHK, int DHV>
+int launch_kv2(AttnK p, hipStream_t st) {
+  if (p.Sq > 320) return -1;
+  p.sqp = ((p.Sq + 31) / 32) * 32;
+  if (p.sqp <= 128) return p.causal ? launch_kv2_c<DHK, DHV, 8, true>(p, st) : launch_kv2_c<DHK, DHV, 8, false>(p, st);
+  return p.causal ? launch_kv2_c<DHK, DHV, 20, true>(p, st) : launch_kv2_c<DHK, DHV, 20, false>(p, st);
+}
+
 template <typename T, int MODE>
 int dispatch_q(const AttnK& p, hipStream_t st) {
   const bool small = p.skp <= 128;
@@ -787,6 +989,19 @@ int dispatch_q(const AttnK& p, hipStream_t st) {
 }
 template <typename T>
 int dispatch_kv(const AttnK& p, hipStream_t st) {
+  if constexpr (sizeof(T) == 2) {
+    static const bool old_only = [] { const char* e = getenv("GPV_ATTN_KV_OLD"); return e && e[0] == '1'; }();
+    int r = -1;
+    if (!old_only) {
+      switch (p.dh) {
+        case 32: r = launch_kv2<32, 32>(p, st); break;
+        case 48: r = launch_kv2<64, 48>(p, st); break;
+        case 64: r = launch_kv2<64, 64>(p, st); break;
+        case 96: r = launch_kv2<96, 96>(p, st); break;
+      }
+    }
+    if (r >= 0) return r;
+  }
   switch (p.dh) {
     case 32: return launch_kv<T, 32, 32>(p, st);
     case 48: return launch_kv<T, 64, 48>(p, st);
