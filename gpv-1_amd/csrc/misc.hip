@@ -99,9 +99,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
 
 // LayerNorm backward: one wave (HALF: half a wave) per row. z = x + drop(s) is recomputed.
 // dz = rstd * (g*dy - mean(g*dy) - zhat*mean(g*dy*zhat)); dx = dz ; ds = dz * dropmask
-// dgamma/dbeta accumulated per block in LDS then atomics.
-template <typename T, int NV, bool HALF>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ s,
+// dgamma/dbeta accumulated per block in LDS then atomics.  NW waves per block: the atomics (blocks x 2 cols of them on cols / 16
+// cache lines) were 11 us of a 19.5 us launch on the 9600 x 256 DETR shapes with 512 blocks of 4 waves; 16 waves per block keep
+// the rows in flight and quarter the blocks.
+template <typename T, int NV, bool HALF, int NW>
+__global__ __launch_bounds__(NW * 64) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ s,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, T* __restrict__ dx, T* __restrict__ ds,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, int rows, int cols,
@@ -109,7 +111,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
                                                      const uint64_t* seed_dev) {
   if (dthresh) seed = eff_seed(seed, seed_dev);
   extern __shared__ float lds[];   // [4 waves][2][cols]: every wave parks its partial dgamma | dbeta, no LDS atomics
-  constexpr int LW = HALF ? 32 : 64, RPI = HALF ? 8 : 4;      // lanes per row, rows per block iteration
+  constexpr int LW = HALF ? 32 : 64, RPI = HALF ? 2 * NW : NW;      // lanes per row, rows per block iteration
   const int lane = threadIdx.x & (LW - 1), wave = threadIdx.x >> 6;
   const int slot = HALF ? threadIdx.x >> 5 : wave;            // which of the block's RPI concurrent rows
   float ag[NV][8], ab[NV][8];
@@ -185,19 +187,30 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
 #pragma unroll
         for (int e = 0; e < 8; ++e) { ag[i][e] += __shfl_xor(ag[i][e], 32); ab[i][e] += __shfl_xor(ab[i][e], 32); }
     }
-    float* wg = lds + wave * 2 * cols;               // this wave's [dgamma | dbeta] partials (plain 16-byte stores)
+    float* wg = lds + (wave & 3) * 2 * cols;         // four [dgamma | dbeta] rows, wave w adds into row w % 4 in round w / 4
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int c = (i * LW + lane) * 8;
-      if (c < cols && (!HALF || (threadIdx.x & 32) == 0)) {
-        *reinterpret_cast<float4*>(wg + c) = make_float4(ag[i][0], ag[i][1], ag[i][2], ag[i][3]);
-        *reinterpret_cast<float4*>(wg + c + 4) = make_float4(ag[i][4], ag[i][5], ag[i][6], ag[i][7]);
-        *reinterpret_cast<float4*>(wg + cols + c) = make_float4(ab[i][0], ab[i][1], ab[i][2], ab[i][3]);
-        *reinterpret_cast<float4*>(wg + cols + c + 4) = make_float4(ab[i][4], ab[i][5], ab[i][6], ab[i][7]);
+    for (int rnd = 0; rnd < NW / 4; ++rnd) {
+      if ((wave >> 2) == rnd) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+          const int c = (i * LW + lane) * 8;
+          if (c < cols && (!HALF || (threadIdx.x & 32) == 0)) {
+            float4 g0 = make_float4(ag[i][0], ag[i][1], ag[i][2], ag[i][3]), g1 = make_float4(ag[i][4], ag[i][5], ag[i][6], ag[i][7]);
+            float4 b0 = make_float4(ab[i][0], ab[i][1], ab[i][2], ab[i][3]), b1 = make_float4(ab[i][4], ab[i][5], ab[i][6], ab[i][7]);
+            if (rnd > 0) {
+              const float4 p0 = *reinterpret_cast<float4*>(wg + c), p1 = *reinterpret_cast<float4*>(wg + c + 4);
+              const float4 q0 = *reinterpret_cast<float4*>(wg + cols + c), q1 = *reinterpret_cast<float4*>(wg + cols + c + 4);
+              g0.x += p0.x; g0.y += p0.y; g0.z += p0.z; g0.w += p0.w; g1.x += p1.x; g1.y += p1.y; g1.z += p1.z; g1.w += p1.w;
+              b0.x += q0.x; b0.y += q0.y; b0.z += q0.z; b0.w += q0.w; b1.x += q1.x; b1.y += q1.y; b1.z += q1.z; b1.w += q1.w;
+            }
+            *reinterpret_cast<float4*>(wg + c) = g0; *reinterpret_cast<float4*>(wg + c + 4) = g1;
+            *reinterpret_cast<float4*>(wg + cols + c) = b0; *reinterpret_cast<float4*>(wg + cols + c + 4) = b1;
+          }
+        }
       }
+      __syncthreads();
     }
-    __syncthreads();
-    for (int c = threadIdx.x; c < 2 * cols; c += 256) {
+    for (int c = threadIdx.x; c < 2 * cols; c += NW * 64) {
       const float v = lds[c] + lds[2 * cols + c] + lds[4 * cols + c] + lds[6 * cols + c];
       atomicAdd(c < cols ? dgamma + c : dbeta + (c - cols), v);
     }
@@ -542,16 +555,21 @@ extern "C" int gpv_layernorm_bwd(const void* dy, const void* x, const void* s, c
   if (cols % 8 != 0 || cols > 4096 || rows <= 0) return (int)hipErrorInvalidValue;
   const uint32_t th = drop_p > 0.f ? drop_thresh(drop_p) : 0u;
   const float sc = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
-  static const int rpb_div = [] { const char* e = getenv("GPV_LN_BWD_BLOCKS"); return e ? atoi(e) : 512; }();   // tuning only (512: fewer same-address global atomics on dgamma)
-  int rpb = (rows + rpb_div - 1) / rpb_div;
-  if (rpb < 8) rpb = 8;
-  dim3 grid((rows + rpb - 1) / rpb), block(256);
-  const size_t lds = dgamma ? 8 * (size_t)cols * sizeof(float) : 0;       // 4 waves x [dgamma | dbeta]; cols <= 4096 -> <= 128 KB
-#define LN_B(T, NV, H) hipLaunchKernelGGL((ln_bwd_kernel<T, NV, H>), grid, block, lds, ST(stream), (const T*)dy, (const T*)x, (const T*)s, gamma, mean, rstd, (T*)dx, (T*)ds, dgamma, dbeta, rows, cols, rpb, th, sc, seed, gpvk::g_seed_dev)
   const int nv = (cols + 511) / 512;
   const bool half = cols <= 256;
-  if (dtype == GPV_BF16) { if (half) LN_B(bf16, 1, true); else if (nv <= 1) LN_B(bf16, 1, false); else if (nv <= 2) LN_B(bf16, 2, false); else if (nv <= 5) LN_B(bf16, 5, false); else LN_B(bf16, 8, false); }
-  else { if (half) LN_B(float, 1, true); else if (nv <= 1) LN_B(float, 1, false); else if (nv <= 2) LN_B(float, 2, false); else if (nv <= 5) LN_B(float, 5, false); else LN_B(float, 8, false); }
+  const bool wide = nv <= 2 && rows >= 2048;             // 16 waves per block (register budget: the NV <= 2 bodies; few rows: no gain)
+  static const int rpb_div = [] { const char* e = getenv("GPV_LN_BWD_BLOCKS"); return e ? atoi(e) : 0; }();   // tuning only
+  const int target = rpb_div > 0 ? rpb_div : (wide ? 160 : 512);   // few blocks: fewer same-address global atomics on dgamma
+  const int rpi = (wide ? 16 : 4) * (half ? 2 : 1);
+  int rpb = (rows + target - 1) / target;
+  if (rpb < rpi) rpb = rpi;
+  dim3 grid((rows + rpb - 1) / rpb), block(wide ? 1024 : 256);
+  const size_t lds = dgamma ? 8 * (size_t)cols * sizeof(float) : 0;       // 4 waves x [dgamma | dbeta]; cols <= 4096 -> <= 128 KB
+#define LN_B(T, NV, H, NW) hipLaunchKernelGGL((ln_bwd_kernel<T, NV, H, NW>), grid, block, lds, ST(stream), (const T*)dy, (const T*)x, (const T*)s, gamma, mean, rstd, (T*)dx, (T*)ds, dgamma, dbeta, rows, cols, rpb, th, sc, seed, gpvk::g_seed_dev)
+#define LN_BW(T, NV, H) do { if (wide) LN_B(T, NV, H, 16); else LN_B(T, NV, H, 4); } while (0)
+  if (dtype == GPV_BF16) { if (half) LN_BW(bf16, 1, true); else if (nv <= 1) LN_BW(bf16, 1, false); else if (nv <= 2) LN_BW(bf16, 2, false); else if (nv <= 5) LN_B(bf16, 5, false, 4); else LN_B(bf16, 8, false, 4); }
+  else { if (half) LN_BW(float, 1, true); else if (nv <= 1) LN_BW(float, 1, false); else if (nv <= 2) LN_BW(float, 2, false); else if (nv <= 5) LN_B(float, 5, false, 4); else LN_B(float, 8, false, 4); }
+#undef LN_BW
 #undef LN_B
   GPV_CHECK_LAUNCH();
   return 0;

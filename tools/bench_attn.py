@@ -36,16 +36,21 @@ def case(name, B, H, Sq, Sk, dh, p, causal=False, kpm=False):
     print('%-28s fwd %6.1f us (%5.1f TF)  bwd %6.1f us (%5.1f TF)' % (name, tf, fl / tf / 1e6, tb, 2.5 * fl / tb / 1e6), flush=True)
 
 
-import sys as _s
-if len(_s.argv) > 1:
-    case('enc self 300x300 dh32', 32, 8, 300, 300, 32, 0.1); _s.exit(0)
-case('enc self 300x300 dh32', 32, 8, 300, 300, 32, 0.1)
-case('enc self 300x300 kpm', 32, 8, 300, 300, 32, 0.1, kpm=True)
-case('enc self 300x300 p=0', 32, 8, 300, 300, 32, 0.0)
-case('dec cross 100x300 dh32', 32, 8, 100, 300, 32, 0.1)
-case('dec self 100x100 dh32', 32, 8, 100, 100, 32, 0.1)
-case('coatt 24x100 dh96', 32, 8, 24, 100, 96, 0.1)
-case('coatt 100x24 dh96', 32, 8, 100, 24, 96, 0.1)
-case('text cross 20x124 dh64', 32, 12, 20, 124, 64, 0.1)
-case('text self 20x20 causal dh64', 32, 12, 20, 20, 64, 0.1, causal=True)
-case('bert 24x24 kpm dh64', 32, 12, 24, 24, 64, 0.1, kpm=True)
+def main():
+    import sys as _s
+    if len(_s.argv) > 1:
+        case('enc self 300x300 dh32', 32, 8, 300, 300, 32, 0.1); _s.exit(0)
+    case('enc self 300x300 dh32', 32, 8, 300, 300, 32, 0.1)
+    case('enc self 300x300 kpm', 32, 8, 300, 300, 32, 0.1, kpm=True)
+    case('enc self 300x300 p=0', 32, 8, 300, 300, 32, 0.0)
+    case('dec cross 100x300 dh32', 32, 8, 100, 300, 32, 0.1)
+    case('dec self 100x100 dh32', 32, 8, 100, 100, 32, 0.1)
+    case('coatt 24x100 dh96', 32, 8, 24, 100, 96, 0.1)
+    case('coatt 100x24 dh96', 32, 8, 100, 24, 96, 0.1)
+    case('text cross 20x124 dh64', 32, 12, 20, 124, 64, 0.1)
+    case('text self 20x20 causal dh64', 32, 12, 20, 20, 64, 0.1, causal=True)
+    case('bert 24x24 kpm dh64', 32, 12, 24, 24, 64, 0.1, kpm=True)
+
+
+if __name__ == '__main__':
+    main()
