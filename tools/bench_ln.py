@@ -26,4 +26,4 @@ for rows, cols in ((9600, 256), (3200, 256), (3200, 768), (3968, 768), (640, 768
     tf = timeit(lambda: hip.layernorm_fwd(x, s, gamma, beta, y, mean, rstd, rows, cols, 1e-5, 0.1, 7))
     tb = timeit(lambda: hip.layernorm_bwd(dy, x, s, gamma, mean, rstd, dx, ds, dg, db, rows, cols, 0.1, 7))
     mb = rows * cols * 2 / 1e6
-    print('%5d x %4d  fwd %5.1f us (%4.0f GB/s)  bwd %5.1f us (%4.0f GB/s)' % (rows, cols, tf, 3 * mb / tf * 1e3 / 1e3, tb, 5 * mb / tb * 1e3 / 1e3), flush=True)
+    print('%5d x %4d  fwd %5.1f us (%4.0f GB/s)  bwd %5.1f us (%4.0f GB/s)' % (rows, cols, tf, 3 * mb / tf * 1e3, tb, 5 * mb / tb * 1e3), flush=True)
