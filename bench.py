@@ -359,7 +359,9 @@ def main():
             'algorithmic_bytes_per_launch': bytes_step / launches,
             'fwd_ms': ms['conv_fwd'] / args.steps, 'bwd_ms': ms['conv_bwd'] / args.steps,
             'timed_region_brackets_ms': {'backbone_fwd_graph_with_bert_branch': sum(a.elapsed_time(b) for t_, a, b in prof_timed if t_ == 'conv_fwd') / args.steps,
-                                         'backbone_bwd_graph_with_wgrad_branch': sum(a.elapsed_time(b) for t_, a, b in prof_timed if t_ == 'conv_bwd') / args.steps},
+                                         'backbone_bwd_graph_with_wgrad_branch': sum(a.elapsed_time(b) for t_, a, b in prof_timed if t_ == 'conv_bwd') / args.steps,
+                                         'graph_f2_after_backbone_to_criterion_inputs': sum(a.elapsed_time(b) for t_, a, b in prof_timed if t_ == 'graph_f2') / args.steps,
+                                         'graph_b1_backward_down_to_backbone': sum(a.elapsed_time(b) for t_, a, b in prof_timed if t_ == 'graph_b1') / args.steps},
             'mfma_tflops': flops_step / (conv_ms * 1e-3) / 1e12, 'mfma_frac_of_2500': flops_step / (conv_ms * 1e-3) / 2.5e15}
     out = {'metric': 'images/sec/node (train step, 480x640, bs32/GPU)', 'value': world * args.batch * args.steps / elapsed,
            'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,

@@ -147,7 +147,10 @@ class GraphedBody:
         self.f1.replay()
         if ev is not None:
             ev.record()
+        ev = bbm._prof('graph_f2')
         self.f2.replay()
+        if ev is not None:
+            ev.record()
         leaves = {}
         for k, v in self.outs.items():
             if torch.is_tensor(v):
@@ -184,7 +187,10 @@ class GraphedBody:
         for (k, _, g), sg in zip(pairs, var['grads']):
             sg.copy_(g, non_blocking=True)
         tr.touched |= var['touched']
+        ev = bbm._prof('graph_b1')
         var['b1'].replay()
+        if ev is not None:
+            ev.record()
         if RT.backward_milestone is not None:
             RT.backward_milestone('backbone')
         ev = bbm._prof('conv_bwd')
