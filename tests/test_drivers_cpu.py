@@ -71,7 +71,9 @@ def test_train_driver_checkpoint_layout_and_resume(shim, tmp_path):
     torch.manual_seed(0)
     cfg = _driver_cfg(tmp_path / 'a')
     model, tr, step = td.train_worker(cfg, dataset=_dataset(vocab), device='cpu', log=logs.append)
-    assert step == 4 and len(logs) == 4 and 'loss' in logs[0]
+    assert any('BERT has random weights' in l for l in logs)            # no model.bert_weights in the fixture: the driver says so
+    steps = [l for l in logs if l.startswith('epoch')]
+    assert step == 4 and len(steps) == 4 and 'loss' in steps[0]
     ck = torch.load(os.path.join(cfg.ckpt_dir, 'model.pth'), weights_only=False)
     assert set(ck) == {'model', 'optimizer', 'epoch', 'step', 'lr', 'model_selection_metric', 'warmup_scheduler'}
     assert ck['epoch'] == 1 and ck['step'] == 4
