@@ -196,6 +196,8 @@ class ResNetBody(nn.Module):
         OH, OW = _out(H, 7, 2, 3), _out(Wd, 7, 2, 3)
         Hp = H + 6
         Wp = ((max(Wd + 6, 2 * (OW - 1) + 8) + 7) // 8) * 8
+        if RT.split is not None and keep is not None:
+            RT.split.prep_fork(self)
         xin = torch.empty(B, Hp, Wp, 4, device=images.device, dtype=RT.dtype)
         hip.image_to_nhwc4(images.contiguous(), xin, B, H, Wd, 3, Hp, Wp)
         ws, shift = self._stem_weight()
@@ -205,6 +207,8 @@ class ResNetBody(nn.Module):
         x = torch.empty(B, PH, PW, 64, device=images.device, dtype=RT.dtype)
         hip.maxpool3x3s2(y, x, B, OH, OW, 64, PH, PW)
         del y, xin
+        if RT.split is not None and keep is not None:
+            RT.split.prep_join()                   # the weight copies were prepared on a branch beside the stem (prep_weights)
         seen_trainable = False
         for blk in self.blocks():
             tr = blk.trainable() and keep is not None
@@ -218,6 +222,20 @@ class ResNetBody(nn.Module):
                 seen_trainable = True
             x = yb
         return x
+
+    def prep_weights(self):
+        """the bf16 copies (BN scale folded in; forward and backward-data layouts) of every trainable block's weights: 42 small
+        launches a training forward would otherwise issue one by one in front of its convolutions"""
+        seen_trainable = False
+        for blk in self.blocks():
+            if not blk.trainable():
+                continue
+            _conv_copies(blk.conv1, blk.bn1, True)
+            _conv_copies(blk.conv2, blk.bn2, True)
+            if blk.downsample is not None:
+                _conv_copies(blk.downsample[0], blk.downsample[1], seen_trainable)
+            _conv_copies(blk.conv3, blk.bn3, True)
+            seen_trainable = True
 
     def backward_nhwc(self, keep, dc5):
         """dc5: gradient w.r.t. the (post-ReLU) c5 output, [B,h,w,2048] compute dtype."""

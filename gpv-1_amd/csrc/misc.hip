@@ -402,6 +402,35 @@ __global__ __launch_bounds__(256) void cast_rowscale_t_kernel(const float* __res
   }
 }
 
+// many cast-transposes in one launch: the problem table travels in the kernel argument, block -> (problem, 32x32 tile) by a
+// linear scan of the tile prefix sums
+struct TcGroup {
+  int n;
+  int tile_start[GPV_TC_GROUP_MAX + 1];
+  gpv_tc_problem prob[GPV_TC_GROUP_MAX];
+};
+template <typename TD>
+__global__ __launch_bounds__(256) void cast_transpose_group_kernel(const TcGroup g) {
+  __shared__ float tile[32][33];
+  int pi = 0;
+  while (pi + 1 < g.n && (int)blockIdx.x >= g.tile_start[pi + 1]) ++pi;
+  const gpv_tc_problem q = g.prob[pi];
+  const int t = (int)blockIdx.x - g.tile_start[pi];
+  const int tc = (q.cols + 31) >> 5;
+  const int r0 = (t / tc) * 32, c0 = (t % tc) * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int j = ty; j < 32; j += 8) {
+    const int r = r0 + j, c = c0 + tx;
+    tile[j][tx] = (r < q.rows && c < q.cols) ? q.src[(int64_t)r * q.cols + c] : 0.f;
+  }
+  __syncthreads();
+  TD* dst = reinterpret_cast<TD*>(q.dstT);
+  for (int j = ty; j < 32; j += 8) {
+    const int c = c0 + j, r = r0 + tx;
+    if (r < q.rows && c < q.cols) dst[(int64_t)c * q.rows + r] = (TD)tile[tx][j];
+  }
+}
+
 // src [Cout][T][Cin] fp32 -> wf [Cout][T][Cin] scaled, wd [Cin][T][Cout] scaled
 template <typename TD>
 __global__ __launch_bounds__(256) void prep_conv_w_kernel(const float* __restrict__ src, const float* __restrict__ scale,
@@ -654,6 +683,27 @@ extern "C" int gpv_cast_rowscale_t(const float* src, const float* scale, void* d
   if (dtype_dst == GPV_BF16) hipLaunchKernelGGL((cast_rowscale_t_kernel<bf16>), grid, dim3(256), 0, ST(stream), src, scale, (bf16*)dst, (bf16*)dstT, rows, cols);
   else hipLaunchKernelGGL((cast_rowscale_t_kernel<float>), grid, dim3(256), 0, ST(stream), src, scale, (float*)dst, (float*)dstT, rows, cols);
   GPV_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int gpv_cast_transpose_group(const gpv_tc_problem* problems, int n, int dtype_dst, void* stream) {
+  if (n < 0 || (n > 0 && !problems)) return (int)hipErrorInvalidValue;
+  for (int i0 = 0; i0 < n; i0 += GPV_TC_GROUP_MAX) {
+    TcGroup g;
+    g.n = n - i0 < GPV_TC_GROUP_MAX ? n - i0 : GPV_TC_GROUP_MAX;
+    int tiles = 0;
+    for (int i = 0; i < g.n; ++i) {
+      const gpv_tc_problem& q = problems[i0 + i];
+      if (!q.src || !q.dstT || q.rows <= 0 || q.cols <= 0) return (int)hipErrorInvalidValue;
+      g.prob[i] = q;
+      g.tile_start[i] = tiles;
+      tiles += ((q.rows + 31) / 32) * ((q.cols + 31) / 32);
+    }
+    g.tile_start[g.n] = tiles;
+    if (dtype_dst == GPV_BF16) hipLaunchKernelGGL((cast_transpose_group_kernel<bf16>), dim3(tiles), dim3(256), 0, ST(stream), g);
+    else hipLaunchKernelGGL((cast_transpose_group_kernel<float>), dim3(tiles), dim3(256), 0, ST(stream), g);
+    GPV_CHECK_LAUNCH();
+  }
   return 0;
 }
 

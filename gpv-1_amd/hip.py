@@ -77,7 +77,7 @@ EXPORTS = ['gpv_abi_version', 'gpv_set_option', 'gpv_gemm', 'gpv_conv2d', 'gpv_i
            'gpv_softmax_ce', 'gpv_roi_weights', 'gpv_add', 'gpv_add_rowbcast', 'gpv_colsum', 'gpv_cast',
            'gpv_cast_rowscale_t', 'gpv_prep_conv_weight', 'gpv_embedding', 'gpv_dropout',
            'gpv_relevance_condition', 'gpv_adamw', 'gpv_sumsq', 'gpv_act_fwd', 'gpv_act_bwd', 'gpv_set_seed_device',
-           'gpv_gemm_tt_group']
+           'gpv_gemm_tt_group', 'gpv_cast_transpose_group']
 
 
 OPT_GLDS, OPT_GLDS_LAUNCHES, OPT_SKINNY, OPT_GLDS_WGRAD, OPT_PIPE, OPT_PIPE_LAUNCHES = 0, 1, 2, 3, 4, 5
@@ -312,6 +312,24 @@ def cast_rowscale_t(src, scale, dst, dstT, rows, cols):
     d = dst if dst is not None else dstT
     _chk(lib().gpv_cast_rowscale_t(_p(_f32(src)), _p(scale), _p(dst), _p(dstT), rows, cols, dcode(d), _stream()),
          'gpv_cast_rowscale_t')
+
+
+class TCProblem(C.Structure):
+    """include/gpv_hip.h: gpv_tc_problem"""
+    _fields_ = [('src', C.c_void_p), ('dstT', C.c_void_p), ('rows', C.c_int), ('cols', C.c_int)]
+
+
+def cast_transpose_group(items):
+    """items: (src fp32 [rows, cols] contiguous, dstT [cols, rows] contiguous in the compute dtype) -- one launch per 128"""
+    if not items:
+        return
+    arr = (TCProblem * len(items))()
+    for t, (src, dstT) in zip(arr, items):
+        _f32(src)
+        rows, cols = src.shape
+        assert src.is_contiguous() and dstT.is_contiguous() and tuple(dstT.shape) == (cols, rows)
+        t.src, t.dstT, t.rows, t.cols = src.data_ptr(), dstT.data_ptr(), rows, cols
+    _chk(lib().gpv_cast_transpose_group(arr, C.c_int(len(items)), C.c_int(dcode(items[0][1])), _stream()), 'gpv_cast_transpose_group')
 
 
 def prep_conv_weight(src, scale, wf, wd, Cout, T, Cin):

@@ -14,6 +14,9 @@ Design
 """
 import math
 
+import os
+import weakref
+
 import torch
 from torch.autograd import Function
 
@@ -164,6 +167,59 @@ def _lp(p):
     return w
 
 
+_T_PARAMS = {}            # id -> weakref of every parameter a transposed mirror has been asked for (refresh_transposed walks it)
+DX_MIRROR = os.environ.get('GPV_DX_MIRROR', '1') != '0'
+
+
+def _lpT(p):
+    """W^T [K, N] of a 2-D parameter in the compute dtype, rebuilt (one cast-transpose launch from the fp32 master) when the
+    parameter's epoch changes.  Backward-data GEMMs dX = dY W then run as K-major x K-major GEMMs on the pipelined
+    direct-to-LDS kernels: 9600 x 256 x 2048 (dz W1 of the DETR feed-forward) 54 -> 24 us against the reduction-major-B form
+    of the register-staged kernel (tools/bench_ffn.py).  Under train.GraphedBody the rebuilds run on a branch of F1."""
+    N = p.shape[0]
+    K = p.numel() // N
+    key = ('linT', id(p), RT.dtype)
+    hit = RT.cache.get(key)
+    ep = RT.epoch_of(p)
+    if hit is not None and hit[2]() is not p:            # id() recycled by a parameter of another model
+        hit = None
+    if hit is not None and hit[0] == ep:
+        return hit[1]
+    src = getattr(p, '_gpv_flat', None)
+    src = p.detach().reshape(N, K) if src is None else src.view(N, K)
+    if not src.is_contiguous():
+        src = src.contiguous()
+    wt = hit[1] if hit is not None else torch.empty(K, N, device=p.device, dtype=RT.dtype)      # same buffer every epoch
+    hip.cast_rowscale_t(src.float() if src.dtype != torch.float32 else src, None, None, wt, N, K)
+    ref = weakref.ref(p)
+    RT.cache[key] = (ep, wt, ref)
+    _T_PARAMS[id(p)] = ref
+    return wt
+
+
+def refresh_transposed():
+    """rebuild every stale transposed mirror now (train.GraphedBody: on a graph branch beside the backbone forward)"""
+    items = []
+    for k, r in list(_T_PARAMS.items()):
+        p = r()
+        hit = RT.cache.get(('linT', k, RT.dtype))
+        if p is None or hit is None or hit[2]() is not p:
+            _T_PARAMS.pop(k, None)
+            continue
+        ep = RT.epoch_of(p)
+        if hit[0] == ep:
+            continue
+        N = p.shape[0]
+        src = getattr(p, '_gpv_flat', None)
+        src = p.detach().reshape(N, -1) if src is None else src.view(N, -1)
+        if src.dtype != torch.float32 or not src.is_contiguous():
+            _lpT(p)                                   # (not the trainer's fp32 master layout: one by one)
+            continue
+        items.append((src, hit[1]))
+        RT.cache[('linT', k, RT.dtype)] = (ep, hit[1], hit[2])
+    hip.cast_transpose_group(items)                  # one launch for all of them (gpv_cast_transpose_group)
+
+
 class W:
     """rows [r0:r1) of a Linear-style weight parameter [N_total, K] (+ matching bias slice)."""
 
@@ -177,6 +233,20 @@ class W:
 
     def lp(self):
         return _lp(self.weight)[self.r0:self.r1]      # [N, K] contiguous rows, ld = K
+
+    def mirror_ok(self):
+        return DX_MIRROR and self.weight.dim() == 2 and self.K % 8 == 0 and self.Ntot % 8 == 0 and self.r0 % 8 == 0 and self.N % 8 == 0
+
+    def lpT(self):
+        return _lpT(self.weight)[:, self.r0:self.r1]  # [K, N] view of W^T, ld = N_total
+
+    def dx_gemm(self, dz, dx, M, **epi):
+        """dx[M, K] = epilogue(dz[M, N] W): through the transposed mirror as a K-major x K-major GEMM, or on W itself read
+        reduction-major"""
+        if self.mirror_ok():
+            hip.gemm(dz, self.lpT(), dx, M, self.K, self.N, self.N, self.Ntot, self.K, **epi)
+        else:
+            hip.gemm(dz, self.lp(), dx, M, self.K, self.N, self.N, self.K, self.K, layoutB=hip.TRANS, **epi)
 
     def bias_f32(self):
         return None if self.bias is None else self.bias.detach()[self.r0:self.r1]
@@ -254,7 +324,7 @@ class LinearFn(Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(M, K, device=dz.device, dtype=RT.dtype)
-            hip.gemm(dz, w.lp(), dx, M, K, N, N, K, K, layoutB=hip.TRANS)      # dx = dz W, W read reduction-major
+            w.dx_gemm(dz, dx, M)                                               # dx = dz W
             dx = dx.reshape(ctx.xshape)
         return dx, None, None, None, None, None
 
@@ -398,15 +468,14 @@ class FFNBlockFn(Function):
         elif nb2:
             hip.colsum(dy2, w2.bgrad(), M, K, K)
         dz = torch.empty(M, Fh, device=d2.device, dtype=RT.dtype)
-        hip.gemm(dy2, w2.lp(), dz, M, Fh, K, K, Fh, Fh, layoutB=hip.TRANS, relu_mask=h, ldm=Fh,
-                 alpha=1.0 / (1.0 - ctx.drop_p) if ctx.drop_p > 0 else 1.0)
+        w2.dx_gemm(dy2, dz, M, relu_mask=h, ldm=Fh, alpha=1.0 / (1.0 - ctx.drop_p) if ctx.drop_p > 0 else 1.0)
         nb1 = w1.bias is not None and w1.bias.requires_grad
         if w1.weight.requires_grad:
             wgrad_linear(dz, x2, w1.wgrad(), w1.bgrad() if nb1 else None, Fh, K, M, _split_k(Fh, K, M))
         elif nb1:
             hip.colsum(dz, w1.bgrad(), M, Fh, Fh)
         dx = torch.empty(M, K, device=dz.device, dtype=RT.dtype)
-        hip.gemm(dz, w1.lp(), dx, M, K, Fh, Fh, K, K, layoutB=hip.TRANS, res=dx_res, ldr=K)
+        w1.dx_gemm(dz, dx, M, res=dx_res, ldr=K)
         return dx.reshape(ctx.xshape), None, None, None, None, None, None
 
 

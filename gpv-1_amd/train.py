@@ -124,12 +124,33 @@ class GraphedBody:
         c5 = body.forward_nhwc(x, self.keep)
         if self.side is not None:
             torch.cuda.current_stream(x.device).wait_stream(self.side)         # join the BERT branch before F1 ends
+        if getattr(self, '_prep_forked', False):
+            torch.cuda.current_stream(x.device).wait_stream(self.wside)        # ... and the weight-mirror branch
+            self._prep_forked = False
         self.f1.capture_end()
         self.f2.capture_begin(pool=self.pool, capture_error_mode=CAPTURE_MODE)
         self.c5 = c5
         self.c5_leaf = c5.detach().requires_grad_(True)
         self.body = body
         return self.c5_leaf
+
+    # the backbone's per-step weight copies (42 launches of 5-9 us) as a branch of F1 beside the stem and layer1
+    def prep_fork(self, body):
+        if os.environ.get('GPV_PREP_BRANCH', '1') == '0':
+            return
+        cur = torch.cuda.current_stream(self.s_img.device)
+        self.wside.wait_stream(cur)
+        with torch.cuda.stream(self.wside):
+            body.prep_weights()
+            self._prep_done = torch.cuda.Event()
+            self._prep_done.record(self.wside)       # layer2 waits for this, not for what follows on the branch
+            from . import ops
+            ops.refresh_transposed()                 # W^T mirrors of the Linear layers (backward-data GEMMs, ops._lpT): needed in B1
+        self._prep_forked = True
+
+    def prep_join(self):
+        if getattr(self, '_prep_forked', False):
+            torch.cuda.current_stream(self.s_img.device).wait_event(self._prep_done)
 
     def stale(self):
         return self.epochs != (RT.static_epoch, RT.dtype)

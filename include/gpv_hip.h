@@ -202,6 +202,13 @@ int gpv_cast(const void* src, void* dst, int64_t n, int dtype_src, int dtype_dst
 /* dst[r,c] = cast(src[r,c] * scale[r]);  dstT[c,r] = same (optional) */
 int gpv_cast_rowscale_t(const float* src, const float* scale, void* dst, void* dstT, int rows, int cols,
                         int dtype_dst, void* stream);
+/* Many cast-transposes in one launch:  dstT_i[c, r] = cast(src_i[r, c])   (src fp32 [rows_i, cols_i] row-major, dstT [cols_i, rows_i]
+ * row-major in dtype_dst).  `problems` is HOST memory, at most GPV_TC_GROUP_MAX per launch (more: several launches).
+ * Replaces nothing in the reference (its autograd reads W as it is); here it refreshes the W^T mirrors of the Linear weights
+ * once per optimizer step so that the backward-data GEMMs dX = dY W run as K-major x K-major GEMMs. */
+#define GPV_TC_GROUP_MAX 128
+typedef struct { const float* src; void* dstT; int rows, cols; } gpv_tc_problem;
+int gpv_cast_transpose_group(const gpv_tc_problem* problems, int n, int dtype_dst, void* stream);
 /* conv weight prep: src fp32 [Cout][T][Cin] -> wf [Cout][T][Cin] (x scale[Cout]) and wd [Cin][T][Cout] */
 int gpv_prep_conv_weight(const float* src, const float* scale, void* wf, void* wd, int Cout, int T,
                          int Cin, int dtype_dst, void* stream);

@@ -237,6 +237,11 @@ def cast_rowscale_t(src, scale, dst, dstT, rows, cols):
         dstT.copy_(v.t().to(dstT.dtype))
 
 
+def cast_transpose_group(items):
+    for src, dstT in items:
+        dstT.copy_(src.t().to(dstT.dtype))
+
+
 def prep_conv_weight(src, scale, wf, wd, Cout, T, Cin):
     v = src.reshape(Cout, T, Cin) * (scale[:, None, None] if scale is not None else 1.0)
     if wf is not None:
@@ -301,7 +306,8 @@ def install(only=None):
     import gpv1_amd.hip as h
     names = only or ['gemm', 'conv2d', 'attention_fwd', 'attention_bwd', 'layernorm_fwd', 'layernorm_bwd', 'softmax_ce',
              'image_to_nhwc4', 'maxpool3x3s2', 'roi_weights', 'add', 'add_rowbcast', 'colsum', 'cast', 'cast_rowscale_t',
-             'prep_conv_weight', 'embedding', 'dropout', 'relevance_condition', 'adamw', 'sumsq', 'act_fwd', 'act_bwd']
+             'prep_conv_weight', 'embedding', 'dropout', 'relevance_condition', 'adamw', 'sumsq', 'act_fwd', 'act_bwd',
+             'cast_transpose_group']
     saved = {n: getattr(h, n) for n in names}
     for n in names:
         setattr(h, n, globals()[n])

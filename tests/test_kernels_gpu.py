@@ -736,3 +736,34 @@ def test_grouped_weight_gradient_gemm():
         if bg is not None:
             assert rel(bg, rb) < 3e-3
     assert not h.tt_group_ok(probs[0][0], probs[0][1], probs[0][2], 100, 768, 192, 768, 768, 768)      # M not a multiple of 128
+
+
+def test_cast_transpose_group_and_mirrored_dx_gemm():
+    """gpv_cast_transpose_group: many fp32 [N,K] -> bf16 [K,N] in one launch (ragged sizes, > 128 problems = two launches);
+    dX = dY W through the transposed mirror equals the reduction-major-B form"""
+    h = hip()
+    torch.manual_seed(3)
+    shapes = [(256, 256), (768, 256), (2048, 256), (256, 2048), (40, 72), (33, 8)] * 23          # 138 problems
+    items = []
+    for n, k in shapes:
+        src = torch.randn(n, k, device=DEV)
+        items.append((src, torch.empty(k, n, device=DEV, dtype=torch.bfloat16)))
+    h.cast_transpose_group(items)
+    torch.cuda.synchronize()
+    for src, dstT in items:
+        assert torch.equal(dstT, src.t().to(torch.bfloat16))
+    M, N, K = 1000, 768, 256
+    dy = torch.randn(M, N, device=DEV).to(torch.bfloat16)
+    w = (torch.randn(N, K, device=DEV) / 16)
+    wb, wt = w.to(torch.bfloat16), torch.empty(K, N, device=DEV, dtype=torch.bfloat16)
+    h.cast_transpose_group([(w, wt)])
+    a, b = torch.empty(M, K, device=DEV, dtype=torch.bfloat16), torch.empty(M, K, device=DEV, dtype=torch.bfloat16)
+    h.gemm(dy, wb, a, M, K, N, N, K, K, layoutB=h.TRANS)
+    c = torch.empty(M, K, device=DEV, dtype=torch.bfloat16)
+    h.gemm(dy[:, 256:512], wt[:, 256:512], c, M, K, 256, N, N, K)               # a row slice of W = a column slice of W^T
+    ref_c = dy[:, 256:512].float() @ wb[256:512].float()
+    assert float((c.float() - ref_c).abs().max()) < 0.02 * float(ref_c.abs().max())
+    h.gemm(dy, wt, b, M, K, N, N, N, K)
+    ref = dy.float() @ wb.float()
+    assert float((a.float() - ref).abs().max()) < 0.02 * float(ref.abs().max())
+    assert float((b.float() - ref).abs().max()) < 0.02 * float(ref.abs().max())
