@@ -411,23 +411,46 @@ struct TcGroup {
 };
 template <typename TD>
 __global__ __launch_bounds__(256) void cast_transpose_group_kernel(const TcGroup g) {
-  __shared__ float tile[32][33];
+  // 64x64 tiles: a thread reads 16 consecutive floats of a source row (four threads = one 256-byte run) and writes 16 consecutive
+  // outputs of a destination row; the tile crosses through LDS with a 65-float pitch (conflict-free both ways)
+  __shared__ float tile[64][65];
   int pi = 0;
   while (pi + 1 < g.n && (int)blockIdx.x >= g.tile_start[pi + 1]) ++pi;
   const gpv_tc_problem q = g.prob[pi];
   const int t = (int)blockIdx.x - g.tile_start[pi];
-  const int tc = (q.cols + 31) >> 5;
-  const int r0 = (t / tc) * 32, c0 = (t % tc) * 32;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  for (int j = ty; j < 32; j += 8) {
-    const int r = r0 + j, c = c0 + tx;
-    tile[j][tx] = (r < q.rows && c < q.cols) ? q.src[(int64_t)r * q.cols + c] : 0.f;
+  const int tc = (q.cols + 63) >> 6;
+  const int r0 = (t / tc) * 64, c0 = (t % tc) * 64;
+  const int lr = threadIdx.x >> 2, seg = (threadIdx.x & 3) * 16;
+  {
+    const int r = r0 + lr, c = c0 + seg;
+    const float* sp = q.src + (int64_t)r * q.cols + c;
+    if (r < q.rows && c + 16 <= q.cols && (q.cols & 3) == 0) {
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const float4 x = *reinterpret_cast<const float4*>(sp + 4 * v);
+        tile[lr][seg + 4 * v] = x.x; tile[lr][seg + 4 * v + 1] = x.y; tile[lr][seg + 4 * v + 2] = x.z; tile[lr][seg + 4 * v + 3] = x.w;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) tile[lr][seg + e] = (r < q.rows && c + e < q.cols) ? sp[e] : 0.f;
+    }
   }
   __syncthreads();
-  TD* dst = reinterpret_cast<TD*>(q.dstT);
-  for (int j = ty; j < 32; j += 8) {
-    const int c = c0 + j, r = r0 + tx;
-    if (r < q.rows && c < q.cols) dst[(int64_t)c * q.rows + r] = (TD)tile[tx][j];
+  {
+    const int c = c0 + lr, r = r0 + seg;          // destination row c (a source column), 16 consecutive source rows
+    if (c >= q.cols) return;
+    TD* dp = reinterpret_cast<TD*>(q.dstT) + (int64_t)c * q.rows + r;
+    float v[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) v[e] = tile[seg + e][lr];
+    if (r + 16 <= q.rows && (q.rows & 7) == 0) {
+      Ld8<TD>::st(dp, v);
+      Ld8<TD>::st(dp + 8, v + 8);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+        if (r + e < q.rows) dp[e] = (TD)v[e];
+    }
   }
 }
 
@@ -697,7 +720,7 @@ extern "C" int gpv_cast_transpose_group(const gpv_tc_problem* problems, int n, i
       if (!q.src || !q.dstT || q.rows <= 0 || q.cols <= 0) return (int)hipErrorInvalidValue;
       g.prob[i] = q;
       g.tile_start[i] = tiles;
-      tiles += ((q.rows + 31) / 32) * ((q.cols + 31) / 32);
+      tiles += ((q.rows + 63) / 64) * ((q.cols + 63) / 64);
     }
     g.tile_start[g.n] = tiles;
     if (dtype_dst == GPV_BF16) hipLaunchKernelGGL((cast_transpose_group_kernel<bf16>), dim3(tiles), dim3(256), 0, ST(stream), g);

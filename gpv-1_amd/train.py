@@ -112,6 +112,7 @@ class GraphedBody:
             self.q_enc = q_enc
             self.outs = model._forward_impl(NestedTensor(self.s_img, self.s_mask, self.all_valid), (self.s_ids, self.s_attn),
                                             self.s_tok, None, query_encodings=q_enc)
+            torch.cuda.current_stream(dev).wait_stream(self.wside)          # join the weight-mirror branch
             self.f2.capture_end()
         finally:
             RT.split = None
@@ -124,11 +125,17 @@ class GraphedBody:
         c5 = body.forward_nhwc(x, self.keep)
         if self.side is not None:
             torch.cuda.current_stream(x.device).wait_stream(self.side)         # join the BERT branch before F1 ends
-        if getattr(self, '_prep_forked', False):
-            torch.cuda.current_stream(x.device).wait_stream(self.wside)        # ... and the weight-mirror branch
-            self._prep_forked = False
+        self._prep_forked = False
         self.f1.capture_end()
         self.f2.capture_begin(pool=self.pool, capture_error_mode=CAPTURE_MODE)
+        # the W^T mirrors of the Linear weights (ops._lpT; needed by B1's backward-data GEMMs) are refreshed by one grouped
+        # cast-transpose launch on a branch of F2: 360 MB of streaming under a chain of latency-bound kernels.  (As a branch of
+        # F1 it ran beside the stem convolution and cost it 0.2 ms.)
+        from . import ops
+        cur = torch.cuda.current_stream(x.device)
+        self.wside.wait_stream(cur)
+        with torch.cuda.stream(self.wside):
+            ops.refresh_transposed()
         self.c5 = c5
         self.c5_leaf = c5.detach().requires_grad_(True)
         self.body = body
@@ -143,9 +150,7 @@ class GraphedBody:
         with torch.cuda.stream(self.wside):
             body.prep_weights()
             self._prep_done = torch.cuda.Event()
-            self._prep_done.record(self.wside)       # layer2 waits for this, not for what follows on the branch
-            from . import ops
-            ops.refresh_transposed()                 # W^T mirrors of the Linear layers (backward-data GEMMs, ops._lpT): needed in B1
+            self._prep_done.record(self.wside)
         self._prep_forked = True
 
     def prep_join(self):
