@@ -5,6 +5,8 @@ backbone (NHWC c5) -> input_proj (1x1 conv == GEMM over the c5 rows) -> transfor
 (fp32 outputs, they feed the matcher) -> RoIAlign(7x7)+mean as a batched GEMM with separable bilinear
 weights -> LayerNorm (no affine) -> concat with the decoder states (2048 + 256 = 2304).
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -29,6 +31,9 @@ class MLP(nn.Module):
             last = i == self.num_layers - 1
             x = layer(x, ops.ACT_NONE if last else ops.ACT_RELU, out_f32=last)
         return x
+
+
+BOUNDARY_BELOW_ROI = os.environ.get('GPV_BOUNDARY', 'roi') == 'hs'
 
 
 class Conv1x1P(nn.Module):
@@ -69,7 +74,13 @@ class DETR(nn.Module):
         src = self.input_proj(rows)                            # [B,S,256]
         need_all = not (self.last_layer_only is True or self.training is not True)
         outs, _ = self.transformer(src, mask.flatten(1), self.query_embed.weight, pos[-1], need_all or self.aux_loss)
+        # (backward: when the gradient arrives here, the text decoder, the co-attention, the heads and the RoI head have run --
+        #  train.GraphedBody launches their grouped weight gradients on a side branch from this point, beside the DETR layers.
+        #  Placed after the RoI head it made that head's LDS-heavy backward kernels wait for the grouped GEMM's blocks:
+        #  LayerNorm backward 20 -> 160 us, pooling backward 60 -> 155 us.)
         hs = torch.stack(outs)                                 # [L,B,Q,D]
+        if BOUNDARY_BELOW_ROI:
+            hs = ops.boundary(hs, 'detr')
         if not need_all:
             hs = hs[-1:]
         outputs_class = self.class_embed(hs, out_f32=True)     # fp32 logits

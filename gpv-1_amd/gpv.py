@@ -17,6 +17,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
+from . import detr as detr_mod
 from .ops import W, RT
 from .detr import create_detr, create_detr_roi_head
 from .bert import Bert
@@ -183,7 +184,9 @@ class GPV(nn.Module):
         parallel branch of the backbone's hipGraph: 110 launches of <= 144 workgroups hide under the convolutions)"""
         outputs = self.detr(images)
         # (backward: everything downstream of the DETR stream -- text decoder, answer head, co-attention -- is done when this fires)
-        outputs['detr_hs'] = self.detr_joiner(ops.boundary(outputs['detr_hs'], 'detr'))     # [L,B,Q,768]
+        if not detr_mod.BOUNDARY_BELOW_ROI:
+            outputs['detr_hs'] = ops.boundary(outputs['detr_hs'], 'detr')
+        outputs['detr_hs'] = self.detr_joiner(outputs['detr_hs'])     # [L,B,Q,768]
         if query_encodings is None:
             with torch.no_grad():
                 query_encodings, _ = self.bert(queries)
