@@ -278,11 +278,51 @@ def _as_compute(x):
 
 
 # --------------------------------------------------------------------------------------------
+# Gradient chains: the gradient of an activation with several consumers, summed inside the consumers' own kernels
+# --------------------------------------------------------------------------------------------
+class GradChain:
+    """A layer input feeds the residual of its LayerNorm AND the projection GEMMs (encoder: src -> norm1, Wqk (through src+pos),
+    Wv); autograd sums the three gradients with two extra element-wise passes per layer (45 such launches per step, ~5 us each,
+    all on the serial chain).  Consumers that share a GradChain hand the running sum along instead: the first one to run in the
+    backward deposits its gradient, every later one adds it in the `res` epilogue of its backward-data GEMM, and only the last one
+    returns a gradient to autograd (the others return None).  Consumers register while the forward is recorded, so a consumer
+    that will never run a backward (no grad path) is not waited for."""
+    ENABLED = os.environ.get('GPV_GRAD_CHAIN', '1') != '0'
+
+    def __init__(self):
+        self.total = 0            # consumers registered in the forward
+        self.left = 0             # ... that have not run yet in the current backward pass
+        self.acc = None
+
+    def join(self):
+        self.total += 1
+        self.left += 1
+        return self
+
+    def done(self, g):
+        """g = this consumer's gradient with self.acc already added; returns the total if this was the last consumer.
+        Re-arms itself: the same autograd graph may be walked again (retain_graph -- train.GraphedBody captures one backward per
+        set of criterion outputs from a single recorded forward)."""
+        self.left -= 1
+        if self.left == 0:
+            self.left = self.total
+            self.acc = None
+            return g
+        self.acc = g
+        return None
+
+
+def grad_chain(x):
+    return GradChain() if (GradChain.ENABLED and torch.is_grad_enabled() and torch.is_tensor(x) and x.requires_grad) else None
+
+
+# --------------------------------------------------------------------------------------------
 # Linear:  y = dropout(act(x W^T + b))      (x: [..., K])
 # --------------------------------------------------------------------------------------------
 class LinearFn(Function):
     @staticmethod
-    def forward(ctx, x, w, act, drop_p, out_f32, dummy=None):
+    def forward(ctx, x, w, act, drop_p, out_f32, dummy=None, chain=None):
+        ctx.chain = chain.join() if (chain is not None and ctx.needs_input_grad[0]) else None
         K, N = w.K, w.N
         x2 = _c(_as_compute(x)).reshape(-1, K)
         M = x2.shape[0]
@@ -324,9 +364,15 @@ class LinearFn(Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(M, K, device=dz.device, dtype=RT.dtype)
-            w.dx_gemm(dz, dx, M)                                               # dx = dz W
+            ch = ctx.chain
+            if ch is not None and ch.acc is not None:
+                w.dx_gemm(dz, dx, M, res=ch.acc.reshape(M, K), ldr=K)         # dx = dz W + (the other consumers' gradients so far)
+            else:
+                w.dx_gemm(dz, dx, M)                                           # dx = dz W
             dx = dx.reshape(ctx.xshape)
-        return dx, None, None, None, None, None
+            if ch is not None:
+                dx = ch.done(dx)
+        return dx, None, None, None, None, None, None
 
 
 _DUMMY = {}
@@ -341,12 +387,12 @@ def _dummy(device):
     return d
 
 
-def linear(x, w, act=ACT_NONE, drop_p=0.0, out_f32=False):
+def linear(x, w, act=ACT_NONE, drop_p=0.0, out_f32=False, chain=None):
     assert not (drop_p > 0 and act != ACT_RELU), 'epilogue dropout is only differentiated through the ReLU form'
     dummy = None
     if torch.is_grad_enabled() and not x.requires_grad and (w.weight.requires_grad or (w.bias is not None and w.bias.requires_grad)):
         dummy = _dummy(x.device)
-    return LinearFn.apply(x, w, act, drop_p, out_f32, dummy)
+    return LinearFn.apply(x, w, act, drop_p, out_f32, dummy, chain)
 
 
 # y = a @ b^T with both operands activations (answer head: h x Wc^T)
@@ -385,7 +431,8 @@ def matmul_nt(a, b):
 # --------------------------------------------------------------------------------------------
 class AddLayerNormFn(Function):
     @staticmethod
-    def forward(ctx, x, s, gamma, beta, eps, drop_p):
+    def forward(ctx, x, s, gamma, beta, eps, drop_p, chain=None):
+        ctx.chain = chain.join() if (chain is not None and ctx.needs_input_grad[0]) else None
         cols = x.shape[-1]
         x2 = _c(_as_compute(x)).reshape(-1, cols)
         s2 = None if s is None else _c(_as_compute(s)).reshape(-1, cols)
@@ -419,7 +466,16 @@ class AddLayerNormFn(Function):
         dsr = None
         if ctx.has_s:
             dsr = (ds if ds is not None else dx).reshape(ctx.shape)
-        return (dxr if ctx.needs_input_grad[0] else None), (dsr if ctx.needs_input_grad[1] else None), None, None, None, None
+        if ctx.chain is not None and ctx.needs_input_grad[0]:
+            ch = ctx.chain
+            if ch.acc is not None:                      # (a LayerNorm is normally the first consumer to run; if not: one add)
+                t = torch.empty_like(dx)
+                hip.add(dx, _c(ch.acc).reshape(rows, cols), t, t.numel())
+                dxr = t.reshape(ctx.shape)
+            elif dsr is not None and ds is None:
+                dxr = dxr.clone()                       # dx doubles as ds here: the chain's later `res` reads must not alias a live output
+            dxr = ch.done(dxr)
+        return (dxr if ctx.needs_input_grad[0] else None), (dsr if ctx.needs_input_grad[1] else None), None, None, None, None, None
 
 
 class FFNBlockFn(Function):
@@ -486,8 +542,8 @@ def ffn_block(x, w1, w2, gamma, beta, eps, drop_p=0.0):
     return FFNBlockFn.apply(x, w1, w2, gamma, beta, eps, drop_p)
 
 
-def add_layernorm(x, s, gamma, beta, eps, drop_p=0.0):
-    return AddLayerNormFn.apply(x, s, gamma, beta, eps, drop_p)
+def add_layernorm(x, s, gamma, beta, eps, drop_p=0.0, chain=None):
+    return AddLayerNormFn.apply(x, s, gamma, beta, eps, drop_p, chain)
 
 
 # --------------------------------------------------------------------------------------------
@@ -541,6 +597,7 @@ class AddFn(Function):
 
     @staticmethod
     def forward(ctx, a, b):
+        ctx.set_materialize_grads(False)                # a chained consumer may hand back None: nothing to pass on
         a2, b2 = _c(_as_compute(a)), _c(_as_compute(b))
         y = torch.empty_like(a2)
         cols = a2.shape[-1]
@@ -553,6 +610,8 @@ class AddFn(Function):
 
     @staticmethod
     def backward(ctx, dy):
+        if dy is None:
+            return None, None
         db = None
         if ctx.needs_input_grad[1]:
             if math.prod(ctx.bshape) == dy.numel():

@@ -23,8 +23,8 @@ class LinearP(nn.Module):
         self.bias = nn.Parameter(ref.bias.detach().clone()) if bias else None
         self.in_features, self.out_features = in_features, out_features
 
-    def forward(self, x, act=ops.ACT_NONE, drop_p=0.0, out_f32=False):
-        return ops.linear(x, W(self.weight, self.bias), act, drop_p, out_f32)
+    def forward(self, x, act=ops.ACT_NONE, drop_p=0.0, out_f32=False, chain=None):
+        return ops.linear(x, W(self.weight, self.bias), act, drop_p, out_f32, chain)
 
 
 def ffn_block(x, l1, l2, norm, drop_p):
@@ -39,9 +39,9 @@ class LayerNormP(nn.Module):
         self.bias = nn.Parameter(torch.zeros(dim))
         self.eps = eps
 
-    def forward(self, x, s=None, drop_p=0.0):
-        """LayerNorm(x + dropout(s))"""
-        return ops.add_layernorm(x, s, self.weight, self.bias, self.eps, drop_p)
+    def forward(self, x, s=None, drop_p=0.0, chain=None):
+        """LayerNorm(x + dropout(s)); chain: the ops.GradChain of x (its gradient is handed to x's other consumers)"""
+        return ops.add_layernorm(x, s, self.weight, self.bias, self.eps, drop_p, chain)
 
 
 class MultiheadAttention(nn.Module):
@@ -57,20 +57,24 @@ class MultiheadAttention(nn.Module):
         nn.init.xavier_uniform_(self.in_proj_weight)
         nn.init.constant_(self.out_proj.bias, 0.)
 
-    def forward(self, q_in, k_in, v_in, B, Sq, Sk, key_padding_mask=None, causal=False):
+    def forward(self, q_in, k_in, v_in, B, Sq, Sk, key_padding_mask=None, causal=False, chains=(None, None, None)):
+        """chains: ops.GradChain (or None) of the tensor behind q_in / k_in / v_in -- only where the projection's input gradient
+        IS that tensor's gradient (the input itself, or input + a constant position term)"""
         E = self.embed_dim
         w, b = self.in_proj_weight, self.in_proj_bias
+        cq, ck, cv = chains
         if q_in is k_in and k_in is v_in:
-            bufs = [ops.linear(q_in, W(w, b, 0, 3 * E))]
+            bufs = [ops.linear(q_in, W(w, b, 0, 3 * E), chain=cq)]
             roles = ((0, 0), (0, E), (0, 2 * E))
         elif q_in is k_in:
-            bufs = [ops.linear(q_in, W(w, b, 0, 2 * E)), ops.linear(v_in, W(w, b, 2 * E, 3 * E))]
+            bufs = [ops.linear(q_in, W(w, b, 0, 2 * E), chain=cq), ops.linear(v_in, W(w, b, 2 * E, 3 * E), chain=cv)]
             roles = ((0, 0), (0, E), (1, 0))
         elif k_in is v_in:
-            bufs = [ops.linear(q_in, W(w, b, 0, E)), ops.linear(k_in, W(w, b, E, 3 * E))]
+            bufs = [ops.linear(q_in, W(w, b, 0, E), chain=cq), ops.linear(k_in, W(w, b, E, 3 * E), chain=ck)]
             roles = ((0, 0), (1, 0), (1, E))
         else:
-            bufs = [ops.linear(q_in, W(w, b, 0, E)), ops.linear(k_in, W(w, b, E, 2 * E)), ops.linear(v_in, W(w, b, 2 * E, 3 * E))]
+            bufs = [ops.linear(q_in, W(w, b, 0, E), chain=cq), ops.linear(k_in, W(w, b, E, 2 * E), chain=ck),
+                    ops.linear(v_in, W(w, b, 2 * E, 3 * E), chain=cv)]
             roles = ((0, 0), (1, 0), (2, 0))
         o = ops.attention(bufs, roles, B, self.num_heads, Sq, Sk, self.head_dim, kpm=key_padding_mask, causal=causal,
                           drop_p=self.dropout if self.training else 0.0)
@@ -90,8 +94,9 @@ class TransformerEncoderLayer(nn.Module):
     def forward(self, src, pos, B, S, kpm):
         """transformer.py:148-161 (forward_post)"""
         p = self.p if self.training else 0.0
+        ch = ops.grad_chain(src)                 # src feeds norm1's residual, Wqk (through src + pos, pos constant) and Wv
         qk = ops.add(src, pos)
-        src = self.norm1(src, self.self_attn(qk, qk, src, B, S, S, kpm), p)
+        src = self.norm1(src, self.self_attn(qk, qk, src, B, S, S, kpm, chains=(ch, ch, ch)), p, chain=ch)
         return ffn_block(src, self.linear1, self.linear2, self.norm2, p)
 
 
@@ -107,12 +112,15 @@ class TransformerDecoderLayer(nn.Module):
         self.norm3 = LayerNormP(d_model)
         self.p = dropout
 
-    def forward(self, tgt, memory, mem_pos, query_pos, B, Q, S, kpm):
-        """transformer.py:211-232 (forward_post); mem_pos = memory + pos is layer-invariant."""
+    def forward(self, tgt, memory, mem_pos, query_pos, B, Q, S, kpm, mem_chain=None):
+        """transformer.py:211-232 (forward_post); mem_pos = memory + pos is layer-invariant.  mem_chain: the GradChain of the
+        encoder memory, shared by the K (through memory + pos) and V projections of all six layers.  The query-side sums
+        tgt + query_pos are NOT chained through: query_pos is learned and needs the projection's gradient on its own."""
         p = self.p if self.training else 0.0
+        ch = ops.grad_chain(tgt)                 # tgt feeds norm1's residual and Wv (and, through tgt + query_pos, Wqk)
         qk = ops.add(tgt, query_pos)
-        tgt = self.norm1(tgt, self.self_attn(qk, qk, tgt, B, Q, Q), p)
-        a = self.multihead_attn(ops.add(tgt, query_pos), mem_pos, memory, B, Q, S, kpm)
+        tgt = self.norm1(tgt, self.self_attn(qk, qk, tgt, B, Q, Q, chains=(None, None, ch)), p, chain=ch)
+        a = self.multihead_attn(ops.add(tgt, query_pos), mem_pos, memory, B, Q, S, kpm, chains=(None, mem_chain, mem_chain))
         tgt = self.norm2(tgt, a, p)
         return ffn_block(tgt, self.linear1, self.linear2, self.norm3, p)
 
@@ -157,13 +165,14 @@ class Transformer(nn.Module):
         for layer in self.encoder.layers:
             x = layer(x, pe, B, S, kpm)
         memory = x
+        mem_chain = ops.grad_chain(memory)
         mem_pos = ops.add(memory, pe)
         qpos = query_embed.to(ops.RT.dtype).unsqueeze(0).expand(B, Q, C).reshape(B * Q, C)
         tgt = torch.zeros(B * Q, C, device=src.device, dtype=ops.RT.dtype)
         outs = []
         n = len(self.decoder.layers)
         for i, layer in enumerate(self.decoder.layers):
-            tgt = layer(tgt, memory, mem_pos, qpos, B, Q, S, kpm)
+            tgt = layer(tgt, memory, mem_pos, qpos, B, Q, S, kpm, mem_chain)
             if need_all_layers or i == n - 1:
                 outs.append(self.decoder.norm(tgt).reshape(B, Q, C))
         return outs, memory.reshape(B, S, C)

@@ -177,3 +177,41 @@ def test_flat_trainer_matches_torch_adamw(shim):
         # either implementation, so the element-wise bound is 2 steps x lr (the loss equality above is the sharp check)
         lr = 1e-5 if param_group_of(n) == 'detr_backbone' else 1e-4
         assert (p1[n].detach() - p2[n].detach()).abs().max().item() <= 2.2 * lr * 2, n
+
+
+def test_grad_chain_matches_autograd_accumulation_and_rearms(shim):
+    """ops.GradChain (layer-input gradients summed in the consumers' `res` epilogues) == autograd's own accumulation, also when
+    the same recorded forward is walked twice (retain_graph: train.GraphedBody captures several backward variants from one forward)"""
+    import gpv1_amd.ops as ops
+    images, mask, ids, attn = synth.synth_batch(B, H, W, Tl, V, pad_to=PAD)
+    grads = {}
+    for on in (False, True):
+        ops.GradChain.ENABLED = on
+        try:
+            torch.manual_seed(0)
+            model, _ = build_small()
+            model.train()
+            model.bert.model.p = 0.0
+            tg = synth.synth_targets(B, V, S=6)
+            _, tid = model.encode_answers(tg)
+            for i, t in enumerate(tg):
+                t['answer_token_ids'] = tid[i, 1:]
+            loss = model(nested(images, mask), (ids, attn), tid, tg)
+            runs = []
+            for _ in range(2 if on else 1):
+                for p in model.parameters():
+                    p.grad = None
+                loss.backward(retain_graph=True)
+                runs.append({n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None})
+            if on:       # (the backbone node releases its activations in its first backward: compared on the transformer side)
+                assert {n for n in runs[0] if 'backbone' not in n} == {n for n in runs[1] if 'backbone' not in n}
+                for n in runs[1]:
+                    if 'backbone' not in n and 'input_proj' not in n:
+                        assert torch.equal(runs[0][n], runs[1][n]), n             # the second walk is not missing any contribution
+            grads[on] = runs[0]
+        finally:
+            ops.GradChain.ENABLED = True
+    assert grads[False].keys() == grads[True].keys()
+    for n, g in grads[False].items():
+        ref = float(g.abs().max())
+        assert float((g - grads[True][n]).abs().max()) <= 1e-5 * max(ref, 1e-3), n
