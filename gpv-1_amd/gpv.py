@@ -57,10 +57,13 @@ class TextDecoderLayer(nn.Module):
         self.norm1, self.norm2, self.norm3 = LayerNormP(d_model), LayerNormP(d_model), LayerNormP(d_model)
         self.p = dropout
 
-    def forward(self, tgt, memory, B, Tt, Tm):
+    def forward(self, tgt, memory, B, Tt, Tm, mem_chain=None):
         p = self.p if self.training else 0.0
-        tgt = self.norm1(tgt, self.self_attn(tgt, tgt, tgt, B, Tt, Tt, causal=True), p)
-        tgt = self.norm2(tgt, self.multihead_attn(tgt, memory, memory, B, Tt, Tm), p)   # no memory padding mask
+        c0 = ops.grad_chain(tgt)                       # (ops.GradChain: tgt feeds the projection and the residual)
+        tgt = self.norm1(tgt, self.self_attn(tgt, tgt, tgt, B, Tt, Tt, causal=True, chains=(c0, c0, c0)), p, chain=c0)
+        c1 = ops.grad_chain(tgt)
+        tgt = self.norm2(tgt, self.multihead_attn(tgt, memory, memory, B, Tt, Tm, chains=(c1, mem_chain, mem_chain)), p,
+                         chain=c1)                     # no memory padding mask
         return ffn_block(tgt, self.linear1, self.linear2, self.norm3, p)
 
 
@@ -215,8 +218,9 @@ class GPV(nn.Module):
             target = ops.add(target.reshape(B * Tt, D), self.pos_enc[0, :Tt].to(RT.dtype)).reshape(B, Tt, D)
         x = target.reshape(B * Tt, D)
         mem = memory.reshape(B * Tm, D)
+        mem_chain = ops.grad_chain(mem)                # the co-attention output feeds the K|V projection of every layer
         for layer in self.text_decoder.layers:
-            x = layer(x, mem, B, Tt, Tm)
+            x = layer(x, mem, B, Tt, Tm, mem_chain)
         return self.answer_head(x).reshape(B, Tt, -1)
 
     # ------------------------------------------------------------------ reference API

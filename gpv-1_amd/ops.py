@@ -289,10 +289,13 @@ class GradChain:
     that will never run a backward (no grad path) is not waited for."""
     ENABLED = os.environ.get('GPV_GRAD_CHAIN', '1') != '0'
 
+    _live = []                    # chains created since the last check_chains() (weak references)
+
     def __init__(self):
         self.total = 0            # consumers registered in the forward
         self.left = 0             # ... that have not run yet in the current backward pass
         self.acc = None
+        GradChain._live.append(weakref.ref(self))
 
     def join(self):
         self.total += 1
@@ -314,6 +317,22 @@ class GradChain:
 
 def grad_chain(x):
     return GradChain() if (GradChain.ENABLED and torch.is_grad_enabled() and torch.is_tensor(x) and x.requires_grad) else None
+
+
+def check_chains(clear=True):
+    """after a backward pass: every chain must be complete (all of its consumers ran, or none).  A chain whose consumers can
+    run independently of each other (two outputs of a layer, one without a loss) silently loses gradient -- the members of a
+    chain must sit behind ONE output (see vilbert.BertConnectionLayer).  Raises instead of training on wrong gradients."""
+    bad = 0
+    for r in GradChain._live:
+        c = r()
+        if c is not None and c.left != c.total:
+            bad += 1
+            c.left, c.acc = c.total, None
+    if clear:
+        del GradChain._live[:]
+    if bad:
+        raise RuntimeError('%d GradChain(s) ended a backward pass half walked: a chained consumer did not run' % bad)
 
 
 # --------------------------------------------------------------------------------------------

@@ -54,6 +54,11 @@ def warmup_linear(step, warmup_steps, t_total):
 CAPTURE_MODE = os.environ.get('GPV_CAPTURE_MODE', 'thread_local')
 
 
+def ops_check_chains(clear=True):
+    from . import ops
+    ops.check_chains(clear)
+
+
 class GraphedBody:
     """Forward and backward of the model body (everything of train_distr.py:413-421 between the host-side tokenisation and
     the criterion) as hipGraphs, for one static input signature (image / query / answer-token shapes).
@@ -276,6 +281,7 @@ class GraphedBody:
             RT.defer_list = deferred if defer else None
             RT.backward_boundary = at_boundary if os.environ.get('GPV_WGRAD_SPLIT', '1') != '0' else None
             torch.autograd.backward([o for _, o, _ in pairs], grads, retain_graph=True)
+            ops_check_chains(clear=False)            # (the recorded forward -- and its chains -- serve further backward variants)
             RT.defer_list = None
             RT.backward_boundary = None
             if deferred and tr.world > 1:
@@ -659,6 +665,7 @@ class FlatTrainer:
         self.begin_backward()
         if loss is not None:
             loss.backward()
+        ops_check_chains()
         self.allreduce_grads()
         self.step()
         return None if loss is None else loss.detach()     # (a stashed loss would keep the step's autograd graph alive)

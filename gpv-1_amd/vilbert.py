@@ -33,11 +33,15 @@ class BertBiAttention(nn.Module):
         self.p1 = cfg.v_attention_probs_dropout_prob
         self.p2 = cfg.attention_probs_dropout_prob
 
-    def forward(self, t1, t2, B, T1, T2):
-        """t1 [B*T1, D] (language), t2 [B*T2, D] (vision) -> ctx1 [B*T2, D], ctx2 [B*T1, D]"""
+    def forward(self, t1, t2, B, T1, T2, own1=None, own2=None):
+        """t1 [B*T1, D] (language), t2 [B*T2, D] (vision) -> ctx1 [B*T2, D], ctx2 [B*T1, D].
+        ops.GradChain: a chain's members must all sit behind the same layer output (a detection-only batch gives the language
+        output of the last layer no gradient).  ctx2 -> stream 1's output uses q1, k2, v2; ctx1 -> stream 2's output uses q2, k1, v1:
+        own1 / own2 = the chain query_i shares with stream i's residual LayerNorm; k_i, v_i form a chain of their own."""
         H, dh, D = self.num_attention_heads, self.attention_head_size, self.all_head_size
-        q1, k1, v1 = self.query1(t1), self.key1(t1), self.value1(t1)
-        q2, k2, v2 = self.query2(t2), self.key2(t2), self.value2(t2)
+        x1, x2 = ops.grad_chain(t1), ops.grad_chain(t2)
+        q1, k1, v1 = self.query1(t1, chain=own1), self.key1(t1, chain=x1), self.value1(t1, chain=x1)
+        q2, k2, v2 = self.query2(t2, chain=own2), self.key2(t2, chain=x2), self.value2(t2, chain=x2)
         p1 = self.p1 if self.training else 0.0
         p2 = self.p2 if self.training else 0.0
         # scores1 = q2 k1^T -> probs (dropout1) @ v1 : vision queries over language keys (vilbert.py:770-787)
@@ -58,11 +62,11 @@ class BertBiOutput(nn.Module):
         self.q_dense2 = LinearP(cfg.bi_hidden_size, cfg.hidden_size)       # unused in forward
         self.p1, self.p2 = cfg.v_hidden_dropout_prob, cfg.hidden_dropout_prob
 
-    def forward(self, hidden1, input1, hidden2, input2):
+    def forward(self, hidden1, input1, hidden2, input2, c1=None, c2=None):
         p1 = self.p1 if self.training else 0.0
         p2 = self.p2 if self.training else 0.0
-        return (self.LayerNorm1(input1, self.dense1(hidden1), p1),
-                self.LayerNorm2(input2, self.dense2(hidden2), p2))
+        return (self.LayerNorm1(input1, self.dense1(hidden1), p1, chain=c1),
+                self.LayerNorm2(input2, self.dense2(hidden2), p2, chain=c2))
 
 
 class _Intermediate(nn.Module):
@@ -72,8 +76,8 @@ class _Intermediate(nn.Module):
             raise NotImplementedError('GPV-1 configs use hidden_act: gelu')
         self.dense = LinearP(hidden, inter)
 
-    def forward(self, x):
-        return self.dense(x, ops.ACT_GELU)
+    def forward(self, x, chain=None):
+        return self.dense(x, ops.ACT_GELU, chain=chain)
 
 
 class _Output(nn.Module):
@@ -83,8 +87,8 @@ class _Output(nn.Module):
         self.LayerNorm = LayerNormP(hidden, eps=1e-12)
         self.p = p
 
-    def forward(self, h, inp):
-        return self.LayerNorm(inp, self.dense(h), self.p if self.training else 0.0)
+    def forward(self, h, inp, chain=None):
+        return self.LayerNorm(inp, self.dense(h), self.p if self.training else 0.0, chain=chain)
 
 
 class BertConnectionLayer(nn.Module):
@@ -99,8 +103,10 @@ class BertConnectionLayer(nn.Module):
 
     def forward(self, t1, t2, B, T1, T2):
         """vilbert.py:872-900.  No attention masks: GPV passes None, so padded BERT tokens are attended."""
-        bi1, bi2 = self.biattention(t1, t2, B, T1, T2)
-        a1, a2 = self.biOutput(bi2, t1, bi1, t2)
-        o1 = self.v_output(self.v_intermediate(a1), a1)
-        o2 = self.t_output(self.t_intermediate(a2), a2)
+        c1, c2 = ops.grad_chain(t1), ops.grad_chain(t2)          # each stream input: three projections + a residual
+        bi1, bi2 = self.biattention(t1, t2, B, T1, T2, c1, c2)
+        a1, a2 = self.biOutput(bi2, t1, bi1, t2, c1, c2)
+        ca1, ca2 = ops.grad_chain(a1), ops.grad_chain(a2)        # feed-forward input + residual
+        o1 = self.v_output(self.v_intermediate(a1, ca1), a1, ca1)
+        o2 = self.t_output(self.t_intermediate(a2, ca2), a2, ca2)
         return o1, o2
