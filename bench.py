@@ -289,14 +289,21 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     bbm.PROF = []
+    import gpv1_amd.train as trm
+    trm.HOST_PROF = {}
     t0 = time.perf_counter()
+    host_s = 0.0
     for _ in range(args.steps):
+        h0 = time.perf_counter()
         loss = step()
+        host_s += time.perf_counter() - h0              # host time inside train_step (no sync): how far the host runs ahead
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    host_prof, trm.HOST_PROF = trm.HOST_PROF, None
+    trm.HOST_PROF = host_prof if False else None
     prof_timed, bbm.PROF = bbm.PROF, None
     # Convolution time for the roofline.  In the timed region the backbone graphs also carry other kernels as parallel branches
     # (train.GraphedBody: the frozen BERT beside the forward convolutions, the model body's weight-gradient GEMMs beside the
@@ -365,7 +372,8 @@ def main():
             'mfma_tflops': flops_step / (conv_ms * 1e-3) / 1e12, 'mfma_frac_of_2500': flops_step / (conv_ms * 1e-3) / 2.5e15}
     out = {'metric': 'images/sec/node (train step, 480x640, bs32/GPU)', 'value': world * args.batch * args.steps / elapsed,
            'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-           'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+           'ms_per_step': elapsed / args.steps * 1e3, 'host_ms_per_step': host_s / args.steps * 1e3,
+           'host_phases_ms': {k: v / max(host_prof.get('steps', 1), 1) * 1e3 for k, v in host_prof.items() if k != 'steps'}, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
            'dtype': 'bf16', 'data': 'synthetic',
            'config': {'workload': 'GPV-1 (ResNet-50 + 6+6 DETR layers, 100 queries, RoI head, BERT-base, 3 co-attention, '
                                   '3 text-decoder layers, V=10000) CocoCaptioning-only train step, dropout 0.1, AdamW',

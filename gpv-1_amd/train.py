@@ -17,6 +17,7 @@ MI355X-first choices
 """
 import gc
 import os
+import time
 
 import torch
 import torch.distributed as dist
@@ -57,6 +58,10 @@ CAPTURE_MODE = os.environ.get('GPV_CAPTURE_MODE', 'thread_local')
 def ops_check_chains(clear=True):
     from . import ops
     ops.check_chains(clear)
+
+
+FLUSH_TAGS = tuple(t for t in os.environ.get('GPV_WGRAD_FLUSH', 'detr').split(',') if t)
+HOST_PROF = None          # bench.py: a dict -> host seconds per phase of the graphed step (time.perf_counter, no syncs)
 
 
 class GraphedBody:
@@ -268,7 +273,9 @@ class GraphedBody:
             # The model body's backward is a latency-bound chain of small kernels.  When it reaches the DETR stream, the weight
             # gradients collected so far (text decoder, answer head, co-attention: the big 768-wide ones) start on a side branch
             # and run beside the DETR decoder / encoder backward; those of the DETR layers follow under the backbone (B2).
-            if tag != 'detr' or not deferred or not defer:
+            # (A second boundary, 'mem' = the encoder output, can do the same for the DETR decoder's weight gradients beside the
+            #  encoder backward -- GPV_WGRAD_FLUSH=detr,mem -- measured zero-sum: B2 6.54 -> 6.24 ms, B1 4.98 -> 5.31 ms.)
+            if tag not in FLUSH_TAGS or not deferred or not defer:
                 return
             cur = torch.cuda.current_stream(dev)
             self.wside.wait_stream(cur)
@@ -487,9 +494,13 @@ class FlatTrainer:
 
     def step(self):
         """clip_grad_norm_(detr params) + AdamW + schedule (train_distr.py:423-428,468-469)"""
+        hp = HOST_PROF
+        t0 = time.perf_counter() if hp is not None else 0.0
         sched = self.lr_factor()
         use_clip = self.clip is not None and self.clip > 0
         self._publish_touched()
+        if hp is not None:
+            t1 = time.perf_counter(); hp['opt_publish'] = hp.get('opt_publish', 0.0) + t1 - t0; t0 = t1
         if use_clip:
             # ||g||^2 over the DETR groups (untouched gradients are zero: whole groups).  Every rank must get the SAME bits
             # from the same all-reduced gradient, or the replicas drift apart one ulp of the clip factor per step:
@@ -503,6 +514,8 @@ class FlatTrainer:
                     self.gsq.addcmul_(n, n)
             # scale = min(1, max_norm / (norm + 1e-6)) on device, no host sync
             torch.clamp(self.clip / (self.gsq.sqrt() + 1e-6), max=1.0, out=self.gscale)
+        if hp is not None:
+            t1 = time.perf_counter(); hp['opt_clip'] = hp.get('opt_clip', 0.0) + t1 - t0; t0 = t1
         self.step_count += 1
         t = self.step_count
         b1, b2 = self.betas
@@ -514,6 +527,8 @@ class FlatTrainer:
                       self.eps, self.wd, bc1, bc2, self.gscale if clip_here else None,
                       seg_id=self.seg_id[s // 8:e // 8], seg_live=self.pstep)
         RT.bump_weights(everything=False)
+        if hp is not None:
+            hp['opt_adamw'] = hp.get('opt_adamw', 0.0) + time.perf_counter() - t0
 
     # ---- checkpointing (train_distr.py:381-389 saves optimizer.state_dict() + the warm-up scheduler's) ----
     def _torch_param_order(self):
@@ -715,8 +730,12 @@ class FlatTrainer:
         RT.backward_boundary = None
 
     def _train_step_graphed(self, body, images, queries, tok, targets):
+        hp = HOST_PROF
+        t0 = time.perf_counter() if hp is not None else 0.0
         try:
             outs = body.forward(images, queries, tok)
+            if hp is not None:
+                t1 = time.perf_counter(); hp['replay_f1_f2'] = hp.get('replay_f1_f2', 0.0) + t1 - t0; t0 = t1
             loss = self.model.criterion(outs, targets)[0]
         except RuntimeError as err:                       # nothing collective has been entered yet: redo the step eagerly
             self._graphs_failed(err)
@@ -725,10 +744,16 @@ class FlatTrainer:
             return None
         self.zero_grad()
         self.begin_backward()
+        if hp is not None:
+            t1 = time.perf_counter(); hp['criterion_zero'] = hp.get('criterion_zero', 0.0) + t1 - t0; t0 = t1
         if loss is not None:
             try:
                 loss.backward()
+                if hp is not None:
+                    t1 = time.perf_counter(); hp['criterion_backward'] = hp.get('criterion_backward', 0.0) + t1 - t0; t0 = t1
                 body.backward(outs)
+                if hp is not None:
+                    t1 = time.perf_counter(); hp['replay_b1_b2'] = hp.get('replay_b1_b2', 0.0) + t1 - t0; t0 = t1
             except RuntimeError as err:                   # the ranks already agreed to step: redo this rank's part eagerly
                 self._graphs_failed(err)
                 torch.cuda.synchronize()
@@ -739,6 +764,9 @@ class FlatTrainer:
                     loss.backward()
         self.allreduce_grads()
         self.step()
+        if hp is not None:
+            hp['optimizer'] = hp.get('optimizer', 0.0) + time.perf_counter() - t0
+            hp['steps'] = hp.get('steps', 0) + 1
         return None if loss is None else loss.detach()
 
     def _any_rank_has_loss(self, has):

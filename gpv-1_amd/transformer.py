@@ -164,7 +164,7 @@ class Transformer(nn.Module):
         pe = pos.reshape(B * S, C)
         for layer in self.encoder.layers:
             x = layer(x, pe, B, S, kpm)
-        memory = x
+        memory = ops.boundary(x, 'mem')           # (backward: every decoder layer has run when the gradient arrives here)
         mem_chain = ops.grad_chain(memory)
         mem_pos = ops.add(memory, pe)
         qpos = query_embed.to(ops.RT.dtype).unsqueeze(0).expand(B, Q, C).reshape(B * Q, C)
