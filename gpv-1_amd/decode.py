@@ -135,7 +135,7 @@ class GreedyKVDecoder:
         if self.use_graphs:
             # Drain the stream after the 20 graph launches.  Without a STREAM synchronisation every few decodes the
             # HIP runtime (ROCm 7.2) faults with HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION once ~140 graph launches
-            # have been issued while the GPU is behind the host (B=64; tools/dbg_decode2.py reproduces it: eager
+            # have been issued while the GPU is behind the host (B=64; tools/repro_graph_launch_fault.py reproduces it: eager
             # launches never fault, event waits do not help, a stream sync every <=4 decodes does).  The sync costs
             # no GPU time: the next call's encoder is host-issued in ~20 ms either way.
             torch.cuda.current_stream().synchronize()
