@@ -351,13 +351,29 @@ template <typename T> struct Vec8IO;
 template <> struct Vec8IO<bf16> {
   static __device__ __forceinline__ void ld(const bf16* p, float* o) { Ld8<bf16>::ld(p, o); }
   static __device__ __forceinline__ void st(bf16* p, const float* o) { Ld8<bf16>::st(p, o); }
+  // non-temporal forms (streaming: do not displace what the next kernels will read from L2 / MALL)
+  static __device__ __forceinline__ void ld_nt(const bf16* p, float* o) {
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const bf16x8 v = __builtin_bit_cast(bf16x8, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p)));
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (float)v[i];
+  }
+  static __device__ __forceinline__ void st_nt(bf16* p, const float* o) {
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    bf16x8 v;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (bf16)o[i];
+    __builtin_nontemporal_store(__builtin_bit_cast(u32x4, v), reinterpret_cast<u32x4*>(p));
+  }
 };
 template <> struct Vec8IO<float> {
   static __device__ __forceinline__ void ld(const float* p, float* o) { Ld8<float>::ld(p, o); }
   static __device__ __forceinline__ void st(float* p, const float* o) { Ld8<float>::st(p, o); }
+  static __device__ __forceinline__ void ld_nt(const float* p, float* o) { Ld8<float>::ld(p, o); }
+  static __device__ __forceinline__ void st_nt(float* p, const float* o) { Ld8<float>::st(p, o); }
 };
 
-template <typename TIn, typename TOut, int AMODE, int BMODE, int BM, int BN, bool VEC>
+template <typename TIn, typename TOut, int AMODE, int BMODE, int BM, int BN, bool VEC, bool NTIO = false>
 __device__ __forceinline__ void gemm_body(const GemmK& p) {
   constexpr bool PRECISE = sizeof(TIn) == 4;
   constexpr int FM = BM / 32, FN = BN / 32;
@@ -629,7 +645,7 @@ __device__ __forceinline__ void gemm_body(const GemmK& p) {
         const bool full = n + 8 <= p.N;
         const int64_t mp = (AMODE == OP_CONV && p.cg.cm && inb) ? s_rowpix[m - row0] : m;     // output pixel of this GEMM row
         if (Rp) {
-          if (inb && v_res && full) Vec8IO<TOut>::ld(Rp + mp * p.ldr + n, rv[g]);
+          if (inb && v_res && full) { if constexpr (NTIO) Vec8IO<TOut>::ld_nt(Rp + mp * p.ldr + n, rv[g]); else Vec8IO<TOut>::ld(Rp + mp * p.ldr + n, rv[g]); }
           else {
 #pragma unroll
             for (int e = 0; e < 8; ++e) rv[g][e] = (inb && n + e < p.N) ? (float)Rp[mp * p.ldr + n + e] : 0.f;
@@ -672,7 +688,7 @@ __device__ __forceinline__ void gemm_body(const GemmK& p) {
         }
         const int64_t mp = (AMODE == OP_CONV && p.cg.cm && m < p.M) ? s_rowpix[m - row0] : m;
         TOut* dst = Cp + mp * ldc + n;
-        if (v_st && full) Vec8IO<TOut>::st(dst, v);
+        if (v_st && full) { if constexpr (NTIO) Vec8IO<TOut>::st_nt(dst, v); else Vec8IO<TOut>::st(dst, v); }   // (a run-time choice: the two stores are merged and lose the hint)
         else {
 #pragma unroll
           for (int e = 0; e < 8; ++e)
@@ -694,6 +710,11 @@ template <typename TIn, typename TOut, int BM, int BN, bool VEC>
 __global__ __launch_bounds__(256) void conv1x1_kernel(GemmK p) {
   if (p.dthresh) p.seed = eff_seed(p.seed, p.seed_dev);
   gemm_body<TIn, TOut, OP_PLAIN, OP_PLAIN, BM, BN, VEC>(p);
+}
+// ... with non-temporal epilogue stores / residual loads (GemmK::nt_io: outputs far larger than the MALL)
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void conv1x1_nt_kernel(GemmK p) {
+  gemm_body<bf16, bf16, OP_PLAIN, OP_PLAIN, BM, BN, true, true>(p);
 }
 
 // C[m, n] += sum_s ws[s][m][n]   (second pass of a workspace split reduction).  A group of G threads shares one run
@@ -785,6 +806,9 @@ int launch_cfg_v(const GemmK& k, int batch, hipStream_t st) {
   auto fn = gemm_kernel<TIn, TOut, AMODE, BMODE, BM, BN, VEC>;
   if constexpr (AMODE == OP_PLAIN && BMODE == OP_PLAIN) {
     if (k.conv1x1) fn = conv1x1_kernel<TIn, TOut, BM, BN, VEC>;
+    if constexpr (std::is_same<TIn, bf16>::value && std::is_same<TOut, bf16>::value && VEC) {
+      if (k.conv1x1 && k.nt_io && !p.dthresh && !two_pass) fn = conv1x1_nt_kernel<BM, BN>;
+    }
   }
   static bool attr_done[2] = {false, false};
   if (lds > 64 * 1024 && !attr_done[k.conv1x1 ? 1 : 0]) {
@@ -947,6 +971,13 @@ extern "C" int gpv_conv2d(const gpv_conv_args* a, void* stream) {
       k.lda = a->Cs;
       k.cg = ConvGeom{};
       k.conv1x1 = 1;
+      {
+        // outputs far beyond the 256 MB MALL (layer1's 314 MB maps) are stored -- and their residual read -- non-temporally:
+        // 64 -> 256 without a residual 150 -> 106 us, with one 177 -> 168 us; smaller outputs are better left cacheable for
+        // the next convolution (layer3 conv3, 79 MB: 58 -> 72 us with non-temporal stores)   [tools/bench_c1.py]
+        static const int64_t nt_min = [] { const char* e = getenv("GPV_NT_MIN_MB"); return (int64_t)(e ? atoi(e) : 200) << 20; }();
+        k.nt_io = (int64_t)k.M * k.N * esz >= nt_min ? 1 : 0;
+      }
       k.vecA = aligned16(a->x) && (a->Cs % vecel == 0) && (int64_t)k.M * a->Cs * esz < 0x7ffffff0ll ? 1 : 0;
       const int pp = pipe_try_launch(k, OP_PLAIN, a->dtype_in, a->dtype_out, 1, st);
       if (pp >= 0) return pp;
