@@ -1,0 +1,207 @@
+// Streaming 1x1 convolution (gfx950): the K <= 256 pointwise convolutions of ResNet layer1 / layer2 over 10^5 .. 6 10^5 pixels,
+// forward and backward-data (exp/gpv/models/backbone.py:93-95 -> torchvision Bottleneck conv1 / conv3 / downsample).
+//
+//   C[px, n] = epilogue( sum_k A[px, k] W[n, k] ),   bf16, K in {64, 128, 256}, N in {64, 128, 256, 512},
+//   epilogue = + bias[n] -> + res[px, n] -> ReLU -> * (mask[px, n] > 0)
+//
+// These launches move 0.7 .. 1.2 KB per pixel for 2 K N flops: they are HBM-streaming, and the tile kernels (conv1x1_kernel,
+// 64x64 tiles) reach 3.2-4.3 TB/s of the 5.3-6.2 TB/s an element-wise kernel gets on the same tensors, because a tile block has
+// loads in flight for only a third of its life (load -> barrier -> MFMA -> barrier -> LDS round trip -> residual load -> store).
+// Here nothing waits on a barrier after the prologue:
+//   * the whole weight matrix sits in LDS (<= 139 KB), staged once per block;
+//   * a WAVE owns 16 pixels at a time: its A fragments come straight from global (16 B per lane, next tile fetched a tile
+//     ahead), the W fragments from LDS, the accumulators for up to 256 output channels stay in registers;
+//   * the output channels are PERMUTED when W is staged so that the two MFMA tiles 2t, 2t+1 leave lane (pixel, g) with the 8
+//     consecutive channels 32 t + 8 g .. + 7: residual, mask and output are then plain 16-byte accesses in the accumulator
+//     layout -- no LDS round trip for the epilogue, four lanes cover a 64-byte run of a pixel's row;
+//   * waves are independent, 8-16 per CU, each with its A prefetch and 8 residual loads in flight.
+#include "gemm_common.h"
+
+namespace gpvk {
+namespace {
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 mfma16s(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+
+// LDS row L of the staged weight matrix holds output channel chan(L): pass h = L / NH (NH channels per register pass), MFMA
+// tile j = (L % NH) / 16, row r = L % 16 -> channel h NH + 32 (j / 2) + 8 (r / 4) + 4 (j & 1) + (r % 4)
+template <int NH>
+__device__ __forceinline__ int c1s_chan(int L) {
+  const int h = L / NH, w = L - h * NH, j = w >> 4, r = w & 15;
+  return h * NH + (j >> 1) * 32 + (r >> 2) * 8 + (j & 1) * 4 + (r & 3);
+}
+
+template <int K, int NH, bool RES, bool MASK, bool NT>
+__global__ __launch_bounds__(512) void c1s_kernel(GemmK p) {
+  constexpr int KP = K + 8, KC = K / 32, NTL = NH / 16, NG = NH / 32, SL = K / 8;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  bf16* Wl = reinterpret_cast<bf16*>(smem_raw);
+  float* bias_l = reinterpret_cast<float*>(Wl + (size_t)p.N * KP);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, pl = lane & 15;
+  const bf16* A = reinterpret_cast<const bf16*>(p.A);
+  const bf16* Wg = reinterpret_cast<const bf16*>(p.B);
+  bf16* C = reinterpret_cast<bf16*>(p.C);
+  const bf16* R = reinterpret_cast<const bf16*>(p.res);
+  const bf16* Mk = reinterpret_cast<const bf16*>(p.mask);
+  const int npass = p.N / NH;
+  const int ntile = (p.M + 15) >> 4;
+  const int nw = (int)gridDim.x * 8;
+  int tile = (int)blockIdx.x * 8 + wave;
+
+  // this wave's first A fragments are requested before the weights are staged
+  bf16x8 an[KC];
+  auto fetch = [&](int t) {
+    const int px = t * 16 + pl;
+    const bool ok = t < ntile && px < p.M;
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) {
+      if (ok) an[kc] = *reinterpret_cast<const bf16x8*>(A + (int64_t)px * p.lda + kc * 32 + g * 8);
+      else an[kc] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
+  };
+  fetch(tile);
+  for (int idx = tid; idx < p.N * SL; idx += 512) {
+    const int L = idx / SL, sl = idx - L * SL;
+    const int c = c1s_chan<NH>(L);
+    *reinterpret_cast<bf16x8*>(Wl + L * KP + sl * 8) = *reinterpret_cast<const bf16x8*>(Wg + (int64_t)c * p.ldb + sl * 8);
+  }
+  for (int c = tid; c < p.N; c += 512) bias_l[c] = p.bias ? p.bias[c] : 0.f;
+  __syncthreads();
+
+  for (; tile < ntile; tile += nw) {
+    bf16x8 af[KC];
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) af[kc] = an[kc];
+    fetch(tile + nw);
+    const int px = tile * 16 + pl;
+    const bool pok = px < p.M;
+    for (int h = 0; h < npass; ++h) {
+      // epilogue operands of this pass: requested before the MFMAs, consumed after them
+      bf16x8 rv[RES ? NG : 1], mv[MASK ? NG : 1];
+      if constexpr (RES) {
+#pragma unroll
+        for (int t = 0; t < NG; ++t) {
+          const bf16* q = R + (int64_t)px * p.ldr + h * NH + t * 32 + g * 8;
+          if (pok) rv[t] = NT ? __builtin_bit_cast(bf16x8, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(q)))
+                              : *reinterpret_cast<const bf16x8*>(q);
+          else rv[t] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+      }
+      if constexpr (MASK) {
+#pragma unroll
+        for (int t = 0; t < NG; ++t) {
+          if (pok) mv[t] = *reinterpret_cast<const bf16x8*>(Mk + (int64_t)px * p.ldm + h * NH + t * 32 + g * 8);
+          else mv[t] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+      }
+      f32x4 acc[NTL];
+#pragma unroll
+      for (int j = 0; j < NTL; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const bf16* wrow = Wl + (h * NH + pl) * KP + g * 8;
+#pragma unroll
+      for (int kc = 0; kc < KC; ++kc) {
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) {
+          const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wrow + j * 16 * KP + kc * 32);
+          acc[j] = mfma16s(wf, af[kc], acc[j]);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < NG; ++t) {
+        const int c0 = h * NH + t * 32 + g * 8;
+        const float4 b0 = *reinterpret_cast<const float4*>(bias_l + c0), b1 = *reinterpret_cast<const float4*>(bias_l + c0 + 4);
+        float v[8] = {acc[2 * t][0] + b0.x, acc[2 * t][1] + b0.y, acc[2 * t][2] + b0.z, acc[2 * t][3] + b0.w,
+                      acc[2 * t + 1][0] + b1.x, acc[2 * t + 1][1] + b1.y, acc[2 * t + 1][2] + b1.z, acc[2 * t + 1][3] + b1.w};
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float x = v[e];
+          if constexpr (RES) x += (float)rv[t][e];
+          if (p.act == GPV_ACT_RELU) x = fmaxf(x, 0.f);
+          if constexpr (MASK) x = (float)mv[t][e] > 0.f ? x : 0.f;
+          o[e] = (bf16)x;
+        }
+        if (pok) {
+          bf16* q = C + (int64_t)px * p.ldc + c0;
+          if constexpr (NT) __builtin_nontemporal_store(__builtin_bit_cast(u32x4, o), reinterpret_cast<u32x4*>(q));
+          else *reinterpret_cast<bf16x8*>(q) = o;
+        }
+      }
+    }
+  }
+}
+
+template <int K, int NH, bool RES, bool MASK, bool NT>
+int c1s_launch(const GemmK& k, hipStream_t st) {
+  constexpr int KP = K + 8;
+  const size_t lds = (size_t)k.N * KP * 2 + (size_t)k.N * sizeof(float);
+  auto fn = c1s_kernel<K, NH, RES, MASK, NT>;
+  static size_t attr = 0;
+  if (lds > 64 * 1024 && lds > attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    attr = lds;
+  }
+  // persistent waves: two blocks of 8 waves per CU when the weights leave room for them, one otherwise
+  const int ntile = (k.M + 15) / 16;
+  static const int bpc = [] { const char* e = getenv("GPV_C1S_BLOCKS"); return e ? atoi(e) : 0; }();
+  int blocks = bpc > 0 ? bpc : (lds <= 72 * 1024 ? 512 : 256);
+  if (blocks * 8 > ntile) blocks = (ntile + 7) / 8;
+  hipLaunchKernelGGL(fn, dim3(blocks), dim3(512), lds, st, k);
+  GPV_CHECK_LAUNCH();
+  return 0;
+}
+
+template <int K, int NH>
+int c1s_flags(const GemmK& k, hipStream_t st) {
+  const bool r = k.res != nullptr, m = k.mask != nullptr, nt = k.nt_io != 0;
+  if (nt) {      // (non-temporal: the layer1 forwards -- never with a mask)
+    if (m) return -1;
+    return r ? c1s_launch<K, NH, true, false, true>(k, st) : c1s_launch<K, NH, false, false, true>(k, st);
+  }
+  if (r && m) return c1s_launch<K, NH, true, true, false>(k, st);
+  if (r) return c1s_launch<K, NH, true, false, false>(k, st);
+  if (m) return c1s_launch<K, NH, false, true, false>(k, st);
+  return c1s_launch<K, NH, false, false, false>(k, st);
+}
+
+template <int K>
+int c1s_n(const GemmK& k, hipStream_t st) {
+  switch (k.N) {
+    case 64: return c1s_flags<K, 64>(k, st);
+    case 128: return c1s_flags<K, 128>(k, st);
+    case 256: return c1s_flags<K, 256>(k, st);
+    case 512: return c1s_flags<K, 256>(k, st);
+  }
+  return -1;
+}
+
+inline bool al16s(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
+
+}  // namespace
+
+int g_c1s_mode = 1;          // 0 never, 1 heuristic, 2 wherever legal (tests)
+
+// 0 = launched, -1 = not applicable, > 0 = hipError_t
+int c1s_try_launch(const GemmK& k, int dtype_in, int dtype_out, hipStream_t st) {
+  static const int env = [] { const char* e = getenv("GPV_C1S"); return e ? atoi(e) : -1; }();
+  const int mode = env >= 0 ? env : g_c1s_mode;
+  if (mode == 0 || dtype_in != GPV_BF16 || dtype_out != GPV_BF16) return -1;
+  if (k.K != 64 && k.K != 128 && k.K != 256) return -1;
+  if (k.N != 64 && k.N != 128 && k.N != 256 && k.N != 512) return -1;
+  if ((size_t)k.N * (k.K + 8) * 2 + (size_t)k.N * 4 > 150 * 1024) return -1;
+  if (k.alpha != 1.0f || k.rowscale || k.dthresh || k.accumulate || k.split_k > 1 || k.a_rowsum) return -1;
+  if (k.act != GPV_ACT_NONE && k.act != GPV_ACT_RELU) return -1;
+  if (k.lda % 8 || k.ldb != k.K || k.ldc % 8 || (k.res && k.ldr % 8) || (k.mask && k.ldm % 8)) return -1;
+  if (!al16s(k.A) || !al16s(k.B) || !al16s(k.C) || (k.res && !al16s(k.res)) || (k.mask && !al16s(k.mask))) return -1;
+  if (mode == 1 && k.M < 65536) return -1;           // a streaming regime needs rows: the layer1 / layer2 maps at training batch sizes
+  switch (k.K) {
+    case 64: return c1s_n<64>(k, st);
+    case 128: return c1s_n<128>(k, st);
+    case 256: return c1s_n<256>(k, st);
+  }
+  return -1;
+}
+
+}  // namespace gpvk

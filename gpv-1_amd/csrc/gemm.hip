@@ -979,6 +979,10 @@ extern "C" int gpv_conv2d(const gpv_conv_args* a, void* stream) {
         k.nt_io = (int64_t)k.M * k.N * esz >= nt_min ? 1 : 0;
       }
       k.vecA = aligned16(a->x) && (a->Cs % vecel == 0) && (int64_t)k.M * a->Cs * esz < 0x7ffffff0ll ? 1 : 0;
+      if (k.vecA) {
+        const int cs = c1s_try_launch(k, a->dtype_in, a->dtype_out, st);
+        if (cs >= 0) return cs;
+      }
       const int pp = pipe_try_launch(k, OP_PLAIN, a->dtype_in, a->dtype_out, 1, st);
       if (pp >= 0) return pp;
       const int g = glds_try_launch(k, OP_PLAIN, a->dtype_in, a->dtype_out, 1, st);

@@ -54,6 +54,11 @@ int pipe_try_launch(const GemmK& k, int amode, int dtype_in, int dtype_out, int 
 int pipe_set_mode(int v);
 long pipe_launches(long set);
 
+// conv1x1_stream.hip: streaming kernel for the K <= 256 pointwise convolutions over >= 65536 pixels (weights resident in LDS,
+// a wave per 16 pixels, register epilogue in a permuted channel order).  Same return convention; tried first on the 1x1 path.
+int c1s_try_launch(const GemmK& k, int dtype_in, int dtype_out, hipStream_t st);
+extern int g_c1s_mode;
+
 // gemm_skinny.hip: 64x64 tiles with the reduction split across the block's four waves, for GEMMs whose tiles cannot
 // fill the chip (M = 192..640 rows).  Same return convention.
 int skinny_try_launch(const GemmK& k, int b_trans, int dtype_in, int dtype_out, int batch, hipStream_t st);

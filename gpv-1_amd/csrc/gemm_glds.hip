@@ -408,6 +408,11 @@ extern "C" int gpv_set_option(int option, int value) {
     gpvk::g_wgrad_mode = value;
     return prev;
   }
+  if (option == GPV_OPT_C1S) {
+    const int prev = gpvk::g_c1s_mode;
+    gpvk::g_c1s_mode = value;
+    return prev;
+  }
   if (option == GPV_OPT_PIPE) return gpvk::pipe_set_mode(value);
   if (option == GPV_OPT_PIPE_LAUNCHES) return (int)gpvk::pipe_launches(value);
   if (option == GPV_OPT_GLDS_LAUNCHES) {

@@ -62,6 +62,7 @@ int gpv_gemm_tt_group(const gpv_tt_problem* problems, int n, void* stream);
 #define GPV_OPT_GLDS_LAUNCHES 1 /* returns the number of direct-to-LDS GEMM/conv launches so far, then sets the counter to value */
 #define GPV_OPT_GLDS_WGRAD 3 /* direct-to-LDS weight-gradient kernel: 0 never, 1 (default) conv wherever legal + linear where it wins, 2 both wherever legal */
 #define GPV_OPT_PIPE 4 /* three-stage pipelined direct-to-LDS GEMM/conv kernel (gemm_pipe.hip): 0 never, 1 (default) heuristic, 100 + i = tile configuration i wherever legal */
+#define GPV_OPT_C1S 6 /* streaming kernel for the K <= 256 1x1 convolutions (conv1x1_stream.hip): 0 never, 1 (default) >= 65536 pixel rows, 2 wherever legal */
 #define GPV_OPT_PIPE_LAUNCHES 5 /* returns the number of pipelined-kernel launches so far, then sets the counter to value */
 int gpv_set_option(int option, int value);
 

@@ -767,3 +767,39 @@ def test_cast_transpose_group_and_mirrored_dx_gemm():
     ref = dy.float() @ wb.float()
     assert float((a.float() - ref).abs().max()) < 0.02 * float(ref.abs().max())
     assert float((b.float() - ref).abs().max()) < 0.02 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize('Cin,Cout,H,W,Bn,with_res,with_mask,relu', [
+    (64, 256, 30, 40, 2, True, False, True), (64, 256, 30, 40, 2, False, False, True), (64, 64, 17, 23, 3, False, False, True),
+    (256, 64, 30, 40, 2, False, True, False), (128, 512, 15, 20, 2, True, False, True), (128, 512, 15, 20, 2, True, True, False),
+    (256, 128, 21, 19, 1, False, False, True), (256, 256, 9, 11, 5, True, True, True), (128, 128, 7, 5, 1, False, True, False)])
+def test_streaming_1x1_conv_kernel_forced(Cin, Cout, H, W, Bn, with_res, with_mask, relu):
+    """conv1x1_stream.hip forced on (by default it takes >= 65536 pixel rows): weights resident in LDS, permuted output channels,
+    register epilogue -- against fp32 math and bit-for-bit against the tile kernel; ragged pixel counts (M % 16 != 0)"""
+    h = hip()
+    torch.manual_seed(Cin + Cout + H)
+    M = Bn * H * W
+    x = torch.randn(M, Cin, device=DEV).to(torch.bfloat16)
+    w = (torch.randn(Cout, 1, Cin, device=DEV) / Cin ** 0.5).to(torch.bfloat16)
+    bias = torch.randn(Cout, device=DEV)
+    res = torch.randn(M, Cout, device=DEV).to(torch.bfloat16) if with_res else None
+    msk = torch.randn(M, Cout, device=DEV).to(torch.bfloat16) if with_mask else None
+    outs = []
+    for mode in (0, 2):
+        prev = h.set_option(h.OPT_C1S, mode)
+        try:
+            y = torch.full((M + 3, Cout), 5.0, device=DEV, dtype=torch.bfloat16)         # 3 guard rows: nothing may be written past M
+            h.conv2d(0, x, w, y, Bn, H, W, Cin, Cin, H, W, Cout, 1, 1, 1, 1, 0, 0, bias=bias, res=res, relu_mask=msk, act=1 if relu else 0)
+        finally:
+            h.set_option(h.OPT_C1S, prev)
+        assert bool((y[M:] == 5.0).all())
+        outs.append(y[:M].float())
+    ref = x.float() @ w.reshape(Cout, Cin).float().t() + bias
+    if with_res:
+        ref = ref + res.float()
+    if relu:
+        ref = ref.clamp_min(0)
+    if with_mask:
+        ref = ref * (msk.float() > 0)
+    assert rel(outs[1], ref) < TOL[torch.bfloat16]
+    assert torch.equal(outs[0], outs[1])                       # same products, same fp32 accumulation order per output: identical bits
