@@ -1,7 +1,7 @@
-// Streaming 1x1 convolution (gfx950): the K <= 256 pointwise convolutions of ResNet layer1 / layer2 over 10^5 .. 6 10^5 pixels,
+// Streaming 1x1 convolution (gfx950): the K <= 512 pointwise convolutions of ResNet layer1 / layer2 over 10^5 .. 6 10^5 pixels,
 // forward and backward-data (exp/gpv/models/backbone.py:93-95 -> torchvision Bottleneck conv1 / conv3 / downsample).
 //
-//   C[px, n] = epilogue( sum_k A[px, k] W[n, k] ),   bf16, K in {64, 128, 256}, N in {64, 128, 256, 512},
+//   C[px, n] = epilogue( sum_k A[px, k] W[n, k] ),   bf16, K in {64, 128, 256, 512}, N in {64, 128, 256, 512}, N (K + 8) <= 75 K,
 //   epilogue = + bias[n] -> + res[px, n] -> ReLU -> * (mask[px, n] > 0)
 //
 // These launches move 0.7 .. 1.2 KB per pixel for 2 K N flops: they are HBM-streaming, and the tile kernels (conv1x1_kernel,
@@ -171,8 +171,8 @@ int c1s_n(const GemmK& k, hipStream_t st) {
   switch (k.N) {
     case 64: return c1s_flags<K, 64>(k, st);
     case 128: return c1s_flags<K, 128>(k, st);
-    case 256: return c1s_flags<K, 256>(k, st);
-    case 512: return c1s_flags<K, 256>(k, st);
+    case 256: if constexpr (K <= 256) return c1s_flags<K, 256>(k, st); else return -1;
+    case 512: if constexpr (K <= 256) return c1s_flags<K, 256>(k, st); else return -1;
   }
   return -1;
 }
@@ -188,7 +188,7 @@ int c1s_try_launch(const GemmK& k, int dtype_in, int dtype_out, hipStream_t st) 
   static const int env = [] { const char* e = getenv("GPV_C1S"); return e ? atoi(e) : -1; }();
   const int mode = env >= 0 ? env : g_c1s_mode;
   if (mode == 0 || dtype_in != GPV_BF16 || dtype_out != GPV_BF16) return -1;
-  if (k.K != 64 && k.K != 128 && k.K != 256) return -1;
+  if (k.K != 64 && k.K != 128 && k.K != 256 && k.K != 512) return -1;
   if (k.N != 64 && k.N != 128 && k.N != 256 && k.N != 512) return -1;
   if ((size_t)k.N * (k.K + 8) * 2 + (size_t)k.N * 4 > 150 * 1024) return -1;
   if (k.alpha != 1.0f || k.rowscale || k.dthresh || k.accumulate || k.split_k > 1 || k.a_rowsum) return -1;
@@ -200,6 +200,7 @@ int c1s_try_launch(const GemmK& k, int dtype_in, int dtype_out, hipStream_t st) 
     case 64: return c1s_n<64>(k, st);
     case 128: return c1s_n<128>(k, st);
     case 256: return c1s_n<256>(k, st);
+    case 512: return c1s_n<512>(k, st);           // (N <= 128: the weights must fit the LDS)
   }
   return -1;
 }
