@@ -33,17 +33,22 @@ __device__ __forceinline__ int c1s_chan(int L) {
 }
 
 template <int K, int NH, bool RES, bool MASK, bool NT>
-__global__ __launch_bounds__(512) void c1s_kernel(GemmK p) {
+__global__ __launch_bounds__(512) void c1s_kernel(GemmK p, int ncols) {
+  // ncols: output channels per block row (gridDim.y slices of a wide layer: layer3's 1024 channels as four 256-channel
+  // problems that share A -- the weights of one slice fit the LDS, A is small next to the output)
   constexpr int KP = K + 8, KC = K / 32, NTL = NH / 16, NG = NH / 32, SL = K / 8;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   bf16* Wl = reinterpret_cast<bf16*>(smem_raw);
-  float* bias_l = reinterpret_cast<float*>(Wl + (size_t)p.N * KP);
+  float* bias_l = reinterpret_cast<float*>(Wl + (size_t)ncols * KP);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, pl = lane & 15;
+  const int cbase = (int)blockIdx.y * ncols;
   const bf16* A = reinterpret_cast<const bf16*>(p.A);
-  const bf16* Wg = reinterpret_cast<const bf16*>(p.B);
-  bf16* C = reinterpret_cast<bf16*>(p.C);
-  const bf16* R = reinterpret_cast<const bf16*>(p.res);
-  const bf16* Mk = reinterpret_cast<const bf16*>(p.mask);
+  const bf16* Wg = reinterpret_cast<const bf16*>(p.B) + (int64_t)cbase * p.ldb;
+  bf16* C = reinterpret_cast<bf16*>(p.C) + cbase;
+  const bf16* R = reinterpret_cast<const bf16*>(p.res) + cbase;
+  const bf16* Mk = reinterpret_cast<const bf16*>(p.mask) + cbase;
+  const float* bias_g = p.bias ? p.bias + cbase : nullptr;
+  p.N = ncols;
   const int npass = p.N / NH;
   const int ntile = (p.M + 15) >> 4;
   const int nw = (int)gridDim.x * 8;
@@ -66,7 +71,7 @@ __global__ __launch_bounds__(512) void c1s_kernel(GemmK p) {
     const int c = c1s_chan<NH>(L);
     *reinterpret_cast<bf16x8*>(Wl + L * KP + sl * 8) = *reinterpret_cast<const bf16x8*>(Wg + (int64_t)c * p.ldb + sl * 8);
   }
-  for (int c = tid; c < p.N; c += 512) bias_l[c] = p.bias ? p.bias[c] : 0.f;
+  for (int c = tid; c < p.N; c += 512) bias_l[c] = bias_g ? bias_g[c] : 0.f;
   __syncthreads();
 
   for (; tile < ntile; tile += nw) {
@@ -135,7 +140,8 @@ __global__ __launch_bounds__(512) void c1s_kernel(GemmK p) {
 template <int K, int NH, bool RES, bool MASK, bool NT>
 int c1s_launch(const GemmK& k, hipStream_t st) {
   constexpr int KP = K + 8;
-  const size_t lds = (size_t)k.N * KP * 2 + (size_t)k.N * sizeof(float);
+  const int ncols = k.N > 512 ? 256 : k.N, nsl = k.N / ncols;
+  const size_t lds = (size_t)ncols * KP * 2 + (size_t)ncols * sizeof(float);
   auto fn = c1s_kernel<K, NH, RES, MASK, NT>;
   static size_t attr = 0;
   if (lds > 64 * 1024 && lds > attr) {
@@ -147,8 +153,9 @@ int c1s_launch(const GemmK& k, hipStream_t st) {
   const int ntile = (k.M + 15) / 16;
   static const int bpc = [] { const char* e = getenv("GPV_C1S_BLOCKS"); return e ? atoi(e) : 0; }();
   int blocks = bpc > 0 ? bpc : (lds <= 72 * 1024 ? 512 : 256);
+  blocks = (blocks + nsl - 1) / nsl;
   if (blocks * 8 > ntile) blocks = (ntile + 7) / 8;
-  hipLaunchKernelGGL(fn, dim3(blocks), dim3(512), lds, st, k);
+  hipLaunchKernelGGL(fn, dim3(blocks, nsl), dim3(512), lds, st, k, ncols);
   GPV_CHECK_LAUNCH();
   return 0;
 }
@@ -172,7 +179,7 @@ int c1s_n(const GemmK& k, hipStream_t st) {
     case 64: return c1s_flags<K, 64>(k, st);
     case 128: return c1s_flags<K, 128>(k, st);
     case 256: if constexpr (K <= 256) return c1s_flags<K, 256>(k, st); else return -1;
-    case 512: if constexpr (K <= 256) return c1s_flags<K, 256>(k, st); else return -1;
+    case 512: case 1024: case 2048: if constexpr (K <= 256) return c1s_flags<K, 256>(k, st); else return -1;
   }
   return -1;
 }
@@ -189,13 +196,16 @@ int c1s_try_launch(const GemmK& k, int dtype_in, int dtype_out, hipStream_t st) 
   const int mode = env >= 0 ? env : g_c1s_mode;
   if (mode == 0 || dtype_in != GPV_BF16 || dtype_out != GPV_BF16) return -1;
   if (k.K != 64 && k.K != 128 && k.K != 256 && k.K != 512) return -1;
-  if (k.N != 64 && k.N != 128 && k.N != 256 && k.N != 512) return -1;
-  if ((size_t)k.N * (k.K + 8) * 2 + (size_t)k.N * 4 > 150 * 1024) return -1;
+  if (k.N != 64 && k.N != 128 && k.N != 256 && k.N != 512 && k.N != 1024 && k.N != 2048) return -1;
+  {
+    const int ncols = k.N > 512 ? 256 : k.N;          // (wider layers: 256-channel slices on gridDim.y)
+    if ((size_t)ncols * (k.K + 8) * 2 + (size_t)ncols * 4 > 150 * 1024) return -1;
+  }
   if (k.alpha != 1.0f || k.rowscale || k.dthresh || k.accumulate || k.split_k > 1 || k.a_rowsum) return -1;
   if (k.act != GPV_ACT_NONE && k.act != GPV_ACT_RELU) return -1;
   if (k.lda % 8 || k.ldb != k.K || k.ldc % 8 || (k.res && k.ldr % 8) || (k.mask && k.ldm % 8)) return -1;
   if (!al16s(k.A) || !al16s(k.B) || !al16s(k.C) || (k.res && !al16s(k.res)) || (k.mask && !al16s(k.mask))) return -1;
-  if (mode == 1 && k.M < 65536) return -1;           // a streaming regime needs rows: the layer1 / layer2 maps at training batch sizes
+  if (mode == 1 && (int64_t)k.M * (k.N > 512 ? k.N / 256 : 1) < 65536) return -1;   // a streaming regime needs rows (x slices): the layer1-3 maps at training batch sizes
   switch (k.K) {
     case 64: return c1s_n<64>(k, st);
     case 128: return c1s_n<128>(k, st);

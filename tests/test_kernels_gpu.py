@@ -773,7 +773,8 @@ def test_cast_transpose_group_and_mirrored_dx_gemm():
     (64, 256, 30, 40, 2, True, False, True), (64, 256, 30, 40, 2, False, False, True), (64, 64, 17, 23, 3, False, False, True),
     (256, 64, 30, 40, 2, False, True, False), (128, 512, 15, 20, 2, True, False, True), (128, 512, 15, 20, 2, True, True, False),
     (256, 128, 21, 19, 1, False, False, True), (256, 256, 9, 11, 5, True, True, True), (128, 128, 7, 5, 1, False, True, False),
-    (512, 128, 15, 20, 2, False, False, True), (512, 128, 15, 20, 2, True, True, False), (512, 64, 9, 7, 3, False, True, False)])
+    (512, 128, 15, 20, 2, False, False, True), (512, 128, 15, 20, 2, True, True, False), (512, 64, 9, 7, 3, False, True, False),
+    (256, 1024, 15, 20, 2, True, False, True), (256, 1024, 9, 7, 1, True, True, False), (128, 2048, 5, 6, 1, False, False, True)])
 def test_streaming_1x1_conv_kernel_forced(Cin, Cout, H, W, Bn, with_res, with_mask, relu):
     """conv1x1_stream.hip forced on (by default it takes >= 65536 pixel rows): weights resident in LDS, permuted output channels,
     register epilogue -- against fp32 math and bit-for-bit against the tile kernel; ragged pixel counts (M % 16 != 0)"""
