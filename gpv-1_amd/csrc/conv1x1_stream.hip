@@ -56,12 +56,19 @@ __global__ __launch_bounds__(512) void c1s_kernel(GemmK p, int ncols) {
 
   // this wave's first A fragments are requested before the weights are staged
   bf16x8 an[KC];
+  // stride 2 (the downsample projections, forward): output pixel (b, oh, ow) reads input pixel (b, 2 oh, 2 ow)
+  const int ow_ = p.cg.OW, ohw = p.cg.OH * p.cg.OW, ihw = p.cg.IH * p.cg.IW, iw_ = p.cg.IW, sxy = p.cg.SH;
   auto fetch = [&](int t) {
     const int px = t * 16 + pl;
     const bool ok = t < ntile && px < p.M;
+    int64_t ipx = px;
+    if (sxy == 2) {
+      const int b = px / ohw, r = px - b * ohw, oh = r / ow_, ow = r - oh * ow_;
+      ipx = (int64_t)b * ihw + (int64_t)(2 * oh) * iw_ + 2 * ow;
+    }
 #pragma unroll
     for (int kc = 0; kc < KC; ++kc) {
-      if (ok) an[kc] = *reinterpret_cast<const bf16x8*>(A + (int64_t)px * p.lda + kc * 32 + g * 8);
+      if (ok) an[kc] = *reinterpret_cast<const bf16x8*>(A + ipx * p.lda + kc * 32 + g * 8);
       else an[kc] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
     }
   };
@@ -137,10 +144,16 @@ __global__ __launch_bounds__(512) void c1s_kernel(GemmK p, int ncols) {
   }
 }
 
+// output channels per block: the whole layer when its weights fit the LDS (K <= 128: up to 512 channels), else slices on gridDim.y
+inline int c1s_cols(int K, int N) {
+  const int cap = K <= 128 ? 512 : (K == 256 ? 256 : 128);
+  return N < cap ? N : cap;
+}
+
 template <int K, int NH, bool RES, bool MASK, bool NT>
 int c1s_launch(const GemmK& k, hipStream_t st) {
   constexpr int KP = K + 8;
-  const int ncols = k.N > 512 ? 256 : k.N, nsl = k.N / ncols;
+  const int ncols = c1s_cols(k.K, k.N), nsl = k.N / ncols;
   const size_t lds = (size_t)ncols * KP * 2 + (size_t)ncols * sizeof(float);
   auto fn = c1s_kernel<K, NH, RES, MASK, NT>;
   static size_t attr = 0;
@@ -175,11 +188,10 @@ int c1s_flags(const GemmK& k, hipStream_t st) {
 
 template <int K>
 int c1s_n(const GemmK& k, hipStream_t st) {
-  switch (k.N) {
+  switch (c1s_cols(K, k.N)) {          // channels per block -> channels per register pass
     case 64: return c1s_flags<K, 64>(k, st);
     case 128: return c1s_flags<K, 128>(k, st);
-    case 256: if constexpr (K <= 256) return c1s_flags<K, 256>(k, st); else return -1;
-    case 512: case 1024: case 2048: if constexpr (K <= 256) return c1s_flags<K, 256>(k, st); else return -1;
+    case 256: case 512: if constexpr (K <= 256) return c1s_flags<K, 256>(k, st); else return -1;
   }
   return -1;
 }
@@ -197,15 +209,13 @@ int c1s_try_launch(const GemmK& k, int dtype_in, int dtype_out, hipStream_t st) 
   if (mode == 0 || dtype_in != GPV_BF16 || dtype_out != GPV_BF16) return -1;
   if (k.K != 64 && k.K != 128 && k.K != 256 && k.K != 512) return -1;
   if (k.N != 64 && k.N != 128 && k.N != 256 && k.N != 512 && k.N != 1024 && k.N != 2048) return -1;
-  {
-    const int ncols = k.N > 512 ? 256 : k.N;          // (wider layers: 256-channel slices on gridDim.y)
-    if ((size_t)ncols * (k.K + 8) * 2 + (size_t)ncols * 4 > 150 * 1024) return -1;
-  }
+  const int ncols = c1s_cols(k.K, k.N), nsl = k.N / ncols;
+  if ((size_t)ncols * (k.K + 8) * 2 + (size_t)ncols * 4 > 150 * 1024 || nsl > 8) return -1;
   if (k.alpha != 1.0f || k.rowscale || k.dthresh || k.accumulate || k.split_k > 1 || k.a_rowsum) return -1;
   if (k.act != GPV_ACT_NONE && k.act != GPV_ACT_RELU) return -1;
   if (k.lda % 8 || k.ldb != k.K || k.ldc % 8 || (k.res && k.ldr % 8) || (k.mask && k.ldm % 8)) return -1;
   if (!al16s(k.A) || !al16s(k.B) || !al16s(k.C) || (k.res && !al16s(k.res)) || (k.mask && !al16s(k.mask))) return -1;
-  if (mode == 1 && (int64_t)k.M * (k.N > 512 ? k.N / 256 : 1) < 65536) return -1;   // a streaming regime needs rows (x slices): the layer1-3 maps at training batch sizes
+  if (mode == 1 && ((int64_t)k.M * nsl < 65536 || k.M < 32768)) return -1;   // a streaming regime needs rows (x slices): the layer1-3 maps at training batch sizes
   switch (k.K) {
     case 64: return c1s_n<64>(k, st);
     case 128: return c1s_n<128>(k, st);

@@ -964,12 +964,22 @@ extern "C" int gpv_conv2d(const gpv_conv_args* a, void* stream) {
     // the stem reads 16-B runs at pixel granularity (Cs = 4 bf16 = 8 B): require 16-B aligned runs
     if ((a->Cs % vecel) != 0) k.vecA = ((a->SW * a->Cs) % vecel == 0 && (a->IW * a->Cs) % vecel == 0 && a->PW == 0) ? k.vecA : 0;
     k.vecB = aligned16(a->w) && (k.K % 8 == 0) ? 1 : 0;
+    if (a->mode == 0 && a->KH == 1 && a->KW == 1 && a->SH == 2 && a->SW == 2 && a->PH == 0 && a->PW == 0 &&
+        aligned16(a->x) && a->Cs % vecel == 0 && (int64_t)a->B * a->IH * a->IW * a->Cs * esz < 0x7ffffff0ll * 4ll) {
+      // stride-2 pointwise projection (the downsample branches), forward: the streaming kernel reads every other pixel of every
+      // other row (conv1x1_stream.hip); anything it does not take goes down the generic gather path below
+      GemmK ks = k;
+      ks.lda = a->Cs; ks.vecA = 1;
+      const int cs = c1s_try_launch(ks, a->dtype_in, a->dtype_out, st);
+      if (cs >= 0) return cs;
+    }
     if (a->KH == 1 && a->KW == 1 && a->SH == 1 && a->SW == 1 && a->PH == 0 && a->PW == 0 && a->IH == a->OH && a->IW == a->OW) {
       // a 1x1 stride-1 convolution IS a GEMM over the pixel rows (row pitch Cs): no tap / pixel decoding per thread
       // (three integer divisions per staged row -- a third of the instructions of a K = 64 tile), and the GEMM-side
       // kernel choices apply
       k.lda = a->Cs;
       k.cg = ConvGeom{};
+      k.cg.SH = k.cg.SW = 1;
       k.conv1x1 = 1;
       {
         // outputs far beyond the 256 MB MALL (layer1's 314 MB maps) are stored -- and their residual read -- non-temporally:

@@ -805,3 +805,27 @@ def test_streaming_1x1_conv_kernel_forced(Cin, Cout, H, W, Bn, with_res, with_ma
         ref = ref * (msk.float() > 0)
     assert rel(outs[1], ref) < TOL[torch.bfloat16]
     assert torch.equal(outs[0], outs[1])                       # same products, same fp32 accumulation order per output: identical bits
+
+
+@pytest.mark.parametrize('Cin,Cout,H,W,Bn', [(256, 512, 30, 40, 2), (512, 1024, 14, 18, 2), (64, 256, 9, 13, 3), (256, 128, 8, 6, 1)])
+def test_streaming_1x1_conv_stride2_forward(Cin, Cout, H, W, Bn):
+    """the downsample projections (1x1, stride 2, no padding) through conv1x1_stream.hip: every other pixel of every other row,
+    256 / 128-channel slices where the weights do not fit the LDS as a whole; against fp32 math and the gather kernel"""
+    h = hip()
+    torch.manual_seed(Cin + H)
+    OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    x = torch.randn(Bn, H, W, Cin, device=DEV).to(torch.bfloat16)
+    w = (torch.randn(Cout, 1, Cin, device=DEV) / Cin ** 0.5).to(torch.bfloat16)
+    bias = torch.randn(Cout, device=DEV)
+    outs = []
+    for mode in (0, 2):
+        prev = h.set_option(h.OPT_C1S, mode)
+        try:
+            y = torch.empty(Bn, OH, OW, Cout, device=DEV, dtype=torch.bfloat16)
+            h.conv2d(0, x, w, y, Bn, H, W, Cin, Cin, OH, OW, Cout, 1, 1, 2, 2, 0, 0, bias=bias)
+        finally:
+            h.set_option(h.OPT_C1S, prev)
+        outs.append(y.float())
+    ref = x[:, ::2, ::2].float() @ w.reshape(Cout, Cin).float().t() + bias
+    assert rel(outs[1], ref) < TOL[torch.bfloat16]
+    assert rel(outs[0], outs[1]) < 1e-2
