@@ -864,6 +864,29 @@ int launch_dtype(const GemmK& k, int batch, int dt_in, int dt_out, hipStream_t s
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// Backward-data of a 1x1 stride-2 convolution (the downsample projections): only output pixels with even row AND column receive a
+// product; the other three quarters are dx = res * (mask > 0) (or 0).  The GEMM kernels take the first quarter (parity class 0 of
+// the class-major row order); this element-wise kernel streams the rest.  (Routed through the GEMM epilogue -- one dummy k-tile
+// per 64/128-row tile, LDS round trip -- those three quarters ran at 2 TB/s and were most of a 245 us launch.)
+__global__ __launch_bounds__(256) void s2_dgrad_fill_kernel(bf16* __restrict__ dx, const bf16* __restrict__ res, const bf16* __restrict__ mask,
+                                                            int64_t total_chunks, int OW, int OH, int C8) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total_chunks) return;
+  const int64_t px = i / C8;
+  const int ow = (int)(px % OW), oh = (int)((px / OW) % OH);
+  if (((oh | ow) & 1) == 0) return;                    // class 0: written by the GEMM
+  bf16x8 o = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+  if (res) {
+    o = *reinterpret_cast<const bf16x8*>(res + i * 8);
+    if (mask) {
+      const bf16x8 m = *reinterpret_cast<const bf16x8*>(mask + i * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (float)m[e] > 0.f ? o[e] : (bf16)0.f;
+    }
+  }
+  *reinterpret_cast<bf16x8*>(dx + i * 8) = o;
+}
+
 }  // namespace
 
 extern "C" int gpv_abi_version(void) { return 1; }
@@ -998,6 +1021,24 @@ extern "C" int gpv_conv2d(const gpv_conv_args* a, void* stream) {
       const int g = glds_try_launch(k, OP_PLAIN, a->dtype_in, a->dtype_out, 1, st);
       if (g >= 0) return g;
       return launch_dtype<OP_PLAIN, OP_PLAIN>(k, 1, a->dtype_in, a->dtype_out, st);
+    }
+    static const bool s2_split = [] { const char* e = getenv("GPV_S2_DGRAD_SPLIT"); return !e || e[0] != '0'; }();
+    if (s2_split && a->mode == 1 && k.cg.cm && a->KH == 1 && a->KW == 1 && a->PH == 0 && a->PW == 0 && a->dtype_in == GPV_BF16 &&
+        a->dtype_out == GPV_BF16 && a->Cout % 8 == 0 && aligned16(a->y) && (!a->res || aligned16(a->res)) &&
+        (!a->relu_mask || aligned16(a->relu_mask)) && k.vecA && k.vecB) {
+      // pointwise stride-2 backward-data: class 0 (even row, even column) through the GEMM kernels, the rest element-wise
+      GemmK k0 = k;
+      k0.M = k.cg.cls_rows;
+      int e = pipe_try_launch(k0, OP_CONV, a->dtype_in, a->dtype_out, 1, st);
+      if (e < 0) e = glds_try_launch(k0, OP_CONV, a->dtype_in, a->dtype_out, 1, st);
+      if (e < 0) e = launch_dtype<OP_CONV, OP_PLAIN>(k0, 1, a->dtype_in, a->dtype_out, st);
+      if (e) return e;
+      const int C8 = a->Cout / 8;
+      const int64_t chunks = (int64_t)a->B * a->OH * a->OW * C8;
+      hipLaunchKernelGGL(s2_dgrad_fill_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, st, reinterpret_cast<bf16*>(a->y),
+                         reinterpret_cast<const bf16*>(a->res), reinterpret_cast<const bf16*>(a->relu_mask), chunks, a->OW, a->OH, C8);
+      GPV_CHECK_LAUNCH();
+      return 0;
     }
     if (k.vecA && k.vecB) {
       const int pp = pipe_try_launch(k, OP_CONV, a->dtype_in, a->dtype_out, 1, st);
