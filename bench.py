@@ -361,7 +361,7 @@ def main():
     except (OSError, KeyError, ValueError, IndexError):
         pass
     roof = {'bound': 'hbm', 'achieved': ach_gbs, 'peak': 8000.0, 'unit': 'GB/s', 'frac': ach_gbs / 8000.0, 'traffic': traffic,
-            'kernel': 'conv1x1_kernel / glds_wgrad_kernel / glds_kernel<OP_CONV> / pipe_kernel<OP_CONV> / pipe_conv1x1_kernel / gemm_kernel<OP_CONV> (NHWC implicit-GEMM conv fwd/dgrad/wgrad, ResNet-50 body)',
+            'kernel': 'c1s_kernel (streaming 1x1) / glds_wgrad_kernel / glds_kernel<OP_CONV> / pipe_kernel<OP_CONV> / pipe_conv1x1_kernel / conv1x1_kernel / gemm_kernel<OP_CONV> (NHWC conv fwd/dgrad/wgrad, ResNet-50 body)',
             'launches_per_step': launches, 'avg_launch_us': conv_ms * 1e3 / launches,
             'algorithmic_bytes_per_launch': bytes_step / launches,
             'fwd_ms': ms['conv_fwd'] / args.steps, 'bwd_ms': ms['conv_bwd'] / args.steps,

@@ -19,22 +19,26 @@ def load(d, counter):
 def is_conv(name):
     n = name.replace('(anonymous namespace)::', '')
     return (('gemm_kernel' in n and 'Li2ELi0E' in n) or ('gemm_kernel<' in n and ', 1, 2, ' in n) or 'glds_kernelILi2E' in n or 'conv1x1_kernel' in n
-            or 'glds_wgrad_kernel' in n or 'pipe_kernelILi2E' in n)
+            or 'glds_wgrad_kernel' in n or 'pipe_kernelILi2E' in n or 'c1s_kernel' in n or 'conv1x1_nt_kernel' in n)
+
+
+def is_conv_helper(name):          # second kernel of a conv launch (1x1 stride-2 backward-data: the element-wise three quarters): bytes count, launches do not
+    return 's2_dgrad_fill_kernel' in name
 
 fd, wd = sys.argv[1], sys.argv[2]
 LAUNCHES_PER_PASS = 135          # conv launches of one forward + backward of the body (bench.py conv_algorithmic)
 F, Wr = load(fd, 'FETCH_SIZE'), load(wd, 'WRITE_SIZE')
-fetch_kb = sum(v[0] for k, v in F.items() if is_conv(k)); nf = sum(v[1] for k, v in F.items() if is_conv(k))
-write_kb = sum(v[0] for k, v in Wr.items() if is_conv(k)); nw = sum(v[1] for k, v in Wr.items() if is_conv(k))
+fetch_kb = sum(v[0] for k, v in F.items() if is_conv(k) or is_conv_helper(k)); nf = sum(v[1] for k, v in F.items() if is_conv(k))
+write_kb = sum(v[0] for k, v in Wr.items() if is_conv(k) or is_conv_helper(k)); nw = sum(v[1] for k, v in Wr.items() if is_conv(k))
 steps = nf / LAUNCHES_PER_PASS
 res = {
-    'what': 'gemm_kernel<OP_CONV,...> / conv1x1_kernel / pipe_kernel<OP_CONV> / pipe_conv1x1_kernel / glds_kernel<OP_CONV> / glds_conv1x1_kernel / glds_wgrad_kernel launches of `python bench.py` (B=32 train step)',
+    'what': 'c1s_kernel / gemm_kernel<OP_CONV,...> / conv1x1_kernel / pipe_kernel<OP_CONV> / pipe_conv1x1_kernel / glds_kernel<OP_CONV> / glds_conv1x1_kernel / glds_wgrad_kernel (+ s2_dgrad_fill_kernel bytes) launches of `python bench.py` (B=32 train step)',
     'steps_profiled': steps, 'conv_launches_fetch_pass': nf, 'conv_launches_write_pass': nw,
     'FETCH_SIZE_KB_raw': fetch_kb, 'WRITE_SIZE_KB_raw': write_kb,
     'fetch_bytes_corrected_x2': fetch_kb * 1024 * 2, 'write_bytes': write_kb * 1024,
     'traffic_bytes_per_step': (fetch_kb * 2 + write_kb) * 1024 / steps,
     'traffic_bytes_per_launch': (fetch_kb * 2 * 1024 / max(nf, 1)) + (write_kb * 1024 / max(nw, 1)),
     'by_kernel_KB': {k.replace('(anonymous namespace)::', '')[:90]: {'fetch_raw': F.get(k, [0, 0])[0], 'write': Wr.get(k, [0, 0])[0], 'launches': F.get(k, [0, 0])[1]}
-                     for k in F if is_conv(k)},
+                     for k in F if is_conv(k) or is_conv_helper(k)},
 }
 print(json.dumps(res, indent=1))

@@ -28,8 +28,13 @@ for li, (pl, n, st) in enumerate(((64, 3, 1), (128, 4, 2), (256, 6, 2), (512, 3,
             convs.append((f'layer{li}.{b}.downsample', B * h2 * w2, pl * 4, inpl, (B * h * w * inpl + B * h2 * w2 * pl * 4) * 2 + inpl * pl * 8))
         convs.append((f'layer{li}.{b}.conv3', B * h2 * w2, pl * 4, pl, (B * h2 * w2 * pl + 2 * B * h2 * w2 * pl * 4) * 2 + pl * pl * 8))
         inpl, h, w = pl * 4, h2, w2
-ck = [r for r in seq if ('gemm_kernel' in r['Kernel_Name'] and 'Li2ELi0E' in r['Kernel_Name']) or 'glds_kernelILi2E' in r['Kernel_Name'] or 'conv1x1_kernel' in r['Kernel_Name']]
-print('\n## backbone forward, one launch per conv (last step): implicit-GEMM kernels `gemm_kernel<bf16,bf16,OP_CONV,OP_PLAIN,...>` / `conv1x1_kernel` / `glds_kernel<OP_CONV,...>`\n')
+def is_conv_fwd(n):
+    return (('gemm_kernel' in n and 'Li2ELi0E' in n) or 'glds_kernelILi2E' in n or 'pipe_kernelILi2E' in n or 'conv1x1_kernel' in n
+            or 'conv1x1_nt_kernel' in n or 'c1s_kernel' in n)
+
+
+ck = [r for r in seq if is_conv_fwd(r['Kernel_Name'])]
+print('\n## backbone forward, one launch per conv (last step): `c1s_kernel` (streaming 1x1) / `conv1x1_kernel` / `pipe_kernel<OP_CONV>` / `pipe_conv1x1_kernel` / `glds_kernel<OP_CONV>` / `gemm_kernel<OP_CONV>`\n')
 print('| conv | M | N | K | us | TFLOP/s | algorithmic GB/s |\n|---|---|---|---|---|---|---|')
 tt = tf = tb = 0
 for (name, M, N, K, byts), r in zip(convs, ck[:len(convs)]):
