@@ -305,10 +305,11 @@ class BackboneBase(nn.Module):
         if self._dummy is None or self._dummy.device != x.device:
             self._dummy = torch.zeros(1, device=x.device, requires_grad=True)       # makes autograd call backward
         need_bwd = torch.is_grad_enabled() and any(b.trainable() for b in self.body.blocks())
-        if RT.split is not None and need_bwd:
+        if RT.split is not None and torch.is_grad_enabled():
             # train.GraphedBody: the backbone is its own pair of hipGraphs (forward here, backward called by the trainer
-            # between the two halves of the gradient exchange); the rest of the model sees c5 as an autograd leaf
-            c5 = RT.split.backbone_forward(self.body, x.float())
+            # between the two halves of the gradient exchange); the rest of the model sees c5 as an autograd leaf.  With a
+            # frozen backbone (phase-1 training.freeze, lr_backbone = 0) the forward graph still ends here, without a backward.
+            c5 = RT.split.backbone_forward(self.body, x.float(), train=need_bwd)
         else:
             c5 = ResNetFn.apply(x.float(), self.body, self._dummy, need_bwd)
         h, w = c5.shape[1:3]

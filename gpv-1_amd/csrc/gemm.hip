@@ -406,7 +406,7 @@ __device__ __forceinline__ void gemm_body(const GemmK& p) {
   if constexpr (AMODE == OP_CONV) {
     // parity-class-major dgrad: the four classes have different tap counts (0..4 taps); cycle the classes
     // through consecutive row panels so every XCD's contiguous tile range gets the same mix of work
-    if (p.cg.cm && p.cg.cls_rows % BM == 0) {
+    if (p.cg.cm && p.cg.cls_rows % BM == 0 && p.M == 4 * p.cg.cls_rows) {
       const int tpc = p.cg.cls_rows / BM;
       tm = (tm & 3) * tpc + (tm >> 2);
     }

@@ -61,7 +61,7 @@ __device__ __forceinline__ void glds_body(const GemmK& p) {
   int tm = __builtin_amdgcn_readfirstlane(tile / p.tilesN);      // (the division is done on the VALU)
   const int tn = tile - tm * p.tilesN;
   if constexpr (AMODE == OP_CONV) {
-    if (p.cg.cm && p.cg.cls_rows % BM == 0) {           // cycle the stride-2 dgrad parity classes through the row panels
+    if (p.cg.cm && p.cg.cls_rows % BM == 0 && p.M == 4 * p.cg.cls_rows) {           // cycle the stride-2 dgrad parity classes through the row panels
       const int tpc = p.cg.cls_rows / BM;
       tm = (tm & 3) * tpc + (tm >> 2);
     }

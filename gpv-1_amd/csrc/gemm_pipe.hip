@@ -83,7 +83,7 @@ __device__ __forceinline__ void pipe_body(const GemmK& p) {
   int tm = __builtin_amdgcn_readfirstlane(tile / p.tilesN);
   const int tn = tile - tm * p.tilesN;
   if constexpr (AMODE == OP_CONV) {
-    if (p.cg.cm && p.cg.cls_rows % BM == 0) {
+    if (p.cg.cm && p.cg.cls_rows % BM == 0 && p.M == 4 * p.cg.cls_rows) {
       const int tpc = p.cg.cls_rows / BM;
       tm = (tm & 3) * tpc + (tm >> 2);
     }

@@ -319,17 +319,17 @@ def grad_chain(x):
     return GradChain() if (GradChain.ENABLED and torch.is_grad_enabled() and torch.is_tensor(x) and x.requires_grad) else None
 
 
-def check_chains(clear=True):
+def check_chains(clear=True, chains=None):
     """after a backward pass: every chain must be complete (all of its consumers ran, or none).  A chain whose consumers can
     run independently of each other (two outputs of a layer, one without a loss) silently loses gradient -- the members of a
     chain must sit behind ONE output (see vilbert.BertConnectionLayer).  Raises instead of training on wrong gradients."""
     bad = 0
-    for r in GradChain._live:
+    for r in (GradChain._live if chains is None else chains):      # chains: the list a train.GraphedBody owns for its forward
         c = r()
         if c is not None and c.left != c.total:
             bad += 1
             c.left, c.acc = c.total, None
-    if clear:
+    if clear and chains is None:
         del GradChain._live[:]
     if bad:
         raise RuntimeError('%d GradChain(s) ended a backward pass half walked: a chained consumer did not run' % bad)

@@ -111,9 +111,15 @@ class GraphedBody:
         # branch of F1 (fork / join on a second stream) and runs under the backbone's convolutions
         self.side = torch.cuda.Stream(device=dev) if os.environ.get('GPV_BERT_BRANCH', '1') != '0' else None
         self.wside = torch.cuda.Stream(device=dev)
+        # the gradient chains of THIS recorded forward belong to the body: an eager step's check_chains(clear=True) must not
+        # drop them from under the backward variants captured later (ops.GradChain._live is the eager steps' list)
+        from . import ops as _ops
+        live_before, _ops.GradChain._live = _ops.GradChain._live, []
         RT.split = self
+        self._open = None                      # the graph whose capture is open (ended / aborted on any failure below)
         try:
             self.f1.capture_begin(pool=self.pool, capture_error_mode=CAPTURE_MODE)
+            self._open = self.f1
             q_enc = None
             if self.side is not None:
                 self.side.wait_stream(trainer.stream)
@@ -122,22 +128,48 @@ class GraphedBody:
             self.q_enc = q_enc
             self.outs = model._forward_impl(NestedTensor(self.s_img, self.s_mask, self.all_valid), (self.s_ids, self.s_attn),
                                             self.s_tok, None, query_encodings=q_enc)
+            if self._open is not self.f2:
+                raise RuntimeError('GraphedBody: the model never reached backbone_forward (F1 was not closed)')
             torch.cuda.current_stream(dev).wait_stream(self.wside)          # join the weight-mirror branch
             self.f2.capture_end()
+            self._open = None
+        except BaseException:
+            self._abort_open()
+            raise
         finally:
             RT.split = None
+            self.chains, _ops.GradChain._live = _ops.GradChain._live, live_before
         self.fwd_touched = trainer.touched.clone()            # (forward kernels never write gradients: stays empty)
         trainer.touched |= saved
 
+    def _abort_open(self):
+        """a failure inside a capture must not leave the trainer's stream capturing (the eager fallback would run on it)"""
+        g, self._open = self._open, None
+        if g is not None:
+            try:
+                g.capture_end()
+            except Exception:
+                pass
+        for st in (self.side, self.wside):
+            if st is not None:
+                try:
+                    st.synchronize()
+                except Exception:
+                    pass
+
     # called by backbone.BackboneBase.forward while this body is being captured (ops.RT.split)
-    def backbone_forward(self, body, x):
-        self.keep = []
+    def backbone_forward(self, body, x, train=True):
+        """train=False: no backbone block is trainable (phase-1 `training.freeze`, lr_backbone = 0): F1 keeps nothing for a
+        backward, c5 is a constant of F2 and B2 has no backbone part"""
+        self.keep = [] if train else None
         c5 = body.forward_nhwc(x, self.keep)
         if self.side is not None:
             torch.cuda.current_stream(x.device).wait_stream(self.side)         # join the BERT branch before F1 ends
         self._prep_forked = False
         self.f1.capture_end()
+        self._open = None
         self.f2.capture_begin(pool=self.pool, capture_error_mode=CAPTURE_MODE)
+        self._open = self.f2
         # the W^T mirrors of the Linear weights (ops._lpT; needed by B1's backward-data GEMMs) are refreshed by one grouped
         # cast-transpose launch on a branch of F2: 360 MB of streaming under a chain of latency-bound kernels.  (As a branch of
         # F1 it ran beside the stem convolution and cost it 0.2 ms.)
@@ -147,7 +179,7 @@ class GraphedBody:
         with torch.cuda.stream(self.wside):
             ops.refresh_transposed()
         self.c5 = c5
-        self.c5_leaf = c5.detach().requires_grad_(True)
+        self.c5_leaf = c5.detach().requires_grad_(bool(train))
         self.body = body
         return self.c5_leaf
 
@@ -230,7 +262,8 @@ class GraphedBody:
         if RT.backward_milestone is not None:
             RT.backward_milestone('backbone')
         ev = bbm._prof('conv_bwd')
-        var['b2'].replay()
+        if var['b2'] is not None:
+            var['b2'].replay()
         if ev is not None:
             ev.record()
 
@@ -285,10 +318,12 @@ class GraphedBody:
             del deferred[:]
         try:
             b1.capture_begin(pool=self.pool, capture_error_mode=CAPTURE_MODE)
+            self._open = b1
             RT.defer_list = deferred if defer else None
             RT.backward_boundary = at_boundary if os.environ.get('GPV_WGRAD_SPLIT', '1') != '0' else None
             torch.autograd.backward([o for _, o, _ in pairs], grads, retain_graph=True)
-            ops_check_chains(clear=False)            # (the recorded forward -- and its chains -- serve further backward variants)
+            from . import ops as _ops
+            _ops.check_chains(clear=False, chains=self.chains)     # (the recorded forward -- and its chains -- serve further backward variants)
             RT.defer_list = None
             RT.backward_boundary = None
             if deferred and tr.world > 1:
@@ -300,16 +335,29 @@ class GraphedBody:
             if side_a:
                 torch.cuda.current_stream(dev).wait_stream(self.wside)
             b1.capture_end()
+            self._open = None
             dc5 = self.c5_leaf.grad
-            b2.capture_begin(pool=self.pool, capture_error_mode=CAPTURE_MODE)
-            if deferred:
-                self.wside.wait_stream(torch.cuda.current_stream(dev))
-                with torch.cuda.stream(self.wside):
+            bb_bwd = bool(self.keep) and dc5 is not None        # (frozen backbone: c5 is a constant, nothing behind it)
+            if deferred or bb_bwd:
+                b2.capture_begin(pool=self.pool, capture_error_mode=CAPTURE_MODE)
+                self._open = b2
+                if deferred and bb_bwd:
+                    self.wside.wait_stream(torch.cuda.current_stream(dev))
+                    with torch.cuda.stream(self.wside):
+                        self._flush(deferred)
+                elif deferred:
                     self._flush(deferred)
-            self.body.backward_nhwc(self.keep, dc5.to(RT.dtype))
-            if deferred:
-                torch.cuda.current_stream(dev).wait_stream(self.wside)
-            b2.capture_end()
+                if bb_bwd:
+                    self.body.backward_nhwc(self.keep, dc5.to(RT.dtype))
+                    if deferred:
+                        torch.cuda.current_stream(dev).wait_stream(self.wside)
+                b2.capture_end()
+                self._open = None
+            else:
+                b2 = None
+        except BaseException:
+            self._abort_open()
+            raise
         finally:
             RT.defer_list = None
             RT.backward_boundary = None

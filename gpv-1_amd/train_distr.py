@@ -173,7 +173,9 @@ def train_worker(cfg, dataset=None, device=None, log=print):
     t0 = time.time()
     for epoch in range(last_epoch + 1, epochs):
         idx = shard_indices(len(dataset), epoch, rank, world)
+        epoch_done = True                     # False: max_steps ended the epoch before its last batch
         for it, (imgs, queries, targets) in enumerate(batches(dataset, idx, per_rank, device)):
+            epoch_done = False
             trainer.set_epoch(epoch, it)
             loss = trainer.train_step(imgs, queries, targets)
             step += 1
@@ -187,9 +189,10 @@ def train_worker(cfg, dataset=None, device=None, log=print):
                 save_checkpoint(ckpt_path, model, trainer, epoch - 1, step)
             if max_steps is not None and step >= max_steps:
                 break
+            epoch_done = True
         stopped = max_steps is not None and step >= max_steps
         if rank == 0:
-            save_checkpoint(ckpt_path, model, trainer, epoch - 1 if stopped and it + 1 < steps_per_epoch else epoch, step)
+            save_checkpoint(ckpt_path, model, trainer, epoch if epoch_done else epoch - 1, step)
         if stopped:
             break
     if world > 1:

@@ -168,9 +168,8 @@ CONVS = [  # Cin, Cout, k, stride, pad, H, W
 
 @pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('Cin,Cout,k,s,p,H,W', CONVS)
-def test_conv_fwd_dgrad_wgrad(dtype, Cin, Cout, k, s, p, H, W):
+def test_conv_fwd_dgrad_wgrad(dtype, Cin, Cout, k, s, p, H, W, Bn=3):
     h = hip()
-    Bn = 3
     x = rnd(Bn, Cin, H, W, dtype=dtype, seed=20)
     w = rnd(Cout, Cin, k, k, dtype=dtype, seed=21, scale=1.0 / math.sqrt(Cin * k * k))
     scale, bias = rnd(Cout, seed=22).abs() + 0.5, rnd(Cout, seed=23)
@@ -202,6 +201,23 @@ def test_conv_fwd_dgrad_wgrad(dtype, Cin, Cout, k, s, p, H, W):
     h.conv2d(2, xn, nhwc(dy), dw, Bn, H, W, Cin, Cin, OH, OW, Cout, k, k, s, s, p, p, rowscale=scale)
     refw = (gw * scale.view(-1, 1, 1, 1)).permute(0, 2, 3, 1)
     assert rel(dw, refw) < (3e-5 if dtype == torch.float32 else 3e-3)
+
+
+@pytest.mark.parametrize('Cin,Cout,H,W,Bn', [(256, 512, 32, 32, 4), (512, 1024, 32, 32, 4), (256, 512, 32, 64, 8), (1024, 2048, 16, 32, 8)])
+def test_conv1x1_stride2_dgrad_class_rows_multiple_of_tile(Cin, Cout, H, W, Bn):
+    """pointwise stride-2 backward-data is split into a GEMM over parity class 0 + an element-wise fill; when the rows of one
+    class are a multiple of the row tile (64 / 128 / 256: the bench batch of 32 hits it on layer3 / layer4) the class-0 launch
+    must NOT cycle its row panels through four classes (round-2 bug: three quarters of class 0 were left unwritten)"""
+    h = hip()
+    assert (Bn * (H // 2) * (W // 2)) % 256 == 0
+    for pipe, glds in ((None, None), (0, 3), (0, 2), (0, 0)):       # default dispatch; 4-wave / 8-wave direct-to-LDS; register-staged
+        prev = (h.set_option(h.OPT_PIPE, pipe), h.set_option(h.OPT_GLDS, glds)) if pipe is not None else None
+        try:
+            test_conv_fwd_dgrad_wgrad(torch.bfloat16, Cin, Cout, 1, 2, 0, H, W, Bn=Bn)
+        finally:
+            if prev is not None:
+                h.set_option(h.OPT_PIPE, prev[0])
+                h.set_option(h.OPT_GLDS, prev[1])
 
 
 @pytest.mark.parametrize('Cin,Cout,k,s,p,H,W,Bn', [

@@ -471,3 +471,42 @@ def test_graphed_train_step_draws_fresh_dropout_masks(rt):
     replayed = losses[2:]
     assert len(set(replayed)) == len(replayed), losses          # different masks -> different losses at identical weights
     assert int(ops.RT.seed_dev) >= 4
+
+
+@pytest.mark.parametrize('how', ['freeze_detr', 'backbone_frozen'])
+def test_graphed_train_step_with_frozen_backbone_equals_eager(rt, how):
+    """phase-1 training (`training.freeze=True`: every DETR parameter frozen, scripts/train.sh; ref train_distr.py:136-140,194)
+    and lr_backbone = 0 leave no trainable backbone block: the forward graph F1 must still end at the backbone's output, B2 has
+    no backbone part, and the step must equal the eager one (round-2 bug: F1 was never closed and the capture crashed)"""
+    from gpv1_amd.train import FlatTrainer
+    from gpv1_amd.train_distr import freeze_detr_params
+    rt.set_precise(False)
+    images, mask, ids, attn = batch()
+    cap = [{'task': 'CocoCaptioning', 'answer': ' '.join(f'w{(3 * i + j) % (V - 4)}' for j in range(4))} for i in range(B)]
+    det = [{'task': 'CocoDetection', 'boxes': torch.tensor([[0.5, 0.5, 0.2, 0.3], [0.3, 0.6, 0.1, 0.1]], device=DEV)[: 1 + i % 2],
+            'labels': torch.zeros(1 + i % 2, dtype=torch.long, device=DEV)} for i in range(B)]
+    mixed = [cap[i] if i % 2 == 0 else det[i] for i in range(B)]
+    res = {}
+    for graphs in (False, True):
+        model, _ = build_small()
+        model.to(DEV).train()
+        model.bert.model.p = 0.0
+        if how == 'freeze_detr':
+            model.init_detr_params = [n for n, _ in model.named_parameters() if n.startswith('detr.')]
+            freeze_detr_params(model)
+        else:
+            for n, p in model.named_parameters():
+                if 'detr.backbone' in n:
+                    p.requires_grad_(False)
+        assert not any(b.trainable() for b in model.detr.backbone[0].body.blocks())
+        tr = FlatTrainer(model, lr=1e-3, lr_backbone=1e-4, graphs=graphs)
+        losses = [float(tr.train_step(nested(images, mask), (ids, attn), [dict(t) for t in tg])) for tg in (cap, cap, cap, mixed, mixed)]
+        res[graphs] = (losses, tr.P.clone(), len(tr._bodies), tr.live_host().clone())
+    (l0, p0, n0, v0), (l1, p1, n1, v1) = res[False], res[True]
+    assert n0 == 0 and n1 >= 1
+    assert torch.equal(v0, v1)
+    for a, b_ in zip(l0, l1):
+        assert abs(a - b_) <= 2e-2 * max(abs(a), 1.0), (l0, l1)
+    assert rel(p1, p0.cpu()) < 1e-2
+    # and the trainer's stream is usable afterwards (no capture left open)
+    assert not torch.cuda.is_current_stream_capturing()
