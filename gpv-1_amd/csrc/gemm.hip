@@ -1040,6 +1040,11 @@ extern "C" int gpv_conv2d(const gpv_conv_args* a, void* stream) {
       GPV_CHECK_LAUNCH();
       return 0;
     }
+    if (a->KH == 3 && a->KW == 3 && k.vecA && k.vecB) {
+      // 3x3 with 64 / 128 input channels over the layer1 / layer2 maps: weights resident in LDS, barrier-free streaming kernel
+      const int c3 = c3s_try_launch(k, a->dtype_in, a->dtype_out, st);
+      if (c3 >= 0) return c3;
+    }
     if (k.vecA && k.vecB) {
       const int pp = pipe_try_launch(k, OP_CONV, a->dtype_in, a->dtype_out, 1, st);
       if (pp >= 0) return pp;

@@ -413,6 +413,16 @@ extern "C" int gpv_set_option(int option, int value) {
     gpvk::g_c1s_mode = value;
     return prev;
   }
+  if (option == GPV_OPT_C3S) {
+    const int prev = gpvk::g_c3s_mode;
+    gpvk::g_c3s_mode = value;
+    return prev;
+  }
+  if (option == GPV_OPT_C3S_LAUNCHES) {
+    const long prev = gpvk::g_c3s_launches;
+    gpvk::g_c3s_launches = value;
+    return (int)prev;
+  }
   if (option == GPV_OPT_PIPE) return gpvk::pipe_set_mode(value);
   if (option == GPV_OPT_PIPE_LAUNCHES) return (int)gpvk::pipe_launches(value);
   if (option == GPV_OPT_GLDS_LAUNCHES) {

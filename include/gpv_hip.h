@@ -63,6 +63,8 @@ int gpv_gemm_tt_group(const gpv_tt_problem* problems, int n, void* stream);
 #define GPV_OPT_GLDS_WGRAD 3 /* direct-to-LDS weight-gradient kernel: 0 never, 1 (default) conv wherever legal + linear where it wins, 2 both wherever legal */
 #define GPV_OPT_PIPE 4 /* three-stage pipelined direct-to-LDS GEMM/conv kernel (gemm_pipe.hip): 0 never, 1 (default) heuristic, 100 + i = tile configuration i wherever legal */
 #define GPV_OPT_C1S 6 /* streaming kernel for the K <= 256 1x1 convolutions (conv1x1_stream.hip): 0 never, 1 (default) >= 65536 pixel rows, 2 wherever legal */
+#define GPV_OPT_C3S 7 /* streaming kernel for the 3x3 convolutions with 64 / 128 input channels (conv3x3_stream.hip): 0 never, 1 (default) >= 65536 output pixels, 2 wherever legal */
+#define GPV_OPT_C3S_LAUNCHES 8 /* returns the number of streaming-3x3 launches so far, then sets the counter to value */
 #define GPV_OPT_PIPE_LAUNCHES 5 /* returns the number of pipelined-kernel launches so far, then sets the counter to value */
 int gpv_set_option(int option, int value);
 

@@ -845,3 +845,53 @@ def test_streaming_1x1_conv_stride2_forward(Cin, Cout, H, W, Bn):
     ref = x[:, ::2, ::2].float() @ w.reshape(Cout, Cin).float().t() + bias
     assert rel(outs[1], ref) < TOL[torch.bfloat16]
     assert rel(outs[0], outs[1]) < 1e-2
+
+
+# ----------------------------------------------------------------------------------------- streaming 3x3 convolution
+@pytest.fixture()
+def c3s():
+    """force the streaming 3x3 kernel (conv3x3_stream.hip) wherever it is legal and count its launches"""
+    h = hip()
+    prev = h.set_option(h.OPT_C3S, 2)
+    h.set_option(h.OPT_C3S_LAUNCHES, 0)
+    yield h
+    h.set_option(h.OPT_C3S, prev)
+
+
+@pytest.mark.parametrize('Cin,Cout,s,H,W,Bn', [
+    (64, 64, 1, 24, 32, 3),        # layer1 shape class; 2304 pixels = 72 whole tiles
+    (64, 64, 1, 17, 23, 3),        # ragged: tiles cross rows and images, 1173 pixels (tail tile of 21)
+    (128, 128, 1, 15, 20, 3),      # layer2: two 64-channel slices
+    (128, 128, 2, 24, 32, 2),      # stride 2: the streaming kernel must decline (forward and the parity-class backward-data), the tile kernels take it
+    (64, 64, 1, 7, 61, 2),         # three strips of 30 columns, the last one a single column; 7 rows = 3 + 3 + 1
+    (128, 64, 1, 9, 40, 2),        # Cout != Cin: forward 128 -> 64 (one slice), backward-data is a 64-channel reduction into 128
+    (64, 128, 1, 8, 8, 5)])
+def test_streaming_3x3_conv_kernel_forced(c3s, Cin, Cout, s, H, W, Bn):
+    """conv3x3_stream.hip against fp32 torch: forward (+ bias, ReLU), backward-data (ReLU mask), incl. the zero-filled border rows /
+    columns, ragged strips and row segments, both slices of a 128-channel layer"""
+    h, dtype = c3s, torch.bfloat16
+    x = rnd(Bn, Cin, H, W, dtype=dtype, seed=60)
+    w = rnd(Cout, Cin, 3, 3, dtype=dtype, seed=61, scale=1.0 / math.sqrt(Cin * 9))
+    bias = rnd(Cout, seed=62)
+    OH, OW = (H + 2 - 3) // s + 1, (W + 2 - 3) // s + 1
+    xn, wn = nhwc(x), w.permute(0, 2, 3, 1).contiguous()
+    for act in (h.ACT_RELU, h.ACT_NONE):
+        y = torch.empty(Bn, OH, OW, Cout, device=DEV, dtype=dtype)
+        h.conv2d(0, xn, wn, y, Bn, H, W, Cin, Cin, OH, OW, Cout, 3, 3, s, s, 1, 1, bias=bias, act=act)
+        ref = F.conv2d(x.float(), w.float(), stride=s, padding=1) + bias.view(1, -1, 1, 1)
+        if act == h.ACT_RELU:
+            ref = F.relu(ref)
+        assert rel(y, nhwc(ref)) < TOL[dtype]
+    assert h.set_option(h.OPT_C3S_LAUNCHES, 0) == (2 if s == 1 else 0)
+    # backward-data: dx = convT(dy) * (saved > 0)
+    dy = rnd(Bn, Cout, OH, OW, dtype=dtype, seed=63)
+    saved = rnd(Bn, Cin, H, W, dtype=dtype, seed=64)
+    xf = x.float().requires_grad_(True)
+    gx, = torch.autograd.grad(F.conv2d(xf, w.float(), stride=s, padding=1), xf, dy.float())
+    wd = w.permute(1, 2, 3, 0).contiguous()
+    for mask in (nhwc(saved), None):
+        dx = torch.full((Bn, H, W, Cin), float('nan'), device=DEV, dtype=dtype)
+        h.conv2d(1, nhwc(dy), wd, dx, Bn, OH, OW, Cout, Cout, H, W, Cin, 3, 3, s, s, 1, 1, relu_mask=mask)
+        ref = gx * (saved.float() > 0) if mask is not None else gx
+        assert rel(dx, nhwc(ref)) < TOL[dtype]
+    assert h.set_option(h.OPT_C3S_LAUNCHES, 0) == (2 if s == 1 else 0)

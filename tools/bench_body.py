@@ -1,0 +1,114 @@
+"""Per-launch table of the ResNet-50 body at the bench workload (B=32, 480x640, bf16): every C-ABI call that
+`ResNetBody.forward_nhwc` / `backward_nhwc` issue is recorded once, then replayed alone on the stream (20 times, HIP events)
+and printed with its own roofline bound  max(bytes / 8 TB/s, flops / 2.5 PFLOP/s)  -- the work list of the conv rounds.
+usage: python tools/bench_body.py [--batch 32] [--filter l1]      (GPU box)"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import gpv1_amd.hip as hip                      # noqa: E402
+import gpv1_amd.backbone as bbm                 # noqa: E402
+from gpv1_amd.ops import RT                     # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument('--batch', type=int, default=32)
+ap.add_argument('--iters', type=int, default=20)
+ap.add_argument('--filter', default='')
+args = ap.parse_args()
+dev = 'cuda'
+hip.lib()
+torch.manual_seed(0)
+body = bbm.ResNetBody().to(dev)
+for n, p in body.named_parameters():
+    if 'layer2' not in n and 'layer3' not in n and 'layer4' not in n:
+        p.requires_grad_(False)
+for n, b in body.named_buffers():
+    if n.endswith('running_var'):
+        b.uniform_(0.5, 1.5)
+RT.set_precise(False)
+images = torch.randn(args.batch, 3, 480, 640, device=dev)
+
+calls = []
+names = {}
+for n, m in body.named_modules():
+    if isinstance(m, bbm.ConvW):
+        names[id(m)] = n
+ENTRY = ('conv2d', 'maxpool3x3s2', 'image_to_nhwc4', 'act_bwd', 'conv_block_tail') if hasattr(hip, 'conv_block_tail') else \
+        ('conv2d', 'maxpool3x3s2', 'image_to_nhwc4', 'act_bwd')
+orig = {k: getattr(hip, k) for k in ENTRY}
+phase = ['fwd']
+
+
+def rec(k):
+    def f(*a, **kw):
+        calls.append((phase[0], k, a, kw))
+        return orig[k](*a, **kw)
+    return f
+
+
+for k in ENTRY:
+    setattr(hip, k, rec(k))
+with torch.no_grad():
+    for g in body.parameters():
+        if g.requires_grad:
+            g.grad = torch.zeros_like(g)
+    keep = []
+    c5 = body.forward_nhwc(images, keep)
+    dc5 = torch.randn(c5.shape, device=dev).to(c5.dtype)
+    phase[0] = 'bwd'
+    body.backward_nhwc(keep, dc5)
+for k in ENTRY:
+    setattr(hip, k, orig[k])
+torch.cuda.synchronize()
+
+
+def describe(k, a, kw):
+    if k != 'conv2d':
+        return k, 0.0, 0.0
+    mode, x, w, y, B, IH, IW, Cs, Cin, OH, OW, Cout, KH, KW, SH, SW, PH, PW = a[:18]
+    T = KH * KW
+    if mode == 0:
+        by = B * IH * IW * Cs * 2 / (SH * SW if KH == 1 else 1) + B * OH * OW * Cout * 2 * (2 if kw.get('res') is not None else 1) + Cout * T * Cin * 2
+        fl = 2.0 * B * OH * OW * Cout * T * Cin
+        nm = 'fwd  %4d->%4d %dx%d/%d %3dx%3d' % (Cin, Cout, KH, KW, SH, OH, OW)
+    elif mode == 1:
+        # dgrad: x = dy [B,IH,IW,Cin=Cout_fwd], y = dx [B,OH,OW,Cout=Cin_fwd]
+        ex = (1 if kw.get('res') is not None else 0) + (1 if kw.get('relu_mask') is not None else 0)
+        by = B * IH * IW * Cin * 2 + B * OH * OW * Cout * 2 * (1 + ex) + Cout * T * Cin * 2
+        fl = 2.0 * B * IH * IW * Cin * T * Cout
+        nm = 'dgrd %4d<-%4d %dx%d/%d %3dx%3d' % (Cout, Cin, KH, KW, SH, OH, OW)
+    else:
+        by = B * IH * IW * Cs * 2 / (SH * SW if KH == 1 else 1) + B * OH * OW * Cout * 2 + Cout * T * Cin * 4 * 2
+        fl = 2.0 * B * OH * OW * Cout * T * Cin
+        nm = 'wgrd %4dx%4d %dx%d/%d %3dx%3d' % (Cout, Cin, KH, KW, SH, OH, OW)
+    return nm, by, fl
+
+
+tot = {'fwd': [0.0, 0.0], 'bwd': [0.0, 0.0]}
+print('%-4s %-34s %9s %9s %8s %8s %7s' % ('', 'launch', 'us', 'bound us', 'TF/s', 'GB/s', 'excess'))
+rows = []
+for ph, k, a, kw in calls:
+    nm, by, fl = describe(k, a, kw)
+    if args.filter and args.filter not in nm:
+        continue
+    fn = orig[k]
+    for _ in range(3):
+        fn(*a, **kw)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(args.iters):
+        fn(*a, **kw)
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / args.iters
+    bound = max(by / 8e12, fl / 2.5e15) * 1e6
+    tot[ph][0] += us
+    tot[ph][1] += bound
+    rows.append((us - bound, nm, ph))
+    print('%-4s %-34s %9.1f %9.1f %8.1f %8.0f %7.1f' % (ph, nm, us, bound, fl / us / 1e6 if us else 0, by / us / 1e3 if us else 0, us - bound))
+for ph in ('fwd', 'bwd'):
+    print('%s total %.1f us, sum of per-launch bounds %.1f us (%.2f)' % (ph, tot[ph][0], tot[ph][1], tot[ph][1] / max(tot[ph][0], 1e-9)))
