@@ -13,6 +13,7 @@ downsample.0/1}).  Differences by design (MI355X-first):
     (conv1/layer1 are always frozen: backbone.py:61-63).
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -24,6 +25,7 @@ from .misc import NestedTensor
 from .position_encoding import build_position_encoding
 
 RELU = hip.ACT_RELU
+FUSED_STEM = os.environ.get('GPV_FUSED_STEM', '1') != '0'
 PROF = None     # bench.py sets this to a list: (tag, start_event, end_event) per backbone forward / backward
 
 
@@ -201,12 +203,17 @@ class ResNetBody(nn.Module):
         xin = torch.empty(B, Hp, Wp, 4, device=images.device, dtype=RT.dtype)
         hip.image_to_nhwc4(images.contiguous(), xin, B, H, Wd, 3, Hp, Wp)
         ws, shift = self._stem_weight()
-        y = torch.empty(B, OH, OW, 64, device=images.device, dtype=RT.dtype)
-        hip.conv2d(0, xin, ws, y, B, Hp, Wp, 4, 32, OH, OW, 64, 7, 1, 2, 2, 0, 0, bias=shift, act=RELU)
         PH, PW = _out(OH, 3, 2, 1), _out(OW, 3, 2, 1)
         x = torch.empty(B, PH, PW, 64, device=images.device, dtype=RT.dtype)
-        hip.maxpool3x3s2(y, x, B, OH, OW, 64, PH, PW)
-        del y, xin
+        if RT.dtype == torch.bfloat16 and FUSED_STEM:
+            # conv1 + bn1 + relu + maxpool in one launch: the 240x320x64 conv map (314 MB at B = 32) is never written
+            hip.stem_pool(xin, ws, shift, x, B, Hp, Wp, OH, OW, PH, PW)
+        else:                                      # fp32 "precise" mode: the generic conv kernel + the pooling kernel
+            y = torch.empty(B, OH, OW, 64, device=images.device, dtype=RT.dtype)
+            hip.conv2d(0, xin, ws, y, B, Hp, Wp, 4, 32, OH, OW, 64, 7, 1, 2, 2, 0, 0, bias=shift, act=RELU)
+            hip.maxpool3x3s2(y, x, B, OH, OW, 64, PH, PW)
+            del y
+        del xin
         if RT.split is not None and keep is not None:
             RT.split.prep_join()                   # the weight copies were prepared on a branch beside the stem (prep_weights)
         seen_trainable = False

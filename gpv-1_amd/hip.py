@@ -77,7 +77,7 @@ EXPORTS = ['gpv_abi_version', 'gpv_set_option', 'gpv_gemm', 'gpv_conv2d', 'gpv_i
            'gpv_softmax_ce', 'gpv_roi_weights', 'gpv_add', 'gpv_add_rowbcast', 'gpv_colsum', 'gpv_cast',
            'gpv_cast_rowscale_t', 'gpv_prep_conv_weight', 'gpv_embedding', 'gpv_dropout',
            'gpv_relevance_condition', 'gpv_adamw', 'gpv_sumsq', 'gpv_act_fwd', 'gpv_act_bwd', 'gpv_set_seed_device',
-           'gpv_gemm_tt_group', 'gpv_cast_transpose_group']
+           'gpv_gemm_tt_group', 'gpv_cast_transpose_group', 'gpv_stem_pool']
 
 
 OPT_GLDS, OPT_GLDS_LAUNCHES, OPT_SKINNY, OPT_GLDS_WGRAD, OPT_PIPE, OPT_PIPE_LAUNCHES, OPT_C1S, OPT_C3S, OPT_C3S_LAUNCHES = 0, 1, 2, 3, 4, 5, 6, 7, 8
@@ -284,6 +284,13 @@ def image_to_nhwc4(img, out, B, H, W, pad, Hp, Wp):
 
 def maxpool3x3s2(x, y, B, H, W, Cc, OH, OW):
     _chk(lib().gpv_maxpool3x3s2(_p(x), _p(y), B, H, W, Cc, OH, OW, dcode(x), _stream()), 'gpv_maxpool3x3s2')
+
+
+def stem_pool(x, w, shift, y, B, Hp, Wp, CH, CW, PH, PW):
+    """gpv_stem_pool: conv 7x7/2 + FrozenBN shift + ReLU + max-pool 3x3/2 in one launch (bf16)"""
+    if x.dtype != torch.bfloat16 or w.dtype != torch.bfloat16 or y.dtype != torch.bfloat16:
+        raise TypeError('stem_pool: bf16 only')
+    _chk(lib().gpv_stem_pool(_p(x), _p(w), _p(_f32(shift)), _p(y), B, Hp, Wp, CH, CW, PH, PW, _stream()), 'gpv_stem_pool')
 
 
 def roi_weights(boxes, wgt, n_roi, H, W, ldw):

@@ -143,6 +143,12 @@ int gpv_image_to_nhwc4(const float* img, void* out, int B, int H, int W, int pad
 /* 3x3 stride-2 pad-1 max-pool, NHWC (torchvision resnet maxpool). */
 int gpv_maxpool3x3s2(const void* x, void* y, int B, int H, int W, int C, int OH, int OW, int dtype,
                      void* stream);
+/* The whole ResNet stem in one launch (exp/gpv/models/backbone.py:93-95 -> torchvision resnet50 conv1 + bn1 (frozen: scale folded
+ * into w, shift here) + relu + maxpool):  y[B,PH,PW,64] = maxpool3x3s2p1(relu(conv7x7s2(x) + shift)).  x = the zero-padded NHWC4
+ * bf16 image gpv_image_to_nhwc4 writes with pad 3 ([B,Hp,Wp,4], Wp even, >= 2 (CW - 1) + 8), w = [64][7][8 px][4 ch] bf16 (8th pixel /
+ * 4th channel zero), CH x CW = conv map, PH x PW = pooled map.  bf16 only; the conv map is never written. */
+int gpv_stem_pool(const void* x, const void* w, const float* shift, void* y, int B, int Hp, int Wp, int CH, int CW, int PH, int PW,
+                  void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Multi-head attention core  O = dropout(softmax(Q K^T * scale + masks)) V   per (batch, head).

@@ -200,6 +200,14 @@ def maxpool3x3s2(x, y, B, H, W, Cc, OH, OW):
     y.copy_(F.max_pool2d(x.float().permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1).to(y.dtype))
 
 
+def stem_pool(x, w, shift, y, B, Hp, Wp, CH, CW, PH, PW):
+    # x [B,Hp,Wp,4] padded NHWC4, w [64][7][32] = [co][r][8 px][4 ch]
+    wk = w.float().view(64, 7, 8, 4).permute(0, 3, 1, 2)                       # [co][ch][r][8]
+    c = F.conv2d(x.float().permute(0, 3, 1, 2), wk, stride=2)[:, :, :CH, :CW] + shift.view(1, -1, 1, 1)
+    c = F.relu(c).to(y.dtype).float()
+    y.copy_(F.max_pool2d(c, 3, 2, 1).permute(0, 2, 3, 1).to(y.dtype))
+
+
 def roi_weights(boxes, wgt, n_roi, H, W, ldw):
     from oracle import gpv_oracle as O
     x1 = W * (boxes[:, 0] - 0.5 * boxes[:, 2]) - 0.5
@@ -305,7 +313,7 @@ def install(only=None):
     `only`: optional list of entry-point names (GPU bisecting: swap single kernels for torch math)."""
     import gpv1_amd.hip as h
     names = only or ['gemm', 'conv2d', 'attention_fwd', 'attention_bwd', 'layernorm_fwd', 'layernorm_bwd', 'softmax_ce',
-             'image_to_nhwc4', 'maxpool3x3s2', 'roi_weights', 'add', 'add_rowbcast', 'colsum', 'cast', 'cast_rowscale_t',
+             'image_to_nhwc4', 'maxpool3x3s2', 'stem_pool', 'roi_weights', 'add', 'add_rowbcast', 'colsum', 'cast', 'cast_rowscale_t',
              'prep_conv_weight', 'embedding', 'dropout', 'relevance_condition', 'adamw', 'sumsq', 'act_fwd', 'act_bwd',
              'cast_transpose_group']
     saved = {n: getattr(h, n) for n in names}

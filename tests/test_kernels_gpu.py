@@ -277,6 +277,37 @@ def test_stem_conv_image_prep_and_maxpool(dtype):
     assert torch.equal(z.float(), nhwc(F.max_pool2d(y.float().permute(0, 3, 1, 2), 3, 2, 1)))
 
 
+@pytest.mark.parametrize('Bn,H,W', [(2, 96, 128), (3, 62, 90), (1, 480, 640), (2, 34, 30)])
+def test_fused_stem_conv_bn_relu_maxpool(Bn, H, W):
+    """gpv_stem_pool (stem_pool.hip: conv 7x7/2 + shift + ReLU + max-pool 3x3/2 in one launch) against fp32 torch on the same
+    bf16-rounded operands, and against the two-kernel path (generic conv kernel + pooling kernel): same bf16 rounding points,
+    fp32 summation order differs.  Odd map sizes: conv 31x45 -> pooled 16x23 (ragged strips of 15 pooled columns, odd rows)."""
+    h, dtype = hip(), torch.bfloat16
+    img = rnd(Bn, 3, H, W, seed=30)
+    w = rnd(64, 3, 7, 7, seed=31, scale=0.08)
+    bias = rnd(64, seed=32)
+    OH, OW = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+    Hp, Wp = H + 6, ((max(W + 6, 2 * (OW - 1) + 8) + 7) // 8) * 8
+    xin = torch.empty(Bn, Hp, Wp, 4, device=DEV, dtype=dtype)
+    h.image_to_nhwc4(img, xin, Bn, H, W, 3, Hp, Wp)
+    ws = torch.zeros(64, 7, 8, 4, device=DEV)
+    ws[:, :, :7, :3] = w.permute(0, 2, 3, 1)
+    ws = ws.reshape(64, 7, 32).to(dtype).contiguous()
+    PH, PW = (OH + 2 - 3) // 2 + 1, (OW + 2 - 3) // 2 + 1
+    z = torch.full((Bn, PH, PW, 64), float('nan'), device=DEV, dtype=dtype)
+    h.stem_pool(xin, ws, bias, z, Bn, Hp, Wp, OH, OW, PH, PW)
+    conv = F.relu(F.conv2d(img.to(dtype).float(), w.to(dtype).float(), stride=2, padding=3) + bias.view(1, -1, 1, 1))
+    ref = F.max_pool2d(conv.to(dtype).float(), 3, 2, 1)
+    assert torch.isfinite(z.float()).all()
+    assert rel(z, nhwc(ref)) < TOL[dtype]
+    y = torch.empty(Bn, OH, OW, 64, device=DEV, dtype=dtype)
+    h.conv2d(0, xin, ws.view(64, 7, 1, 32), y, Bn, Hp, Wp, 4, 32, OH, OW, 64, 7, 1, 2, 2, 0, 0, bias=bias, act=h.ACT_RELU)
+    z2 = torch.empty_like(z)
+    h.maxpool3x3s2(y, z2, Bn, OH, OW, 64, PH, PW)
+    assert rel(z, z2) < 8e-3                   # one bf16 ulp where the two summation orders round differently
+    assert (z != z2).float().mean() < 0.02
+
+
 # ------------------------------------------------------------- 8-wave direct-to-LDS kernel (gemm_glds.hip)
 @pytest.fixture(params=[2, 3], ids=['8wave', '4wave128'])
 def glds(request):
