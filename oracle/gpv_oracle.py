@@ -39,11 +39,39 @@ P = Dict[str, Tensor]
 
 
 # --------------------------------------------------------------------------
+# bf16-faithful mode (test infrastructure for the production bf16 path)
+# --------------------------------------------------------------------------
+# The fp32 restatement above/below is what is pinned to the reference.  The HIP path that bench.py times stores every
+# activation in bf16 (fp32 accumulate inside a kernel): against fp32 math that is 0.5-1.2 % of max|ref| after ~60 layers, a
+# band wide enough to hide real bugs.  With ``set_bf16_faithful(True)`` the SAME functions round to bf16 exactly where
+# the HIP path stores bf16 -- compute copies of the weights (FrozenBN scale folded in first), every GEMM / conv epilogue
+# output (after bias / residual / activation), LayerNorm outputs, element-wise sums (x + pos), embedding gathers, the
+# un-normalised attention probabilities that feed P.V (the row sum stays fp32), attention outputs -- and nowhere else
+# (LayerNorm / softmax / CE statistics, class / box heads' last layer and the criterion stay fp32, as in the kernels).
+# Rounding is a straight-through estimator for autograd: gradients are the fp32 backward of the rounded forward.
+_BF16 = [False]
+
+
+def set_bf16_faithful(on: bool = True) -> bool:
+    prev, _BF16[0] = _BF16[0], bool(on)
+    return prev
+
+
+def _r(x: Tensor) -> Tensor:
+    """round to bf16 (value kept in fp32) when the faithful mode is on; identity otherwise"""
+    if not _BF16[0]:
+        return x
+    return x + (x.detach().to(torch.bfloat16).to(x.dtype) - x.detach())
+
+
+# --------------------------------------------------------------------------
 # small primitives
 # --------------------------------------------------------------------------
-def linear(x: Tensor, w: Tensor, b: Optional[Tensor] = None) -> Tensor:
-    y = x @ w.t()
-    return y if b is None else y + b
+def linear(x: Tensor, w: Tensor, b: Optional[Tensor] = None, out_f32: bool = False) -> Tensor:
+    """out_f32: the GEMMs whose output the HIP path keeps in fp32 (class head, last box-MLP layer, relevance predictor)"""
+    y = _r(x) @ _r(w).t()
+    y = y if b is None else y + b
+    return y if out_f32 else _r(y)
 
 
 def layer_norm(x: Tensor, w: Optional[Tensor], b: Optional[Tensor], eps: float) -> Tensor:
@@ -55,12 +83,12 @@ def layer_norm(x: Tensor, w: Optional[Tensor], b: Optional[Tensor], eps: float) 
     y = (x - u) / torch.sqrt(s + eps)
     if w is not None:
         y = y * w + b
-    return y
+    return _r(y)
 
 
 def gelu_erf(x: Tensor) -> Tensor:
     """vilbert.py:111-117"""
-    return x * 0.5 * (1.0 + torch.erf(x / math.sqrt(2.0)))
+    return _r(x * 0.5 * (1.0 + torch.erf(x / math.sqrt(2.0))))
 
 
 def attention_core(q: Tensor, k: Tensor, v: Tensor, nhead: int,
@@ -80,8 +108,16 @@ def attention_core(q: Tensor, k: Tensor, v: Tensor, nhead: int,
     if causal:
         cm = torch.ones(Tq, Tk, dtype=torch.bool, device=q.device).triu(1)
         s = s.masked_fill(cm, float('-inf'))
-    p = torch.softmax(s, -1)
-    o = p @ vh
+    if _BF16[0]:
+        # attention.hip: e = exp(s - max) in fp32, P.V on bf16(e), divided by the fp32 row sum of the unrounded e
+        m = s.amax(-1, keepdim=True)
+        m = torch.where(torch.isinf(m), torch.zeros_like(m), m)
+        e = torch.exp(s - m)
+        l = e.sum(-1, keepdim=True)
+        o = _r((_r(e) @ vh) / l.clamp_min(1e-30))
+    else:
+        p = torch.softmax(s, -1)
+        o = p @ vh
     return o.transpose(1, 2).reshape(B, Tq, D)
 
 
@@ -112,8 +148,27 @@ def frozen_bn(x: Tensor, Pm: P, pre: str) -> Tensor:
     return x * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1)
 
 
+def _conv_bn_bf16(x: Tensor, Pm: P, conv: str, bn: str, stride: int = 1, padding: int = 0,
+                  res: Optional[Tensor] = None, relu: bool = True) -> Tensor:
+    """the HIP conv epilogue: bf16(W * scale) (*) x -> + shift -> (+ residual) -> ReLU -> bf16"""
+    if bn + 'folded_scale' in Pm:            # (tests: the fold as the device computed it -- rsqrt differs in the last fp32 bit
+        scale, shift = Pm[bn + 'folded_scale'], Pm[bn + 'folded_shift']      #  between CPU and GPU, which flips bf16 weight roundings)
+    else:
+        scale = Pm[bn + 'weight'] * (Pm[bn + 'running_var'] + 1e-5).rsqrt()
+        shift = Pm[bn + 'bias'] - Pm[bn + 'running_mean'] * scale
+    y = F.conv2d(_r(x), _r(Pm[conv] * scale.view(-1, 1, 1, 1)), stride=stride, padding=padding) + shift.view(1, -1, 1, 1)
+    if res is not None:
+        y = y + res
+    return _r(F.relu(y) if relu else y)
+
+
 def bottleneck(x: Tensor, Pm: P, pre: str, stride: int, downsample: bool) -> Tensor:
     """torchvision Bottleneck v1.5: stride lives on the 3x3."""
+    if _BF16[0]:
+        out = _conv_bn_bf16(x, Pm, pre + 'conv1.weight', pre + 'bn1.')
+        out = _conv_bn_bf16(out, Pm, pre + 'conv2.weight', pre + 'bn2.', stride=stride, padding=1)
+        idt = _conv_bn_bf16(x, Pm, pre + 'downsample.0.weight', pre + 'downsample.1.', stride=stride, relu=False) if downsample else x
+        return _conv_bn_bf16(out, Pm, pre + 'conv3.weight', pre + 'bn3.', res=idt)
     out = F.relu(frozen_bn(F.conv2d(x, Pm[pre + 'conv1.weight']), Pm, pre + 'bn1.'))
     out = F.relu(frozen_bn(F.conv2d(out, Pm[pre + 'conv2.weight'], stride=stride, padding=1), Pm, pre + 'bn2.'))
     out = frozen_bn(F.conv2d(out, Pm[pre + 'conv3.weight']), Pm, pre + 'bn3.')
@@ -123,7 +178,10 @@ def bottleneck(x: Tensor, Pm: P, pre: str, stride: int, downsample: bool) -> Ten
 
 
 def resnet50_c5(x: Tensor, Pm: P, pre: str = 'detr.backbone.0.body.') -> Tensor:
-    x = F.relu(frozen_bn(F.conv2d(x, Pm[pre + 'conv1.weight'], stride=2, padding=3), Pm, pre + 'bn1.'))
+    if _BF16[0]:
+        x = _conv_bn_bf16(x, Pm, pre + 'conv1.weight', pre + 'bn1.', stride=2, padding=3)
+    else:
+        x = F.relu(frozen_bn(F.conv2d(x, Pm[pre + 'conv1.weight'], stride=2, padding=3), Pm, pre + 'bn1.'))
     x = F.max_pool2d(x, 3, 2, 1)
     for li, (planes, nblk, stride) in enumerate(RESNET50_LAYERS, 1):
         for bi in range(nblk):
@@ -161,7 +219,7 @@ def sine_position(mask: Tensor, num_pos_feats: int = 128, temperature: float = 1
 # DETR transformer (transformer.py:46-58,148-161,211-232,94-123), batch-first internally
 # --------------------------------------------------------------------------
 def detr_encoder_layer(Pm: P, pre: str, src: Tensor, pos: Tensor, kpm: Tensor, nhead: int) -> Tensor:
-    qk = src + pos
+    qk = _r(src + pos)
     a = torch_mha(Pm, pre + 'self_attn.', qk, qk, src, nhead, kpm)
     src = layer_norm(src + a, Pm[pre + 'norm1.weight'], Pm[pre + 'norm1.bias'], 1e-5)
     f = linear(F.relu(linear(src, Pm[pre + 'linear1.weight'], Pm[pre + 'linear1.bias'])),
@@ -171,10 +229,10 @@ def detr_encoder_layer(Pm: P, pre: str, src: Tensor, pos: Tensor, kpm: Tensor, n
 
 def detr_decoder_layer(Pm: P, pre: str, tgt: Tensor, memory: Tensor, pos: Tensor, qpos: Tensor,
                        kpm: Tensor, nhead: int) -> Tensor:
-    qk = tgt + qpos
+    qk = _r(tgt + qpos)
     a = torch_mha(Pm, pre + 'self_attn.', qk, qk, tgt, nhead)
     tgt = layer_norm(tgt + a, Pm[pre + 'norm1.weight'], Pm[pre + 'norm1.bias'], 1e-5)
-    a = torch_mha(Pm, pre + 'multihead_attn.', tgt + qpos, memory + pos, memory, nhead, kpm)
+    a = torch_mha(Pm, pre + 'multihead_attn.', _r(tgt + qpos), _r(memory + pos), memory, nhead, kpm)
     tgt = layer_norm(tgt + a, Pm[pre + 'norm2.weight'], Pm[pre + 'norm2.bias'], 1e-5)
     f = linear(F.relu(linear(tgt, Pm[pre + 'linear1.weight'], Pm[pre + 'linear1.bias'])),
                Pm[pre + 'linear2.weight'], Pm[pre + 'linear2.bias'])
@@ -186,13 +244,13 @@ def detr_transformer(Pm: P, cfg, src: Tensor, mask: Tensor, pos: Tensor) -> Tupl
     pre = 'detr.transformer.'
     B, C, h, w = src.shape
     x = src.flatten(2).transpose(1, 2)      # (B,S,C)
-    pe = pos.flatten(2).transpose(1, 2)
+    pe = _r(pos.flatten(2).transpose(1, 2))
     kpm = mask.flatten(1)
     nhead = cfg['nheads']
     for i in range(cfg['num_encoder_layers']):
         x = detr_encoder_layer(Pm, f'{pre}encoder.layers.{i}.', x, pe, kpm, nhead)
     memory = x
-    qpos = Pm['detr.query_embed.weight'][None].expand(B, -1, -1)
+    qpos = _r(Pm['detr.query_embed.weight'])[None].expand(B, -1, -1)
     tgt = torch.zeros_like(qpos)
     inter = []
     for i in range(cfg['num_decoder_layers']):
@@ -304,7 +362,7 @@ def extract_roi(feat: Tensor, boxes: Tensor) -> Tensor:
     Ax = roi_axis_weights(x1.reshape(-1), (x2 - x1).reshape(-1), W).view(B, N, W)
     # roi_align has no gradient w.r.t. boxes (torchvision) -> weights are constants
     Wgt = (Ay.detach()[:, :, :, None] * Ax.detach()[:, :, None, :]).reshape(B, N, H * W)
-    return Wgt @ feat.flatten(2).transpose(1, 2)
+    return _r(_r(Wgt) @ _r(feat.flatten(2).transpose(1, 2)))
 
 
 # --------------------------------------------------------------------------
@@ -315,14 +373,17 @@ def detr_forward(Pm: P, cfg: dict, images: Tensor, mask: Tensor, training: bool 
     c5 = resnet50_c5(images, Pm)
     m = downsample_mask(mask, c5.shape[-2], c5.shape[-1])
     pos = sine_position(m, dc['hidden_dim'] // 2)
-    src = F.conv2d(c5, Pm['detr.input_proj.weight'], Pm['detr.input_proj.bias'])
+    if _BF16[0]:
+        src = _r(F.conv2d(_r(c5), _r(Pm['detr.input_proj.weight'])) + Pm['detr.input_proj.bias'].view(1, -1, 1, 1))
+    else:
+        src = F.conv2d(c5, Pm['detr.input_proj.weight'], Pm['detr.input_proj.bias'])
     hs, _ = detr_transformer(Pm, dc, src, m, pos)
     if dc['last_layer_only'] or not training:
         hs = hs[-1:]
-    logits = linear(hs, Pm['detr.class_embed.weight'], Pm['detr.class_embed.bias'])
+    logits = linear(hs, Pm['detr.class_embed.weight'], Pm['detr.class_embed.bias'], out_f32=True)
     x = hs
     for i in range(3):
-        x = linear(x, Pm[f'detr.bbox_embed.layers.{i}.weight'], Pm[f'detr.bbox_embed.layers.{i}.bias'])
+        x = linear(x, Pm[f'detr.bbox_embed.layers.{i}.weight'], Pm[f'detr.bbox_embed.layers.{i}.bias'], out_f32=(i == 2))
         if i < 2:
             x = F.relu(x)
     boxes = x.sigmoid()
@@ -347,9 +408,9 @@ def bert_forward(Pm: P, input_ids: Tensor, attention_mask: Tensor,
     if token_type_ids is None:
         token_type_ids = torch.zeros_like(input_ids)
     e = pre + 'embeddings.'
-    x = (Pm[e + 'word_embeddings.weight'][input_ids]
-         + Pm[e + 'position_embeddings.weight'][:T][None]
-         + Pm[e + 'token_type_embeddings.weight'][token_type_ids])
+    x = (_r(Pm[e + 'word_embeddings.weight'][input_ids])
+         + _r(Pm[e + 'position_embeddings.weight'][:T][None])
+         + _r(Pm[e + 'token_type_embeddings.weight'][token_type_ids]))
     x = layer_norm(x, Pm[e + 'LayerNorm.weight'], Pm[e + 'LayerNorm.bias'], 1e-12)
     kpm = attention_mask == 0
     i = 0
@@ -413,12 +474,12 @@ def answer_head(Pm: P, h: Tensor) -> Tensor:
     """answer_head.py:26-33"""
     wc = linear(Pm['answer_head.vocab_embed'], Pm['answer_head.classifier_transform.weight'],
                 Pm['answer_head.classifier_transform.bias'])
-    return h @ wc.t()
+    return _r(_r(h) @ wc.t())
 
 
 def answer_input_embed(Pm: P, ids: Tensor) -> Tensor:
     """gpv.py:46-55"""
-    e = Pm['answer_input_embedings.embedding_layer.weight'][ids]
+    e = _r(Pm['answer_input_embedings.embedding_layer.weight'][ids])
     return linear(e, Pm['answer_input_embedings.transform.weight'], Pm['answer_input_embedings.transform.bias'])
 
 
@@ -426,7 +487,7 @@ def decode_text(Pm: P, cfg: dict, target: Tensor, memory: Tensor) -> Tensor:
     """gpv.py:449-466. target (B,Tt,D) memory (B,Tm,D) -> logits (B,Tt,V)."""
     tc = cfg['text_decoder']
     if tc.get('pos_enc', False):
-        target = target + Pm['pos_enc'][0, :target.shape[1]]
+        target = _r(target + _r(Pm['pos_enc'][0, :target.shape[1]]))
     x = target
     for i in range(tc['num_layers']):
         x = text_decoder_layer(Pm, f'text_decoder.layers.{i}.', x, memory, tc['nheads'])
@@ -447,11 +508,11 @@ def gpv_encode(Pm: P, cfg: dict, images: Tensor, mask: Tensor, query_ids: Tensor
     ca = cfg['co_att']
     for i in range(ca['num_layers']):
         lv, vl = co_attention_layer(Pm, f'co_att_transformer.{i}.', lv, vl, ca['bi_num_attention_heads'])
-    rel = linear(vl, Pm['relevance_predictor.weight'], Pm['relevance_predictor.bias'])
+    rel = linear(vl, Pm['relevance_predictor.weight'], Pm['relevance_predictor.bias'], out_f32=True)
     out['pred_relevance_logits'] = out['pred_relevance_logits'] + rel
     if cfg.get('relevance_conditioning', True):          # gpv.py:364-375
         prob = out['pred_relevance_logits'].softmax(-1)   # B,R,2
-        vl = vl + prob @ Pm['relevance_tokens']
+        vl = _r(vl + prob @ Pm['relevance_tokens'])
     memory = torch.cat((vl, lv), 1)
     return out, memory
 

@@ -510,3 +510,320 @@ def test_graphed_train_step_with_frozen_backbone_equals_eager(rt, how):
     assert rel(p1, p0.cpu()) < 1e-2
     # and the trainer's stream is usable afterwards (no capture left open)
     assert not torch.cuda.is_current_stream_capturing()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# bf16 production kernels against the bf16-FAITHFUL oracle (oracle.set_bf16_faithful: rounds where the HIP path stores bf16)
+# ------------------------------------------------------------------------------------------------------------------
+GRAD_SAMPLE = [   # one parameter (at least) per backward kernel family of the bench
+    'detr.backbone.0.body.layer2.0.conv2.weight',          # 3x3 stride-2 weight gradient; its dgrad = the parity-class kernel
+    'detr.backbone.0.body.layer2.0.downsample.0.weight',   # 1x1 stride-2 weight gradient
+    'detr.backbone.0.body.layer2.1.conv2.weight',          # 3x3 weight gradient behind the streaming 3x3 backward-data kernel
+    'detr.backbone.0.body.layer2.3.conv1.weight',          # behind the streaming 1x1 backward-data kernel
+    'detr.backbone.0.body.layer3.0.conv2.weight',
+    'detr.backbone.0.body.layer3.0.downsample.0.weight',   # behind the split 1x1 stride-2 backward-data (GEMM + fill kernel)
+    'detr.backbone.0.body.layer3.3.conv1.weight',
+    'detr.backbone.0.body.layer3.5.conv3.weight',
+    'detr.backbone.0.body.layer4.0.downsample.0.weight',
+    'detr.backbone.0.body.layer4.1.conv1.weight',
+    'detr.backbone.0.body.layer4.2.conv2.weight',
+    'detr.input_proj.weight',
+    'detr.transformer.encoder.layers.0.self_attn.in_proj_weight',     # attention dQ / dK / dV (300 x 300)
+    'detr.transformer.encoder.layers.5.linear1.weight',
+    'detr.transformer.decoder.layers.0.multihead_attn.in_proj_weight',
+    'detr.transformer.decoder.layers.5.norm3.weight',
+    'detr.query_embed.weight',
+    'detr.class_embed.weight',
+    'detr.bbox_embed.layers.0.weight',
+    'detr_joiner.weight',
+    'co_att_transformer.0.biattention.value2.weight',
+    'co_att_transformer.2.v_intermediate.dense.weight',
+    'relevance_predictor.weight',
+    'text_decoder.layers.0.self_attn.in_proj_weight',
+    'text_decoder.layers.2.linear2.weight',
+    'answer_input_embedings.transform.weight',
+    'answer_head.classifier_transform.weight',
+]
+
+
+def _faithful_oracle(model, cfg, images, mask, ids, attn, tok, tg_cpu, grad_names, faithful=True):
+    """forward + criterion + backward of the (bf16-faithful | fp32) oracle on the host; returns (outputs, loss, {name: grad})"""
+    from oracle import gpv_oracle as O
+    Pm = {k: v.detach().float().cpu().contiguous() for k, v in model.state_dict().items()}
+    leaves = {n: Pm[n].clone().requires_grad_(True) for n in grad_names if n in Pm}
+    Pm.update(leaves)
+    prev = O.set_bf16_faithful(faithful)
+    try:
+        ref = O.gpv_forward(Pm, cfg, images.cpu(), mask.cpu(), ids.cpu(), attn.cpu(), tok.cpu(), training=True)
+        loss, _ = O.gpv_criterion(ref, tg_cpu, cfg['losses'])
+        loss.backward()
+    finally:
+        O.set_bf16_faithful(prev)
+    return ref, loss.detach(), {n: l.grad for n, l in leaves.items()}
+
+
+def _cmp_grads(model, grads_ref, report):
+    params = dict(model.named_parameters())
+    gmax = max(float(g.norm()) for g in grads_ref.values() if g is not None)
+    for n, gr in grads_ref.items():
+        g = params[n].grad
+        assert g is not None and gr is not None, n
+        g = g.detach().float().cpu()
+        nr, nh = float(gr.norm()), float(g.norm())
+        cos = float((g.flatten() @ gr.flatten()) / max(nr * nh, 1e-30))
+        report[n] = (abs(nh - nr) / max(nr, 1e-3 * gmax), cos, nr / gmax)
+    return report
+
+
+def _grad_rules(rep):
+    """end-to-end gradient rules against the bf16-faithful oracle.  Everything above the DETR encoder agrees in direction to
+    >= 0.99; the backbone (and what sits right on top of it) is limited by the chaos documented in DESIGN.md 4 -- the sharp check
+    of those kernels is test_backbone_blocks_at_bench_shapes_vs_bf16_faithful_oracle_isolated."""
+    bad = {}
+    for n, (nerr, cos, size) in rep.items():
+        if size < 1e-3:
+            continue                                        # round-off level gradient
+        if 'backbone' in n:
+            ok = cos >= 0.5 and nerr <= 0.3
+        elif 'input_proj' in n or 'transformer.encoder' in n:
+            ok = cos >= 0.9 and nerr <= 0.06
+        else:
+            ok = cos >= 0.99 and nerr <= 0.03
+        if not ok:
+            bad[n] = (nerr, cos, size)
+    return bad
+
+
+def test_bf16_production_path_vs_bf16_faithful_oracle_small(rt):
+    """the kernels bench.py times (bf16 storage: direct-to-LDS / pipelined / streaming GEMM + conv kernels,
+    one-block-per-head attention) against an oracle that rounds to bf16 at the same points, small fixture (96x128 images, 2+2
+    DETR layers, V = 40), forward + loss + backward.  Measured: loss 2.7e-4 (asserted 2e-3); outputs 4e-3 .. 1.1e-2 of max|ref|
+    (asserted 2e-2) -- NOT better than against the fp32 oracle, because single-ulp rounding ties (fp32 summation order) are
+    amplified by the random-init ResNet: per convolution the two agree to one bf16 ulp on all but 1e-4 of the elements (see the
+    isolated test below), after 53 convolutions the map differs by 1 % of its largest value."""
+    rt.set_precise(False)
+    model, _ = build_small()
+    model.to(DEV).train()
+    model.bert.model.p = 0.0
+    images, mask, ids, attn = batch()
+    targets = gpu_targets()
+    _, tok = model.encode_answers(targets)
+    for i, t in enumerate(targets):
+        t['answer_token_ids'] = tok[i, 1:]
+    out = model._forward_impl(nested(images, mask), (ids, attn), tok, None)
+    loss = model.criterion(out, targets)[0]
+    loss.backward()
+    cfg = synth.small_cfg(0.0)
+    cfg['_cls_id'] = V - 3
+    tg_cpu = [{k: (v.cpu() if torch.is_tensor(v) else v) for k, v in t.items()} for t in targets]
+    names = [n for n, p in model.named_parameters() if p.requires_grad and p.grad is not None and not n.startswith('bert.')]
+    ref, ref_loss, gref = _faithful_oracle(model, cfg, images, mask, ids, attn, tok, tg_cpu, names)
+    errs = {k: rel(out[k], ref[k].detach()) for k in ('pred_boxes', 'pred_relevance_logits', 'detr_hs', 'answer_logits')}
+    rep = _cmp_grads(model, gref, {})
+    print('FAITHFUL small', errs, 'loss', float(loss), float(ref_loss))
+    assert max(errs.values()) < 2e-2, errs
+    assert abs(float(loss) - float(ref_loss)) <= 2e-3 * abs(float(ref_loss))
+    bad = _grad_rules(rep)
+    assert not bad, bad
+
+
+def test_full_size_bf16_forward_and_backward_vs_bf16_faithful_oracle(rt):
+    """full-size (480x640, ResNet-50, 6+6, Q = 100, 12-layer BERT, V = 10000, B = 2: one caption + one
+    detection sample) forward, loss AND backward of the production bf16 path against the bf16-faithful oracle's autograd;
+    gradients of one parameter per backward kernel family (GRAD_SAMPLE) by norm and direction; the direct-to-LDS / pipelined /
+    streaming kernels are asserted to have run.  Tolerances are stated below next to what was measured.  (Precise mode at this
+    size: weight-gradient cosine >= 0.9995 against the fp32 oracle for the same parameters, gpurun_exp/dbg_grad.py.)"""
+    import gpv1_amd.hip as hip
+    Vf, Bf = 10000, 2
+    rt.set_precise(False)
+    model = full_model(Vf, dropout=0.0)
+    model.bert.model.p = 0.0
+    model.train()
+    g, images, mask, ids, attn = _full_batch(Bf, Vf)
+    tg = [{'task': 'CocoCaptioning', 'answer': ' '.join(f'w{(37 * j) % (Vf - 4)}' for j in range(18))},
+          {'task': 'CocoDetection', 'boxes': torch.tensor([[0.5, 0.5, 0.2, 0.3], [0.3, 0.6, 0.1, 0.15], [0.7, 0.3, 0.25, 0.2]], device=DEV),
+           'labels': torch.zeros(3, dtype=torch.long, device=DEV)}]
+    _, tok = model.encode_answers(tg)
+    for i, t in enumerate(tg):
+        t['answer_token_ids'] = tok[i, 1:]
+    for opt in (hip.OPT_GLDS_LAUNCHES, hip.OPT_PIPE_LAUNCHES, hip.OPT_C3S_LAUNCHES):
+        hip.set_option(opt, 0)
+    out = model._forward_impl(nested(images, mask), (ids, attn), tok, None)
+    loss = model.criterion(out, tg)[0]
+    loss.backward()
+    counts = [hip.set_option(opt, 0) for opt in (hip.OPT_GLDS_LAUNCHES, hip.OPT_PIPE_LAUNCHES, hip.OPT_C3S_LAUNCHES)]
+    assert counts[0] + counts[1] > 40, counts
+    torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
+    cfg = synth.model_cfg(vocab=synth.make_vocab(Vf))
+    cfg['detr']['dropout'] = 0.0
+    cfg['_cls_id'] = Vf - 3
+    tg_cpu = [{k: (v.cpu() if torch.is_tensor(v) else v) for k, v in t.items()} for t in tg]
+    ref, ref_loss, gref = _faithful_oracle(model, cfg, images, mask, ids, attn, tok, tg_cpu, GRAD_SAMPLE)
+    assert set(gref) == set(GRAD_SAMPLE)
+    errs = {k: rel(out[k], ref[k].detach()) for k in ('pred_boxes', 'pred_relevance_logits', 'detr_hs', 'answer_logits')}
+    rep = _cmp_grads(model, gref, {})
+    print('FAITHFUL full', errs, 'loss', float(loss), float(ref_loss))
+    for n, v in rep.items():
+        print('  grad %-70s norm err %.4f cos %.5f rel size %.3g' % (n, v[0], v[1], v[2]))
+    # measured: loss 5.8e-4; boxes 1.8e-3, decoder states 8e-3, answer logits 8e-3, relevance logits 2.9e-2 of max|ref| (small
+    # numbers behind the chaotic backbone, see the small-fixture test); gradient cosines 0.996 .. 1.0000 above the encoder,
+    # 0.958 / 0.985 for encoder layer 0 / input_proj, 0.61 .. 0.98 inside the backbone -- the same figures the fp32 oracle and the
+    # faithful oracle have between THEMSELVES (0.63 .. 0.95): chaos of the random-init ResNet, not kernels
+    assert max(errs.values()) < 5e-2, errs
+    assert abs(float(loss) - float(ref_loss)) <= 3e-3 * abs(float(ref_loss))
+    bad = _grad_rules(rep)
+    assert not bad, bad
+
+
+def _ulp_stats(a, ref):
+    """a, ref: bf16-representable values.  -> (largest |a - ref| in units of ref's bf16 spacing, fraction of elements that differ)"""
+    a, ref = a.detach().float().cpu(), ref.detach().float().cpu()
+    d = (a - ref).abs()
+    # bf16: 8 significand bits.  Magnitudes are floored at 2^-6 of the tensor's largest, i.e. differences below 2^-13 = 1.2e-4 of
+    # max|ref| count as at most one unit: that is the fp32 summation-order noise of a K = 10^3 reduction with cancellation, which
+    # near a ReLU's zero is "0 vs 1e-4", not hundreds of ulps of the tiny value
+    mag = torch.maximum(a.abs(), ref.abs()).clamp_min(float(ref.abs().max()) * 2.0 ** -6)
+    spacing = torch.pow(2.0, torch.floor(torch.log2(mag)) - 7)
+    return float((d / spacing).max()), float((d > 0).float().mean())
+
+
+@pytest.mark.parametrize('layer', [1, 2, 3, 4])
+def test_backbone_blocks_at_bench_shapes_vs_bf16_faithful_oracle_isolated(rt, layer):
+    """What the end-to-end bf16 comparison cannot show: a random-init ResNet amplifies single-ulp rounding flips chaotically
+    (oracle fp32 vs oracle bf16-faithful, both CPU autograd: cosine 0.63 on layer2 weight gradients -- see DESIGN.md 4), so a
+    whole-model tolerance hides kernel bugs.  Here every bottleneck block runs ISOLATED at the BENCH shapes (B = 32, 480 x 640:
+    the very launches bench.py times -- streaming 1x1 / 3x3, direct-to-LDS, pipelined, parity-class and split stride-2 kernels,
+    direct-to-LDS weight gradients): the oracle block gets the HIP block's own input.
+      forward, per convolution (the oracle conv gets the HIP conv's own input): every output within ONE bf16 ulp, < 0.2 % of the
+      elements differ at all (fp32 summation order at rounding ties);
+      backward (layer2-4, pairs of consecutive blocks so that conv1 / downsample backward-data are inside): weight-gradient
+      cosine >= 0.9995 and norm within 0.8 % against the oracle's autograd through the same two blocks."""
+    import gpv1_amd.backbone as bbm
+    import gpv1_amd.hip as hip
+    from oracle import gpv_oracle as O
+    rt.set_precise(False)
+    Bn = int(os.environ.get('GPV_TEST_BLOCK_B', '32'))
+    torch.manual_seed(3)
+    body = bbm.ResNetBody().to(DEV)
+    for n, buf in body.named_buffers():
+        if n.endswith('running_var'):
+            buf.uniform_(0.5, 1.5)
+        elif n.endswith('running_mean'):
+            buf.normal_(0, 0.1)
+        elif n.endswith('bias'):
+            buf.normal_(0, 0.1)
+        elif n.endswith('weight'):
+            buf.uniform_(0.8, 1.2)
+    for n, p in body.named_parameters():
+        p.requires_grad_(not n.startswith('conv1'))
+    rt.bump_weights()
+    Pm = {k: v.detach().float().cpu().contiguous() for k, v in body.state_dict().items()}
+    for n, m in body.named_modules():
+        if isinstance(m, bbm.FrozenBatchNorm2d):
+            sc, sh = m.scale_shift()                       # the FrozenBN fold exactly as the device computes it
+            Pm[n + '.folded_scale'], Pm[n + '.folded_shift'] = sc.cpu(), sh.cpu()
+    images = torch.randn(Bn, 3, 480, 640, device=DEV)
+    torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
+    hip.set_option(hip.OPT_C3S_LAUNCHES, 0)
+    with torch.no_grad():
+        keep = []
+        body.forward_nhwc(images, keep)
+    assert len(keep) == 16
+    names = [f'layer{li}.{bi}' for li, (_, nb, _) in enumerate(O.RESNET50_LAYERS, 1) for bi in range(nb)]
+    idx = [i for i, n in enumerate(names) if n.startswith(f'layer{layer}.')]
+    prev = O.set_bf16_faithful(True)
+    try:
+        for i in idx:
+            blk, x, a1, a2, yb, _ = keep[i]
+            li, bi = int(names[i][5]), int(names[i][7:])
+            stride = O.RESNET50_LAYERS[li - 1][2] if bi == 0 else 1
+            # ---- forward, every convolution isolated: the oracle conv gets the HIP conv's own input ----
+            nchw = lambda t: t.permute(0, 3, 1, 2).float().cpu()
+            pre = names[i] + '.'
+            with torch.no_grad():
+                idt_h = x if bi != 0 else bbm._conv_fwd(x, blk.downsample[0], blk.downsample[1], False, hip.ACT_NONE)
+                checks = [('conv1', a1, O._conv_bn_bf16(nchw(x), Pm, pre + 'conv1.weight', pre + 'bn1.')),
+                          ('conv2', a2, O._conv_bn_bf16(nchw(a1), Pm, pre + 'conv2.weight', pre + 'bn2.', stride=stride, padding=1)),
+                          ('conv3', yb, O._conv_bn_bf16(nchw(a2), Pm, pre + 'conv3.weight', pre + 'bn3.', res=nchw(idt_h)))]
+                if bi == 0:
+                    checks.append(('downsample', idt_h, O._conv_bn_bf16(nchw(x), Pm, pre + 'downsample.0.weight', pre + 'downsample.1.',
+                                                                      stride=stride, relu=False)))
+            for cn, got, want in checks:
+                ulps, frac = _ulp_stats(nchw(got), want)
+                print('BLOCK fwd %s.%s: max %.2f ulp, %.5f of the elements differ' % (names[i], cn, ulps, frac))
+                assert ulps <= 2.0 and frac < 0.002, (names[i], cn, ulps, frac)      # measured: 1.00 ulp, <= 1.5e-4 of the elements (2: one ulp across a binade boundary)
+            del checks
+            # ---- backward of the pair (i - 1, i), isolated ----
+            if layer == 1 or i == 0:
+                continue
+            j = i - 1 if names[i - 1].startswith('layer1') is False else None
+            pair = [keep[i]] if j is None else [keep[j], keep[i]]
+            pnames = [names[i]] if j is None else [names[j], names[i]]
+            for b_, *_ in pair:
+                for c, _ in b_.convs():
+                    c.weight.grad = None
+            g = torch.Generator(device='cpu').manual_seed(100 + i)
+            dy = (torch.randn(yb.shape, generator=g) * 0.1).to(torch.bfloat16)
+            ents = [tuple(e[:5]) + (k > 0,) for k, e in enumerate(pair)]
+            with torch.no_grad():
+                body.backward_nhwc(ents, dy.to(DEV))
+            x0 = pair[0][1].permute(0, 3, 1, 2).float().cpu()
+            leaves = {}
+            Pg = dict(Pm)
+            for pn in pnames:
+                for cn in ('conv1', 'conv2', 'conv3', 'downsample.0'):
+                    k = f'{pn}.{cn}.weight'
+                    if k in Pm:
+                        leaves[k] = Pm[k].clone().requires_grad_(True)
+            Pg.update(leaves)
+            h = x0
+            for pn in pnames:
+                l2, b2 = int(pn[5]), int(pn[7:])
+                h = O.bottleneck(h, Pg, pn + '.', O.RESNET50_LAYERS[l2 - 1][2] if b2 == 0 else 1, b2 == 0)
+            h.backward(dy.float().permute(0, 3, 1, 2))
+            P = dict(body.named_parameters())
+            for k, leaf in leaves.items():
+                gh, gr = P[k].grad.detach().float().cpu(), leaf.grad
+                # the HIP gradient carries the FrozenBN scale of its layer in the weight gradient (rowscale); so does autograd here
+                c = float((gh.flatten().double() @ gr.flatten().double()) / (gh.norm().double() * gr.norm().double()).clamp_min(1e-30))
+                ne = abs(float(gh.norm()) - float(gr.norm())) / float(gr.norm())
+                print('BLOCK bwd %-34s cos %.6f norm err %.5f' % (k, c, ne))
+                assert c >= 0.9995 and ne <= 0.008, (k, c, ne)             # measured: >= 0.99981, <= 0.0038
+            del h, leaves, Pg
+    finally:
+        O.set_bf16_faithful(prev)
+    if layer in (1, 2):
+        assert hip.set_option(hip.OPT_C3S_LAUNCHES, 0) >= 3          # the streaming 3x3 kernel ran at these shapes
+
+
+def test_full_size_precise_backward_vs_fp32_oracle(rt):
+    """north_star's 1e-3 bar on the BACKWARD at full size (480x640, 6+6, Q = 100, V = 10000, B = 2: caption + detection sample):
+    precise mode (fp32 storage, split-bf16 MFMA) against the fp32 oracle's autograd -- the pinned restatement of the reference --
+    for one parameter per backward kernel family: weight-gradient direction (cosine >= 0.999; measured >= 0.9995, the rest is
+    ReLU flips at |pre-activation| ~ 1e-7) and norm within 1 % (2 % inside the backbone: measured 1.1 % on layer2)."""
+    Vf, Bf = 10000, 2
+    rt.set_precise(True)
+    model = full_model(Vf, dropout=0.0)
+    model.bert.model.p = 0.0
+    model.train()
+    g, images, mask, ids, attn = _full_batch(Bf, Vf)
+    tg = [{'task': 'CocoCaptioning', 'answer': ' '.join(f'w{(37 * j) % (Vf - 4)}' for j in range(18))},
+          {'task': 'CocoDetection', 'boxes': torch.tensor([[0.5, 0.5, 0.2, 0.3], [0.3, 0.6, 0.1, 0.15], [0.7, 0.3, 0.25, 0.2]], device=DEV),
+           'labels': torch.zeros(3, dtype=torch.long, device=DEV)}]
+    _, tok = model.encode_answers(tg)
+    for i, t in enumerate(tg):
+        t['answer_token_ids'] = tok[i, 1:]
+    out = model._forward_impl(nested(images, mask), (ids, attn), tok, None)
+    loss = model.criterion(out, tg)[0]
+    loss.backward()
+    torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
+    cfg = synth.model_cfg(vocab=synth.make_vocab(Vf))
+    cfg['detr']['dropout'] = 0.0
+    cfg['_cls_id'] = Vf - 3
+    tg_cpu = [{k: (v.cpu() if torch.is_tensor(v) else v) for k, v in t.items()} for t in tg]
+    ref, ref_loss, gref = _faithful_oracle(model, cfg, images, mask, ids, attn, tok, tg_cpu, GRAD_SAMPLE, faithful=False)
+    assert abs(float(loss) - float(ref_loss)) <= 1e-3 * abs(float(ref_loss))
+    rep = _cmp_grads(model, gref, {})
+    bad = {n: v for n, v in rep.items() if v[2] >= 1e-3 and (v[1] < 0.999 or v[0] > (0.02 if 'backbone' in n else 0.01))}
+    assert not bad, bad
+    rt.set_precise(False)
