@@ -26,6 +26,15 @@ from .position_encoding import build_position_encoding
 
 RELU = hip.ACT_RELU
 FUSED_STEM = os.environ.get('GPV_FUSED_STEM', '1') != '0'
+WGRAD_STREAM = os.environ.get('GPV_WGRAD_STREAM', '1') != '0'
+_WSTREAMS = {}
+
+
+def _wgrad_stream(dev):
+    st = _WSTREAMS.get(dev)
+    if st is None:
+        st = _WSTREAMS[dev] = torch.cuda.Stream(device=dev)
+    return st
 PROF = None     # bench.py sets this to a list: (tag, start_event, end_event) per backbone forward / backward
 
 
@@ -245,31 +254,54 @@ class ResNetBody(nn.Module):
             seen_trainable = True
 
     def backward_nhwc(self, keep, dc5):
-        """dc5: gradient w.r.t. the (post-ReLU) c5 output, [B,h,w,2048] compute dtype."""
+        """dc5: gradient w.r.t. the (post-ReLU) c5 output, [B,h,w,2048] compute dtype.
+
+        The backward-data convolutions form a serial chain; the 42 weight gradients hang off it and nobody needs them before the
+        optimizer.  They run on a SIDE stream (a parallel branch when the pass is captured into a hipGraph): each is ordered
+        behind the backward-data launch that produced its dy, the chain never waits for them, one join at the end.  Both kinds
+        of launch fill the chip on their own but neither keeps it busy (prologues, tails, split-reduction passes): together
+        they do -- GPV_WGRAD_STREAM=0 puts them back in line."""
         if not keep:
             return
+        dev = dc5.device
+        main = torch.cuda.current_stream(dev) if dev.type == 'cuda' else None
+        side = _wgrad_stream(dev) if (main is not None and WGRAD_STREAM) else None
+        held = []                                        # operands of the side-stream launches stay referenced until the join
+
+        def wgrad(xa, dy, conv, bn):
+            if not conv.weight.requires_grad:
+                return
+            if side is None:
+                _conv_wgrad(xa, dy, conv, bn)
+                return
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                _conv_wgrad(xa, dy, conv, bn)
+            held.append((xa, dy))
         y_last = keep[-1][4]
         gz = torch.empty_like(y_last)
         hip.act_bwd(dc5.contiguous(), y_last, gz, gz.numel(), RELU, 1.0)          # through the final ReLU
         for blk, x, a1, a2, yb, need_dx in reversed(keep):
             # gz = gradient w.r.t. (conv3 + shift + identity), i.e. already masked by (yb > 0)
-            _conv_wgrad(a2, gz, blk.conv3, blk.bn3)
+            wgrad(a2, gz, blk.conv3, blk.bn3)
             g2 = _conv_dgrad(gz, blk.conv3, blk.bn3, a2.shape, relu_mask=a2)
-            _conv_wgrad(a1, g2, blk.conv2, blk.bn2)
+            wgrad(a1, g2, blk.conv2, blk.bn2)
             g1 = _conv_dgrad(g2, blk.conv2, blk.bn2, a1.shape, relu_mask=a1)
-            del g2
-            _conv_wgrad(x, g1, blk.conv1, blk.bn1)
+            wgrad(x, g1, blk.conv1, blk.bn1)
             if blk.downsample is not None:
-                _conv_wgrad(x, gz, blk.downsample[0], blk.downsample[1])
+                wgrad(x, gz, blk.downsample[0], blk.downsample[1])
             if not need_dx:
                 break
             if blk.downsample is not None:
-                side = _conv_dgrad(gz, blk.downsample[0], blk.downsample[1], x.shape)
+                side_g = _conv_dgrad(gz, blk.downsample[0], blk.downsample[1], x.shape)
             else:
-                side = gz
+                side_g = gz
             # input gradient, masked by the previous block's ReLU (x is that block's output)
-            gz = _conv_dgrad(g1, blk.conv1, blk.bn1, x.shape, res=side, relu_mask=x)
-            del g1, side
+            gz = _conv_dgrad(g1, blk.conv1, blk.bn1, x.shape, res=side_g, relu_mask=x)
+            del g1, g2, side_g
+        if side is not None:
+            main.wait_stream(side)
+        del held
 
 
 class ResNetFn(Function):

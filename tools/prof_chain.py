@@ -8,7 +8,8 @@ back = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 trace = list(csv.DictReader(open(glob.glob(os.path.join(d, '**', '*kernel_trace.csv'), recursive=True)[0])))
 trace.sort(key=lambda r: int(r['Start_Timestamp']))
 idx = [i for i, r in enumerate(trace) if 'image_to_nhwc4' in r['Kernel_Name']]
-a, b = idx[-1 - back], idx[-back]
+steps = [(a, b) for a, b in zip(idx[:-1], idx[1:]) if any('adamw' in r['Kernel_Name'] for r in trace[a:b])]      # (the isolated conv loop prepares images too)
+a, b = steps[-back]
 seq = trace[a:b]
 t0 = int(seq[0]['Start_Timestamp'])
 end = t0
