@@ -57,13 +57,14 @@ class TextDecoderLayer(nn.Module):
         self.norm1, self.norm2, self.norm3 = LayerNormP(d_model), LayerNormP(d_model), LayerNormP(d_model)
         self.p = dropout
 
-    def forward(self, tgt, memory, B, Tt, Tm, mem_chain=None):
+    def forward(self, tgt, memory, B, Tt, Tm, mem_chain=None, mem_kpm=None):
         p = self.p if self.training else 0.0
         c0 = ops.grad_chain(tgt)                       # (ops.GradChain: tgt feeds the projection and the residual)
         tgt = self.norm1(tgt, self.self_attn(tgt, tgt, tgt, B, Tt, Tt, causal=True, chains=(c0, c0, c0)), p, chain=c0)
         c1 = ops.grad_chain(tgt)
-        tgt = self.norm2(tgt, self.multihead_attn(tgt, memory, memory, B, Tt, Tm, chains=(c1, mem_chain, mem_chain)), p,
-                         chain=c1)                     # no memory padding mask
+        tgt = self.norm2(tgt, self.multihead_attn(tgt, memory, memory, B, Tt, Tm, key_padding_mask=mem_kpm,
+                                                  chains=(c1, mem_chain, mem_chain)), p,
+                         chain=c1)                     # no memory padding mask in the reference (mem_kpm: size-class padding only)
         return ffn_block(tgt, self.linear1, self.linear2, self.norm3, p)
 
 
@@ -182,7 +183,7 @@ class GPV(nn.Module):
         self.load_state_dict(cur)
 
     # ------------------------------------------------------------------ encoder shared by all branches
-    def _encode(self, images, queries, query_encodings=None):
+    def _encode(self, images, queries, query_encodings=None, lang_extra=None):
         """query_encodings: BERT features computed by the caller (train.GraphedBody runs the frozen, no_grad BERT as a
         parallel branch of the backbone's hipGraph: 110 launches of <= 144 workgroups hide under the convolutions)"""
         outputs = self.detr(images)
@@ -199,7 +200,7 @@ class GPV(nn.Module):
         Tv = vl.shape[1]
         lv2, vl2 = lv.reshape(B * Tl, D), vl.reshape(B * Tv, D)
         for layer in self.co_att_transformer:
-            lv2, vl2 = layer(lv2, vl2, B, Tl, Tv)
+            lv2, vl2 = layer(lv2, vl2, B, Tl, Tv, kpm1=lang_extra)
         rel = self.relevance_predictor(vl2, out_f32=True).reshape(B, Tv, -1)       # fp32
         outputs['pred_relevance_logits'] = outputs['pred_relevance_logits'] + rel
         if self.cfg.detr.aux_loss:
@@ -210,7 +211,7 @@ class GPV(nn.Module):
         memory = torch.cat((vl2.reshape(B, Tv, D), lv2.reshape(B, Tl, D)), 1)      # [B, Tv+Tl, D]
         return outputs, memory
 
-    def decode_text(self, target, memory):
+    def decode_text(self, target, memory, mem_kpm=None):
         """target [B,Tt,D], memory [B,Tm,D] -> logits [B,Tt,V]   (gpv.py:449-466)"""
         B, Tt, D = target.shape
         Tm = memory.shape[1]
@@ -220,7 +221,7 @@ class GPV(nn.Module):
         mem = memory.reshape(B * Tm, D)
         mem_chain = ops.grad_chain(mem)                # the co-attention output feeds the K|V projection of every layer
         for layer in self.text_decoder.layers:
-            x = layer(x, mem, B, Tt, Tm, mem_chain)
+            x = layer(x, mem, B, Tt, Tm, mem_chain, mem_kpm)
         return self.answer_head(x).reshape(B, Tt, -1)
 
     # ------------------------------------------------------------------ reference API
@@ -275,8 +276,12 @@ class GPV(nn.Module):
         torch.cuda.current_stream().synchronize()       # see decode.py: graph launches are not left queued behind a busy GPU
         return res
 
-    def _forward_impl(self, images, queries, answer_token_ids, targets=None, vocab_mask=None, kv_graphs=None, query_encodings=None):
-        outputs, memory = self._encode(images, queries, query_encodings)
+    def _forward_impl(self, images, queries, answer_token_ids, targets=None, vocab_mask=None, kv_graphs=None, query_encodings=None,
+                      lang_extra=None):
+        """lang_extra (uint8 [B, T_l], 1 = a query token beyond the batch's own longest query): the trainer pads queries to a few
+        size classes so that one captured hipGraph serves many batches (train.FlatTrainer); those tokens are masked as keys in the
+        co-attention and in the text decoder's memory, which reproduces the unpadded batch exactly.  Teacher forcing only."""
+        outputs, memory = self._encode(images, queries, query_encodings, lang_extra)
         B = memory.shape[0]
         dev = memory.device
         if answer_token_ids is None:                                               # greedy, gpv.py:178-196
@@ -293,7 +298,11 @@ class GPV(nn.Module):
                 outputs['answer_logits'] = self.greedy_full_prefix(memory, vocab_mask)
         else:                                                                      # teacher forcing, :197-201
             target = self.answer_input_embedings(answer_token_ids.to(dev))
-            outputs['answer_logits'] = self.decode_text(target, memory)[:, :-1].unsqueeze(0)
+            mem_kpm = None
+            if lang_extra is not None:                                             # memory = [vision tokens | language tokens]
+                Tv = memory.shape[1] - lang_extra.shape[1]
+                mem_kpm = torch.cat((torch.zeros(B, Tv, dtype=torch.uint8, device=dev), lang_extra), 1).contiguous()
+            outputs['answer_logits'] = self.decode_text(target, memory, mem_kpm)[:, :-1].unsqueeze(0)
         if targets is None:
             return outputs
         return self.criterion(outputs, targets)[0]
@@ -391,6 +400,13 @@ class GPV(nn.Module):
 
     def encode_answers(self, targets):
         """gpv.py:377-430 (generation branch)"""
+        padded_inputs, ids = self._encode_answers_host(targets)
+        dev = self.vision_token.device
+        from .misc import STAGER
+        return padded_inputs, STAGER.to_device(ids, torch.long, dev)          # no host<->device sync (misc.PinnedStager)
+
+    def _encode_answers_host(self, targets):
+        """-> (token strings per sample padded to the batch's longest, their vocabulary ids as host lists)"""
         answers = [t.get('answer', '') for t in targets]
         padded_inputs, S = [], 0
         for a in answers:
@@ -401,9 +417,22 @@ class GPV(nn.Module):
         for toks in padded_inputs:
             toks.extend(['__pad__'] * (S - len(toks)))
             ids.append([self.word_to_idx.get(w, self.word_to_idx['__unk__']) for w in toks][:self.cfg.max_text_len])
+        return padded_inputs, ids
+
+    def encode_answers_classed(self, targets, multiple=4):
+        """encode_answers (gpv.py:377-430) with the token axis padded up to a multiple of `multiple` (<= max_text_len):
+        -> (input token ids [B, S_c] padded with __pad__, CE targets [B, S_c - 1] with -100 beyond the batch's own length S).
+        The decoder is causal and the cross-entropy ignores -100 rows, so logits, loss and gradients of the first S - 1 positions
+        are those of the unpadded batch (pad positions INSIDE the batch's own length stay targets, as in the reference)."""
+        _, padded = self._encode_answers_host(targets)
+        S = len(padded[0])
+        Sc = min(self.cfg.max_text_len, -(-S // multiple) * multiple)
+        pad = self.word_to_idx['__pad__']
+        ids = [row + [pad] * (Sc - len(row)) for row in padded]
+        tgt = [row[1:] + [-100] * (Sc - len(row)) for row in padded]
         dev = self.vision_token.device
         from .misc import STAGER
-        return padded_inputs, STAGER.to_device(ids, torch.long, dev)          # no host<->device sync (misc.PinnedStager)
+        return STAGER.to_device(ids, torch.long, dev), STAGER.to_device(tgt, torch.long, dev), S
 
     def token_ids_to_words(self, token_ids):
         B, S = token_ids.shape

@@ -47,9 +47,9 @@ class PinnedStager:
     """small host->device transfers without a host<->device synchronisation: a pageable-memory copy
     (`torch.tensor(list, device='cuda')`) waits for everything queued on the stream, i.e. the previous training step.
     A ring of pinned staging buffers + non_blocking copies keeps the host free to run ahead; the ring is deep enough
-    (8 slots, each protected by the event of its last copy) that a slot is never rewritten while its copy is pending."""
+    (32 slots -- a training step stages up to five small tensors --, each protected by the event of its last copy) that a slot is never rewritten while its copy is pending."""
 
-    def __init__(self, slots=8, nbytes=1 << 16):
+    def __init__(self, slots=32, nbytes=1 << 16):
         self.slots, self.nbytes, self.bufs, self.events, self.i = slots, nbytes, None, None, 0
 
     def to_device(self, data, dtype, device):
@@ -63,7 +63,7 @@ class PinnedStager:
         k = self.i
         self.i = (k + 1) % self.slots
         if self.events[k] is not None:
-            self.events[k].synchronize()                      # only ever waits when the host is 8 transfers ahead
+            self.events[k].synchronize()                      # only ever waits when the host is 32 transfers ahead
         n = t.numel() * t.element_size()
         host = self.bufs[k][:n].view(dtype).view(t.shape)
         host.copy_(t)

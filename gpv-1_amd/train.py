@@ -15,6 +15,7 @@ MI355X-first choices
   * torch-1.6 optimizer semantics kept: a parameter is only updated (incl. weight decay) once it has
     received a gradient at least once; the touched set is agreed across ranks (MAX all-reduce).
 """
+import collections
 import gc
 import os
 import time
@@ -88,7 +89,7 @@ class GraphedBody:
 
     GRAD_KEYS = ('answer_logits', 'pred_relevance_logits', 'pred_boxes')
 
-    def __init__(self, trainer, images, queries, tok):
+    def __init__(self, trainer, images, queries, tok, lang_extra=None):
         from .misc import NestedTensor
         self.tr = trainer
         model = trainer.model
@@ -97,6 +98,7 @@ class GraphedBody:
         self.all_valid = getattr(images, 'all_valid', None)
         self.s_ids, self.s_attn = queries[0].clone(), queries[1].clone()
         self.s_tok = tok.clone()
+        self.s_extra = None if lang_extra is None else lang_extra.clone()      # size-class padding of the queries (FlatTrainer._classed)
         self.epochs = (RT.static_epoch, RT.dtype)
         self.keep, self.c5, self.c5_leaf = None, None, None
         self.variants = {}
@@ -127,7 +129,7 @@ class GraphedBody:
                     q_enc, _ = model.bert((self.s_ids, self.s_attn))
             self.q_enc = q_enc
             self.outs = model._forward_impl(NestedTensor(self.s_img, self.s_mask, self.all_valid), (self.s_ids, self.s_attn),
-                                            self.s_tok, None, query_encodings=q_enc)
+                                            self.s_tok, None, query_encodings=q_enc, lang_extra=self.s_extra)
             if self._open is not self.f2:
                 raise RuntimeError('GraphedBody: the model never reached backbone_forward (F1 was not closed)')
             torch.cuda.current_stream(dev).wait_stream(self.wside)          # join the weight-mirror branch
@@ -202,7 +204,7 @@ class GraphedBody:
     def stale(self):
         return self.epochs != (RT.static_epoch, RT.dtype)
 
-    def forward(self, images, queries, tok):
+    def forward(self, images, queries, tok, lang_extra=None):
         """replay F1 + F2 on the current stream; returns the outputs dict as fresh autograd leaves"""
         from . import backbone as bbm
         self.s_img.copy_(images.tensors, non_blocking=True)
@@ -210,6 +212,8 @@ class GraphedBody:
         self.s_ids.copy_(queries[0], non_blocking=True)
         self.s_attn.copy_(queries[1], non_blocking=True)
         self.s_tok.copy_(tok, non_blocking=True)
+        if self.s_extra is not None:
+            self.s_extra.copy_(lang_extra, non_blocking=True)
         RT.seed_dev.add_(1)
         ev = bbm._prof('conv_fwd')
         self.f1.replay()
@@ -376,7 +380,10 @@ class FlatTrainer:
         self.epoch, self.it_in_epoch = 0, 0
         # hipGraph replay of the model body (GraphedBody): default on for bf16 on the GPU; GPV_TRAIN_GRAPHS=0 turns it off
         self.graphs = (os.environ.get('GPV_TRAIN_GRAPHS', '1') != '0') if graphs is None else bool(graphs)
-        self._bodies, self._seen, self.stream = {}, {}, None
+        self._bodies, self._seen, self.stream = collections.OrderedDict(), {}, None      # captured bodies, least recently used first
+        self.graph_slots = int(os.environ.get('GPV_TRAIN_GRAPH_SLOTS', '8'))             # each body pins its activation pool (a few GB at B = 32)
+        self.graph_steps, self.eager_steps = 0, 0
+        self._extra_cache = {}
         self.defer_wgrad = None          # decided below (single rank only): model-body weight gradients as a branch of the backbone backward graph
         # Python's cyclic collector costs 1-3 ms per step once it has a few hundred thousand module / tensor objects to
         # walk (measured: 970-1020 vs 1062-1070 images/s over 20 steps), while a step leaves ~17 small cycles and no
@@ -711,13 +718,25 @@ class FlatTrainer:
                 gc.collect()
         if not model.training:                      # nn.Module.train() walks ~600 modules (0.66 ms): only when needed
             model.train()
-        _, answer_token_ids = model.encode_answers(targets)
-        for i, t in enumerate(targets):
-            t['answer_token_ids'] = answer_token_ids[i, 1:]
-        body = self._graphed_body(images, queries, answer_token_ids)
-        if body is not None:
-            return self._train_step_graphed(body, images, queries, answer_token_ids, targets)
-        loss = model(images, queries, answer_token_ids, targets)
+        lang_extra, orig_queries = None, queries
+        cls = self._classed(images, queries, targets)
+        if cls is not None:
+            # hipGraph path: string queries are tokenised here on the host; query and answer token axes are padded to a few size
+            # classes with the padding masked out exactly (GPV._forward_impl `lang_extra`, CE target -100), so one captured body
+            # serves every batch of its class with the numerics of the unpadded batch
+            queries, lang_extra, answer_token_ids, ce_targets = cls
+            for i, t in enumerate(targets):
+                t['answer_token_ids'] = ce_targets[i]
+            body = self._graphed_body(images, queries, answer_token_ids, lang_extra)
+            if body is not None:
+                self.graph_steps += 1
+                return self._train_step_graphed(body, images, queries, answer_token_ids, targets, lang_extra, orig_queries)
+        else:
+            _, answer_token_ids = model.encode_answers(targets)
+            for i, t in enumerate(targets):
+                t['answer_token_ids'] = answer_token_ids[i, 1:]
+        self.eager_steps += 1
+        loss = model._forward_impl(images, queries, answer_token_ids, targets, lang_extra=lang_extra)
         # The reference skips the update when no criterion applies to the batch (losses.py:163-169, train_distr.py:420); under
         # its DDP a rank-local skip leaves the other ranks waiting in the gradient all-reduce forever.  Here the ranks agree on
         # the host (one int through gloo, issued while the GPU still runs the forward): nobody has a loss -> everyone skips
@@ -734,17 +753,67 @@ class FlatTrainer:
         return None if loss is None else loss.detach()     # (a stashed loss would keep the step's autograd graph alive)
 
     # ---- hipGraph path ----
-    def _graphed_body(self, images, queries, tok):
-        """the GraphedBody for this batch signature, captured the second time the signature is seen (the first, eager,
-        step is the warm-up: weight copies, kernel attributes, workspaces); None -> eager step"""
+    # size classes of the token axes: query tokens in multiples of 8 (device-tensor queries of <= 8 tokens are taken as they are),
+    # answer tokens in multiples of 8 up to max_text_len -- six signatures cover T_l <= 16 x S <= 20; every signature costs one
+    # eager warm-up step and one capture, every captured body pins its activation pool
+    T_EXACT, T_STEP, S_STEP = 8, 8, 8
+
+    def _graphs_apply(self, images):
         from .misc import NestedTensor
-        if not self.graphs or not isinstance(images, NestedTensor) or not torch.is_tensor(images.tensors) \
-                or not images.tensors.is_cuda or images.mask is None or RT.dtype != torch.bfloat16 \
-                or not isinstance(queries, (tuple, list)) or len(queries) != 2 or not all(torch.is_tensor(q) for q in queries) \
-                or torch.cuda.is_current_stream_capturing():
+        return bool(self.graphs) and isinstance(images, NestedTensor) and torch.is_tensor(images.tensors) and images.tensors.is_cuda \
+            and images.mask is not None and RT.dtype == torch.bfloat16 and not torch.cuda.is_current_stream_capturing()
+
+    def _classed(self, images, queries, targets):
+        """-> ((ids, attn) [B, T_c], lang_extra uint8 [B, T_c], answer ids [B, S_c], CE targets [B, S_c - 1]) on the device, or None
+        when the graph path does not apply (then the step runs as the reference does, on the batch's own lengths).
+        The reference pads a batch to ITS longest query / answer (bert.py:12-15 padding=True, gpv.py:377-430) and both lengths
+        enter the numerics (padded BERT tokens are attended by the co-attention, pad answer tokens are CE targets), so a captured
+        graph is only valid for one (T, S).  Real batches vary in both: the token axes are therefore padded on to a few size
+        classes and the EXTRA positions are masked out exactly -- query tokens beyond the batch's longest as attention keys,
+        answer positions beyond the batch's longest as CE rows -- which leaves loss and gradients those of the unpadded batch."""
+        if not self._graphs_apply(images):
+            return None
+        from .misc import STAGER
+        model, dev = self.model, images.tensors.device
+        if isinstance(queries, (tuple, list)) and len(queries) == 2 and all(torch.is_tensor(q) for q in queries):
+            ids, attn = queries
+            if ids.is_cuda and ids.shape[1] <= self.T_EXACT:
+                ids_c, attn_c = ids, attn                                           # device tensors of an exact class: as they are
+                Tb = Tc = ids.shape[1]
+            else:
+                ids, attn = ids.cpu(), attn.cpu()
+                ids_c = None
+        else:
+            tok = getattr(model.bert, 'tokenizer', None)
+            if tok is None:
+                return None                                                         # (Bert.forward raises with the reason)
+            ids, attn = tok(list(queries))
+            ids_c = None
+        if ids_c is None:
+            Tb = ids.shape[1]
+            Tc = -(-Tb // self.T_STEP) * self.T_STEP
+            pi = torch.zeros(ids.shape[0], Tc, dtype=torch.long)
+            pa = torch.zeros(ids.shape[0], Tc, dtype=torch.long)
+            pi[:, :Tb], pa[:, :Tb] = ids, attn
+            ids_c, attn_c = STAGER.to_device(pi, torch.long, dev), STAGER.to_device(pa, torch.long, dev)
+        key = (dev, ids_c.shape[0], Tc, Tb)
+        extra = self._extra_cache.get(key)
+        if extra is None:
+            e = torch.zeros(ids_c.shape[0], Tc, dtype=torch.uint8)
+            e[:, Tb:] = 1
+            extra = self._extra_cache[key] = e.to(dev)
+        tok_c, tgt_c, _ = model.encode_answers_classed(targets, self.S_STEP)
+        return (ids_c, attn_c), extra, tok_c, tgt_c
+
+    def _graphed_body(self, images, queries, tok, lang_extra=None):
+        """the GraphedBody for this batch signature, captured the second time the signature is seen (the first, eager,
+        step is the warm-up: weight copies, kernel attributes, workspaces); None -> eager step.  At most `graph_slots` bodies
+        are kept (each pins its activation pool): the least recently used one makes room."""
+        if not self._graphs_apply(images) or not isinstance(queries, (tuple, list)) or len(queries) != 2 \
+                or not all(torch.is_tensor(q) for q in queries):
             return None
         key = (tuple(images.tensors.shape), images.tensors.dtype, getattr(images, 'all_valid', None), tuple(queries[0].shape),
-               tuple(tok.shape))
+               tuple(tok.shape), lang_extra is not None)
         body = self._bodies.get(key)
         if body is not None and body.stale():
             del self._bodies[key]
@@ -754,13 +823,17 @@ class FlatTrainer:
             self._seen[key] = n + 1
             if n < 1:
                 return None
-            if len(self._bodies) >= int(os.environ.get('GPV_TRAIN_GRAPH_SLOTS', '4')):       # each body pins its activations
-                return None
+            if len(self._bodies) >= self.graph_slots:
+                self._bodies.popitem(last=False)                                   # least recently used
+                gc.collect()
+                torch.cuda.empty_cache()
             try:
-                body = self._bodies[key] = GraphedBody(self, images, queries, tok)
+                body = self._bodies[key] = GraphedBody(self, images, queries, tok, lang_extra)
             except RuntimeError as err:
                 self._graphs_failed(err)
                 return None
+        else:
+            self._bodies.move_to_end(key)
         return body
 
     def _graphs_failed(self, err):
@@ -777,17 +850,17 @@ class FlatTrainer:
         RT.defer_list = None
         RT.backward_boundary = None
 
-    def _train_step_graphed(self, body, images, queries, tok, targets):
+    def _train_step_graphed(self, body, images, queries, tok, targets, lang_extra=None, orig_queries=None):
         hp = HOST_PROF
         t0 = time.perf_counter() if hp is not None else 0.0
         try:
-            outs = body.forward(images, queries, tok)
+            outs = body.forward(images, queries, tok, lang_extra)
             if hp is not None:
                 t1 = time.perf_counter(); hp['replay_f1_f2'] = hp.get('replay_f1_f2', 0.0) + t1 - t0; t0 = t1
             loss = self.model.criterion(outs, targets)[0]
         except RuntimeError as err:                       # nothing collective has been entered yet: redo the step eagerly
             self._graphs_failed(err)
-            return self._train_step_impl(images, queries, targets)
+            return self._train_step_impl(images, queries if orig_queries is None else orig_queries, targets)
         if not self._any_rank_has_loss(loss is not None):
             return None
         self.zero_grad()
@@ -807,7 +880,7 @@ class FlatTrainer:
                 torch.cuda.synchronize()
                 self.zero_grad()
                 self.begin_backward()
-                loss = self.model(images, queries, tok, targets)
+                loss = self.model._forward_impl(images, queries, tok, targets, lang_extra=lang_extra)
                 if loss is not None:
                     loss.backward()
         self.allreduce_grads()

@@ -174,8 +174,8 @@ def train_worker(cfg, dataset=None, device=None, log=print):
     for epoch in range(last_epoch + 1, epochs):
         idx = shard_indices(len(dataset), epoch, rank, world)
         epoch_done = True                     # False: max_steps ended the epoch before its last batch
-        for it, (imgs, queries, targets) in enumerate(batches(dataset, idx, per_rank, device)):
-            epoch_done = False
+        batch_iter = iter(batches(dataset, idx, per_rank, device))
+        for it, (imgs, queries, targets) in enumerate(batch_iter):
             trainer.set_epoch(epoch, it)
             loss = trainer.train_step(imgs, queries, targets)
             step += 1
@@ -188,8 +188,8 @@ def train_worker(cfg, dataset=None, device=None, log=print):
                 # kept as is (with lr_linear_decay the tail of such a run sits at lr 0 once step passes t_total)
                 save_checkpoint(ckpt_path, model, trainer, epoch - 1, step)
             if max_steps is not None and step >= max_steps:
+                epoch_done = next(batch_iter, None) is None      # stopped on the epoch's last batch: the epoch is complete
                 break
-            epoch_done = True
         stopped = max_steps is not None and step >= max_steps
         if rank == 0:
             save_checkpoint(ckpt_path, model, trainer, epoch if epoch_done else epoch - 1, step)

@@ -33,7 +33,7 @@ class BertBiAttention(nn.Module):
         self.p1 = cfg.v_attention_probs_dropout_prob
         self.p2 = cfg.attention_probs_dropout_prob
 
-    def forward(self, t1, t2, B, T1, T2, own1=None, own2=None):
+    def forward(self, t1, t2, B, T1, T2, own1=None, own2=None, kpm1=None):
         """t1 [B*T1, D] (language), t2 [B*T2, D] (vision) -> ctx1 [B*T2, D], ctx2 [B*T1, D].
         ops.GradChain: a chain's members must all sit behind the same layer output (a detection-only batch gives the language
         output of the last layer no gradient).  ctx2 -> stream 1's output uses q1, k2, v2; ctx1 -> stream 2's output uses q2, k1, v1:
@@ -45,7 +45,7 @@ class BertBiAttention(nn.Module):
         p1 = self.p1 if self.training else 0.0
         p2 = self.p2 if self.training else 0.0
         # scores1 = q2 k1^T -> probs (dropout1) @ v1 : vision queries over language keys (vilbert.py:770-787)
-        ctx1 = ops.attention([q2, k1, v1], ((0, 0), (1, 0), (2, 0)), B, H, T2, T1, dh, drop_p=p1)
+        ctx1 = ops.attention([q2, k1, v1], ((0, 0), (1, 0), (2, 0)), B, H, T2, T1, dh, kpm=kpm1, drop_p=p1)
         # scores2 = q1 k2^T -> probs (dropout2) @ v2 : language queries over vision keys (:790-810)
         ctx2 = ops.attention([q1, k2, v2], ((0, 0), (1, 0), (2, 0)), B, H, T1, T2, dh, drop_p=p2)
         return ctx1, ctx2
@@ -101,10 +101,12 @@ class BertConnectionLayer(nn.Module):
         self.t_intermediate = _Intermediate(cfg.hidden_size, cfg.intermediate_size, cfg.hidden_act)
         self.t_output = _Output(cfg.intermediate_size, cfg.hidden_size, cfg.hidden_dropout_prob)
 
-    def forward(self, t1, t2, B, T1, T2):
-        """vilbert.py:872-900.  No attention masks: GPV passes None, so padded BERT tokens are attended."""
+    def forward(self, t1, t2, B, T1, T2, kpm1=None):
+        """vilbert.py:872-900.  No attention masks: GPV passes None, so padded BERT tokens are attended.
+        kpm1 (uint8 [B, T1], 1 = ignore): NOT a reference argument -- the trainer's size-classed batches (train.FlatTrainer) carry
+        language tokens beyond the batch's own longest query; masking exactly those keys reproduces the unpadded batch."""
         c1, c2 = ops.grad_chain(t1), ops.grad_chain(t2)          # each stream input: three projections + a residual
-        bi1, bi2 = self.biattention(t1, t2, B, T1, T2, c1, c2)
+        bi1, bi2 = self.biattention(t1, t2, B, T1, T2, c1, c2, kpm1)
         a1, a2 = self.biOutput(bi2, t1, bi1, t2, c1, c2)
         ca1, ca2 = ops.grad_chain(a1), ops.grad_chain(a2)        # feed-forward input + residual
         o1 = self.v_output(self.v_intermediate(a1, ca1), a1, ca1)
