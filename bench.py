@@ -61,6 +61,7 @@ def conv_algorithmic(model, B):
     ff = 2.0 * B * oh * ow * 64 * 7 * 32
     n_f, n_b = 1, 0
     bb = bf = 0.0
+    bound = [max(fb / 8e12, ff / 2.5e15)]        # per launch: max(bytes / HBM peak, flops / dense bf16 MFMA peak), seconds
     h, w = (oh + 2 - 3) // 2 + 1, (ow + 2 - 3) // 2 + 1
     seen = False
     for blk in body.blocks():
@@ -77,20 +78,24 @@ def conv_algorithmic(model, B):
             fb += x_b + y_b + w_b
             ff += fl
             n_f += 1
+            bound.append(max((x_b + y_b + w_b) / 8e12, fl / 2.5e15))
             if tr:
                 bb += x_b + y_b + 2 * w_b                      # wgrad: read x, dy ; write dW (fp32)
                 bf += fl
                 n_b += 1
+                bound.append(max((x_b + y_b + 2 * w_b) / 8e12, fl / 2.5e15))
                 needs_dx = not (conv is blk.conv1 or (blk.downsample is not None and conv is blk.downsample[0])) or seen
                 if needs_dx:
                     bb += x_b + y_b + w_b                      # dgrad: read dy, W ; write dx
                     bf += fl
                     n_b += 1
+                    bound.append(max((x_b + y_b + w_b) / 8e12, fl / 2.5e15))
             if conv is blk.conv2:
                 h, w = o_h, o_w
         if tr:
             seen = True
-    return {'fwd_bytes': fb, 'fwd_flops': ff, 'bwd_bytes': bb, 'bwd_flops': bf, 'fwd_launches': n_f, 'bwd_launches': n_b}
+    return {'fwd_bytes': fb, 'fwd_flops': ff, 'bwd_bytes': bb, 'bwd_flops': bf, 'fwd_launches': n_f, 'bwd_launches': n_b,
+            'mixed_bound_s': sum(bound)}
 
 
 def cpu_baseline(model, seconds_budget=40.0):
@@ -228,6 +233,89 @@ def greedy_decode_bench(model, dev):
     return res
 
 
+def ragged_bench(model, tr, dev, rank, steps=36):
+    """the reference's own API and batch shapes (train_distr.py:399-428): `queries` as strings of 4..14 words (6..16 WordPiece
+    tokens), caption answers of 1..18 words, a fresh combination every step; the trainer tokenises on the host, pads to size classes
+    and replays captured hipGraphs (train.FlatTrainer._classed).  Reported next to the fixed-shape number."""
+    import tempfile
+    from gpv1_amd import synthetic
+    from gpv1_amd.bert import WordPieceTokenizer
+    from gpv1_amd.misc import nested_tensor_from_tensor_list
+    with tempfile.TemporaryDirectory() as td:
+        words = synthetic.write_wordpiece_vocab(os.path.join(td, 'vocab.txt'))
+        model.bert.tokenizer = WordPieceTokenizer(os.path.join(td, 'vocab.txt'))
+    g = torch.Generator().manual_seed(4321 + rank)
+    images = torch.randn(BATCH, 3, *IMG, generator=g).to(dev)
+    samples = nested_tensor_from_tensor_list(images)
+
+    def make(it):
+        nq = 4 + (5 * it) % 11                                            # longest query of the batch: 4..14 words
+        na = 1 + (7 * it) % 18                                            # longest caption: 1..18 words
+        qs = [' '.join(words[int(j)] for j in torch.randint(0, len(words), (max(2, nq - i % 3),), generator=g)) for i in range(BATCH)]
+        tg = [{'task': 'CocoCaptioning', 'answer': ' '.join(f'w{int(j)}' for j in torch.randint(0, V - 4, (max(1, na - i % 4),), generator=g))}
+              for i in range(BATCH)]
+        return qs, tg
+    batches = [make(it) for it in range(steps)]
+    g0, e0 = tr.graph_steps, tr.eager_steps
+    for qs, tg in batches[:18]:                                           # warm-up: every size class is seen twice (eager, capture)
+        tr.train_step(samples, list(qs), [dict(t) for t in tg])
+    for qs, tg in batches[:18]:
+        tr.train_step(samples, list(qs), [dict(t) for t in tg])
+    torch.cuda.synchronize()
+    g1, e1 = tr.graph_steps, tr.eager_steps
+    t0 = time.perf_counter()
+    for qs, tg in batches:
+        tr.train_step(samples, list(qs), [dict(t) for t in tg])
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {'ms_per_step': dt / steps * 1e3, 'images_per_sec': BATCH * steps / dt, 'steps': steps,
+            'graph_steps_timed': tr.graph_steps - g1, 'eager_steps_timed': tr.eager_steps - e1,
+            'captured_bodies': len(tr._bodies),
+            'what': 'string queries of 6..16 WordPiece tokens, captions of 1..18 words, a different (T_l, S) every step; host tokenisation + '
+                    'size-class padding inside the timed region'}
+
+
+def extra_configs(model, tr, dev, rank):
+    """BASELINE.json configs[3] (beam_size 5 decode, 64 images, one hipGraph) and configs[4] (CocoDetection-only train step, 64
+    images per GPU: Hungarian matcher + set criterion on 100 queries) -- single-GPU figures."""
+    from gpv1_amd.misc import nested_tensor_from_tensor_list
+    out = {}
+    images, mask, ids, attn, _ = make_batch(11 + rank, 64, dev)
+    samples = nested_tensor_from_tensor_list(images)
+    g = torch.Generator().manual_seed(99 + rank)
+    tg = []
+    for i in range(64):
+        n = 1 + int(torch.randint(0, 10, (1,), generator=g))
+        cxcy = 0.25 + 0.5 * torch.rand(n, 2, generator=g)
+        wh = 0.05 + 0.3 * torch.rand(n, 2, generator=g)
+        tg.append({'task': 'CocoDetection', 'boxes': torch.cat((cxcy, wh), 1).to(dev), 'labels': torch.zeros(n, dtype=torch.long, device=dev)})
+    for _ in range(3):
+        tr.train_step(samples, (ids, attn), [dict(t) for t in tg])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n_it = 6
+    for _ in range(n_it):
+        tr.train_step(samples, (ids, attn), [dict(t) for t in tg])
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n_it
+    out['detection_only_bs64_train_step'] = {'ms_per_step': dt * 1e3, 'images_per_sec': 64 / dt,
+                                             'what': 'configs[4]: CocoDetection-only targets (1..10 boxes), B = 64, matcher + set criterion on the host, AdamW'}
+    model.eval()
+    with torch.no_grad():
+        for _ in range(2):
+            model.forward_beam_search(samples, (ids, attn), beam_size=5)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            model.forward_beam_search(samples, (ids, attn), beam_size=5)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 3
+    model.train()
+    out['beam5_bs64'] = {'ms_per_batch': dt * 1e3, 'ms_per_image': dt * 1e3 / 64,
+                         'what': 'configs[3]: forward_beam_search(beam_size=5), 64 images, KV cache, the whole search one hipGraph, incl. host detokenisation'}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -236,6 +324,9 @@ def main():
     ap.add_argument('--batch', type=int, default=BATCH)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-decode', action='store_true')
+    ap.add_argument('--no-ragged', action='store_true', help='skip the string-query / ragged-length run reported next to the fixed-shape number')
+    ap.add_argument('--no-extra', action='store_true', help='skip BASELINE configs[3] (beam 5, bs64) and configs[4] (detection-only bs64)')
+    ap.add_argument('--soak', type=int, default=0, help='after the timed region: this many more graphed steps (soak of the hipGraph replay path)')
     args = ap.parse_args()
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(self_launch(args))
@@ -338,6 +429,14 @@ def main():
         if world > 1:
             dist.destroy_process_group()
         return
+    soak = None
+    if args.soak > 0 and world == 1:
+        t0s = time.perf_counter()
+        for _ in range(args.soak):
+            ls = step()
+        torch.cuda.synchronize()
+        soak = {'steps': args.soak, 'ms_per_step': (time.perf_counter() - t0s) / args.soak * 1e3, 'final_loss': float(ls.detach()),
+                'finite': bool(torch.isfinite(ls.detach()))}
     # ---- roofline of the dominant kernel (implicit-GEMM conv, backbone fwd+bwd), live HIP events ----
     alg = conv_algorithmic(model, args.batch)
     ms = {'conv_fwd': 0.0, 'conv_bwd': 0.0}
@@ -352,16 +451,20 @@ def main():
     # inside a timed run, so it is the committed measurement of this same command (tools/pmc_traffic.py ->
     # profiles/r02_pmc_conv_traffic.json); null if that file is missing or was taken for another launch count.
     traffic = None
+    traffic_source = None
     try:
         import glob
         latest = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r*_pmc_conv_traffic.json')))[-1]
         pm = json.load(open(latest))
         if pm['conv_launches_fetch_pass'] % launches == 0 and pm['conv_launches_fetch_pass'] == pm['conv_launches_write_pass'] and args.batch == BATCH:
             traffic = pm['traffic_bytes_per_launch']
+            traffic_source = 'profiles/%s (committed PMC measurement of this command, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE: not collected by this run)' % os.path.basename(latest)
     except (OSError, KeyError, ValueError, IndexError):
         pass
     roof = {'bound': 'hbm', 'achieved': ach_gbs, 'peak': 8000.0, 'unit': 'GB/s', 'frac': ach_gbs / 8000.0, 'traffic': traffic,
-            'kernel': 'c1s_kernel (streaming 1x1) / glds_wgrad_kernel / glds_kernel<OP_CONV> / pipe_kernel<OP_CONV> / pipe_conv1x1_kernel / conv1x1_kernel / gemm_kernel<OP_CONV> (NHWC conv fwd/dgrad/wgrad, ResNet-50 body)',
+            'traffic_source': traffic_source,
+            'frac_mixed_per_conv_bound': alg['mixed_bound_s'] / (conv_ms * 1e-3),      # sum over launches of max(bytes / 8 TB/s, flops / 2.5 PF) / measured time
+            'kernel': 'c1s_kernel (streaming 1x1) / c3r_kernel (streaming 3x3) / stem_pool_kernel / glds_wgrad_kernel / glds_kernel<OP_CONV> / pipe_kernel<OP_CONV> / pipe_conv1x1_kernel / conv1x1_kernel / gemm_kernel<OP_CONV> (NHWC conv fwd/dgrad/wgrad, ResNet-50 body)',
             'launches_per_step': launches, 'avg_launch_us': conv_ms * 1e3 / launches,
             'algorithmic_bytes_per_launch': bytes_step / launches,
             'fwd_ms': ms['conv_fwd'] / args.steps, 'bwd_ms': ms['conv_bwd'] / args.steps,
@@ -381,6 +484,12 @@ def main():
                       'parallelism': f'dp{world}', 'final_loss': float(loss.detach())},
            'roofline': roof}
     out['roofline_attention'] = attention_roofline(dev, args.batch)
+    if soak is not None:
+        out['soak'] = soak
+    if world == 1 and not args.no_ragged and args.batch == BATCH:
+        out['ragged'] = ragged_bench(model, tr, dev, rank)
+    if world == 1 and not args.no_extra:
+        out['extra'] = extra_configs(model, tr, dev, rank)
     if world == 1 and not args.no_decode:
         out['greedy_decode'] = greedy_decode_bench(model, dev)
     if world == 1 and not args.no_cpu_baseline:

@@ -53,3 +53,14 @@ def make_vocab(V):
     """specials are the LAST four entries (exp/gpv/compute_vocab_bert.py:35-41)."""
     words = [f'w{i}' for i in range(V - 4)]
     return words + ['__pad__', '__cls__', '__stop__', '__unk__']
+
+
+def write_wordpiece_vocab(path, n_words=400):
+    """a WordPiece vocabulary file in bert-base-uncased's layout (specials first) with n_words synthetic whole-word tokens
+    (`q0`, `q1`, ...): bench.py's string-query mode needs a tokenizer, the real vocab.txt is not available offline"""
+    toks = ['[PAD]'] + [f'[unused{i}]' for i in range(99)] + ['[UNK]', '[CLS]', '[SEP]', '[MASK]']
+    toks += list('abcdefghijklmnopqrstuvwxyz0123456789') + ['##' + c for c in 'abcdefghijklmnopqrstuvwxyz0123456789']
+    words = [f'q{i}' for i in range(n_words)]
+    with open(path, 'w') as f:
+        f.write('\n'.join(toks + words) + '\n')
+    return words
