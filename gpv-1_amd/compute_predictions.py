@@ -39,6 +39,8 @@ COCO_CLASSES = (
     'cell phone', 'microwave', 'oven', 'toaster', 'sink', 'refrigerator', 'book', 'clock', 'vase', 'scissors', 'teddy bear',
     'hair drier', 'toothbrush')
 
+COCO_CLASSES = tuple(sorted(COCO_CLASSES))      # the reference iterates data/coco/synonyms.py's table, whose keys are in alphabetical order
+
 _WORD = re.compile(r"\w+|[^\w\s]")
 
 
@@ -54,6 +56,8 @@ def create_vocab_mask(model, classes=COCO_CLASSES, synonyms=None, use_syns=False
     for cls in classes:
         names = [cls]
         if use_syns and synonyms is not None:
+            if cls not in synonyms:
+                continue
             names = synonyms[cls]
         for name in names:
             for token in word_tokenize(name):

@@ -7,10 +7,15 @@ What the reference's drivers use from Hydra/OmegaConf and what is reproduced her
   * ``key=value`` command-line overrides with dotted keys (scripts/train.sh passes ``exp_name=... training.freeze=True``):
     values are parsed as YAML scalars (``True``/``null``/``1e-4``/``[10,15]``), new keys may be added with ``+key=value``;
   * attribute access, ``.items()``, real bools (the model reads ``cfg.roi_head is True`` style flags).
-The ``defaults:`` list (dataset / task groups) selects data-loading YAMLs, which are out of scope here (BASELINE uses
-synthetic COCO-shaped tensors); it is kept in the tree untouched.
-This loads the reference's own ``configs/exp/gpv.yaml``; the drivers' built-in tree is gpv1_amd/default_config.py.
+  * the ``defaults:`` list (configs/exp/gpv.yaml:23-25 ``- task: coco_learning_tasks`` / ``- learning_datasets: vqa``): every
+    entry ``group: name`` names ``<config root>/<group>/<name>.yaml``, merged into the tree at the package its first line
+    declares (``# @package _group_`` -> under ``group``, ``# @package task_configs`` -> under that key, ``_global_`` -> root);
+    an override whose key is a defaults group -- ``learning_datasets=all`` as scripts/train.sh passes it (:14-34) -- selects
+    the file instead of assigning a value.  The primary file's own keys win over a defaults file's (Hydra 1.0 ordering).
+This loads the reference's own ``configs/exp/gpv.yaml``; the drivers' built-in tree is gpv1_amd/default_config.py, whose
+``learning_datasets`` group options are the reference's eleven task mixes (configs/learning_datasets/*.yaml).
 """
+import os
 import re
 
 import yaml
@@ -88,16 +93,86 @@ def apply_overrides(tree, overrides, strict=True):
     return tree
 
 
+_PACKAGE = re.compile(r'^#\s*@package\s+(\S+)')
+
+
+def _merge_under(tree, package, sub):
+    """merge dict `sub` into `tree` at dotted `package` ('' = root); existing keys of `tree` win"""
+    cur = tree
+    for part in [p for p in package.split('.') if p]:
+        cur = cur.setdefault(part, {})
+    for k, v in sub.items():
+        if isinstance(v, dict) and isinstance(cur.get(k), dict):
+            _merge_under(cur, k, v)
+        else:
+            cur.setdefault(k, v)
+
+
+def _group_file(root_dirs, group, name):
+    for d in root_dirs:
+        p = os.path.join(d, group, f'{name}.yaml')
+        if os.path.exists(p):
+            return p
+    raise FileNotFoundError(f'config: defaults entry {group}: {name} -- no {group}/{name}.yaml under {root_dirs}')
+
+
+def _compose_defaults(tree, root_dirs, selected):
+    """Hydra ``defaults:`` list -> the named group files merged into `tree` (see the module docstring)"""
+    for entry in tree.get('defaults') or []:
+        if not isinstance(entry, dict):
+            continue                                     # (a bare string entry names another primary config: not used by the reference)
+        for group, name in entry.items():
+            name = selected.get(group, name)
+            if name is None:
+                continue
+            path = _group_file(root_dirs, group, name)
+            with open(path) as f:
+                text = f.read()
+            m = _PACKAGE.match(text.lstrip())
+            package = m.group(1) if m else group
+            package = {'_group_': group.replace('/', '.'), '_global_': ''}.get(package, package)
+            _merge_under(tree, package, _fix_floats(yaml.safe_load(text) or {}))
+    return tree
+
+
+def _split_group_overrides(tree, overrides, groups=None):
+    """overrides whose key is a defaults group (``learning_datasets=all``) select a file / a built-in option, the rest assign"""
+    names = set(groups or ())
+    for entry in tree.get('defaults') or []:
+        if isinstance(entry, dict):
+            names.update(entry)
+    selected, rest = {}, []
+    for ov in overrides or ():
+        key, _, text = ov.partition('=')
+        if key.lstrip('+') in names and '=' in ov:
+            selected[key.lstrip('+')] = _scalar(text)
+        else:
+            rest.append(ov)
+    return selected, rest
+
+
 def load_config(path, overrides=(), strict=True):
-    """YAML file + overrides -> resolved AttrDict tree."""
+    """YAML file (+ its ``defaults:`` groups) + overrides -> resolved AttrDict tree."""
     with open(path) as f:
         tree = _fix_floats(yaml.safe_load(f) or {})
-    apply_overrides(tree, overrides, strict)
+    here = os.path.dirname(os.path.abspath(path))
+    root_dirs = [here, os.path.dirname(here)]            # config_name 'exp/gpv' under config_path 'configs': groups sit beside `exp/`
+    selected, rest = _split_group_overrides(tree, overrides)
+    _compose_defaults(tree, root_dirs, selected)
+    apply_overrides(tree, rest, strict)
     return AttrDict.wrap(_resolve(tree, tree))
 
 
-def from_dict(tree, overrides=(), strict=True):
+def from_dict(tree, overrides=(), strict=True, group_options=None):
+    """group_options: {group: {name: subtree}} -- the built-in counterpart of the defaults group files
+    (default_config.GROUP_OPTIONS): ``learning_datasets=cap`` replaces tree['learning_datasets'] by that option"""
     import copy
     tree = copy.deepcopy(dict(tree))
-    apply_overrides(tree, overrides, strict)
+    group_options = group_options or {}
+    selected, rest = _split_group_overrides(tree, overrides, groups=group_options)
+    for group, name in selected.items():
+        if group not in group_options or name not in group_options[group]:
+            raise KeyError(f'config: no option {name!r} for group {group!r} (have {sorted(group_options.get(group, {}))})')
+        tree[group] = copy.deepcopy(group_options[group][name])
+    apply_overrides(tree, rest, strict)
     return AttrDict.wrap(_resolve(tree, tree))

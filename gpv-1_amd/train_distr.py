@@ -28,7 +28,7 @@ import torch
 import torch.distributed as dist
 
 from .config import from_dict, load_config
-from .default_config import default_tree
+from .default_config import default_tree, GROUP_OPTIONS
 from .gpv import GPV
 from .misc import nested_tensor_from_tensor_list
 from .train import FlatTrainer
@@ -143,7 +143,10 @@ def train_worker(cfg, dataset=None, device=None, log=print):
         freeze_detr_params(model)
     model.to(device)
     if dataset is None:
-        dataset = SyntheticCocoDataset(int(cfg.get('synthetic_samples', 4 * batch_size)), model.vocab)
+        # the task mix: configs/learning_datasets/<name>.yaml selected by `learning_datasets=<name>` (scripts/train.sh:14-34),
+        # CocoMultitaskDataset(cfg.learning_datasets, ...) in the reference (train_distr.py:163-166)
+        tasks = tuple(cfg.get('learning_datasets', {}) or ()) or ('CocoCaptioning', 'CocoVqa', 'CocoClassification', 'CocoDetection')
+        dataset = SyntheticCocoDataset(int(cfg.get('synthetic_samples', 4 * batch_size)), model.vocab, tasks=tasks)
     steps_per_epoch = (-(-len(dataset) // world)) // per_rank
     t_total = steps_per_epoch * epochs if tr_cfg.lr_linear_decay else 0
     have_ckpt = tr_cfg.ckpt is not None and os.path.exists(str(tr_cfg.ckpt))
@@ -205,7 +208,7 @@ def main(argv=None):
     ap.add_argument('--config', default=None, help='YAML file (e.g. the reference configs/exp/gpv.yaml); default: gpv1_amd.default_config')
     ap.add_argument('overrides', nargs='*', help='Hydra-style key=value overrides')
     args = ap.parse_args(argv)
-    cfg = load_config(args.config, args.overrides) if args.config else from_dict(default_tree(), args.overrides)
+    cfg = load_config(args.config, args.overrides) if args.config else from_dict(default_tree(), args.overrides, group_options=GROUP_OPTIONS)
     train_worker(cfg)
 
 

@@ -190,3 +190,37 @@ def test_compute_predictions_files_and_vocab_mask(shim, tmp_path):
     r = inf.resize_image(img, (48, 64))
     assert r.shape == (48, 64, 3) and r.dtype == np.float32 and abs(float(r.mean()) - img.mean() / 255) < 2e-3
     assert r.std() < (img / 255.0).std()                                                  # low-pass before subsampling
+
+
+def test_hydra_defaults_groups_and_learning_datasets_override(tmp_path):
+    """configs/exp/gpv.yaml:23-25 `defaults:` + scripts/train.sh:14-34 `learning_datasets=all|cap|det`: group files are merged at
+    the package their first line declares, an override on a group name selects the file; the built-in tree's options equal the
+    reference's eleven configs/learning_datasets/*.yaml (fixture dumped by tools/gen_golden_harness.py)."""
+    import json
+    from gpv1_amd.config import load_config, from_dict
+    from gpv1_amd.default_config import default_tree, GROUP_OPTIONS
+    root = tmp_path / 'configs'
+    for d in ('exp', 'task', 'learning_datasets'):
+        (root / d).mkdir(parents=True)
+    (root / 'exp' / 'gpv.yaml').write_text('exp_name: x\ndata_dir: /d\ndefaults:\n  - task: coco_learning_tasks\n  - learning_datasets: vqa\n'
+                                           'training:\n  lr: 1e-4\n')
+    (root / 'task' / 'coco_learning_tasks.yaml').write_text('# @package task_configs\nimage_dir: ${data_dir}/images\nimage_size:\n  H: 480\n  W: 640\n')
+    (root / 'learning_datasets' / 'vqa.yaml').write_text('# @package _group_\nCocoVqa:\n  task_config: coco_vqa\n  name: coco_vqa\n')
+    (root / 'learning_datasets' / 'det_cap.yaml').write_text('# @package _group_\nCocoCaptioning:\n  task_config: coco_captioning\n  name: coco_cap\n'
+                                                             'CocoDetection:\n  task_config: coco_detection\n  name: coco_det\n')
+    cfg = load_config(str(root / 'exp' / 'gpv.yaml'))
+    assert list(cfg.learning_datasets) == ['CocoVqa'] and cfg.task_configs.image_dir == '/d/images' and cfg.task_configs.image_size.W == 640
+    cfg = load_config(str(root / 'exp' / 'gpv.yaml'), ['learning_datasets=det_cap', 'training.lr=2e-4'])
+    assert list(cfg.learning_datasets) == ['CocoCaptioning', 'CocoDetection'] and cfg.training.lr == 2e-4
+    with pytest.raises(FileNotFoundError):
+        load_config(str(root / 'exp' / 'gpv.yaml'), ['learning_datasets=nope'])
+    # built-in tree: same options as the reference's files, same key order (= the order tasks are concatenated in)
+    ref = json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'harness.json')))['learning_datasets']
+    assert sorted(ref) == sorted(GROUP_OPTIONS['learning_datasets'])
+    for name, items in ref.items():
+        assert [[k, dict(v)] for k, v in GROUP_OPTIONS['learning_datasets'][name].items()] == items, name
+    assert list(from_dict(default_tree(), [], group_options=GROUP_OPTIONS).learning_datasets) == ['CocoVqa']      # gpv.yaml:25
+    cfg = from_dict(default_tree(), ['learning_datasets=cap'], group_options=GROUP_OPTIONS)
+    assert list(cfg.learning_datasets) == ['CocoCaptioning']
+    with pytest.raises(KeyError):
+        from_dict(default_tree(), ['learning_datasets=nope'], group_options=GROUP_OPTIONS)
