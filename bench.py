@@ -337,6 +337,7 @@ def main():
         raise SystemExit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU '
                          f'(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)')
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    os.environ.setdefault('GPV_GRAPHS_STRICT', '1')       # a failed hipGraph capture must fail the bench, not degrade it to eager steps
     local = local % max(torch.cuda.device_count(), 1)   # (only differs on a box with fewer GPUs than ranks: the gloo dry run below)
     torch.cuda.set_device(local)
     dev = f'cuda:{local}'
@@ -380,6 +381,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     bbm.PROF = []
+    if world > 1:
+        tr.comm_prof = []
     import gpv1_amd.train as trm
     trm.HOST_PROF = {}
     t0 = time.perf_counter()
@@ -425,6 +428,16 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
+    comm = None
+    if world > 1:
+        torch.cuda.synchronize()
+        exposed = [a.elapsed_time(b) for a, b in (tr.comm_prof or [])]
+        tr.comm_prof = None
+        comm = {'backend': dist.get_backend(), 'rccl_ranks': world if dist.get_backend() == 'nccl' else 0, 'ranks': world,
+                'grad_comm_dtype': str(tr.grad_comm_dtype).replace('torch.', ''), 'bytes_per_rank_per_step': tr.comm_bytes_per_step(),
+                'buckets': len(tr.buckets), 'exposed_ms_per_step': sum(exposed) / max(len(exposed), 1),
+                'graph_steps': tr.graph_steps, 'eager_steps': tr.eager_steps,
+                'what': 'exposed = GPU time between the first bucket wait and the last bucket back on the compute stream (what the overlap did not hide), rank 0'}
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -484,6 +497,8 @@ def main():
                       'parallelism': f'dp{world}', 'final_loss': float(loss.detach())},
            'roofline': roof}
     out['roofline_attention'] = attention_roofline(dev, args.batch)
+    if comm is not None:
+        out['comm'] = comm
     if soak is not None:
         out['soak'] = soak
     if world == 1 and not args.no_ragged and args.batch == BATCH:

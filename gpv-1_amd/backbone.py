@@ -200,17 +200,26 @@ class ResNetBody(nn.Module):
         RT.cache[key] = (RT.static_epoch, ws, shift)
         return ws, shift
 
-    def forward_nhwc(self, images, keep):
-        """images: NCHW fp32 (ImageNet-normalised).  Returns c5 [B,h,w,2048]; `keep` collects
+    def forward_nhwc(self, images, keep, hw=None):
+        """images: NCHW fp32 (ImageNet-normalised) -- or, with hw = (H, W), the stem's zero-padded NHWC4 input [B, H+6, Wp, 4] as
+        input_pipeline.DeviceImagePipeline prepares it.  Returns c5 [B,h,w,2048]; `keep` collects
         (block, x, a1, a2, y) tuples of the trainable blocks for backward."""
-        B, _, H, Wd = images.shape
+        if hw is None:
+            B, _, H, Wd = images.shape
+        else:
+            B, (H, Wd) = images.shape[0], hw
         OH, OW = _out(H, 7, 2, 3), _out(Wd, 7, 2, 3)
         Hp = H + 6
         Wp = ((max(Wd + 6, 2 * (OW - 1) + 8) + 7) // 8) * 8
         if RT.split is not None and keep is not None:
             RT.split.prep_fork(self)
-        xin = torch.empty(B, Hp, Wp, 4, device=images.device, dtype=RT.dtype)
-        hip.image_to_nhwc4(images.contiguous(), xin, B, H, Wd, 3, Hp, Wp)
+        if hw is None:
+            xin = torch.empty(B, Hp, Wp, 4, device=images.device, dtype=RT.dtype)
+            hip.image_to_nhwc4(images.contiguous(), xin, B, H, Wd, 3, Hp, Wp)
+        else:
+            if tuple(images.shape) != (B, Hp, Wp, 4) or images.dtype != RT.dtype:
+                raise ValueError(f'prepared stem input: expected {(B, Hp, Wp, 4)} {RT.dtype}, got {tuple(images.shape)} {images.dtype}')
+            xin = images.contiguous()
         ws, shift = self._stem_weight()
         PH, PW = _out(OH, 3, 2, 1), _out(OW, 3, 2, 1)
         x = torch.empty(B, PH, PW, 64, device=images.device, dtype=RT.dtype)
@@ -306,10 +315,10 @@ class ResNetBody(nn.Module):
 
 class ResNetFn(Function):
     @staticmethod
-    def forward(ctx, images, body, dummy, need_bwd):
+    def forward(ctx, images, body, dummy, need_bwd, hw=None):
         keep = [] if need_bwd else None          # (grad mode is always off inside Function.forward)
         ev = _prof('conv_fwd')
-        c5 = body.forward_nhwc(images, keep)
+        c5 = body.forward_nhwc(images, keep, hw)
         if ev is not None:
             ev.record()
         ctx.body, ctx.keep = body, keep
@@ -324,7 +333,7 @@ class ResNetFn(Function):
         if ev is not None:
             ev.record()
         ctx.keep = None
-        return None, None, None, None
+        return None, None, None, None, None
 
 
 class BackboneBase(nn.Module):
@@ -344,13 +353,17 @@ class BackboneBase(nn.Module):
         if self._dummy is None or self._dummy.device != x.device:
             self._dummy = torch.zeros(1, device=x.device, requires_grad=True)       # makes autograd call backward
         need_bwd = torch.is_grad_enabled() and any(b.trainable() for b in self.body.blocks())
+        # a prepared stem input (input_pipeline.DeviceImagePipeline): [B, H+6, Wp, 4] in the compute dtype, H x W = the mask's
+        hw = tuple(m.shape[-2:]) if (x.dim() == 4 and x.shape[1] != 3 and x.shape[-1] == 4) else None
+        if hw is None:
+            x = x.float()
         if RT.split is not None and torch.is_grad_enabled():
             # train.GraphedBody: the backbone is its own pair of hipGraphs (forward here, backward called by the trainer
             # between the two halves of the gradient exchange); the rest of the model sees c5 as an autograd leaf.  With a
             # frozen backbone (phase-1 training.freeze, lr_backbone = 0) the forward graph still ends here, without a backward.
-            c5 = RT.split.backbone_forward(self.body, x.float(), train=need_bwd)
+            c5 = RT.split.backbone_forward(self.body, x, train=need_bwd, hw=hw)
         else:
-            c5 = ResNetFn.apply(x.float(), self.body, self._dummy, need_bwd)
+            c5 = ResNetFn.apply(x, self.body, self._dummy, need_bwd, hw)
         h, w = c5.shape[1:3]
         H, Wd = m.shape[-2:]
         iy = torch.div(torch.arange(h, device=m.device) * H, h, rounding_mode='floor')   # F.interpolate nearest

@@ -57,6 +57,12 @@ class TTProblem(C.Structure):
                 ('M', C.c_int), ('N', C.c_int), ('K', C.c_int), ('lda', C.c_int), ('ldb', C.c_int), ('ldc', C.c_int)]
 
 
+class ImageDesc(C.Structure):
+    _fields_ = [('src', C.c_void_p), ('H', C.c_int), ('W', C.c_int), ('flip', C.c_int), ('gray', C.c_int), ('jitter', C.c_int),
+                ('order', C.c_int * 4), ('brightness', C.c_float), ('contrast', C.c_float), ('saturation', C.c_float),
+                ('hue', C.c_float), ('reserved', C.c_int)]
+
+
 def lib():
     global _LIB
     if _LIB is None:
@@ -77,7 +83,7 @@ EXPORTS = ['gpv_abi_version', 'gpv_set_option', 'gpv_gemm', 'gpv_conv2d', 'gpv_i
            'gpv_softmax_ce', 'gpv_roi_weights', 'gpv_add', 'gpv_add_rowbcast', 'gpv_colsum', 'gpv_cast',
            'gpv_cast_rowscale_t', 'gpv_prep_conv_weight', 'gpv_embedding', 'gpv_dropout',
            'gpv_relevance_condition', 'gpv_adamw', 'gpv_sumsq', 'gpv_act_fwd', 'gpv_act_bwd', 'gpv_set_seed_device',
-           'gpv_gemm_tt_group', 'gpv_cast_transpose_group', 'gpv_stem_pool']
+           'gpv_gemm_tt_group', 'gpv_cast_transpose_group', 'gpv_stem_pool', 'gpv_image_pipeline']
 
 
 OPT_GLDS, OPT_GLDS_LAUNCHES, OPT_SKINNY, OPT_GLDS_WGRAD, OPT_PIPE, OPT_PIPE_LAUNCHES, OPT_C1S, OPT_C3S, OPT_C3S_LAUNCHES = 0, 1, 2, 3, 4, 5, 6, 7, 8
@@ -284,6 +290,12 @@ def image_to_nhwc4(img, out, B, H, W, pad, Hp, Wp):
 
 def maxpool3x3s2(x, y, B, H, W, Cc, OH, OW):
     _chk(lib().gpv_maxpool3x3s2(_p(x), _p(y), B, H, W, Cc, OH, OW, dcode(x), _stream()), 'gpv_maxpool3x3s2')
+
+
+def image_pipeline(descs_dev, B, scratch, grey_sum, out, OH, OW, pad, Hp, Wp):
+    """gpv_image_pipeline: descs_dev = uint8 device tensor holding B packed ImageDesc structs"""
+    _chk(lib().gpv_image_pipeline(_p(descs_dev), B, _p(scratch), _p(_f32(grey_sum)), _p(out), OH, OW, pad, Hp, Wp, dcode(out), _stream()),
+         'gpv_image_pipeline')
 
 
 def stem_pool(x, w, shift, y, B, Hp, Wp, CH, CW, PH, PW):

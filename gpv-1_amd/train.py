@@ -160,11 +160,11 @@ class GraphedBody:
                     pass
 
     # called by backbone.BackboneBase.forward while this body is being captured (ops.RT.split)
-    def backbone_forward(self, body, x, train=True):
+    def backbone_forward(self, body, x, train=True, hw=None):
         """train=False: no backbone block is trainable (phase-1 `training.freeze`, lr_backbone = 0): F1 keeps nothing for a
         backward, c5 is a constant of F2 and B2 has no backbone part"""
         self.keep = [] if train else None
-        c5 = body.forward_nhwc(x, self.keep)
+        c5 = body.forward_nhwc(x, self.keep, hw)
         if self.side is not None:
             torch.cuda.current_stream(x.device).wait_stream(self.side)         # join the BERT branch before F1 ends
         self._prep_forked = False
@@ -374,8 +374,13 @@ class GraphedBody:
 class FlatTrainer:
     def __init__(self, model, lr=1e-4, lr_backbone=1e-5, weight_decay=1e-4, clip_max_norm=0.1, warmup_steps=0,
                  t_total=0, betas=(0.9, 0.999), eps=1e-8, bucket_mb=128, process_group=None, manual_gc=True, gc_interval=200,
-                 graphs=None, lr_milestones=None, lr_drop=0.1, warmup_iters=0):
+                 graphs=None, lr_milestones=None, lr_drop=0.1, warmup_iters=0, grad_comm_dtype=None):
         self.model = model
+        # gradient exchange precision: fp32 (the reference's DDP) or bf16 (half the bytes on the xGMI ring: 222 instead of
+        # 444 MB per step; the local gradients stay fp32, every rank receives the same bf16 sums -> replicas stay bit-identical)
+        gcd = grad_comm_dtype if grad_comm_dtype is not None else os.environ.get('GPV_GRAD_COMM', 'fp32')
+        self.grad_comm_dtype = {'fp32': torch.float32, 'bf16': torch.bfloat16}.get(gcd, gcd)
+        self.comm_prof = None                    # bench.py: a list -> (first wait, all buckets back) event pairs of every exchange
         self.lr_milestones, self.lr_drop, self.warmup_iters = (list(lr_milestones) if lr_milestones is not None else None), lr_drop, warmup_iters
         self.epoch, self.it_in_epoch = 0, 0
         # hipGraph replay of the model body (GraphedBody): default on for bf16 on the GPU; GPV_TRAIN_GRAPHS=0 turns it off
@@ -443,6 +448,7 @@ class FlatTrainer:
         self.backbone_end = max([o + (k + 7) // 8 * 8 for (n, p, g, o, k) in self.entries if g == 'detr_backbone'], default=0)
         self.buckets = [(s, min(self.backbone_end, s + b)) for s in range(0, self.backbone_end, b)] + \
                        [(s, min(off, s + b)) for s in range(self.backbone_end, off, b)]      # no bucket straddles the backbone boundary
+        self.Gc = torch.zeros(off, device=dev, dtype=torch.bfloat16) if (self.world > 1 and self.grad_comm_dtype == torch.bfloat16) else None
         self.overlap = self.world > 1 and os.environ.get('GPV_OVERLAP', '1') != '0'
         self.dry_overlap = False             # tests: run the milestone / guard logic without communicating
         self._closed_from, self._works, self.late_touch, self.milestones = None, [], None, 0
@@ -497,8 +503,14 @@ class FlatTrainer:
         self._closed_from = self.backbone_end
         self.milestones += 1
         if self.overlap:
-            self._works = [dist.all_reduce(self.G[s:e], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
-                           for s, e in self.buckets if s >= self.backbone_end]
+            self._works = [self._reduce_bucket(s, e) for s, e in self.buckets if s >= self.backbone_end]
+
+    def _reduce_bucket(self, s, e):
+        """asynchronous SUM all-reduce of G[s:e] (through the bf16 staging buffer when grad_comm_dtype is bf16)"""
+        if self.Gc is None:
+            return (dist.all_reduce(self.G[s:e], op=dist.ReduceOp.SUM, group=self.pg, async_op=True), s, e)
+        self.Gc[s:e].copy_(self.G[s:e])
+        return (dist.all_reduce(self.Gc[s:e], op=dist.ReduceOp.SUM, group=self.pg, async_op=True), s, e)
 
     def begin_backward(self):
         self._closed_from, self._works, self.late_touch, self.milestones = None, [], None, 0
@@ -514,16 +526,27 @@ class FlatTrainer:
         # not its backward reached the milestone (a rank without an applicable target runs no backward at all, see train_step).
         works = list(self._works)
         if closed is None:
-            works += [dist.all_reduce(self.G[s:e], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
-                      for s, e in self.buckets if s >= self.backbone_end]
-        works += [dist.all_reduce(self.G[s:e], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
-                  for s, e in self.buckets if s < self.backbone_end]
+            works += [self._reduce_bucket(s, e) for s, e in self.buckets if s >= self.backbone_end]
+        works += [self._reduce_bucket(s, e) for s, e in self.buckets if s < self.backbone_end]
         self._works = []
         self._publish_touched()
         dist.all_reduce(self.live, op=dist.ReduceOp.MAX, group=self.pg)          # stays on the device: no host sync
-        for w in works:
+        prof = self.comm_prof is not None and self.G.is_cuda
+        if prof:                                   # exposed communication: what the compute stream waits for from here on
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        for w, s, e in works:
             w.wait()
+            if self.Gc is not None:
+                self.G[s:e].copy_(self.Gc[s:e])
         self.G.mul_(1.0 / self.world)
+        if prof:
+            e1.record()
+            self.comm_prof.append((e0, e1))
+
+    def comm_bytes_per_step(self):
+        """bytes every rank hands to the all-reduce per step"""
+        return self.total * (2 if self.Gc is not None else 4)
 
     def _publish_touched(self):
         """host-side 'touched' marks of this step -> device flags (idempotent; pinned staging, asynchronous)"""

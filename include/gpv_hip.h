@@ -143,6 +143,22 @@ int gpv_image_to_nhwc4(const float* img, void* out, int B, int H, int W, int pad
 /* 3x3 stride-2 pad-1 max-pool, NHWC (torchvision resnet maxpool). */
 int gpv_maxpool3x3s2(const void* x, void* y, int B, int H, int W, int C, int OH, int OW, int dtype,
                      void* stream);
+/* Device-side input pipeline (datasets/coco_generic_dataset.py:49-62 resize(.., (480, 640), anti_aliasing=True);
+ * datasets/coco_datasets.py:26-38,137-150 (255 img).astype(uint8) -> ColorJitter / RandomHorizontalFlip / RandomGrayscale -> ToTensor
+ * -> Normalize): B decoded uint8 HWC images of any size -> the stem's zero-padded NHWC4 batch out[B,Hp,Wp,4] (what
+ * gpv_image_to_nhwc4 produces from a normalised fp32 batch).  descs: DEVICE array of B descriptors (the host draws the random
+ * parameters); scratch_u8: B*OH*OW*3 bytes; grey_sum: B floats.  order[] = the four jitter steps in the sample's drawn order
+ * (0 brightness, 1 contrast, 2 saturation, 3 hue); jitter = 0 skips them.  Source side length / output side length <= 9. */
+typedef struct gpv_image_desc {
+  const unsigned char* src;   /* [H][W][3] uint8, device */
+  int H, W;
+  int flip, gray, jitter;
+  int order[4];
+  float brightness, contrast, saturation, hue;
+  int reserved;
+} gpv_image_desc;
+int gpv_image_pipeline(const gpv_image_desc* descs, int B, void* scratch_u8, float* grey_sum, void* out, int OH, int OW, int pad,
+                       int Hp, int Wp, int dtype_out, void* stream);
 /* The whole ResNet stem in one launch (exp/gpv/models/backbone.py:93-95 -> torchvision resnet50 conv1 + bn1 (frozen: scale folded
  * into w, shift here) + relu + maxpool):  y[B,PH,PW,64] = maxpool3x3s2p1(relu(conv7x7s2(x) + shift)).  x = the zero-padded NHWC4
  * bf16 image gpv_image_to_nhwc4 writes with pad 3 ([B,Hp,Wp,4], Wp even, >= 2 (CW - 1) + 8), w = [64][7][8 px][4 ch] bf16 (8th pixel /

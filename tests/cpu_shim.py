@@ -200,6 +200,10 @@ def maxpool3x3s2(x, y, B, H, W, Cc, OH, OW):
     y.copy_(F.max_pool2d(x.float().permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1).to(y.dtype))
 
 
+def image_pipeline(descs_dev, B, scratch, grey_sum, out, OH, OW, pad, Hp, Wp):
+    raise RuntimeError('cpu_shim: the device input pipeline has no CPU emulation (oracle/image_oracle.py is its checker)')
+
+
 def stem_pool(x, w, shift, y, B, Hp, Wp, CH, CW, PH, PW):
     # x [B,Hp,Wp,4] padded NHWC4, w [64][7][32] = [co][r][8 px][4 ch]
     wk = w.float().view(64, 7, 8, 4).permute(0, 3, 1, 2)                       # [co][ch][r][8]

@@ -99,6 +99,20 @@ def test_two_rank_gradient_exchange(tmp_path):
     assert torch.equal(r0['touched'], r1['touched']) and r0['touched'][ib].all()
     # parameters were broadcast from rank 0 at construction and stay bit-identical after two steps
     assert torch.equal(r0['P'], r1['P'])
+    # bf16 gradient exchange (GPV_GRAD_COMM=bf16: half the bytes on the ring): both ranks receive the same bf16 sums -> still
+    # bit-identical replicas; the exchanged gradient is the fp32 average to bf16 precision
+    os.environ['GPV_GRAD_COMM'] = 'bf16'
+    try:
+        out = tmp_path / 'bf16'
+        out.mkdir()
+        mp.spawn(_worker, args=(2, _free_port(), str(out)), nprocs=2, join=True)
+    finally:
+        os.environ.pop('GPV_GRAD_COMM')
+    b0, b1 = [torch.load(os.path.join(out, f'rank{r}.pt')) for r in range(2)]
+    assert torch.equal(b0['avg'], b1['avg']) and torch.equal(b0['P'], b1['P'])
+    avg = (b0['local'] + b1['local']) / 2
+    assert (b0['avg'] - avg).abs().max().item() <= 8e-3 * max(avg.abs().max().item(), 1e-6)
+    assert not torch.equal(b0['avg'], r0['avg'])                   # (it really went through bf16)
 
 
 def _worker_noloss(rank, world, port, out):

@@ -4,6 +4,8 @@ composite).  Tolerances: precise (fp32 I/O, split-bf16 MFMA) 3e-5 of max|ref|; b
 max|ref| against fp32 math on the bf16-rounded inputs (one bf16 output rounding = 3.9e-3)."""
 import math
 
+import numpy as np
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -926,3 +928,74 @@ def test_streaming_3x3_conv_kernel_forced(c3s, Cin, Cout, s, H, W, Bn):
         ref = gx * (saved.float() > 0) if mask is not None else gx
         assert rel(dx, nhwc(ref)) < TOL[dtype]
     assert h.set_option(h.OPT_C3S_LAUNCHES, 0) == (2 if s == 1 else 0)
+
+
+# ----------------------------------------------------------------------------------------- device-side input pipeline
+def test_device_input_pipeline_vs_oracle():
+    """gpv_image_pipeline (image_pipeline.hip) against oracle/image_oracle.py (numpy / scipy float64 restatement of the reference's
+    resize + ToPILImage / ColorJitter / flip / grayscale / Normalize; "parity unpinned" against the real skimage / PIL): images of
+    different sizes incl. down-scaling with the anti-aliasing filter, every jitter order class, flip, grayscale.  The two differ
+    only where fp32 vs fp64 arithmetic lands on the other side of a uint8 truncation / rounding: at most one uint8 step for 99.5 %
+    of the values, never more than three (hue: a sector boundary), and the padding frame is exactly zero."""
+    from oracle import image_oracle as IO
+    from gpv1_amd.input_pipeline import DeviceImagePipeline, stem_geometry
+    h = hip()
+    rs = np.random.RandomState(3)
+    H, W = 96, 128
+    shapes = [(96, 128), (150, 131), (60, 90), (300, 420), (97, 128), (200, 64)]
+    params = [dict(jitter=0, order=(0, 1, 2, 3), brightness=1.0, contrast=1.0, saturation=1.0, hue=0.0, flip=0, gray=0),
+              dict(jitter=1, order=(0, 1, 2, 3), brightness=1.3, contrast=0.7, saturation=1.2, hue=0.05, flip=1, gray=0),
+              dict(jitter=1, order=(3, 2, 1, 0), brightness=0.65, contrast=1.35, saturation=0.6, hue=-0.1, flip=0, gray=0),
+              dict(jitter=1, order=(1, 3, 0, 2), brightness=1.1, contrast=1.1, saturation=1.4, hue=0.08, flip=1, gray=1),
+              dict(jitter=0, order=(0, 1, 2, 3), brightness=1.0, contrast=1.0, saturation=1.0, hue=0.0, flip=1, gray=1),
+              dict(jitter=1, order=(2, 0, 3, 1), brightness=0.9, contrast=0.8, saturation=0.9, hue=-0.03, flip=0, gray=0)]
+    # smooth images + noise (a pure-noise image makes every truncation a coin flip)
+    imgs = []
+    for (ih, iw) in shapes:
+        yy, xx = np.mgrid[0:ih, 0:iw]
+        base = np.stack([127 + 100 * np.sin(yy / 9.0 + c) * np.cos(xx / 13.0 - c) for c in range(3)], -1)
+        imgs.append(np.clip(base + rs.randn(ih, iw, 3) * 12, 0, 255).astype(np.uint8))
+    pipe = DeviceImagePipeline(size=(H, W), train=True)
+    for dtype in (torch.float32, torch.bfloat16):
+        import gpv1_amd.ops as ops
+        ops.RT.set_precise(dtype == torch.float32)
+        try:
+            nt = pipe([torch.from_numpy(i) for i in imgs], params=params)
+        finally:
+            ops.RT.set_precise(False)
+        Hp, Wp = stem_geometry(H, W)
+        out = nt.tensors.float().cpu().numpy()
+        assert out.shape == (len(imgs), Hp, Wp, 4) and nt.mask.shape == (len(imgs), H, W) and not bool(nt.mask.any())
+        frame = out.copy()
+        frame[:, 3:3 + H, 3:3 + W, :3] = 0
+        assert np.all(frame == 0)                                                   # padding ring + 4th channel
+        for b, (img, p) in enumerate(zip(imgs, params)):
+            ref = IO.pipeline(img, (H, W), p).transpose(1, 2, 0)                    # [H, W, 3] normalised
+            got = out[b, 3:3 + H, 3:3 + W, :3]
+            steps = np.abs(got - ref) * (255.0 * IO.STD)                            # difference in uint8 steps
+            tol = 0.6 if dtype == torch.float32 else 2.0                            # bf16 output rounding: up to 2^-8 of |x| <= 2.7
+            assert (steps <= 1.0 + tol).mean() >= 0.995 and steps.max() <= 3.0 + tol, (b, dtype, float(steps.max()), float((steps <= 1 + tol).mean()))
+            if p['gray']:
+                assert np.array_equal(np.rint(got[..., 0] * 0.229 * 255), np.rint(got[..., 0] * 0.229 * 255))
+
+
+def test_model_accepts_the_prepared_stem_input():
+    """backbone: the pipeline's NHWC4 batch takes the place of (fp32 NCHW image -> gpv_image_to_nhwc4): same c5 as feeding the
+    oracle-processed fp32 image through the usual path (bf16: the two NHWC4 inputs differ where the uint8 steps above do)"""
+    from oracle import image_oracle as IO
+    from gpv1_amd.input_pipeline import DeviceImagePipeline
+    import gpv1_amd.backbone as bbm
+    from gpv1_amd.misc import NestedTensor
+    hip()
+    torch.manual_seed(0)
+    bb = bbm.Backbone('resnet50', True, False, False).to(DEV)
+    rs = np.random.RandomState(5)
+    imgs = [np.clip(127 + 60 * np.sin(np.mgrid[0:80, 0:100][0][..., None] / 7.0 + np.arange(3)) + rs.randn(80, 100, 3) * 10, 0, 255).astype(np.uint8) for _ in range(2)]
+    p0 = dict(jitter=0, order=(0, 1, 2, 3), brightness=1.0, contrast=1.0, saturation=1.0, hue=0.0, flip=0, gray=0)
+    pipe = DeviceImagePipeline(size=(64, 96), train=False)
+    nt = pipe([torch.from_numpy(i) for i in imgs], params=[p0, p0])
+    ref_img = torch.from_numpy(np.stack([IO.pipeline(i, (64, 96), p0) for i in imgs])).float().to(DEV)
+    with torch.no_grad():
+        a = bb(nt)['0'].tensors
+        b_ = bb(NestedTensor(ref_img, torch.zeros(2, 64, 96, dtype=torch.bool, device=DEV), True))['0'].tensors
+    assert a.shape == b_.shape and rel(a, b_) < 3e-2
