@@ -1,5 +1,5 @@
-"""attention core timings (forward, backward) on the model's shapes at B=32: encoder self (300x300), decoder cross (100x300),
-decoder self (100x100), co-attention (100x24 / 24x100), text (20x20 causal).  usage: python tools/bench_attn.py"""
+"""attention core timings (forward, backward) on the model's shapes at B=32: encoder self (300x300, 8 x 32), decoder cross (100x300) /
+self (100x100), co-attention (16 heads x 48: 100x6 / 6x100), text decoder (8 x 96: 20x20 causal, 20x106), BERT (12 x 64).  usage: python tools/bench_attn.py"""
 import math, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import gpv1_amd.hip as hip
@@ -45,12 +45,14 @@ def main():
     case('enc self 300x300 p=0', 32, 8, 300, 300, 32, 0.0)
     case('dec cross 100x300 dh32', 32, 8, 100, 300, 32, 0.1)
     case('dec self 100x100 dh32', 32, 8, 100, 100, 32, 0.1)
-    case('coatt 24x100 dh96', 32, 8, 24, 100, 96, 0.1)
-    case('coatt 100x24 dh96', 32, 8, 100, 24, 96, 0.1)
-    case('text cross 20x124 dh64', 32, 12, 20, 124, 64, 0.1)
-    case('text self 20x20 causal dh64', 32, 12, 20, 20, 64, 0.1, causal=True)
-    case('bert 24x24 kpm dh64', 32, 12, 24, 24, 64, 0.1, kpm=True)
-
+    # co-attention: 16 heads x dh 48 (configs/exp/gpv.yaml:70 bi_num_attention_heads 16, bi_hidden 768); T_l = 6 query tokens (bench), 16 (longest class)
+    case('coatt vis->lang 100x6 dh48', 32, 16, 100, 6, 48, 0.1)
+    case('coatt lang->vis 6x100 dh48', 32, 16, 6, 100, 48, 0.1)
+    case('coatt vis->lang 100x16 dh48 kpm', 32, 16, 100, 16, 48, 0.1, kpm=True)
+    # text decoder: 8 heads x dh 96 (gpv.yaml text_decoder.nheads 8, hidden 768); S = 20 tokens, memory = 100 + T_l
+    case('text cross 20x106 dh96', 32, 8, 20, 106, 96, 0.1)
+    case('text self 20x20 causal dh96', 32, 8, 20, 20, 96, 0.1, causal=True)
+    case('bert 6x6 kpm dh64', 32, 12, 6, 6, 64, 0.1, kpm=True)
 
 if __name__ == '__main__':
     main()

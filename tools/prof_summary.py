@@ -5,7 +5,7 @@ d, nsteps = sys.argv[1], int(sys.argv[2])
 stats = list(csv.DictReader(open(glob.glob(os.path.join(d, '**', '*kernel_stats.csv'), recursive=True)[0])))
 trace = list(csv.DictReader(open(glob.glob(os.path.join(d, '**', '*kernel_trace.csv'), recursive=True)[0])))
 tot = sum(float(r['TotalDurationNs']) for r in stats)
-print('# rocprofv3 --kernel-trace --stats summary of `python bench.py` (%d steps incl. warm-up)\n' % nsteps)
+print('# rocprofv3 --kernel-trace --stats summary of `python bench.py --steps 4 --warmup 3` (%d passes of the conv body: 7 training steps + 6 isolated forward/backward passes; kernels outside the body run 7 times)\n' % nsteps)
 print('total GPU kernel time per step: %.2f ms over %.0f launches\n' % (tot / nsteps / 1e6, sum(int(r['Calls']) for r in stats) / nsteps))
 print('| % | ms/step | calls/step | avg us | kernel |\n|---|---|---|---|---|')
 for r in stats[:30]:
@@ -30,11 +30,11 @@ for li, (pl, n, st) in enumerate(((64, 3, 1), (128, 4, 2), (256, 6, 2), (512, 3,
         inpl, h, w = pl * 4, h2, w2
 def is_conv_fwd(n):
     return (('gemm_kernel' in n and 'Li2ELi0E' in n) or 'glds_kernelILi2E' in n or 'pipe_kernelILi2E' in n or 'conv1x1_kernel' in n
-            or 'conv1x1_nt_kernel' in n or 'c1s_kernel' in n)
+            or 'conv1x1_nt_kernel' in n or 'c1s_kernel' in n or 'c3r_kernel' in n or 'stem_pool_kernel' in n)
 
 
 ck = [r for r in seq if is_conv_fwd(r['Kernel_Name'])]
-print('\n## backbone forward, one launch per conv (last step): `c1s_kernel` (streaming 1x1) / `conv1x1_kernel` / `pipe_kernel<OP_CONV>` / `pipe_conv1x1_kernel` / `glds_kernel<OP_CONV>` / `gemm_kernel<OP_CONV>`\n')
+print('\n## backbone forward, one launch per conv (last step): `stem_pool_kernel` (conv1 + pool) / `c1s_kernel` (streaming 1x1) / `c3r_kernel` (streaming 3x3) / `conv1x1_kernel` / `pipe_kernel<OP_CONV>` / `pipe_conv1x1_kernel` / `glds_kernel<OP_CONV>` / `gemm_kernel<OP_CONV>`\n')
 print('| conv | M | N | K | us | TFLOP/s | algorithmic GB/s |\n|---|---|---|---|---|---|---|')
 tt = tf = tb = 0
 for (name, M, N, K, byts), r in zip(convs, ck[:len(convs)]):
