@@ -1,5 +1,5 @@
 // Streaming 3x3 convolution (gfx950): the stride-1 3x3 convolutions of ResNet layer1 / layer2 (64 or 128 input channels, 10^5 ..
-// 6 10^5 output pixels at the training batch), forward and backward-data
+// 6 10^5 output pixels at the training batch), forward and backward-data, and the stride-2 backward-data of layer2's first block
 // (exp/gpv/models/backbone.py:93-95 -> torchvision Bottleneck.conv2).
 //
 //   y[px, n] = epilogue( sum_{r,s,c} x[pix(px, r, s), c] W[n, r, s, c] ),   bf16, Cin in {64, 128}, 64 output channels per block
@@ -204,6 +204,165 @@ int c3r_launch(const GemmK& k, hipStream_t st) {
   return c3r_launch_w<CIN, DGRAD, MASK, 8>(k, st);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Stride-2 backward-data (the 3x3 / 2 of a stage's first block: dx [2 IH x 2 IW] from dy [IH x IW]), same row-walking scheme.
+// dx(oh, ow) only receives the taps with (oh + 1 - r) and (ow + 1 - s) even:
+//   even row 2y   : r = 1 <- dy row y                   odd row 2y+1  : r = 2 <- dy row y,  r = 0 <- dy row y + 1
+//   even col 2c   : s = 1 <- dy col c                   odd col 2c+1  : s = 2 <- dy col c,  s = 0 <- dy col c + 1 (lane shift)
+// A wave holds 32 dy columns of the dy rows y and y + 1 in registers and writes, for every y, the four parity tiles of the dx rows
+// 2y, 2y+1 (1 + 2 + 2 + 4 = 9 tap products, 31 of the 32 columns: lane 31 only lends its column to lane 30's odd outputs).  The
+// tile kernels ran this launch (layer2.0 conv2, B = 32) at 213 us by parity-class tiles with gathered rows; its bytes (dy 39 MB,
+// mask + dx 2 x 157 MB) take 56 us at the measured 6.3 TB/s.
+template <int CIN, bool MASK, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void c3d2_kernel(GemmK p, int rows_per_item, int nstrip, int nseg, int nitems) {
+  constexpr int KTOT = 9 * CIN, KP = KTOT + 8, KCN = CIN / 16, SWD = 31;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  bf16* Wl = reinterpret_cast<bf16*>(smem_raw);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), h = lane >> 5, pl = lane & 31;
+  const int cbase = (int)blockIdx.y * C3_NSL;
+  const ConvGeom& g = p.cg;                      // IH x IW = dy, OH x OW = dx = 2 IH x 2 IW
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), (short)0, C3_OOB, 0x00020000);
+  bf16* Y = reinterpret_cast<bf16*>(p.C) + cbase;
+  const bf16* Mk = reinterpret_cast<const bf16*>(p.mask) + cbase;
+  int i_hi, i_step, item;
+  {
+    const int nb = gridDim.x;
+    if ((nb & 7) == 0) {
+      const int per = (nitems + 7) >> 3, xcd = blockIdx.x & 7, lb = blockIdx.x >> 3, nbx = nb >> 3;
+      i_hi = min(nitems, (xcd + 1) * per);
+      i_step = nbx * WAVES;
+      item = xcd * per + lb * WAVES + wave;
+    } else {
+      i_hi = nitems; i_step = nb * WAVES;
+      item = blockIdx.x * WAVES + wave;
+    }
+  }
+  {
+    const bf16* Wg = reinterpret_cast<const bf16*>(p.B);
+    constexpr int SL = KTOT / 8;
+    for (int idx = tid; idx < C3_NSL * SL; idx += WAVES * 64) {
+      const int L = idx / SL, sl = idx - L * SL;
+      const int c = cbase + (L & ~31) + c3_perm(L & 31);
+      *reinterpret_cast<bf16x8*>(Wl + L * KP + sl * 8) = *reinterpret_cast<const bf16x8*>(Wg + (int64_t)c * KTOT + sl * 8);
+    }
+  }
+  __syncthreads();
+  const bf16* wlane = Wl + pl * KP + h * 8;
+  u32x4 row[2][KCN];
+  for (; item < i_hi; item += i_step) {
+    const int seg = item % nseg, t1 = item / nseg, strip = t1 % nstrip, b = t1 / nstrip;
+    const int y0 = seg * rows_per_item, x0 = strip * SWD;
+    const int xd = x0 + pl;                                           // this lane's dy column
+    const bool xok = xd < g.IW;
+    const int colo = ((b * g.IH) * g.IW + xd) * g.Cs * 2 + h * 16;
+    const int rowb = g.IW * g.Cs * 2;
+    auto load_row = [&](int ih, int slot) {
+      const int vo = (xok && (unsigned)ih < (unsigned)g.IH) ? colo + ih * rowb : C3_OOB;
+#pragma unroll
+      for (int kc = 0; kc < KCN; ++kc) row[slot][kc] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, kc * 32, 0);
+    };
+    load_row(y0, 0);
+    load_row(y0 + 1, 1);
+    const bool cok = pl < SWD && xd < g.IW;
+    const int rows_here = min(rows_per_item, g.IH - y0);
+    for (int j0 = 0; j0 < rows_here; j0 += 2) {
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        if (j0 + jj < rows_here) {                                    // (uniform)
+          const int y = y0 + j0 + jj;
+          // four parity tiles: (py, px); taps of tile = {r in R(py)} x {s in S(px)}; r = 1 | {2, 0} reads slot jj | {jj, jj ^ 1}
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const int py = t >> 1, px = t & 1;
+            int wvo = 0;
+            asm volatile("" : "+v"(wvo));                             // (keeps the weight reads inside the loops, see c3r_kernel)
+            const bf16* wl = wlane + wvo;
+            const int opix = (b * g.OH + 2 * y + py) * g.OW + 2 * xd + px;
+            bf16x8 mv[MASK ? 4 : 1];
+            if constexpr (MASK) {
+#pragma unroll
+              for (int c = 0; c < 4; ++c)
+                mv[c] = cok ? *reinterpret_cast<const bf16x8*>(Mk + (int64_t)opix * p.ldm + (c >> 1) * 32 + (c & 1) * 16 + h * 8) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            }
+            f32x16 acc[2];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+              for (int e = 0; e < 16; ++e) acc[nt][e] = 0.f;
+#pragma unroll
+            for (int ri = 0; ri <= py; ++ri) {
+              const int r = py ? (ri ? 0 : 2) : 1;                    // odd rows: r = 2 (dy row y), r = 0 (dy row y + 1)
+              const int slot = (py && ri) ? (jj ^ 1) : jj;
+#pragma unroll
+              for (int kc = 0; kc < KCN; ++kc) {
+                u32x4 a = row[slot][kc];
+#pragma unroll
+                for (int si = 0; si <= px; ++si) {
+                  const int sx = px ? (si ? 0 : 2) : 1;               // odd cols: s = 2 (dy col c), s = 0 (dy col c + 1: lane shift)
+                  if (si > 0) {
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) a[d] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)a[d], 0x130 /* wave_shl:1 */, 0xf, 0xf, true);
+                  }
+                  const int tap = r * 3 + sx;
+#pragma unroll
+                  for (int nt = 0; nt < 2; ++nt) {
+                    const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wl + nt * 32 * KP + tap * CIN + kc * 16);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, __builtin_bit_cast(bf16x8, a), acc[nt], 0, 0, 0);
+                  }
+                }
+              }
+            }
+            if (cok) {
+#pragma unroll
+              for (int c = 0; c < 4; ++c) {
+                const int nt = c >> 1, hi = c & 1;
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                  float x = acc[nt][hi * 8 + e];
+                  if constexpr (MASK) x = (float)mv[c][e] > 0.f ? x : 0.f;
+                  o[e] = (bf16)x;
+                }
+                *reinterpret_cast<bf16x8*>(Y + (int64_t)opix * p.ldc + nt * 32 + hi * 16 + h * 8) = o;
+              }
+            }
+          }
+          load_row(y + 2, jj);                                        // dy row y is done: its slot takes row y + 2
+        }
+      }
+    }
+  }
+}
+
+template <int CIN, bool MASK>
+int c3d2_launch(const GemmK& k, hipStream_t st) {
+  constexpr int WAVES = 8, KP = 9 * CIN + 8;
+  const size_t lds = (size_t)C3_NSL * KP * 2;
+  auto fn = c3d2_kernel<CIN, MASK, WAVES>;
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    attr = true;
+  }
+  const ConvGeom& g = k.cg;
+  const int nsl = k.N / C3_NSL, Bn = k.M / (g.OH * g.OW);
+  const int nstrip = (g.IW + 30) / 31;
+  static const int env_rows = [] { const char* e = getenv("GPV_C3D2_ROWS"); return e ? atoi(e) : 0; }();
+  int blocks = 256 / nsl;
+  int rows = env_rows > 0 ? env_rows : 2;
+  if (env_rows <= 0) {
+    const int64_t waves = (int64_t)blocks * WAVES;
+    while (rows < 16 && (int64_t)Bn * nstrip * ((g.IH + rows + 1) / (rows + 2)) >= 2 * waves) rows += 2;
+  }
+  const int nseg = (g.IH + rows - 1) / rows;
+  const int nitems = Bn * nstrip * nseg;
+  while (blocks > 8 && (int64_t)(blocks - 8) * WAVES >= nitems) blocks -= 8;
+  hipLaunchKernelGGL(fn, dim3(blocks, nsl), dim3(WAVES * 64), lds, st, k, rows, nstrip, nseg, nitems);
+  GPV_CHECK_LAUNCH();
+  return 0;
+}
+
 template <int CIN>
 int c3r_mode(const GemmK& k, bool dgrad, hipStream_t st) {
   const bool m = k.mask != nullptr;
@@ -231,12 +390,15 @@ int c3s_try_launch(const GemmK& k, int dtype_in, int dtype_out, hipStream_t st) 
   if (k.res || k.rowscale || k.alpha != 1.0f || k.dthresh || k.accumulate || k.split_k > 1 || k.a_rowsum) return -1;
   if (k.act != GPV_ACT_NONE && k.act != GPV_ACT_RELU) return -1;
   if (!al16c(k.A) || !al16c(k.B) || !al16c(k.C) || (k.mask && !al16c(k.mask))) return -1;
-  if (g.SH != 1) return -1;              // (stride 2 -- forward and the backward-data parity classes -- stays on the tile kernels)
+  const bool d2 = g.SH == 2 && g.dgrad && g.Cin == 128 && g.OH == 2 * g.IH && g.OW == 2 * g.IW && k.act == GPV_ACT_NONE && !k.bias;
+  if (g.SH != 1 && !d2) return -1;       // (the stride-2 forward stays on the tile kernels)
   // input extent addressed with 32-bit byte offsets (dgrad: the "input" is dy)
   const int64_t in_px = (int64_t)(k.M / (g.OH * g.OW)) * g.IH * g.IW;
   if (in_px * g.Cs * 2 >= (int64_t)C3_OOB) return -1;
   if (mode == 1 && k.M < 65536) return -1;          // a streaming regime needs rows: the layer1 / layer2 maps at training batch sizes
-  const int e = g.Cin == 64 ? c3r_mode<64>(k, g.dgrad != 0, st) : c3r_mode<128>(k, g.dgrad != 0, st);
+  int e;
+  if (d2) e = k.mask ? c3d2_launch<128, true>(k, st) : c3d2_launch<128, false>(k, st);
+  else e = g.Cin == 64 ? c3r_mode<64>(k, g.dgrad != 0, st) : c3r_mode<128>(k, g.dgrad != 0, st);
   if (e == 0) ++g_c3s_launches;
   return e;
 }
