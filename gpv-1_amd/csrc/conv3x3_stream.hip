@@ -271,6 +271,17 @@ __global__ __launch_bounds__(WAVES * 64) void c3d2_kernel(GemmK p, int rows_per_
         if (j0 + jj < rows_here) {                                    // (uniform)
           const int y = y0 + j0 + jj;
           // four parity tiles: (py, px); taps of tile = {r in R(py)} x {s in S(px)}; r = 1 | {2, 0} reads slot jj | {jj, jj ^ 1}
+          // the ReLU masks of all four tiles are requested up front: the first tile has only 16 MFMAs to hide an HBM read behind
+          bf16x8 mv[MASK ? 16 : 1];
+          if constexpr (MASK) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              const int opix = (b * g.OH + 2 * y + (t >> 1)) * g.OW + 2 * xd + (t & 1);
+#pragma unroll
+              for (int c = 0; c < 4; ++c)
+                mv[t * 4 + c] = cok ? *reinterpret_cast<const bf16x8*>(Mk + (int64_t)opix * p.ldm + (c >> 1) * 32 + (c & 1) * 16 + h * 8) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            }
+          }
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
             const int py = t >> 1, px = t & 1;
@@ -278,12 +289,6 @@ __global__ __launch_bounds__(WAVES * 64) void c3d2_kernel(GemmK p, int rows_per_
             asm volatile("" : "+v"(wvo));                             // (keeps the weight reads inside the loops, see c3r_kernel)
             const bf16* wl = wlane + wvo;
             const int opix = (b * g.OH + 2 * y + py) * g.OW + 2 * xd + px;
-            bf16x8 mv[MASK ? 4 : 1];
-            if constexpr (MASK) {
-#pragma unroll
-              for (int c = 0; c < 4; ++c)
-                mv[c] = cok ? *reinterpret_cast<const bf16x8*>(Mk + (int64_t)opix * p.ldm + (c >> 1) * 32 + (c & 1) * 16 + h * 8) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-            }
             f32x16 acc[2];
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
@@ -320,7 +325,7 @@ __global__ __launch_bounds__(WAVES * 64) void c3d2_kernel(GemmK p, int rows_per_
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                   float x = acc[nt][hi * 8 + e];
-                  if constexpr (MASK) x = (float)mv[c][e] > 0.f ? x : 0.f;
+                  if constexpr (MASK) x = (float)mv[t * 4 + c][e] > 0.f ? x : 0.f;
                   o[e] = (bf16)x;
                 }
                 *reinterpret_cast<bf16x8*>(Y + (int64_t)opix * p.ldc + nt * 32 + hi * 16 + h * 8) = o;
