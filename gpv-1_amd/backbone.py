@@ -26,6 +26,7 @@ from .position_encoding import build_position_encoding
 
 RELU = hip.ACT_RELU
 FUSED_STEM = os.environ.get('GPV_FUSED_STEM', '1') != '0'
+FUSED_TAIL = os.environ.get('GPV_FUSED_TAIL', '1') != '0'
 WGRAD_STREAM = os.environ.get('GPV_WGRAD_STREAM', '1') != '0'
 _WSTREAMS = {}
 
@@ -147,6 +148,26 @@ def _conv_fwd(x, conv, bn, need_wd, act, res=None):
     return y
 
 
+def _block_tail_fused(x, a2, blk, tr, need_wd):
+    """ReLU(conv3(a2) + downsample(x)) of a stage's first block as ONE launch (gpv_conv1x1_dual: layer1 / layer2); None = not a
+    shape the kernel takes"""
+    c3, cd = blk.conv3, blk.downsample[0]
+    B, OH, OW, K1 = a2.shape
+    _, IH, IW, K2 = x.shape
+    if (K1, K2, c3.cout) not in ((64, 64, 256), (128, 256, 512)):
+        return None
+    w3, _, _, s3 = _conv_copies(c3, blk.bn3, tr)
+    wd, _, _, sd = _conv_copies(cd, blk.downsample[1], need_wd)
+    key = ('tail_shift', id(blk))
+    hit = RT.cache.get(key)
+    if hit is None or hit[0] != RT.static_epoch:
+        hit = RT.cache[key] = (RT.static_epoch, (s3 + sd).contiguous())          # FrozenBN shifts: constants of the static epoch
+    y = torch.empty(B, OH, OW, c3.cout, device=x.device, dtype=RT.dtype)
+    if not hip.conv1x1_dual(a2, w3, x, wd, hit[1], y, B, OH, OW, K1, IH, IW, K2, cd.stride, c3.cout, RELU):
+        return None
+    return y
+
+
 def _conv_dgrad(dy, conv, bn, xshape, res=None, relu_mask=None):
     """dx[B,H,W,Cin] = convT(dy) (+res) * (relu_mask > 0)"""
     B, H, Wd, Cin = xshape
@@ -240,8 +261,10 @@ class ResNetBody(nn.Module):
             need_wd = tr and seen_trainable         # dgrad into this block's input only if something upstream trains
             a1 = _conv_fwd(x, blk.conv1, blk.bn1, tr, RELU)
             a2 = _conv_fwd(a1, blk.conv2, blk.bn2, tr, RELU)
-            idt = x if blk.downsample is None else _conv_fwd(x, blk.downsample[0], blk.downsample[1], need_wd, hip.ACT_NONE)
-            yb = _conv_fwd(a2, blk.conv3, blk.bn3, tr, RELU, res=idt)
+            yb = _block_tail_fused(x, a2, blk, tr, need_wd) if (blk.downsample is not None and FUSED_TAIL and RT.dtype == torch.bfloat16) else None
+            if yb is None:
+                idt = x if blk.downsample is None else _conv_fwd(x, blk.downsample[0], blk.downsample[1], need_wd, hip.ACT_NONE)
+                yb = _conv_fwd(a2, blk.conv3, blk.bn3, tr, RELU, res=idt)
             if tr:
                 keep.append((blk, x, a1, a2, yb, seen_trainable))
                 seen_trainable = True

@@ -83,7 +83,7 @@ EXPORTS = ['gpv_abi_version', 'gpv_set_option', 'gpv_gemm', 'gpv_conv2d', 'gpv_i
            'gpv_softmax_ce', 'gpv_roi_weights', 'gpv_add', 'gpv_add_rowbcast', 'gpv_colsum', 'gpv_cast',
            'gpv_cast_rowscale_t', 'gpv_prep_conv_weight', 'gpv_embedding', 'gpv_dropout',
            'gpv_relevance_condition', 'gpv_adamw', 'gpv_sumsq', 'gpv_act_fwd', 'gpv_act_bwd', 'gpv_set_seed_device',
-           'gpv_gemm_tt_group', 'gpv_cast_transpose_group', 'gpv_stem_pool', 'gpv_image_pipeline']
+           'gpv_gemm_tt_group', 'gpv_cast_transpose_group', 'gpv_stem_pool', 'gpv_image_pipeline', 'gpv_conv1x1_dual']
 
 
 OPT_GLDS, OPT_GLDS_LAUNCHES, OPT_SKINNY, OPT_GLDS_WGRAD, OPT_PIPE, OPT_PIPE_LAUNCHES, OPT_C1S, OPT_C3S, OPT_C3S_LAUNCHES = 0, 1, 2, 3, 4, 5, 6, 7, 8
@@ -296,6 +296,18 @@ def image_pipeline(descs_dev, B, scratch, grey_sum, out, OH, OW, pad, Hp, Wp):
     """gpv_image_pipeline: descs_dev = uint8 device tensor holding B packed ImageDesc structs"""
     _chk(lib().gpv_image_pipeline(_p(descs_dev), B, _p(scratch), _p(_f32(grey_sum)), _p(out), OH, OW, pad, Hp, Wp, dcode(out), _stream()),
          'gpv_image_pipeline')
+
+
+def conv1x1_dual(a1, w1, a2, w2, bias, y, B, OH, OW, K1, IH2, IW2, K2, s2, N, act=ACT_RELU):
+    """gpv_conv1x1_dual: y = act(a1 . w1^T + a2(stride s2) . w2^T + bias); returns False when the shape is not one the kernel
+    takes (hipErrorNotSupported) -- the caller then runs the two convolutions"""
+    if not all(t.dtype == torch.bfloat16 for t in (a1, w1, a2, w2, y)):
+        return False
+    err = lib().gpv_conv1x1_dual(_p(a1), _p(w1), _p(a2), _p(w2), _p(_f32(bias)), _p(y), B, OH, OW, K1, IH2, IW2, K2, s2, N, act, _stream())
+    if err == 801:
+        return False
+    _chk(err, 'gpv_conv1x1_dual')
+    return True
 
 
 def stem_pool(x, w, shift, y, B, Hp, Wp, CH, CW, PH, PW):

@@ -159,6 +159,12 @@ typedef struct gpv_image_desc {
 } gpv_image_desc;
 int gpv_image_pipeline(const gpv_image_desc* descs, int B, void* scratch_u8, float* grey_sum, void* out, int OH, int OW, int pad,
                        int Hp, int Wp, int dtype_out, void* stream);
+/* The tail of a stage's first bottleneck in one launch (torchvision Bottleneck.forward with a downsample branch,
+ * exp/gpv/models/backbone.py:93-95): y = act(conv3(a1) + downsample(a2 at stride s2) + bias), both pointwise, FrozenBN scales folded
+ * into w1 [N,K1] / w2 [N,K2], bias = the two shifts added.  bf16; (K1, K2, N) in {(64, 64, 256), (128, 256, 512)} (layer1 / layer2);
+ * hipErrorNotSupported (801) for anything else -- the caller then issues the two convolutions. */
+int gpv_conv1x1_dual(const void* a1, const void* w1, const void* a2, const void* w2, const float* bias, void* y, int B, int OH, int OW,
+                     int K1, int IH2, int IW2, int K2, int s2, int N, int act, void* stream);
 /* The whole ResNet stem in one launch (exp/gpv/models/backbone.py:93-95 -> torchvision resnet50 conv1 + bn1 (frozen: scale folded
  * into w, shift here) + relu + maxpool):  y[B,PH,PW,64] = maxpool3x3s2p1(relu(conv7x7s2(x) + shift)).  x = the zero-padded NHWC4
  * bf16 image gpv_image_to_nhwc4 writes with pad 3 ([B,Hp,Wp,4], Wp even, >= 2 (CW - 1) + 8), w = [64][7][8 px][4 ch] bf16 (8th pixel /

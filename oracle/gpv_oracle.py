@@ -148,8 +148,12 @@ def frozen_bn(x: Tensor, Pm: P, pre: str) -> Tensor:
     return x * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1)
 
 
+FUSED_TAIL_PLANES = (64, 128)     # stages whose first block runs conv3 + downsample as ONE kernel (gpv_conv1x1_dual): the identity
+                                  # branch is never stored, hence never rounded to bf16
+
+
 def _conv_bn_bf16(x: Tensor, Pm: P, conv: str, bn: str, stride: int = 1, padding: int = 0,
-                  res: Optional[Tensor] = None, relu: bool = True) -> Tensor:
+                  res: Optional[Tensor] = None, relu: bool = True, round_out: bool = True) -> Tensor:
     """the HIP conv epilogue: bf16(W * scale) (*) x -> + shift -> (+ residual) -> ReLU -> bf16"""
     if bn + 'folded_scale' in Pm:            # (tests: the fold as the device computed it -- rsqrt differs in the last fp32 bit
         scale, shift = Pm[bn + 'folded_scale'], Pm[bn + 'folded_shift']      #  between CPU and GPU, which flips bf16 weight roundings)
@@ -159,7 +163,8 @@ def _conv_bn_bf16(x: Tensor, Pm: P, conv: str, bn: str, stride: int = 1, padding
     y = F.conv2d(_r(x), _r(Pm[conv] * scale.view(-1, 1, 1, 1)), stride=stride, padding=padding) + shift.view(1, -1, 1, 1)
     if res is not None:
         y = y + res
-    return _r(F.relu(y) if relu else y)
+    y = F.relu(y) if relu else y
+    return _r(y) if round_out else y
 
 
 def bottleneck(x: Tensor, Pm: P, pre: str, stride: int, downsample: bool) -> Tensor:
@@ -167,7 +172,9 @@ def bottleneck(x: Tensor, Pm: P, pre: str, stride: int, downsample: bool) -> Ten
     if _BF16[0]:
         out = _conv_bn_bf16(x, Pm, pre + 'conv1.weight', pre + 'bn1.')
         out = _conv_bn_bf16(out, Pm, pre + 'conv2.weight', pre + 'bn2.', stride=stride, padding=1)
-        idt = _conv_bn_bf16(x, Pm, pre + 'downsample.0.weight', pre + 'downsample.1.', stride=stride, relu=False) if downsample else x
+        fused = downsample and Pm[pre + 'conv3.weight'].shape[1] in FUSED_TAIL_PLANES
+        idt = _conv_bn_bf16(x, Pm, pre + 'downsample.0.weight', pre + 'downsample.1.', stride=stride, relu=False,
+                            round_out=not fused) if downsample else x
         return _conv_bn_bf16(out, Pm, pre + 'conv3.weight', pre + 'bn3.', res=idt)
     out = F.relu(frozen_bn(F.conv2d(x, Pm[pre + 'conv1.weight']), Pm, pre + 'bn1.'))
     out = F.relu(frozen_bn(F.conv2d(out, Pm[pre + 'conv2.weight'], stride=stride, padding=1), Pm, pre + 'bn2.'))

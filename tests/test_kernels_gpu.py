@@ -1002,3 +1002,30 @@ def test_model_accepts_the_prepared_stem_input():
         a = bb(nt)['0'].tensors
         b_ = bb(NestedTensor(ref_img, torch.zeros(2, 64, 96, dtype=torch.bool, device=DEV), True))['0'].tensors
     assert a.shape == b_.shape and rel(a, b_) < 3e-2
+
+
+@pytest.mark.parametrize('K1,K2,N,s2,OH,OW,Bn', [(64, 64, 256, 1, 24, 32, 3), (64, 64, 256, 1, 7, 9, 5), (128, 256, 512, 2, 15, 20, 3),
+                                                 (128, 256, 512, 2, 8, 6, 2)])
+def test_fused_block_tail_conv3_plus_downsample(K1, K2, N, s2, OH, OW, Bn):
+    """gpv_conv1x1_dual (conv1x1_dual.hip): ReLU(conv3(a2) + downsample(x at the block's stride) + shifts) in one launch against
+    fp32 torch and against the two-launch path it replaces (downsample conv, then conv3 with the residual epilogue: one more bf16
+    rounding, of the identity branch)"""
+    h, dtype = hip(), torch.bfloat16
+    IH, IW = OH * s2 - (s2 - 1) * (OH % 2), OW * s2                   # an odd input height for the strided case
+    IH = max(IH, (OH - 1) * s2 + 1)
+    a2 = rnd(Bn, OH, OW, K1, dtype=dtype, seed=70)
+    x = rnd(Bn, IH, IW, K2, dtype=dtype, seed=71)
+    w3 = rnd(N, K1, dtype=dtype, seed=72, scale=1.0 / math.sqrt(K1))
+    wd = rnd(N, K2, dtype=dtype, seed=73, scale=1.0 / math.sqrt(K2))
+    b3, bd = rnd(N, seed=74), rnd(N, seed=75)
+    y = torch.full((Bn, OH, OW, N), float('nan'), device=DEV, dtype=dtype)
+    assert h.conv1x1_dual(a2, w3, x, wd, (b3 + bd).contiguous(), y, Bn, OH, OW, K1, IH, IW, K2, s2, N, h.ACT_RELU)
+    xs = x[:, ::s2, ::s2][:, :OH, :OW].float()
+    ref = F.relu(a2.float() @ w3.float().t() + xs @ wd.float().t() + b3 + bd)
+    assert rel(y, ref) < TOL[dtype]
+    idt = torch.empty(Bn, OH, OW, N, device=DEV, dtype=dtype)
+    h.conv2d(0, x, wd.view(N, 1, K2), idt, Bn, IH, IW, K2, K2, OH, OW, N, 1, 1, s2, s2, 0, 0, bias=bd)
+    y2 = torch.empty_like(y)
+    h.conv2d(0, a2, w3.view(N, 1, K1), y2, Bn, OH, OW, K1, K1, OH, OW, N, 1, 1, 1, 1, 0, 0, bias=b3, res=idt, act=h.ACT_RELU)
+    assert rel(y, y2) < 1.2e-2
+    assert not h.conv1x1_dual(a2[..., :32].contiguous(), w3[:, :32].contiguous(), x, wd, b3, y, Bn, OH, OW, 32, IH, IW, K2, s2, N, h.ACT_RELU)
