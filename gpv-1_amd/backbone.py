@@ -28,6 +28,7 @@ RELU = hip.ACT_RELU
 FUSED_STEM = os.environ.get('GPV_FUSED_STEM', '1') != '0'
 FUSED_TAIL = os.environ.get('GPV_FUSED_TAIL', '1') != '0'
 WGRAD_STREAM = os.environ.get('GPV_WGRAD_STREAM', '1') != '0'
+WGRAD_GROUP = os.environ.get('GPV_WGRAD_GROUP', '1') != '0'      # all conv weight gradients of a backward pass as one grouped call (bf16)
 _WSTREAMS = {}
 
 
@@ -179,13 +180,16 @@ def _conv_dgrad(dy, conv, bn, xshape, res=None, relu_mask=None):
     return dx
 
 
-def _conv_wgrad(x, dy, conv, bn):
+def _conv_wgrad(x, dy, conv, bn, group=None):
     if not conv.weight.requires_grad:
         return
     B, H, Wd, Cin = x.shape
     _, OH, OW, Cout = dy.shape
     _, _, scale, _ = _conv_copies(conv, bn, False)
     g = conv.phys(ensure_grad(conv.weight))
+    if group is not None:
+        group.append((x, dy, g, scale, B, H, Wd, Cin, Cin, OH, OW, Cout, conv.k, conv.k, conv.stride, conv.stride, conv.pad, conv.pad))
+        return
     hip.conv2d(2, x, dy, g, B, H, Wd, Cin, Cin, OH, OW, Cout, conv.k, conv.k, conv.stride, conv.stride, conv.pad, conv.pad,
                rowscale=scale)
 
@@ -289,19 +293,23 @@ class ResNetBody(nn.Module):
         """dc5: gradient w.r.t. the (post-ReLU) c5 output, [B,h,w,2048] compute dtype.
 
         The backward-data convolutions form a serial chain; the 42 weight gradients hang off it and nobody needs them before the
-        optimizer.  They run on a SIDE stream (a parallel branch when the pass is captured into a hipGraph): each is ordered
-        behind the backward-data launch that produced its dy, the chain never waits for them, one join at the end.  Both kinds
-        of launch fill the chip on their own but neither keeps it busy (prologues, tails, split-reduction passes): together
-        they do -- GPV_WGRAD_STREAM=0 puts them back in line."""
+        optimizer.  bf16: they are collected and handed to ONE grouped call at the end of the pass (gpv_conv_wgrad_group: equal
+        work units over all problems, layer4 without a split reduction) -- GPV_WGRAD_GROUP=0 / fp32 "precise" mode: one launch
+        each on a SIDE stream (a parallel branch when the pass is captured into a hipGraph), ordered behind the backward-data
+        launch that produced its dy, one join at the end (GPV_WGRAD_STREAM=0 puts them back in line)."""
         if not keep:
             return
         dev = dc5.device
         main = torch.cuda.current_stream(dev) if dev.type == 'cuda' else None
-        side = _wgrad_stream(dev) if (main is not None and WGRAD_STREAM) else None
+        group = [] if (WGRAD_GROUP and dc5.dtype == torch.bfloat16) else None
+        side = _wgrad_stream(dev) if (main is not None and WGRAD_STREAM and group is None) else None
         held = []                                        # operands of the side-stream launches stay referenced until the join
 
         def wgrad(xa, dy, conv, bn):
             if not conv.weight.requires_grad:
+                return
+            if group is not None:
+                _conv_wgrad(xa, dy, conv, bn, group)
                 return
             if side is None:
                 _conv_wgrad(xa, dy, conv, bn)
@@ -331,6 +339,8 @@ class ResNetBody(nn.Module):
             # input gradient, masked by the previous block's ReLU (x is that block's output)
             gz = _conv_dgrad(g1, blk.conv1, blk.bn1, x.shape, res=side_g, relu_mask=x)
             del g1, g2, side_g
+        if group:
+            hip.conv_wgrad_group(group)
         if side is not None:
             main.wait_stream(side)
         del held

@@ -266,6 +266,72 @@ __global__ __launch_bounds__(256) void glds_tt_group_kernel(GroupK g) {
   glds_tt_core<false>(p, bid - g.tile_start[pi], 0);
 }
 
+// ---- grouped launch: ALL conv weight gradients of a backward pass in one or two grids --------------------------------------------
+// Launched one by one (42 per step) every weight gradient sizes its split to fill the chip alone: 14..64 slabs of partial products
+// per gradient -- as many bytes as the operands -- a reduction pass each, a ramp and a tail each.  Nobody needs a weight gradient
+// before the optimizer, so the backward pass hands all of them over at its end: the work unit is (problem, split, tile), the split
+// of a problem is sized so that every unit walks ~GPV_WGRAD_GROUP_KT (150) k-tiles of 64 pixels -- layer4 needs NO split at all
+// (a tile adds itself into the gradient), layer3 4 slabs instead of 14..32 -- thousands of equal units keep the chip full, and
+// one grouped pass adds the remaining slabs.
+struct WgProb {
+  const void* A; const void* B; float* C; const float* rowscale;
+  int M, N, K, lda, ldc;
+  int kt_per_split, tilesN, tiles;
+  int unit_start;                        // prefix sum of tiles * split
+  int direct;                            // split == 1: the tile is added into C
+  int64_t ws_off;                        // floats into the workspace
+  int IH, IW, Cs, Cin, OH, OW, KH, KW, SH, SW, PH, PW;
+};
+static_assert(sizeof(WgProb) == 128, "descriptor size");
+constexpr int WG_MAX = 28;
+struct WgGroupK { int n; int pad; float* ws; WgProb prob[WG_MAX]; };
+static_assert(sizeof(WgGroupK) <= 4096, "kernel argument segment");
+
+__global__ __launch_bounds__(256) void glds_wgrad_group_kernel(WgGroupK g) {
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+  const int v = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;     // contiguous unit range per XCD
+  int pi = 0;
+  while (pi + 1 < g.n && v >= g.prob[pi + 1].unit_start) ++pi;
+  const WgProb& q = g.prob[pi];
+  GemmK p{};
+  p.A = q.A; p.B = q.B; p.C = q.C; p.rowscale = q.rowscale;
+  p.M = q.M; p.N = q.N; p.K = q.K; p.lda = q.lda; p.ldb = 0; p.ldc = q.ldc;
+  p.alpha = 1.0f;
+  p.ws = q.direct ? nullptr : g.ws + q.ws_off;
+  p.tilesN = q.tilesN; p.kt_per_split = q.kt_per_split;
+  p.cg.IH = q.IH; p.cg.IW = q.IW; p.cg.Cs = q.Cs; p.cg.Cin = q.Cin; p.cg.OH = q.OH; p.cg.OW = q.OW;
+  p.cg.KH = q.KH; p.cg.KW = q.KW; p.cg.SH = q.SH; p.cg.SW = q.SW; p.cg.PH = q.PH; p.cg.PW = q.PW;
+  const int u = v - q.unit_start;
+  const int ksplit = u / q.tiles;
+  glds_tt_core<true>(p, u - ksplit * q.tiles, ksplit);
+}
+
+struct WgRed { const float* ws; float* C; int64_t MN; int split, N, ldc, blk_start; };
+struct WgRedK { int n; int pad; WgRed r[WG_MAX]; };
+
+__global__ __launch_bounds__(256) void wgrad_group_reduce_kernel(WgRedK g) {
+  const int bid = blockIdx.x;
+  int pi = 0;
+  while (pi + 1 < g.n && bid >= g.r[pi + 1].blk_start) ++pi;
+  const WgRed& q = g.r[pi];
+  const int64_t idx = (int64_t)(bid - q.blk_start) * 256 + threadIdx.x;     // one quad of 4 columns per thread
+  if (idx * 4 >= q.MN) return;
+  const int nq = q.N >> 2;
+  const int m = (int)(idx / nq), c4 = (int)(idx - (int64_t)m * nq);
+  const float* src = q.ws + (int64_t)m * q.N + c4 * 4;
+  float4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+  for (int sidx = 0; sidx < q.split; ++sidx) {
+    const float4 v = *reinterpret_cast<const float4*>(src + (int64_t)sidx * q.MN);
+    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+  }
+  float4* dst = reinterpret_cast<float4*>(q.C + (int64_t)m * q.ldc + c4 * 4);
+  float4 c = *dst;
+  c.x += a.x; c.y += a.y; c.z += a.z; c.w += a.w;
+  *dst = c;
+}
+
 // shared launch tail: split sizing, workspace slabs, kernel, reduction
 template <typename F>
 int launch_tt(F fn, const GemmK& k, bool& attr_done, hipStream_t st) {
@@ -366,3 +432,86 @@ extern "C" int gpv_gemm_tt_group(const gpv_tt_problem* problems, int n, void* st
   return 0;
 }
 
+extern "C" int gpv_conv_wgrad_group(const gpv_conv_wgrad_problem* probs, int n, void* workspace, int64_t workspace_bytes, void* stream) {
+  using namespace gpvk;
+  if (!probs || n <= 0) return (int)hipErrorInvalidValue;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  // k-tiles of 64 pixels per work unit: 150 = layer4's whole reduction at B = 32 (measured: 75 / 100 / 150 / 250 / 300 ->
+  // 2.06 / 2.03 / 2.00 / 2.37 / 2.45 ms for the 42 gradients of the training step)
+  static const int target_kt = [] { const char* e = getenv("GPV_WGRAD_GROUP_KT"); const int v = e ? atoi(e) : 150; return v < 8 ? 8 : v; }();
+  static bool attr_done = false;
+  constexpr int lds = 2 * TSTAGE;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(glds_wgrad_group_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return (int)e;
+    attr_done = true;
+  }
+  WgGroupK g{};
+  WgRedK rk{};
+  int units = 0, rblocks = 0;
+  int64_t ws_used = 0;
+  const int64_t ws_floats = workspace ? workspace_bytes / 4 : 0;
+  auto flush = [&]() -> int {
+    if (g.n == 0) return 0;
+    g.ws = reinterpret_cast<float*>(workspace);
+    hipLaunchKernelGGL(glds_wgrad_group_kernel, dim3(units), dim3(256), lds, st, g);
+    GPV_CHECK_LAUNCH();
+    if (rk.n > 0) {
+      hipLaunchKernelGGL(wgrad_group_reduce_kernel, dim3(rblocks), dim3(256), 0, st, rk);
+      GPV_CHECK_LAUNCH();
+    }
+    g.n = 0; rk.n = 0; units = 0; rblocks = 0; ws_used = 0;
+    return 0;
+  };
+  for (int i = 0; i < n; ++i) {
+    const gpv_conv_wgrad_problem& q = probs[i];
+    if (!q.x || !q.dy || !q.dw || q.B <= 0) return (int)hipErrorInvalidValue;
+    const int M = q.Cout, N = q.KH * q.KW * q.Cin;
+    const int64_t K64 = (int64_t)q.B * q.OH * q.OW;
+    const bool ok = M % TBM == 0 && q.Cin % TBN == 0 && q.Cs % 8 == 0 && al16t(q.dy) && al16t(q.x) && al16t(q.dw) &&
+                    TBK / q.OW + 2 <= q.OH && (int64_t)q.IH * q.IW * q.Cs * q.B < (1ll << 30) && K64 * M < (1ll << 30) && K64 >= 8 * TBK;
+    if (!ok) {                                       // a shape the direct-to-LDS kernel does not take: its own launch
+      gpv_conv_args a{};
+      a.mode = 2; a.x = q.x; a.w = q.dy; a.y = q.dw;
+      a.B = q.B; a.IH = q.IH; a.IW = q.IW; a.Cs = q.Cs; a.Cin = q.Cin; a.OH = q.OH; a.OW = q.OW; a.Cout = q.Cout;
+      a.KH = q.KH; a.KW = q.KW; a.SH = q.SH; a.SW = q.SW; a.PH = q.PH; a.PW = q.PW;
+      a.dtype_in = GPV_BF16; a.dtype_out = GPV_F32; a.rowscale = q.rowscale;
+      int e = flush();                               // (the workspace is busy with this group's slabs until it is flushed)
+      if (e) return e;
+      a.workspace = workspace; a.workspace_bytes = workspace_bytes;
+      e = gpv_conv2d(&a, stream);
+      if (e) return e;
+      continue;
+    }
+    const int K = (int)K64;
+    const int kt_total = (K + TBK - 1) / TBK;
+    int split = (kt_total + target_kt / 2) / target_kt;
+    if (split < 1) split = 1;
+    const int64_t MN = (int64_t)M * N;
+    while (split > 1 && (int64_t)split * MN > ws_floats) --split;
+    const int kps = (kt_total + split - 1) / split;
+    split = (kt_total + kps - 1) / kps;
+    if (g.n == WG_MAX || (split > 1 && ws_used + (int64_t)split * MN > ws_floats)) {
+      const int e = flush();
+      if (e) return e;
+    }
+    WgProb& d = g.prob[g.n];
+    d.A = q.dy; d.B = q.x; d.C = q.dw; d.rowscale = q.rowscale;
+    d.M = M; d.N = N; d.K = K; d.lda = M; d.ldc = N;
+    d.kt_per_split = kps; d.tilesN = N / TBN; d.tiles = (M / TBM) * (N / TBN);
+    d.unit_start = units; d.direct = split == 1 ? 1 : 0; d.ws_off = ws_used;
+    d.IH = q.IH; d.IW = q.IW; d.Cs = q.Cs; d.Cin = q.Cin; d.OH = q.OH; d.OW = q.OW;
+    d.KH = q.KH; d.KW = q.KW; d.SH = q.SH; d.SW = q.SW; d.PH = q.PH; d.PW = q.PW;
+    units += d.tiles * split;
+    if (split > 1) {
+      WgRed& r = rk.r[rk.n];
+      r.ws = reinterpret_cast<const float*>(workspace) + ws_used; r.C = q.dw; r.MN = MN; r.split = split; r.N = N; r.ldc = N;
+      r.blk_start = rblocks;
+      rblocks += (int)((MN / 4 + 255) / 256);
+      ++rk.n;
+      ws_used += (int64_t)split * MN;
+    }
+    ++g.n;
+  }
+  return flush();
+}

@@ -57,6 +57,11 @@ class TTProblem(C.Structure):
                 ('M', C.c_int), ('N', C.c_int), ('K', C.c_int), ('lda', C.c_int), ('ldb', C.c_int), ('ldc', C.c_int)]
 
 
+class ConvWgradProblem(C.Structure):
+    _fields_ = [('x', C.c_void_p), ('dy', C.c_void_p), ('dw', C.c_void_p), ('rowscale', C.c_void_p)] + \
+               [(k, C.c_int) for k in ('B', 'IH', 'IW', 'Cs', 'Cin', 'OH', 'OW', 'Cout', 'KH', 'KW', 'SH', 'SW', 'PH', 'PW')]
+
+
 class ImageDesc(C.Structure):
     _fields_ = [('src', C.c_void_p), ('H', C.c_int), ('W', C.c_int), ('flip', C.c_int), ('gray', C.c_int), ('jitter', C.c_int),
                 ('order', C.c_int * 4), ('brightness', C.c_float), ('contrast', C.c_float), ('saturation', C.c_float),
@@ -83,7 +88,8 @@ EXPORTS = ['gpv_abi_version', 'gpv_set_option', 'gpv_gemm', 'gpv_conv2d', 'gpv_i
            'gpv_softmax_ce', 'gpv_roi_weights', 'gpv_add', 'gpv_add_rowbcast', 'gpv_colsum', 'gpv_cast',
            'gpv_cast_rowscale_t', 'gpv_prep_conv_weight', 'gpv_embedding', 'gpv_dropout',
            'gpv_relevance_condition', 'gpv_adamw', 'gpv_sumsq', 'gpv_act_fwd', 'gpv_act_bwd', 'gpv_set_seed_device',
-           'gpv_gemm_tt_group', 'gpv_cast_transpose_group', 'gpv_stem_pool', 'gpv_image_pipeline', 'gpv_conv1x1_dual']
+           'gpv_gemm_tt_group', 'gpv_cast_transpose_group', 'gpv_stem_pool', 'gpv_image_pipeline', 'gpv_conv1x1_dual',
+           'gpv_conv_wgrad_group']
 
 
 OPT_GLDS, OPT_GLDS_LAUNCHES, OPT_SKINNY, OPT_GLDS_WGRAD, OPT_PIPE, OPT_PIPE_LAUNCHES, OPT_C1S, OPT_C3S, OPT_C3S_LAUNCHES = 0, 1, 2, 3, 4, 5, 6, 7, 8
@@ -232,6 +238,23 @@ def conv2d(mode, x, w, y, B, IH, IW, Cs, Cin, OH, OW, Cout, KH, KW, SH, SW, PH, 
         ws = _workspace(x.device, WS_MAX)
         a.workspace, a.workspace_bytes = _p(ws), ws.numel()
     _chk(lib().gpv_conv2d(C.byref(a), _stream()), 'gpv_conv2d')
+
+
+def conv_wgrad_group(problems):
+    """gpv_conv_wgrad_group: problems = [(x, dy, dw, rowscale, B, IH, IW, Cs, Cin, OH, OW, Cout, KH, KW, SH, SW, PH, PW), ...],
+    bf16 x / dy, fp32 dw (accumulated into)"""
+    if not problems:
+        return
+    arr = (ConvWgradProblem * len(problems))()
+    for i, q in enumerate(problems):
+        x, dy, dw, scale = q[:4]
+        if x.dtype != torch.bfloat16 or dy.dtype != torch.bfloat16 or dw.dtype != torch.float32:
+            raise TypeError('conv_wgrad_group: bf16 operands, fp32 gradients')
+        a = arr[i]
+        a.x, a.dy, a.dw, a.rowscale = _p(x), _p(dy), _p(dw), _p(_f32(scale))
+        (a.B, a.IH, a.IW, a.Cs, a.Cin, a.OH, a.OW, a.Cout, a.KH, a.KW, a.SH, a.SW, a.PH, a.PW) = q[4:]
+    ws = _workspace(problems[0][0].device, WS_MAX)
+    _chk(lib().gpv_conv_wgrad_group(arr, C.c_int(len(problems)), _p(ws), C.c_int64(ws.numel()), _stream()), 'gpv_conv_wgrad_group')
 
 
 def _attn_args(q, k, v, o, strides, B, H, Sq, Sk, dh, scale, kpm, causal, drop_p, seed, lse):

@@ -136,6 +136,20 @@ typedef struct {
 } gpv_conv_args;
 int gpv_conv2d(const gpv_conv_args* a, void* stream);
 
+/* All conv weight gradients of a backward pass in one call (the 42 trainable convolutions of ResNet-50 layer2-4,
+ * exp/gpv/models/backbone.py:61-63: what autograd's 42 cudnn_convolution_backward_weight calls compute):
+ *   dw[co,r,s,ci] += rowscale[co] * sum_{b,oh,ow} dy[b,oh,ow,co] x[b,oh*SH+r-PH,ow*SW+s-PW,ci]      for every problem
+ * bf16 operands (x: B x IH x IW pixels of pixel stride Cs; dy: B x OH x OW x Cout), fp32 gradients [Cout][KH][KW][Cin] that are
+ * ACCUMULATED into.  The problems run as one or two grids of equal work units (problem, reduction slice, 128 x 128 tile);
+ * workspace: scratch for the partial products of the sliced problems (256 MB covers the training shapes), busy until the call's
+ * work has run on `stream`.  A problem the grouped kernel does not take (Cout or Cin not a multiple of 128, ...) is issued as
+ * its own gpv_conv2d mode-2 launch.  Results equal gpv_conv2d's up to fp32 summation order. */
+typedef struct gpv_conv_wgrad_problem {
+  const void* x; const void* dy; float* dw; const float* rowscale;
+  int B, IH, IW, Cs, Cin, OH, OW, Cout, KH, KW, SH, SW, PH, PW;
+} gpv_conv_wgrad_problem;
+int gpv_conv_wgrad_group(const gpv_conv_wgrad_problem* problems, int n, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* NCHW fp32 image -> zero-padded NHWC4 (bf16 or f32) with `pad` pixels on every side and the
  * row length rounded up to Wp pixels (nested_tensor images, detr_misc.py:282-299 -> backbone). */
 int gpv_image_to_nhwc4(const float* img, void* out, int B, int H, int W, int pad, int Hp, int Wp,

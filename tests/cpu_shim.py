@@ -208,6 +208,11 @@ def conv1x1_dual(a1, w1, a2, w2, bias, y, B, OH, OW, K1, IH2, IW2, K2, s2, N, ac
     return False                       # (bf16 kernel only: the CPU emulation runs the two convolutions)
 
 
+def conv_wgrad_group(problems):
+    for x, dy, dw, scale, B, IH, IW, Cs, Cin, OH, OW, Cout, KH, KW, SH, SW, PH, PW in problems:
+        conv2d(2, x, dy, dw, B, IH, IW, Cs, Cin, OH, OW, Cout, KH, KW, SH, SW, PH, PW, rowscale=scale)
+
+
 def stem_pool(x, w, shift, y, B, Hp, Wp, CH, CW, PH, PW):
     # x [B,Hp,Wp,4] padded NHWC4, w [64][7][32] = [co][r][8 px][4 ch]
     wk = w.float().view(64, 7, 8, 4).permute(0, 3, 1, 2)                       # [co][ch][r][8]
@@ -321,7 +326,7 @@ def install(only=None):
     `only`: optional list of entry-point names (GPU bisecting: swap single kernels for torch math)."""
     import gpv1_amd.hip as h
     names = only or ['gemm', 'conv2d', 'attention_fwd', 'attention_bwd', 'layernorm_fwd', 'layernorm_bwd', 'softmax_ce',
-             'image_to_nhwc4', 'maxpool3x3s2', 'stem_pool', 'conv1x1_dual', 'roi_weights', 'add', 'add_rowbcast', 'colsum', 'cast', 'cast_rowscale_t',
+             'image_to_nhwc4', 'maxpool3x3s2', 'stem_pool', 'conv1x1_dual', 'conv_wgrad_group', 'roi_weights', 'add', 'add_rowbcast', 'colsum', 'cast', 'cast_rowscale_t',
              'prep_conv_weight', 'embedding', 'dropout', 'relevance_condition', 'adamw', 'sumsq', 'act_fwd', 'act_bwd',
              'cast_transpose_group']
     saved = {n: getattr(h, n) for n in names}

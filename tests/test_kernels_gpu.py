@@ -250,6 +250,35 @@ def test_conv_wgrad_direct_to_lds_vs_register_staged(Cin, Cout, k, s, p, H, W, B
     assert rel(outs[1], outs[0]) < 1e-5                                # same bf16 products, fp32 sums in a different order
 
 
+def test_conv_wgrad_group_equals_single_launches():
+    """gpv_conv_wgrad_group: a mix of problems -- no split (short reduction: tiles add themselves into dw), sliced reductions through
+    the workspace, stride 2, 3x3 borders, a ragged last k-tile, a shape the grouped kernel declines (Cin = 64 -> its own launch) --
+    against one gpv_conv2d mode-2 call each, gradients accumulated into"""
+    h, dtype = hip(), torch.bfloat16
+    cases = [(512, 512, 3, 1, 1, 15, 20, 4),       # K = 1200 pixels: 19 k-tiles -> no split
+             (256, 256, 3, 1, 1, 30, 40, 32),      # K = 38400: 600 k-tiles -> 4 slices
+             (128, 128, 3, 2, 1, 60, 80, 8),       # stride 2
+             (512, 128, 1, 1, 0, 15, 20, 5),       # 1x1, K = 1500: ragged last k-tile
+             (256, 1024, 1, 1, 0, 30, 40, 16),     # 1x1, 8 x 2 tiles, sliced
+             (64, 128, 3, 1, 1, 30, 40, 4),        # Cin = 64: declined by the grouped kernel
+             (128, 256, 3, 1, 1, 8, 24, 6)]        # short rows
+    probs, single = [], []
+    for i, (Cin, Cout, k, s, p, H, W, Bn) in enumerate(cases):
+        x = nhwc(rnd(Bn, Cin, H, W, dtype=dtype, seed=60 + i))
+        OH, OW = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+        dy = nhwc(rnd(Bn, Cout, OH, OW, dtype=dtype, seed=80 + i))
+        scale = rnd(Cout, seed=90 + i).abs() + 0.5
+        dw_g = torch.full((Cout, k, k, Cin), 0.25, device=DEV)
+        dw_s = dw_g.clone()
+        probs.append((x, dy, dw_g, scale, Bn, H, W, Cin, Cin, OH, OW, Cout, k, k, s, s, p, p))
+        h.conv2d(2, x, dy, dw_s, Bn, H, W, Cin, Cin, OH, OW, Cout, k, k, s, s, p, p, rowscale=scale)
+        single.append(dw_s)
+    h.conv_wgrad_group(probs)
+    torch.cuda.synchronize()
+    for q, ref, c in zip(probs, single, cases):
+        assert rel(q[2], ref) < 1e-5, (c, rel(q[2], ref))
+
+
 @pytest.mark.parametrize('dtype', DTYPES)
 def test_stem_conv_image_prep_and_maxpool(dtype):
     h = hip()

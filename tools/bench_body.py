@@ -36,7 +36,7 @@ names = {}
 for n, m in body.named_modules():
     if isinstance(m, bbm.ConvW):
         names[id(m)] = n
-ENTRY = ('conv2d', 'maxpool3x3s2', 'image_to_nhwc4', 'act_bwd', 'stem_pool', 'conv1x1_dual')
+ENTRY = ('conv2d', 'maxpool3x3s2', 'image_to_nhwc4', 'act_bwd', 'stem_pool', 'conv1x1_dual', 'conv_wgrad_group')
 orig = {k: getattr(hip, k) for k in ENTRY}
 phase = ['fwd']
 
@@ -73,6 +73,12 @@ def describe(k, a, kw):
         a1, w1, a2, w2, bias, y, B, OH, OW, K1, IH2, IW2, K2, s2, N = a[:15]
         by = B * OH * OW * K1 * 2 + B * IH2 * IW2 * K2 * 2 / (s2 * s2) + B * OH * OW * N * 2 + N * (K1 + K2) * 2
         return 'fwd  %d+%d->%4d conv3+downsample/%d %3dx%3d' % (K1, K2, N, s2, OH, OW), by, 2.0 * B * OH * OW * N * (K1 + K2)
+    if k == 'conv_wgrad_group':
+        by = fl = 0.0
+        for x, dy, dw, scale, B, IH, IW, Cs, Cin, OH, OW, Cout, KH, KW, SH, SW, PH, PW in a[0]:
+            by += B * IH * IW * Cs * 2 / (SH * SW if KH == 1 else 1) + B * OH * OW * Cout * 2 + Cout * KH * KW * Cin * 4 * 2
+            fl += 2.0 * B * OH * OW * Cout * KH * KW * Cin
+        return 'wgrd group of %d problems' % len(a[0]), by, fl
     if k != 'conv2d':
         return k, 0.0, 0.0
     mode, x, w, y, B, IH, IW, Cs, Cin, OH, OW, Cout, KH, KW, SH, SW, PH, PW = a[:18]

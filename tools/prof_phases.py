@@ -20,7 +20,7 @@ def short(n):
         n = m.group(2)[:int(m.group(1))] + '<' + m.group(3)[:28] + '>'
     return n[:64]
 def is_conv(n):
-    return any(t in n for t in ('c1s_kernel', 'c3r_kernel', 'stem_pool', 'conv1x1', 'glds_wgrad', 'Li2ELi', 'ILi2E', 's2_dgrad', 'maxpool', 'splitk_reduce'))
+    return any(t in n for t in ('c1s_kernel', 'c3r_kernel', 'stem_pool', 'conv1x1', 'c3d2_kernel', 'c1d_kernel', 'glds_wgrad', 'wgrad_group', 'Li2ELi', 'ILi2E', 's2_dgrad', 'maxpool', 'splitk_reduce'))
 # phases by landmarks: F1 = [image_to_nhwc4 .. last forward conv before the first LayerNorm]; optimizer = adamw
 names = [r['Kernel_Name'] for r in seq]
 first_ln = next(i for i, n in enumerate(names) if 'ln_fwd' in n and i > 60)
@@ -28,8 +28,8 @@ f1_end = max(i for i in range(first_ln) if is_conv(short(names[i])) or 'c1s' in 
 ce = [i for i, n in enumerate(names) if 'ce_kernelI' in n and 'reduce' not in n]
 ce_f, ce_b = ce[0], ce[-1]
 adam = next(i for i, n in enumerate(names) if 'adamw' in n)
-# B2 starts at the act_bwd that precedes the first conv wgrad / the backbone: find first glds_wgrad after ce_b
-b2_start = next(i for i in range(ce_b, len(names)) if 'glds_wgrad' in names[i])
+# B2 starts at the act_bwd that precedes the backbone's first backward convolution
+b2_start = next(i for i in range(ce_b, len(names)) if any(t in names[i] for t in ('glds_wgrad', 'pipe_conv1x1', 'pipe_kernelILi2E', 'glds_kernelILi2E', 'glds_conv1x1'))) - 1
 phases = [('F1 backbone fwd', 0, f1_end + 1), ('F2 forward rest', f1_end + 1, ce_f), ('criterion', ce_f, ce_b + 1), ('B1 backward body', ce_b + 1, b2_start),
           ('B2 backbone bwd', b2_start, adam), ('optimizer', adam, len(seq))]
 for pname, a, b in phases:
