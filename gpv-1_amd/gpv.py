@@ -191,6 +191,8 @@ class GPV(nn.Module):
         if not detr_mod.BOUNDARY_BELOW_ROI:
             outputs['detr_hs'] = ops.boundary(outputs['detr_hs'], 'detr')
         outputs['detr_hs'] = self.detr_joiner(outputs['detr_hs'])     # [L,B,Q,768]
+        if callable(query_encodings):                  # (a branch forked earlier: joined here, where the features are first needed)
+            query_encodings = query_encodings()
         if query_encodings is None:
             with torch.no_grad():
                 query_encodings, _ = self.bert(queries)

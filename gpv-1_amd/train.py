@@ -110,8 +110,10 @@ class GraphedBody:
         saved = trainer.touched.clone()
         assert torch.cuda.current_stream(dev) == trainer.stream            # captures run on the trainer's side stream
         # the frozen BERT (no_grad, ~110 launches of 36-144 workgroups) only needs the query ids: it is captured as a parallel
-        # branch of F1 (fork / join on a second stream) and runs under the backbone's convolutions
-        self.side = torch.cuda.Stream(device=dev) if os.environ.get('GPV_BERT_BRANCH', '1') != '0' else None
+        # branch (fork / join on a second stream) -- beside the DETR transformer's latency-bound chain in F2, where its small
+        # kernels find idle CUs (under the backbone's full-chip convolutions in F1 they cost the convolutions more)
+        self.bert_mode = int(os.environ.get('GPV_BERT_BRANCH', '2'))      # 2: branch of F2 beside the DETR transformer (F1 3.88 -> 3.71 ms, F2 3.68 -> 3.81), 1: branch of F1, 0: in line
+        self.side = torch.cuda.Stream(device=dev) if self.bert_mode else None
         self.wside = torch.cuda.Stream(device=dev)
         # the gradient chains of THIS recorded forward belong to the body: an eager step's check_chains(clear=True) must not
         # drop them from under the backward variants captured later (ops.GradChain._live is the eager steps' list)
@@ -123,10 +125,12 @@ class GraphedBody:
             self.f1.capture_begin(pool=self.pool, capture_error_mode=CAPTURE_MODE)
             self._open = self.f1
             q_enc = None
-            if self.side is not None:
+            if self.bert_mode == 1:
                 self.side.wait_stream(trainer.stream)
                 with torch.cuda.stream(self.side), torch.no_grad():
                     q_enc, _ = model.bert((self.s_ids, self.s_attn))
+            elif self.bert_mode == 2:
+                q_enc = self._bert_join                # forked when F2 opens (backbone_forward), joined where the model needs it
             self.q_enc = q_enc
             self.outs = model._forward_impl(NestedTensor(self.s_img, self.s_mask, self.all_valid), (self.s_ids, self.s_attn),
                                             self.s_tok, None, query_encodings=q_enc, lang_extra=self.s_extra)
@@ -165,13 +169,18 @@ class GraphedBody:
         backward, c5 is a constant of F2 and B2 has no backbone part"""
         self.keep = [] if train else None
         c5 = body.forward_nhwc(x, self.keep, hw)
-        if self.side is not None:
+        if self.bert_mode == 1:
             torch.cuda.current_stream(x.device).wait_stream(self.side)         # join the BERT branch before F1 ends
         self._prep_forked = False
         self.f1.capture_end()
         self._open = None
         self.f2.capture_begin(pool=self.pool, capture_error_mode=CAPTURE_MODE)
         self._open = self.f2
+        if self.bert_mode == 2:
+            cur = torch.cuda.current_stream(x.device)
+            self.side.wait_stream(cur)
+            with torch.cuda.stream(self.side), torch.no_grad():
+                self._q_enc, _ = self.tr.model.bert((self.s_ids, self.s_attn))
         # the W^T mirrors of the Linear weights (ops._lpT; needed by B1's backward-data GEMMs) are refreshed by one grouped
         # cast-transpose launch on a branch of F2: 360 MB of streaming under a chain of latency-bound kernels.  (As a branch of
         # F1 it ran beside the stem convolution and cost it 0.2 ms.)
@@ -184,6 +193,10 @@ class GraphedBody:
         self.c5_leaf = c5.detach().requires_grad_(bool(train))
         self.body = body
         return self.c5_leaf
+
+    def _bert_join(self):
+        torch.cuda.current_stream(self.s_img.device).wait_stream(self.side)
+        return self._q_enc
 
     # the backbone's per-step weight copies (42 launches of 5-9 us) as a branch of F1 beside the stem and layer1
     def prep_fork(self, body):
