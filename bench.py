@@ -316,6 +316,44 @@ def extra_configs(model, tr, dev, rank):
     return out
 
 
+def input_pipeline_bench(dev):
+    """32 COCO-sized JPEG files -> host entropy decoding (8 threads) -> GPU (IDCT, upsampling, colour, anti-aliased
+    resize to 480x640, ColorJitter / flip / grayscale, normalise) -> the stem's NHWC4 input.  Needs Pillow to WRITE the synthetic
+    files; reported beside the train step because this is what has to keep up with it."""
+    try:
+        from PIL import Image
+    except ImportError:
+        return {'skipped': 'Pillow not importable (it only writes the synthetic test files)'}
+    import io
+    import numpy as np
+    from gpv1_amd.jpeg import DeviceJpegDecoder
+    from gpv1_amd.input_pipeline import DeviceImagePipeline
+    r = np.random.RandomState(0)
+    files = []
+    for i in range(BATCH):
+        h, w = ((480, 640), (427, 640), (640, 480), (500, 375))[i % 4]
+        yy, xx = np.mgrid[0:h, 0:w]
+        img = np.stack([128 + 100 * np.sin(xx / (11.0 + i)) * np.cos(yy / 23.0), xx * 255.0 / w, yy * 255.0 / h], -1) + r.randn(h, w, 3) * 14
+        buf = io.BytesIO()
+        Image.fromarray(np.clip(img, 0, 255).astype(np.uint8)).save(buf, 'JPEG', quality=90, subsampling=2)
+        files.append(buf.getvalue())
+    dec, pipe = DeviceJpegDecoder(device=dev, threads=8), DeviceImagePipeline(size=IMG, train=True, device=dev)
+    tasks = ['CocoClassification'] * BATCH
+    for _ in range(2):
+        pipe(dec(files), tasks)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n_it = 10
+    for _ in range(n_it):
+        out = pipe(dec(files), tasks)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n_it
+    return {'ms_per_batch': dt * 1e3, 'images_per_sec': BATCH / dt, 'jpeg_mbytes_per_batch': sum(len(f) for f in files) / 1e6,
+            'host_threads': 8, 'output': list(out.tensors.shape),
+            'what': '32 JPEG files (4:2:0, q90, 480x640 / 427x640 / 640x480 / 500x375) -> host Huffman decoding -> device IDCT + upsampling + '
+                    'colour + resize + augmentation + normalise -> NHWC4 bf16 stem input; wall clock incl. the uploads'}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -505,6 +543,7 @@ def main():
         out['ragged'] = ragged_bench(model, tr, dev, rank)
     if world == 1 and not args.no_extra:
         out['extra'] = extra_configs(model, tr, dev, rank)
+        out['extra']['input_pipeline_bs32'] = input_pipeline_bench(dev)
     if world == 1 and not args.no_decode:
         out['greedy_decode'] = greedy_decode_bench(model, dev)
     if world == 1 and not args.no_cpu_baseline:

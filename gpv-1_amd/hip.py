@@ -62,6 +62,19 @@ class ConvWgradProblem(C.Structure):
                [(k, C.c_int) for k in ('B', 'IH', 'IW', 'Cs', 'Cin', 'OH', 'OW', 'Cout', 'KH', 'KW', 'SH', 'SW', 'PH', 'PW')]
 
 
+class JpegInfo(C.Structure):
+    _fields_ = [('width', C.c_int), ('height', C.c_int), ('ncomp', C.c_int), ('hmax', C.c_int), ('vmax', C.c_int),
+                ('mcus_x', C.c_int), ('mcus_y', C.c_int), ('bh', C.c_int * 3), ('bw', C.c_int * 3), ('reserved', C.c_int),
+                ('coef_offset', C.c_int64 * 3), ('coef_count', C.c_int64), ('quant', (C.c_ushort * 64) * 3)]
+
+
+class JpegDesc(C.Structure):
+    _fields_ = [('coefs', C.c_void_p), ('planes', C.c_void_p), ('out', C.c_void_p),
+                ('width', C.c_int), ('height', C.c_int), ('ncomp', C.c_int), ('hmax', C.c_int), ('vmax', C.c_int),
+                ('bh', C.c_int * 3), ('bw', C.c_int * 3), ('coef_off', C.c_int * 3), ('plane_off', C.c_int * 3),
+                ('quant', (C.c_ushort * 64) * 3)]
+
+
 class ImageDesc(C.Structure):
     _fields_ = [('src', C.c_void_p), ('H', C.c_int), ('W', C.c_int), ('flip', C.c_int), ('gray', C.c_int), ('jitter', C.c_int),
                 ('order', C.c_int * 4), ('brightness', C.c_float), ('contrast', C.c_float), ('saturation', C.c_float),
@@ -89,7 +102,7 @@ EXPORTS = ['gpv_abi_version', 'gpv_set_option', 'gpv_gemm', 'gpv_conv2d', 'gpv_i
            'gpv_cast_rowscale_t', 'gpv_prep_conv_weight', 'gpv_embedding', 'gpv_dropout',
            'gpv_relevance_condition', 'gpv_adamw', 'gpv_sumsq', 'gpv_act_fwd', 'gpv_act_bwd', 'gpv_set_seed_device',
            'gpv_gemm_tt_group', 'gpv_cast_transpose_group', 'gpv_stem_pool', 'gpv_image_pipeline', 'gpv_conv1x1_dual',
-           'gpv_conv_wgrad_group']
+           'gpv_conv_wgrad_group', 'gpv_jpeg_parse', 'gpv_jpeg_decode']
 
 
 OPT_GLDS, OPT_GLDS_LAUNCHES, OPT_SKINNY, OPT_GLDS_WGRAD, OPT_PIPE, OPT_PIPE_LAUNCHES, OPT_C1S, OPT_C3S, OPT_C3S_LAUNCHES = 0, 1, 2, 3, 4, 5, 6, 7, 8
@@ -319,6 +332,37 @@ def image_pipeline(descs_dev, B, scratch, grey_sum, out, OH, OW, pad, Hp, Wp):
     """gpv_image_pipeline: descs_dev = uint8 device tensor holding B packed ImageDesc structs"""
     _chk(lib().gpv_image_pipeline(_p(descs_dev), B, _p(scratch), _p(_f32(grey_sum)), _p(out), OH, OW, pad, Hp, Wp, dcode(out), _stream()),
          'gpv_image_pipeline')
+
+
+class JpegUnsupported(ValueError):
+    """a JPEG flavour outside the decoder's scope (progressive, arithmetic coding, 12 bit, CMYK, exotic sampling): convert the file"""
+
+
+def jpeg_parse(data, coefs=None):
+    """gpv_jpeg_parse (host side, releases the GIL): data = bytes; coefs = None (header pass) or a writable int16 buffer / numpy
+    array / CPU tensor of at least info.coef_count elements.  -> JpegInfo"""
+    info = JpegInfo()
+    fn = lib().gpv_jpeg_parse
+    fn.argtypes = [C.c_char_p, C.c_int64, C.POINTER(JpegInfo), C.c_void_p, C.c_int64]
+    if coefs is None:
+        ptr, cap = None, 0
+    elif torch.is_tensor(coefs):
+        if coefs.is_cuda or coefs.dtype != torch.int16:
+            raise TypeError('jpeg_parse: coefs must be a CPU int16 tensor (pinned for the upload)')
+        ptr, cap = coefs.data_ptr(), coefs.numel()
+    else:
+        ptr, cap = coefs.ctypes.data, coefs.size
+    err = fn(data, len(data), C.byref(info), ptr, cap)
+    if err == 801:
+        raise JpegUnsupported('gpv_jpeg_parse: not a baseline 8-bit 1- or 3-component JPEG with 4:4:4 / 4:2:2 / 4:2:0 sampling')
+    if err:
+        raise ValueError(f'gpv_jpeg_parse: malformed JPEG (hipError {err})')
+    return info
+
+
+def jpeg_decode(descs_dev, B, max_blocks, max_pixels):
+    """gpv_jpeg_decode: descs_dev = uint8 device tensor holding B packed JpegDesc structs"""
+    _chk(lib().gpv_jpeg_decode(_p(descs_dev), B, int(max_blocks), C.c_int64(int(max_pixels)), _stream()), 'gpv_jpeg_decode')
 
 
 def conv1x1_dual(a1, w1, a2, w2, bias, y, B, OH, OW, K1, IH2, IW2, K2, s2, N, act=ACT_RELU):

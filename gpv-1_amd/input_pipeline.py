@@ -23,7 +23,7 @@ import numpy as np
 import torch
 
 from . import hip
-from .misc import NestedTensor
+from .misc import NestedTensor, upload_bytes
 from .ops import RT
 
 JITTER = (0.4, 0.4, 0.4, 0.1)            # brightness, contrast, saturation, hue  (coco_datasets.py:30,141)
@@ -86,7 +86,7 @@ class DeviceImagePipeline:
             d.flip, d.gray, d.jitter = int(p['flip']), int(p['gray']), int(p['jitter'])
             d.order[:] = list(p['order'])
             d.brightness, d.contrast, d.saturation, d.hue = p['brightness'], p['contrast'], p['saturation'], p['hue']
-        raw = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).pin_memory().to(dev, non_blocking=True)
+        raw = upload_bytes(bytes(descs), dev)
         key = (B, H, W)
         sc = self._scratch.get(key)
         if sc is None:

@@ -75,6 +75,12 @@ class PinnedStager:
 
 
 STAGER = PinnedStager()
+_DESC_STAGER = PinnedStager(slots=16, nbytes=1 << 18)
+
+
+def upload_bytes(raw, device):
+    """a packed descriptor array (bytes) -> uint8 device tensor through the pinned ring (no per-call pinned allocation, no sync)"""
+    return _DESC_STAGER.to_device(torch.frombuffer(bytearray(raw), dtype=torch.uint8), torch.uint8, device)
 
 
 def collate_fn(batch):

@@ -173,6 +173,39 @@ typedef struct gpv_image_desc {
 } gpv_image_desc;
 int gpv_image_pipeline(const gpv_image_desc* descs, int B, void* scratch_u8, float* grey_sum, void* out, int OH, int OW, int pad,
                        int Hp, int Wp, int dtype_out, void* stream);
+/* Baseline JPEG decoding for the device-side input pipeline: `skio.imread(img_path)` of the reference's loader workers
+ * (datasets/coco_generic_dataset.py:54, datasets/coco_datasets.py:157, inference_util.py:10 -> Pillow -> libjpeg-turbo defaults:
+ * accurate integer IDCT, fancy chroma upsampling, YCbCr -> RGB), bit-exact against that decoder.
+ *   gpv_jpeg_parse  (HOST, thread-safe, no GPU work): header + Huffman decoding of one file into quantised coefficient blocks
+ *                   coefs[component][block row][block col][64] (int16, natural order; whole MCUs).  coefs == NULL: header pass,
+ *                   fills `info` only (coef_count = the int16 capacity the second call needs).
+ *                   Returns 0, hipErrorInvalidValue (malformed) or hipErrorNotSupported (801: progressive / arithmetic / 12-bit /
+ *                   CMYK / non-interleaved / other sampling factors than luma 1x1, 2x1, 2x2 over 1x1 chroma).
+ *   gpv_jpeg_decode (DEVICE, two launches for the whole batch): descs = DEVICE array of B descriptors; per image the coefficients
+ *                   (device), a scratch of sum_c bh[c]*8 * bw[c]*8 bytes for the component planes, and the output
+ *                   out[height][width][3] uint8 RGB (a single-component file is replicated to three channels, as
+ *                   coco_generic_dataset.py:55-56 does) -- the `src` of gpv_image_pipeline.  max_blocks / max_pixels: the largest
+ *                   block count (all components) / pixel count of a batch member (grid sizing). */
+typedef struct gpv_jpeg_info {
+  int width, height, ncomp;            /* ncomp 1 (grey) or 3 (YCbCr) */
+  int hmax, vmax;                      /* luma sampling factors (chroma is 1x1) */
+  int mcus_x, mcus_y;
+  int bh[3], bw[3];                    /* blocks per component */
+  int reserved;
+  int64_t coef_offset[3];              /* int16 element offset of the component's blocks in `coefs` */
+  int64_t coef_count;
+  unsigned short quant[3][64];         /* quantisation table per component, natural order */
+} gpv_jpeg_info;
+typedef struct gpv_jpeg_desc {
+  const short* coefs; unsigned char* planes; unsigned char* out;
+  int width, height, ncomp, hmax, vmax;
+  int bh[3], bw[3];
+  int coef_off[3];                     /* int16 element offsets into coefs */
+  int plane_off[3];                    /* byte offsets into planes */
+  unsigned short quant[3][64];
+} gpv_jpeg_desc;
+int gpv_jpeg_parse(const unsigned char* data, int64_t nbytes, gpv_jpeg_info* info, short* coefs, int64_t coefs_capacity);
+int gpv_jpeg_decode(const gpv_jpeg_desc* descs, int B, int max_blocks, int64_t max_pixels, void* stream);
 /* The tail of a stage's first bottleneck in one launch (torchvision Bottleneck.forward with a downsample branch,
  * exp/gpv/models/backbone.py:93-95): y = act(conv3(a1) + downsample(a2 at stride s2) + bias), both pointwise, FrozenBN scales folded
  * into w1 [N,K1] / w2 [N,K2], bias = the two shifts added.  bf16; (K1, K2, N) in {(64, 64, 256), (128, 256, 512)} (layer1 / layer2);
