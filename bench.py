@@ -412,10 +412,37 @@ def main():
         tg = [dict(t) for t in targets]
         return tr.train_step(samples, (ids, attn), tg)
 
-    for _ in range(args.warmup):
-        loss = step()
-    torch.cuda.synchronize()
+    if os.environ.get('GPV_BENCH_INJECT_CAPTURE_FAILURE') == '1':            # exercises the fallback below (tests / dry runs only)
+        import gpv1_amd.train as _trm
+
+        def _boom(self, *a, **k):
+            raise RuntimeError('injected capture failure (GPV_BENCH_INJECT_CAPTURE_FAILURE)')
+        _trm.GraphedBody.__init__ = _boom
+    # warm-up (captures the hipGraphs on its second step).  GPV_GRAPHS_STRICT=1: a failed capture raises instead of silently
+    # degrading a rank to eager steps.  On one GPU that ends the bench (it is a bug).  With several ranks -- RCCL + capture is the
+    # one path no single-GPU box could exercise -- the ranks agree on the failure, ALL switch the graphs off, warm up again, and the
+    # line says so (`graphs.enabled: false` + the error): a labelled eager number instead of none.
+    graphs_note = None
+    try:
+        for _ in range(args.warmup):
+            loss = step()
+        torch.cuda.synchronize()
+        ok = 1
+    except RuntimeError as err:
+        if world == 1:
+            raise
+        ok, graphs_note = 0, '%s: %s' % (type(err).__name__, (str(err).splitlines() or [''])[0])
     if world > 1:
+        flag = torch.tensor([ok], device=dev, dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag) == 0:
+            os.environ['GPV_GRAPHS_STRICT'] = '0'
+            tr.disable_graphs(graphs_note or 'another rank failed to capture')
+            graphs_note = graphs_note or 'another rank failed to capture'
+            torch.cuda.synchronize()
+            for _ in range(args.warmup):
+                loss = step()
+            torch.cuda.synchronize()
         dist.barrier()
     torch.cuda.synchronize()
     bbm.PROF = []
@@ -534,6 +561,9 @@ def main():
                       'global_batch': world * args.batch, 'image': '480x640', 'caption_tokens': 20,
                       'parallelism': f'dp{world}', 'final_loss': float(loss.detach())},
            'roofline': roof}
+    out['graphs'] = {'enabled': bool(tr.graphs), 'graph_steps': tr.graph_steps, 'eager_steps': tr.eager_steps}
+    if graphs_note:
+        out['graphs']['error'] = graphs_note
     out['roofline_attention'] = attention_roofline(dev, args.batch)
     if comm is not None:
         out['comm'] = comm

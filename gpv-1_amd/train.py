@@ -877,10 +877,15 @@ class FlatTrainer:
         can exercise under RCCL) the trainer drops to eager steps for the rest of the run instead of losing the job."""
         if self.world == 1 or os.environ.get('GPV_GRAPHS_STRICT', '0') == '1':
             raise err
+        self.disable_graphs('%s: %s' % (type(err).__name__, str(err).splitlines()[0] if str(err) else ''))
+
+    def disable_graphs(self, why):
+        """eager steps from here on (every rank must do this at the same step: the eager and the graphed step enter the same
+        collectives, so a mixed job stays correct, but its timing is the eager ranks')"""
         import sys
-        print('[gpv1_amd] rank %d: hipGraph capture failed (%s: %s) -- continuing with eager steps'
-              % (self.rank, type(err).__name__, str(err).splitlines()[0] if str(err) else ''), file=sys.stderr, flush=True)
+        print('[gpv1_amd] rank %d: hipGraph path switched off (%s) -- continuing with eager steps' % (self.rank, why), file=sys.stderr, flush=True)
         self.graphs = False
+        self.graphs_off_reason = why
         self._bodies.clear()
         RT.split = None
         RT.defer_list = None
