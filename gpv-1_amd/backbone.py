@@ -399,10 +399,23 @@ class BackboneBase(nn.Module):
             c5 = ResNetFn.apply(x, self.body, self._dummy, need_bwd, hw)
         h, w = c5.shape[1:3]
         H, Wd = m.shape[-2:]
-        iy = torch.div(torch.arange(h, device=m.device) * H, h, rounding_mode='floor')   # F.interpolate nearest
-        ix = torch.div(torch.arange(w, device=m.device) * Wd, w, rounding_mode='floor')
-        mask = m[:, iy][:, :, ix]
-        return {'0': NestedTensor(c5, mask, getattr(tensor_list, 'all_valid', None))}
+        hint = getattr(tensor_list, 'all_valid', None)
+        if hint is True:
+            # the host knows there is no padding: the down-sampled mask is a constant (8 index / arange launches less per step)
+            key = (m.shape[0], h, w, m.device)
+            mask = self._zero_masks.get(key) if hasattr(self, '_zero_masks') else None
+            if mask is None:
+                if not hasattr(self, '_zero_masks'):
+                    self._zero_masks = {}
+                if not (m.is_cuda and torch.cuda.is_current_stream_capturing()):
+                    mask = self._zero_masks[key] = torch.zeros(m.shape[0], h, w, dtype=torch.bool, device=m.device)
+        else:
+            mask = None
+        if mask is None:
+            iy = torch.div(torch.arange(h, device=m.device) * H, h, rounding_mode='floor')   # F.interpolate nearest
+            ix = torch.div(torch.arange(w, device=m.device) * Wd, w, rounding_mode='floor')
+            mask = m[:, iy][:, :, ix]
+        return {'0': NestedTensor(c5, mask, hint)}
 
 
 class Backbone(BackboneBase):

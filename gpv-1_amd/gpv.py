@@ -254,7 +254,8 @@ class GPV(nn.Module):
         ids, attn = queries
         if not x.is_cuda or torch.cuda.is_current_stream_capturing():
             return None
-        key = kind + (tuple(x.shape), tuple(ids.shape), x.dtype, RT.dtype, vocab_mask is not None, RT.weights_epoch, RT.static_epoch)
+        key = kind + (tuple(x.shape), tuple(ids.shape), x.dtype, RT.dtype, vocab_mask is not None, getattr(images, 'all_valid', None),
+                      RT.weights_epoch, RT.static_epoch)
         ent = self._igraphs.get(key)
         if ent is None:
             for k in [k for k in self._igraphs if k[-2:] != key[-2:]]:          # weights changed: those graphs hold stale copies
