@@ -227,9 +227,24 @@ class GPV(nn.Module):
         return self.answer_head(x).reshape(B, Tt, -1)
 
     # ------------------------------------------------------------------ reference API
+    def _host_tokenize(self, images, queries):
+        """list[str] queries -> (ids, mask) on the images' device, padded to the batch's own longest query exactly like the
+        reference's tokenizer call (bert.py:12-15 padding=True); staged through pinned memory (no host<->device sync).  Lets the
+        string-query inference of inference.py / compute_predictions.py replay the captured graphs instead of launching eagerly."""
+        if not (isinstance(queries, (list, tuple)) and queries and all(isinstance(q, str) for q in queries)):
+            return queries
+        tok = getattr(self.bert, 'tokenizer', None)
+        dev = images.tensors.device if hasattr(images, 'tensors') else None
+        if tok is None or dev is None or dev.type != 'cuda':
+            return queries
+        from .misc import STAGER
+        ids, attn = tok(list(queries))
+        return STAGER.to_device(ids, torch.long, dev), STAGER.to_device(attn, torch.long, dev)
+
     def forward(self, images, queries, answer_token_ids, targets=None, vocab_mask=None):
         if (answer_token_ids is None and targets is None and not self.training and torch.is_grad_enabled() is False
                 and self.cfg.get('graph_inference', True) and self.cfg.get('kv_decode', True)):
+            queries = self._host_tokenize(images, queries)
             g = self._graphed_greedy(images, queries, vocab_mask)
             if g is not None:
                 return g
@@ -260,6 +275,8 @@ class GPV(nn.Module):
         if ent is None:
             for k in [k for k in self._igraphs if k[-2:] != key[-2:]]:          # weights changed: those graphs hold stale copies
                 del self._igraphs[k]
+            while len(self._igraphs) >= int(self.cfg.get('inference_graph_slots', 8)):      # string queries: one graph per (batch, query length)
+                self._igraphs.pop(next(iter(self._igraphs)))                      # least recently used first (re-inserted on every hit below)
             sx, sm, sids, sattn = x.clone(), m.clone(), ids.clone(), attn.clone()
             svm = vocab_mask.clone().float() if vocab_mask is not None else None
             run = lambda: fn(NestedTensor(sx, sm, getattr(images, 'all_valid', None)), (sids, sattn), svm)
@@ -270,6 +287,7 @@ class GPV(nn.Module):
             with torch.cuda.graph(graph):
                 out = run()
             ent = self._igraphs[key] = (graph, (sx, sm, sids, sattn, svm), out)
+        self._igraphs[key] = self._igraphs.pop(key)                               # most recently used last
         graph, (sx, sm, sids, sattn, svm), out = ent
         sx.copy_(x); sm.copy_(m); sids.copy_(ids); sattn.copy_(attn)
         if svm is not None:
@@ -333,6 +351,7 @@ class GPV(nn.Module):
                 and self.cfg.get('kv_decode', True)):
             # the whole beam search (encoder + 19 KV-cached steps with their top-k / sort / cache reordering) has static
             # shapes: one hipGraph, like the greedy path
+            queries = self._host_tokenize(images, queries)
             outputs = self._graphed(('beam', beam_size), lambda im, q, vm: self._beam_device(im, q, beam_size), images, queries, None)
         if outputs is None:
             outputs = self._beam_device(images, queries, beam_size)

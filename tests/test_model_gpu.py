@@ -944,3 +944,32 @@ def test_size_class_padding_is_exact(rt):
     worst = max(float((grads[0][n] - grads[1][n]).abs().max()) for n in grads[0])
     assert worst <= 1e-4 * gmax, (worst, gmax)
     rt.set_precise(False)
+
+
+def test_string_query_inference_replays_graphs_and_equals_tokenised_call(rt):
+    """inference.py / compute_predictions.py hand `model(images, list_of_strings, None)` (inference.py:53-60): the strings are
+    tokenised on the host (the reference's padding: the batch's own longest query) and the call replays the captured inference
+    graph -- same outputs as the call with the token tensors, one graph per (batch, query length), a bounded number of them"""
+    from gpv1_amd.bert import WordPieceTokenizer
+    rt.set_precise(False)
+    images, mask, _, _ = batch()
+    vocab_file = os.path.join(GOLD, 'bert_vocab_synthetic.txt')
+    words = [l.strip() for l in open(vocab_file) if l.strip().isalpha() and len(l.strip()) > 2][:100]
+    model, _ = build_small()
+    model.bert.tokenizer = WordPieceTokenizer(vocab_file)
+    model.cfg['inference_graph_slots'] = 3
+    model.to(DEV).eval()
+    samples = nested(images, mask)
+    with torch.no_grad():
+        for n in (3, 5, 3, 7, 9, 5, 3):                                     # query lengths: five distinct shapes through three slots
+            qs = [' '.join(words[(7 * i + j) % len(words)] for j in range(max(1, n - i))) for i in range(B)]
+            out_s = model(samples, qs, None)
+            ids, attn = model.bert.tokenizer(qs)
+            out_t = model(samples, (ids.to(DEV), attn.to(DEV)), None)
+            assert len(model._igraphs) <= 3
+            for k in ('pred_boxes', 'pred_relevance_logits', 'answer_logits'):
+                assert torch.equal(out_s[k], out_t[k]), k
+        assert len(model._igraphs) == 3
+        beam_s = model.forward_beam_search(samples, qs, beam_size=2)
+        beam_t = model.forward_beam_search(samples, (ids.to(DEV), attn.to(DEV)), beam_size=2)
+        assert beam_s['answers'] == beam_t['answers']
