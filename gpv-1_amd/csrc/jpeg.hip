@@ -117,7 +117,7 @@ extern "C" int gpv_jpeg_parse(const unsigned char* data, int64_t nbytes, gpv_jpe
   bool qt_ok[4] = {false, false, false, false};
   int comp_id[3] = {0, 0, 0}, comp_h[3] = {1, 1, 1}, comp_v[3] = {1, 1, 1}, comp_tq[3] = {0, 0, 0}, comp_td[3], comp_ta[3];
   int W = 0, H = 0, nf = 0, ri = 0;
-  bool have_frame = false;
+  bool have_frame = false, adobe_rgb = false;
   for (;;) {
     while (p < end && *p != 0xFF) ++p;
     while (p < end && *p == 0xFF) ++p;
@@ -164,6 +164,9 @@ extern "C" int gpv_jpeg_parse(const unsigned char* data, int64_t nbytes, gpv_jpe
       have_frame = true;
     } else if (m == 0xC2 || m == 0xC3 || (m >= 0xC5 && m <= 0xC7) || (m >= 0xC9 && m <= 0xCB) || (m >= 0xCD && m <= 0xCF)) {
       return (int)hipErrorNotSupported;                 // progressive / lossless / arithmetic coding
+    } else if (m == 0xEE) {
+      // Adobe APP14: transform 0 = the components are RGB (3) / CMYK (4), not YCbCr -- libjpeg then skips the colour conversion
+      if (sl >= 12 && memcmp(seg, "Adobe", 5) == 0 && seg[11] == 0) adobe_rgb = true;
     } else if (m == 0xDD) {
       if (sl < 2) return (int)hipErrorInvalidValue;
       ri = rd16(seg);
@@ -182,6 +185,7 @@ extern "C" int gpv_jpeg_parse(const unsigned char* data, int64_t nbytes, gpv_jpe
     }
     p += ln;
   }
+  if (nf == 3 && adobe_rgb) return (int)hipErrorNotSupported;       // RGB-coded file (no YCbCr transform)
   if (nf == 3) {
     const bool luma_ok = (comp_h[0] == 1 && comp_v[0] == 1) || (comp_h[0] == 2 && comp_v[0] == 1) || (comp_h[0] == 2 && comp_v[0] == 2);
     if (!luma_ok || comp_h[1] != 1 || comp_v[1] != 1 || comp_h[2] != 1 || comp_v[2] != 1) return (int)hipErrorNotSupported;

@@ -89,7 +89,7 @@ def parse(data):
     if d[:2] != b'\xff\xd8':
         raise ValueError('not a JPEG')
     p, qt, hd, ha = 2, {}, {}, {}
-    frame, ri = None, 0
+    frame, ri, adobe_rgb = None, 0, False
     while True:
         while d[p] != 0xFF:
             p += 1
@@ -130,6 +130,9 @@ def parse(data):
             frame = dict(width=W, height=H, comps=comps)
         elif m in (0xC2, 0xC3, 0xC5, 0xC6, 0xC7, 0xC9, 0xCA, 0xCB, 0xCD, 0xCE, 0xCF):
             raise Unsupported('SOF%d (progressive / lossless / arithmetic)' % (m - 0xC0))
+        elif m == 0xEE:
+            if len(seg) >= 12 and seg[:5] == b'Adobe' and seg[11] == 0:
+                adobe_rgb = True                      # components are RGB / CMYK, no YCbCr transform
         elif m == 0xDD:
             ri = (seg[0] << 8) | seg[1]
         elif m == 0xDA:
@@ -149,6 +152,8 @@ def parse(data):
     comps = frame['comps']
     if len(comps) not in (1, 3):
         raise Unsupported('%d components' % len(comps))
+    if len(comps) == 3 and adobe_rgb:
+        raise Unsupported('Adobe RGB-coded file (no YCbCr transform)')
     hmax, vmax = max(c['h'] for c in comps), max(c['v'] for c in comps)
     if len(comps) == 3 and ((comps[0]['h'], comps[0]['v']) not in ((1, 1), (2, 1), (2, 2)) or any((c['h'], c['v']) != (1, 1) for c in comps[1:])):
         raise Unsupported('sampling factors')

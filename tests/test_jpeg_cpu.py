@@ -58,6 +58,12 @@ def test_host_decoder_rejects_what_it_does_not_decode():
     with pytest.raises(hip.JpegUnsupported):
         hip.jpeg_parse(buf.getvalue())
     good = open(FILES[0], 'rb').read()
+    # an Adobe APP14 segment with transform = 0 (RGB-coded components) spliced in front of the frame header
+    adobe = good[:2] + b'\xff\xee\x00\x0eAdobe\x00\x64\x00\x00\x00\x00\x00' + good[2:]
+    with pytest.raises(hip.JpegUnsupported):
+        hip.jpeg_parse(adobe)
+    with pytest.raises(J.Unsupported):
+        J.parse(adobe)
     with pytest.raises(ValueError):
         hip.jpeg_parse(b'not a jpeg at all')
     info = hip.jpeg_parse(good)
