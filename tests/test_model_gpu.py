@@ -973,3 +973,49 @@ def test_string_query_inference_replays_graphs_and_equals_tokenised_call(rt):
         beam_s = model.forward_beam_search(samples, qs, beam_size=2)
         beam_t = model.forward_beam_search(samples, (ids.to(DEV), attn.to(DEV)), beam_size=2)
         assert beam_s['answers'] == beam_t['answers']
+
+
+def test_graphed_training_from_jpeg_files_through_the_device_input_pipeline(rt):
+    """SURVEY 8(f)-3 end to end: .jpg files -> DeviceJpegDecoder -> DeviceImagePipeline (prepared NHWC4 stem input) ->
+    FlatTrainer.train_step on the hipGraph path; against the same steps fed with the fp32 NCHW batch the reference's loader would
+    have produced from the Pillow-decoded arrays (oracle/image_oracle.py): the two inputs differ only where a uint8 floor of the
+    resize lands on the other side of an integer, so the losses follow each other closely and the graphed path is really used"""
+    from oracle import image_oracle as IO
+    from gpv1_amd.train import FlatTrainer
+    from gpv1_amd.jpeg import DeviceJpegDecoder
+    from gpv1_amd.input_pipeline import DeviceImagePipeline
+    rt.set_precise(False)
+    gold = os.path.join(GOLD, 'jpeg')
+    exp = np.load(os.path.join(gold, 'expected.npz'))
+    names = ['c420_big', 'c444_q90', 'gray_q80', 'c422_q75'][:B] * (B // 4 + 1)
+    names = names[:B]
+    files = [open(os.path.join(gold, n + '.jpg'), 'rb').read() for n in names]
+    p0 = dict(jitter=0, order=(0, 1, 2, 3), brightness=1.0, contrast=1.0, saturation=1.0, hue=0.0, flip=0, gray=0)
+    _, _, ids, attn = batch()
+    tg = gpu_targets()
+    rgb = [e if e.ndim == 3 else np.repeat(e[..., None], 3, 2) for e in (exp[n] for n in names)]
+    ref_img = torch.from_numpy(np.stack([IO.pipeline(a, (H, W), p0) for a in rgb])).float().to(DEV)
+    mask = torch.zeros(B, H, W, dtype=torch.bool, device=DEV)
+    losses = {}
+    for how in ('files', 'arrays'):
+        model, _ = build_small()
+        model.to(DEV).train()
+        model.bert.model.p = 0.0
+        for m in model.modules():
+            if hasattr(m, 'p') and isinstance(getattr(m, 'p'), float):
+                m.p = 0.0
+        tr = FlatTrainer(model, lr=1e-4, lr_backbone=1e-5, graphs=True)
+        dec, pipe = DeviceJpegDecoder(threads=2), DeviceImagePipeline(size=(H, W), train=False)
+        ls = []
+        for _ in range(5):
+            if how == 'files':
+                samples = pipe(dec(files), params=[p0] * B)
+            else:
+                from gpv1_amd.misc import NestedTensor
+                samples = NestedTensor(ref_img, mask, True)
+            ls.append(float(tr.train_step(samples, (ids, attn), [dict(t) for t in tg])))
+        losses[how] = ls
+        assert tr.graph_steps >= 3, (how, tr.graph_steps, tr.eager_steps)
+    a, b_ = losses['files'], losses['arrays']
+    assert all(np.isfinite(a)) and a[-1] < a[0]
+    assert max(abs(x - y) / abs(y) for x, y in zip(a, b_)) < 3e-2, (a, b_)
