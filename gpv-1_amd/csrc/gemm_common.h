@@ -66,6 +66,25 @@ int c3s_try_launch(const GemmK& k, int dtype_in, int dtype_out, hipStream_t st);
 extern int g_c3s_mode;
 extern long g_c3s_launches;
 
+// tile height (160 | 96) with which (rows / h) x (N / 128) tiles fill the 512 two-per-CU slots in whole rounds (>= 90 % of the last
+// round's slots, more than 384 tiles), 0 = none
+extern int g_two_per_cu;
+inline int two_per_cu_bm(const GemmK& k, int batch) {
+  if (k.N % 128 != 0 || batch != 1) return 0;
+  int best = 0;
+  double best_u = 0.0;
+  for (int bm : {160, 96}) {
+    const int64_t t = (int64_t)((k.M + bm - 1) / bm) * (k.N / 128);
+    if (t <= 384) continue;
+    const double u = (double)t / (512.0 * ((t + 511) / 512));
+    if ((t <= 512 || u >= 0.9) && u > best_u) { best = bm; best_u = u; }     // one round: every tile is resident at once, whatever the fill
+  }
+  return best;
+}
+inline bool glds_two_per_cu(const GemmK& k, int batch) {
+  return g_two_per_cu && k.K >= 512 && !(k.cg.cm) && two_per_cu_bm(k, batch) != 0;      // (K = 256: measured, no gain)
+}
+
 // gemm_skinny.hip: 64x64 tiles with the reduction split across the block's four waves, for GEMMs whose tiles cannot
 // fill the chip (M = 192..640 rows).  Same return convention.
 int skinny_try_launch(const GemmK& k, int b_trans, int dtype_in, int dtype_out, int batch, hipStream_t st);

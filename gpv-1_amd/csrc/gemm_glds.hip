@@ -39,7 +39,7 @@ typedef const __attribute__((address_space(1))) void glb_void_t;
 
 template <int AMODE, int BM, int BN, typename TOut>
 __device__ __forceinline__ void glds_body(const GemmK& p) {
-  constexpr int NT = BM * 2, NW = NT / 64;     // 512 threads = 8 waves (BM 256) | 256 threads = 4 waves (BM 128, two blocks per CU)
+  constexpr int NT = BM == 256 ? 512 : 256, NW = NT / 64;     // 512 threads = 8 waves (BM 256) | 256 threads = 4 waves (BM 96 / 128 / 160, two blocks per CU)
   constexpr int WN = BN / 64, WM = NW / WN;
   constexpr int WTM = BM / WM;                 // 128 | 64
   constexpr int FM = WTM / 16, FN = 4;
@@ -305,7 +305,7 @@ __device__ __forceinline__ void glds_body(const GemmK& p) {
 }
 
 template <int AMODE, int BM, int BN, typename TOut>
-__global__ __launch_bounds__(BM * 2) void glds_kernel(GemmK p) {
+__global__ __launch_bounds__(BM == 256 ? 512 : 256) void glds_kernel(GemmK p) {
   if (p.dthresh) p.seed = eff_seed(p.seed, p.seed_dev);
   glds_body<AMODE, BM, BN, TOut>(p);
 }
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(BM * 2) void glds_kernel(GemmK p) {
 // 1x1 stride-1 convolutions are plain GEMMs over the NHWC rows; their own kernel name keeps them attributable to the
 // backbone in rocprofv3 traces and PMC passes (like conv1x1_kernel in gemm.hip)
 template <int BM, int BN, typename TOut>
-__global__ __launch_bounds__(BM * 2) void glds_conv1x1_kernel(GemmK p) {
+__global__ __launch_bounds__(BM == 256 ? 512 : 256) void glds_conv1x1_kernel(GemmK p) {
   if (p.dthresh) p.seed = eff_seed(p.seed, p.seed_dev);
   glds_body<OP_PLAIN, BM, BN, TOut>(p);
 }
@@ -336,7 +336,7 @@ int launch_glds(const GemmK& k, int batch, hipStream_t st) {
   }
   dim3 grid(tilesM * p.tilesN, 1, batch);
   ++g_glds_launches;
-  hipLaunchKernelGGL(fn, grid, dim3(BM * 2), lds, st, p);
+  hipLaunchKernelGGL(fn, grid, dim3(BM == 256 ? 512 : 256), lds, st, p);
   GPV_CHECK_LAUNCH();
   return 0;
 }
@@ -347,6 +347,9 @@ int launch_glds_out(const GemmK& k, int dtype_out, int batch, hipStream_t st) {
   return launch_glds<AMODE, BM, BN, float>(k, batch, st);
 }
 
+}  // namespace
+int g_two_per_cu = [] { const char* e = getenv("GPV_TWO_PER_CU"); return e ? atoi(e) : 1; }();
+namespace {
 int g_glds_mode = [] { const char* e = getenv("GPV_GLDS"); return e ? atoi(e) : 1; }();   // gpv_set_option(GPV_OPT_GLDS, .)
 
 inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
@@ -369,6 +372,14 @@ int glds_try_launch(const GemmK& k, int amode, int dtype_in, int dtype_out, int 
     if (k.lda % 8 != 0 || (int64_t)k.M * k.lda >= lim) return -1;
   } else {
     return -1;
+  }
+  // one-tile-per-CU launches (layer3 / layer4 at B = 32: 240 tiles of 160 x 256) serialise load ramp, main loop and store burst:
+  // ~16 us of fixed cost on a 33-57 us kernel (tools/bench_ktile.py).  Half-width tiles at two blocks per CU (160 x 128: 480
+  // tiles, 96 x 128 for the 9600-row maps) let one block's epilogue run under the other's main loop.
+  if (glds_two_per_cu(k, batch) && mode != 2 && mode != 3) {
+    const int bm2 = two_per_cu_bm(k, batch);
+    if (bm2 == 160) return amode == OP_CONV ? launch_glds_out<OP_CONV, 160, 128>(k, dtype_out, batch, st) : launch_glds_out<OP_PLAIN, 160, 128>(k, dtype_out, batch, st);
+    if (bm2 == 96) return amode == OP_CONV ? launch_glds_out<OP_CONV, 96, 128>(k, dtype_out, batch, st) : launch_glds_out<OP_PLAIN, 96, 128>(k, dtype_out, batch, st);
   }
   const int bn = k.N > 128 ? 256 : 128;
   bool small_tiles = mode == 3;

@@ -20,6 +20,9 @@
 // Epilogue: alpha, rowscale, bias, residual, ReLU/GELU, dropout, ReLU-mask; fp32 tile staged through LDS in two halves.
 #include "gemm_common.h"
 #include <cstdlib>
+#ifndef GPV_PIPE_SWP
+#define GPV_PIPE_SWP 1
+#endif
 
 namespace gpvk {
 namespace {
@@ -61,6 +64,7 @@ __device__ __forceinline__ void wait_vm(int n) {
 template <int AMODE, int BM, int BN, int WM, int NS, typename TOut>
 __device__ __forceinline__ void pipe_body(const GemmK& p) {
   constexpr int WN = NW / WM;
+  constexpr bool SWP = GPV_PIPE_SWP != 0 && (BM / WM / 16 + BN / (NW / WM) / 16) * 8 + (BM / WM / 16) * (BN / (NW / WM) / 16) * 4 <= 200;
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int FM = WTM / 16, FN = WTN / 16;
   static_assert(WTM % 16 == 0 && WTN % 16 == 0 && BM % 16 == 0 && BN % 64 == 0, "tile shape");
@@ -228,6 +232,30 @@ __device__ __forceinline__ void pipe_body(const GemmK& p) {
     asm volatile("" ::: "memory");
     if (t + NS - 1 < nk) issue(si);
     const unsigned char* st = smem + sc * STAGE;
+    if constexpr (SWP) {
+      // all fragment reads of the k-tile (both 32-deep halves) are requested before its first MFMA: left to itself the
+      // scheduler keeps ~6 fragments live and re-loads just in time -- ten `s_waitcnt lgkmcnt` stops per k-tile with 1..4 MFMAs
+      // (16..64 clocks) of cover each against ~150 clocks of LDS latency.  Here one exposed latency per k-tile; the second
+      // half's reads land under the first half's MFMAs.
+      bf16x8 af[2][FM], bfr[2][FN];
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const int slot = ((kk * 4 + fkg) ^ fsw) << 4;
+#pragma unroll
+        for (int j = 0; j < FN; ++j) bfr[kk][j] = *reinterpret_cast<const bf16x8*>(st + b_off + j * 16 * ROWB + slot);
+#pragma unroll
+        for (int i = 0; i < FM; ++i) af[kk][i] = *reinterpret_cast<const bf16x8*>(st + a_off + i * 16 * ROWB + slot);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int j = 0; j < FN; ++j) acc[i][j] = mfma16(bfr[kk][j], af[kk][i], acc[i][j]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       const int slot = ((kk * 4 + fkg) ^ fsw) << 4;
@@ -240,6 +268,7 @@ __device__ __forceinline__ void pipe_body(const GemmK& p) {
       for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = mfma16(bfr[j], af[i], acc[i][j]);
+    }
     }
     sc = sc == NS - 1 ? 0 : sc + 1;
     si = si == NS - 1 ? 0 : si + 1;
@@ -441,6 +470,7 @@ int pipe_try_launch(const GemmK& k, int amode, int dtype_in, int dtype_out, int 
   } else {
     return -1;
   }
+  if (mode < 100 && glds_two_per_cu(k, batch)) return -1;       // (gemm_glds.hip takes these: two half-width tiles per CU)
   int idx;
   if (mode >= 100) {
     idx = mode - 100;

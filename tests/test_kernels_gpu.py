@@ -279,6 +279,21 @@ def test_conv_wgrad_group_equals_single_launches():
         assert rel(q[2], ref) < 1e-5, (c, rel(q[2], ref))
 
 
+@pytest.mark.parametrize('Cin,Cout,k,H,W,Bn', [
+    (64, 256, 3, 50, 80, 8),        # 32000 rows x 256: 200 x 2 tiles of 160 x 128 (two per CU), K = 576
+    (64, 512, 3, 30, 40, 8),        # 9600 rows x 512: 100 x 4 tiles of 96 x 128
+    (512, 256, 1, 50, 80, 8)])      # the 1x1 form (plain GEMM over the pixel rows)
+def test_conv_two_tiles_per_cu_variants(Cin, Cout, k, H, W, Bn):
+    """gemm_glds.hip with 160 x 128 / 96 x 128 tiles (launches whose row tiles fill the chip's two-per-CU slots in one round):
+    forward and backward-data against the register-staged kernel on the same operands, and that these shapes really take it"""
+    h = hip()
+    test_conv_fwd_dgrad_wgrad(torch.bfloat16, Cin, Cout, k, 1, k // 2, H, W, Bn=Bn)         # (default dispatch, vs fp32 torch)
+    n0 = h.set_option(h.OPT_GLDS_LAUNCHES, 0)
+    test_conv_fwd_dgrad_wgrad(torch.bfloat16, Cin, Cout, k, 1, k // 2, H, W, Bn=Bn)
+    used = h.set_option(h.OPT_GLDS_LAUNCHES, n0)
+    assert used >= 1, used
+
+
 @pytest.mark.parametrize('dtype', DTYPES)
 def test_stem_conv_image_prep_and_maxpool(dtype):
     h = hip()
