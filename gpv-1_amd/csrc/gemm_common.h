@@ -82,7 +82,7 @@ inline int two_per_cu_bm(const GemmK& k, int batch) {
   return best;
 }
 inline bool glds_two_per_cu(const GemmK& k, int batch) {
-  return g_two_per_cu && k.K >= 512 && !(k.cg.cm) && two_per_cu_bm(k, batch) != 0;      // (K = 256: measured, no gain)
+  return g_two_per_cu && k.K >= 512 && (!k.cg.cm || k.cg.KH == 1) && two_per_cu_bm(k, batch) != 0;      // (K = 256: measured, no gain)
 }
 
 // gemm_skinny.hip: 64x64 tiles with the reduction split across the block's four waves, for GEMMs whose tiles cannot
