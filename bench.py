@@ -527,14 +527,17 @@ def main():
     ach_gbs = bytes_step / (conv_ms * 1e-3) / 1e9
     # HBM traffic per launch from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, MI355X_MICROARCH.md): cannot be collected
     # inside a timed run, so it is the committed measurement of this same command (tools/pmc_traffic.py ->
-    # profiles/r02_pmc_conv_traffic.json); null if that file is missing or was taken for another launch count.
+    # profiles/rNN_pmc_conv_traffic.json, per-launch = a pass's bytes / the reference's 135 convolutions); null if that file is
+    # missing or does not hold whole passes.
     traffic = None
     traffic_source = None
     try:
         import glob
         latest = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r*_pmc_conv_traffic.json')))[-1]
         pm = json.load(open(latest))
-        if pm['conv_launches_fetch_pass'] % launches == 0 and pm['conv_launches_fetch_pass'] == pm['conv_launches_write_pass'] and args.batch == BATCH:
+        passes = pm['passes_profiled']                # whole forward + backward passes of the body in the profiled run (stem launches)
+        if passes >= 1 and passes == int(passes) and pm['conv_launches_fetch_pass'] % int(passes) == 0 \
+                and pm['conv_launches_fetch_pass'] == pm['conv_launches_write_pass'] and args.batch == BATCH:
             traffic = pm['traffic_bytes_per_launch']
             traffic_source = 'profiles/%s (committed PMC measurement of this command, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE: not collected by this run)' % os.path.basename(latest)
     except (OSError, KeyError, ValueError, IndexError):
