@@ -319,6 +319,7 @@ __global__ __launch_bounds__(256) void jpeg_idct_kernel(const gpv_jpeg_desc* __r
 __device__ __forceinline__ int chroma_at(const unsigned char* pl, int pitch, int cw, int ch, int hs, int vs, int y, int x) {
   if (hs == 1) return pl[(int64_t)y * pitch + x];
   const int c = x >> 1;
+  if (cw <= 2) return pl[(int64_t)(vs == 2 ? y >> 1 : y) * pitch + c];     // jdsample.c: fancy upsampling needs downsampled_width > 2; replication below
   if (vs == 1) {                                       // h2v1 fancy: 3/4 nearer + 1/4 further column
     const unsigned char* r = pl + (int64_t)y * pitch;
     const int a = r[c];

@@ -306,6 +306,8 @@ def decode(data):
     for p in pl[1:]:
         if (hs, vs) == (1, 1):
             u = p
+        elif cw <= 2:                                         # jdsample.c: the triangle filter needs downsampled_width > 2,
+            u = np.repeat(np.repeat(p[:ch, :cw], vs, 0), hs, 1)   # narrower components are replicated (h2v1_upsample / h2v2_upsample)
         elif (hs, vs) == (2, 1):
             u = _h2v1_fancy(p, cw)
         else:

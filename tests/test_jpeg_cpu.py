@@ -87,3 +87,19 @@ def test_random_images_round_trip_through_both_decoders():
         Image.fromarray(img).save(buf, 'JPEG', quality=q, subsampling=sub)
         exp = np.asarray(Image.open(io.BytesIO(buf.getvalue())))
         assert np.array_equal(J.decode(buf.getvalue()), exp), (h, w, sub, q)
+
+
+def test_narrow_images_use_replication_not_the_triangle_filter():
+    """jdsample.c picks the fancy up-sampler only for components wider than two samples: images up to four pixels wide (and any
+    such height / sampling mix) are replicated -- found by the random-file test on the device decoder"""
+    from PIL import Image
+    r = np.random.RandomState(5)
+    for i in range(120):
+        h, w = int(r.randint(1, 40)), int(r.randint(1, 8))
+        if i % 2:
+            h, w = w, h
+        img = (r.rand(h, w, 3) * 255).astype(np.uint8)
+        buf = io.BytesIO()
+        Image.fromarray(img).save(buf, 'JPEG', quality=int(r.randint(20, 100)), subsampling=int(r.randint(0, 3)))
+        exp = np.asarray(Image.open(io.BytesIO(buf.getvalue())))
+        assert np.array_equal(J.decode(buf.getvalue()), exp), (h, w)

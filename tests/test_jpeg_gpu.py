@@ -63,3 +63,34 @@ def test_jpeg_files_to_stem_input_equals_pipeline_on_decoded_arrays():
     a = pipe(DeviceJpegDecoder()(files), params=params).tensors.float().cpu()
     b = pipe([as_rgb(exp[n]) for n in names], params=params).tensors.float().cpu()
     assert torch.equal(a, b)
+
+
+def test_device_decoder_random_files_property():
+    """40 freshly encoded files of random size (1..200 pixels a side), sampling mode, quality, Huffman optimisation and restart
+    interval, colour and grey, decoded as two batches: every one bit-exact against Pillow"""
+    from PIL import Image
+    from gpv1_amd.jpeg import DeviceJpegDecoder
+    r = np.random.RandomState(11)
+    files, exp = [], []
+    for i in range(40):
+        h, w = int(r.randint(1, 201)), int(r.randint(1, 201))
+        grey = i % 7 == 3
+        base = r.rand(h, w, 1 if grey else 3) * 255
+        if i % 3 == 0:                                                   # smooth content: long zero runs, EOB-heavy blocks
+            yy, xx = np.mgrid[0:h, 0:w]
+            base = np.stack([(xx * 3 + yy * 2 + 40 * c) % 256 for c in range(base.shape[2])], -1).astype(np.float64)
+        img = np.clip(base, 0, 255).astype(np.uint8)
+        kw = dict(quality=int(r.randint(5, 100)), optimize=bool(i % 2))
+        if not grey:
+            kw['subsampling'] = int(r.randint(0, 3))
+        if i % 4 == 1:
+            kw['restart_marker_blocks'] = int(r.randint(1, 9))
+        buf = io.BytesIO()
+        Image.fromarray(img[..., 0] if grey else img, 'L' if grey else 'RGB').save(buf, 'JPEG', **kw)
+        files.append(buf.getvalue())
+        exp.append(as_rgb(np.asarray(Image.open(io.BytesIO(buf.getvalue())))))
+    dec = DeviceJpegDecoder(threads=4)
+    outs = dec(files[:25]) + dec(files[25:])
+    torch.cuda.synchronize()
+    for i, (o, e) in enumerate(zip(outs, exp)):
+        assert tuple(o.shape) == e.shape and np.array_equal(o.cpu().numpy(), e), (i, e.shape)
