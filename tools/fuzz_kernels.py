@@ -1,0 +1,74 @@
+"""Random-shape sweep of the round-3 kernels against the references the unit tests use (fp32 torch / the oracles): calls the tests'
+own check functions with shapes no parametrisation lists.  A failure prints the shape and keeps going.
+usage: python tools/fuzz_kernels.py [seed] [rounds]        (GPU box)"""
+import os, sys, random, traceback
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import tests.test_kernels_gpu as T
+
+seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 12
+rng = random.Random(seed)
+h = T.hip()
+fails = []
+
+
+def run(name, fn, *a, **kw):
+    try:
+        fn(*a, **kw)
+    except Exception as e:                                   # noqa: BLE001
+        fails.append((name, a, kw, repr(e)[:200]))
+        print('FAIL', name, a, kw, repr(e)[:300], flush=True)
+        torch.cuda.synchronize()
+
+
+for it in range(rounds):
+    # streaming 3x3 (forced on): strips of 30 columns, row segments of 3, both channel counts, stride-2 backward-data
+    prev = h.set_option(h.OPT_C3S, 2)
+    h.set_option(h.OPT_C3S_LAUNCHES, 0)
+    Cin, Cout = rng.choice([(64, 64), (128, 128), (64, 128), (128, 64)])
+    s = rng.choice([1, 1, 2])
+    H, W = rng.randint(3, 40), rng.randint(3, 95)
+    if s == 2:
+        H, W = 2 * rng.randint(2, 18), 2 * rng.randint(2, 40)
+    run('c3s', T.test_streaming_3x3_conv_kernel_forced.__wrapped__ if hasattr(T.test_streaming_3x3_conv_kernel_forced, '__wrapped__') else T.test_streaming_3x3_conv_kernel_forced,
+        h, Cin, Cout, s, H, W, rng.randint(1, 4))
+    h.set_option(h.OPT_C3S, prev)
+    # fused stem
+    run('stem', T.test_fused_stem_conv_bn_relu_maxpool, rng.randint(1, 3), rng.randint(20, 140), rng.randint(20, 200))
+    # fused block tails
+    K1, K2, N, s2 = rng.choice([(64, 64, 256, 1), (128, 256, 512, 2)])
+    run('c1d', T.test_fused_block_tail_conv3_plus_downsample, K1, K2, N, s2, rng.randint(2, 33), rng.randint(2, 41), rng.randint(1, 4))
+    # generic conv fwd / dgrad / wgrad on random shapes incl. the two-per-CU and pipelined kernels' territory
+    Cin = rng.choice([64, 128, 256, 512])
+    Cout = rng.choice([64, 128, 256, 512])
+    k = rng.choice([1, 3])
+    s = rng.choice([1, 2])
+    run('conv', T.test_conv_fwd_dgrad_wgrad, torch.bfloat16, Cin, Cout, k, s, k // 2, rng.randint(6, 48), rng.randint(6, 64), Bn=rng.randint(1, 6))
+# grouped weight gradients: random problem lists
+import math
+for it in range(max(rounds // 3, 2)):
+    def one():
+        probs, single = [], []
+        for i in range(rng.randint(2, 9)):
+            Cin, Cout = rng.choice([64, 128, 256, 512]), rng.choice([128, 256, 512])
+            k = rng.choice([1, 3]); s = rng.choice([1, 2]); p = k // 2
+            H, W, Bn = rng.randint(6, 40), rng.randint(6, 40), rng.randint(1, 9)
+            OH, OW = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+            x = T.nhwc(T.rnd(Bn, Cin, H, W, dtype=torch.bfloat16, seed=100 + i))
+            dy = T.nhwc(T.rnd(Bn, Cout, OH, OW, dtype=torch.bfloat16, seed=200 + i))
+            scale = T.rnd(Cout, seed=300 + i).abs() + 0.5
+            g = torch.full((Cout, k, k, Cin), 0.25, device=T.DEV)
+            g2 = g.clone()
+            probs.append((x, dy, g, scale, Bn, H, W, Cin, Cin, OH, OW, Cout, k, k, s, s, p, p))
+            h.conv2d(2, x, dy, g2, Bn, H, W, Cin, Cin, OH, OW, Cout, k, k, s, s, p, p, rowscale=scale)
+            single.append(g2)
+        h.conv_wgrad_group(probs)
+        torch.cuda.synchronize()
+        for q, ref in zip(probs, single):
+            r = T.rel(q[2], ref)
+            assert r < 1e-5, (q[4:], r)
+    run('wgrad_group', one)
+print('fuzz done: %d failures' % len(fails))
+for f in fails:
+    print(f)
