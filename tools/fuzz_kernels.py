@@ -45,6 +45,40 @@ for it in range(rounds):
     k = rng.choice([1, 3])
     s = rng.choice([1, 2])
     run('conv', T.test_conv_fwd_dgrad_wgrad, torch.bfloat16, Cin, Cout, k, s, k // 2, rng.randint(6, 48), rng.randint(6, 64), Bn=rng.randint(1, 6))
+# GEMM with the full epilogue under the DEFAULT dispatch (every kernel family gets its share of shapes, incl. the two-tiles-per-CU
+# territory: 385..512 tiles of 160 x 128 / 96 x 128), and the dropout epilogue against the register-staged kernel
+import torch.nn.functional as F
+
+
+def gemm_case():
+    M = rng.choice([rng.randint(1, 700), rng.randint(700, 12000), rng.randint(20000, 70000)])
+    N = rng.choice([8 * rng.randint(1, 40), 64 * rng.randint(1, 16), 128 * rng.randint(1, 8)])
+    K = rng.choice([8 * rng.randint(1, 40), 64 * rng.randint(1, 40)])
+    if M * N > 40e6:
+        N = 128 * rng.randint(1, 4)
+    dtype = torch.bfloat16
+    A, B = T.rnd(M, K, dtype=dtype, seed=1), T.rnd(N, K, dtype=dtype, seed=2)
+    bias, rs = T.rnd(N, seed=5), T.rnd(M, seed=6)
+    res, mask = T.rnd(M, N, dtype=dtype, seed=7), T.rnd(M, N, dtype=dtype, seed=8)
+    ref0 = A.float() @ B.float().t()
+    Cm = torch.empty(M, N, device=T.DEV, dtype=dtype)
+    h.gemm(A, B, Cm, M, N, K, K, K, N)
+    assert T.rel(Cm, ref0) < T.TOL[dtype], ('plain', M, N, K, T.rel(Cm, ref0))
+    act, fn = rng.choice([(h.ACT_NONE, lambda x: x), (h.ACT_RELU, F.relu), (h.ACT_GELU, lambda x: F.gelu(x))])
+    h.gemm(A, B, Cm, M, N, K, K, K, N, alpha=0.5, rowscale=rs, bias=bias, res=res, ldr=N, relu_mask=mask, ldm=N, act=act)
+    r2 = fn(0.5 * ref0 * rs[:, None] + bias + res.float()) * (mask.float() > 0)
+    assert T.rel(Cm, r2) < T.TOL[dtype], ('epilogue', M, N, K, act, T.rel(Cm, r2))
+    c1, c2 = torch.empty(M, N, device=T.DEV, dtype=dtype), torch.empty(M, N, device=T.DEV, dtype=dtype)
+    h.gemm(A, B, c1, M, N, K, K, K, N, drop_p=0.25, seed=77)
+    m1, m2, m3 = h.set_option(h.OPT_PIPE, 0), h.set_option(h.OPT_GLDS, 0), h.set_option(h.OPT_SKINNY, 0)
+    h.gemm(A, B, c2, M, N, K, K, K, N, drop_p=0.25, seed=77)
+    h.set_option(h.OPT_PIPE, m1); h.set_option(h.OPT_GLDS, m2); h.set_option(h.OPT_SKINNY, m3)
+    assert torch.equal(c1 == 0, c2 == 0) or float(((c1 == 0) != (c2 == 0)).float().mean()) < 1e-4, ('dropout pattern', M, N, K)
+    assert T.rel(c1, c2.float()) < 2e-2, ('dropout values', M, N, K)
+
+
+for it in range(rounds):
+    run('gemm', gemm_case)
 # grouped weight gradients: random problem lists
 import math
 for it in range(max(rounds // 3, 2)):
