@@ -896,9 +896,10 @@ int launch_q_f(AttnK p, hipStream_t st) {
   size_t lds = elems * 2 * (PRECISE ? 2 : 1) + (size_t)p.skp * sizeof(float);
   auto fn = attn_q_kernel<T, DHK, DHV, NT, MODE, MASKED, FULL>;
   static size_t attr = 0;
+  if (lds > 160 * 1024) return (int)hipErrorInvalidValue;      // more LDS than a CU has: this shape is outside the kernel's range
   if (lds > 64 * 1024 && lds > attr) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
+    if (e != hipSuccess) { (void)hipGetLastError(); return (int)e; }      // (leave no stale error behind for the next launch check)
     attr = lds;
   }
   // one block of 8 waves per (batch, head) when those fill the chip; fewer query tiles per block (down to one per wave) otherwise
@@ -931,9 +932,10 @@ int launch_kv(const AttnK& p, hipStream_t st) {
   size_t lds = ((size_t)2 * QC * KP + (size_t)2 * DHV * QTP) * 2 * (PRECISE ? 2 : 1) + 3 * QC * sizeof(float);
   auto fn = attn_kv_kernel<T, DHK, DHV>;
   static size_t attr = 0;
+  if (lds > 160 * 1024) return (int)hipErrorInvalidValue;      // more LDS than a CU has: this shape is outside the kernel's range
   if (lds > 64 * 1024 && lds > attr) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
+    if (e != hipSuccess) { (void)hipGetLastError(); return (int)e; }      // (leave no stale error behind for the next launch check)
     attr = lds;
   }
   dim3 grid((p.Sk + 63) / 64, p.H, p.B);
@@ -951,9 +953,10 @@ int launch_kv2_c(AttnK p, hipStream_t st) {
   if (lds > 160 * 1024) return -1;
   auto fn = attn_kv2_kernel<DHK, DHV, NQT, CAUSAL>;
   static size_t attr = 0;
+  if (lds > 160 * 1024) return (int)hipErrorInvalidValue;      // more LDS than a CU has: this shape is outside the kernel's range
   if (lds > 64 * 1024 && lds > attr) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
+    if (e != hipSuccess) { (void)hipGetLastError(); return (int)e; }      // (leave no stale error behind for the next launch check)
     attr = lds;
   }
   const int nkt = (p.Sk + 15) / 16;

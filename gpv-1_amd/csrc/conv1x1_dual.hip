@@ -124,7 +124,7 @@ int c1d_launch(const DualK& p, int ncols, hipStream_t st) {
   static size_t attr = 0;
   if (lds > 64 * 1024 && lds > attr) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
+    if (e != hipSuccess) { (void)hipGetLastError(); return (int)e; }      // (leave no stale error behind for the next launch check)
     attr = lds;
   }
   const int nsl = p.N / ncols, ntile = (p.M + 15) / 16;

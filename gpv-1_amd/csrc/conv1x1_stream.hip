@@ -159,7 +159,7 @@ int c1s_launch(const GemmK& k, hipStream_t st) {
   static size_t attr = 0;
   if (lds > 64 * 1024 && lds > attr) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
+    if (e != hipSuccess) { (void)hipGetLastError(); return (int)e; }      // (leave no stale error behind for the next launch check)
     attr = lds;
   }
   // persistent waves: two blocks of 8 waves per CU when the weights leave room for them, one otherwise

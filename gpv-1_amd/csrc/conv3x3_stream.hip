@@ -173,7 +173,7 @@ int c3r_launch_w(const GemmK& k, hipStream_t st) {
   static bool attr = false;
   if (!attr) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
+    if (e != hipSuccess) { (void)hipGetLastError(); return (int)e; }      // (leave no stale error behind for the next launch check)
     attr = true;
   }
   const ConvGeom& g = k.cg;
@@ -347,7 +347,7 @@ int c3d2_launch(const GemmK& k, hipStream_t st) {
   static bool attr = false;
   if (!attr) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
+    if (e != hipSuccess) { (void)hipGetLastError(); return (int)e; }      // (leave no stale error behind for the next launch check)
     attr = true;
   }
   const ConvGeom& g = k.cg;

@@ -813,7 +813,7 @@ int launch_cfg_v(const GemmK& k, int batch, hipStream_t st) {
   static bool attr_done[2] = {false, false};
   if (lds > 64 * 1024 && !attr_done[k.conv1x1 ? 1 : 0]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
+    if (e != hipSuccess) { (void)hipGetLastError(); return (int)e; }      // (leave no stale error behind for the next launch check)
     attr_done[k.conv1x1 ? 1 : 0] = true;
   }
   dim3 grid(tilesM * p.tilesN, split, batch);

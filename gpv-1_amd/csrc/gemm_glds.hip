@@ -331,7 +331,7 @@ int launch_glds(const GemmK& k, int batch, hipStream_t st) {
   static bool attr_done[2] = {false, false};
   if (!attr_done[c11]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
+    if (e != hipSuccess) { (void)hipGetLastError(); return (int)e; }      // (leave no stale error behind for the next launch check)
     attr_done[c11] = true;
   }
   dim3 grid(tilesM * p.tilesN, 1, batch);

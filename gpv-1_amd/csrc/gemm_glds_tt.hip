@@ -353,7 +353,7 @@ int launch_tt(F fn, const GemmK& k, bool& attr_done, hipStream_t st) {
   constexpr int lds = 2 * TSTAGE;                    // 64 KB (the fp32 epilogue image needs 33 KB)
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return (int)e;
+    if (e != hipSuccess) { (void)hipGetLastError(); return (int)e; }      // (leave no stale error behind for the next launch check)
     attr_done = true;
   }
   dim3 grid((p.M / TBM) * p.tilesN, split, 1);
@@ -408,7 +408,7 @@ extern "C" int gpv_gemm_tt_group(const gpv_tt_problem* problems, int n, void* st
   constexpr int lds = 2 * TSTAGE;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(glds_tt_group_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return (int)e;
+    if (e != hipSuccess) { (void)hipGetLastError(); return (int)e; }      // (leave no stale error behind for the next launch check)
     attr_done = true;
   }
   for (int i0 = 0; i0 < n; i0 += GPV_TT_GROUP_MAX) {
@@ -443,7 +443,7 @@ extern "C" int gpv_conv_wgrad_group(const gpv_conv_wgrad_problem* probs, int n, 
   constexpr int lds = 2 * TSTAGE;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(glds_wgrad_group_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return (int)e;
+    if (e != hipSuccess) { (void)hipGetLastError(); return (int)e; }      // (leave no stale error behind for the next launch check)
     attr_done = true;
   }
   WgGroupK g{};

@@ -223,7 +223,7 @@ int launch_skinny(const GemmK& k, hipStream_t st) {
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
+    if (e != hipSuccess) { (void)hipGetLastError(); return (int)e; }      // (leave no stale error behind for the next launch check)
     attr_done = true;
   }
   hipLaunchKernelGGL(fn, dim3(tilesM * p.tilesN), dim3(256), lds, st, p);
@@ -403,7 +403,7 @@ int skinny_tt_try_launch(const GemmK& k, int dtype_in, int dtype_out, int batch,
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(skinny_tt_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
+    if (e != hipSuccess) { (void)hipGetLastError(); return (int)e; }      // (leave no stale error behind for the next launch check)
     attr_done = true;
   }
   hipLaunchKernelGGL(skinny_tt_kernel, dim3((unsigned)tiles, split), dim3(256), lds, st, p);

@@ -178,7 +178,7 @@ extern "C" int gpv_image_pipeline(const gpv_image_desc* descs, int B, void* scra
   if (Hp < OH + 2 * pad || Wp < OW + 2 * pad) return (int)hipErrorInvalidValue;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   hipError_t e = hipMemsetAsync(grey_sum, 0, sizeof(float) * B, st);
-  if (e != hipSuccess) return (int)e;
+  if (e != hipSuccess) { (void)hipGetLastError(); return (int)e; }      // (leave no stale error behind for the next launch check)
   const int n = OH * OW;
   dim3 g1((unsigned)((n + 255) / 256 < 480 ? (n + 255) / 256 : 480), (unsigned)B);
   hipLaunchKernelGGL(resize_kernel, g1, dim3(256), 0, st, descs, reinterpret_cast<uint8_t*>(scratch_u8), grey_sum, OH, OW);

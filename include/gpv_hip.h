@@ -224,6 +224,9 @@ int gpv_stem_pool(const void* x, const void* w, const float* shift, void* y, int
  * Q/K/V/O are addressed as ptr[b*bs + t*rs + h*dh + d] so they can be slices of fused projection
  * buffers.  Sk <= 320.  dh in {32,48,64,96}.  kpm: uint8 [B,Sk] (1 = ignore key) or NULL.
  * causal: key j > query i masked.  lse: fp32 [B,H,Sq] (saved for backward).
+ * Range: Sk <= 320; a head's K and V (backward: + Q) stay in LDS -- in GPV_F32 ("precise": hi + lo bf16 pairs) that caps
+ * Sk x dh at about 300 x 32 / 190 x 64 / 120 x 96 (more than covers the model's shapes); beyond it the call returns
+ * hipErrorInvalidValue before anything is launched.  A row whose keys are ALL masked has no defined output.
  * Replaces nn.MultiheadAttention's core (transformer.py:153-155,218-226; gpv.py:38-43), the
  * two co-attention products of BertBiAttention (vilbert.py:770-810) and BERT self-attention.
  * ------------------------------------------------------------------------------------------- */

@@ -13,9 +13,19 @@ h = T.hip()
 fails = []
 
 
+out_of_range = 0
+
+
 def run(name, fn, *a, **kw):
+    global out_of_range
     try:
         fn(*a, **kw)
+    except RuntimeError as e:
+        if name == 'attention' and 'hipError 1' in str(e):   # K / V (+ Q) of a head beyond the LDS: refused before any launch (gpv_hip.h)
+            out_of_range += 1
+            return
+        fails.append((name, a, kw, repr(e)[:200]))
+        print('FAIL', name, a, kw, repr(e)[:300], flush=True)
     except Exception as e:                                   # noqa: BLE001
         fails.append((name, a, kw, repr(e)[:200]))
         print('FAIL', name, a, kw, repr(e)[:300], flush=True)
@@ -79,6 +89,22 @@ def gemm_case():
 
 for it in range(rounds):
     run('gemm', gemm_case)
+# attention (forward, dQ, dK/dV; strided fused-projection operands, key-padding masks, causal) and LayerNorm on random geometry
+for it in range(rounds):
+    dh = rng.choice([32, 48, 64, 96])
+    H = rng.choice([8, 12, 16]) if dh != 96 else 8
+    Sq, Sk = rng.randint(1, 320), rng.randint(2, 320)          # (Sk = 1: softmax is the constant 1, dQ = dK = 0 exactly: a relative error against ~0)
+    causal = rng.random() < 0.2
+    if causal:
+        Sk = Sq
+    adt = rng.choice([torch.bfloat16, torch.bfloat16, torch.float32])
+    if adt == torch.float32 and Sk * dh > 192 * 32 * 2:
+        Sk = max(1, 192 * 32 * 2 // dh)              # fp32 ("precise") keeps K / V (backward: + Q) of a head in LDS as hi + lo bf16 pairs: capacity
+        Sq = min(Sq, Sk) if causal else Sq
+        Sk = Sq if causal else Sk
+    # (causal + key padding is not a model shape: a padded key 0 leaves the first causal row without any key)
+    run('attention', T.test_attention_fwd_bwd, adt, H, dh, Sq, Sk, causal, (not causal) and rng.random() < 0.5)
+    run('layernorm', T.test_layernorm_fwd_bwd, rng.choice([torch.bfloat16, torch.float32]), rng.randint(1, 12000), 8 * rng.randint(1, 300))
 # grouped weight gradients: random problem lists
 import math
 for it in range(max(rounds // 3, 2)):
@@ -103,6 +129,6 @@ for it in range(max(rounds // 3, 2)):
             r = T.rel(q[2], ref)
             assert r < 1e-5, (q[4:], r)
     run('wgrad_group', one)
-print('fuzz done: %d failures' % len(fails))
+print('fuzz done: %d failures (%d attention shapes refused as out of range)' % (len(fails), out_of_range))
 for f in fails:
     print(f)
