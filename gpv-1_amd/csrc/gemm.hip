@@ -933,6 +933,8 @@ extern "C" int gpv_gemm(const gpv_gemm_args* a, void* stream) {
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int la = a->layoutA, lb = a->layoutB;
   if (la == GPV_KMAJOR && lb == GPV_KMAJOR) {
+    const int gv = gemv_try_launch(k, a->dtype_in, a->dtype_out, a->batch, st);                // M <= 8: matrix-vector products of the decode step
+    if (gv >= 0) return gv;
     const int pp = pipe_try_launch(k, OP_PLAIN, a->dtype_in, a->dtype_out, a->batch, st);     // pipelined direct-to-LDS kernel (big tiles, and the small-M 6-8 stage tiles)
     if (pp >= 0) return pp;
     const int sk = skinny_try_launch(k, 0, a->dtype_in, a->dtype_out, a->batch, st);             // few tiles, long reduction: what the pipelined kernel does not take (fp32 outputs, ragged N)

@@ -90,6 +90,11 @@ inline bool glds_two_per_cu(const GemmK& k, int batch) {
 int skinny_try_launch(const GemmK& k, int b_trans, int dtype_in, int dtype_out, int batch, hipStream_t st);
 extern int g_skinny_mode;
 
+// gemv.hip: M <= 8 rows (the greedy decode step at small batch): a wave per 1..4 output columns, no LDS.  Same return convention.
+int gemv_try_launch(const GemmK& k, int dtype_in, int dtype_out, int batch, hipStream_t st);
+extern int g_gemv_mode;
+extern long g_gemv_launches;
+
 // gemm.hip: second pass of a workspace split reduction, C[m,n] += sum_s ws[s][m][n]
 int launch_splitk_reduce(const float* ws, int split, int M, int N, float* C, int64_t ldc, hipStream_t st);
 // gemm_skinny.hip: weight-gradient form (both operands reduction-major), fp32 accumulate into C, optional a_rowsum

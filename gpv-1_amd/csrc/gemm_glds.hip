@@ -414,6 +414,16 @@ extern "C" int gpv_set_option(int option, int value) {
     gpvk::g_skinny_mode = value;
     return prev;
   }
+  if (option == GPV_OPT_GEMV) {
+    const int prev = gpvk::g_gemv_mode;
+    gpvk::g_gemv_mode = value;
+    return prev;
+  }
+  if (option == GPV_OPT_GEMV_LAUNCHES) {
+    const long prev = gpvk::g_gemv_launches;
+    gpvk::g_gemv_launches = value;
+    return (int)prev;
+  }
   if (option == GPV_OPT_GLDS_WGRAD) {
     const int prev = gpvk::g_wgrad_mode;
     gpvk::g_wgrad_mode = value;

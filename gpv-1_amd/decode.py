@@ -5,9 +5,12 @@ the vocabulary embedding on every call).
 Per image batch:
   * once: cross-attention keys/values of the memory for every decoder layer, the vocabulary classifiers W_c
     (answer_head.py:31-33, batch independent) and the transformed input-embedding table row of ``__cls__``;
-  * per step t: ONE new token per sequence goes through the 3 decoder layers: q/k/v projections of the new row
-    (k, v are written straight into the [B, T, D] caches by the GEMM epilogue: ldc = T*D), single-query attention
-    over the t+1 cached keys and over the memory, FFN, logits for that position, arg-max.
+  * per step t: ONE new token per sequence goes through the 3 decoder layers: the q | k | v projection of the new row as one
+    GEMM that writes row t of the layer's [B, T, 3D] cache (ldc = T*3D; the attention kernel reads q, k and v out of it by
+    stride), single-query attention over the t+1 cached keys and over the memory, FFN, the logits of that position written
+    into row t of the [B, T, V] result, and one launch that picks the next token (logit + vocabulary mask, arg-max) and
+    stores it as the next input and as ids[:, t+1].  36 launches per token; at B <= 8 every projection runs on the
+    few-row kernel (csrc/gemv.hip).
 Because the decoder is causal, the hidden state of position t only depends on tokens <= t: the per-step logits
 are exactly the rows of the reference's final full pass, so ``answer_logits`` (1,B,T,V) is assembled from them.
 
@@ -34,8 +37,7 @@ class GreedyKVDecoder:
         dt = RT.dtype
         D, T = self.D, self.T
         self.memory = torch.empty(B * Tm, D, device=dev, dtype=dt)
-        self.kc = [torch.zeros(B, T, D, device=dev, dtype=dt) for _ in range(self.L)]
-        self.vc = [torch.zeros(B, T, D, device=dev, dtype=dt) for _ in range(self.L)]
+        self.qkvc = [torch.zeros(B, T, 3 * D, device=dev, dtype=dt) for _ in range(self.L)]     # q | k | v of every decoded position
         self.kvm = [torch.empty(B * Tm, 2 * D, device=dev, dtype=dt) for _ in range(self.L)]
         self.tok = torch.zeros(B, dtype=torch.long, device=dev)
         self.logits = torch.empty(B, T, self.V, device=dev, dtype=dt)
@@ -65,15 +67,13 @@ class GreedyKVDecoder:
             x = ops.add(x, m.pos_enc[0, t:t + 1].to(RT.dtype).contiguous())
         for l, layer in enumerate(m.text_decoder.layers):
             sa = layer.self_attn
-            w, b = sa.in_proj_weight, sa.in_proj_bias
-            q = ops.linear(x, W(w, b, 0, D))
-            # k_t, v_t written in place into the caches: row b of the GEMM output lands at cache[b, t, :]
-            kt, vt = self.kc[l][:, t], self.vc[l][:, t]
-            hip.gemm(x, W(w, b, D, 2 * D).lp(), kt, B, D, D, D, D, T * D, bias=W(w, b, D, 2 * D).bias_f32())
-            hip.gemm(x, W(w, b, 2 * D, 3 * D).lp(), vt, B, D, D, D, D, T * D, bias=W(w, b, 2 * D, 3 * D).bias_f32())
+            wqkv = W(sa.in_proj_weight, sa.in_proj_bias, 0, 3 * D)
+            c = self.qkvc[l]
+            # q_t | k_t | v_t written in place: row b of the GEMM output lands at cache[b, t, :]
+            hip.gemm(x, wqkv.lp(), c[:, t], B, 3 * D, D, D, D, T * 3 * D, bias=wqkv.bias_f32())
             o = torch.empty(B, D, device=x.device, dtype=RT.dtype)
-            st = ((D, D), (T * D, D), (T * D, D), (D, D))
-            hip.attention_fwd(q, self.kc[l], self.vc[l], o, st, B, H, 1, t + 1, dh, 1.0 / dh ** 0.5)
+            st = ((T * 3 * D, 3 * D), (T * 3 * D, 3 * D), (T * 3 * D, 3 * D), (D, D))
+            hip.attention_fwd(c[:, t], c[:, :, D:], c[:, :, 2 * D:], o, st, B, H, 1, t + 1, dh, 1.0 / dh ** 0.5)
             x = layer.norm1(x, sa.out_proj(o))
             ca = layer.multihead_attn
             q = ops.linear(x, W(ca.in_proj_weight, ca.in_proj_bias, 0, D))
@@ -83,21 +83,19 @@ class GreedyKVDecoder:
             hip.attention_fwd(q, kvm, kvm[:, D:], o, st, B, H, 1, Tm, dh, 1.0 / dh ** 0.5)
             x = layer.norm2(x, ca.out_proj(o))
             x = layer.norm3(x, layer.linear2(layer.linear1(x, ops.ACT_RELU)))
-        return ops.matmul_nt(x, self.wc)                                                    # [B, V] logits of position t
+        lg = self.logits[:, t]                                                              # [B, V] logits of position t
+        hip.gemm(x, self.wc, lg, B, self.V, D, D, D, T * self.V)
+        return lg
 
     def _step(self, t):
         lg = self._step_core(t)
-        self.logits[:, t].copy_(lg)
-        nxt = torch.topk(lg.float() + self.vocab_mask, k=1, dim=-1).indices[:, 0]
-        self.tok.copy_(nxt)
-        if t + 1 < self.T:
-            self.ids[:, t + 1].copy_(nxt)
+        # next input token = arg-max of logit + vocabulary mask (gpv.py:185-188), also stored as ids[:, t+1]
+        hip.argmax_rows(lg, self.vocab_mask, self.tok, self.ids[:, t + 1] if t + 1 < self.T else None)
 
     def reorder(self, perm, upto):
         """beam search: sequence i continues the hypothesis that lived in slot perm[i]; positions < upto are valid"""
         for l in range(self.L):
-            self.kc[l][:, :upto].copy_(self.kc[l][:, :upto].index_select(0, perm))
-            self.vc[l][:, :upto].copy_(self.vc[l][:, :upto].index_select(0, perm))
+            self.qkvc[l][:, :upto].copy_(self.qkvc[l][:, :upto].index_select(0, perm))
 
     @torch.no_grad()
     def decode(self, memory, vocab_mask=None):

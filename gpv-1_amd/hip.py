@@ -102,10 +102,11 @@ EXPORTS = ['gpv_abi_version', 'gpv_set_option', 'gpv_gemm', 'gpv_conv2d', 'gpv_i
            'gpv_cast_rowscale_t', 'gpv_prep_conv_weight', 'gpv_embedding', 'gpv_dropout',
            'gpv_relevance_condition', 'gpv_adamw', 'gpv_sumsq', 'gpv_act_fwd', 'gpv_act_bwd', 'gpv_set_seed_device',
            'gpv_gemm_tt_group', 'gpv_cast_transpose_group', 'gpv_stem_pool', 'gpv_image_pipeline', 'gpv_conv1x1_dual',
-           'gpv_conv_wgrad_group', 'gpv_jpeg_parse', 'gpv_jpeg_decode']
+           'gpv_conv_wgrad_group', 'gpv_jpeg_parse', 'gpv_jpeg_decode', 'gpv_argmax_rows']
 
 
 OPT_GLDS, OPT_GLDS_LAUNCHES, OPT_SKINNY, OPT_GLDS_WGRAD, OPT_PIPE, OPT_PIPE_LAUNCHES, OPT_C1S, OPT_C3S, OPT_C3S_LAUNCHES = 0, 1, 2, 3, 4, 5, 6, 7, 8
+OPT_GEMV, OPT_GEMV_LAUNCHES = 9, 10
 
 
 def set_option(option, value):
@@ -463,6 +464,18 @@ def sumsq(x, n, out):
 
 def act_fwd(x, y, n, act):
     _chk(lib().gpv_act_fwd(_p(x), _p(y), C.c_int64(n), act, dcode(x), _stream()), 'gpv_act_fwd')
+
+
+def argmax_rows(x, addend, out0=None, out1=None):
+    """x [rows, V] (row pitch x.stride(0), unit column stride), addend fp32 [V] or None; out0 / out1: int64 tensors whose element
+    r * stride(0) receives row r's pick (views such as ids[:, t + 1] work)"""
+    rows, V = x.shape
+    assert x.stride(1) == 1 and (addend is None or (addend.dtype == torch.float32 and addend.is_contiguous()))
+    for o in (out0, out1):
+        assert o is None or (o.dtype == torch.int64 and o.dim() == 1 and o.shape[0] == rows)
+    _chk(lib().gpv_argmax_rows(_p(x), C.c_int64(x.stride(0)), _p(addend), rows, V, dcode(x),
+                               _p(out0), C.c_int64(out0.stride(0) if out0 is not None else 0),
+                               _p(out1), C.c_int64(out1.stride(0) if out1 is not None else 0), _stream()), 'gpv_argmax_rows')
 
 
 def act_bwd(dy, ref, dx, n, act, alpha=1.0):

@@ -65,6 +65,8 @@ int gpv_gemm_tt_group(const gpv_tt_problem* problems, int n, void* stream);
 #define GPV_OPT_C1S 6 /* streaming kernel for the K <= 256 1x1 convolutions (conv1x1_stream.hip): 0 never, 1 (default) >= 65536 pixel rows, 2 wherever legal */
 #define GPV_OPT_C3S 7 /* streaming kernel for the 3x3 convolutions with 64 / 128 input channels (conv3x3_stream.hip): 0 never, 1 (default) >= 65536 output pixels, 2 wherever legal */
 #define GPV_OPT_C3S_LAUNCHES 8 /* returns the number of streaming-3x3 launches so far, then sets the counter to value */
+#define GPV_OPT_GEMV 9 /* few-row kernel (gemv.hip) for M <= 8: 0 never, 1 (default) wherever legal */
+#define GPV_OPT_GEMV_LAUNCHES 10 /* returns the number of few-row launches so far, then sets the counter to value */
 #define GPV_OPT_PIPE_LAUNCHES 5 /* returns the number of pipelined-kernel launches so far, then sets the counter to value */
 int gpv_set_option(int option, int value);
 
@@ -295,6 +297,12 @@ int gpv_prep_conv_weight(const float* src, const float* scale, void* wf, void* w
                          int Cin, int dtype_dst, void* stream);
 int gpv_embedding(const void* table, const int64_t* ids, void* out, int64_t n_ids, int dim, int dtype_table,
                   int dtype_out, void* stream);
+/* Greedy token pick: for every row r the index of the largest x[r*ld + v] + addend[v] (addend: fp32 [V] or NULL; the sum is
+ * formed in fp32), written as int64 to out0[r*stride0] and / or out1[r*stride1] (either may be NULL).  Equal values: the lowest
+ * index; NaNs never win.  Replaces `answer_logits + vocab_mask` followed by torch.topk(k=1) in the sampling loop of
+ * GPV.forward (exp/gpv/models/gpv.py:185-188): the next input token and the id row of the step in one launch. */
+int gpv_argmax_rows(const void* x, int64_t ld, const float* addend, int rows, int V, int dtype,
+                    int64_t* out0, int64_t stride0, int64_t* out1, int64_t stride1, void* stream);
 /* y = act(x), act in {RELU, GELU};  dx = dy * act'(ref) * alpha with ref = OUTPUT for relu (works through a
  * fused inverted dropout: alpha = 1/(1-p)), ref = PRE-activation for gelu.  n % 8 == 0. */
 int gpv_act_fwd(const void* x, void* y, int64_t n, int act, int dtype, void* stream);

@@ -310,6 +310,14 @@ def act_fwd(x, y, n, act):
     y.copy_(_act(x.float(), act).to(y.dtype))
 
 
+def argmax_rows(x, addend, out0=None, out1=None):
+    f = x.float() if addend is None else x.float() + addend
+    idx = f.argmax(-1)                       # (first maximum)
+    for o in (out0, out1):
+        if o is not None:
+            o.copy_(idx)
+
+
 def act_bwd(dy, ref, dx, n, act, alpha=1.0):
     g, r = dy.float(), ref.float()
     if act == 1:
@@ -328,7 +336,7 @@ def install(only=None):
     names = only or ['gemm', 'conv2d', 'attention_fwd', 'attention_bwd', 'layernorm_fwd', 'layernorm_bwd', 'softmax_ce',
              'image_to_nhwc4', 'maxpool3x3s2', 'stem_pool', 'conv1x1_dual', 'conv_wgrad_group', 'roi_weights', 'add', 'add_rowbcast', 'colsum', 'cast', 'cast_rowscale_t',
              'prep_conv_weight', 'embedding', 'dropout', 'relevance_condition', 'adamw', 'sumsq', 'act_fwd', 'act_bwd',
-             'cast_transpose_group']
+             'cast_transpose_group', 'argmax_rows']
     saved = {n: getattr(h, n) for n in names}
     for n in names:
         setattr(h, n, globals()[n])

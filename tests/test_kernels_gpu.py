@@ -48,6 +48,68 @@ def test_gemm_nt_plain(dtype, M, N, K):
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('M,N,K', [(1, 768, 768), (1, 2304, 768), (1, 2048, 768), (1, 768, 2048), (1, 10000, 768), (2, 768, 3072),
+                                   (3, 100, 96), (5, 2049, 520), (8, 4099, 768), (6, 768, 768), (1, 3, 8)])
+def test_gemm_few_rows(dtype, M, N, K):
+    """M <= 8: the wave-per-column kernel of the decode step (csrc/gemv.hip), every epilogue term, strided output rows, the
+    tile kernels on the same problem as a second reference"""
+    h = hip()
+    A, B = rnd(M, K, dtype=dtype, seed=21), rnd(N, K, dtype=dtype, seed=22)
+    bias = rnd(N, seed=23)
+    h.set_option(h.OPT_GEMV_LAUNCHES, 0)
+    for act, fn in ((h.ACT_NONE, lambda x: x), (h.ACT_RELU, F.relu), (h.ACT_GELU, lambda x: F.gelu(x))):
+        ldc = N + 24
+        Cw = torch.full((M, ldc), 7.0, device=DEV, dtype=dtype)
+        res = rnd(M, ldc, dtype=dtype, seed=24)
+        h.gemm(A, B, Cw, M, N, K, K, K, ldc, alpha=0.75, bias=bias, res=res, ldr=ldc, act=act)
+        ref = fn(0.75 * (A.float() @ B.float().t()) + bias + res[:, :N].float())
+        assert rel(Cw[:, :N], ref) < TOL[dtype], act
+        assert (Cw[:, N:] == 7.0).all()
+        prev = h.set_option(h.OPT_GEMV, 0)
+        C2 = torch.empty(M, N, device=DEV, dtype=dtype)
+        try:
+            h.gemm(A, B, C2, M, N, K, K, K, N, alpha=0.75, bias=bias, res=res, ldr=ldc, act=act)
+        finally:
+            h.set_option(h.OPT_GEMV, prev)
+        assert rel(C2, ref) < TOL[dtype]
+    Cp = torch.empty(M, N, device=DEV, dtype=dtype)
+    h.gemm(A, B, Cp, M, N, K, K, K, N)
+    assert rel(Cp, A.float() @ B.float().t()) < TOL[dtype]
+    if dtype == torch.bfloat16:                       # fp32 output from bf16 inputs
+        Cf = torch.empty(M, N, device=DEV)
+        h.gemm(A, B, Cf, M, N, K, K, K, N)
+        assert rel(Cf, A.float() @ B.float().t()) < 1e-5
+    assert h.set_option(h.OPT_GEMV_LAUNCHES, 0) >= 4
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_argmax_rows(dtype):
+    """greedy token pick: arg-max of logit + mask in fp32, lowest index among equal values, strided outputs"""
+    h = hip()
+    for rows, V in ((1, 10000), (64, 10000), (5, 37), (3, 1), (2, 70001)):
+        x = rnd(rows, V + 8, dtype=dtype, seed=31)[:, :V]                # row pitch V + 8
+        add = torch.zeros(V, device=DEV)
+        add[::3] = -10000.0
+        tok = torch.full((rows,), -1, dtype=torch.long, device=DEV)
+        ids = torch.full((rows, 20), -1, dtype=torch.long, device=DEV)
+        h.argmax_rows(x, add, tok, ids[:, 7])
+        ref = (x.float() + add).argmax(-1)
+        assert torch.equal(tok, ref) and torch.equal(ids[:, 7], ref)
+        assert (ids[:, :7] == -1).all() and (ids[:, 8:] == -1).all()
+        h.argmax_rows(x, None, tok, None)
+        assert torch.equal(tok, x.float().argmax(-1))
+    # equal values: the lowest index wins (bf16 logits do tie)
+    x = torch.zeros(4, 1000, device=DEV, dtype=dtype)
+    x[0, [5, 700]] = 3.0
+    x[1, [999, 64, 65]] = 2.0
+    x[2, 300] = -1.0
+    x[3] = float('-inf')
+    tok = torch.empty(4, dtype=torch.long, device=DEV)
+    h.argmax_rows(x, None, tok, None)
+    assert tok.tolist() == [5, 64, 0, 0]
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
 def test_gemm_epilogue_and_batch(dtype):
     h = hip()
     Bt, M, N, K = 3, 200, 192, 160
