@@ -88,15 +88,29 @@ int launch_mr(const GemmK& k, hipStream_t st) {
 
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-// one workgroup per row: the index of the largest x[r, v] + addend[v]; equal values -> the lowest index; NaNs never win
+// one workgroup of 1024 threads per row: the index of the largest x[r, v] + addend[v]; equal values -> the lowest index; NaNs
+// never win.  16-byte pieces of the row when its base and pitch allow (V = 10000 bf16: 1250 pieces, 1.2 per thread).
 template <typename T>
-__global__ __launch_bounds__(256) void argmax_rows_kernel(const T* __restrict__ x, int64_t ld, const float* __restrict__ addend, int V,
-                                                          int64_t* o0, int64_t s0, int64_t* o1, int64_t s1) {
+__global__ __launch_bounds__(1024) void argmax_rows_kernel(const T* __restrict__ x, int64_t ld, const float* __restrict__ addend, int V, int vec,
+                                                           int64_t* o0, int64_t s0, int64_t* o1, int64_t s1) {
   const int r = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const T* row = x + (int64_t)r * ld;
   float best = -INFINITY;
   int bi = 0x7fffffff;
-  for (int v = threadIdx.x; v < V; v += 256) {
+  const int V8 = vec ? (V & ~7) : 0;
+  for (int v = threadIdx.x * 8; v < V8; v += 8192) {
+    float f[8], a[8];
+    Ld8<T>::ld(row + v, f);
+    if (addend) {
+      Ld8<float>::ld(addend + v, a);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] += a[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      if (f[e] > best) { best = f[e]; bi = v + e; }           // ascending v within a thread: the first of equal values stays
+  }
+  for (int v = V8 + threadIdx.x; v < V; v += 1024) {
     float f = (float)row[v];
     if (addend) f += addend[v];
     if (f > best || (f == best && v < bi)) { best = f; bi = v; }
@@ -107,17 +121,148 @@ __global__ __launch_bounds__(256) void argmax_rows_kernel(const T* __restrict__ 
     const int oi = __shfl_xor(bi, o);
     if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
   }
-  __shared__ float sb[4];
-  __shared__ int si[4];
+  __shared__ float sb[16];
+  __shared__ int si[16];
   if (lane == 0) { sb[wave] = best; si[wave] = bi; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    for (int w = 1; w < 4; ++w)
+    for (int w = 1; w < 16; ++w)
       if (sb[w] > best || (sb[w] == best && si[w] < bi)) { best = sb[w]; bi = si[w]; }
     if (bi == 0x7fffffff) bi = 0;                     // a row of NaNs / -inf only
     if (o0) o0[(int64_t)r * s0] = bi;
     if (o1) o1[(int64_t)r * s1] = bi;
   }
+}
+
+// LayerNorm -> Linear for <= 4 rows of <= 1024 columns: xn = LayerNorm(x + s) * gamma + beta, y = act(xn W^T + bias).
+// Every wave normalises the rows itself (the same lane layout, sums and rounding as ln_fwd_kernel: the fused result equals the
+// two launches bit for bit), wave 0 of workgroup 0 also stores xn -- the residual input of the next LayerNorm.
+struct LnGemvK {
+  const void* x; const void* s; const float* gamma; const float* beta; float eps; void* xn;
+  const void* W; int64_t ldw; const float* bias; void* y; int64_t ldy;
+  int rows, N, K, act;
+};
+
+template <typename T, int MR, int NW>
+__global__ __launch_bounds__(256) void ln_gemv_kernel(LnGemvK p) {
+  constexpr int NV = 2;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n0 = (blockIdx.x * 4 + wave) * NW;
+  if (n0 >= p.N) return;
+  const bool writer = blockIdx.x == 0 && wave == 0;
+  const int cols = p.K;
+  float xn[MR][NV][8];
+#pragma unroll
+  for (int m = 0; m < MR; ++m) {
+    if (m >= p.rows) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xn[m][i][e] = 0.f;
+      continue;
+    }
+    const T* xr = reinterpret_cast<const T*>(p.x) + (int64_t)m * cols;
+    const T* sr = p.s ? reinterpret_cast<const T*>(p.s) + (int64_t)m * cols : nullptr;
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (i * 64 + lane) * 8;
+      if (c < cols) {
+        Ld8<T>::ld(xr + c, xn[m][i]);
+        if (sr) {
+          float t[8];
+          Ld8<T>::ld(sr + c, t);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) xn[m][i][e] += t[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sum += xn[m][i][e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xn[m][i][e] = 0.f;
+      }
+    }
+    sum = wave_sum(sum);
+    const float mu = sum / cols;
+    float var = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (i * 64 + lane) * 8;
+      if (c < cols) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float d = xn[m][i][e] - mu; var += d * d; }
+      }
+    }
+    var = wave_sum(var) / cols;
+    const float rs = rsqrtf(var + p.eps);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (i * 64 + lane) * 8;
+      if (c < cols) {
+        float gm[8], bt[8], o[8];
+        if (p.gamma) { Ld8<float>::ld(p.gamma + c, gm); Ld8<float>::ld(p.beta + c, bt); }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float n = (xn[m][i][e] - mu) * rs;
+          o[e] = (float)(T)(p.gamma ? n * gm[e] + bt[e] : n);          // the value the LayerNorm kernel stores
+          xn[m][i][e] = o[e];
+        }
+        if (writer) Ld8<T>::st(reinterpret_cast<T*>(p.xn) + (int64_t)m * cols + c, o);
+      }
+    }
+  }
+  float acc[MR][NW];
+#pragma unroll
+  for (int m = 0; m < MR; ++m)
+#pragma unroll
+    for (int j = 0; j < NW; ++j) acc[m][j] = 0.f;
+  const T* Wp = reinterpret_cast<const T*>(p.W);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (i * 64 + lane) * 8;
+    if (c < cols) {
+#pragma unroll
+      for (int j = 0; j < NW; ++j) {
+        float w[8];
+        Ld8<T>::ld(Wp + (int64_t)min(n0 + j, p.N - 1) * p.ldw + c, w);
+#pragma unroll
+        for (int m = 0; m < MR; ++m)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[m][j] = fmaf(xn[m][i][e], w[e], acc[m][j]);
+      }
+    }
+  }
+  float mine = 0.f;
+#pragma unroll
+  for (int m = 0; m < MR; ++m)
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+      const float t = wave_sum(acc[m][j]);
+      if (lane == m * NW + j) mine = t;
+    }
+  const int m = lane / NW, j = lane - m * NW, n = n0 + j;
+  if (lane >= MR * NW || m >= p.rows || n >= p.N) return;
+  float v = mine;
+  if (p.bias) v += p.bias[n];
+  if (p.act == GPV_ACT_RELU) v = fmaxf(v, 0.f);
+  else if (p.act == GPV_ACT_GELU) v = gelu_erf(v);
+  reinterpret_cast<T*>(p.y)[(int64_t)m * p.ldy + n] = (T)v;
+}
+
+template <typename T, int MR>
+int launch_ln_nw(const LnGemvK& k, hipStream_t st) {
+  const int nw = k.N >= 4096 ? 4 : (k.N >= 2048 ? 2 : 1);
+  const dim3 block(256);
+  if (nw == 4) ln_gemv_kernel<T, MR, 4><<<dim3((k.N + 15) / 16), block, 0, st>>>(k);
+  else if (nw == 2) ln_gemv_kernel<T, MR, 2><<<dim3((k.N + 7) / 8), block, 0, st>>>(k);
+  else ln_gemv_kernel<T, MR, 1><<<dim3((k.N + 3) / 4), block, 0, st>>>(k);
+  return (int)hipGetLastError();
+}
+template <typename T>
+int launch_ln_mr(const LnGemvK& k, hipStream_t st) {
+  if (k.rows == 1) return launch_ln_nw<T, 1>(k, st);
+  if (k.rows == 2) return launch_ln_nw<T, 2>(k, st);
+  return launch_ln_nw<T, 4>(k, st);
 }
 
 }  // namespace
@@ -139,11 +284,27 @@ extern "C" int gpv_argmax_rows(const void* x, int64_t ld, const float* addend, i
                                int64_t* out0, int64_t stride0, int64_t* out1, int64_t stride1, void* stream) {
   if (!x || rows <= 0 || V <= 0 || (!out0 && !out1)) return (int)hipErrorInvalidValue;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int esz = dtype == GPV_F32 ? 4 : 2;
+  const int vec = (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (ld * esz) % 16 == 0 && (!addend || (reinterpret_cast<uintptr_t>(addend) & 15) == 0);
   if (dtype == GPV_BF16)
-    gpvk::argmax_rows_kernel<bf16><<<dim3(rows), dim3(256), 0, st>>>(reinterpret_cast<const bf16*>(x), ld, addend, V, out0, stride0, out1, stride1);
+    gpvk::argmax_rows_kernel<bf16><<<dim3(rows), dim3(1024), 0, st>>>(reinterpret_cast<const bf16*>(x), ld, addend, V, vec, out0, stride0, out1, stride1);
   else if (dtype == GPV_F32)
-    gpvk::argmax_rows_kernel<float><<<dim3(rows), dim3(256), 0, st>>>(reinterpret_cast<const float*>(x), ld, addend, V, out0, stride0, out1, stride1);
+    gpvk::argmax_rows_kernel<float><<<dim3(rows), dim3(1024), 0, st>>>(reinterpret_cast<const float*>(x), ld, addend, V, vec, out0, stride0, out1, stride1);
   else
     return (int)hipErrorInvalidValue;
   return (int)hipGetLastError();
+}
+
+extern "C" int gpv_ln_linear_rows(const void* x, const void* s, const float* gamma, const float* beta, float eps, void* xn,
+                                  const void* W, int64_t ldw, const float* bias, void* y, int64_t ldy,
+                                  int rows, int N, int K, int act, int dtype, void* stream) {
+  if (!x || !xn || !W || !y || rows <= 0 || rows > 4 || N <= 0 || K <= 0 || K > 1024 || K % 8 != 0 || ldw % 8 != 0) return (int)hipErrorInvalidValue;
+  if ((gamma == nullptr) != (beta == nullptr) || xn == x || xn == s) return (int)hipErrorInvalidValue;
+  for (const void* q : {x, s, (const void*)xn, W, (const void*)gamma, (const void*)beta})
+    if (reinterpret_cast<uintptr_t>(q) & 15) return (int)hipErrorInvalidValue;
+  gpvk::LnGemvK k{x, s, gamma, beta, eps, xn, W, ldw, bias, y, ldy, rows, N, K, act};
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == GPV_BF16) return gpvk::launch_ln_mr<bf16>(k, st);
+  if (dtype == GPV_F32) return gpvk::launch_ln_mr<float>(k, st);
+  return (int)hipErrorInvalidValue;
 }

@@ -9,8 +9,8 @@ Per image batch:
     GEMM that writes row t of the layer's [B, T, 3D] cache (ldc = T*3D; the attention kernel reads q, k and v out of it by
     stride), single-query attention over the t+1 cached keys and over the memory, FFN, the logits of that position written
     into row t of the [B, T, V] result, and one launch that picks the next token (logit + vocabulary mask, arg-max) and
-    stores it as the next input and as ids[:, t+1].  36 launches per token; at B <= 8 every projection runs on the
-    few-row kernel (csrc/gemv.hip).
+    stores it as the next input and as ids[:, t+1].  At B <= 8 every projection runs on the few-row kernel (csrc/gemv.hip),
+    at B <= 4 every LayerNorm is computed inside the projection that consumes it (gpv_ln_linear_rows): 27 launches per token.
 Because the decoder is causal, the hidden state of position t only depends on tokens <= t: the per-step logits
 are exactly the rows of the reference's final full pass, so ``answer_logits`` (1,B,T,V) is assembled from them.
 
@@ -59,32 +59,53 @@ class GreedyKVDecoder:
         self.wc.copy_(m.answer_head.classifiers())                                         # [V, D]
 
     # ---- one decoding step (static shapes for a fixed t) ------------------------------------
+    def _ln_lin(self, norm, x, s, w, bias, y, ldy, N, act=ops.ACT_NONE):
+        """x' = norm(x + s); y[:, :N] (row pitch ldy) = act(x' w^T + bias); returns x'.  One launch at B <= 4 (gpv_ln_linear_rows)."""
+        B, D = x.shape
+        if B <= hip.LN_LINEAR_MAX_ROWS and D <= hip.LN_LINEAR_MAX_COLS and D % 8 == 0:
+            xn = torch.empty_like(x)
+            hip.ln_linear_rows(x, s, norm.weight.detach(), norm.bias.detach(), norm.eps, xn, w, bias, y, ldy, B, N, D, act)
+            return xn
+        xn = norm(x, s)
+        hip.gemm(xn, w, y, B, N, D, D, D, ldy, bias=bias, act=act)
+        return xn
+
     def _step_core(self, t):
         m, B, D, H, T, Tm = self.m, self.B, self.D, self.H, self.T, self.Tm
         dh = D // H
+        dev = self.tok.device
         x = m.answer_input_embedings(self.tok)                                              # [B, D]
         if m.cfg.text_decoder.pos_enc is True:
             x = ops.add(x, m.pos_enc[0, t:t + 1].to(RT.dtype).contiguous())
+        s = prev = None
         for l, layer in enumerate(m.text_decoder.layers):
-            sa = layer.self_attn
+            sa, ca = layer.self_attn, layer.multihead_attn
             wqkv = W(sa.in_proj_weight, sa.in_proj_bias, 0, 3 * D)
             c = self.qkvc[l]
             # q_t | k_t | v_t written in place: row b of the GEMM output lands at cache[b, t, :]
-            hip.gemm(x, wqkv.lp(), c[:, t], B, 3 * D, D, D, D, T * 3 * D, bias=wqkv.bias_f32())
-            o = torch.empty(B, D, device=x.device, dtype=RT.dtype)
+            if prev is None:
+                hip.gemm(x, wqkv.lp(), c[:, t], B, 3 * D, D, D, D, T * 3 * D, bias=wqkv.bias_f32())
+            else:
+                x = self._ln_lin(prev.norm3, x, s, wqkv.lp(), wqkv.bias_f32(), c[:, t], T * 3 * D, 3 * D)
+            o = torch.empty(B, D, device=dev, dtype=RT.dtype)
             st = ((T * 3 * D, 3 * D), (T * 3 * D, 3 * D), (T * 3 * D, 3 * D), (D, D))
             hip.attention_fwd(c[:, t], c[:, :, D:], c[:, :, 2 * D:], o, st, B, H, 1, t + 1, dh, 1.0 / dh ** 0.5)
-            x = layer.norm1(x, sa.out_proj(o))
-            ca = layer.multihead_attn
-            q = ops.linear(x, W(ca.in_proj_weight, ca.in_proj_bias, 0, D))
-            o = torch.empty(B, D, device=x.device, dtype=RT.dtype)
+            s = sa.out_proj(o)
+            wq = W(ca.in_proj_weight, ca.in_proj_bias, 0, D)
+            q = torch.empty(B, D, device=dev, dtype=RT.dtype)
+            x = self._ln_lin(layer.norm1, x, s, wq.lp(), wq.bias_f32(), q, D, D)
+            o = torch.empty(B, D, device=dev, dtype=RT.dtype)
             kvm = self.kvm[l]
             st = ((D, D), (Tm * 2 * D, 2 * D), (Tm * 2 * D, 2 * D), (D, D))
             hip.attention_fwd(q, kvm, kvm[:, D:], o, st, B, H, 1, Tm, dh, 1.0 / dh ** 0.5)
-            x = layer.norm2(x, ca.out_proj(o))
-            x = layer.norm3(x, layer.linear2(layer.linear1(x, ops.ACT_RELU)))
+            s = ca.out_proj(o)
+            w1 = W(layer.linear1.weight, layer.linear1.bias)
+            h = torch.empty(B, w1.N, device=dev, dtype=RT.dtype)
+            x = self._ln_lin(layer.norm2, x, s, w1.lp(), w1.bias_f32(), h, w1.N, w1.N, ops.ACT_RELU)
+            s = layer.linear2(h)
+            prev = layer
         lg = self.logits[:, t]                                                              # [B, V] logits of position t
-        hip.gemm(x, self.wc, lg, B, self.V, D, D, D, T * self.V)
+        self._ln_lin(prev.norm3, x, s, self.wc, None, lg, T * self.V, self.V)
         return lg
 
     def _step(self, t):

@@ -102,7 +102,7 @@ EXPORTS = ['gpv_abi_version', 'gpv_set_option', 'gpv_gemm', 'gpv_conv2d', 'gpv_i
            'gpv_cast_rowscale_t', 'gpv_prep_conv_weight', 'gpv_embedding', 'gpv_dropout',
            'gpv_relevance_condition', 'gpv_adamw', 'gpv_sumsq', 'gpv_act_fwd', 'gpv_act_bwd', 'gpv_set_seed_device',
            'gpv_gemm_tt_group', 'gpv_cast_transpose_group', 'gpv_stem_pool', 'gpv_image_pipeline', 'gpv_conv1x1_dual',
-           'gpv_conv_wgrad_group', 'gpv_jpeg_parse', 'gpv_jpeg_decode', 'gpv_argmax_rows']
+           'gpv_conv_wgrad_group', 'gpv_jpeg_parse', 'gpv_jpeg_decode', 'gpv_argmax_rows', 'gpv_ln_linear_rows']
 
 
 OPT_GLDS, OPT_GLDS_LAUNCHES, OPT_SKINNY, OPT_GLDS_WGRAD, OPT_PIPE, OPT_PIPE_LAUNCHES, OPT_C1S, OPT_C3S, OPT_C3S_LAUNCHES = 0, 1, 2, 3, 4, 5, 6, 7, 8
@@ -476,6 +476,17 @@ def argmax_rows(x, addend, out0=None, out1=None):
     _chk(lib().gpv_argmax_rows(_p(x), C.c_int64(x.stride(0)), _p(addend), rows, V, dcode(x),
                                _p(out0), C.c_int64(out0.stride(0) if out0 is not None else 0),
                                _p(out1), C.c_int64(out1.stride(0) if out1 is not None else 0), _stream()), 'gpv_argmax_rows')
+
+
+LN_LINEAR_MAX_ROWS, LN_LINEAR_MAX_COLS = 4, 1024
+
+
+def ln_linear_rows(x, s, gamma, beta, eps, xn, Wm, bias, y, ldy, rows, N, K, act=ACT_NONE):
+    """xn = LayerNorm(x + s) * gamma + beta ; y = act(xn Wm^T + bias)  (rows <= 4, K <= 1024; Wm [N, K] rows of pitch Wm.stride(0))"""
+    if x.dtype != Wm.dtype or x.dtype != y.dtype or x.dtype != xn.dtype or (s is not None and s.dtype != x.dtype):
+        raise TypeError('ln_linear_rows: dtypes differ')
+    _chk(lib().gpv_ln_linear_rows(_p(x), _p(s), _p(_f32(gamma)), _p(_f32(beta)), C.c_float(eps), _p(xn), _p(Wm), C.c_int64(Wm.stride(0)),
+                                  _p(_f32(bias)), _p(y), C.c_int64(ldy), rows, N, K, act, dcode(x), _stream()), 'gpv_ln_linear_rows')
 
 
 def act_bwd(dy, ref, dx, n, act, alpha=1.0):

@@ -303,6 +303,16 @@ int gpv_embedding(const void* table, const int64_t* ids, void* out, int64_t n_id
  * GPV.forward (exp/gpv/models/gpv.py:185-188): the next input token and the id row of the step in one launch. */
 int gpv_argmax_rows(const void* x, int64_t ld, const float* addend, int rows, int V, int dtype,
                     int64_t* out0, int64_t stride0, int64_t* out1, int64_t stride1, void* stream);
+/* LayerNorm -> Linear on at most 4 rows (the decode step at small batch; inference only, no statistics are kept):
+ *   xn[r, :] = LayerNorm(x[r, :] + s[r, :]) * gamma + beta      (s, gamma / beta may be NULL; K <= 1024 columns, K % 8 == 0)
+ *   y[r*ldy + n] = act(sum_k xn[r, k] W[n*ldw + k] + bias[n])    n < N
+ * x, s, xn: [rows, K] contiguous, dtype; W: [N, K] rows of pitch ldw (multiple of 8), dtype; y: dtype; 16-byte aligned bases;
+ * xn must not alias x or s.  Bit-identical to gpv_layernorm_fwd followed by gpv_gemm on the same operands.
+ * Replaces norm{1,2,3}(x + sublayer) followed by the next nn.Linear of torch's TransformerDecoderLayer in the sampling loop
+ * (exp/gpv/models/gpv.py:183-184 -> decode_text). */
+int gpv_ln_linear_rows(const void* x, const void* s, const float* gamma, const float* beta, float eps, void* xn,
+                       const void* W, int64_t ldw, const float* bias, void* y, int64_t ldy,
+                       int rows, int N, int K, int act, int dtype, void* stream);
 /* y = act(x), act in {RELU, GELU};  dx = dy * act'(ref) * alpha with ref = OUTPUT for relu (works through a
  * fused inverted dropout: alpha = 1/(1-p)), ref = PRE-activation for gelu.  n % 8 == 0. */
 int gpv_act_fwd(const void* x, void* y, int64_t n, int act, int dtype, void* stream);

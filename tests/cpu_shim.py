@@ -318,6 +318,16 @@ def argmax_rows(x, addend, out0=None, out1=None):
             o.copy_(idx)
 
 
+def ln_linear_rows(x, s, gamma, beta, eps, xn, Wm, bias, y, ldy, rows, N, K, act=0):
+    z = x.float().reshape(rows, K) + (0 if s is None else s.float().reshape(rows, K))
+    n = F.layer_norm(z, (K,), None if gamma is None else gamma.float(), None if beta is None else beta.float(), eps).to(xn.dtype)
+    xn.reshape(rows, K).copy_(n)
+    o = n.float() @ Wm.float().t()
+    if bias is not None:
+        o = o + bias.float()
+    _sv(y, (rows, N), (ldy, 1)).copy_(_act(o, act).to(y.dtype))
+
+
 def act_bwd(dy, ref, dx, n, act, alpha=1.0):
     g, r = dy.float(), ref.float()
     if act == 1:
@@ -336,7 +346,7 @@ def install(only=None):
     names = only or ['gemm', 'conv2d', 'attention_fwd', 'attention_bwd', 'layernorm_fwd', 'layernorm_bwd', 'softmax_ce',
              'image_to_nhwc4', 'maxpool3x3s2', 'stem_pool', 'conv1x1_dual', 'conv_wgrad_group', 'roi_weights', 'add', 'add_rowbcast', 'colsum', 'cast', 'cast_rowscale_t',
              'prep_conv_weight', 'embedding', 'dropout', 'relevance_condition', 'adamw', 'sumsq', 'act_fwd', 'act_bwd',
-             'cast_transpose_group', 'argmax_rows']
+             'cast_transpose_group', 'argmax_rows', 'ln_linear_rows']
     saved = {n: getattr(h, n) for n in names}
     for n in names:
         setattr(h, n, globals()[n])

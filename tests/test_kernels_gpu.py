@@ -83,6 +83,32 @@ def test_gemm_few_rows(dtype, M, N, K):
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('rows,N,K', [(1, 768, 768), (1, 2304, 768), (1, 2048, 768), (1, 10000, 768), (2, 768, 256), (3, 100, 520),
+                                      (4, 4099, 1024), (4, 5, 8)])
+def test_ln_linear_rows_equals_layernorm_then_gemm(dtype, rows, N, K):
+    """gpv_ln_linear_rows: bit-identical to gpv_layernorm_fwd + gpv_gemm (same lane layout, sums and rounding), and within the
+    usual tolerance of fp32 math"""
+    h = hip()
+    x, s = rnd(rows, K, dtype=dtype, seed=41), rnd(rows, K, dtype=dtype, seed=42)
+    g, b = 1.0 + 0.1 * rnd(K, seed=43), 0.1 * rnd(K, seed=44)
+    Wm, bias = rnd(N, K, dtype=dtype, seed=45, scale=0.05), rnd(N, seed=46)
+    for act, fn in ((h.ACT_NONE, lambda t: t), (h.ACT_RELU, F.relu)):
+        for ss, bb in ((s, bias), (None, None)):
+            ldy = N + 16
+            xn, y = torch.empty_like(x), torch.full((rows, ldy), 5.0, device=DEV, dtype=dtype)
+            h.ln_linear_rows(x, ss, g, b, 1e-5, xn, Wm, bb, y, ldy, rows, N, K, act)
+            xn2, y2 = torch.empty_like(x), torch.empty(rows, N, device=DEV, dtype=dtype)
+            h.layernorm_fwd(x, ss, g, b, xn2, None, None, rows, K, 1e-5)
+            h.gemm(xn2, Wm, y2, rows, N, K, K, K, N, bias=bb, act=act)
+            assert torch.equal(xn, xn2)
+            assert torch.equal(y[:, :N], y2)
+            assert (y[:, N:] == 5.0).all()
+            z = x.float() + (ss.float() if ss is not None else 0)
+            ref = fn(F.layer_norm(z, (K,), g, b, 1e-5).to(dtype).float() @ Wm.float().t() + (bb if bb is not None else 0))
+            assert rel(y[:, :N], ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
 def test_argmax_rows(dtype):
     """greedy token pick: arg-max of logit + mask in fp32, lowest index among equal values, strided outputs"""
     h = hip()
