@@ -30,22 +30,22 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemmK p) {
   const TI* brow[NW];
 #pragma unroll
   for (int j = 0; j < NW; ++j) brow[j] = B + (int64_t)min(n0 + j, p.N - 1) * p.ldb;
+  const TI* arow[MR];
+#pragma unroll
+  for (int m = 0; m < MR; ++m) arow[m] = A + (int64_t)min(m, p.M - 1) * p.lda;      // rows beyond M repeat the last one (never stored)
 #pragma unroll 2
   for (int k = lane * 8; k < p.K; k += 512) {
-    float w[NW][8];
+    float w[NW][8], x[MR][8];
 #pragma unroll
     for (int j = 0; j < NW; ++j) Ld8<TI>::ld(brow[j] + k, w[j]);
 #pragma unroll
-    for (int m = 0; m < MR; ++m) {
-      if (m < p.M) {                                   // uniform
-        float x[8];
-        Ld8<TI>::ld(A + (int64_t)m * p.lda + k, x);
+    for (int m = 0; m < MR; ++m) Ld8<TI>::ld(arow[m] + k, x[m]);
 #pragma unroll
-        for (int j = 0; j < NW; ++j)
+    for (int m = 0; m < MR; ++m)
 #pragma unroll
-          for (int e = 0; e < 8; ++e) acc[m][j] = fmaf(x[e], w[j][e], acc[m][j]);
-      }
-    }
+      for (int j = 0; j < NW; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[m][j] = fmaf(x[m][e], w[j][e], acc[m][j]);
   }
   float mine = 0.f;                                    // lane m * NW + j keeps the sum of (row m, column n0 + j)
 #pragma unroll
@@ -151,6 +151,20 @@ __global__ __launch_bounds__(256) void ln_gemv_kernel(LnGemvK p) {
   if (n0 >= p.N) return;
   const bool writer = blockIdx.x == 0 && wave == 0;
   const int cols = p.K;
+  // the weight pieces and gamma / beta are requested first: their latency passes under the LayerNorm arithmetic
+  typedef typename std::conditional<std::is_same<T, float>::value, float __attribute__((ext_vector_type(8))), bf16x8>::type RawT;
+  const T* Wp = reinterpret_cast<const T*>(p.W);
+  RawT wraw[NV][NW];
+  float gm[NV][8], bt[NV][8];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (i * 64 + lane) * 8;
+    if (c < cols) {
+#pragma unroll
+      for (int j = 0; j < NW; ++j) wraw[i][j] = *reinterpret_cast<const RawT*>(Wp + (int64_t)min(n0 + j, p.N - 1) * p.ldw + c);
+      if (p.gamma) { Ld8<float>::ld(p.gamma + c, gm[i]); Ld8<float>::ld(p.beta + c, bt[i]); }
+    }
+  }
   float xn[MR][NV][8];
 #pragma unroll
   for (int m = 0; m < MR; ++m) {
@@ -199,12 +213,11 @@ __global__ __launch_bounds__(256) void ln_gemv_kernel(LnGemvK p) {
     for (int i = 0; i < NV; ++i) {
       const int c = (i * 64 + lane) * 8;
       if (c < cols) {
-        float gm[8], bt[8], o[8];
-        if (p.gamma) { Ld8<float>::ld(p.gamma + c, gm); Ld8<float>::ld(p.beta + c, bt); }
+        float o[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const float n = (xn[m][i][e] - mu) * rs;
-          o[e] = (float)(T)(p.gamma ? n * gm[e] + bt[e] : n);          // the value the LayerNorm kernel stores
+          o[e] = (float)(T)(p.gamma ? n * gm[i][e] + bt[i][e] : n);    // the value the LayerNorm kernel stores
           xn[m][i][e] = o[e];
         }
         if (writer) Ld8<T>::st(reinterpret_cast<T*>(p.xn) + (int64_t)m * cols + c, o);
@@ -216,19 +229,16 @@ __global__ __launch_bounds__(256) void ln_gemv_kernel(LnGemvK p) {
   for (int m = 0; m < MR; ++m)
 #pragma unroll
     for (int j = 0; j < NW; ++j) acc[m][j] = 0.f;
-  const T* Wp = reinterpret_cast<const T*>(p.W);
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c = (i * 64 + lane) * 8;
     if (c < cols) {
 #pragma unroll
       for (int j = 0; j < NW; ++j) {
-        float w[8];
-        Ld8<T>::ld(Wp + (int64_t)min(n0 + j, p.N - 1) * p.ldw + c, w);
 #pragma unroll
         for (int m = 0; m < MR; ++m)
 #pragma unroll
-          for (int e = 0; e < 8; ++e) acc[m][j] = fmaf(xn[m][i][e], w[e], acc[m][j]);
+          for (int e = 0; e < 8; ++e) acc[m][j] = fmaf(xn[m][i][e], (float)wraw[i][j][e], acc[m][j]);
       }
     }
   }
@@ -271,6 +281,7 @@ int launch_ln_mr(const LnGemvK& k, hipStream_t st) {
 int gemv_try_launch(const GemmK& k, int dtype_in, int dtype_out, int batch, hipStream_t st) {
   if (g_gemv_mode == 0 || k.M > 8 || batch != 1 || k.accumulate || k.split_k > 1) return -1;
   if (k.rowscale || k.mask || k.dthresh || k.a_rowsum) return -1;
+  if (k.M > 2 && k.N >= 4096) return -1;            // 4 columns x > 2 rows per wave: the tile kernels are faster (tools/bench_gemv.py)
   if (k.K % 8 != 0 || k.lda % 8 != 0 || k.ldb % 8 != 0 || !al16(k.A) || !al16(k.B)) return -1;
   if (dtype_in == GPV_BF16 && dtype_out == GPV_BF16) return launch_mr<bf16, bf16>(k, st);
   if (dtype_in == GPV_BF16 && dtype_out == GPV_F32) return launch_mr<bf16, float>(k, st);

@@ -79,7 +79,8 @@ def test_gemm_few_rows(dtype, M, N, K):
         Cf = torch.empty(M, N, device=DEV)
         h.gemm(A, B, Cf, M, N, K, K, K, N)
         assert rel(Cf, A.float() @ B.float().t()) < 1e-5
-    assert h.set_option(h.OPT_GEMV_LAUNCHES, 0) >= 4
+    n = h.set_option(h.OPT_GEMV_LAUNCHES, 0)
+    assert (n == 0) if (M > 2 and N >= 4096) else (n >= 4)        # (many columns x > 2 rows stay on the tile kernels)
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
