@@ -832,6 +832,70 @@ int launch_cfg(const GemmK& k, int batch, hipStream_t st) {
   return launch_cfg_v<TIn, TOut, AMODE, BMODE, BM, BN, false>(k, batch, st);
 }
 
+// Second pass of a split FORWARD convolution: y[m, n] = act(sum_s ws[s][m][n] + bias[n] + res[m, n]), four columns per thread.
+__global__ __launch_bounds__(256) void conv_split_epilogue_kernel(const float* __restrict__ ws, int nsplit, int M, int N, const float* __restrict__ bias,
+                                                                  const bf16* __restrict__ res, int act, bf16* __restrict__ y) {
+  const int nq = N >> 2;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)M * nq) return;
+  const int m = (int)(i / nq), n = (int)(i - (int64_t)m * nq) * 4;
+  const int64_t slab = (int64_t)M * N, off = (int64_t)m * N + n;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int sidx = 0; sidx < nsplit; ++sidx) {
+    const float4 v = *reinterpret_cast<const float4*>(ws + sidx * slab + off);
+    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+  }
+  float o[4] = {a.x, a.y, a.z, a.w};
+  if (bias) {
+    const float4 b = *reinterpret_cast<const float4*>(bias + n);
+    o[0] += b.x; o[1] += b.y; o[2] += b.z; o[3] += b.w;
+  }
+  if (res) {
+    const bf16x4 r = *reinterpret_cast<const bf16x4*>(res + off);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] += (float)r[e];
+  }
+  bf16x4 out;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) out[e] = (bf16)(act == GPV_ACT_RELU ? fmaxf(o[e], 0.f) : o[e]);
+  *reinterpret_cast<bf16x4*>(y + off) = out;
+}
+
+// Forward convolutions over a few hundred to a few thousand output pixels (inference at batch 1: layer2-4 see 4800 / 1200 / 300
+// pixels): 12..40 tiles of a 128-wide kernel walk K = 1152..4608 alone on a 256-CU chip.  The reduction is split over grid.y
+// into fp32 slabs of the caller's workspace (64 x 64 tiles, ~300 workgroups of >= 8 k-tiles), a second launch sums the slabs and
+// applies bias / residual / ReLU.  Returns 0 = launched, -1 = not applicable.
+inline bool a16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+int conv_split_try_launch(const GemmK& k, int dtype_in, int dtype_out, hipStream_t st) {
+  static const int on = [] { const char* e = getenv("GPV_CONV_SPLIT"); return e ? atoi(e) : 1; }();
+  if (!on || g_kernel_forced || dtype_in != GPV_BF16 || dtype_out != GPV_BF16 || !k.vecA || !k.vecB || !k.ws_base) return -1;
+  if (k.mask || k.rowscale || k.dthresh || k.accumulate || k.cg.dgrad || k.alpha != 1.0f || (k.act != 0 && k.act != GPV_ACT_RELU)) return -1;
+  if (k.N % 4 != 0 || k.ldc != k.N || (k.res && k.ldr != k.N) || !a16(k.C) || (k.res && !a16(k.res)) || (k.bias && !a16(k.bias))) return -1;
+  const int tiles = ((k.M + 63) / 64) * ((k.N + 63) / 64);
+  const int kt_total = (k.K + BK - 1) / BK;
+  if (tiles > 160 || kt_total < 32) return -1;
+  int split = (384 + tiles - 1) / tiles;
+  if (split > kt_total / 8) split = kt_total / 8;
+  if (split > 16) split = 16;
+  while (split > 1 && (int64_t)split * k.M * k.N * 4 > k.ws_bytes) --split;
+  if (split < 2) return -1;
+  GemmK p = k;
+  p.tilesN = (p.N + 63) / 64;
+  p.kt_per_split = (kt_total + split - 1) / split;
+  split = (kt_total + p.kt_per_split - 1) / p.kt_per_split;
+  p.split_k = split;
+  p.ws = reinterpret_cast<float*>(k.ws_base);
+  p.res = nullptr; p.bias = nullptr; p.act = 0;
+  constexpr size_t lds = (size_t)2 * (64 + 64) * LDK * 2;
+  hipLaunchKernelGGL((gemm_kernel<bf16, float, OP_CONV, OP_PLAIN, 64, 64, true>), dim3(tiles, split, 1), dim3(256), lds, st, p);
+  GPV_CHECK_LAUNCH();
+  const int64_t quads = (int64_t)k.M * (k.N / 4);
+  hipLaunchKernelGGL(conv_split_epilogue_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, st, p.ws, split, k.M, k.N, k.bias,
+                     reinterpret_cast<const bf16*>(k.res), k.act, reinterpret_cast<bf16*>(k.C));
+  GPV_CHECK_LAUNCH();
+  return 0;
+}
+
 template <typename TIn, typename TOut, int AMODE, int BMODE>
 int launch_tiles(const GemmK& k, int batch, hipStream_t st) {
   const int64_t sk = (k.split_k < 1 ? 1 : k.split_k);
@@ -1020,6 +1084,10 @@ extern "C" int gpv_conv2d(const gpv_conv_args* a, void* stream) {
       }
       const int pp = pipe_try_launch(k, OP_PLAIN, a->dtype_in, a->dtype_out, 1, st);
       if (pp >= 0) return pp;
+      if (k.M <= 8192 && !g_kernel_forced) {               // a few thousand pixels (inference at batch 1): 64x64 tiles, reduction split over the block's waves
+        const int sk = skinny_try_launch(k, 0, a->dtype_in, a->dtype_out, 1, st);
+        if (sk >= 0) return sk;
+      }
       const int g = glds_try_launch(k, OP_PLAIN, a->dtype_in, a->dtype_out, 1, st);
       if (g >= 0) return g;
       return launch_dtype<OP_PLAIN, OP_PLAIN>(k, 1, a->dtype_in, a->dtype_out, st);
@@ -1048,6 +1116,12 @@ extern "C" int gpv_conv2d(const gpv_conv_args* a, void* stream) {
       if (c3 >= 0) return c3;
     }
     if (k.vecA && k.vecB) {
+      if (a->mode == 0 && a->workspace) {                  // few output pixels, long reduction (inference at batch 1): split + second pass
+        GemmK ks = k;
+        ks.ws_base = a->workspace; ks.ws_bytes = a->workspace_bytes;
+        const int cs = conv_split_try_launch(ks, a->dtype_in, a->dtype_out, st);
+        if (cs >= 0) return cs;
+      }
       const int pp = pipe_try_launch(k, OP_CONV, a->dtype_in, a->dtype_out, 1, st);
       if (pp >= 0) return pp;
       const int g = glds_try_launch(k, OP_CONV, a->dtype_in, a->dtype_out, 1, st);

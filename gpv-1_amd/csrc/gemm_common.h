@@ -69,6 +69,7 @@ extern long g_c3s_launches;
 // tile height (160 | 96) with which (rows / h) x (N / 128) tiles fill the 512 two-per-CU slots in whole rounds (>= 90 % of the last
 // round's slots, more than 384 tiles), 0 = none
 extern int g_two_per_cu;
+extern int g_kernel_forced;
 inline int two_per_cu_bm(const GemmK& k, int batch) {
   if (k.N % 128 != 0 || batch != 1) return 0;
   int best = 0;

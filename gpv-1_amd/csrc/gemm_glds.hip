@@ -348,6 +348,7 @@ int launch_glds_out(const GemmK& k, int dtype_out, int batch, hipStream_t st) {
 }
 
 }  // namespace
+int g_kernel_forced = 0;      // bit 0: GPV_OPT_GLDS >= 2, bit 1: GPV_OPT_PIPE >= 100 -- a kernel family is being forced (tests / tuning): the small-problem side paths step aside
 int g_two_per_cu = [] { const char* e = getenv("GPV_TWO_PER_CU"); return e ? atoi(e) : 1; }();
 namespace {
 int g_glds_mode = [] { const char* e = getenv("GPV_GLDS"); return e ? atoi(e) : 1; }();   // gpv_set_option(GPV_OPT_GLDS, .)
@@ -407,6 +408,7 @@ extern "C" int gpv_set_option(int option, int value) {
   if (option == GPV_OPT_GLDS) {
     const int prev = gpvk::g_glds_mode;
     gpvk::g_glds_mode = value;
+    gpvk::g_kernel_forced = (gpvk::g_kernel_forced & ~1) | (value >= 2 ? 1 : 0);
     return prev;
   }
   if (option == GPV_OPT_SKINNY) {
@@ -444,7 +446,10 @@ extern "C" int gpv_set_option(int option, int value) {
     gpvk::g_c3s_launches = value;
     return (int)prev;
   }
-  if (option == GPV_OPT_PIPE) return gpvk::pipe_set_mode(value);
+  if (option == GPV_OPT_PIPE) {
+    gpvk::g_kernel_forced = (gpvk::g_kernel_forced & ~2) | (value >= 100 ? 2 : 0);
+    return gpvk::pipe_set_mode(value);
+  }
   if (option == GPV_OPT_PIPE_LAUNCHES) return (int)gpvk::pipe_launches(value);
   if (option == GPV_OPT_GLDS_LAUNCHES) {
     const long prev = gpvk::g_glds_launches;

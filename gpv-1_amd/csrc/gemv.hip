@@ -279,7 +279,7 @@ int launch_ln_mr(const LnGemvK& k, hipStream_t st) {
 
 // returns 0 = launched, -1 = not applicable, > 0 = hipError_t
 int gemv_try_launch(const GemmK& k, int dtype_in, int dtype_out, int batch, hipStream_t st) {
-  if (g_gemv_mode == 0 || k.M > 8 || batch != 1 || k.accumulate || k.split_k > 1) return -1;
+  if (g_gemv_mode == 0 || g_kernel_forced || k.M > 8 || batch != 1 || k.accumulate || k.split_k > 1) return -1;
   if (k.rowscale || k.mask || k.dthresh || k.a_rowsum) return -1;
   if (k.M > 2 && k.N >= 4096) return -1;            // 4 columns x > 2 rows per wave: the tile kernels are faster (tools/bench_gemv.py)
   if (k.K % 8 != 0 || k.lda % 8 != 0 || k.ldb % 8 != 0 || !al16(k.A) || !al16(k.B)) return -1;

@@ -251,6 +251,10 @@ def conv2d(mode, x, w, y, B, IH, IW, Cs, Cin, OH, OW, Cout, KH, KW, SH, SW, PH, 
     if mode == 2:                                      # wgrad: the library picks the split; lend it the shared scratch
         ws = _workspace(x.device, WS_MAX)
         a.workspace, a.workspace_bytes = _p(ws), ws.numel()
+    elif mode == 0 and B * OH * OW <= 8192 and KH * KW * Cin >= 1024:
+        # forward over a few thousand pixels with a long reduction (inference at batch 1): the library may split it
+        ws = _workspace(x.device, 16 * B * OH * OW * Cout * 4)
+        a.workspace, a.workspace_bytes = _p(ws), ws.numel()
     _chk(lib().gpv_conv2d(C.byref(a), _stream()), 'gpv_conv2d')
 
 

@@ -349,7 +349,7 @@ class LinearFn(Function):
         y = torch.empty(M, N, device=x.device, dtype=out_dtype)
         seed = RT.next_seed() if drop_p > 0 else 0
         z = None
-        if act == ACT_GELU:                       # keep the pre-activation for backward
+        if act == ACT_GELU and any(ctx.needs_input_grad):   # keep the pre-activation for backward (inference / frozen BERT: GELU in the epilogue)
             z = torch.empty_like(y)
             hip.gemm(x2, w.lp(), z, M, N, K, K, K, N, bias=w.bias_f32())
             hip.act_fwd(z, y, M * N, ACT_GELU)

@@ -134,7 +134,8 @@ typedef struct {
   const void* res; const void* relu_mask;  /* same shape as y */
   int act;
   int split_k;                             /* wgrad only */
-  void* workspace; int64_t workspace_bytes; /* wgrad only, optional: split reduction scratch, same contract as gpv_gemm_args */
+  void* workspace; int64_t workspace_bytes; /* optional split-reduction scratch, same contract as gpv_gemm_args: wgrad, and forward
+                                               convolutions over <= 8192 output pixels (fp32 slabs + a second pass with the epilogue) */
 } gpv_conv_args;
 int gpv_conv2d(const gpv_conv_args* a, void* stream);
 

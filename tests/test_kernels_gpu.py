@@ -102,7 +102,10 @@ def test_ln_linear_rows_equals_layernorm_then_gemm(dtype, rows, N, K):
             h.layernorm_fwd(x, ss, g, b, xn2, None, None, rows, K, 1e-5)
             h.gemm(xn2, Wm, y2, rows, N, K, K, K, N, bias=bb, act=act)
             assert torch.equal(xn, xn2)
-            assert torch.equal(y[:, :N], y2)
+            if rows > 2 and N >= 4096:                # (the unfused GEMM of this shape runs on the tile kernels: another summation order)
+                assert rel(y[:, :N], y2) < TOL[dtype]
+            else:
+                assert torch.equal(y[:, :N], y2)
             assert (y[:, N:] == 5.0).all()
             z = x.float() + (ss.float() if ss is not None else 0)
             ref = fn(F.layer_norm(z, (K,), g, b, 1e-5).to(dtype).float() @ Wm.float().t() + (bb if bb is not None else 0))
@@ -381,6 +384,19 @@ def test_conv_two_tiles_per_cu_variants(Cin, Cout, k, H, W, Bn):
     test_conv_fwd_dgrad_wgrad(torch.bfloat16, Cin, Cout, k, 1, k // 2, H, W, Bn=Bn)
     used = h.set_option(h.OPT_GLDS_LAUNCHES, n0)
     assert used >= 1, used
+
+
+@pytest.mark.parametrize('Cin,Cout,k,s,H,W', [
+    (512, 512, 3, 1, 15, 20),       # layer4 conv2 at batch 1: 300 pixels, K = 4608 -> split 8
+    (256, 256, 3, 1, 30, 40),       # layer3 conv2: 1200 pixels, K = 2304
+    (256, 256, 3, 2, 60, 80),       # layer3.0 conv2 (stride 2)
+    (128, 128, 3, 1, 60, 80),       # layer2 conv2: 4800 pixels, K = 1152
+    (1024, 256, 1, 1, 30, 40), (2048, 512, 1, 1, 15, 20), (512, 2048, 1, 1, 15, 20)])       # the 1x1s around them (64 x 64 tiles, waves split K)
+def test_conv_forward_at_batch_one(Cin, Cout, k, s, H, W):
+    """inference at batch 1: forward convolutions over a few thousand pixels (split reduction + second pass with the epilogue for
+    the 3x3s, the small-M kernel for the 1x1s) against fp32 torch (inside test_conv_fwd_dgrad_wgrad)"""
+    test_conv_fwd_dgrad_wgrad(torch.bfloat16, Cin, Cout, k, s, k // 2, H, W, Bn=1)
+    test_conv_fwd_dgrad_wgrad(torch.bfloat16, Cin, Cout, k, s, k // 2, H, W, Bn=2)
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
@@ -971,11 +987,13 @@ def test_streaming_1x1_conv_kernel_forced(Cin, Cout, H, W, Bn, with_res, with_ma
     outs = []
     for mode in (0, 2):
         prev = h.set_option(h.OPT_C1S, mode)
+        prevs = h.set_option(h.OPT_SKINNY, 0)          # (the tile kernel as the second reference: these pixel counts would go to the small-M kernel)
         try:
             y = torch.full((M + 3, Cout), 5.0, device=DEV, dtype=torch.bfloat16)         # 3 guard rows: nothing may be written past M
             h.conv2d(0, x, w, y, Bn, H, W, Cin, Cin, H, W, Cout, 1, 1, 1, 1, 0, 0, bias=bias, res=res, relu_mask=msk, act=1 if relu else 0)
         finally:
             h.set_option(h.OPT_C1S, prev)
+            h.set_option(h.OPT_SKINNY, prevs)
         assert bool((y[M:] == 5.0).all())
         outs.append(y[:M].float())
     ref = x.float() @ w.reshape(Cout, Cin).float().t() + bias
