@@ -9,10 +9,10 @@ no CPU path; the module raises if it is called with CPU tensors or without the l
 import copy
 import json
 import math
+import os
 import re
 
 import numpy as np
-import os
 import torch
 import torch.nn as nn
 
@@ -252,8 +252,29 @@ class GPV(nn.Module):
 
     # ---- whole greedy inference as ONE hipGraph ---------------------------------------------------------------
     def _graphed_greedy(self, images, queries, vocab_mask):
-        return self._graphed(('greedy',), lambda im, q, vm: self._forward_impl(im, q, None, None, vm, kv_graphs=False),
+        return self._graphed(('greedy',), lambda im, q, vm: self._forward_impl(im, q, None, None, vm, kv_graphs=False,
+                                                                             query_encodings=self._bert_fork(im, q)),
                              images, queries, vocab_mask)
+
+    def _bert_fork(self, images, queries):
+        """the frozen BERT on a side stream -- inside a capture: a parallel branch of the inference graph beside the backbone and the
+        DETR transformer (~110 launches of <= 8 token rows at batch 1); returns the join, called where the features are first
+        needed (_encode).  GPV_INFER_BERT_BRANCH=0: in line."""
+        dev = images.tensors.device
+        if dev.type != 'cuda' or os.environ.get('GPV_INFER_BERT_BRANCH', '1') == '0':
+            return None
+        side = getattr(self, '_iside', None)
+        if side is None:
+            side = self._iside = torch.cuda.Stream(device=dev)
+        cur = torch.cuda.current_stream(dev)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side), torch.no_grad():
+            enc, _ = self.bert(queries)
+
+        def join():
+            torch.cuda.current_stream(dev).wait_stream(side)
+            return enc
+        return join
 
     def _graphed(self, kind, fn, images, queries, vocab_mask):
         """Greedy inference (gpv.py:178-196) has static shapes for a fixed batch: ~1000 encoder launches + 20 decode
@@ -376,7 +397,9 @@ class GPV(nn.Module):
 
     def _beam_device(self, images, queries, beam_size):
         """device part of the beam search: outputs dict + '_beam_seqs' [K,B,T] + '_beam_lp' [B,K] (no host round trip)"""
-        outputs, memory = self._encode(images, queries)
+        graphed = isinstance(queries, (tuple, list)) and len(queries) == 2 and all(torch.is_tensor(q) for q in queries) and \
+            hasattr(images, 'tensors') and torch.cuda.is_current_stream_capturing()
+        outputs, memory = self._encode(images, queries, self._bert_fork(images, queries) if graphed else None)
         B, K, T = memory.shape[0], beam_size, self.cfg.max_text_len
         dev = memory.device
         tok = torch.full((K, B, 1), self.word_to_idx['__cls__'], dtype=torch.long, device=dev)
