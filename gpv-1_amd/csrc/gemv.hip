@@ -141,6 +141,7 @@ struct LnGemvK {
   const void* x; const void* s; const float* gamma; const float* beta; float eps; void* xn;
   const void* W; int64_t ldw; const float* bias; void* y; int64_t ldy;
   int rows, N, K, act;
+  const float* s_part; int s_parts; const float* s_bias;      // s[r, c] = (T)(sum_h s_part[(r * s_parts + h) * K + c] + s_bias[c])  instead of `s`
 };
 
 template <typename T, int MR, int NW>
@@ -188,6 +189,27 @@ __global__ __launch_bounds__(256) void ln_gemv_kernel(LnGemvK p) {
           Ld8<T>::ld(sr + c, t);
 #pragma unroll
           for (int e = 0; e < 8; ++e) xn[m][i][e] += t[e];
+        } else if (p.s_part) {                       // the sublayer output as per-head partial sums (attn1_proj_kernel), summed in head order
+          float t[8];
+          if (p.s_bias) Ld8<float>::ld(p.s_bias + c, t);
+          else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t[e] = 0.f;
+          }
+          for (int h0 = 0; h0 < p.s_parts; h0 += 8) {                 // eight partial rows requested at once, added in head order
+            float uu[8][8];
+#pragma unroll
+            for (int hh = 0; hh < 8; ++hh)
+              if (h0 + hh < p.s_parts) Ld8<float>::ld(p.s_part + ((int64_t)m * p.s_parts + h0 + hh) * cols + c, uu[hh]);
+#pragma unroll
+            for (int hh = 0; hh < 8; ++hh)
+              if (h0 + hh < p.s_parts) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) t[e] += uu[hh][e];
+              }
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) xn[m][i][e] += (float)(T)t[e];      // (what a stored sublayer output would hold)
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) sum += xn[m][i][e];
@@ -259,6 +281,117 @@ __global__ __launch_bounds__(256) void ln_gemv_kernel(LnGemvK p) {
   reinterpret_cast<T*>(p.y)[(int64_t)m * p.ldy + n] = (T)v;
 }
 
+// Single-query attention with the output projection folded in (the decode step: one new token attends over its t + 1 cached keys
+// or over the memory).  Workgroup (4 waves) = (sequence b, head h, slab of 64 output columns): it recomputes the head's
+// attention -- scores of the Sk keys (16 lanes per key row, 16 keys per pass), softmax through LDS, o_h = P V -- and
+// multiplies o_h (rounded like a stored attention output) with its 64 x dh block of the out-projection weight.  The per-head
+// partial rows part[b][h][:] are summed in head order by the LayerNorm + Linear kernel that consumes them (ln_gemv_kernel): the
+// out-projection, its bias and its output round trip cost no launch.  K / V of a head are 2 * Sk * dh elements (44 KB for 116 keys):
+// recomputing them per slab is cheaper than a node of the graph.
+struct Attn1K {
+  const void* q; int64_t q_bs; const void* k; int64_t k_bs, k_rs; const void* v; int64_t v_bs, v_rs;
+  const void* Wo; int64_t ldw; float* part; int B, H, Sk, dh, slabs; float scale;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn1_proj_kernel(Attn1K p) {
+  __shared__ float sc_s[256];          // scores, then probabilities (Sk <= 256)
+  __shared__ float red_s[4][128];      // per-wave partial o_h
+  __shared__ float o_s[128];
+  __shared__ float wred[8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int slab = blockIdx.x % p.slabs, h = (blockIdx.x / p.slabs) % p.H, b = blockIdx.x / (p.slabs * p.H);
+  const int dh = p.dh, D = p.H * dh, pieces = dh >> 3;
+  const T* q = reinterpret_cast<const T*>(p.q) + (int64_t)b * p.q_bs + h * dh;
+  const T* K = reinterpret_cast<const T*>(p.k) + (int64_t)b * p.k_bs + h * dh;
+  const T* V = reinterpret_cast<const T*>(p.v) + (int64_t)b * p.v_bs + h * dh;
+  // a key row is `pieces` 16-byte pieces: 16 lanes per key (pieces <= 16), 4 keys per wave and pass, 16 per workgroup.
+  // Every K / V / Wo piece a thread will use is requested before anything is computed (the cache rows were written by other
+  // XCDs' kernels: each dependent load is a ~1 us round trip to the MALL) -- one latency instead of 2 * Sk / 16 + 3.
+  typedef typename std::conditional<std::is_same<T, float>::value, float __attribute__((ext_vector_type(8))), bf16x8>::type RawT;
+  constexpr int MAXIT = 16;                               // Sk <= 256
+  const int kl = lane >> 4, pc = lane & 15;
+  const bool live = pc < pieces;
+  const int j0 = wave * 4 + kl;
+  RawT qraw, kraw[MAXIT], vraw[MAXIT], wraw[4];
+  if (live) qraw = *reinterpret_cast<const RawT*>(q + pc * 8);
+#pragma unroll
+  for (int it = 0; it < MAXIT; ++it) {
+    const int j = j0 + it * 16;
+    if (live && j < p.Sk) kraw[it] = *reinterpret_cast<const RawT*>(K + (int64_t)j * p.k_rs + pc * 8);
+  }
+#pragma unroll
+  for (int it = 0; it < MAXIT; ++it) {
+    const int j = j0 + it * 16;
+    if (live && j < p.Sk) vraw[it] = *reinterpret_cast<const RawT*>(V + (int64_t)j * p.v_rs + pc * 8);
+  }
+  const int n = slab * 64 + (tid >> 2), quarter = tid & 3;
+  {
+    const T* w = reinterpret_cast<const T*>(p.Wo) + (int64_t)min(n, D - 1) * p.ldw + h * dh;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (quarter + 4 * i < pieces) wraw[i] = *reinterpret_cast<const RawT*>(w + (quarter + 4 * i) * 8);
+  }
+#pragma unroll
+  for (int it = 0; it < MAXIT; ++it) {
+    const int j = j0 + it * 16;
+    if (it * 16 >= p.Sk) break;                            // uniform
+    float a = 0.f;
+    if (live && j < p.Sk) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a = fmaf((float)qraw[e], (float)kraw[it][e], a);
+    }
+    a += __shfl_xor(a, 1); a += __shfl_xor(a, 2); a += __shfl_xor(a, 4); a += __shfl_xor(a, 8);
+    if (pc == 0 && j < p.Sk) sc_s[j] = a * p.scale;
+  }
+  __syncthreads();
+  const float sv = tid < p.Sk ? sc_s[tid] : -INFINITY;
+  float mx = wave_max(sv);
+  if (lane == 0) wred[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(wred[0], wred[1]), fmaxf(wred[2], wred[3]));
+  const float ev = tid < p.Sk ? __expf(sv - mx) : 0.f;
+  float l = wave_sum(ev);
+  if (lane == 0) wred[4 + wave] = l;
+  if (tid < p.Sk) sc_s[tid] = (float)(T)ev;               // the probabilities enter P V rounded, as in the MFMA kernels
+  __syncthreads();
+  const float inv = 1.f / (wred[4] + wred[5] + wred[6] + wred[7]);
+  float acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+  for (int it = 0; it < MAXIT; ++it) {
+    const int j = j0 + it * 16;
+    if (it * 16 >= p.Sk) break;
+    if (live && j < p.Sk) {
+      const float pj = sc_s[j];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] = fmaf(pj, (float)vraw[it][e], acc[e]);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { acc[e] += __shfl_xor(acc[e], 16); acc[e] += __shfl_xor(acc[e], 32); }
+  if (kl == 0 && live) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red_s[wave][pc * 8 + e] = acc[e];
+  }
+  __syncthreads();
+  if (tid < dh) o_s[tid] = (float)(T)((red_s[0][tid] + red_s[1][tid] + red_s[2][tid] + red_s[3][tid]) * inv);   // rounded like a stored attention output
+  __syncthreads();
+  // this slab's 64 columns of the out-projection: 4 lanes per column, pieces dealt round-robin
+  float a = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = quarter + 4 * i;
+    if (c < pieces) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a = fmaf(o_s[c * 8 + e], (float)wraw[i][e], a);
+    }
+  }
+  a += __shfl_xor(a, 1); a += __shfl_xor(a, 2);
+  if (n < D && quarter == 0) p.part[((int64_t)b * p.H + h) * D + n] = a;
+}
+
 template <typename T, int MR>
 int launch_ln_nw(const LnGemvK& k, hipStream_t st) {
   const int nw = k.N >= 4096 ? 4 : (k.N >= 2048 ? 2 : 1);
@@ -306,14 +439,34 @@ extern "C" int gpv_argmax_rows(const void* x, int64_t ld, const float* addend, i
   return (int)hipGetLastError();
 }
 
+extern "C" int gpv_attention_row_proj(const void* q, int64_t q_bs, const void* k, int64_t k_bs, int64_t k_rs, const void* v, int64_t v_bs,
+                                      int64_t v_rs, const void* Wo, int64_t ldw, float* partial, int B, int H, int Sk, int dh, float scale,
+                                      int dtype, void* stream) {
+  if (!q || !k || !v || !Wo || !partial || B <= 0 || H <= 0 || Sk <= 0 || Sk > 256 || dh <= 0 || dh > 128 || dh % 8 != 0) return (int)hipErrorInvalidValue;
+  const int esz = dtype == GPV_F32 ? 4 : 2;
+  for (const void* ptr : {q, k, v, Wo})
+    if (reinterpret_cast<uintptr_t>(ptr) & 15) return (int)hipErrorInvalidValue;
+  for (int64_t st : {q_bs, k_bs, k_rs, v_bs, v_rs, ldw})
+    if ((st * esz) % 16 != 0) return (int)hipErrorInvalidValue;
+  const int D = H * dh, slabs = (D + 63) / 64;
+  gpvk::Attn1K a{q, q_bs, k, k_bs, k_rs, v, v_bs, v_rs, Wo, ldw, partial, B, H, Sk, dh, slabs, scale};
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == GPV_BF16) gpvk::attn1_proj_kernel<bf16><<<dim3(B * H * slabs), dim3(256), 0, st>>>(a);
+  else if (dtype == GPV_F32) gpvk::attn1_proj_kernel<float><<<dim3(B * H * slabs), dim3(256), 0, st>>>(a);
+  else return (int)hipErrorInvalidValue;
+  return (int)hipGetLastError();
+}
+
 extern "C" int gpv_ln_linear_rows(const void* x, const void* s, const float* gamma, const float* beta, float eps, void* xn,
                                   const void* W, int64_t ldw, const float* bias, void* y, int64_t ldy,
-                                  int rows, int N, int K, int act, int dtype, void* stream) {
+                                  int rows, int N, int K, int act, int dtype, const float* s_partial, int s_parts, const float* s_bias,
+                                  void* stream) {
+  if (s_partial && (s || s_parts <= 0 || (reinterpret_cast<uintptr_t>(s_partial) & 15) || (reinterpret_cast<uintptr_t>(s_bias) & 15))) return (int)hipErrorInvalidValue;
   if (!x || !xn || !W || !y || rows <= 0 || rows > 4 || N <= 0 || K <= 0 || K > 1024 || K % 8 != 0 || ldw % 8 != 0) return (int)hipErrorInvalidValue;
   if ((gamma == nullptr) != (beta == nullptr) || xn == x || xn == s) return (int)hipErrorInvalidValue;
   for (const void* q : {x, s, (const void*)xn, W, (const void*)gamma, (const void*)beta})
     if (reinterpret_cast<uintptr_t>(q) & 15) return (int)hipErrorInvalidValue;
-  gpvk::LnGemvK k{x, s, gamma, beta, eps, xn, W, ldw, bias, y, ldy, rows, N, K, act};
+  gpvk::LnGemvK k{x, s, gamma, beta, eps, xn, W, ldw, bias, y, ldy, rows, N, K, act, s_partial, s_partial ? s_parts : 0, s_bias};
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (dtype == GPV_BF16) return gpvk::launch_ln_mr<bf16>(k, st);
   if (dtype == GPV_F32) return gpvk::launch_ln_mr<float>(k, st);

@@ -10,7 +10,8 @@ Per image batch:
     stride), single-query attention over the t+1 cached keys and over the memory, FFN, the logits of that position written
     into row t of the [B, T, V] result, and one launch that picks the next token (logit + vocabulary mask, arg-max) and
     stores it as the next input and as ids[:, t+1].  At B <= 8 every projection runs on the few-row kernel (csrc/gemv.hip),
-    at B <= 4 every LayerNorm is computed inside the projection that consumes it (gpv_ln_linear_rows): 27 launches per token.
+    at B <= 4 every LayerNorm is computed inside the projection that consumes it (gpv_ln_linear_rows): 27 launches per token;
+    at B = 1 the out-projections ride in the single-query attention launches (gpv_attention_row_proj): 21.
 Because the decoder is causal, the hidden state of position t only depends on tokens <= t: the per-step logits
 are exactly the rows of the reference's final full pass, so ``answer_logits`` (1,B,T,V) is assembled from them.
 
@@ -18,6 +19,8 @@ Every step has static shapes, so it is captured once into a HIP graph (torch.cud
 ROCm; our kernels are launched on the capturing stream through the C ABI) and replayed: 19+1 graph launches per
 decode instead of ~20 x 60 kernel launches from Python.
 """
+import os
+
 import torch
 
 from . import hip, ops
@@ -45,6 +48,11 @@ class GreedyKVDecoder:
         self.vocab_mask = torch.zeros(self.V, device=dev, dtype=torch.float32)
         self.wc = torch.empty(self.V, D, device=dev, dtype=dt)          # static: the captured graphs read these addresses
         self.use_graphs = use_graphs and dev.type == 'cuda'
+        # B <= 4: LayerNorm inside the consuming projection, out-projection inside the single-query attention (csrc/gemv.hip)
+        self.fused_rows = B <= hip.LN_LINEAR_MAX_ROWS and D <= hip.LN_LINEAR_MAX_COLS and D % 8 == 0
+        self.part = torch.empty(B, self.H, D, device=dev, dtype=torch.float32) if self.fused_rows else None
+        # out-projection inside the attention launch: 5.31-5.38 -> 5.24 ms at B = 1, 7.80 -> 8.18 ms at B = 4 (same box) -- B = 1 only
+        self.row_proj = os.environ.get('GPV_DECODE_ROW_PROJ', '1' if B == 1 else '0') != '0'
         self.graphs = [None] * T
         self.key = (RT.weights_epoch, RT.static_epoch, dt)
 
@@ -60,15 +68,31 @@ class GreedyKVDecoder:
 
     # ---- one decoding step (static shapes for a fixed t) ------------------------------------
     def _ln_lin(self, norm, x, s, w, bias, y, ldy, N, act=ops.ACT_NONE):
-        """x' = norm(x + s); y[:, :N] (row pitch ldy) = act(x' w^T + bias); returns x'.  One launch at B <= 4 (gpv_ln_linear_rows)."""
+        """x' = norm(x + s); y[:, :N] (row pitch ldy) = act(x' w^T + bias); returns x'.  One launch at B <= 4 (gpv_ln_linear_rows);
+        s: a tensor, or (partial rows, bias) from _attend"""
         B, D = x.shape
-        if B <= hip.LN_LINEAR_MAX_ROWS and D <= hip.LN_LINEAR_MAX_COLS and D % 8 == 0:
+        if self.fused_rows:
             xn = torch.empty_like(x)
-            hip.ln_linear_rows(x, s, norm.weight.detach(), norm.bias.detach(), norm.eps, xn, w, bias, y, ldy, B, N, D, act)
+            sp, sb = s if isinstance(s, tuple) else (None, None)
+            hip.ln_linear_rows(x, None if sp is not None else s, norm.weight.detach(), norm.bias.detach(), norm.eps, xn, w, bias, y, ldy,
+                               B, N, D, act, s_partial=sp, s_bias=sb)
             return xn
         xn = norm(x, s)
         hip.gemm(xn, w, y, B, N, D, D, D, ldy, bias=bias, act=act)
         return xn
+
+    def _attend(self, att, q, q_bs, k, v, kv_bs, kv_rs, Sk):
+        """the sublayer output of one query row per sequence: attention over Sk keys + out_proj.  At B <= 4 one launch that leaves
+        per-head partial rows for the LayerNorm + Linear kernel to sum (gpv_attention_row_proj), else attention + GEMM"""
+        B, D, H = self.B, self.D, self.H
+        dh = D // H
+        if self.fused_rows and self.row_proj and Sk <= hip.ROW_PROJ_MAX_KEYS:
+            wo = W(att.out_proj.weight, att.out_proj.bias)
+            hip.attention_row_proj(q, q_bs, k, kv_bs, kv_rs, v, kv_bs, kv_rs, wo.lp(), self.part, B, H, Sk, dh, 1.0 / dh ** 0.5)
+            return self.part, wo.bias_f32()
+        o = torch.empty(B, D, device=self.tok.device, dtype=RT.dtype)
+        hip.attention_fwd(q, k, v, o, ((q_bs, D), (kv_bs, kv_rs), (kv_bs, kv_rs), (D, D)), B, H, 1, Sk, dh, 1.0 / dh ** 0.5)
+        return att.out_proj(o)
 
     def _step_core(self, t):
         m, B, D, H, T, Tm = self.m, self.B, self.D, self.H, self.T, self.Tm
@@ -87,18 +111,12 @@ class GreedyKVDecoder:
                 hip.gemm(x, wqkv.lp(), c[:, t], B, 3 * D, D, D, D, T * 3 * D, bias=wqkv.bias_f32())
             else:
                 x = self._ln_lin(prev.norm3, x, s, wqkv.lp(), wqkv.bias_f32(), c[:, t], T * 3 * D, 3 * D)
-            o = torch.empty(B, D, device=dev, dtype=RT.dtype)
-            st = ((T * 3 * D, 3 * D), (T * 3 * D, 3 * D), (T * 3 * D, 3 * D), (D, D))
-            hip.attention_fwd(c[:, t], c[:, :, D:], c[:, :, 2 * D:], o, st, B, H, 1, t + 1, dh, 1.0 / dh ** 0.5)
-            s = sa.out_proj(o)
+            s = self._attend(sa, c[:, t], T * 3 * D, c[:, :, D:], c[:, :, 2 * D:], T * 3 * D, 3 * D, t + 1)
             wq = W(ca.in_proj_weight, ca.in_proj_bias, 0, D)
             q = torch.empty(B, D, device=dev, dtype=RT.dtype)
             x = self._ln_lin(layer.norm1, x, s, wq.lp(), wq.bias_f32(), q, D, D)
-            o = torch.empty(B, D, device=dev, dtype=RT.dtype)
             kvm = self.kvm[l]
-            st = ((D, D), (Tm * 2 * D, 2 * D), (Tm * 2 * D, 2 * D), (D, D))
-            hip.attention_fwd(q, kvm, kvm[:, D:], o, st, B, H, 1, Tm, dh, 1.0 / dh ** 0.5)
-            s = ca.out_proj(o)
+            s = self._attend(ca, q, D, kvm, kvm[:, D:], Tm * 2 * D, 2 * D, Tm)
             w1 = W(layer.linear1.weight, layer.linear1.bias)
             h = torch.empty(B, w1.N, device=dev, dtype=RT.dtype)
             x = self._ln_lin(layer.norm2, x, s, w1.lp(), w1.bias_f32(), h, w1.N, w1.N, ops.ACT_RELU)

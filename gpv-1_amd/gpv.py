@@ -398,7 +398,7 @@ class GPV(nn.Module):
     def _beam_device(self, images, queries, beam_size):
         """device part of the beam search: outputs dict + '_beam_seqs' [K,B,T] + '_beam_lp' [B,K] (no host round trip)"""
         graphed = isinstance(queries, (tuple, list)) and len(queries) == 2 and all(torch.is_tensor(q) for q in queries) and \
-            hasattr(images, 'tensors') and torch.cuda.is_current_stream_capturing()
+            hasattr(images, 'tensors') and images.tensors.is_cuda and torch.cuda.is_current_stream_capturing()
         outputs, memory = self._encode(images, queries, self._bert_fork(images, queries) if graphed else None)
         B, K, T = memory.shape[0], beam_size, self.cfg.max_text_len
         dev = memory.device

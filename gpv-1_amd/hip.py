@@ -102,7 +102,7 @@ EXPORTS = ['gpv_abi_version', 'gpv_set_option', 'gpv_gemm', 'gpv_conv2d', 'gpv_i
            'gpv_cast_rowscale_t', 'gpv_prep_conv_weight', 'gpv_embedding', 'gpv_dropout',
            'gpv_relevance_condition', 'gpv_adamw', 'gpv_sumsq', 'gpv_act_fwd', 'gpv_act_bwd', 'gpv_set_seed_device',
            'gpv_gemm_tt_group', 'gpv_cast_transpose_group', 'gpv_stem_pool', 'gpv_image_pipeline', 'gpv_conv1x1_dual',
-           'gpv_conv_wgrad_group', 'gpv_jpeg_parse', 'gpv_jpeg_decode', 'gpv_argmax_rows', 'gpv_ln_linear_rows']
+           'gpv_conv_wgrad_group', 'gpv_jpeg_parse', 'gpv_jpeg_decode', 'gpv_argmax_rows', 'gpv_ln_linear_rows', 'gpv_attention_row_proj']
 
 
 OPT_GLDS, OPT_GLDS_LAUNCHES, OPT_SKINNY, OPT_GLDS_WGRAD, OPT_PIPE, OPT_PIPE_LAUNCHES, OPT_C1S, OPT_C3S, OPT_C3S_LAUNCHES = 0, 1, 2, 3, 4, 5, 6, 7, 8
@@ -485,12 +485,30 @@ def argmax_rows(x, addend, out0=None, out1=None):
 LN_LINEAR_MAX_ROWS, LN_LINEAR_MAX_COLS = 4, 1024
 
 
-def ln_linear_rows(x, s, gamma, beta, eps, xn, Wm, bias, y, ldy, rows, N, K, act=ACT_NONE):
-    """xn = LayerNorm(x + s) * gamma + beta ; y = act(xn Wm^T + bias)  (rows <= 4, K <= 1024; Wm [N, K] rows of pitch Wm.stride(0))"""
+def ln_linear_rows(x, s, gamma, beta, eps, xn, Wm, bias, y, ldy, rows, N, K, act=ACT_NONE, s_partial=None, s_bias=None):
+    """xn = LayerNorm(x + s) * gamma + beta ; y = act(xn Wm^T + bias)  (rows <= 4, K <= 1024; Wm [N, K] rows of pitch Wm.stride(0)).
+    s_partial (fp32 [rows, parts, K], from attention_row_proj) + s_bias instead of s: s = sum over parts + bias"""
     if x.dtype != Wm.dtype or x.dtype != y.dtype or x.dtype != xn.dtype or (s is not None and s.dtype != x.dtype):
         raise TypeError('ln_linear_rows: dtypes differ')
+    parts = 0
+    if s_partial is not None:
+        assert s is None and s_partial.dtype == torch.float32 and s_partial.is_contiguous() and s_partial.shape[0] == rows and s_partial.shape[2] == K
+        parts = s_partial.shape[1]
     _chk(lib().gpv_ln_linear_rows(_p(x), _p(s), _p(_f32(gamma)), _p(_f32(beta)), C.c_float(eps), _p(xn), _p(Wm), C.c_int64(Wm.stride(0)),
-                                  _p(_f32(bias)), _p(y), C.c_int64(ldy), rows, N, K, act, dcode(x), _stream()), 'gpv_ln_linear_rows')
+                                  _p(_f32(bias)), _p(y), C.c_int64(ldy), rows, N, K, act, dcode(x), _p(s_partial), parts, _p(_f32(s_bias)),
+                                  _stream()), 'gpv_ln_linear_rows')
+
+
+ROW_PROJ_MAX_KEYS = 256
+
+
+def attention_row_proj(q, q_bs, k, k_bs, k_rs, v, v_bs, v_rs, Wo, partial, B, H, Sk, dh, scale):
+    """gpv_attention_row_proj: one query row per sequence over Sk keys, out-projection folded in -> partial fp32 [B, H, H*dh]"""
+    if q.dtype != k.dtype or q.dtype != v.dtype or q.dtype != Wo.dtype or partial.dtype != torch.float32:
+        raise TypeError('attention_row_proj: dtypes')
+    _chk(lib().gpv_attention_row_proj(_p(q), C.c_int64(q_bs), _p(k), C.c_int64(k_bs), C.c_int64(k_rs), _p(v), C.c_int64(v_bs), C.c_int64(v_rs),
+                                      _p(Wo), C.c_int64(Wo.stride(0)), _p(partial), B, H, Sk, dh, C.c_float(scale), dcode(q), _stream()),
+         'gpv_attention_row_proj')
 
 
 def act_bwd(dy, ref, dx, n, act, alpha=1.0):

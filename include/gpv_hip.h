@@ -310,10 +310,23 @@ int gpv_argmax_rows(const void* x, int64_t ld, const float* addend, int rows, in
  * x, s, xn: [rows, K] contiguous, dtype; W: [N, K] rows of pitch ldw (multiple of 8), dtype; y: dtype; 16-byte aligned bases;
  * xn must not alias x or s.  Bit-identical to gpv_layernorm_fwd followed by gpv_gemm on the same operands.
  * Replaces norm{1,2,3}(x + sublayer) followed by the next nn.Linear of torch's TransformerDecoderLayer in the sampling loop
- * (exp/gpv/models/gpv.py:183-184 -> decode_text). */
+ * (exp/gpv/models/gpv.py:183-184 -> decode_text).
+ * The sublayer output may instead arrive as fp32 partial rows (gpv_attention_row_proj): with s == NULL and s_partial != NULL,
+ *   s[r, c] = round_dtype(sum_{h < s_parts} s_partial[(r*s_parts + h)*K + c] + s_bias[c])     (s_bias may be NULL) */
 int gpv_ln_linear_rows(const void* x, const void* s, const float* gamma, const float* beta, float eps, void* xn,
                        const void* W, int64_t ldw, const float* bias, void* y, int64_t ldy,
-                       int rows, int N, int K, int act, int dtype, void* stream);
+                       int rows, int N, int K, int act, int dtype, const float* s_partial, int s_parts, const float* s_bias,
+                       void* stream);
+/* Single-query attention with the output projection folded in (one new token per sequence over Sk <= 256 keys; no mask, no
+ * dropout: the sampling loop):  o[b, h, :] = softmax(scale * q[b, h] K[b, :, h]^T) V[b, :, h];
+ *   partial[(b*H + h)*D + n] = sum_d round_dtype(o[b, h, d]) * Wo[n*ldw + h*dh + d]          n < D = H*dh
+ * q: element (b, h*dh + d) at q[b*q_bs + h*dh + d]; K / V: (b, j, h*dh + d) at k[b*k_bs + j*k_rs + h*dh + d]; strides in
+ * elements, multiples of 8 (fp32: 4); dh % 8 == 0, dh <= 128.  The sum over h (+ the projection's bias) is formed by the
+ * consumer (gpv_ln_linear_rows).  Replaces self_attn / multihead_attn of torch's TransformerDecoderLayer incl. their out_proj at
+ * one query row (exp/gpv/models/gpv.py:183-184 -> decode_text). */
+int gpv_attention_row_proj(const void* q, int64_t q_bs, const void* k, int64_t k_bs, int64_t k_rs, const void* v, int64_t v_bs,
+                           int64_t v_rs, const void* Wo, int64_t ldw, float* partial, int B, int H, int Sk, int dh, float scale,
+                           int dtype, void* stream);
 /* y = act(x), act in {RELU, GELU};  dx = dy * act'(ref) * alpha with ref = OUTPUT for relu (works through a
  * fused inverted dropout: alpha = 1/(1-p)), ref = PRE-activation for gelu.  n % 8 == 0. */
 int gpv_act_fwd(const void* x, void* y, int64_t n, int act, int dtype, void* stream);

@@ -318,7 +318,20 @@ def argmax_rows(x, addend, out0=None, out1=None):
             o.copy_(idx)
 
 
-def ln_linear_rows(x, s, gamma, beta, eps, xn, Wm, bias, y, ldy, rows, N, K, act=0):
+def attention_row_proj(q, q_bs, k, k_bs, k_rs, v, v_bs, v_rs, Wo, partial, B, H, Sk, dh, scale):
+    D = H * dh
+    qh = _sv(q, (B, H, dh), (q_bs, dh, 1)).float()
+    kh = _sv(k, (B, Sk, H, dh), (k_bs, k_rs, dh, 1)).float()
+    vh = _sv(v, (B, Sk, H, dh), (v_bs, v_rs, dh, 1)).float()
+    p = torch.softmax(torch.einsum('bhd,bjhd->bhj', qh, kh) * scale, -1)
+    o = torch.einsum('bhj,bjhd->bhd', p, vh).to(q.dtype).float()
+    w = Wo.float().reshape(D, H, dh)
+    partial.copy_(torch.einsum('bhd,nhd->bhn', o, w))
+
+
+def ln_linear_rows(x, s, gamma, beta, eps, xn, Wm, bias, y, ldy, rows, N, K, act=0, s_partial=None, s_bias=None):
+    if s_partial is not None:
+        s = (s_partial.sum(1) + (0 if s_bias is None else s_bias.float())).to(x.dtype)
     z = x.float().reshape(rows, K) + (0 if s is None else s.float().reshape(rows, K))
     n = F.layer_norm(z, (K,), None if gamma is None else gamma.float(), None if beta is None else beta.float(), eps).to(xn.dtype)
     xn.reshape(rows, K).copy_(n)
@@ -346,7 +359,7 @@ def install(only=None):
     names = only or ['gemm', 'conv2d', 'attention_fwd', 'attention_bwd', 'layernorm_fwd', 'layernorm_bwd', 'softmax_ce',
              'image_to_nhwc4', 'maxpool3x3s2', 'stem_pool', 'conv1x1_dual', 'conv_wgrad_group', 'roi_weights', 'add', 'add_rowbcast', 'colsum', 'cast', 'cast_rowscale_t',
              'prep_conv_weight', 'embedding', 'dropout', 'relevance_condition', 'adamw', 'sumsq', 'act_fwd', 'act_bwd',
-             'cast_transpose_group', 'argmax_rows', 'ln_linear_rows']
+             'cast_transpose_group', 'argmax_rows', 'ln_linear_rows', 'attention_row_proj']
     saved = {n: getattr(h, n) for n in names}
     for n in names:
         setattr(h, n, globals()[n])

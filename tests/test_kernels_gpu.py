@@ -113,6 +113,47 @@ def test_ln_linear_rows_equals_layernorm_then_gemm(dtype, rows, N, K):
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('B,H,dh,Sk', [(1, 8, 96, 1), (1, 8, 96, 20), (1, 8, 96, 116), (3, 8, 96, 200), (4, 4, 32, 70), (2, 16, 48, 256)])
+def test_attention_row_proj_and_partial_sum_consumer(dtype, B, H, dh, Sk):
+    """gpv_attention_row_proj (one query row per sequence, out-projection folded in, per-head partial rows) against fp32 math and
+    against attention_fwd + gemm on the same strided cache layout; gpv_ln_linear_rows summing the partials"""
+    h = hip()
+    D, T = H * dh, Sk + 3
+    cache = rnd(B, T, 3 * D, dtype=dtype, seed=61)                        # q | k | v rows of a decoder cache
+    t = Sk - 1
+    q, k, v = cache[:, t], cache[:, :, D:], cache[:, :, 2 * D:]
+    Wo, bo = rnd(D, D, dtype=dtype, seed=62, scale=dh ** -0.5), rnd(D, seed=63)
+    part = torch.full((B, H, D), 9.0, device=DEV)
+    scale = dh ** -0.5
+    h.attention_row_proj(q, T * 3 * D, k, T * 3 * D, 3 * D, v, T * 3 * D, 3 * D, Wo, part, B, H, Sk, dh, scale)
+    qh = cache[:, t, :D].float().reshape(B, H, dh)
+    kh = cache[:, :Sk, D:2 * D].float().reshape(B, Sk, H, dh)
+    vh = cache[:, :Sk, 2 * D:].float().reshape(B, Sk, H, dh)
+    pr = torch.softmax(torch.einsum('bhd,bjhd->bhj', qh, kh) * scale, -1)
+    o = torch.einsum('bhj,bjhd->bhd', pr, vh)
+    ref = o.reshape(B, D) @ Wo.float().t() + bo
+    got = part.sum(1) + bo
+    assert rel(got, ref) < TOL[dtype]
+    # the two-launch path on the same operands
+    if Sk <= 128 or dtype == torch.bfloat16:          # (the fp32 attention kernel stages at most 128 keys of 96 channels)
+        o2 = torch.empty(B, D, device=DEV, dtype=dtype)
+        h.attention_fwd(q, k, v, o2, ((T * 3 * D, D), (T * 3 * D, 3 * D), (T * 3 * D, 3 * D), (D, D)), B, H, 1, Sk, dh, scale)
+        s2 = torch.empty(B, D, device=DEV, dtype=dtype)
+        h.gemm(o2, Wo, s2, B, D, D, D, D, D, bias=bo)
+        assert rel(got, s2.float()) < TOL[dtype]
+    # consumer: LayerNorm(x + sum of partials + bias) -> Linear
+    if D <= 1024:
+        x = rnd(B, D, dtype=dtype, seed=64)
+        g, b = 1.0 + 0.1 * rnd(D, seed=65), 0.1 * rnd(D, seed=66)
+        Wm, bias = rnd(40, D, dtype=dtype, seed=67, scale=0.05), rnd(40, seed=68)
+        xn, y = torch.empty_like(x), torch.empty(B, 40, device=DEV, dtype=dtype)
+        h.ln_linear_rows(x, None, g, b, 1e-5, xn, Wm, bias, y, 40, B, 40, D, h.ACT_NONE, s_partial=part, s_bias=bo)
+        xn2, y2 = torch.empty_like(x), torch.empty(B, 40, device=DEV, dtype=dtype)
+        h.ln_linear_rows(x, got.to(dtype), g, b, 1e-5, xn2, Wm, bias, y2, 40, B, 40, D, h.ACT_NONE)
+        assert rel(xn, xn2.float()) < TOL[dtype] and rel(y, y2.float()) < TOL[dtype]
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
 def test_argmax_rows(dtype):
     """greedy token pick: arg-max of logit + mask in fp32, lowest index among equal values, strided outputs"""
     h = hip()
