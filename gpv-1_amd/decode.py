@@ -163,7 +163,8 @@ class GreedyKVDecoder:
                 self.tok.copy_(tok_in)
                 self.ids.copy_(ids_in)
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                from .misc import capture_guard
+                with capture_guard(), torch.cuda.graph(g):
                     self._step(t)
                 self.graphs[t] = g
                 self.tok.copy_(tok_in)

@@ -305,8 +305,14 @@ class GPV(nn.Module):
                 run()
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                out = run()
+            from .misc import capture_guard
+            with capture_guard(), torch.cuda.graph(graph):
+                try:
+                    out = run()
+                except BaseException:
+                    import traceback
+                    traceback.print_exc()          # (the capture's teardown can abort the process before the exception surfaces)
+                    raise
             ent = self._igraphs[key] = (graph, (sx, sm, sids, sattn, svm), out)
         self._igraphs[key] = self._igraphs.pop(key)                               # most recently used last
         graph, (sx, sm, sids, sattn, svm), out = ent

@@ -1,4 +1,6 @@
 """Batch container + collate helpers (reference: utils/detr_misc.py:267-322, 394-410)."""
+import contextlib
+import gc
 from typing import List, Optional
 
 import torch
@@ -120,3 +122,20 @@ class AttrDict(dict):
         if isinstance(d, (list, tuple)):
             return [AttrDict.wrap(v) for v in d]
         return d
+
+
+@contextlib.contextmanager
+def capture_guard():
+    """No cyclic garbage collection while a stream is capturing: a CUDAGraph that becomes collectable in there (the captured graphs
+    of a model that was dropped earlier -- GPV and its decoders reference each other, so only the cycle collector frees them) would
+    be destroyed inside the capture, which HIP refuses and PyTorch's destructor turns into std::terminate (tools/fuzz_decode.py
+    found it: a new model per configuration)."""
+    was = gc.isenabled()
+    gc.collect()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if was:
+            gc.enable()
+
