@@ -83,8 +83,10 @@ struct BitReader {
     if (nb) { n -= nb; return t.look_sym[look]; }
     int l = LOOK + 1;
     int code = (int)((acc >> (n - l)) & ((1u << l) - 1));
-    while (l <= 16 && code > t.maxcode[l]) { ++l; code = (int)((acc >> (n - l)) & ((1u << l) - 1)); }
-    if (l > 16) return -1;
+    while (code > t.maxcode[l]) {                       // (never shifts by n - 17: a code longer than 16 bits does not exist)
+      if (++l > 16) return -1;
+      code = (int)((acc >> (n - l)) & ((1u << l) - 1));
+    }
     n -= l;
     return t.syms[(code + t.valoffset[l]) & 255];
   }

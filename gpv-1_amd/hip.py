@@ -96,13 +96,20 @@ def lib():
     return _LIB
 
 
-EXPORTS = ['gpv_abi_version', 'gpv_set_option', 'gpv_gemm', 'gpv_conv2d', 'gpv_image_to_nhwc4', 'gpv_maxpool3x3s2',
+EXPORTS = ['gpv_abi_version', 'gpv_build_id', 'gpv_set_option', 'gpv_gemm', 'gpv_conv2d', 'gpv_image_to_nhwc4', 'gpv_maxpool3x3s2',
            'gpv_attention_fwd', 'gpv_attention_bwd', 'gpv_layernorm_fwd', 'gpv_layernorm_bwd',
            'gpv_softmax_ce', 'gpv_roi_weights', 'gpv_add', 'gpv_add_rowbcast', 'gpv_colsum', 'gpv_cast',
            'gpv_cast_rowscale_t', 'gpv_prep_conv_weight', 'gpv_embedding', 'gpv_dropout',
            'gpv_relevance_condition', 'gpv_adamw', 'gpv_sumsq', 'gpv_act_fwd', 'gpv_act_bwd', 'gpv_set_seed_device',
            'gpv_gemm_tt_group', 'gpv_cast_transpose_group', 'gpv_stem_pool', 'gpv_image_pipeline', 'gpv_conv1x1_dual',
            'gpv_conv_wgrad_group', 'gpv_jpeg_parse', 'gpv_jpeg_decode', 'gpv_argmax_rows', 'gpv_ln_linear_rows', 'gpv_attention_row_proj']
+
+
+def build_id():
+    """gpv_build_id: sha256 prefix of the sources the loaded library was compiled from"""
+    buf = C.create_string_buffer(64)
+    _chk(lib().gpv_build_id(buf, C.c_int(64)), 'gpv_build_id')
+    return buf.value.decode()
 
 
 OPT_GLDS, OPT_GLDS_LAUNCHES, OPT_SKINNY, OPT_GLDS_WGRAD, OPT_PIPE, OPT_PIPE_LAUNCHES, OPT_C1S, OPT_C3S, OPT_C3S_LAUNCHES = 0, 1, 2, 3, 4, 5, 6, 7, 8

@@ -23,8 +23,12 @@ from .misc import upload_bytes
 
 
 class DeviceJpegDecoder:
-    def __init__(self, device='cuda', threads=8, slots=3):
+    def __init__(self, device='cuda', threads=8, slots=3, max_pixels=64 << 20):
+        """max_pixels: refuse files whose header declares more than this many pixels (default 64 MPix; COCO's largest is 0.4) BEFORE
+        anything is sized from it -- a 300-byte file may declare 65535 x 65535 -- and keep every offset of gpv_jpeg_desc inside its
+        32-bit fields (3 components x 64 MPix x 1 byte < 2^31)"""
         self.device = torch.device(device)
+        self.max_pixels = int(min(max_pixels, 512 << 20))
         self.pool = ThreadPoolExecutor(max_workers=threads) if threads > 1 else None
         # pinned staging for the coefficients: a ring of buffers, each guarded by the event of its last upload (allocating
         # pinned memory per batch costs more than decoding the batch)
@@ -49,7 +53,9 @@ class DeviceJpegDecoder:
         run = (lambda f, it: list(self.pool.map(f, it))) if self.pool is not None else (lambda f, it: [f(x) for x in it])
         infos = run(hip.jpeg_parse, files)                                            # header pass: sizes
         starts, total = [], 0
-        for inf in infos:
+        for i, inf in enumerate(infos):
+            if inf.width * inf.height > self.max_pixels or int(inf.coef_count) > 4 * self.max_pixels:
+                raise ValueError(f'DeviceJpegDecoder: file {i} declares {inf.width} x {inf.height} pixels, more than max_pixels = {self.max_pixels}')
             starts.append(total)
             total += int(inf.coef_count)
         slot, stage = self._staging(total)                                            # one pinned buffer, one upload
@@ -72,6 +78,8 @@ class DeviceJpegDecoder:
             off = 0
             for c in range(inf.ncomp):
                 d.bh[c], d.bw[c] = inf.bh[c], inf.bw[c]
+                if int(inf.coef_offset[c]) >= 1 << 31 or off >= 1 << 31:        # (cannot happen under max_pixels; never truncate silently)
+                    raise OverflowError('DeviceJpegDecoder: component offset does not fit gpv_jpeg_desc')
                 d.coef_off[c] = int(inf.coef_offset[c])
                 d.plane_off[c] = off
                 off += inf.bh[c] * inf.bw[c] * 64

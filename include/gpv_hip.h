@@ -36,6 +36,10 @@ extern "C" {
 #define GPV_TRANS 1  /* element (row r, red k) at ptr[k*ld + r]  (reduction index is the slow dim) */
 
 int gpv_abi_version(void); /* = 1 */
+/* writes the NUL-terminated build id (sha256 prefix of the sources the library was compiled from: csrc/Makefile BUILD_ID) into the
+ * HOST buffer `buf` of `cap` bytes; 0 = ok.  No reference counterpart: it lets a loader refuse a library that is older than the
+ * tree next to it (__graft_entry__.build()). */
+int gpv_build_id(char* buf, int cap);
 
 /* ---------------------------------------------------------------------------------------------
  * Grouped weight-gradient GEMM:  for every problem i:  C_i[M_i, N_i] += A_i^T B_i   (fp32 accumulate into C)

@@ -103,3 +103,18 @@ def test_narrow_images_use_replication_not_the_triangle_filter():
         Image.fromarray(img).save(buf, 'JPEG', quality=int(r.randint(20, 100)), subsampling=int(r.randint(0, 3)))
         exp = np.asarray(Image.open(io.BytesIO(buf.getvalue())))
         assert np.array_equal(J.decode(buf.getvalue()), exp), (h, w)
+
+
+def test_decoder_refuses_a_header_that_declares_a_huge_image_before_sizing_anything():
+    """a ~300-byte file may declare 65535 x 65535 pixels: DeviceJpegDecoder checks the header against max_pixels before any buffer
+    is sized from it (26 GB pinned + offsets wrapping gpv_jpeg_desc's 32-bit fields)"""
+    from gpv1_amd.jpeg import DeviceJpegDecoder
+    data = bytearray(open(os.path.join(GOLD, 'c444_odd_q97.jpg'), 'rb').read())
+    i = data.index(b'\xff\xc0')                       # SOF0: marker, length(2), precision(1), height(2), width(2)
+    data[i + 5:i + 9] = b'\xff\xff\xff\xff'
+    dec = DeviceJpegDecoder(threads=1)
+    with pytest.raises(ValueError, match='max_pixels'):
+        dec([bytes(data)])
+    small = DeviceJpegDecoder(threads=1, max_pixels=100)
+    with pytest.raises(ValueError, match='max_pixels'):
+        small([open(os.path.join(GOLD, 'c444_odd_q97.jpg'), 'rb').read()])
