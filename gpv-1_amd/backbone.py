@@ -29,6 +29,11 @@ FUSED_STEM = os.environ.get('GPV_FUSED_STEM', '1') != '0'
 FUSED_TAIL = os.environ.get('GPV_FUSED_TAIL', '1') != '0'
 WGRAD_STREAM = os.environ.get('GPV_WGRAD_STREAM', '1') != '0'
 WGRAD_GROUP = os.environ.get('GPV_WGRAD_GROUP', '1') != '0'      # all conv weight gradients of a backward pass as one grouped call (bf16)
+# ... issued per STAGE (layer4, then layer3, then layer2) right behind that stage's backward-data chain, while the stage's dy / x
+# are still in the 256 MB MALL -- and so that a data-parallel trainer can hand layer4's gradients (60 of the backbone's 94 MB) to
+# the all-reduce while layer3 / layer2 still compute (train.FlatTrainer stage milestones).  0: one call at the end of the pass
+# (round 3); 'side': the stage groups on a parallel branch
+WGRAD_STAGES = os.environ.get('GPV_WGRAD_STAGES', '1')
 _WSTREAMS = {}
 
 
@@ -212,6 +217,12 @@ class ResNetBody(nn.Module):
     def blocks(self):
         return [b for li in range(1, 5) for b in getattr(self, f'layer{li}')]
 
+    def stage_of(self, blk):
+        m = getattr(self, '_stage_map', None)
+        if m is None:
+            m = self._stage_map = {id(b): li for li in range(1, 5) for b in getattr(self, f'layer{li}')}
+        return m[id(blk)]
+
     def _stem_weight(self):
         key = ('stem', id(self), RT.dtype)
         hit = RT.cache.get(key)
@@ -289,20 +300,25 @@ class ResNetBody(nn.Module):
             _conv_copies(blk.conv3, blk.bn3, True)
             seen_trainable = True
 
-    def backward_nhwc(self, keep, dc5):
+    def backward_nhwc(self, keep, dc5, stage_done=None):
         """dc5: gradient w.r.t. the (post-ReLU) c5 output, [B,h,w,2048] compute dtype.
 
         The backward-data convolutions form a serial chain; the 42 weight gradients hang off it and nobody needs them before the
-        optimizer.  bf16: they are collected and handed to ONE grouped call at the end of the pass (gpv_conv_wgrad_group: equal
-        work units over all problems, layer4 without a split reduction) -- GPV_WGRAD_GROUP=0 / fp32 "precise" mode: one launch
-        each on a SIDE stream (a parallel branch when the pass is captured into a hipGraph), ordered behind the backward-data
-        launch that produced its dy, one join at the end (GPV_WGRAD_STREAM=0 puts them back in line)."""
+        optimizer (or the gradient exchange).  bf16: they are collected and handed to gpv_conv_wgrad_group (equal work units over
+        all problems, layer4 without a split reduction) -- one call per STAGE, issued right behind the stage's last backward-data
+        launch (GPV_WGRAD_STAGES=0: one call at the end of the pass; 'side': on a parallel branch).  `stage_done(li)` is called
+        when every gradient of layer li has been issued (train.py: bucket milestones / graph cuts).
+        GPV_WGRAD_GROUP=0 / fp32 "precise" mode: one launch each on a SIDE stream (a parallel branch when the pass is captured
+        into a hipGraph), ordered behind the backward-data launch that produced its dy, one join at the end
+        (GPV_WGRAD_STREAM=0 puts them back in line)."""
         if not keep:
             return
         dev = dc5.device
         main = torch.cuda.current_stream(dev) if dev.type == 'cuda' else None
         group = [] if (WGRAD_GROUP and dc5.dtype == torch.bfloat16) else None
         side = _wgrad_stream(dev) if (main is not None and WGRAD_STREAM and group is None) else None
+        gside = _wgrad_stream(dev) if (main is not None and group is not None and WGRAD_STAGES == 'side') else None
+        per_stage = WGRAD_STAGES != '0' or stage_done is not None
         held = []                                        # operands of the side-stream launches stay referenced until the join
 
         def wgrad(xa, dy, conv, bn):
@@ -318,11 +334,28 @@ class ResNetBody(nn.Module):
             with torch.cuda.stream(side):
                 _conv_wgrad(xa, dy, conv, bn)
             held.append((xa, dy))
+
+        def flush(li):
+            if group:
+                if gside is not None:
+                    gside.wait_stream(main)
+                    with torch.cuda.stream(gside):
+                        hip.conv_wgrad_group(group)
+                    held.extend(group)
+                else:
+                    hip.conv_wgrad_group(group)
+                del group[:]
+            if stage_done is not None:
+                if gside is not None:
+                    main.wait_stream(gside)
+                stage_done(li)
         y_last = keep[-1][4]
         gz = torch.empty_like(y_last)
         hip.act_bwd(dc5.contiguous(), y_last, gz, gz.numel(), RELU, 1.0)          # through the final ReLU
-        for blk, x, a1, a2, yb, need_dx in reversed(keep):
+        order = list(reversed(keep))
+        for i, (blk, x, a1, a2, yb, need_dx) in enumerate(order):
             # gz = gradient w.r.t. (conv3 + shift + identity), i.e. already masked by (yb > 0)
+            li = self.stage_of(blk)
             wgrad(a2, gz, blk.conv3, blk.bn3)
             g2 = _conv_dgrad(gz, blk.conv3, blk.bn3, a2.shape, relu_mask=a2)
             wgrad(a1, g2, blk.conv2, blk.bn2)
@@ -331,6 +364,7 @@ class ResNetBody(nn.Module):
             if blk.downsample is not None:
                 wgrad(x, gz, blk.downsample[0], blk.downsample[1])
             if not need_dx:
+                flush(li)
                 break
             if blk.downsample is not None:
                 side_g = _conv_dgrad(gz, blk.downsample[0], blk.downsample[1], x.shape)
@@ -339,10 +373,13 @@ class ResNetBody(nn.Module):
             # input gradient, masked by the previous block's ReLU (x is that block's output)
             gz = _conv_dgrad(g1, blk.conv1, blk.bn1, x.shape, res=side_g, relu_mask=x)
             del g1, g2, side_g
-        if group:
-            hip.conv_wgrad_group(group)
+            last = i + 1 == len(order)
+            if last or (per_stage and self.stage_of(order[i + 1][0]) != li):
+                flush(li)
         if side is not None:
             main.wait_stream(side)
+        if gside is not None:
+            main.wait_stream(gside)
         del held
 
 
@@ -362,7 +399,8 @@ class ResNetFn(Function):
         if RT.backward_milestone is not None:          # everything downstream of the backbone has finished its backward
             RT.backward_milestone('backbone')
         ev = _prof('conv_bwd')
-        ctx.body.backward_nhwc(ctx.keep, dc5.to(RT.dtype))
+        ms = RT.backward_milestone
+        ctx.body.backward_nhwc(ctx.keep, dc5.to(RT.dtype), (lambda li: ms('layer%d' % li)) if ms is not None else None)
         if ev is not None:
             ev.record()
         ctx.keep = None

@@ -279,8 +279,10 @@ class GraphedBody:
         if RT.backward_milestone is not None:
             RT.backward_milestone('backbone')
         ev = bbm._prof('conv_bwd')
-        if var['b2'] is not None:
-            var['b2'].replay()
+        for g, tag in var['b2']:                 # one graph (single GPU) or one per backbone stage (several ranks: stage milestones)
+            g.replay()
+            if tag is not None and RT.backward_milestone is not None:
+                RT.backward_milestone(tag)
         if ev is not None:
             ev.record()
 
@@ -303,6 +305,7 @@ class GraphedBody:
         gc.collect()
         grads = [torch.zeros_like(g) for _, _, g in pairs]
         b1, b2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        b2_list = []
         saved = tr.touched.clone()
         tr.touched.zero_()
         milestone, RT.backward_milestone = RT.backward_milestone, None
@@ -365,13 +368,30 @@ class GraphedBody:
                 elif deferred:
                     self._flush(deferred)
                 if bb_bwd:
-                    self.body.backward_nhwc(self.keep, dc5.to(RT.dtype))
+                    # several ranks: B2 is cut into one graph per backbone stage (layer4 | layer3 | layer2) so that the trainer
+                    # can hand a finished stage's gradient buckets to the all-reduce between the replays (the exchange is not
+                    # captured); tensors crossing a cut live in the shared graph pool, like c5 between F1 and F2
+                    cut = tr.world > 1 or tr.dry_overlap or os.environ.get('GPV_B2_STAGES', '0') == '1'
+                    last_li = self.body.stage_of(self.keep[0][0])
+                    cur = [b2]
+
+                    def stage_done(li):
+                        if li == last_li:
+                            return
+                        cur[0].capture_end()
+                        b2_list.append((cur[0], 'layer%d' % li))
+                        g = torch.cuda.CUDAGraph()
+                        g.capture_begin(pool=self.pool, capture_error_mode=CAPTURE_MODE)
+                        self._open = cur[0] = g
+                    self.body.backward_nhwc(self.keep, dc5.to(RT.dtype), stage_done if cut else None)
                     if deferred:
                         torch.cuda.current_stream(dev).wait_stream(self.wside)
-                b2.capture_end()
+                    cur[0].capture_end()
+                    b2_list.append((cur[0], 'layer%d' % last_li))
+                else:
+                    b2.capture_end()
+                    b2_list.append((b2, None))
                 self._open = None
-            else:
-                b2 = None
         except BaseException:
             self._abort_open()
             raise
@@ -379,7 +399,7 @@ class GraphedBody:
             RT.defer_list = None
             RT.backward_boundary = None
         RT.backward_milestone = milestone
-        var = {'b1': b1, 'b2': b2, 'grads': grads, 'touched': tr.touched.clone(), 'dc5': dc5, 'deferred': deferred + side_a}
+        var = {'b1': b1, 'b2': b2_list, 'grads': grads, 'touched': tr.touched.clone(), 'dc5': dc5, 'deferred': deferred + side_a}
         tr.touched |= saved
         return var
 
@@ -459,12 +479,25 @@ class FlatTrainer:
         self.gscale = torch.ones(1, device=dev, dtype=torch.float32)
         b = bucket_mb * 1024 * 1024 // 4
         self.backbone_end = max([o + (k + 7) // 8 * 8 for (n, p, g, o, k) in self.entries if g == 'detr_backbone'], default=0)
-        self.buckets = [(s, min(self.backbone_end, s + b)) for s in range(0, self.backbone_end, b)] + \
-                       [(s, min(off, s + b)) for s in range(self.backbone_end, off, b)]      # no bucket straddles the backbone boundary
+        # flat ranges of the backbone's stages (module order = flat order: layer2 | layer3 | layer4): each is a milestone of the
+        # backward pass -- its buckets go to the all-reduce as soon as the stage's weight gradients have been issued
+        self.stage_range = {}
+        for (n, p, g, o, k) in self.entries:
+            if g != 'detr_backbone':
+                continue
+            st = next((t for t in ('layer1', 'layer2', 'layer3', 'layer4') if '.%s.' % t in n), 'stem')
+            lo, hi = self.stage_range.get(st, (o, o))
+            self.stage_range[st] = (min(lo, o), max(hi, o + (k + 7) // 8 * 8))
+        cuts = sorted({0, self.backbone_end, off} | {v for r in self.stage_range.values() for v in r})
+        self.buckets = [(s, min(hi, s + b)) for lo, hi in zip(cuts[:-1], cuts[1:]) for s in range(lo, hi, b)]   # no bucket straddles a stage / the backbone boundary
+        # the order in which EVERY rank issues them: behind the backbone first, then the backbone stages last-to-first
+        self.bucket_order = [q for q in self.buckets if q[0] >= self.backbone_end] + \
+            sorted((q for q in self.buckets if q[0] < self.backbone_end), key=lambda q: -q[0])
         self.Gc = torch.zeros(off, device=dev, dtype=torch.bfloat16) if (self.world > 1 and self.grad_comm_dtype == torch.bfloat16) else None
         self.overlap = self.world > 1 and os.environ.get('GPV_OVERLAP', '1') != '0'
         self.dry_overlap = False             # tests: run the milestone / guard logic without communicating
         self._closed_from, self._works, self.late_touch, self.milestones = None, [], None, 0
+        self._next_bucket, self.milestone_log = 0, []
         self.defer_wgrad = os.environ.get('GPV_DEFER_WGRAD', '1') != '0'       # (with several ranks the groups stay inside B1)
         self.host_pg = None
         if self.world > 1:
@@ -511,12 +544,31 @@ class FlatTrainer:
     # that milestone the buckets behind the backbone segment are all-reduced on RCCL's stream while the backbone
     # backward (8 of the ~22 ms) computes; the backbone segment follows after the pass.  _mark() guards the assumption.
     def _on_milestone(self, what):
-        if what != 'backbone' or self._closed_from is not None or not (self.overlap or self.dry_overlap):
+        """'backbone': the backward pass has reached the backbone (every gradient behind its flat segment is complete);
+        'layerN': every weight gradient of backbone stage N has been issued (backbone.backward_nhwc stage_done).  The flat
+        offsets from the milestone's start on are closed (_mark guards it) and their buckets handed to the all-reduce."""
+        if not (self.overlap or self.dry_overlap):
             return
-        self._closed_from = self.backbone_end
+        if what == 'backbone':
+            start = self.backbone_end
+        elif what in self.stage_range:
+            start = self.stage_range[what][0]
+        else:
+            return
+        if self._closed_from is not None and start >= self._closed_from:
+            return
+        self._closed_from = start
         self.milestones += 1
+        self.milestone_log.append((what, start))
         if self.overlap:
-            self._works = [self._reduce_bucket(s, e) for s, e in self.buckets if s >= self.backbone_end]
+            self._issue_upto(start)
+
+    def _issue_upto(self, start):
+        """issue, in the canonical order, every bucket not yet issued that lies at or behind flat offset `start`"""
+        while self._next_bucket < len(self.bucket_order) and self.bucket_order[self._next_bucket][0] >= start:
+            s, e = self.bucket_order[self._next_bucket]
+            self._works.append(self._reduce_bucket(s, e))
+            self._next_bucket += 1
 
     def _reduce_bucket(self, s, e):
         """asynchronous SUM all-reduce of G[s:e] (through the bf16 staging buffer when grad_comm_dtype is bf16)"""
@@ -527,21 +579,22 @@ class FlatTrainer:
 
     def begin_backward(self):
         self._closed_from, self._works, self.late_touch, self.milestones = None, [], None, 0
+        self._next_bucket, self.milestone_log = 0, []
         RT.backward_milestone = self._on_milestone
 
     def allreduce_grads(self):
         RT.backward_milestone = None
-        closed = self._closed_from
         self._closed_from = None
         if self.world == 1:
             return
-        # Every rank issues the buckets in the SAME order -- [behind the backbone segment] then [backbone segment] -- whether or
-        # not its backward reached the milestone (a rank without an applicable target runs no backward at all, see train_step).
+        # Every rank issues the buckets in the SAME order (bucket_order: behind the backbone segment, then layer4, layer3, layer2)
+        # whether or not its backward reached the milestones (a rank without an applicable target runs no backward at all, see
+        # train_step): whatever has not been handed over yet goes now.
+        first_late = self._next_bucket              # buckets [0, first_late) of bucket_order were handed over during the backward pass
+        self._issue_upto(0)
         works = list(self._works)
-        if closed is None:
-            works += [self._reduce_bucket(s, e) for s, e in self.buckets if s >= self.backbone_end]
-        works += [self._reduce_bucket(s, e) for s, e in self.buckets if s < self.backbone_end]
         self._works = []
+        self.left_after_backward = sum(e - s for s, e in self.bucket_order[first_late:]) * (2 if self.Gc is not None else 4)   # bytes
         self._publish_touched()
         dist.all_reduce(self.live, op=dist.ReduceOp.MAX, group=self.pg)          # stays on the device: no host sync
         prof = self.comm_prof is not None and self.G.is_cuda

@@ -66,6 +66,8 @@ def _worker(rank, world, port, out):
         tr.train_step(nested(images, mask), (ids, attn), _targets(rank, V))
     # train_step overlaps the exchange of everything behind the backbone segment with the backbone's backward
     res['milestones'], res['late_touch'], res['overlap'] = tr.milestones, tr.late_touch, tr.overlap
+    res['milestone_log'], res['bucket_order'], res['stage_range'] = list(tr.milestone_log), list(tr.bucket_order), dict(tr.stage_range)
+    res['left_after_backward'], res['backbone_end'], res['total'] = getattr(tr, 'left_after_backward', None), tr.backbone_end, tr.total
     res['P'] = tr.P.clone()
     res['names'] = [e[0] for e in tr.entries]
     torch.save(res, os.path.join(out, f'rank{rank}.pt'))
@@ -83,7 +85,22 @@ def test_two_rank_gradient_exchange(tmp_path):
         runs[overlap] = [torch.load(os.path.join(out, f'rank{r}.pt')) for r in range(2)]
     os.environ.pop('GPV_OVERLAP')
     r0, r1 = runs['1']
-    assert r0['overlap'] and r0['milestones'] == 1 and r0['late_touch'] is None and r1['late_touch'] is None
+    assert r0['overlap'] and r0['late_touch'] is None and r1['late_touch'] is None
+    # hand-over order: everything behind the backbone segment when the backward pass reaches the backbone, then the backbone's
+    # stages as each one's weight gradients have been issued -- layer4 (the largest) while layer3 / layer2 still compute
+    for r in (r0, r1):
+        assert [m for m, _ in r['milestone_log']] == ['backbone', 'layer4', 'layer3', 'layer2']
+        starts = [st for _, st in r['milestone_log']]
+        assert starts == [r['backbone_end'], r['stage_range']['layer4'][0], r['stage_range']['layer3'][0], r['stage_range']['layer2'][0]]
+        assert starts == sorted(starts, reverse=True) and starts[-1] == 0
+        order = r['bucket_order']
+        assert order == r0['bucket_order'] and sum(e - s for s, e in order) == r['total']
+        firsts = [s for s, _ in order]
+        nb = sum(1 for s in firsts if s >= r['backbone_end'])
+        assert all(s >= r['backbone_end'] for s in firsts[:nb]) and firsts[nb:] == sorted(firsts[nb:], reverse=True)
+        for lo, hi in r['stage_range'].values():                       # no bucket straddles a stage boundary
+            assert all(e <= lo or s >= hi or (s >= lo and e <= hi) for s, e in order)
+        assert r['left_after_backward'] == 0                           # every bucket was handed over during the backward pass
     assert not runs['0'][0]['overlap'] and runs['0'][0]['milestones'] == 0
     # same parameters after the steps whichever way the gradients were exchanged (same sums, same order per bucket)
     assert torch.equal(r0['P'], runs['0'][0]['P'])

@@ -50,7 +50,7 @@ def _worker(rank, world, port, out, comm='fp32'):
                     d[k] = v.cuda()
         model.bert.model.p = 0.0
         loss = tr.train_step(nested(images, mask), (ids, attn), tg)
-        assert tr.milestones == 1 and tr.late_touch is None
+        assert [m for m, _ in tr.milestone_log] == ['backbone', 'layer4', 'layer3', 'layer2'] and tr.late_touch is None, (tr.milestone_log, tr.late_touch)
         losses.append(float(loss.detach()))
     torch.cuda.synchronize()
     # steps 2.. replay the captured hipGraphs; with two ranks the DETR weight-gradient group is flushed at the END of B1 (every

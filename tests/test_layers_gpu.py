@@ -1,0 +1,242 @@
+"""Isolated bf16-faithful checks of the transformer-side layers at the BENCH shapes.
+
+The end-to-end bf16 comparison is held to a few percent of max|ref| because a random-init ResNet amplifies single-ulp flips
+chaotically; tests/test_model_gpu.py::test_backbone_blocks_at_bench_shapes_vs_bf16_faithful_oracle_isolated is the
+sharp check for the convolutions.  This file is the same construction for everything behind the backbone: ONE layer of each kind
+-- DETR encoder (transformer.py:148-161), DETR decoder (:211-232), co-attention (vilbert.py:872-900), text decoder (torch
+nn.TransformerDecoderLayer, gpv.py:37-43) -- alone, at the shapes bench.py times (B = 32: 9600 encoder rows, 3200 query rows,
+192 language rows, 640 answer rows), dropout off, in the production bf16 mode, against oracle/gpv_oracle.py in bf16-faithful mode
+(the fp32 restatement pinned to the reference, rounding where the HIP path stores bf16) fed the SAME input:
+  forward: distance in bf16 ulps of the reference value (magnitudes floored at 2^-6 of the tensor's largest);
+  backward: input-gradient and weight-gradient direction (cosine) and norm against the oracle's autograd.
+Bounds are stated next to what was measured."""
+import os
+
+import pytest
+import torch
+
+from tests import synth
+from tests.test_model_gpu import _ulp_stats, rt  # noqa: F401  (fixture)
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+B = 32
+
+
+def _randomise(mod, gen):
+    """default initialisation leaves every bias 0 and every LayerNorm at (1, 0): a wrong bias / gamma / beta path would pass"""
+    with torch.no_grad():
+        for n, p in mod.named_parameters():
+            if n.endswith('bias'):
+                p.copy_(0.1 * torch.randn(p.shape, generator=gen))
+            elif p.dim() == 1:
+                p.copy_(1.0 + 0.2 * torch.randn(p.shape, generator=gen))
+
+
+def _state(mod, pre):
+    return {pre + k: v.detach().float().cpu().contiguous() for k, v in mod.state_dict().items()}
+
+
+def _cos(a, b):
+    a, b = a.detach().double().flatten().cpu(), b.detach().double().flatten().cpu()
+    return float(a @ b / (a.norm() * b.norm()).clamp_min(1e-30)), abs(float(a.norm()) - float(b.norm())) / max(float(b.norm()), 1e-30)
+
+
+def _check_fwd(tag, got, want, max_ulp, max_frac_gt1):
+    """got: HIP output (bf16), want: faithful-oracle output (bf16-representable fp32)"""
+    ulps, frac = _ulp_stats(got, want)
+    a, r = got.detach().float().cpu(), want.detach().float().cpu()
+    mag = torch.maximum(a.abs(), r.abs()).clamp_min(float(r.abs().max()) * 2.0 ** -6)
+    spacing = torch.pow(2.0, torch.floor(torch.log2(mag)) - 7)
+    gt1 = float(((a - r).abs() / spacing > 1.0).float().mean())
+    print('LAYER fwd %-28s max %.2f ulp, %.5f of the elements differ, %.6f by more than one ulp' % (tag, ulps, frac, gt1))
+    assert ulps <= max_ulp and gt1 <= max_frac_gt1, (tag, ulps, frac, gt1)
+
+
+def _check_grads(tag, pairs, min_cos, max_norm_err):
+    worst = (1.0, 0.0, None)
+    for name, gh, gr in pairs:
+        c, ne = _cos(gh, gr)
+        print('LAYER bwd %-20s %-44s cos %.6f norm err %.5f' % (tag, name, c, ne))
+        if c < worst[0]:
+            worst = (c, ne, name)
+        assert c >= min_cos and ne <= max_norm_err, (tag, name, c, ne)
+    return worst
+
+
+def _leaf_params(Pm):
+    leaves = {k: v.clone().requires_grad_(True) for k, v in Pm.items() if v.dtype.is_floating_point}
+    return leaves
+
+
+def _param_grads(mod, pre, leaves):
+    out = []
+    for n, p in mod.named_parameters():
+        if p.grad is None:
+            continue
+        leaf = leaves.get(pre + n)
+        if leaf is None or leaf.grad is None:
+            continue
+        out.append((n, p.grad, leaf.grad))
+    return out
+
+
+def _setup(rt):
+    import gpv1_amd.hip as hip
+    hip.lib()
+    rt.set_precise(False)
+    torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
+
+
+def test_detr_encoder_layer_at_bench_shape_vs_bf16_faithful_oracle(rt):
+    """9600 rows (B = 32 x 15 x 20 positions) x 256, 8 heads of 32, key-padding mask on the last two images"""
+    from gpv1_amd.transformer import TransformerEncoderLayer
+    from oracle import gpv_oracle as O
+    _setup(rt)
+    S, C = 300, 256
+    g = torch.Generator().manual_seed(11)
+    layer = TransformerEncoderLayer(C, 8, 2048, dropout=0.0)
+    _randomise(layer, g)
+    layer.to(DEV).train()
+    rt.bump_weights()
+    x = torch.randn(B, S, C, generator=g).to(torch.bfloat16)
+    pos = torch.randn(B, S, C, generator=g).to(torch.bfloat16)
+    kpm = torch.zeros(B, S, dtype=torch.bool)
+    kpm[-1, 250:] = True
+    kpm[-2, 100:] = True
+    dy = (0.1 * torch.randn(B, S, C, generator=g)).to(torch.bfloat16)
+    xh = x.to(DEV).reshape(B * S, C).requires_grad_(True)
+    out = layer(xh, pos.to(DEV).reshape(B * S, C), B, S, kpm.to(torch.uint8).to(DEV).contiguous())
+    out.backward(dy.to(DEV).reshape(B * S, C))
+    torch.cuda.synchronize()
+    Pm = _state(layer, 'L.')
+    leaves = _leaf_params(Pm)
+    xr = x.float().requires_grad_(True)
+    prev = O.set_bf16_faithful(True)
+    try:
+        ref = O.detr_encoder_layer(leaves, 'L.', xr, pos.float(), kpm, 8)
+        ref.backward(dy.float())
+    finally:
+        O.set_bf16_faithful(prev)
+    _check_fwd('detr encoder layer', out.reshape(B, S, C), ref, 4.0, 2e-3)
+    _check_grads('detr encoder', [('input', xh.grad.reshape(B, S, C), xr.grad)] + _param_grads(layer, 'L.', leaves), 0.9995, 0.01)
+
+
+def test_detr_decoder_layer_at_bench_shape_vs_bf16_faithful_oracle(rt):
+    """3200 query rows (B = 32 x 100) against 9600 memory rows, self- and cross-attention (key-padding mask), FFN"""
+    from gpv1_amd.transformer import TransformerDecoderLayer
+    from gpv1_amd import ops
+    from oracle import gpv_oracle as O
+    _setup(rt)
+    S, Q, C = 300, 100, 256
+    g = torch.Generator().manual_seed(12)
+    layer = TransformerDecoderLayer(C, 8, 2048, dropout=0.0)
+    _randomise(layer, g)
+    layer.to(DEV).train()
+    rt.bump_weights()
+    tgt = torch.randn(B, Q, C, generator=g).to(torch.bfloat16)
+    mem = torch.randn(B, S, C, generator=g).to(torch.bfloat16)
+    pos = torch.randn(B, S, C, generator=g).to(torch.bfloat16)
+    qpos = torch.randn(Q, C, generator=g).to(torch.bfloat16)
+    kpm = torch.zeros(B, S, dtype=torch.bool)
+    kpm[0, 200:] = True
+    dy = (0.1 * torch.randn(B, Q, C, generator=g)).to(torch.bfloat16)
+    th = tgt.to(DEV).reshape(B * Q, C).requires_grad_(True)
+    mh = mem.to(DEV).reshape(B * S, C).requires_grad_(True)
+    ph = pos.to(DEV).reshape(B * S, C)
+    qh = qpos.to(DEV).unsqueeze(0).expand(B, Q, C).reshape(B * Q, C)
+    mem_chain = ops.grad_chain(mh)
+    mem_pos = ops.add(mh, ph)
+    out = layer(th, mh, mem_pos, qh, B, Q, S, kpm.to(torch.uint8).to(DEV).contiguous(), mem_chain)
+    out.backward(dy.to(DEV).reshape(B * Q, C))
+    ops.check_chains()
+    torch.cuda.synchronize()
+    Pm = _state(layer, 'L.')
+    leaves = _leaf_params(Pm)
+    tr_, mr = tgt.float().requires_grad_(True), mem.float().requires_grad_(True)
+    prev = O.set_bf16_faithful(True)
+    try:
+        ref = O.detr_decoder_layer(leaves, 'L.', tr_, mr, pos.float(), qpos.float()[None].expand(B, -1, -1), kpm, 8)
+        ref.backward(dy.float())
+    finally:
+        O.set_bf16_faithful(prev)
+    _check_fwd('detr decoder layer', out.reshape(B, Q, C), ref, 4.0, 2e-3)
+    _check_grads('detr decoder', [('tgt', th.grad.reshape(B, Q, C), tr_.grad), ('memory', mh.grad.reshape(B, S, C), mr.grad)]
+                 + _param_grads(layer, 'L.', leaves), 0.9995, 0.01)
+
+
+def test_co_attention_layer_at_bench_shape_vs_bf16_faithful_oracle(rt):
+    """language stream 32 x 6 tokens, vision stream 32 x 100 boxes, 768 wide, 16 heads of 48, erf-GELU feed-forward of 3072"""
+    from gpv1_amd.vilbert import BertConnectionLayer
+    from gpv1_amd.misc import AttrDict
+    from gpv1_amd import ops
+    from oracle import gpv_oracle as O
+    _setup(rt)
+    T1, T2, D = 6, 100, 768
+    g = torch.Generator().manual_seed(13)
+    cfg = AttrDict.wrap(dict(synth.model_cfg(vocab=synth.make_vocab(16))['co_att'], attention_probs_dropout_prob=0.0, hidden_dropout_prob=0.0,
+                             v_attention_probs_dropout_prob=0.0, v_hidden_dropout_prob=0.0))
+    layer = BertConnectionLayer(cfg)
+    _randomise(layer, g)
+    layer.to(DEV).train()
+    rt.bump_weights()
+    t1 = torch.randn(B, T1, D, generator=g).to(torch.bfloat16)
+    t2 = torch.randn(B, T2, D, generator=g).to(torch.bfloat16)
+    d1 = (0.1 * torch.randn(B, T1, D, generator=g)).to(torch.bfloat16)
+    d2 = (0.1 * torch.randn(B, T2, D, generator=g)).to(torch.bfloat16)
+    h1 = t1.to(DEV).reshape(B * T1, D).requires_grad_(True)
+    h2 = t2.to(DEV).reshape(B * T2, D).requires_grad_(True)
+    o1, o2 = layer(h1, h2, B, T1, T2)
+    torch.autograd.backward([o1, o2], [d1.to(DEV).reshape(B * T1, D), d2.to(DEV).reshape(B * T2, D)])
+    ops.check_chains()
+    torch.cuda.synchronize()
+    Pm = _state(layer, 'L.')
+    leaves = _leaf_params(Pm)
+    r1, r2 = t1.float().requires_grad_(True), t2.float().requires_grad_(True)
+    prev = O.set_bf16_faithful(True)
+    try:
+        q1, q2 = O.co_attention_layer(leaves, 'L.', r1, r2, cfg.bi_num_attention_heads)
+        torch.autograd.backward([q1, q2], [d1.float(), d2.float()])
+    finally:
+        O.set_bf16_faithful(prev)
+    _check_fwd('co-attention language out', o1.reshape(B, T1, D), q1, 4.0, 2e-3)
+    _check_fwd('co-attention vision out', o2.reshape(B, T2, D), q2, 4.0, 2e-3)
+    _check_grads('co-attention', [('language in', h1.grad.reshape(B, T1, D), r1.grad), ('vision in', h2.grad.reshape(B, T2, D), r2.grad)]
+                 + _param_grads(layer, 'L.', leaves), 0.9995, 0.01)
+
+
+def test_text_decoder_layer_at_bench_shape_vs_bf16_faithful_oracle(rt):
+    """640 answer rows (B = 32 x 20 tokens, causal) over a memory of 106 rows per sample (100 boxes + 6 query tokens), 768 wide, 8
+    heads of 96, ReLU feed-forward of 2048"""
+    from gpv1_amd.gpv import TextDecoderLayer
+    from gpv1_amd import ops
+    from oracle import gpv_oracle as O
+    _setup(rt)
+    Tt, Tm, D = 20, 106, 768
+    g = torch.Generator().manual_seed(14)
+    layer = TextDecoderLayer(D, 8, 0.0)
+    _randomise(layer, g)
+    layer.to(DEV).train()
+    rt.bump_weights()
+    tgt = torch.randn(B, Tt, D, generator=g).to(torch.bfloat16)
+    mem = torch.randn(B, Tm, D, generator=g).to(torch.bfloat16)
+    dy = (0.1 * torch.randn(B, Tt, D, generator=g)).to(torch.bfloat16)
+    th = tgt.to(DEV).reshape(B * Tt, D).requires_grad_(True)
+    mh = mem.to(DEV).reshape(B * Tm, D).requires_grad_(True)
+    mem_chain = ops.grad_chain(mh)
+    out = layer(th, mh, B, Tt, Tm, mem_chain)
+    out.backward(dy.to(DEV).reshape(B * Tt, D))
+    ops.check_chains()
+    torch.cuda.synchronize()
+    Pm = _state(layer, 'L.')
+    leaves = _leaf_params(Pm)
+    tr_, mr = tgt.float().requires_grad_(True), mem.float().requires_grad_(True)
+    prev = O.set_bf16_faithful(True)
+    try:
+        ref = O.text_decoder_layer(leaves, 'L.', tr_, mr, 8)
+        ref.backward(dy.float())
+    finally:
+        O.set_bf16_faithful(prev)
+    _check_fwd('text decoder layer', out.reshape(B, Tt, D), ref, 4.0, 2e-3)
+    _check_grads('text decoder', [('tgt', th.grad.reshape(B, Tt, D), tr_.grad), ('memory', mh.grad.reshape(B, Tm, D), mr.grad)]
+                 + _param_grads(layer, 'L.', leaves), 0.9995, 0.01)

@@ -175,7 +175,7 @@ def test_full_size_properties(rt):
         targets[1] = {'task': 'CocoDetection', 'boxes': torch.tensor([[0.5, 0.5, 0.2, 0.3], [0.3, 0.6, 0.1, 0.1]], device=DEV),
                       'labels': torch.zeros(2, dtype=torch.long, device=DEV)}
         loss = tr.train_step(nested(images, mask), (ids, attn), targets)
-        assert tr.milestones == 1 and tr.late_touch is None, tr.late_touch
+        assert [m for m, _ in tr.milestone_log] == ['backbone', 'layer4', 'layer3', 'layer2'] and tr.late_touch is None, (tr.milestone_log, tr.late_touch)
         assert torch.isfinite(loss)
         assert torch.isfinite(tr.G).all()
         losses.append(float(loss))
@@ -326,7 +326,7 @@ def _run_config_steps(model, det_only, Bf, Vf):
         losses = []
         for it in range(4):
             loss = tr.train_step(nested(images, mask), (ids, attn), [dict(t) for t in tg])
-            assert tr.milestones == 1 and tr.late_touch is None, tr.late_touch
+            assert [m for m, _ in tr.milestone_log] == ['backbone', 'layer4', 'layer3', 'layer2'] and tr.late_touch is None, (tr.milestone_log, tr.late_touch)
             assert torch.isfinite(loss) and torch.isfinite(tr.G).all()
             losses.append(float(loss.detach()))
             ind = model.criterion.localization_criterion.set_criterion.last_indices
