@@ -41,7 +41,10 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* p) {
   return __builtin_bit_cast(bf16x8, r);
 }
 
-template <bool CONV>
+// ABL: timing-only ablations of the k-loop (results are wrong): 1 = no MFMAs, 2 = no fragment reads and no MFMAs (loads + barriers
+// only), 3 = no global loads (fragment reads + MFMAs on whatever the LDS holds), 4 = as 2 but every iteration loads the FIRST k-tile
+// (the loop's rate when every line hits the L2) -- tools/bench_wgrad_ablate.py
+template <bool CONV, int ABL = 0>
 __device__ __forceinline__ void glds_tt_core(const GemmK& p, int tile, int ksplit) {
   extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -159,13 +162,14 @@ __device__ __forceinline__ void glds_tt_core(const GemmK& p, int tile, int kspli
 #pragma unroll
   for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
 
-  issue(kt0, 0);
+  if (ABL != 3) issue(kt0, 0);
   for (int kt = kt0; kt < kt1; ++kt) {
     const int t = kt - kt0;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (kt + 1 < kt1) issue(kt + 1, (t + 1) & 1);
+    if (ABL != 3 && kt + 1 < kt1) issue(ABL == 4 ? kt0 : kt + 1, (t + 1) & 1);
     const unsigned char* st = smem + (t & 1) * TSTAGE;
+    if (ABL == 2 || ABL == 4) continue;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       bf16x8 af[4], bfr[4];
@@ -173,6 +177,11 @@ __device__ __forceinline__ void glds_tt_core(const GemmK& p, int tile, int kspli
       for (int j = 0; j < 4; ++j) bfr[j] = tr_frag(st + b_sl[j] + kk * 32 * ROWBYTES);
 #pragma unroll
       for (int i = 0; i < 4; ++i) af[i] = tr_frag(st + a_sl[i] + kk * 32 * ROWBYTES);
+      if (ABL == 1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(af[i]), "v"(bfr[i]));
+        continue;
+      }
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -287,7 +296,8 @@ constexpr int WG_MAX = 28;
 struct WgGroupK { int n; int pad; float* ws; WgProb prob[WG_MAX]; };
 static_assert(sizeof(WgGroupK) <= 4096, "kernel argument segment");
 
-__global__ __launch_bounds__(256) void glds_wgrad_group_kernel(WgGroupK g) {
+template <int ABL>
+__device__ __forceinline__ void wgrad_group_body(const WgGroupK& g) {
   const int nwg = gridDim.x, bid = blockIdx.x;
   const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7, loc = bid >> 3;
   const int v = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;     // contiguous unit range per XCD
@@ -304,8 +314,13 @@ __global__ __launch_bounds__(256) void glds_wgrad_group_kernel(WgGroupK g) {
   p.cg.KH = q.KH; p.cg.KW = q.KW; p.cg.SH = q.SH; p.cg.SW = q.SW; p.cg.PH = q.PH; p.cg.PW = q.PW;
   const int u = v - q.unit_start;
   const int ksplit = u / q.tiles;
-  glds_tt_core<true>(p, u - ksplit * q.tiles, ksplit);
+  glds_tt_core<true, ABL>(p, u - ksplit * q.tiles, ksplit);
 }
+__global__ __launch_bounds__(256) void glds_wgrad_group_kernel(WgGroupK g) { wgrad_group_body<0>(g); }
+__global__ __launch_bounds__(256) void glds_wgrad_group_abl1_kernel(WgGroupK g) { wgrad_group_body<1>(g); }
+__global__ __launch_bounds__(256) void glds_wgrad_group_abl2_kernel(WgGroupK g) { wgrad_group_body<2>(g); }
+__global__ __launch_bounds__(256) void glds_wgrad_group_abl3_kernel(WgGroupK g) { wgrad_group_body<3>(g); }
+__global__ __launch_bounds__(256) void glds_wgrad_group_abl4_kernel(WgGroupK g) { wgrad_group_body<4>(g); }
 
 struct WgRed { const float* ws; float* C; int64_t MN; int split, N, ldc, blk_start; };
 struct WgRedK { int n; int pad; WgRed r[WG_MAX]; };
@@ -441,8 +456,13 @@ extern "C" int gpv_conv_wgrad_group(const gpv_conv_wgrad_problem* probs, int n, 
   static const int target_kt = [] { const char* e = getenv("GPV_WGRAD_GROUP_KT"); const int v = e ? atoi(e) : 150; return v < 8 ? 8 : v; }();
   static bool attr_done = false;
   constexpr int lds = 2 * TSTAGE;
+  // GPV_WG_ABL=1|2|3 (timing experiments only, wrong results): see glds_tt_core
+  static const int abl = [] { const char* e = getenv("GPV_WG_ABL"); return e ? atoi(e) : 0; }();
+  typedef void (*wg_fn)(WgGroupK);
+  const wg_fn fn = abl == 1 ? glds_wgrad_group_abl1_kernel : abl == 2 ? glds_wgrad_group_abl2_kernel : abl == 3 ? glds_wgrad_group_abl3_kernel : abl == 4 ? glds_wgrad_group_abl4_kernel
+                                                                                                        : glds_wgrad_group_kernel;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(glds_wgrad_group_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) { (void)hipGetLastError(); return (int)e; }      // (leave no stale error behind for the next launch check)
     attr_done = true;
   }
@@ -454,7 +474,7 @@ extern "C" int gpv_conv_wgrad_group(const gpv_conv_wgrad_problem* probs, int n, 
   auto flush = [&]() -> int {
     if (g.n == 0) return 0;
     g.ws = reinterpret_cast<float*>(workspace);
-    hipLaunchKernelGGL(glds_wgrad_group_kernel, dim3(units), dim3(256), lds, st, g);
+    hipLaunchKernelGGL(fn, dim3(units), dim3(256), lds, st, g);
     GPV_CHECK_LAUNCH();
     if (rk.n > 0) {
       hipLaunchKernelGGL(wgrad_group_reduce_kernel, dim3(rblocks), dim3(256), 0, st, rk);

@@ -627,6 +627,49 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x,
   if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
 }
 
+// ---- gradient-norm clip factor, deterministic (train_distr.py:423-425: clip_grad_norm_(detr params, 0.1)) ----------------------
+// Every rank must derive the SAME bits from the same all-reduced gradient, or the replicas drift apart one ulp of the clip factor per
+// step -- so no atomics (sumsq_kernel's float atomics arrive in a different order every run): pass 1 = CLIP_BLOCKS blocks, block b
+// sums x^2 over ITS contiguous chunk in a fixed order (thread-strided partial sums, shuffle tree, the four waves in order) ->
+// partial[b]; pass 2 = one block sums the partials in a fixed order (double), writes gscale = min(1, max_norm / (norm + 1e-6)) and,
+// riding along, adds the per-parameter liveness flags into the per-parameter Adam step counts (pstep += live).
+constexpr int CLIP_BLOCKS = 1024;
+__global__ __launch_bounds__(256) void clip_partial_kernel(const float* __restrict__ x, int64_t nquads, float* __restrict__ partial) {
+  __shared__ float red[4];
+  const int64_t per = (nquads + CLIP_BLOCKS - 1) / CLIP_BLOCKS;
+  const int64_t q0 = (int64_t)blockIdx.x * per, q1 = q0 + per < nquads ? q0 + per : nquads;
+  float s = 0.f;
+  for (int64_t q = q0 + threadIdx.x; q < q1; q += 256) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + q * 4);
+    s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+}
+__global__ __launch_bounds__(256) void clip_final_kernel(const float* __restrict__ partial, float max_norm, float* __restrict__ gscale,
+                                                         int32_t* __restrict__ pstep, const int32_t* __restrict__ live, int nparam) {
+  __shared__ double red[256];
+  if (partial) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < CLIP_BLOCKS; i += 256) s += (double)partial[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+      const float norm = (float)sqrt(red[0]);
+      const float c = max_norm / (norm + 1e-6f);
+      *gscale = c < 1.f ? c : 1.f;
+    }
+  }
+  if (pstep)
+    for (int i = threadIdx.x; i < nparam; i += 256) pstep[i] += live[i];
+}
+
 #define ST(s) reinterpret_cast<hipStream_t>(s)
 }  // namespace
 
@@ -850,6 +893,19 @@ extern "C" int gpv_adamw(float* p, const float* g, float* m, float* v, void* p_l
     return 0;
   }
   hipLaunchKernelGGL(adamw_kernel, dim3(grid1d(n, 256)), dim3(256), 0, ST(stream), p, g, m, v, (bf16*)p_lowp, n, lr, beta1, beta2, eps, wd, bc1, bc2, gscale, seg_id, seg_live);
+  GPV_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int gpv_clip_scale(const float* g, int64_t n, float max_norm, float* partial, float* gscale, int32_t* pstep,
+                              const int32_t* live, int nparam, void* stream) {
+  if (g && (n % 4 != 0 || (reinterpret_cast<uintptr_t>(g) & 15) != 0 || !partial || !gscale)) return (int)hipErrorInvalidValue;
+  if ((pstep == nullptr) != (live == nullptr) || (!g && !pstep)) return (int)hipErrorInvalidValue;
+  if (g) {
+    hipLaunchKernelGGL(clip_partial_kernel, dim3(CLIP_BLOCKS), dim3(256), 0, ST(stream), g, n / 4, partial);
+    GPV_CHECK_LAUNCH();
+  }
+  hipLaunchKernelGGL(clip_final_kernel, dim3(1), dim3(256), 0, ST(stream), g ? partial : nullptr, max_norm, gscale, pstep, live, nparam);
   GPV_CHECK_LAUNCH();
   return 0;
 }

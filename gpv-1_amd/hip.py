@@ -100,7 +100,7 @@ EXPORTS = ['gpv_abi_version', 'gpv_build_id', 'gpv_set_option', 'gpv_gemm', 'gpv
            'gpv_attention_fwd', 'gpv_attention_bwd', 'gpv_layernorm_fwd', 'gpv_layernorm_bwd',
            'gpv_softmax_ce', 'gpv_roi_weights', 'gpv_add', 'gpv_add_rowbcast', 'gpv_colsum', 'gpv_cast',
            'gpv_cast_rowscale_t', 'gpv_prep_conv_weight', 'gpv_embedding', 'gpv_dropout',
-           'gpv_relevance_condition', 'gpv_adamw', 'gpv_sumsq', 'gpv_act_fwd', 'gpv_act_bwd', 'gpv_set_seed_device',
+           'gpv_relevance_condition', 'gpv_adamw', 'gpv_sumsq', 'gpv_clip_scale', 'gpv_act_fwd', 'gpv_act_bwd', 'gpv_set_seed_device',
            'gpv_gemm_tt_group', 'gpv_cast_transpose_group', 'gpv_stem_pool', 'gpv_image_pipeline', 'gpv_conv1x1_dual',
            'gpv_conv_wgrad_group', 'gpv_jpeg_parse', 'gpv_jpeg_decode', 'gpv_argmax_rows', 'gpv_ln_linear_rows', 'gpv_attention_row_proj']
 
@@ -467,6 +467,22 @@ def adamw(p, g, m, v, p_lowp, n, lr, beta1, beta2, eps, wd, bc1, bc2, gscale=Non
     _chk(lib().gpv_adamw(_p(p), _p(g), _p(m), _p(v), _p(p_lowp), C.c_int64(n), C.c_float(lr), C.c_float(beta1),
                          C.c_float(beta2), C.c_float(eps), C.c_float(wd), C.c_float(bc1), C.c_float(bc2),
                          _p(gscale), _p(seg_id), _p(seg_live), _stream()), 'gpv_adamw')
+
+
+CLIP_PARTIALS = 1024
+
+
+def clip_scale(g, max_norm, partial, gscale, pstep=None, live=None):
+    """gpv_clip_scale: gscale = min(1, max_norm / (||g|| + 1e-6)) over the contiguous fp32 range g (None: no norm), deterministic;
+    pstep += live (int32 per-parameter Adam step counts) in the same launch"""
+    n = 0 if g is None else g.numel()
+    if g is not None and (not g.is_contiguous() or partial.numel() < CLIP_PARTIALS):
+        raise ValueError('clip_scale: contiguous gradient range and >= CLIP_PARTIALS floats of scratch')
+    for t in (pstep, live):
+        if t is not None and t.dtype != torch.int32:
+            raise TypeError('clip_scale: int32 step counts / liveness flags')
+    _chk(lib().gpv_clip_scale(_p(_f32(g)), C.c_int64(n), C.c_float(max_norm), _p(_f32(partial)), _p(_f32(gscale)), _p(pstep), _p(live),
+                              C.c_int(0 if pstep is None else pstep.numel()), _stream()), 'gpv_clip_scale')
 
 
 def sumsq(x, n, out):

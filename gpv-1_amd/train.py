@@ -115,6 +115,7 @@ class GraphedBody:
         self.bert_mode = int(os.environ.get('GPV_BERT_BRANCH', '2'))      # 2: branch of F2 beside the DETR transformer (F1 3.88 -> 3.71 ms, F2 3.68 -> 3.81), 1: branch of F1, 0: in line
         self.side = torch.cuda.Stream(device=dev) if self.bert_mode else None
         self.wside = torch.cuda.Stream(device=dev)
+        self.zero_in_graph = os.environ.get('GPV_ZERO_IN_GRAPH', '1') != '0'
         # the gradient chains of THIS recorded forward belong to the body: an eager step's check_chains(clear=True) must not
         # drop them from under the backward variants captured later (ops.GradChain._live is the eager steps' list)
         from . import ops as _ops
@@ -189,6 +190,11 @@ class GraphedBody:
         self.wside.wait_stream(cur)
         with torch.cuda.stream(self.wside):
             ops.refresh_transposed()
+            if self.zero_in_graph:
+                # the flat gradient buffer is cleared here, on the branch beside the transformer's latency-bound chain (444 MB of
+                # streaming stores), instead of between the criterion and B1 on the critical path: nobody reads G between the
+                # previous step's AdamW and this step's first weight-gradient kernel (B1)
+                self.tr.G.zero_()
         self.c5 = c5
         self.c5_leaf = c5.detach().requires_grad_(bool(train))
         self.body = body
@@ -217,8 +223,9 @@ class GraphedBody:
     def stale(self):
         return self.epochs != (RT.static_epoch, RT.dtype)
 
-    def forward(self, images, queries, tok, lang_extra=None):
-        """replay F1 + F2 on the current stream; returns the outputs dict as fresh autograd leaves"""
+    def forward(self, images, queries, tok, lang_extra=None, leaves=True):
+        """replay F1 + F2 on the current stream; returns the outputs dict as fresh autograd leaves (leaves=False: nothing -- the
+        criterion runs inside the backward graph, backward_fused)"""
         from . import backbone as bbm
         self.s_img.copy_(images.tensors, non_blocking=True)
         self.s_mask.copy_(images.mask, non_blocking=True)
@@ -236,6 +243,8 @@ class GraphedBody:
         self.f2.replay()
         if ev is not None:
             ev.record()
+        if not leaves:
+            return None
         leaves = {}
         for k, v in self.outs.items():
             if torch.is_tensor(v):
@@ -260,7 +269,6 @@ class GraphedBody:
 
     def backward(self, leaves):
         """d(outputs) = the .grad of the leaves forward() returned -> replay B1 (+ the trainer's milestone) + B2"""
-        from . import backbone as bbm
         tr = self.tr
         pairs = self._roots(leaves)
         if not pairs:
@@ -271,6 +279,11 @@ class GraphedBody:
             var = self.variants[vkey] = self._capture_backward(pairs)
         for (k, _, g), sg in zip(pairs, var['grads']):
             sg.copy_(g, non_blocking=True)
+        self._replay_backward(var)
+
+    def _replay_backward(self, var):
+        from . import backbone as bbm
+        tr = self.tr
         tr.touched |= var['touched']
         ev = bbm._prof('graph_b1')
         var['b1'].replay()
@@ -286,6 +299,35 @@ class GraphedBody:
         if ev is not None:
             ev.record()
 
+    # ---- criterion inside the graph: batches whose every sample carries the SAME text task and no boxes (caption-only = BASELINE
+    # configs[1], VQA-only, classification-only).  Their criterion is one cross-entropy kernel plus a handful of tiny reductions,
+    # all on the device; eager, those ~10 launches and the copies of d(outputs) into B1's static inputs sit between F2 and B1 with
+    # host-paced gaps (0.47 ms wall for 0.13 ms of kernels, profiles/r03_step_phases.txt).  Here criterion forward, its backward
+    # and B1 are ONE graph whose only input is the CE target ids.  Batches with boxes keep the eager criterion (Hungarian matching
+    # on the host, north_star).
+    @staticmethod
+    def fused_task(criterion, targets):
+        """the single text task of a batch the fused variant serves, or None"""
+        if os.environ.get('GPV_FUSED_CRITERION', '1') == '0' or not targets:
+            return None
+        task = targets[0].get('task')
+        for t in targets:
+            if t.get('task') != task or 'answer' not in t or 'boxes' in t or 'answer_token_ids' not in t:
+                return None
+        names = [n for n in criterion.criterion_names if getattr(getattr(criterion, n), 'task', '-') == task]
+        return task if len(names) == 1 else None
+
+    def backward_fused(self, task, ce_targets):
+        """ce_targets: [B, S_c - 1] int64 device tensor (the rows the targets' 'answer_token_ids' are views of) -> the loss"""
+        tr = self.tr
+        vkey = ('fused', task, bool(tr.defer_wgrad))
+        var = self.variants.get(vkey)
+        if var is None:
+            var = self.variants[vkey] = self._capture_backward([], fused=(task, ce_targets))
+        var['s_ce'].copy_(ce_targets, non_blocking=True)
+        self._replay_backward(var)
+        return var['loss']
+
     @staticmethod
     def _flush(deferred):
         """launch the collected weight gradients: every problem the grouped kernel takes (128-multiples, bf16) in
@@ -299,11 +341,16 @@ class GraphedBody:
             if prob is None or not group:
                 fn()
 
-    def _capture_backward(self, pairs):
+    def _capture_backward(self, pairs, fused=None):
         tr = self.tr
         torch.cuda.synchronize()
         gc.collect()
         grads = [torch.zeros_like(g) for _, _, g in pairs]
+        s_ce, s_targets, loss_static = None, None, None
+        if fused is not None:
+            task, ce = fused
+            s_ce = ce.clone()
+            s_targets = [{'task': task, 'answer': '', 'answer_token_ids': s_ce[i]} for i in range(s_ce.shape[0])]
         b1, b2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         b2_list = []
         saved = tr.touched.clone()
@@ -341,7 +388,15 @@ class GraphedBody:
             self._open = b1
             RT.defer_list = deferred if defer else None
             RT.backward_boundary = at_boundary if os.environ.get('GPV_WGRAD_SPLIT', '1') != '0' else None
-            torch.autograd.backward([o for _, o, _ in pairs], grads, retain_graph=True)
+            if fused is None:
+                torch.autograd.backward([o for _, o, _ in pairs], grads, retain_graph=True)
+            else:
+                loss = tr.model.criterion(self.outs, s_targets)[0]
+                if loss is None:
+                    raise RuntimeError('GraphedBody: the fused criterion found no applicable loss for task %r' % (fused[0],))
+                loss_static = loss.detach()
+                torch.autograd.backward([loss], retain_graph=True)
+                del loss
             from . import ops as _ops
             _ops.check_chains(clear=False, chains=self.chains)     # (the recorded forward -- and its chains -- serve further backward variants)
             RT.defer_list = None
@@ -378,6 +433,8 @@ class GraphedBody:
                     def stage_done(li):
                         if li == last_li:
                             return
+                        if deferred and len(b2_list) == 0:          # (single rank + cut: the DETR weight-gradient branch forked at the
+                            torch.cuda.current_stream(dev).wait_stream(self.wside)      # top of B2 joins before the first cut)
                         cur[0].capture_end()
                         b2_list.append((cur[0], 'layer%d' % li))
                         g = torch.cuda.CUDAGraph()
@@ -399,7 +456,7 @@ class GraphedBody:
             RT.defer_list = None
             RT.backward_boundary = None
         RT.backward_milestone = milestone
-        var = {'b1': b1, 'b2': b2_list, 'grads': grads, 'touched': tr.touched.clone(), 'dc5': dc5, 'deferred': deferred + side_a}
+        var = {'b1': b1, 'b2': b2_list, 'grads': grads, 's_ce': s_ce, 'loss': loss_static, 'touched': tr.touched.clone(), 'dc5': dc5, 'deferred': deferred + side_a}
         tr.touched |= saved
         return var
 
@@ -475,8 +532,9 @@ class FlatTrainer:
             p._gpv_lp_static = -1                                                  # mirror not yet written (ops._lp casts on first use)
             p._gpv_touch = (lambda i=i: self._mark(i))                            # kernel-accumulated gradients
             p.register_hook(lambda grad, i=i: self._mark(i))                       # autograd-delivered gradients
-        self.gsq = torch.zeros(1, device=dev, dtype=torch.float32)
         self.gscale = torch.ones(1, device=dev, dtype=torch.float32)
+        self._clip_ws = torch.zeros(hip.CLIP_PARTIALS, device=dev, dtype=torch.float32)
+        self._published = None                   # the host 'touched' marks as last sent to the device
         b = bucket_mb * 1024 * 1024 // 4
         self.backbone_end = max([o + (k + 7) // 8 * 8 for (n, p, g, o, k) in self.entries if g == 'detr_backbone'], default=0)
         # flat ranges of the backbone's stages (module order = flat order: layer2 | layer3 | layer4): each is a milestone of the
@@ -617,8 +675,11 @@ class FlatTrainer:
     def _publish_touched(self):
         """host-side 'touched' marks of this step -> device flags (idempotent; pinned staging, asynchronous)"""
         from .misc import STAGER
+        if self._published is not None and torch.equal(self._published, self.touched) and self.world == 1:
+            return                               # (steady state: the same parameters every step -- nothing new to tell the device)
         loc = STAGER.to_device(self.touched.to(torch.int32), torch.int32, self.live.device)
         torch.maximum(self.live, loc, out=self.live)
+        self._published = self.touched.clone()
 
     def live_host(self):
         return self.live.cpu().bool()
@@ -645,26 +706,24 @@ class FlatTrainer:
         self._publish_touched()
         if hp is not None:
             t1 = time.perf_counter(); hp['opt_publish'] = hp.get('opt_publish', 0.0) + t1 - t0; t0 = t1
-        if use_clip:
-            # ||g||^2 over the DETR groups (untouched gradients are zero: whole groups).  Every rank must get the SAME bits
-            # from the same all-reduced gradient, or the replicas drift apart one ulp of the clip factor per step:
-            # torch's norm is a fixed-order tree reduction; gpv_sumsq accumulates its blocks with float atomics, whose
-            # order differs from run to run (found by tests/test_distributed_gpu.py).
-            self.gsq.zero_()
-            for g in ('detr_backbone', 'detr_head'):
-                if g in self.group_range:
-                    s, e = self.group_range[g]
-                    n = torch.linalg.vector_norm(self.G[s:e])
-                    self.gsq.addcmul_(n, n)
-            # scale = min(1, max_norm / (norm + 1e-6)) on device, no host sync
-            torch.clamp(self.clip / (self.gsq.sqrt() + 1e-6), max=1.0, out=self.gscale)
+        # clip factor over the DETR groups (backbone | head: adjacent in the flat buffer; untouched gradients are zero) and the
+        # per-parameter Adam step counts, two launches (gpv_clip_scale).  Every rank must get the SAME bits from the same
+        # all-reduced gradient, or the replicas drift apart one ulp of the clip factor per step: the kernel sums in a fixed
+        # order (gpv_sumsq's float atomics do not -- found by tests/test_distributed_gpu.py); no host sync.
+        rng = [self.group_range[g] for g in ('detr_backbone', 'detr_head') if g in self.group_range] if use_clip else []
+        if rng:
+            s0, e1 = min(r[0] for r in rng), max(r[1] for r in rng)
+            if sum(r[1] - r[0] for r in rng) != e1 - s0:
+                raise RuntimeError('FlatTrainer: the DETR groups are not contiguous in the flat buffer')
+            hip.clip_scale(self.G[s0:e1], self.clip, self._clip_ws, self.gscale, self.pstep, self.live)
+        else:
+            hip.clip_scale(None, 0.0, self._clip_ws, self.gscale, self.pstep, self.live)
         if hp is not None:
             t1 = time.perf_counter(); hp['opt_clip'] = hp.get('opt_clip', 0.0) + t1 - t0; t0 = t1
         self.step_count += 1
         t = self.step_count
         b1, b2 = self.betas
         bc1, bc2 = 1 - b1 ** t, 1 - b2 ** t                                   # (unused by the kernel when the per-parameter counts are given)
-        self.pstep.add_(self.live)
         for g, (s, e) in self.group_range.items():                           # one launch per group; the kernel skips dead parameters
             clip_here = use_clip and g in ('detr_backbone', 'detr_head')
             hip.adamw(self.P[s:e], self.G[s:e], self.M[s:e], self.V[s:e], self.Pb[s:e], e - s, self.lr[g] * sched, b1, b2,
@@ -819,7 +878,7 @@ class FlatTrainer:
             body = self._graphed_body(images, queries, answer_token_ids, lang_extra)
             if body is not None:
                 self.graph_steps += 1
-                return self._train_step_graphed(body, images, queries, answer_token_ids, targets, lang_extra, orig_queries)
+                return self._train_step_graphed(body, images, queries, answer_token_ids, targets, lang_extra, orig_queries, ce_targets)
         else:
             _, answer_token_ids = model.encode_answers(targets)
             for i, t in enumerate(targets):
@@ -944,29 +1003,34 @@ class FlatTrainer:
         RT.defer_list = None
         RT.backward_boundary = None
 
-    def _train_step_graphed(self, body, images, queries, tok, targets, lang_extra=None, orig_queries=None):
+    def _train_step_graphed(self, body, images, queries, tok, targets, lang_extra=None, orig_queries=None, ce_targets=None):
         hp = HOST_PROF
         t0 = time.perf_counter() if hp is not None else 0.0
+        fused = GraphedBody.fused_task(self.model.criterion, targets) if ce_targets is not None else None
         try:
-            outs = body.forward(images, queries, tok, lang_extra)
+            outs = body.forward(images, queries, tok, lang_extra, leaves=fused is None)
             if hp is not None:
                 t1 = time.perf_counter(); hp['replay_f1_f2'] = hp.get('replay_f1_f2', 0.0) + t1 - t0; t0 = t1
-            loss = self.model.criterion(outs, targets)[0]
+            loss = self.model.criterion(outs, targets)[0] if fused is None else True
         except RuntimeError as err:                       # nothing collective has been entered yet: redo the step eagerly
             self._graphs_failed(err)
             return self._train_step_impl(images, queries if orig_queries is None else orig_queries, targets)
         if not self._any_rank_has_loss(loss is not None):
             return None
-        self.zero_grad()
+        if not body.zero_in_graph:
+            self.zero_grad()
         self.begin_backward()
         if hp is not None:
             t1 = time.perf_counter(); hp['criterion_zero'] = hp.get('criterion_zero', 0.0) + t1 - t0; t0 = t1
         if loss is not None:
             try:
-                loss.backward()
-                if hp is not None:
-                    t1 = time.perf_counter(); hp['criterion_backward'] = hp.get('criterion_backward', 0.0) + t1 - t0; t0 = t1
-                body.backward(outs)
+                if fused is not None:
+                    loss = body.backward_fused(fused, ce_targets).clone()        # (the static scalar is rewritten by the next replay)
+                else:
+                    loss.backward()
+                    if hp is not None:
+                        t1 = time.perf_counter(); hp['criterion_backward'] = hp.get('criterion_backward', 0.0) + t1 - t0; t0 = t1
+                    body.backward(outs)
                 if hp is not None:
                     t1 = time.perf_counter(); hp['replay_b1_b2'] = hp.get('replay_b1_b2', 0.0) + t1 - t0; t0 = t1
             except RuntimeError as err:                   # the ranks already agreed to step: redo this rank's part eagerly

@@ -360,6 +360,15 @@ int gpv_adamw(float* p, const float* g, float* m, float* v, void* p_lowp, int64_
  * at its first gradient) and bc1 / bc2 are ignored.  The counts live on the device (agreed across ranks with a MAX
  * all-reduce of the "ever touched" flags), so picking the live parameters costs no host round trip. */
 int gpv_sumsq(const float* x, int64_t n, float* out /* += */, void* stream);
+/* Clip factor of torch.nn.utils.clip_grad_norm_(params, max_norm) (exp/gpv/train_distr.py:423-425, the DETR parameters at 0.1) over
+ * the contiguous fp32 gradient range g[0, n) (n a multiple of 4, 16-byte aligned):  *gscale = min(1, max_norm / (||g||_2 + 1e-6)).
+ * Deterministic -- fixed summation order, no atomics: every data-parallel rank derives the same bits from the same all-reduced
+ * gradient.  `partial`: >= GPV_CLIP_PARTIALS floats of scratch.  g == NULL: no norm (gscale untouched).
+ * pstep / live (both or neither, `nparam` entries): pstep[i] += live[i] in the same launch -- the per-parameter Adam step counts
+ * gpv_adamw reads (seg_live), advanced for the parameters that have ever received a gradient.  Two launches. */
+#define GPV_CLIP_PARTIALS 1024
+int gpv_clip_scale(const float* g, int64_t n, float max_norm, float* partial, float* gscale, int32_t* pstep, const int32_t* live,
+                   int nparam, void* stream);
 
 #ifdef __cplusplus
 }

@@ -302,6 +302,14 @@ def adamw(p, g, m, v, p_lowp, n, lr, beta1, beta2, eps, wd, bc1, bc2, gscale=Non
         p_lowp.copy_(p.to(p_lowp.dtype))
 
 
+def clip_scale(g, max_norm, partial, gscale, pstep=None, live=None):
+    if g is not None:
+        norm = g.double().pow(2).sum().sqrt().float()
+        gscale.copy_(torch.clamp(max_norm / (norm + 1e-6), max=1.0))
+    if pstep is not None:
+        pstep.add_(live)
+
+
 def sumsq(x, n, out):
     out += (x * x).sum()
 
@@ -358,7 +366,7 @@ def install(only=None):
     import gpv1_amd.hip as h
     names = only or ['gemm', 'conv2d', 'attention_fwd', 'attention_bwd', 'layernorm_fwd', 'layernorm_bwd', 'softmax_ce',
              'image_to_nhwc4', 'maxpool3x3s2', 'stem_pool', 'conv1x1_dual', 'conv_wgrad_group', 'roi_weights', 'add', 'add_rowbcast', 'colsum', 'cast', 'cast_rowscale_t',
-             'prep_conv_weight', 'embedding', 'dropout', 'relevance_condition', 'adamw', 'sumsq', 'act_fwd', 'act_bwd',
+             'prep_conv_weight', 'embedding', 'dropout', 'relevance_condition', 'adamw', 'sumsq', 'clip_scale', 'act_fwd', 'act_bwd',
              'cast_transpose_group', 'argmax_rows', 'ln_linear_rows', 'attention_row_proj']
     saved = {n: getattr(h, n) for n in names}
     for n in names:

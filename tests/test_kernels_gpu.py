@@ -1221,3 +1221,27 @@ def test_fused_block_tail_conv3_plus_downsample(K1, K2, N, s2, OH, OW, Bn):
     h.conv2d(0, a2, w3.view(N, 1, K1), y2, Bn, OH, OW, K1, K1, OH, OW, N, 1, 1, 1, 1, 0, 0, bias=b3, res=idt, act=h.ACT_RELU)
     assert rel(y, y2) < 1.2e-2
     assert not h.conv1x1_dual(a2[..., :32].contiguous(), w3[:, :32].contiguous(), x, wd, b3, y, Bn, OH, OW, 32, IH, IW, K2, s2, N, h.ACT_RELU)
+
+
+def test_clip_scale_is_deterministic_and_matches_torch():
+    """gpv_clip_scale: min(1, max_norm / (||g|| + 1e-6)) over a flat fp32 range (train_distr.py:423-425), fixed summation order:
+    bit-identical over repeated launches (what keeps data-parallel replicas identical), equal to torch's clip factor to fp32
+    rounding; the per-parameter step counts advance by the liveness flags in the same launch; g = None leaves gscale alone."""
+    h = hip()
+    torch.manual_seed(5)
+    for n, mx in ((4 * 1000 + 4, 0.1), (111_000_000 // 4 * 4, 0.1), (4096, 1e9)):
+        g = torch.randn(n, device=DEV) * 1e-3
+        ws = torch.zeros(h.CLIP_PARTIALS, device=DEV)
+        sc = torch.full((1,), -1.0, device=DEV)
+        pstep = torch.arange(700, device=DEV, dtype=torch.int32)
+        live = (torch.arange(700, device=DEV) % 3 == 0).to(torch.int32)
+        h.clip_scale(g, mx, ws, sc, pstep, live)
+        first = sc.clone()
+        want = torch.clamp(mx / (torch.linalg.vector_norm(g.double()) + 1e-6), max=1.0).float()
+        assert abs(float(first) - float(want)) <= 2e-6 * float(want), (n, float(first), float(want))
+        assert torch.equal(pstep, torch.arange(700, device=DEV, dtype=torch.int32) + live)
+        for _ in range(5):
+            h.clip_scale(g, mx, ws, sc)
+            assert torch.equal(sc, first)
+        h.clip_scale(None, 0.0, ws, sc, pstep, live)
+        assert torch.equal(sc, first) and torch.equal(pstep, torch.arange(700, device=DEV, dtype=torch.int32) + 2 * live)
