@@ -33,7 +33,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      T* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd,
                                                      int rows, int cols, float eps, uint32_t dthresh, float dscale,
-                                                     uint64_t seed, const uint64_t* seed_dev) {
+                                                     uint64_t seed, const uint64_t* seed_dev, const T* __restrict__ pos, int pos_rows,
+                                                     T* __restrict__ y2) {
+  // y2 (optional second output) = y + pos[row % pos_rows]: the `x + pos` / `tgt + query_pos` sums the DETR layers feed their q / k
+  // projections (transformer.py:150,216,221) leave the LayerNorm that produces x instead of being a launch of their own; computed
+  // from the ROUNDED y, so it is bit-identical to gpv_add on the stored output
   if (dthresh) seed = eff_seed(seed, seed_dev);
   constexpr int LW = HALF ? 32 : 64;                       // lanes per row
   const int lane = threadIdx.x & (LW - 1);
@@ -93,6 +97,13 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
         o[e] = gamma ? n * gm[e] + bt[e] : n;
       }
       Ld8<T>::st(yr + c, o);
+      if (y2) {
+        float pv[8];
+        Ld8<T>::ld(pos + (int64_t)(row % pos_rows) * cols + c, pv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pv[e] += (float)(T)o[e];
+        Ld8<T>::st(y2 + (int64_t)row * cols + c, pv);
+      }
     }
   }
 }
@@ -108,7 +119,8 @@ __global__ __launch_bounds__(NW * 64) void ln_bwd_kernel(const T* __restrict__ d
                                                      const float* __restrict__ rstd, T* __restrict__ dx, T* __restrict__ ds,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, int rows, int cols,
                                                      int rows_per_block, uint32_t dthresh, float dscale, uint64_t seed,
-                                                     const uint64_t* seed_dev) {
+                                                     const uint64_t* seed_dev, const T* __restrict__ dy2) {
+  // dy2 (optional): a second gradient of the same output (the consumer of the forward's y2 = y + pos), summed on load in fp32
   if (dthresh) seed = eff_seed(seed, seed_dev);
   extern __shared__ float lds[];   // [4 waves][2][cols]: every wave parks its partial dgamma | dbeta, no LDS atomics
   constexpr int LW = HALF ? 32 : 64, RPI = HALF ? 2 * NW : NW;      // lanes per row, rows per block iteration
@@ -135,6 +147,12 @@ __global__ __launch_bounds__(NW * 64) void ln_bwd_kernel(const T* __restrict__ d
         float xv[8], dv[8];
         Ld8<T>::ld(x + (int64_t)row * cols + c, xv);
         Ld8<T>::ld(dy + (int64_t)row * cols + c, dv);
+        if (dy2) {
+          float d2[8];
+          Ld8<T>::ld(dy2 + (int64_t)row * cols + c, d2);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) dv[e] += d2[e];
+        }
         if (dthresh) keep[i] = drop_mask<8>(seed, (uint64_t)row * cols + c, dthresh);
         if (s) {
           float t[8];
@@ -673,14 +691,16 @@ __global__ __launch_bounds__(256) void clip_final_kernel(const float* __restrict
 #define ST(s) reinterpret_cast<hipStream_t>(s)
 }  // namespace
 
-extern "C" int gpv_layernorm_fwd(const void* x, const void* s, const float* gamma, const float* beta, void* y, float* mean,
-                                 float* rstd, int rows, int cols, float eps, float drop_p, uint64_t seed, int dtype, void* stream) {
+extern "C" int gpv_layernorm_pos_fwd(const void* x, const void* s, const float* gamma, const float* beta, void* y, float* mean,
+                                     float* rstd, int rows, int cols, float eps, float drop_p, uint64_t seed, const void* pos,
+                                     int pos_rows, void* y2, int dtype, void* stream) {
   if (cols % 8 != 0 || cols > 4096 || rows <= 0) return (int)hipErrorInvalidValue;
+  if ((pos == nullptr) != (y2 == nullptr) || (pos && (pos_rows <= 0 || rows % pos_rows != 0))) return (int)hipErrorInvalidValue;
   const uint32_t th = drop_p > 0.f ? drop_thresh(drop_p) : 0u;
   const float sc = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
   const bool half = cols <= 256;                         // two rows per wave (see ln_fwd_kernel)
   dim3 grid(half ? (rows + 7) / 8 : (rows + 3) / 4), block(256);
-#define LN_F(T, NV, H) hipLaunchKernelGGL((ln_fwd_kernel<T, NV, H>), grid, block, 0, ST(stream), (const T*)x, (const T*)s, gamma, beta, (T*)y, mean, rstd, rows, cols, eps, th, sc, seed, gpvk::g_seed_dev)
+#define LN_F(T, NV, H) hipLaunchKernelGGL((ln_fwd_kernel<T, NV, H>), grid, block, 0, ST(stream), (const T*)x, (const T*)s, gamma, beta, (T*)y, mean, rstd, rows, cols, eps, th, sc, seed, gpvk::g_seed_dev, (const T*)pos, pos_rows, (T*)y2)
   const int nv = (cols + 511) / 512;
   if (dtype == GPV_BF16) { if (half) LN_F(bf16, 1, true); else if (nv <= 1) LN_F(bf16, 1, false); else if (nv <= 2) LN_F(bf16, 2, false); else if (nv <= 5) LN_F(bf16, 5, false); else LN_F(bf16, 8, false); }
   else { if (half) LN_F(float, 1, true); else if (nv <= 1) LN_F(float, 1, false); else if (nv <= 2) LN_F(float, 2, false); else if (nv <= 5) LN_F(float, 5, false); else LN_F(float, 8, false); }
@@ -689,10 +709,15 @@ extern "C" int gpv_layernorm_fwd(const void* x, const void* s, const float* gamm
   return 0;
 }
 
-extern "C" int gpv_layernorm_bwd(const void* dy, const void* x, const void* s, const float* gamma, const float* mean,
-                                 const float* rstd, void* dx, void* ds, float* dgamma, float* dbeta, int rows, int cols,
-                                 float drop_p, uint64_t seed, int dtype, void* stream) {
-  if (cols % 8 != 0 || cols > 4096 || rows <= 0) return (int)hipErrorInvalidValue;
+extern "C" int gpv_layernorm_fwd(const void* x, const void* s, const float* gamma, const float* beta, void* y, float* mean,
+                                 float* rstd, int rows, int cols, float eps, float drop_p, uint64_t seed, int dtype, void* stream) {
+  return gpv_layernorm_pos_fwd(x, s, gamma, beta, y, mean, rstd, rows, cols, eps, drop_p, seed, nullptr, 0, nullptr, dtype, stream);
+}
+
+extern "C" int gpv_layernorm_bwd2(const void* dy, const void* dy2, const void* x, const void* s, const float* gamma, const float* mean,
+                                  const float* rstd, void* dx, void* ds, float* dgamma, float* dbeta, int rows, int cols,
+                                  float drop_p, uint64_t seed, int dtype, void* stream) {
+  if (cols % 8 != 0 || cols > 4096 || rows <= 0 || !dy) return (int)hipErrorInvalidValue;
   const uint32_t th = drop_p > 0.f ? drop_thresh(drop_p) : 0u;
   const float sc = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
   const int nv = (cols + 511) / 512;
@@ -705,7 +730,7 @@ extern "C" int gpv_layernorm_bwd(const void* dy, const void* x, const void* s, c
   if (rpb < rpi) rpb = rpi;
   dim3 grid((rows + rpb - 1) / rpb), block(wide ? 1024 : 256);
   const size_t lds = dgamma ? 8 * (size_t)cols * sizeof(float) : 0;       // 4 waves x [dgamma | dbeta]; cols <= 4096 -> <= 128 KB
-#define LN_B(T, NV, H, NW) hipLaunchKernelGGL((ln_bwd_kernel<T, NV, H, NW>), grid, block, lds, ST(stream), (const T*)dy, (const T*)x, (const T*)s, gamma, mean, rstd, (T*)dx, (T*)ds, dgamma, dbeta, rows, cols, rpb, th, sc, seed, gpvk::g_seed_dev)
+#define LN_B(T, NV, H, NW) hipLaunchKernelGGL((ln_bwd_kernel<T, NV, H, NW>), grid, block, lds, ST(stream), (const T*)dy, (const T*)x, (const T*)s, gamma, mean, rstd, (T*)dx, (T*)ds, dgamma, dbeta, rows, cols, rpb, th, sc, seed, gpvk::g_seed_dev, (const T*)dy2)
 #define LN_BW(T, NV, H) do { if (wide) LN_B(T, NV, H, 16); else LN_B(T, NV, H, 4); } while (0)
   if (dtype == GPV_BF16) { if (half) LN_BW(bf16, 1, true); else if (nv <= 1) LN_BW(bf16, 1, false); else if (nv <= 2) LN_BW(bf16, 2, false); else if (nv <= 5) LN_B(bf16, 5, false, 4); else LN_B(bf16, 8, false, 4); }
   else { if (half) LN_BW(float, 1, true); else if (nv <= 1) LN_BW(float, 1, false); else if (nv <= 2) LN_BW(float, 2, false); else if (nv <= 5) LN_B(float, 5, false, 4); else LN_B(float, 8, false, 4); }
@@ -713,6 +738,12 @@ extern "C" int gpv_layernorm_bwd(const void* dy, const void* x, const void* s, c
 #undef LN_B
   GPV_CHECK_LAUNCH();
   return 0;
+}
+
+extern "C" int gpv_layernorm_bwd(const void* dy, const void* x, const void* s, const float* gamma, const float* mean,
+                                 const float* rstd, void* dx, void* ds, float* dgamma, float* dbeta, int rows, int cols,
+                                 float drop_p, uint64_t seed, int dtype, void* stream) {
+  return gpv_layernorm_bwd2(dy, nullptr, x, s, gamma, mean, rstd, dx, ds, dgamma, dbeta, rows, cols, drop_p, seed, dtype, stream);
 }
 
 extern "C" int gpv_softmax_ce(const void* logits, int64_t ld, const int64_t* target, float* loss, void* dlogits, const float* gscale,

@@ -97,7 +97,7 @@ def lib():
 
 
 EXPORTS = ['gpv_abi_version', 'gpv_build_id', 'gpv_set_option', 'gpv_gemm', 'gpv_conv2d', 'gpv_image_to_nhwc4', 'gpv_maxpool3x3s2',
-           'gpv_attention_fwd', 'gpv_attention_bwd', 'gpv_layernorm_fwd', 'gpv_layernorm_bwd',
+           'gpv_attention_fwd', 'gpv_attention_bwd', 'gpv_layernorm_fwd', 'gpv_layernorm_bwd', 'gpv_layernorm_pos_fwd', 'gpv_layernorm_bwd2',
            'gpv_softmax_ce', 'gpv_roi_weights', 'gpv_add', 'gpv_add_rowbcast', 'gpv_colsum', 'gpv_cast',
            'gpv_cast_rowscale_t', 'gpv_prep_conv_weight', 'gpv_embedding', 'gpv_dropout',
            'gpv_relevance_condition', 'gpv_adamw', 'gpv_sumsq', 'gpv_clip_scale', 'gpv_act_fwd', 'gpv_act_bwd', 'gpv_set_seed_device',
@@ -313,17 +313,26 @@ def attention_bwd(q, k, v, o, dout, dq, dk, dv, strides, do_strides, B, H, Sq, S
     _chk(lib().gpv_attention_bwd(C.byref(a), _stream()), 'gpv_attention_bwd')
 
 
-def layernorm_fwd(x, s, gamma, beta, y, mean, rstd, rows, cols, eps, drop_p=0.0, seed=0):
-    _chk(lib().gpv_layernorm_fwd(_p(x), _p(s), _p(_f32(gamma)), _p(_f32(beta)), _p(y), _p(mean), _p(rstd),
-                                 C.c_int(rows), C.c_int(cols), C.c_float(eps), C.c_float(drop_p),
-                                 C.c_uint64(seed), C.c_int(dcode(x)), _stream()), 'gpv_layernorm_fwd')
+def layernorm_fwd(x, s, gamma, beta, y, mean, rstd, rows, cols, eps, drop_p=0.0, seed=0, pos=None, y2=None):
+    """pos [pos_rows, cols] + y2 [rows, cols] (both or neither): second output y2 = y + pos[row % pos_rows] (gpv_layernorm_pos_fwd)"""
+    if (pos is None) != (y2 is None):
+        raise ValueError('layernorm_fwd: pos and y2 come together')
+    if pos is not None and (pos.dtype != x.dtype or y2.dtype != x.dtype or pos.numel() % cols != 0):
+        raise TypeError('layernorm_fwd: pos / y2 in the activation dtype, whole rows')
+    _chk(lib().gpv_layernorm_pos_fwd(_p(x), _p(s), _p(_f32(gamma)), _p(_f32(beta)), _p(y), _p(mean), _p(rstd),
+                                     C.c_int(rows), C.c_int(cols), C.c_float(eps), C.c_float(drop_p), C.c_uint64(seed),
+                                     _p(pos), C.c_int(0 if pos is None else pos.numel() // cols), _p(y2),
+                                     C.c_int(dcode(x)), _stream()), 'gpv_layernorm_pos_fwd')
 
 
-def layernorm_bwd(dy, x, s, gamma, mean, rstd, dx, ds, dgamma, dbeta, rows, cols, drop_p=0.0, seed=0):
-    _chk(lib().gpv_layernorm_bwd(_p(dy), _p(x), _p(s), _p(_f32(gamma)), _p(mean), _p(rstd), _p(dx), _p(ds),
-                                 _p(_f32(dgamma)), _p(_f32(dbeta)), C.c_int(rows), C.c_int(cols),
-                                 C.c_float(drop_p), C.c_uint64(seed), C.c_int(dcode(x)), _stream()),
-         'gpv_layernorm_bwd')
+def layernorm_bwd(dy, x, s, gamma, mean, rstd, dx, ds, dgamma, dbeta, rows, cols, drop_p=0.0, seed=0, dy2=None):
+    """dy2: a second gradient of the same output (came back through the forward's y2), summed on load"""
+    if dy2 is not None and dy2.dtype != dy.dtype:
+        raise TypeError('layernorm_bwd: dy2 dtype')
+    _chk(lib().gpv_layernorm_bwd2(_p(dy), _p(dy2), _p(x), _p(s), _p(_f32(gamma)), _p(mean), _p(rstd), _p(dx), _p(ds),
+                                  _p(_f32(dgamma)), _p(_f32(dbeta)), C.c_int(rows), C.c_int(cols),
+                                  C.c_float(drop_p), C.c_uint64(seed), C.c_int(dcode(x)), _stream()),
+         'gpv_layernorm_bwd2')
 
 
 def softmax_ce(logits, ld, target, loss, dlogits, gscale, rows, V):

@@ -448,10 +448,37 @@ def matmul_nt(a, b):
 # --------------------------------------------------------------------------------------------
 # y = LayerNorm(x + dropout(s)) * gamma + beta
 # --------------------------------------------------------------------------------------------
+def _pos_rows(pos, cols):
+    """pos as [pos_rows, cols] rows in the compute dtype (a constant of autograd: its gradient, if any, goes to `pos_param`)"""
+    p2 = _c(_as_compute(pos.detach())).reshape(-1, cols)
+    return p2
+
+
+def _pos_sink(pos_param, dy2, rows, cols):
+    """gradient of a learned, row-broadcast position term (DETR's query_embed, [Q, cols]): column sums of dy2 viewed as
+    [rows / Q, Q * cols], accumulated straight into the parameter's fp32 gradient (parameter gradients never travel through
+    autograd here) -- instead of one [rows, cols] gradient per use summed by autograd with an element-wise launch each"""
+    if pos_param is None or not pos_param.requires_grad or dy2 is None:
+        return
+    n = pos_param.numel()
+    g = ensure_grad(pos_param)
+    hip.colsum(dy2.reshape(-1, n), g.reshape(-1), rows * cols // n, n, n)
+
+
+def _two_grads(dy, dy2, rows, cols):
+    """(dy, dy2) as the kernels take them: the first one must exist"""
+    a = None if dy is None else _c(_as_compute(dy)).reshape(rows, cols)
+    b = None if dy2 is None else _c(_as_compute(dy2)).reshape(rows, cols)
+    return (b, None) if a is None else (a, b)
+
+
 class AddLayerNormFn(Function):
+    """y = LayerNorm(x + dropout(s)); with `pos` a second output y2 = y + pos (rows broadcast): gpv_layernorm_pos_fwd"""
+
     @staticmethod
-    def forward(ctx, x, s, gamma, beta, eps, drop_p, chain=None):
+    def forward(ctx, x, s, gamma, beta, eps, drop_p, chain=None, pos=None, pos_param=None):
         ctx.chain = chain.join() if (chain is not None and ctx.needs_input_grad[0]) else None
+        ctx.set_materialize_grads(False)
         cols = x.shape[-1]
         x2 = _c(_as_compute(x)).reshape(-1, cols)
         s2 = None if s is None else _c(_as_compute(s)).reshape(-1, cols)
@@ -462,25 +489,34 @@ class AddLayerNormFn(Function):
         seed = RT.next_seed() if (drop_p > 0 and s is not None) else 0
         if s is None:
             drop_p = 0.0
+        p2 = None if pos is None else _pos_rows(pos, cols)
+        y2 = None if pos is None else torch.empty_like(x2)
         hip.layernorm_fwd(x2, s2, None if gamma is None else gamma.detach(), None if beta is None else beta.detach(),
-                          y, mean, rstd, rows, cols, eps, drop_p, seed)
+                          y, mean, rstd, rows, cols, eps, drop_p, seed, pos=p2, y2=y2)
         ctx.gamma, ctx.beta, ctx.drop_p, ctx.seed, ctx.shape = gamma, beta, drop_p, seed, x.shape
-        ctx.has_s = s is not None
+        ctx.has_s, ctx.pos_param = s is not None, pos_param
         ctx.save_for_backward(x2, s2, mean, rstd)
-        return y.reshape(x.shape)
+        if pos is None:
+            return y.reshape(x.shape)
+        return y.reshape(x.shape), y2.reshape(x.shape)
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dy2=None):
+        nin = 9
+        if dy is None and dy2 is None:
+            return (None,) * nin
         x2, s2, mean, rstd = ctx.saved_tensors
         rows, cols = x2.shape
-        dy2 = _c(_as_compute(dy)).reshape(rows, cols)
+        if dy2 is not None:
+            _pos_sink(ctx.pos_param, _c(_as_compute(dy2)).reshape(rows, cols), rows, cols)
+        d1, d2 = _two_grads(dy, dy2, rows, cols)
         dx = torch.empty_like(x2)
         ds = torch.empty_like(x2) if (ctx.has_s and ctx.drop_p > 0) else None
         gamma, beta = ctx.gamma, ctx.beta
         need_g = gamma is not None and gamma.requires_grad
-        hip.layernorm_bwd(dy2, x2, s2, None if gamma is None else gamma.detach(), mean, rstd, dx, ds,
+        hip.layernorm_bwd(d1, x2, s2, None if gamma is None else gamma.detach(), mean, rstd, dx, ds,
                           ensure_grad(gamma) if need_g else None, ensure_grad(beta) if need_g else None,
-                          rows, cols, ctx.drop_p, ctx.seed)
+                          rows, cols, ctx.drop_p, ctx.seed, dy2=d2)
         dxr = dx.reshape(ctx.shape)
         dsr = None
         if ctx.has_s:
@@ -494,7 +530,7 @@ class AddLayerNormFn(Function):
             elif dsr is not None and ds is None:
                 dxr = dxr.clone()                       # dx doubles as ds here: the chain's later `res` reads must not alias a live output
             dxr = ch.done(dxr)
-        return (dxr if ctx.needs_input_grad[0] else None), (dsr if ctx.needs_input_grad[1] else None), None, None, None, None, None
+        return ((dxr if ctx.needs_input_grad[0] else None), (dsr if ctx.needs_input_grad[1] else None)) + (None,) * (nin - 2)
 
 
 class FFNBlockFn(Function):
@@ -503,10 +539,11 @@ class FFNBlockFn(Function):
     autograd sums their gradients with an extra elementwise pass -- here the residual gradient from the LayerNorm backward is
     the `res` operand of the last backward-data GEMM (dx = dz W1 + dx_res), and the ReLU/dropout derivative sits in the epilogue
     of dz = dy W2: alpha = 1/(1-p), ReLU mask = the saved hidden activation, which is zero exactly where the unit was
-    dropped or inactive (no separate pass over the [M, 2048] gradient)."""
+    dropped or inactive (no separate pass over the [M, 2048] gradient).  With `pos`: second output out + pos (AddLayerNormFn)."""
 
     @staticmethod
-    def forward(ctx, x, w1, w2, gamma, beta, eps, drop_p):
+    def forward(ctx, x, w1, w2, gamma, beta, eps, drop_p, pos=None, pos_param=None):
+        ctx.set_materialize_grads(False)
         K, Fh = w1.K, w1.N
         x2 = _c(_as_compute(x)).reshape(-1, K)
         M = x2.shape[0]
@@ -519,23 +556,33 @@ class FFNBlockFn(Function):
         mean = torch.empty(M, device=x.device, dtype=torch.float32)
         rstd = torch.empty_like(mean)
         seed2 = RT.next_seed() if drop_p > 0 else 0
-        hip.layernorm_fwd(x2, y, gamma.detach(), beta.detach(), out, mean, rstd, M, K, eps, drop_p, seed2)
+        p2 = None if pos is None else _pos_rows(pos, K)
+        out2 = None if pos is None else torch.empty_like(x2)
+        hip.layernorm_fwd(x2, y, gamma.detach(), beta.detach(), out, mean, rstd, M, K, eps, drop_p, seed2, pos=p2, y2=out2)
         ctx.w1, ctx.w2, ctx.gamma, ctx.beta, ctx.drop_p, ctx.seed2, ctx.xshape = w1, w2, gamma, beta, drop_p, seed2, x.shape
+        ctx.pos_param = pos_param
         ctx.save_for_backward(x2, h, y, mean, rstd)
-        return out.reshape(x.shape)
+        if pos is None:
+            return out.reshape(x.shape)
+        return out.reshape(x.shape), out2.reshape(x.shape)
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, dout2=None):
+        nin = 9
+        if dout is None and dout2 is None:
+            return (None,) * nin
         w1, w2, gamma, beta = ctx.w1, ctx.w2, ctx.gamma, ctx.beta
         x2, h, y, mean, rstd = ctx.saved_tensors
         M, K = x2.shape
         Fh = w1.N
-        d2 = _c(_as_compute(dout)).reshape(M, K)
+        if dout2 is not None:
+            _pos_sink(ctx.pos_param, _c(_as_compute(dout2)).reshape(M, K), M, K)
+        d2, d2b = _two_grads(dout, dout2, M, K)
         dx_res = torch.empty_like(x2)
         ds = torch.empty_like(x2) if ctx.drop_p > 0 else None
         need_g = gamma.requires_grad
         hip.layernorm_bwd(d2, x2, y, gamma.detach(), mean, rstd, dx_res, ds, ensure_grad(gamma) if need_g else None,
-                          ensure_grad(beta) if need_g else None, M, K, ctx.drop_p, ctx.seed2)
+                          ensure_grad(beta) if need_g else None, M, K, ctx.drop_p, ctx.seed2, dy2=d2b)
         dy2 = ds if ds is not None else dx_res
         nb2 = w2.bias is not None and w2.bias.requires_grad
         if w2.weight.requires_grad:
@@ -551,18 +598,32 @@ class FFNBlockFn(Function):
             hip.colsum(dz, w1.bgrad(), M, Fh, Fh)
         dx = torch.empty(M, K, device=dz.device, dtype=RT.dtype)
         w1.dx_gemm(dz, dx, M, res=dx_res, ldr=K)
-        return dx.reshape(ctx.xshape), None, None, None, None, None, None
+        return (dx.reshape(ctx.xshape),) + (None,) * (nin - 1)
 
 
-def ffn_block(x, w1, w2, gamma, beta, eps, drop_p=0.0):
-    """LayerNorm(x + dropout(ffn(x))) -- one node when gradients flow, the plain composition otherwise"""
+LN_POS = os.environ.get('GPV_LN_POS', '1') != '0'       # 0: TIMING A/B ONLY -- the sums as separate launches, query_embed loses the sink's gradient
+
+
+def _unfused_pos(y, pos):
+    cols = y.shape[-1]
+    return y, add(y, _pos_rows(pos, cols))
+
+
+def ffn_block(x, w1, w2, gamma, beta, eps, drop_p=0.0, pos=None, pos_param=None):
+    """LayerNorm(x + dropout(ffn(x))) -- one node when gradients flow, the plain composition otherwise; with `pos` -> (out, out + pos)"""
+    if pos is not None and not LN_POS:
+        return _unfused_pos(ffn_block(x, w1, w2, gamma, beta, eps, drop_p), pos)
     if not (torch.is_grad_enabled() and x.requires_grad):
-        return add_layernorm(x, linear(linear(x, w1, ACT_RELU, drop_p), w2), gamma, beta, eps, drop_p)
-    return FFNBlockFn.apply(x, w1, w2, gamma, beta, eps, drop_p)
+        return add_layernorm(x, linear(linear(x, w1, ACT_RELU, drop_p), w2), gamma, beta, eps, drop_p, pos=pos, pos_param=pos_param)
+    return FFNBlockFn.apply(x, w1, w2, gamma, beta, eps, drop_p, pos, pos_param)
 
 
-def add_layernorm(x, s, gamma, beta, eps, drop_p=0.0, chain=None):
-    return AddLayerNormFn.apply(x, s, gamma, beta, eps, drop_p, chain)
+def add_layernorm(x, s, gamma, beta, eps, drop_p=0.0, chain=None, pos=None, pos_param=None):
+    """pos ([rows_p, cols], rows a multiple of rows_p; a constant for autograd): -> (y, y + pos); pos_param: the learned parameter
+    behind a row-broadcast pos, whose gradient is accumulated by the backward (ops._pos_sink)"""
+    if pos is not None and not LN_POS:
+        return _unfused_pos(AddLayerNormFn.apply(x, s, gamma, beta, eps, drop_p, chain, None, None), pos)
+    return AddLayerNormFn.apply(x, s, gamma, beta, eps, drop_p, chain, pos, pos_param)
 
 
 # --------------------------------------------------------------------------------------------

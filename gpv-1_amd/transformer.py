@@ -27,9 +27,9 @@ class LinearP(nn.Module):
         return ops.linear(x, W(self.weight, self.bias), act, drop_p, out_f32, chain)
 
 
-def ffn_block(x, l1, l2, norm, drop_p):
-    """norm(x + dropout(linear2(dropout(relu(linear1(x)))))) as one autograd node (ops.FFNBlockFn)"""
-    return ops.ffn_block(x, W(l1.weight, l1.bias), W(l2.weight, l2.bias), norm.weight, norm.bias, norm.eps, drop_p)
+def ffn_block(x, l1, l2, norm, drop_p, pos=None, pos_param=None):
+    """norm(x + dropout(linear2(dropout(relu(linear1(x)))))) as one autograd node (ops.FFNBlockFn); pos: -> (out, out + pos)"""
+    return ops.ffn_block(x, W(l1.weight, l1.bias), W(l2.weight, l2.bias), norm.weight, norm.bias, norm.eps, drop_p, pos, pos_param)
 
 
 class LayerNormP(nn.Module):
@@ -39,9 +39,10 @@ class LayerNormP(nn.Module):
         self.bias = nn.Parameter(torch.zeros(dim))
         self.eps = eps
 
-    def forward(self, x, s=None, drop_p=0.0, chain=None):
-        """LayerNorm(x + dropout(s)); chain: the ops.GradChain of x (its gradient is handed to x's other consumers)"""
-        return ops.add_layernorm(x, s, self.weight, self.bias, self.eps, drop_p, chain)
+    def forward(self, x, s=None, drop_p=0.0, chain=None, pos=None, pos_param=None):
+        """LayerNorm(x + dropout(s)); chain: the ops.GradChain of x (its gradient is handed to x's other consumers);
+        pos (rows broadcast): -> (y, y + pos) from one launch, pos_param: the learned parameter behind pos (gradient sink)"""
+        return ops.add_layernorm(x, s, self.weight, self.bias, self.eps, drop_p, chain, pos, pos_param)
 
 
 class MultiheadAttention(nn.Module):
@@ -91,13 +92,14 @@ class TransformerEncoderLayer(nn.Module):
         self.norm2 = LayerNormP(d_model)
         self.p = dropout
 
-    def forward(self, src, pos, B, S, kpm):
-        """transformer.py:148-161 (forward_post)"""
+    def forward(self, src, qk, pos, B, S, kpm):
+        """transformer.py:148-161 (forward_post).  qk = src + pos arrives with src: the second output of the LayerNorm that
+        produced src (the previous layer's norm2; layer 0: one add) -- and this layer's norm2 emits the next layer's.
+        -> (out, out + pos)"""
         p = self.p if self.training else 0.0
         ch = ops.grad_chain(src)                 # src feeds norm1's residual, Wqk (through src + pos, pos constant) and Wv
-        qk = ops.add(src, pos)
         src = self.norm1(src, self.self_attn(qk, qk, src, B, S, S, kpm, chains=(ch, ch, ch)), p, chain=ch)
-        return ffn_block(src, self.linear1, self.linear2, self.norm2, p)
+        return ffn_block(src, self.linear1, self.linear2, self.norm2, p, pos=pos)
 
 
 class TransformerDecoderLayer(nn.Module):
@@ -112,17 +114,23 @@ class TransformerDecoderLayer(nn.Module):
         self.norm3 = LayerNormP(d_model)
         self.p = dropout
 
-    def forward(self, tgt, memory, mem_pos, query_pos, B, Q, S, kpm, mem_chain=None):
+    def forward(self, tgt, tgt_qp, memory, mem_pos, qpos, qpos_param, B, Q, S, kpm, mem_chain=None, emit=True):
         """transformer.py:211-232 (forward_post); mem_pos = memory + pos is layer-invariant.  mem_chain: the GradChain of the
-        encoder memory, shared by the K (through memory + pos) and V projections of all six layers.  The query-side sums
-        tgt + query_pos are NOT chained through: query_pos is learned and needs the projection's gradient on its own."""
+        encoder memory, shared by the K (through memory + pos) and V projections of all six layers.
+        tgt_qp = tgt + query_pos arrives with tgt (second output of the LayerNorm that produced tgt); norm1 emits the
+        cross-attention's query sum, norm3 the next layer's tgt_qp (emit).  qpos: query_embed as [Q, C] rows in the compute dtype
+        (a constant for autograd), qpos_param: the parameter itself -- the gradients of the sums w.r.t. query_pos are column sums
+        accumulated into its gradient by the LayerNorm backward (ops._pos_sink); w.r.t. tgt they are summed inside that kernel.
+        -> (out, out + query_pos | None)"""
         p = self.p if self.training else 0.0
         ch = ops.grad_chain(tgt)                 # tgt feeds norm1's residual and Wv (and, through tgt + query_pos, Wqk)
-        qk = ops.add(tgt, query_pos)
-        tgt = self.norm1(tgt, self.self_attn(qk, qk, tgt, B, Q, Q, chains=(None, None, ch)), p, chain=ch)
-        a = self.multihead_attn(ops.add(tgt, query_pos), mem_pos, memory, B, Q, S, kpm, chains=(None, mem_chain, mem_chain))
+        tgt, tq = self.norm1(tgt, self.self_attn(tgt_qp, tgt_qp, tgt, B, Q, Q, chains=(None, None, ch)), p, chain=ch,
+                             pos=qpos, pos_param=qpos_param)
+        a = self.multihead_attn(tq, mem_pos, memory, B, Q, S, kpm, chains=(None, mem_chain, mem_chain))
         tgt = self.norm2(tgt, a, p)
-        return ffn_block(tgt, self.linear1, self.linear2, self.norm3, p)
+        if not emit:
+            return ffn_block(tgt, self.linear1, self.linear2, self.norm3, p), None
+        return ffn_block(tgt, self.linear1, self.linear2, self.norm3, p, pos=qpos, pos_param=qpos_param)
 
 
 class TransformerEncoder(nn.Module):
@@ -162,17 +170,24 @@ class Transformer(nn.Module):
         kpm = mask.to(torch.uint8).contiguous() if mask is not None else None
         x = src.reshape(B * S, C)
         pe = pos.reshape(B * S, C)
-        for layer in self.encoder.layers:
-            x = layer(x, pe, B, S, kpm)
+        if len(self.encoder.layers) == 0:
+            xq = ops.add(x, pe)
+        else:
+            xq = ops.add(x, pe)                   # layer 0's q / k input; every later `x + pos` leaves the LayerNorm that makes x
+            for layer in self.encoder.layers:
+                x, xq = layer(x, xq, pe, B, S, kpm)
         memory = ops.boundary(x, 'mem')           # (backward: every decoder layer has run when the gradient arrives here)
         mem_chain = ops.grad_chain(memory)
-        mem_pos = ops.add(memory, pe)
-        qpos = query_embed.to(ops.RT.dtype).unsqueeze(0).expand(B, Q, C).reshape(B * Q, C)
+        mem_pos = xq                              # memory + pos: the last encoder LayerNorm's second output
+        qp = query_embed.detach().to(ops.RT.dtype).contiguous()                     # [Q, C] rows for the LayerNorm kernels
         tgt = torch.zeros(B * Q, C, device=src.device, dtype=ops.RT.dtype)
+        # layer 0: tgt = 0, so tgt + query_pos IS query_pos (bit-identical to the add); its gradient reaches query_embed through
+        # autograd (expand), the later layers' through ops._pos_sink
+        tq = query_embed.to(ops.RT.dtype).unsqueeze(0).expand(B, Q, C).reshape(B * Q, C)
         outs = []
         n = len(self.decoder.layers)
         for i, layer in enumerate(self.decoder.layers):
-            tgt = layer(tgt, memory, mem_pos, qpos, B, Q, S, kpm, mem_chain)
+            tgt, tq = layer(tgt, tq, memory, mem_pos, qp, query_embed, B, Q, S, kpm, mem_chain, emit=i + 1 < n)
             if need_all_layers or i == n - 1:
                 outs.append(self.decoder.norm(tgt).reshape(B, Q, C))
         return outs, memory.reshape(B, S, C)

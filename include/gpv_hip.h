@@ -268,6 +268,18 @@ int gpv_layernorm_bwd(const void* dy, const void* x, const void* s, const float*
                       const float* mean, const float* rstd, void* dx, void* ds, float* dgamma,
                       float* dbeta, int rows, int cols, float drop_p, uint64_t seed, int dtype,
                       void* stream);
+/* The same LayerNorm with a second output  y2 = y + pos[row % pos_rows]  (pos: [pos_rows, cols] in the activation dtype, rows a
+ * multiple of pos_rows; pos == y2 == NULL: gpv_layernorm_fwd): the sums `src + pos` / `tgt + query_pos` that DETR's layers feed their
+ * q / k projections (transformer.py:150-151,216-217,221-222) leave the LayerNorm that produces src / tgt instead of being an
+ * element-wise launch each; y2 is computed from the stored (rounded) y, bit-identical to gpv_add(y, pos).
+ * gpv_layernorm_bwd2: dy2 (nullable) is a second gradient of the same output -- the gradient that came back through y2 -- summed with
+ * dy on load. */
+int gpv_layernorm_pos_fwd(const void* x, const void* s, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                          int rows, int cols, float eps, float drop_p, uint64_t seed, const void* pos, int pos_rows, void* y2,
+                          int dtype, void* stream);
+int gpv_layernorm_bwd2(const void* dy, const void* dy2, const void* x, const void* s, const float* gamma, const float* mean,
+                       const float* rstd, void* dx, void* ds, float* dgamma, float* dbeta, int rows, int cols, float drop_p,
+                       uint64_t seed, int dtype, void* stream);
 
 /* softmax cross-entropy over the vocabulary (losses.py:20-26, nn.CrossEntropyLoss reduction none).
  * logits [rows, V] (ld), target int64 [rows] (ignore_index < 0 rows give loss 0);

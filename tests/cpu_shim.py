@@ -152,7 +152,7 @@ def attention_bwd(q, k, v, o, dout, dq, dk, dv, strides, do_strides, B, H, Sq, S
     _sv(dv, (B, H, Sk, dh), (vb, dh, vr, 1)).copy_(gv.to(dv.dtype))
 
 
-def layernorm_fwd(x, s, gamma, beta, y, mean, rstd, rows, cols, eps, drop_p=0.0, seed=0):
+def layernorm_fwd(x, s, gamma, beta, y, mean, rstd, rows, cols, eps, drop_p=0.0, seed=0, pos=None, y2=None):
     assert drop_p == 0.0
     z = x.float().reshape(rows, cols) + (0 if s is None else s.float().reshape(rows, cols))
     mu = z.mean(-1)
@@ -162,15 +162,20 @@ def layernorm_fwd(x, s, gamma, beta, y, mean, rstd, rows, cols, eps, drop_p=0.0,
     if gamma is not None:
         n = n * gamma + beta
     y.reshape(rows, cols).copy_(n.to(y.dtype))
+    if y2 is not None:
+        pr = pos.numel() // cols
+        y2.reshape(rows // pr, pr, cols).copy_((y.reshape(rows // pr, pr, cols).float() + pos.reshape(1, pr, cols).float()).to(y2.dtype))
     mean.copy_(mu)
     rstd.copy_(rs)
 
 
-def layernorm_bwd(dy, x, s, gamma, mean, rstd, dx, ds, dgamma, dbeta, rows, cols, drop_p=0.0, seed=0):
+def layernorm_bwd(dy, x, s, gamma, mean, rstd, dx, ds, dgamma, dbeta, rows, cols, drop_p=0.0, seed=0, dy2=None):
     assert drop_p == 0.0
     z = x.float().reshape(rows, cols) + (0 if s is None else s.float().reshape(rows, cols))
     zh = (z - mean[:, None]) * rstd[:, None]
     g = dy.float().reshape(rows, cols)
+    if dy2 is not None:
+        g = g + dy2.float().reshape(rows, cols)
     gy = g * (gamma if gamma is not None else 1.0)
     dz = rstd[:, None] * (gy - gy.mean(-1, keepdim=True) - zh * (gy * zh).mean(-1, keepdim=True))
     dx.reshape(rows, cols).copy_(dz.to(dx.dtype))

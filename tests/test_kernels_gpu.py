@@ -1245,3 +1245,33 @@ def test_clip_scale_is_deterministic_and_matches_torch():
             assert torch.equal(sc, first)
         h.clip_scale(None, 0.0, ws, sc, pstep, live)
         assert torch.equal(sc, first) and torch.equal(pstep, torch.arange(700, device=DEV, dtype=torch.int32) + 2 * live)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('rows,cols,prow', [(600, 256, 600), (600, 256, 100), (96, 768, 96), (96, 768, 12), (40, 2048, 8)])
+def test_layernorm_second_output_and_second_gradient(dtype, rows, cols, prow):
+    """gpv_layernorm_pos_fwd: y2 = y + pos[row % pos_rows] bit-identical to gpv_add on the stored y (every row width / broadcast
+    period); gpv_layernorm_bwd2: (dy, dy2) gives what one launch on dy + dy2 (summed in fp32) gives, dgamma / dbeta included."""
+    h = hip()
+    x, s_ = rnd(rows, cols, dtype=dtype, seed=1), rnd(rows, cols, dtype=dtype, seed=2)
+    pos = rnd(prow, cols, dtype=dtype, seed=3)
+    gamma, beta = (1 + 0.1 * torch.randn(cols, device=DEV)), 0.1 * torch.randn(cols, device=DEV)
+    y, y2 = torch.empty_like(x), torch.empty_like(x)
+    mean, rstd = torch.empty(rows, device=DEV), torch.empty(rows, device=DEV)
+    h.layernorm_fwd(x, s_, gamma, beta, y, mean, rstd, rows, cols, 1e-5, pos=pos, y2=y2)
+    y0 = torch.empty_like(x)
+    h.layernorm_fwd(x, s_, gamma, beta, y0, mean, rstd, rows, cols, 1e-5)
+    assert torch.equal(y, y0)
+    want = (y.float().reshape(rows // prow, prow, cols) + pos.float()[None]).to(dtype).reshape(rows, cols)
+    assert torch.equal(y2, want)
+    dy, dy2 = rnd(rows, cols, dtype=dtype, seed=4), rnd(rows, cols, dtype=dtype, seed=5)
+    dx, dg, db = torch.empty_like(x), torch.zeros(cols, device=DEV), torch.zeros(cols, device=DEV)
+    h.layernorm_bwd(dy, x, s_, gamma, mean, rstd, dx, None, dg, db, rows, cols, dy2=dy2)
+    # reference: fp32 math on the fp32 sum
+    z = x.float() + s_.float()
+    zh = (z - mean[:, None]) * rstd[:, None]
+    gsum = dy.float() + dy2.float()
+    gy = gsum * gamma
+    ref = rstd[:, None] * (gy - gy.mean(-1, keepdim=True) - zh * (gy * zh).mean(-1, keepdim=True))
+    assert rel(dx, ref) < TOL[dtype]
+    assert rel(dg, (gsum * zh).sum(0)) < 2e-3 and rel(db, gsum.sum(0)) < 2e-3

@@ -114,17 +114,24 @@ def test_detr_encoder_layer_at_bench_shape_vs_bf16_faithful_oracle(rt):
     kpm[-1, 250:] = True
     kpm[-2, 100:] = True
     dy = (0.1 * torch.randn(B, S, C, generator=g)).to(torch.bfloat16)
+    dy2 = (0.1 * torch.randn(B, S, C, generator=g)).to(torch.bfloat16)
+    from gpv1_amd import ops
     xh = x.to(DEV).reshape(B * S, C).requires_grad_(True)
-    out = layer(xh, pos.to(DEV).reshape(B * S, C), B, S, kpm.to(torch.uint8).to(DEV).contiguous())
-    out.backward(dy.to(DEV).reshape(B * S, C))
+    ph = pos.to(DEV).reshape(B * S, C)
+    # the layer takes (src, src + pos) and returns (out, out + pos): the sums leave the LayerNorm kernels (gpv_layernorm_pos_fwd)
+    out, out2 = layer(xh, ops.add(xh, ph), ph, B, S, kpm.to(torch.uint8).to(DEV).contiguous())
+    torch.autograd.backward([out, out2], [dy.to(DEV).reshape(B * S, C), dy2.to(DEV).reshape(B * S, C)])
+    ops.check_chains()
     torch.cuda.synchronize()
+    assert torch.equal(out2, (out.float() + ph.float()).to(torch.bfloat16))           # bit-identical to an add on the stored output
     Pm = _state(layer, 'L.')
     leaves = _leaf_params(Pm)
     xr = x.float().requires_grad_(True)
     prev = O.set_bf16_faithful(True)
     try:
         ref = O.detr_encoder_layer(leaves, 'L.', xr, pos.float(), kpm, 8)
-        ref.backward(dy.float())
+        ref2 = O._r(ref + pos.float())
+        torch.autograd.backward([ref, ref2], [dy.float(), dy2.float()])
     finally:
         O.set_bf16_faithful(prev)
     _check_fwd('detr encoder layer', out.reshape(B, S, C), ref, 32.0, 1e-2)
@@ -150,27 +157,36 @@ def test_detr_decoder_layer_at_bench_shape_vs_bf16_faithful_oracle(rt):
     kpm = torch.zeros(B, S, dtype=torch.bool)
     kpm[0, 200:] = True
     dy = (0.1 * torch.randn(B, Q, C, generator=g)).to(torch.bfloat16)
+    dy2 = (0.1 * torch.randn(B, Q, C, generator=g)).to(torch.bfloat16)
     th = tgt.to(DEV).reshape(B * Q, C).requires_grad_(True)
     mh = mem.to(DEV).reshape(B * S, C).requires_grad_(True)
     ph = pos.to(DEV).reshape(B * S, C)
-    qh = qpos.to(DEV).unsqueeze(0).expand(B, Q, C).reshape(B * Q, C)
+    qparam = torch.nn.Parameter(qpos.float().to(DEV))                      # query_embed: learned, broadcast over the batch
+    qrows = qparam.detach().to(torch.bfloat16).contiguous()
+    tq = ops.add(th, qparam.to(torch.bfloat16).unsqueeze(0).expand(B, Q, C).reshape(B * Q, C))
     mem_chain = ops.grad_chain(mh)
     mem_pos = ops.add(mh, ph)
-    out = layer(th, mh, mem_pos, qh, B, Q, S, kpm.to(torch.uint8).to(DEV).contiguous(), mem_chain)
-    out.backward(dy.to(DEV).reshape(B * Q, C))
+    # (tgt, tgt + query_pos) in, (out, out + query_pos) out; the query_pos gradients of the in-kernel sums go to qparam.grad
+    out, out2 = layer(th, tq, mh, mem_pos, qrows, qparam, B, Q, S, kpm.to(torch.uint8).to(DEV).contiguous(), mem_chain, emit=True)
+    torch.autograd.backward([out, out2], [dy.to(DEV).reshape(B * Q, C), dy2.to(DEV).reshape(B * Q, C)])
     ops.check_chains()
     torch.cuda.synchronize()
+    assert torch.equal(out2.reshape(B, Q, C), (out.reshape(B, Q, C).float() + qrows.float()[None]).to(torch.bfloat16))
     Pm = _state(layer, 'L.')
     leaves = _leaf_params(Pm)
     tr_, mr = tgt.float().requires_grad_(True), mem.float().requires_grad_(True)
+    qr = qpos.float().requires_grad_(True)
     prev = O.set_bf16_faithful(True)
     try:
-        ref = O.detr_decoder_layer(leaves, 'L.', tr_, mr, pos.float(), qpos.float()[None].expand(B, -1, -1), kpm, 8)
-        ref.backward(dy.float())
+        qe = qr[None].expand(B, -1, -1)
+        ref = O.detr_decoder_layer(leaves, 'L.', tr_, mr, pos.float(), qe, kpm, 8)
+        ref2 = O._r(ref + qe)
+        torch.autograd.backward([ref, ref2], [dy.float(), dy2.float()])
     finally:
         O.set_bf16_faithful(prev)
     _check_fwd('detr decoder layer', out.reshape(B, Q, C), ref, 32.0, 1e-2)
-    _check_grads('detr decoder', [('tgt', th.grad.reshape(B, Q, C), tr_.grad), ('memory', mh.grad.reshape(B, S, C), mr.grad)]
+    _check_grads('detr decoder', [('tgt', th.grad.reshape(B, Q, C), tr_.grad), ('memory', mh.grad.reshape(B, S, C), mr.grad),
+                                  ('query_pos', qparam.grad, qr.grad)]
                  + _param_grads(layer, 'L.', leaves), 0.9995, 0.01)
 
 
