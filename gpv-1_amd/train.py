@@ -535,6 +535,7 @@ class FlatTrainer:
         self.gscale = torch.ones(1, device=dev, dtype=torch.float32)
         self._clip_ws = torch.zeros(hip.CLIP_PARTIALS, device=dev, dtype=torch.float32)
         self._published = None                   # the host 'touched' marks as last sent to the device
+        self._step_state = None
         b = bucket_mb * 1024 * 1024 // 4
         self.backbone_end = max([o + (k + 7) // 8 * 8 for (n, p, g, o, k) in self.entries if g == 'detr_backbone'], default=0)
         # flat ranges of the backbone's stages (module order = flat order: layer2 | layer3 | layer4): each is a milestone of the
@@ -697,38 +698,52 @@ class FlatTrainer:
                 out.append([g, o, end])
         return out
 
+    def _begin_step(self):
+        """first half of the optimizer step, legal as soon as this step's `touched` set is final: liveness flags to the device,
+        per-parameter Adam step counts += live, schedule position.  Idempotent within a step."""
+        if self._step_state is not None:
+            return self._step_state
+        sched = self.lr_factor()
+        self._publish_touched()
+        hip.clip_scale(None, 0.0, self._clip_ws, self.gscale, self.pstep, self.live)          # pstep += live (one tiny launch)
+        self.step_count += 1
+        t = self.step_count
+        b1, b2 = self.betas
+        self._step_state = {'sched': sched, 'bc': (1 - b1 ** t, 1 - b2 ** t), 'done': set()}
+        return self._step_state
+
+    def _adamw_group(self, g, st, clip_here):
+        s, e = self.group_range[g]
+        b1, b2 = self.betas
+        hip.adamw(self.P[s:e], self.G[s:e], self.M[s:e], self.V[s:e], self.Pb[s:e], e - s, self.lr[g] * st['sched'], b1, b2,
+                  self.eps, self.wd, st['bc'][0], st['bc'][1], self.gscale if clip_here else None,
+                  seg_id=self.seg_id[s // 8:e // 8], seg_live=self.pstep)
+        st['done'].add(g)
+
     def step(self):
         """clip_grad_norm_(detr params) + AdamW + schedule (train_distr.py:423-428,468-469)"""
         hp = HOST_PROF
         t0 = time.perf_counter() if hp is not None else 0.0
-        sched = self.lr_factor()
         use_clip = self.clip is not None and self.clip > 0
-        self._publish_touched()
+        st = self._begin_step()
         if hp is not None:
             t1 = time.perf_counter(); hp['opt_publish'] = hp.get('opt_publish', 0.0) + t1 - t0; t0 = t1
-        # clip factor over the DETR groups (backbone | head: adjacent in the flat buffer; untouched gradients are zero) and the
-        # per-parameter Adam step counts, two launches (gpv_clip_scale).  Every rank must get the SAME bits from the same
-        # all-reduced gradient, or the replicas drift apart one ulp of the clip factor per step: the kernel sums in a fixed
-        # order (gpv_sumsq's float atomics do not -- found by tests/test_distributed_gpu.py); no host sync.
+        # clip factor over the DETR groups (backbone | head: adjacent in the flat buffer; untouched gradients are zero), two launches
+        # (gpv_clip_scale).  Every rank must get the SAME bits from the same all-reduced gradient, or the replicas drift apart one
+        # ulp of the clip factor per step: the kernel sums in a fixed order (gpv_sumsq's float atomics do not -- found by
+        # tests/test_distributed_gpu.py); no host sync.
         rng = [self.group_range[g] for g in ('detr_backbone', 'detr_head') if g in self.group_range] if use_clip else []
         if rng:
             s0, e1 = min(r[0] for r in rng), max(r[1] for r in rng)
             if sum(r[1] - r[0] for r in rng) != e1 - s0:
                 raise RuntimeError('FlatTrainer: the DETR groups are not contiguous in the flat buffer')
-            hip.clip_scale(self.G[s0:e1], self.clip, self._clip_ws, self.gscale, self.pstep, self.live)
-        else:
-            hip.clip_scale(None, 0.0, self._clip_ws, self.gscale, self.pstep, self.live)
+            hip.clip_scale(self.G[s0:e1], self.clip, self._clip_ws, self.gscale)
         if hp is not None:
             t1 = time.perf_counter(); hp['opt_clip'] = hp.get('opt_clip', 0.0) + t1 - t0; t0 = t1
-        self.step_count += 1
-        t = self.step_count
-        b1, b2 = self.betas
-        bc1, bc2 = 1 - b1 ** t, 1 - b2 ** t                                   # (unused by the kernel when the per-parameter counts are given)
-        for g, (s, e) in self.group_range.items():                           # one launch per group; the kernel skips dead parameters
-            clip_here = use_clip and g in ('detr_backbone', 'detr_head')
-            hip.adamw(self.P[s:e], self.G[s:e], self.M[s:e], self.V[s:e], self.Pb[s:e], e - s, self.lr[g] * sched, b1, b2,
-                      self.eps, self.wd, bc1, bc2, self.gscale if clip_here else None,
-                      seg_id=self.seg_id[s // 8:e // 8], seg_live=self.pstep)
+        for g in self.group_range:                                           # one launch per group; the kernel skips dead parameters
+            if g not in st['done']:
+                self._adamw_group(g, st, use_clip and g in ('detr_backbone', 'detr_head'))
+        self._step_state = None
         RT.bump_weights(everything=False)
         if hp is not None:
             hp['opt_adamw'] = hp.get('opt_adamw', 0.0) + time.perf_counter() - t0

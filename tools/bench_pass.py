@@ -18,6 +18,7 @@ ap.add_argument('--batch', type=int, default=32)
 ap.add_argument('--iters', type=int, default=20)
 ap.add_argument('--variants', default='0,1,side')
 ap.add_argument('--graph', action='store_true', help='time hipGraph replays of the two passes instead of eager launches')
+ap.add_argument('--split', type=int, default=1, help='(with --graph) the batch as this many independent sub-batches on parallel graph branches: do the ramps / tails of one chain hide under the other? (timing only: the weight gradients of the branches race)')
 args = ap.parse_args()
 dev = 'cuda'
 hip.lib()
@@ -49,13 +50,29 @@ def run(variant):
             torch.cuda.synchronize()
             gf, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             pool = torch.cuda.graph_pool_handle()
-            keep = []
-            gf.capture_begin(pool=pool)
-            c5 = body.forward_nhwc(images, keep)
-            gf.capture_end()
-            gb.capture_begin(pool=pool)
-            body.backward_nhwc(keep, dc5)
-            gb.capture_end()
+            if args.split <= 1:
+                keep = []
+                gf.capture_begin(pool=pool)
+                c5 = body.forward_nhwc(images, keep)
+                gf.capture_end()
+                gb.capture_begin(pool=pool)
+                body.backward_nhwc(keep, dc5)
+                gb.capture_end()
+            else:
+                n = args.split
+                parts = [images[i * args.batch // n:(i + 1) * args.batch // n].contiguous() for i in range(n)]
+                dparts = [dc5[i * args.batch // n:(i + 1) * args.batch // n].contiguous() for i in range(n)]
+                sts = [torch.cuda.Stream() for _ in range(n)]
+                keeps = [[] for _ in range(n)]
+                for cap, fn in ((gf, lambda i: body.forward_nhwc(parts[i], keeps[i])), (gb, lambda i: body.backward_nhwc(keeps[i], dparts[i]))):
+                    cap.capture_begin(pool=pool)
+                    for i in range(n):
+                        sts[i].wait_stream(st)
+                        with torch.cuda.stream(sts[i]):
+                            fn(i)
+                    for i in range(n):
+                        st.wait_stream(sts[i])
+                    cap.capture_end()
         for it in range(args.iters + 3):
             e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
             e0.record()
@@ -83,4 +100,4 @@ def run(variant):
 
 for v in args.variants.split(','):
     f, b = run(v)
-    print('GPV_WGRAD_STAGES=%-5s %s  forward %.3f ms  backward %.3f ms  body %.3f ms' % (v, 'graph' if args.graph else 'eager', f, b, f + b), flush=True)
+    print('split %d ' % args.split + 'GPV_WGRAD_STAGES=%-5s %s  forward %.3f ms  backward %.3f ms  body %.3f ms' % (v, 'graph' if args.graph else 'eager', f, b, f + b), flush=True)
