@@ -186,7 +186,18 @@ def attention_roofline(dev, B):
         out[name] = e0.elapsed_time(e1) / 20 * 1e3
     fl = 4.0 * B * H * S * S * dh
     tf = fl / (out['fwd'] * 1e-6) / 1e12
-    return {'bound': 'mfma', 'achieved': tf, 'peak': 2500.0, 'unit': 'TFLOP/s', 'frac': tf / 2500.0,
+    # The VALU ceiling the core sits under: instruction count x issue rate.  SQ_INSTS_VALU of the forward launch at
+    # this shape = 4.579e6 wave-instructions (profiles/r03_pmc_attention.txt: rocprofv3 --pmc, per launch, B = 32); a wave64 VALU
+    # instruction occupies its SIMD16 for 4 cycles, v_exp_f32 (one per score and lane: B h S^2 / 64 = 3.6e5 of them) for 16; the
+    # chip has 256 CUs x 4 SIMDs at 2.4 GHz.  Scaled with B h S^2 for other batch sizes.
+    valu_insts = 4.579e6 * (B * H * S * S) / (32.0 * 8 * 300 * 300)
+    exp_insts = B * H * S * S / 64.0
+    valu_cycles = (valu_insts * 4.0 + exp_insts * 12.0) / (256 * 4)
+    valu_us = valu_cycles / 2400.0
+    valu_tf = fl / (valu_us * 1e-6) / 1e12
+    return {'bound': 'mfma', 'valu_ceiling_tflops': valu_tf, 'valu_ceiling_us': valu_us, 'frac_of_valu_ceiling': tf / valu_tf,
+            'valu_ceiling_how': 'SQ_INSTS_VALU per launch (profiles/r03_pmc_attention.txt) x 4 cycles per wave64 instruction (+12 for each '
+                                'quarter-rate v_exp_f32) / 1024 SIMDs / 2.4 GHz: the time the launch needs for its vector instructions alone', 'achieved': tf, 'peak': 2500.0, 'unit': 'TFLOP/s', 'frac': tf / 2500.0,
             'kernel': 'attn_q_kernel<bf16,32,32,20,0> (DETR encoder self-attention core, forward; B x 8 heads, 300x300, dh 32, dropout on)',
             'flops_per_launch': fl, 'avg_launch_us': out['fwd'], 'bwd_us': out['bwd'],
             'bwd_tflops': 2.5 * fl / (out['bwd'] * 1e-6) / 1e12,
@@ -314,6 +325,30 @@ def extra_configs(model, tr, dev, rank):
     out['beam5_bs64'] = {'ms_per_batch': dt * 1e3, 'ms_per_image': dt * 1e3 / 64,
                          'what': 'configs[3]: forward_beam_search(beam_size=5), 64 images, KV cache, the whole search one hipGraph, incl. host detokenisation'}
     return out
+
+
+def precise_bench(model, tr, dev, rank):
+    """the mode that meets north_star's 1e-3 parity bar (fp32 storage, every MFMA product as hi*hi + lo*hi + hi*lo on split bf16
+    operands: tests/test_model_gpu.py precise cases) on the SAME workload and trainer: eager steps (the hipGraph path is bf16 only)"""
+    from gpv1_amd.ops import RT
+    from gpv1_amd.misc import nested_tensor_from_tensor_list
+    images, mask, ids, attn, targets = make_batch(rank, BATCH, dev)
+    samples = nested_tensor_from_tensor_list(images)
+    RT.set_precise(True)
+    try:
+        for _ in range(2):
+            tr.train_step(samples, (ids, attn), [dict(t) for t in targets])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n_it = 3
+        for _ in range(n_it):
+            loss = tr.train_step(samples, (ids, attn), [dict(t) for t in targets])
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n_it
+    finally:
+        RT.set_precise(False)
+    return {'ms_per_step': dt * 1e3, 'images_per_sec': BATCH / dt, 'finite': bool(torch.isfinite(loss.detach())),
+            'what': 'configs[1] workload in precise mode (fp32 storage, 3-MFMA split-bf16 products; the mode the 1e-3 parity bar is checked in), eager launches'}
 
 
 def input_pipeline_bench(dev):
@@ -579,6 +614,8 @@ def main():
         out['extra']['input_pipeline_bs32'] = input_pipeline_bench(dev)
     if world == 1 and not args.no_decode:
         out['greedy_decode'] = greedy_decode_bench(model, dev)
+    if world == 1 and not args.no_extra and args.batch == BATCH:
+        out['extra']['precise_train_step_ms'] = precise_bench(model, tr, dev, rank)       # (last: it retires every captured graph)
     if world == 1 and not args.no_cpu_baseline:
         try:
             out['cpu_baseline'] = cpu_baseline(model)

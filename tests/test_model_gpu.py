@@ -343,6 +343,42 @@ def _run_config_steps(model, det_only, Bf, Vf):
         torch.cuda.empty_cache()
 
 
+def test_baseline_config1_caption_only_bs32_graphed_equals_eager(rt):
+    """BASELINE.json configs[1], literally what bench.py times: CocoCaptioning-only targets (20 tokens incl. __cls__ / __stop__),
+    B = 32, 480 x 640, bf16, V = 10 000 -- dropout off here so that steps are comparable.  Graphed trainer (F1 | F2 | criterion +
+    B1 as one graph | B2, replayed) against the eager trainer from the same initial weights: same touched set (the box head
+    stays untouched: torch-1.6 optimizer semantics), losses equal step by step to fp32-atomics noise, both fall, everything
+    finite; the steps after the first ran through the captured graphs with the criterion inside (backward_fused)."""
+    from gpv1_amd.train import FlatTrainer
+    rt.set_precise(False)
+    Vf, Bf = 10000, 32
+    g, images, mask, ids, attn = _full_batch(Bf, Vf, tl=6)
+    tg = [{'task': 'CocoCaptioning', 'answer': ' '.join(f'w{(41 * i + 7 * j) % (Vf - 4)}' for j in range(18))} for i in range(Bf)]
+    res = {}
+    for graphs in (False, True):
+        model = full_model(Vf, dropout=0.0)
+        model.bert.model.p = 0.0
+        tr = FlatTrainer(model, lr=1e-4, lr_backbone=1e-5, graphs=graphs)
+        losses = []
+        for it in range(4):
+            loss = tr.train_step(nested(images, mask), (ids, attn), [dict(t) for t in tg])
+            assert torch.isfinite(loss) and torch.isfinite(tr.G).all()
+            losses.append(float(loss))
+        fused = [k for b in tr._bodies.values() for k in b.variants if k[0] == 'fused']
+        res[graphs] = (losses, tr.live_host().clone(), tr.graph_steps, fused, [e[0] for e in tr.entries])
+        del tr, model
+        torch.cuda.empty_cache()
+    (l0, v0, n0, f0, names), (l1, v1, n1, f1, _) = res[False], res[True]
+    print('CONFIG1 eager', l0, 'graphed', l1)
+    assert n0 == 0 and n1 == 3 and f1 == [('fused', 'CocoCaptioning', True)], (n0, n1, f1)
+    assert torch.equal(v0, v1)
+    ib = [i for i, n in enumerate(names) if 'bbox_embed' in n]
+    assert ib and not v1[ib].any()
+    for a, b_ in zip(l0, l1):
+        assert abs(a - b_) <= 1e-2 * abs(a), (l0, l1)
+    assert l0[-1] < l0[0] and l1[-1] < l1[0]
+
+
 def test_baseline_config3_beam_search_and_config0_single_image(rt):
     """configs[3]: beam_size 5 decode of a batch of 64 480x640 images (K*B = 320 decoder rows, KV caches following the beams,
     the whole search one hipGraph); configs[0]: one image, greedy.  Probabilities in (0,1], beams sorted best-first, greedy
@@ -970,6 +1006,9 @@ def test_string_query_inference_replays_graphs_and_equals_tokenised_call(rt):
             for k in ('pred_boxes', 'pred_relevance_logits', 'answer_logits'):
                 assert torch.equal(out_s[k], out_t[k]), k
         assert len(model._igraphs) == 3
+        # the repeated query batches (lengths 3, 5, 3 again) were served from the query -> BERT-feature cache: the inference graph
+        # WITHOUT the BERT branch on the cached rows, bit-identical outputs (asserted above against the tokenised call)
+        assert model.qcache_hits >= 3 and any(k[0] == 'greedy_cached' for k in model._igraphs), (model.qcache_hits, [k[0] for k in model._igraphs])
         beam_s = model.forward_beam_search(samples, qs, beam_size=2)
         beam_t = model.forward_beam_search(samples, (ids.to(DEV), attn.to(DEV)), beam_size=2)
         assert beam_s['answers'] == beam_t['answers']

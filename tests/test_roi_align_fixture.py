@@ -93,3 +93,72 @@ def test_hip_roi_pool_matches_hand_computed_values(precise):
             assert got[b, :, 5:].abs().max() == 0
     finally:
         ops.RT.set_precise(False)
+
+
+# ---- bins that are exact integers, +- one ulp of the box size ---------------------------------------------
+# grid = ceil(extent / 7) flips between g and g + 1 when extent / 7 is an integer and the fp32 box arithmetic lands one ulp above
+# it (7/15 and 7/20 are not representable, so a "7-pixel" box is always such a case).  What must hold WHICHEVER way it falls:
+#   * linear channels: a bin's mean of a linear function is its midpoint value for any grid -> one hand value;
+#   * the y^2 channel: one of the two hand values (grid g or g + 1): sum over samples of y^2 + t(1 - t).
+def _y2_mean(y0, extent, grid):
+    """float64 mean over the 7 x grid interior samples of the bilinear interpolant of y^2"""
+    b = extent / 7.0
+    tot = 0.0
+    for p in range(7):
+        for i in range(grid):
+            y = y0 + p * b + (i + 0.5) * b / grid
+            t = y - int(y)
+            tot += y * y + t * (1.0 - t)
+    return tot / (7 * grid)
+
+
+def _ulp_boxes():
+    import numpy as np
+    out = []
+    for y0, ext in ((2.0, 7.0), (-0.25, 14.0), (3.25, 7.0)):       # (every sample stays inside [0, H - 1]: no border clamping)
+        h = np.float32(ext / H)
+        for k in (-1, 0, 1):
+            hk = float(np.nextafter(h, np.float32(2.0 * k)) if k else h)              # one ulp below / the rounded value / one ulp above
+            b = nbox(y0, ext)
+            b[3] = hk
+            g0 = int(round(ext / 7.0))
+            ymid = y0 + ext / 2.0
+            out.append((b, ymid, (_y2_mean(y0, ext, g0), _y2_mean(y0, ext, g0 + 1))))
+    return out
+
+
+def _check_ulp_rows(got, tol):
+    for row, (b, ymid, (c0, c1)) in zip(got, _ulp_boxes()):
+        lin = torch.tensor([1.0, ymid, XM, 3 + 2 * ymid - 0.5 * XM])
+        assert (row[[0, 1, 2, 4]] - lin).abs().max() <= tol * lin.abs().max(), (b, row, lin)
+        assert min(abs(float(row[3]) - c0), abs(float(row[3]) - c1)) <= tol * c0, (b, float(row[3]), c0, c1)
+
+
+def test_oracle_roi_align_at_integer_bins_plus_minus_one_ulp():
+    from oracle import gpv_oracle as O
+    feat = feature_maps()
+    bx = torch.tensor([b for b, _, _ in _ulp_boxes()], dtype=torch.float32)
+    got = O.extract_roi(feat[None], bx[None])[0]
+    _check_ulp_rows(got, 2e-5)
+    xyxy = torch.stack([W * (bx[:, 0] - bx[:, 2] / 2), H * (bx[:, 1] - bx[:, 3] / 2), W * (bx[:, 0] + bx[:, 2] / 2), H * (bx[:, 1] + bx[:, 3] / 2)], 1)
+    _check_ulp_rows(O.roi_align_mean_direct(feat, xyxy), 2e-5)
+
+
+@pytest.mark.gpu
+def test_hip_roi_pool_at_integer_bins_plus_minus_one_ulp():
+    """the HIP kernel on the same boxes: one of the two hand values, and the SAME one the oracle's separable form picks (both
+    derive the grid from the box in the same fp32 order: start = size * (c - e / 2) - 0.5, length = size * e)"""
+    import gpv1_amd.ops as ops
+    from oracle import gpv_oracle as O
+    ops.RT.set_precise(True)
+    try:
+        feat = feature_maps()
+        f = torch.zeros(1, H * W, 8)
+        f[0, :, :5] = feat.permute(1, 2, 0).reshape(H * W, 5)
+        bx = torch.tensor([b for b, _, _ in _ulp_boxes()], dtype=torch.float32)
+        got = ops.roi_pool(f.cuda(), bx[None].contiguous().cuda(), H, W).float().cpu()[0, :, :5]
+        _check_ulp_rows(got, 2e-5)
+        ref = O.extract_roi(feat[None], bx[None])[0]
+        assert (got - ref).abs().max() <= 2e-5 * ref.abs().max(), (got - ref).abs().max()
+    finally:
+        ops.RT.set_precise(False)
