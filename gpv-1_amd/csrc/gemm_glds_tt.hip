@@ -162,6 +162,19 @@ __device__ __forceinline__ void glds_tt_core(const GemmK& p, int tile, int kspli
 #pragma unroll
   for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
 
+  if (ABL == 5 || ABL == 6) {
+    // loads-only with TWO (5) / THREE (6) k-tiles in flight per block (the LDS image is overwritten at will: nobody reads it):
+    // what a deeper pipeline could deliver -- 1.65 ms either way against 1.87 ms with one (profiles/r04_wgrad_ablations.txt)
+    constexpr int AHEAD = ABL == 5 ? 2 : 3;
+    for (int a = 0; a < AHEAD && kt0 + a < kt1; ++a) issue(kt0 + a, a & 1);
+    for (int kt = kt0; kt < kt1; ++kt) {
+      if (ABL == 5) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      __syncthreads();
+      if (kt + AHEAD < kt1) issue(kt + AHEAD, kt & 1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return;
+  }
   if (ABL != 3) issue(kt0, 0);
   for (int kt = kt0; kt < kt1; ++kt) {
     const int t = kt - kt0;
@@ -321,6 +334,8 @@ __global__ __launch_bounds__(256) void glds_wgrad_group_abl1_kernel(WgGroupK g) 
 __global__ __launch_bounds__(256) void glds_wgrad_group_abl2_kernel(WgGroupK g) { wgrad_group_body<2>(g); }
 __global__ __launch_bounds__(256) void glds_wgrad_group_abl3_kernel(WgGroupK g) { wgrad_group_body<3>(g); }
 __global__ __launch_bounds__(256) void glds_wgrad_group_abl4_kernel(WgGroupK g) { wgrad_group_body<4>(g); }
+__global__ __launch_bounds__(256) void glds_wgrad_group_abl5_kernel(WgGroupK g) { wgrad_group_body<5>(g); }
+__global__ __launch_bounds__(256) void glds_wgrad_group_abl6_kernel(WgGroupK g) { wgrad_group_body<6>(g); }
 
 struct WgRed { const float* ws; float* C; int64_t MN; int split, N, ldc, blk_start; };
 struct WgRedK { int n; int pad; WgRed r[WG_MAX]; };
@@ -459,7 +474,7 @@ extern "C" int gpv_conv_wgrad_group(const gpv_conv_wgrad_problem* probs, int n, 
   // GPV_WG_ABL=1|2|3 (timing experiments only, wrong results): see glds_tt_core
   static const int abl = [] { const char* e = getenv("GPV_WG_ABL"); return e ? atoi(e) : 0; }();
   typedef void (*wg_fn)(WgGroupK);
-  const wg_fn fn = abl == 1 ? glds_wgrad_group_abl1_kernel : abl == 2 ? glds_wgrad_group_abl2_kernel : abl == 3 ? glds_wgrad_group_abl3_kernel : abl == 4 ? glds_wgrad_group_abl4_kernel
+  const wg_fn fn = abl == 1 ? glds_wgrad_group_abl1_kernel : abl == 2 ? glds_wgrad_group_abl2_kernel : abl == 3 ? glds_wgrad_group_abl3_kernel : abl == 4 ? glds_wgrad_group_abl4_kernel : abl == 5 ? glds_wgrad_group_abl5_kernel : abl == 6 ? glds_wgrad_group_abl6_kernel
                                                                                                         : glds_wgrad_group_kernel;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, lds);

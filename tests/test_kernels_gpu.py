@@ -872,6 +872,12 @@ def test_small_helpers():
     out = torch.zeros(256, device=DEV)
     h.colsum(x, out, 777, 256, 256)
     assert rel(out, x.float().sum(0)) < 1e-5
+    for rows, cols, ld, dt in ((32, 25600, 25600, torch.bfloat16), (9600, 256, 512, torch.bfloat16), (5, 24, 24, torch.float32), (33, 100, 100, torch.bfloat16),
+                               (640, 768, 768, torch.float32)):                       # 16-byte form, its row / column splits, the scalar fallback
+        xx = rnd(rows, ld, dtype=dt, seed=76)
+        out = torch.ones(cols, device=DEV)
+        h.colsum(xx, out, rows, cols, ld)
+        assert rel(out, 1 + xx[:, :cols].float().sum(0)) < 2e-5, (rows, cols)
     a, b = rnd(300 * 4, 256, dtype=torch.bfloat16, seed=71), rnd(300, 256, dtype=torch.bfloat16, seed=72)
     y = torch.empty_like(a)
     h.add_rowbcast(a, b, y, 1200, 300, 256)
