@@ -27,6 +27,7 @@ from .position_encoding import build_position_encoding
 RELU = hip.ACT_RELU
 FUSED_STEM = os.environ.get('GPV_FUSED_STEM', '1') != '0'
 FUSED_TAIL = os.environ.get('GPV_FUSED_TAIL', '1') != '0'
+FUSED_CHAIN = os.environ.get('GPV_FUSED_CHAIN', '1') != '0'      # a layer1 block's tail + the next block's conv1 in one launch (gpv_conv1x1_chain)
 WGRAD_STREAM = os.environ.get('GPV_WGRAD_STREAM', '1') != '0'
 WGRAD_GROUP = os.environ.get('GPV_WGRAD_GROUP', '1') != '0'      # all conv weight gradients of a backward pass as one grouped call (bf16)
 # ... issued per STAGE (layer4, then layer3, then layer2) right behind that stage's backward-data chain, while the stage's dy / x
@@ -174,6 +175,33 @@ def _block_tail_fused(x, a2, blk, tr, need_wd):
     return y
 
 
+def _block_tail_chain(x, a2, blk, nxt, tr_next):
+    """(yb, a1_next): this block's tail -- conv3 (+ downsample | + identity) + ReLU -- and the NEXT block's conv1 + ReLU as ONE launch
+    (gpv_conv1x1_chain: the 256-channel map is written once and not read back); None = not a shape the kernel takes.  Frozen
+    layer1 blocks only (64 planes): nothing between the two convolutions is needed by a backward pass."""
+    c3, c1n = blk.conv3, nxt.conv1
+    if c3.cin != 64 or c3.cout != 256 or c1n.cin != 256 or c1n.cout not in (64, 128) or c1n.stride != 1 or blk.trainable():
+        return None
+    B, OH, OW, _ = a2.shape
+    w3, _, _, s3 = _conv_copies(c3, blk.bn3, False)
+    wn, _, _, sn = _conv_copies(c1n, nxt.bn1, tr_next)
+    yb = torch.empty(B, OH, OW, 256, device=x.device, dtype=RT.dtype)
+    an = torch.empty(B, OH, OW, c1n.cout, device=x.device, dtype=RT.dtype)
+    if blk.downsample is not None:
+        cd = blk.downsample[0]
+        if cd.cin != 64 or cd.stride != 1:
+            return None
+        wd, _, _, sd = _conv_copies(cd, blk.downsample[1], False)
+        key = ('tail_shift', id(blk))
+        hit = RT.cache.get(key)
+        if hit is None or hit[0] != RT.static_epoch:
+            hit = RT.cache[key] = (RT.static_epoch, (s3 + sd).contiguous())
+        ok = hip.conv1x1_chain(a2, w3, x, wd, 1, None, hit[1], yb, wn, sn, an, B, OH, OW)
+    else:
+        ok = hip.conv1x1_chain(a2, w3, None, None, 1, x, s3, yb, wn, sn, an, B, OH, OW)
+    return (yb, an) if ok else None
+
+
 def _conv_dgrad(dy, conv, bn, xshape, res=None, relu_mask=None):
     """dx[B,H,W,Cin] = convT(dy) (+res) * (relu_mask > 0)"""
     B, H, Wd, Cin = xshape
@@ -271,12 +299,22 @@ class ResNetBody(nn.Module):
         if RT.split is not None and keep is not None:
             RT.split.prep_join()                   # the weight copies were prepared on a branch beside the stem (prep_weights)
         seen_trainable = False
-        for blk in self.blocks():
+        blocks = self.blocks()
+        a1_next = None                              # the next block's conv1 output when the previous tail already computed it
+        for bi, blk in enumerate(blocks):
             tr = blk.trainable() and keep is not None
             need_wd = tr and seen_trainable         # dgrad into this block's input only if something upstream trains
-            a1 = _conv_fwd(x, blk.conv1, blk.bn1, tr, RELU)
+            a1 = a1_next if a1_next is not None else _conv_fwd(x, blk.conv1, blk.bn1, tr, RELU)
+            a1_next = None
             a2 = _conv_fwd(a1, blk.conv2, blk.bn2, tr, RELU)
-            yb = _block_tail_fused(x, a2, blk, tr, need_wd) if (blk.downsample is not None and FUSED_TAIL and RT.dtype == torch.bfloat16) else None
+            yb = None
+            if FUSED_CHAIN and RT.dtype == torch.bfloat16 and bi + 1 < len(blocks):
+                nxt = blocks[bi + 1]
+                ch = _block_tail_chain(x, a2, blk, nxt, nxt.trainable() and keep is not None)
+                if ch is not None:
+                    yb, a1_next = ch
+            if yb is None:
+                yb = _block_tail_fused(x, a2, blk, tr, need_wd) if (blk.downsample is not None and FUSED_TAIL and RT.dtype == torch.bfloat16) else None
             if yb is None:
                 idt = x if blk.downsample is None else _conv_fwd(x, blk.downsample[0], blk.downsample[1], need_wd, hip.ACT_NONE)
                 yb = _conv_fwd(a2, blk.conv3, blk.bn3, tr, RELU, res=idt)

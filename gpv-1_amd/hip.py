@@ -101,7 +101,7 @@ EXPORTS = ['gpv_abi_version', 'gpv_build_id', 'gpv_set_option', 'gpv_gemm', 'gpv
            'gpv_softmax_ce', 'gpv_roi_weights', 'gpv_add', 'gpv_add_rowbcast', 'gpv_colsum', 'gpv_cast',
            'gpv_cast_rowscale_t', 'gpv_prep_conv_weight', 'gpv_embedding', 'gpv_dropout',
            'gpv_relevance_condition', 'gpv_adamw', 'gpv_sumsq', 'gpv_clip_scale', 'gpv_act_fwd', 'gpv_act_bwd', 'gpv_set_seed_device',
-           'gpv_gemm_tt_group', 'gpv_cast_transpose_group', 'gpv_stem_pool', 'gpv_image_pipeline', 'gpv_conv1x1_dual',
+           'gpv_gemm_tt_group', 'gpv_cast_transpose_group', 'gpv_stem_pool', 'gpv_image_pipeline', 'gpv_conv1x1_dual', 'gpv_conv1x1_chain',
            'gpv_conv_wgrad_group', 'gpv_jpeg_parse', 'gpv_jpeg_decode', 'gpv_argmax_rows', 'gpv_ln_linear_rows', 'gpv_attention_row_proj']
 
 
@@ -395,6 +395,23 @@ def conv1x1_dual(a1, w1, a2, w2, bias, y, B, OH, OW, K1, IH2, IW2, K2, s2, N, ac
     if err == 801:
         return False
     _chk(err, 'gpv_conv1x1_dual')
+    return True
+
+
+def conv1x1_chain(a1, w1, a2, w2, s2, res, bias, y, wn, bias_n, z, B, OH, OW):
+    """gpv_conv1x1_chain: y = relu(a1 . w1^T (+ a2[::s2] . w2^T) (+ res) + bias), z = relu(y . wn^T + bias_n) in one launch; False when
+    the shape is not one the kernel takes -- the caller then runs the convolutions one by one"""
+    ts = [t for t in (a1, w1, a2, w2, res, y, wn, z) if t is not None]
+    if not all(t.dtype == torch.bfloat16 for t in ts):
+        return False
+    K1, N, N2 = a1.shape[-1], y.shape[-1], z.shape[-1]
+    K2 = 0 if a2 is None else a2.shape[-1]
+    IH2, IW2 = (a2.shape[1], a2.shape[2]) if a2 is not None else (OH, OW)
+    err = lib().gpv_conv1x1_chain(_p(a1), _p(w1), K1, _p(a2), _p(w2), K2, IH2, IW2, s2, _p(res), _p(_f32(bias)), _p(y), B, OH, OW, N,
+                                  _p(wn), _p(_f32(bias_n)), _p(z), N2, _stream())
+    if err == 801:
+        return False
+    _chk(err, 'gpv_conv1x1_chain')
     return True
 
 

@@ -219,6 +219,18 @@ int gpv_jpeg_decode(const gpv_jpeg_desc* descs, int B, int max_blocks, int64_t m
  * hipErrorNotSupported (801) for anything else -- the caller then issues the two convolutions. */
 int gpv_conv1x1_dual(const void* a1, const void* w1, const void* a2, const void* w2, const float* bias, void* y, int B, int OH, int OW,
                      int K1, int IH2, int IW2, int K2, int s2, int N, int act, void* stream);
+
+/* A layer1 bottleneck tail AND the conv1 of the bottleneck that follows, one launch (torchvision Bottleneck.forward twice:
+ * exp/gpv/models/backbone.py:93-95; conv1 / layer1 are frozen, :61-63, so nothing in between is needed by a backward pass):
+ *   y[B,OH,OW,256] = relu( a1[B,OH,OW,K1] . w1[256,K1]^T (+ a2[B,IH2,IW2,K2] sampled at stride s2 . w2[256,K2]^T) (+ res) + bias )
+ *   z[B,OH,OW,N2]  = relu( y . wn[N2,256]^T + bias_n )
+ * bf16 operands and outputs, fp32 biases (FrozenBN shifts; the scales are folded into the weights).  The second GEMM consumes the
+ * rounded y out of registers: y is written once and not read back (314 MB at B = 32 in layer1).  Bit-identical to the two
+ * launches.  K1 = 64, K2 in {0, 64} (a2 = w2 = NULL when 0), N = 256, N2 in {64, 128}; res (identity branch) and a2 (downsample
+ * branch) are mutually exclusive; anything else: hipErrorNotSupported (801), the caller then launches the convolutions separately. */
+int gpv_conv1x1_chain(const void* a1, const void* w1, int K1, const void* a2, const void* w2, int K2, int IH2, int IW2, int s2,
+                      const void* res, const float* bias, void* y, int B, int OH, int OW, int N, const void* wn,
+                      const float* bias_n, void* z, int N2, void* stream);
 /* The whole ResNet stem in one launch (exp/gpv/models/backbone.py:93-95 -> torchvision resnet50 conv1 + bn1 (frozen: scale folded
  * into w, shift here) + relu + maxpool):  y[B,PH,PW,64] = maxpool3x3s2p1(relu(conv7x7s2(x) + shift)).  x = the zero-padded NHWC4
  * bf16 image gpv_image_to_nhwc4 writes with pad 3 ([B,Hp,Wp,4], Wp even, >= 2 (CW - 1) + 8), w = [64][7][8 px][4 ch] bf16 (8th pixel /

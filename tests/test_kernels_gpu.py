@@ -1229,6 +1229,50 @@ def test_fused_block_tail_conv3_plus_downsample(K1, K2, N, s2, OH, OW, Bn):
     assert not h.conv1x1_dual(a2[..., :32].contiguous(), w3[:, :32].contiguous(), x, wd, b3, y, Bn, OH, OW, 32, IH, IW, K2, s2, N, h.ACT_RELU)
 
 
+@pytest.mark.parametrize('branch', ['identity', 'downsample', 'plain'])
+@pytest.mark.parametrize('N2,OH,OW,Bn', [(64, 24, 32, 3), (128, 7, 9, 5), (64, 120, 160, 2)])
+def test_conv1x1_chain_equals_the_two_launches(branch, N2, OH, OW, Bn):
+    """gpv_conv1x1_chain (conv1x1_chain.hip): a layer1 bottleneck tail -- conv3 + identity | conv3 + downsample | conv3 alone, ReLU --
+    and the next bottleneck's conv1 + ReLU in one launch: y BIT-IDENTICAL to the launch it replaces (gpv_conv2d with the residual
+    epilogue / gpv_conv1x1_dual), z bit-identical to gpv_conv2d on that y (same products, same fp32 order; streaming kernel forced so
+    that small maps take the same path as the bench shapes), both within bf16 rounding of fp32 torch; unsupported shapes decline"""
+    h, dtype = hip(), torch.bfloat16
+    K1, N = 64, 256
+    a = rnd(Bn, OH, OW, K1, dtype=dtype, seed=170)
+    w3 = rnd(N, K1, dtype=dtype, seed=171, scale=1.0 / math.sqrt(K1))
+    b3 = rnd(N, seed=172)
+    wn = rnd(N2, N, dtype=dtype, seed=173, scale=1.0 / math.sqrt(N))
+    bn_ = rnd(N2, seed=174)
+    x = rnd(Bn, OH, OW, N if branch == 'identity' else 64, dtype=dtype, seed=175)
+    wd = rnd(N, 64, dtype=dtype, seed=176, scale=0.125)
+    y = torch.full((Bn, OH, OW, N), float('nan'), device=DEV, dtype=dtype)
+    z = torch.full((Bn, OH, OW, N2), float('nan'), device=DEV, dtype=dtype)
+    prev = h.set_option(h.OPT_C1S, 2)
+    try:
+        y_ref = torch.empty_like(y)
+        if branch == 'identity':
+            assert h.conv1x1_chain(a, w3, None, None, 1, x, b3, y, wn, bn_, z, Bn, OH, OW)
+            h.conv2d(0, a, w3.view(N, 1, K1), y_ref, Bn, OH, OW, K1, K1, OH, OW, N, 1, 1, 1, 1, 0, 0, bias=b3, res=x, act=h.ACT_RELU)
+            ref = F.relu(a.float() @ w3.float().t() + b3 + x.float())
+        elif branch == 'downsample':
+            assert h.conv1x1_chain(a, w3, x, wd, 1, None, b3, y, wn, bn_, z, Bn, OH, OW)
+            assert h.conv1x1_dual(a, w3, x, wd, b3, y_ref, Bn, OH, OW, K1, OH, OW, 64, 1, N, h.ACT_RELU)
+            ref = F.relu(a.float() @ w3.float().t() + x.float() @ wd.float().t() + b3)
+        else:
+            assert h.conv1x1_chain(a, w3, None, None, 1, None, b3, y, wn, bn_, z, Bn, OH, OW)
+            h.conv2d(0, a, w3.view(N, 1, K1), y_ref, Bn, OH, OW, K1, K1, OH, OW, N, 1, 1, 1, 1, 0, 0, bias=b3, act=h.ACT_RELU)
+            ref = F.relu(a.float() @ w3.float().t() + b3)
+        z_ref = torch.empty_like(z)
+        h.conv2d(0, y_ref, wn.view(N2, 1, N), z_ref, Bn, OH, OW, N, N, OH, OW, N2, 1, 1, 1, 1, 0, 0, bias=bn_, act=h.ACT_RELU)
+    finally:
+        h.set_option(h.OPT_C1S, prev)
+    assert torch.equal(y, y_ref) and torch.equal(z, z_ref)
+    assert rel(y, ref) < TOL[dtype]
+    assert rel(z, F.relu(y.float() @ wn.float().t() + bn_)) < TOL[dtype]
+    a32 = a[..., :32].contiguous()
+    assert not h.conv1x1_chain(a32, w3[:, :32].contiguous(), None, None, 1, None, b3, y, wn, bn_, z, Bn, OH, OW)
+
+
 def test_clip_scale_is_deterministic_and_matches_torch():
     """gpv_clip_scale: min(1, max_norm / (||g|| + 1e-6)) over a flat fp32 range (train_distr.py:423-425), fixed summation order:
     bit-identical over repeated launches (what keeps data-parallel replicas identical), equal to torch's clip factor to fp32

@@ -36,7 +36,7 @@ names = {}
 for n, m in body.named_modules():
     if isinstance(m, bbm.ConvW):
         names[id(m)] = n
-ENTRY = ('conv2d', 'maxpool3x3s2', 'image_to_nhwc4', 'act_bwd', 'stem_pool', 'conv1x1_dual', 'conv_wgrad_group')
+ENTRY = ('conv2d', 'maxpool3x3s2', 'image_to_nhwc4', 'act_bwd', 'stem_pool', 'conv1x1_dual', 'conv1x1_chain', 'conv_wgrad_group')
 orig = {k: getattr(hip, k) for k in ENTRY}
 phase = ['fwd']
 
@@ -73,6 +73,14 @@ def describe(k, a, kw):
         a1, w1, a2, w2, bias, y, B, OH, OW, K1, IH2, IW2, K2, s2, N = a[:15]
         by = B * OH * OW * K1 * 2 + B * IH2 * IW2 * K2 * 2 / (s2 * s2) + B * OH * OW * N * 2 + N * (K1 + K2) * 2
         return 'fwd  %d+%d->%4d conv3+downsample/%d %3dx%3d' % (K1, K2, N, s2, OH, OW), by, 2.0 * B * OH * OW * N * (K1 + K2)
+    if k == 'conv1x1_chain':
+        a1, w1, a2, w2, s2, res, bias, y, wn, bias_n, z, B, OH, OW = a[:14]
+        K1, N, N2 = a1.shape[-1], y.shape[-1], z.shape[-1]
+        K2 = 0 if a2 is None else a2.shape[-1]
+        px = B * OH * OW
+        # algorithmic bytes of the TWO convolutions it replaces (bench.py's yardstick): conv3 (+ downsample | + residual) and the next conv1, which re-reads y
+        by = px * (K1 + K2) * 2 + px * N * 2 * (2 if res is not None else 1) + N * (K1 + K2) * 2 + px * N * 2 + px * N2 * 2 + N2 * N * 2
+        return 'fwd  %d%s->%d->%d tail + next conv1 %3dx%3d' % (K1, ('+%d' % K2) if K2 else ('+id' if res is not None else ''), N, N2, OH, OW), by, 2.0 * px * (N * (K1 + K2) + N2 * N)
     if k == 'conv_wgrad_group':
         by = fl = 0.0
         for x, dy, dw, scale, B, IH, IW, Cs, Cin, OH, OW, Cout, KH, KW, SH, SW, PH, PW in a[0]:
@@ -108,7 +116,7 @@ for ph, k, a, kw in calls:
     if args.filter and args.filter not in nm:
         continue
     fn = orig[k]
-    if k == 'conv1x1_dual' and not fn(*a, **kw):
+    if k in ('conv1x1_dual', 'conv1x1_chain') and not fn(*a, **kw):
         continue                                     # (declined: the two convolutions that follow in the list did the work)
     for _ in range(3):
         fn(*a, **kw)
