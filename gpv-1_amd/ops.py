@@ -87,17 +87,20 @@ def off_critical_path(fn, *tensors):
     RT.defer_list.append((fn, tensors, None))
 
 
-def wgrad_linear(dz, x2, wg, bg, N, K, M, split):
+def wgrad_linear(dz, x2, wg, bg, N, K, M, split, lda=None):
     """dW[N,K] += dz[M,N]^T x2[M,K] (+ bias gradient = column sums of dz): in place, or -- while a backward is being captured --
-    handed to the deferred list as a PROBLEM (train.GraphedBody groups the eligible ones into gpv_gemm_tt_group launches)"""
+    handed to the deferred list as a PROBLEM (train.GraphedBody groups the eligible ones into gpv_gemm_tt_group launches).
+    lda: row pitch of dz when it is a column slice of a wider buffer (multi_linear)"""
+    lda = N if lda is None else lda
+
     def run():
-        hip.gemm(dz, x2, wg, N, K, M, N, K, K, layoutA=hip.TRANS, layoutB=hip.TRANS, accumulate=True, split_k=split, a_rowsum=bg)
+        hip.gemm(dz, x2, wg, N, K, M, lda, K, K, layoutA=hip.TRANS, layoutB=hip.TRANS, accumulate=True, split_k=split, a_rowsum=bg)
     if RT.defer_list is None:
         run()
         return
     prob = None
-    if wg.stride(1) == 1 and hip.tt_group_ok(dz, x2, wg, N, K, M, N, K, wg.stride(0)):
-        prob = (dz, x2, wg, bg, N, K, M, N, K, wg.stride(0))
+    if wg.stride(1) == 1 and hip.tt_group_ok(dz, x2, wg, N, K, M, lda, K, wg.stride(0)):
+        prob = (dz, x2, wg, bg, N, K, M, lda, K, wg.stride(0))
     RT.defer_list.append((run, (dz, x2), prob))
 
 
@@ -333,6 +336,81 @@ def check_chains(clear=True, chains=None):
         del GradChain._live[:]
     if bad:
         raise RuntimeError('%d GradChain(s) ended a backward pass half walked: a chained consumer did not run' % bad)
+
+
+class GradSink(GradChain):
+    """The gradient of ONE wide buffer whose column slices are consumed by several attention calls (the DETR decoder's cross-
+    attention keys / values of all layers, projected by one GEMM: multi_linear): every consumer's backward writes its columns
+    straight into the shared gradient buffer (`acc`), the last one hands the complete buffer to autograd, the others return None --
+    instead of one zero-filled full-width gradient per slice summed by autograd.  Registered with the chains: check_chains()
+    raises if a backward pass left it half written."""
+
+    def __init__(self, n):
+        super().__init__()
+        self.total = self.left = n
+
+    def slot(self, like):
+        if self.acc is None:
+            self.acc = torch.empty_like(like)
+        return self.acc
+
+    def wrote(self):
+        self.left -= 1
+        if self.left == 0:
+            g, self.acc, self.left = self.acc, None, self.total
+            return g
+        return None
+
+
+class MultiLinearFn(Function):
+    """y[M, n*N] = x [M, K] . [W_0; W_1; ...]^T + [b_0; b_1; ...]: n Linear layers of equal width on the SAME input as one GEMM over
+    the concatenated weights (the six DETR decoder layers' cross-attention key -- or value -- projections of the encoder memory,
+    transformer.py:221-225: memory is layer-invariant).  Backward: one GEMM dx = dy . Wcat (K = n*N) instead of n chained ones,
+    weight gradients per layer from the column slices of dy (row pitch n*N)."""
+
+    @staticmethod
+    def forward(ctx, x, ws):
+        K, N, n = ws[0].K, ws[0].N, len(ws)
+        x2 = _c(_as_compute(x)).reshape(-1, K)
+        M = x2.shape[0]
+        wcat = torch.cat([w.lp() for w in ws], 0)                              # [n*N, K] compute dtype (weights change every step)
+        bcat = torch.cat([w.bias_f32() for w in ws], 0) if ws[0].bias is not None else None
+        y = torch.empty(M, n * N, device=x.device, dtype=RT.dtype)
+        hip.gemm(x2, wcat, y, M, n * N, K, K, K, n * N, bias=bcat)
+        ctx.ws, ctx.xshape = ws, x.shape
+        ctx.save_for_backward(x2)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        ws = ctx.ws
+        (x2,) = ctx.saved_tensors
+        K, N, n = ws[0].K, ws[0].N, len(ws)
+        M = x2.shape[0]
+        dz = _c(_as_compute(dy)).reshape(M, n * N)
+        for i, w in enumerate(ws):
+            need_b = w.bias is not None and w.bias.requires_grad
+            if w.weight.requires_grad:
+                wgrad_linear(dz[:, i * N:(i + 1) * N], x2, w.wgrad(), w.bgrad() if need_b else None, N, K, M, _split_k(N, K, M), lda=n * N)
+            elif need_b:
+                hip.colsum(dz[:, i * N:(i + 1) * N], w.bgrad(), M, N, n * N)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(M, K, device=dz.device, dtype=RT.dtype)
+            if all(w.mirror_ok() for w in ws):
+                wT = torch.cat([w.lpT() for w in ws], 1)                       # [K, n*N]: K-major x K-major on the pipelined kernels
+                hip.gemm(dz, wT, dx, M, K, n * N, n * N, n * N, K)
+            else:
+                hip.gemm(dz, torch.cat([w.lp() for w in ws], 0), dx, M, K, n * N, n * N, K, K, layoutB=hip.TRANS)
+            dx = dx.reshape(ctx.xshape)
+        return dx, None
+
+
+def multi_linear(x, ws):
+    dummy_needed = torch.is_grad_enabled() and not x.requires_grad and any(w.weight.requires_grad for w in ws)
+    if dummy_needed:                     # (no caller needs it: the decoder memory always carries a gradient when its weights train)
+        raise RuntimeError('multi_linear: input without gradient but trainable weights')
+    return MultiLinearFn.apply(x, tuple(ws))
 
 
 # --------------------------------------------------------------------------------------------
@@ -635,7 +713,7 @@ class AttentionFn(Function):
 
     @staticmethod
     def forward(ctx, meta, *bufs):
-        roles, B, H, Sq, Sk, dh, kpm, causal, drop_p = meta
+        roles, B, H, Sq, Sk, dh, kpm, causal, drop_p = meta[:9]
         D = H * dh
         bufs = tuple(_c(_as_compute(b)) for b in bufs)
         (qi, qo), (ki, ko), (vi, vo) = roles
@@ -653,20 +731,24 @@ class AttentionFn(Function):
 
     @staticmethod
     def backward(ctx, do):
-        roles, B, H, Sq, Sk, dh, kpm, causal, drop_p = ctx.meta
+        roles, B, H, Sq, Sk, dh, kpm, causal, drop_p = ctx.meta[:9]
+        sinks = ctx.meta[9] if len(ctx.meta) > 9 and ctx.meta[9] is not None else (None,) * (len(ctx.saved_tensors) - 2)
         D = H * dh
         o, lse, *bufs = ctx.saved_tensors
         (qi, qo), (ki, ko), (vi, vo) = roles
         do = _c(_as_compute(do))
-        grads = [torch.empty_like(b) for b in bufs]
+        # a buffer with a GradSink is shared with other attention calls (column slices of one wide projection): its gradient
+        # columns are written into the sink's buffer, which the last writer hands to autograd
+        grads = [torch.empty_like(b) if s is None else s.slot(b) for b, s in zip(bufs, sinks)]
         hip.attention_bwd(bufs[qi][:, qo:], bufs[ki][:, ko:], bufs[vi][:, vo:], o, do,
                           grads[qi][:, qo:], grads[ki][:, ko:], grads[vi][:, vo:], ctx.st, (Sq * D, D),
                           B, H, Sq, Sk, dh, ctx.scale, kpm=kpm, causal=causal, drop_p=drop_p, seed=ctx.seed, lse=lse)
-        return (None, *grads)
+        return (None, *[g if s is None else s.wrote() for g, s in zip(grads, sinks)])
 
 
-def attention(bufs, roles, B, H, Sq, Sk, dh, kpm=None, causal=False, drop_p=0.0):
-    return AttentionFn.apply((roles, B, H, Sq, Sk, dh, kpm, causal, drop_p), *bufs)
+def attention(bufs, roles, B, H, Sq, Sk, dh, kpm=None, causal=False, drop_p=0.0, sinks=None):
+    """sinks: per buffer None or the ops.GradSink of a buffer shared with other attention calls (see AttentionFn.backward)"""
+    return AttentionFn.apply((roles, B, H, Sq, Sk, dh, kpm, causal, drop_p, sinks), *bufs)
 
 
 # --------------------------------------------------------------------------------------------

@@ -6,11 +6,15 @@ layers only (configs/exp/gpv.yaml: pre_norm False).  Internally batch-first: act
     projection GEMM(s) -> attention kernel -> out-proj GEMM -> fused (residual + dropout + LayerNorm)
     -> FFN GEMM (bias+ReLU+dropout epilogue) -> GEMM -> fused (residual + dropout + LayerNorm).
 """
+import os
+
 import torch
 import torch.nn as nn
 
 from . import ops
 from .ops import W
+
+HOIST_KV = os.environ.get('GPV_HOIST_KV', '1') != '0'       # decoder cross-attention K / V of all layers as two GEMMs (ops.multi_linear)
 
 
 class LinearP(nn.Module):
@@ -58,12 +62,21 @@ class MultiheadAttention(nn.Module):
         nn.init.xavier_uniform_(self.in_proj_weight)
         nn.init.constant_(self.out_proj.bias, 0.)
 
-    def forward(self, q_in, k_in, v_in, B, Sq, Sk, key_padding_mask=None, causal=False, chains=(None, None, None)):
+    def forward(self, q_in, k_in, v_in, B, Sq, Sk, key_padding_mask=None, causal=False, chains=(None, None, None), kv=None):
         """chains: ops.GradChain (or None) of the tensor behind q_in / k_in / v_in -- only where the projection's input gradient
-        IS that tensor's gradient (the input itself, or input + a constant position term)"""
+        IS that tensor's gradient (the input itself, or input + a constant position term).
+        kv = (K_all, V_all, column offset, sink_K, sink_V): keys / values already projected, as column slices of buffers shared with
+        other layers (Transformer.forward: ops.multi_linear over all decoder layers); k_in / v_in are then unused"""
         E = self.embed_dim
         w, b = self.in_proj_weight, self.in_proj_bias
         cq, ck, cv = chains
+        if kv is not None:
+            k_all, v_all, col, sk, sv = kv
+            bufs = [ops.linear(q_in, W(w, b, 0, E), chain=cq), k_all, v_all]
+            o = ops.attention(bufs, ((0, 0), (1, col), (2, col)), B, self.num_heads, Sq, Sk, self.head_dim, kpm=key_padding_mask,
+                              causal=causal, drop_p=self.dropout if self.training else 0.0,
+                              sinks=(None, sk, sv) if (sk is not None or sv is not None) else None)
+            return self.out_proj(o)
         if q_in is k_in and k_in is v_in:
             bufs = [ops.linear(q_in, W(w, b, 0, 3 * E), chain=cq)]
             roles = ((0, 0), (0, E), (0, 2 * E))
@@ -114,7 +127,7 @@ class TransformerDecoderLayer(nn.Module):
         self.norm3 = LayerNormP(d_model)
         self.p = dropout
 
-    def forward(self, tgt, tgt_qp, memory, mem_pos, qpos, qpos_param, B, Q, S, kpm, mem_chain=None, emit=True):
+    def forward(self, tgt, tgt_qp, memory, mem_pos, qpos, qpos_param, B, Q, S, kpm, mem_chain=None, emit=True, kv=None):
         """transformer.py:211-232 (forward_post); mem_pos = memory + pos is layer-invariant.  mem_chain: the GradChain of the
         encoder memory, shared by the K (through memory + pos) and V projections of all six layers.
         tgt_qp = tgt + query_pos arrives with tgt (second output of the LayerNorm that produced tgt); norm1 emits the
@@ -126,7 +139,7 @@ class TransformerDecoderLayer(nn.Module):
         ch = ops.grad_chain(tgt)                 # tgt feeds norm1's residual and Wv (and, through tgt + query_pos, Wqk)
         tgt, tq = self.norm1(tgt, self.self_attn(tgt_qp, tgt_qp, tgt, B, Q, Q, chains=(None, None, ch)), p, chain=ch,
                              pos=qpos, pos_param=qpos_param)
-        a = self.multihead_attn(tq, mem_pos, memory, B, Q, S, kpm, chains=(None, mem_chain, mem_chain))
+        a = self.multihead_attn(tq, mem_pos, memory, B, Q, S, kpm, chains=(None, mem_chain, mem_chain), kv=kv)
         tgt = self.norm2(tgt, a, p)
         if not emit:
             return ffn_block(tgt, self.linear1, self.linear2, self.norm3, p), None
@@ -177,17 +190,29 @@ class Transformer(nn.Module):
             for layer in self.encoder.layers:
                 x, xq = layer(x, xq, pe, B, S, kpm)
         memory = ops.boundary(x, 'mem')           # (backward: every decoder layer has run when the gradient arrives here)
-        mem_chain = ops.grad_chain(memory)
         mem_pos = xq                              # memory + pos: the last encoder LayerNorm's second output
+        n = len(self.decoder.layers)
+        k_all = v_all = sk = sv = mem_chain = None
+        if HOIST_KV and n > 1:
+            # the cross-attention keys / values of ALL decoder layers: memory is layer-invariant, so the 2 n projections of it are
+            # two GEMMs over the concatenated weights (9600 x 256 -> 1536 at B = 32 instead of twelve 9600 x 256 -> 256), and
+            # their backward-data one GEMM each with K = 1536 instead of twelve chained ones
+            ca = [l.multihead_attn for l in self.decoder.layers]
+            k_all = ops.multi_linear(mem_pos, [W(a.in_proj_weight, a.in_proj_bias, C, 2 * C) for a in ca])
+            v_all = ops.multi_linear(memory, [W(a.in_proj_weight, a.in_proj_bias, 2 * C, 3 * C) for a in ca])
+            if torch.is_grad_enabled() and k_all.requires_grad:
+                sk, sv = ops.GradSink(n), ops.GradSink(n)
+        else:
+            mem_chain = ops.grad_chain(memory)
         qp = query_embed.detach().to(ops.RT.dtype).contiguous()                     # [Q, C] rows for the LayerNorm kernels
         tgt = torch.zeros(B * Q, C, device=src.device, dtype=ops.RT.dtype)
         # layer 0: tgt = 0, so tgt + query_pos IS query_pos (bit-identical to the add); its gradient reaches query_embed through
         # autograd (expand), the later layers' through ops._pos_sink
         tq = query_embed.to(ops.RT.dtype).unsqueeze(0).expand(B, Q, C).reshape(B * Q, C)
         outs = []
-        n = len(self.decoder.layers)
         for i, layer in enumerate(self.decoder.layers):
-            tgt, tq = layer(tgt, tq, memory, mem_pos, qp, query_embed, B, Q, S, kpm, mem_chain, emit=i + 1 < n)
+            tgt, tq = layer(tgt, tq, memory, mem_pos, qp, query_embed, B, Q, S, kpm, mem_chain, emit=i + 1 < n,
+                            kv=None if k_all is None else (k_all, v_all, i * C, sk, sv))
             if need_all_layers or i == n - 1:
                 outs.append(self.decoder.norm(tgt).reshape(B, Q, C))
         return outs, memory.reshape(B, S, C)
