@@ -22,6 +22,7 @@ from .ops import W, RT
 from .detr import create_detr, create_detr_roi_head
 from .bert import Bert
 from .vilbert import BertConnectionLayer
+from . import transformer as transformer_mod
 from .transformer import LinearP, LayerNormP, MultiheadAttention, ffn_block
 from .criterion import GPVCriterion
 from .misc import AttrDict, NestedTensor
@@ -57,13 +58,14 @@ class TextDecoderLayer(nn.Module):
         self.norm1, self.norm2, self.norm3 = LayerNormP(d_model), LayerNormP(d_model), LayerNormP(d_model)
         self.p = dropout
 
-    def forward(self, tgt, memory, B, Tt, Tm, mem_chain=None, mem_kpm=None):
+    def forward(self, tgt, memory, B, Tt, Tm, mem_chain=None, mem_kpm=None, kv=None):
+        """kv: the cross-attention keys | values of this layer as columns of the buffer GPV.decode_text projected for all layers"""
         p = self.p if self.training else 0.0
         c0 = ops.grad_chain(tgt)                       # (ops.GradChain: tgt feeds the projection and the residual)
         tgt = self.norm1(tgt, self.self_attn(tgt, tgt, tgt, B, Tt, Tt, causal=True, chains=(c0, c0, c0)), p, chain=c0)
         c1 = ops.grad_chain(tgt)
         tgt = self.norm2(tgt, self.multihead_attn(tgt, memory, memory, B, Tt, Tm, key_padding_mask=mem_kpm,
-                                                  chains=(c1, mem_chain, mem_chain)), p,
+                                                  chains=(c1, mem_chain, mem_chain), kv=kv), p,
                          chain=c1)                     # no memory padding mask in the reference (mem_kpm: size-class padding only)
         return ffn_block(tgt, self.linear1, self.linear2, self.norm3, p)
 
@@ -229,8 +231,18 @@ class GPV(nn.Module):
             target = ops.add(target.reshape(B * Tt, D), self.pos_enc[0, :Tt].to(RT.dtype)).reshape(B, Tt, D)
         x = target.reshape(B * Tt, D)
         mem = memory.reshape(B * Tm, D)
+        layers = self.text_decoder.layers
+        if transformer_mod.HOIST_KV and len(layers) > 1:
+            # the co-attention output feeds the k | v projection of every layer: one GEMM over the concatenated weights
+            # (ops.multi_linear), one gradient buffer the layers' attention backwards fill (ops.GradSink)
+            ws = [W(l.multihead_attn.in_proj_weight, l.multihead_attn.in_proj_bias, D, 3 * D) for l in layers]
+            kv_all = ops.multi_linear(mem, ws)
+            sink = ops.GradSink(len(layers)) if (torch.is_grad_enabled() and kv_all.requires_grad) else None
+            for i, layer in enumerate(layers):
+                x = layer(x, mem, B, Tt, Tm, None, mem_kpm, kv=(kv_all, 2 * D * i, kv_all, 2 * D * i + D, sink, sink))
+            return self.answer_head(x).reshape(B, Tt, -1)
         mem_chain = ops.grad_chain(mem)                # the co-attention output feeds the K|V projection of every layer
-        for layer in self.text_decoder.layers:
+        for layer in layers:
             x = layer(x, mem, B, Tt, Tm, mem_chain, mem_kpm)
         return self.answer_head(x).reshape(B, Tt, -1)
 

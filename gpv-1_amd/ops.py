@@ -362,6 +362,32 @@ class GradSink(GradChain):
         return None
 
 
+class GradSlots(GradSink):
+    """GradSink for consumers that may NOT all run in a backward pass (the co-attention layer's two attention calls: a
+    detection-only batch gives the language stream of the last layer no gradient): the first writer allocates the buffer
+    zero-filled and hands it to autograd at once, later writers fill their columns in place (same stream, before the buffer's
+    consumer runs) and return None; the consumer (MultiLinearFn.backward) releases it."""
+
+    def __init__(self):
+        super().__init__(0)
+        self.fresh = False
+
+    def slot(self, like):
+        if self.acc is None:
+            self.acc = torch.zeros_like(like)
+            self.fresh = True
+        return self.acc
+
+    def wrote(self):
+        if self.fresh:
+            self.fresh = False
+            return self.acc
+        return None
+
+    def release(self):
+        self.acc, self.fresh = None, False
+
+
 class MultiLinearFn(Function):
     """y[M, n*N] = x [M, K] . [W_0; W_1; ...]^T + [b_0; b_1; ...]: n Linear layers of equal width on the SAME input as one GEMM over
     the concatenated weights (the six DETR decoder layers' cross-attention key -- or value -- projections of the encoder memory,
@@ -369,7 +395,8 @@ class MultiLinearFn(Function):
     weight gradients per layer from the column slices of dy (row pitch n*N)."""
 
     @staticmethod
-    def forward(ctx, x, ws):
+    def forward(ctx, x, ws, sink=None):
+        ctx.sink = sink
         K, N, n = ws[0].K, ws[0].N, len(ws)
         x2 = _c(_as_compute(x)).reshape(-1, K)
         M = x2.shape[0]
@@ -388,6 +415,8 @@ class MultiLinearFn(Function):
         K, N, n = ws[0].K, ws[0].N, len(ws)
         M = x2.shape[0]
         dz = _c(_as_compute(dy)).reshape(M, n * N)
+        if ctx.sink is not None:
+            ctx.sink.release()
         for i, w in enumerate(ws):
             need_b = w.bias is not None and w.bias.requires_grad
             if w.weight.requires_grad:
@@ -403,14 +432,15 @@ class MultiLinearFn(Function):
             else:
                 hip.gemm(dz, torch.cat([w.lp() for w in ws], 0), dx, M, K, n * N, n * N, K, K, layoutB=hip.TRANS)
             dx = dx.reshape(ctx.xshape)
-        return dx, None
+        return dx, None, None
 
 
-def multi_linear(x, ws):
+def multi_linear(x, ws, sink=None):
+    """sink: the ops.GradSlots through which the consumers deliver this output's gradient (released by the backward)"""
     dummy_needed = torch.is_grad_enabled() and not x.requires_grad and any(w.weight.requires_grad for w in ws)
-    if dummy_needed:                     # (no caller needs it: the decoder memory always carries a gradient when its weights train)
+    if dummy_needed:                     # (no caller needs it: these inputs always carry a gradient when the weights train)
         raise RuntimeError('multi_linear: input without gradient but trainable weights')
-    return MultiLinearFn.apply(x, tuple(ws))
+    return MultiLinearFn.apply(x, tuple(ws), sink)
 
 
 # --------------------------------------------------------------------------------------------

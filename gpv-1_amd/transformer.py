@@ -65,17 +65,22 @@ class MultiheadAttention(nn.Module):
     def forward(self, q_in, k_in, v_in, B, Sq, Sk, key_padding_mask=None, causal=False, chains=(None, None, None), kv=None):
         """chains: ops.GradChain (or None) of the tensor behind q_in / k_in / v_in -- only where the projection's input gradient
         IS that tensor's gradient (the input itself, or input + a constant position term).
-        kv = (K_all, V_all, column offset, sink_K, sink_V): keys / values already projected, as column slices of buffers shared with
-        other layers (Transformer.forward: ops.multi_linear over all decoder layers); k_in / v_in are then unused"""
+        kv = (K buffer, key column, V buffer, value column, sink_K, sink_V): keys / values already projected, as column slices of
+        buffers shared with other layers (ops.multi_linear over all decoder layers; K and V may be the SAME buffer, then one
+        sink); k_in / v_in are then unused"""
         E = self.embed_dim
         w, b = self.in_proj_weight, self.in_proj_bias
         cq, ck, cv = chains
         if kv is not None:
-            k_all, v_all, col, sk, sv = kv
-            bufs = [ops.linear(q_in, W(w, b, 0, E), chain=cq), k_all, v_all]
-            o = ops.attention(bufs, ((0, 0), (1, col), (2, col)), B, self.num_heads, Sq, Sk, self.head_dim, kpm=key_padding_mask,
+            k_all, kcol, v_all, vcol, sk, sv = kv
+            q = ops.linear(q_in, W(w, b, 0, E), chain=cq)
+            if k_all is v_all:
+                bufs, roles, sinks = [q, k_all], ((0, 0), (1, kcol), (1, vcol)), (None, sk)
+            else:
+                bufs, roles, sinks = [q, k_all, v_all], ((0, 0), (1, kcol), (2, vcol)), (None, sk, sv)
+            o = ops.attention(bufs, roles, B, self.num_heads, Sq, Sk, self.head_dim, kpm=key_padding_mask,
                               causal=causal, drop_p=self.dropout if self.training else 0.0,
-                              sinks=(None, sk, sv) if (sk is not None or sv is not None) else None)
+                              sinks=sinks if (sk is not None or sv is not None) else None)
             return self.out_proj(o)
         if q_in is k_in and k_in is v_in:
             bufs = [ops.linear(q_in, W(w, b, 0, 3 * E), chain=cq)]
@@ -212,7 +217,7 @@ class Transformer(nn.Module):
         outs = []
         for i, layer in enumerate(self.decoder.layers):
             tgt, tq = layer(tgt, tq, memory, mem_pos, qp, query_embed, B, Q, S, kpm, mem_chain, emit=i + 1 < n,
-                            kv=None if k_all is None else (k_all, v_all, i * C, sk, sv))
+                            kv=None if k_all is None else (k_all, i * C, v_all, i * C, sk, sv))
             if need_all_layers or i == n - 1:
                 outs.append(self.decoder.norm(tgt).reshape(B, Q, C))
         return outs, memory.reshape(B, S, C)

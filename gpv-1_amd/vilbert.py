@@ -8,12 +8,16 @@ kernel (dh = 48, K-dim padded to 64); residual+dropout+LayerNorm is one kernel, 
 that keeps the pre-activation for backward.  Parameter names match the reference so checkpoints load,
 including the declared-but-unused q_dense1/q_dense2 (vilbert.py:835-843).
 """
+import os
+
 import torch
 import torch.nn as nn
 
 from . import ops
 from .ops import W
 from .transformer import LinearP, LayerNormP
+
+FUSE_QKV = os.environ.get('GPV_COATT_QKV', '1') != '0'
 
 
 class BertBiAttention(nn.Module):
@@ -39,11 +43,23 @@ class BertBiAttention(nn.Module):
         output of the last layer no gradient).  ctx2 -> stream 1's output uses q1, k2, v2; ctx1 -> stream 2's output uses q2, k1, v1:
         own1 / own2 = the chain query_i shares with stream i's residual LayerNorm; k_i, v_i form a chain of their own."""
         H, dh, D = self.num_attention_heads, self.attention_head_size, self.all_head_size
+        p1 = self.p1 if self.training else 0.0
+        p2 = self.p2 if self.training else 0.0
+        if FUSE_QKV and t1.shape[-1] == t2.shape[-1]:
+            # q | k | v of a stream as ONE GEMM over the three concatenated weights (ops.multi_linear: 6 projection launches -> 2, and
+            # 2 backward-data GEMMs with K = 3 D instead of 6); both attention calls read column slices of the two buffers and
+            # write their gradient columns into shared buffers (ops.GradSlots: either call may be absent from a backward pass)
+            grad = torch.is_grad_enabled() and (t1.requires_grad or t2.requires_grad)
+            s1, s2 = (ops.GradSlots(), ops.GradSlots()) if grad else (None, None)
+            qkv1 = ops.multi_linear(t1, [W(m.weight, m.bias) for m in (self.query1, self.key1, self.value1)], s1)
+            qkv2 = ops.multi_linear(t2, [W(m.weight, m.bias) for m in (self.query2, self.key2, self.value2)], s2)
+            roles = ((0, 0), (1, D), (1, 2 * D))
+            ctx1 = ops.attention([qkv2, qkv1], roles, B, H, T2, T1, dh, kpm=kpm1, drop_p=p1, sinks=(s2, s1) if grad else None)
+            ctx2 = ops.attention([qkv1, qkv2], roles, B, H, T1, T2, dh, drop_p=p2, sinks=(s1, s2) if grad else None)
+            return ctx1, ctx2
         x1, x2 = ops.grad_chain(t1), ops.grad_chain(t2)
         q1, k1, v1 = self.query1(t1, chain=own1), self.key1(t1, chain=x1), self.value1(t1, chain=x1)
         q2, k2, v2 = self.query2(t2, chain=own2), self.key2(t2, chain=x2), self.value2(t2, chain=x2)
-        p1 = self.p1 if self.training else 0.0
-        p2 = self.p2 if self.training else 0.0
         # scores1 = q2 k1^T -> probs (dropout1) @ v1 : vision queries over language keys (vilbert.py:770-787)
         ctx1 = ops.attention([q2, k1, v1], ((0, 0), (1, 0), (2, 0)), B, H, T2, T1, dh, kpm=kpm1, drop_p=p1)
         # scores2 = q1 k2^T -> probs (dropout2) @ v2 : language queries over vision keys (:790-810)
