@@ -38,6 +38,7 @@ class Runtime:
         self.seed_dev = None             # device int64 word lent to the library as the dropout seed epoch (hipGraph replays)
         self.defer_list = None           # set by train.GraphedBody while it captures a backward: deferred weight-gradient launches
         self.backward_boundary = None    # callback(tag) from ops.BoundaryFn.backward (same capture)
+        self.multi_wait = None           # set by train.GraphedBody while it captures F2: joins the branch that ran refresh_multi
 
     def set_precise(self, on=True):
         self.dtype = torch.float32 if on else torch.bfloat16
@@ -388,6 +389,52 @@ class GradSlots(GradSink):
         self.acc, self.fresh = None, False
 
 
+# concatenated compute copies of the weights behind a multi_linear site: [n*N, K] (forward), [K, n*N] (backward-data), fp32 biases.
+# They change with every optimizer step; built once per weights epoch -- inline on first use, or, under train.GraphedBody, for all
+# registered sites on the weight branch of F2 (refresh_multi) beside the transformer's chain, where three concatenation launches per
+# site cost nothing (in line they were 29 launches / 190 us per step)
+_MULTI = {}
+
+
+def _multi_key(ws):
+    return ('multi', tuple((id(w.weight), w.r0, w.r1) for w in ws), RT.dtype)
+
+
+def _multi_build(ws, old=None):
+    """old: the site's previous (wcat, bcat, wT) -- rewritten in place (stable addresses: captured graphs of several bodies and
+    backward variants read them, like the transposed mirrors of _lpT)"""
+    o = old if old is not None else (None, None, None)
+    wcat = torch.cat([w.lp() for w in ws], 0, out=o[0])
+    bcat = torch.cat([w.bias_f32() for w in ws], 0, out=o[1]) if ws[0].bias is not None else None
+    wT = torch.cat([w.lpT() for w in ws], 1, out=o[2]) if all(w.mirror_ok() for w in ws) else None
+    return wcat, bcat, wT
+
+
+def _multi_get(ws):
+    key = _multi_key(ws)
+    ep = max(RT.epoch_of(w.weight) for w in ws)
+    hit = RT.cache.get(key)
+    if hit is not None and hit[0] == ep and all(r() is w.weight for r, w in zip(hit[4], ws)):
+        return hit[1:4]
+    same = hit is not None and all(r() is w.weight for r, w in zip(hit[4], ws))
+    built = _multi_build(ws, hit[1:4] if same else None)
+    RT.cache[key] = (ep,) + built + (tuple(weakref.ref(w.weight) for w in ws),)
+    _MULTI[key] = tuple(ws)
+    return built
+
+
+def refresh_multi():
+    """rebuild the concatenated copies of every known multi_linear site now (train.GraphedBody: captured on the weight branch of F2,
+    after refresh_transposed on the same stream -- the [K, n*N] copies are cut from the transposed mirrors)"""
+    for key, ws in list(_MULTI.items()):
+        hit = RT.cache.get(key)
+        if hit is None or key[2] != RT.dtype or any(r() is not w.weight for r, w in zip(hit[4], ws)):
+            _MULTI.pop(key, None)
+            continue
+        ep = max(RT.epoch_of(w.weight) for w in ws)
+        RT.cache[key] = (ep,) + _multi_build(ws, hit[1:4]) + (hit[4],)
+
+
 class MultiLinearFn(Function):
     """y[M, n*N] = x [M, K] . [W_0; W_1; ...]^T + [b_0; b_1; ...]: n Linear layers of equal width on the SAME input as one GEMM over
     the concatenated weights (the six DETR decoder layers' cross-attention key -- or value -- projections of the encoder memory,
@@ -400,8 +447,9 @@ class MultiLinearFn(Function):
         K, N, n = ws[0].K, ws[0].N, len(ws)
         x2 = _c(_as_compute(x)).reshape(-1, K)
         M = x2.shape[0]
-        wcat = torch.cat([w.lp() for w in ws], 0)                              # [n*N, K] compute dtype (weights change every step)
-        bcat = torch.cat([w.bias_f32() for w in ws], 0) if ws[0].bias is not None else None
+        if RT.multi_wait is not None:
+            RT.multi_wait()                                                    # (the branch that rebuilt the copies: joined at first use)
+        wcat, bcat, _ = _multi_get(ws)                                         # [n*N, K] compute dtype, fp32 biases
         y = torch.empty(M, n * N, device=x.device, dtype=RT.dtype)
         hip.gemm(x2, wcat, y, M, n * N, K, K, K, n * N, bias=bcat)
         ctx.ws, ctx.xshape = ws, x.shape
@@ -426,11 +474,11 @@ class MultiLinearFn(Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(M, K, device=dz.device, dtype=RT.dtype)
-            if all(w.mirror_ok() for w in ws):
-                wT = torch.cat([w.lpT() for w in ws], 1)                       # [K, n*N]: K-major x K-major on the pipelined kernels
+            wcat, _, wT = _multi_get(ws)
+            if wT is not None:                                                 # [K, n*N]: K-major x K-major on the pipelined kernels
                 hip.gemm(dz, wT, dx, M, K, n * N, n * N, n * N, K)
             else:
-                hip.gemm(dz, torch.cat([w.lp() for w in ws], 0), dx, M, K, n * N, n * N, K, K, layoutB=hip.TRANS)
+                hip.gemm(dz, wcat, dx, M, K, n * N, n * N, K, K, layoutB=hip.TRANS)
             dx = dx.reshape(ctx.xshape)
         return dx, None, None
 

@@ -145,6 +145,7 @@ class GraphedBody:
             raise
         finally:
             RT.split = None
+            RT.multi_wait = None
             self.chains, _ops.GradChain._live = _ops.GradChain._live, live_before
         self.fwd_touched = trainer.touched.clone()            # (forward kernels never write gradients: stays empty)
         trainer.touched |= saved
@@ -190,11 +191,18 @@ class GraphedBody:
         self.wside.wait_stream(cur)
         with torch.cuda.stream(self.wside):
             ops.refresh_transposed()
+            ops.refresh_multi()            # concatenated weights of the multi_linear sites (cross-attention K / V, co-attention q|k|v)
+            multi_ready = torch.cuda.Event()
+            multi_ready.record(self.wside)
             if self.zero_in_graph:
                 # the flat gradient buffer is cleared here, on the branch beside the transformer's latency-bound chain (444 MB of
                 # streaming stores), instead of between the criterion and B1 on the critical path: nobody reads G between the
                 # previous step's AdamW and this step's first weight-gradient kernel (B1)
                 self.tr.G.zero_()
+        def multi_wait():                  # first multi_linear of F2: the copies are ready (long before: they follow the six encoder layers)
+            torch.cuda.current_stream(x.device).wait_event(multi_ready)
+            RT.multi_wait = None
+        RT.multi_wait = multi_wait
         self.c5 = c5
         self.c5_leaf = c5.detach().requires_grad_(bool(train))
         self.body = body

@@ -20,7 +20,7 @@ def short(n):
         n = m.group(2)[:int(m.group(1))] + '<' + m.group(3)[:28] + '>'
     return n[:64]
 def is_conv(n):
-    return any(t in n for t in ('c1s_kernel', 'c3r_kernel', 'stem_pool', 'conv1x1', 'c3d2_kernel', 'c1d_kernel', 'glds_wgrad', 'wgrad_group', 'Li2ELi', 'ILi2E', 's2_dgrad', 'maxpool', 'splitk_reduce'))
+    return any(t in n for t in ('c1s_kernel', 'c1c_kernel', 'c3r_kernel', 'stem_pool', 'conv1x1', 'c3d2_kernel', 'c1d_kernel', 'glds_wgrad', 'wgrad_group', 'Li2ELi', 'ILi2E', 's2_dgrad', 'maxpool', 'splitk_reduce'))
 # phases by landmarks: F1 = [image_to_nhwc4 .. last forward conv before the first LayerNorm]; optimizer = adamw
 names = [r['Kernel_Name'] for r in seq]
 first_ln = next(i for i, n in enumerate(names) if 'ln_fwd' in n and i > 60)

@@ -8,6 +8,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/p_trace -o r 
 python tools/prof_summary.py gpurun_out/p_trace 13 > gpurun_out/${TAG}_bench_kernel_trace_summary.md 2>&1
 python tools/prof_gaps.py gpurun_out/p_trace > gpurun_out/${TAG}_step_gpu_idle_gaps.txt 2>&1
 python tools/prof_phases.py gpurun_out/p_trace > gpurun_out/${TAG}_step_phases.txt 2>&1
+python tools/prof_native.py gpurun_out/p_trace > gpurun_out/${TAG}_step_torch_native_kernels.txt 2>&1
 cp gpurun_out/p_trace/r_kernel_stats.csv gpurun_out/${TAG}_bench_kernel_stats.csv
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/p_fetch -o r -- $B > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/p_write -o r -- $B > /dev/null 2>&1
