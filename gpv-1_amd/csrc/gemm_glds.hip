@@ -25,6 +25,7 @@
 // bf16 operands only: the fp32 "precise" mode needs the hi/lo split on the way into LDS and stays on gemm.hip.
 #include "gemm_common.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace gpvk {
 namespace {
@@ -122,10 +123,21 @@ __device__ __forceinline__ void glds_body(const GemmK& p) {
     }
   }
   const bool bz = (AMODE == OP_CONV) && cm_empty;
+  // Register epilogue (round 4): when the tile's columns are whole and every access is 16-byte aligned, the B rows
+  // (= output columns) are staged PERMUTED -- LDS row L of a 32-row group holds column 8 (r / 4) + 4 jj + (r % 4), jj = L / 16 % 2,
+  // r = L % 16 (conv1x1_stream.hip's c1s_chan) -- so that the accumulator tiles 2t, 2t + 1 leave lane (row, g) with the 8 consecutive
+  // columns 32 t + 8 g .. + 7 of its row: bias / residual / mask / output are plain 16-byte accesses in the accumulator layout, and
+  // the fp32 LDS image with its four barriers per tile (16 us of serial ramp + store burst around the main loop) goes.
+  const bool depi = p.depi && std::is_same<TOut, bf16>::value && p.N % BN == 0 && p.ldc % 8 == 0 &&
+                    ((reinterpret_cast<uintptr_t>(p.C) | (uintptr_t)(p.sC * 2)) & 15) == 0 &&
+                    (!p.res || (p.ldr % 8 == 0 && ((reinterpret_cast<uintptr_t>(p.res) | (uintptr_t)(p.sR * 2)) & 15) == 0)) &&
+                    (!p.mask || (p.ldm % 8 == 0 && (reinterpret_cast<uintptr_t>(p.mask) & 15) == 0)) &&
+                    (!p.bias || (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0);
 #pragma unroll
   for (int j = 0; j < BI; ++j) {
     const int r = wave * (BI * 8) + j * 8 + lrow;
-    const int n = min(col0 + r, p.N - 1);
+    const int rp = depi ? (r & ~31) + ((r & 15) >> 2) * 8 + ((r >> 4) & 1) * 4 + (r & 3) : r;
+    const int n = min(col0 + rp, p.N - 1);
     b_vo[j] = bz ? OOB : (n * (int)p.ldb + lchunk * 8) * 2;
   }
   auto bload = [&](const decltype(rsA)& rs, int voff, int soff, unsigned char* l) {
@@ -224,6 +236,52 @@ __device__ __forceinline__ void glds_body(const GemmK& p) {
   const bool v_st = (p.ldc % 8 == 0) && ((reinterpret_cast<uintptr_t>(Cp) & 15) == 0);
   const bool v_res = Rp && (p.ldr % 8 == 0) && ((reinterpret_cast<uintptr_t>(Rp) & 15) == 0);
   const bool v_msk = Mp && (p.ldm % 8 == 0) && ((reinterpret_cast<uintptr_t>(Mp) & 15) == 0);
+  if (depi) {
+    const int mrow = wm * WTM + frow;                // + i * 16: this lane's row inside the tile
+    float bq[2][8];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int n = col0 + wn * 64 + t * 32 + fkg * 8;
+      if (p.bias) {
+        const float4 b0 = *reinterpret_cast<const float4*>(p.bias + n), b1 = *reinterpret_cast<const float4*>(p.bias + n + 4);
+        bq[t][0] = b0.x; bq[t][1] = b0.y; bq[t][2] = b0.z; bq[t][3] = b0.w; bq[t][4] = b1.x; bq[t][5] = b1.y; bq[t][6] = b1.z; bq[t][7] = b1.w;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bq[t][e] = 0.f;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      const int ml = mrow + i * 16, m = row0 + ml;
+      if (m >= p.M) continue;
+      int64_t mp = m;
+      if constexpr (AMODE == OP_CONV) { if (p.cg.cm) mp = s_rowpix[ml]; }
+      const float rs = p.rowscale ? p.rowscale[m] * p.alpha : p.alpha;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int n = col0 + wn * 64 + t * 32 + fkg * 8;
+        float rv[8], mv[8];
+        if (Rp) Ld8<TOut>::ld(Rp + mp * p.ldr + n, rv);
+        if (Mp) Ld8<TOut>::ld(Mp + mp * p.ldm + n, mv);
+        const uint32_t keep8 = p.dthresh ? drop_mask<8>(p.seed, ((uint64_t)batch * p.M + m) * (uint64_t)p.N + n, p.dthresh) : 0xffu;
+        float v[8] = {acc[i][2 * t][0], acc[i][2 * t][1], acc[i][2 * t][2], acc[i][2 * t][3],
+                      acc[i][2 * t + 1][0], acc[i][2 * t + 1][1], acc[i][2 * t + 1][2], acc[i][2 * t + 1][3]};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float x = v[e] * rs;
+          x += bq[t][e];
+          if (Rp) x += rv[e];
+          if (p.act == GPV_ACT_RELU) x = fmaxf(x, 0.f);
+          else if (p.act == GPV_ACT_GELU) x = gelu_erf(x);
+          if (p.dthresh) x = ((keep8 >> e) & 1u) ? x * p.dscale : 0.f;
+          if (Mp) x = mv[e] > 0.f ? x : 0.f;
+          v[e] = x;
+        }
+        Ld8<TOut>::st(Cp + mp * p.ldc + n, v);
+      }
+    }
+    return;
+  }
   float bv[8];
   {
     const int nb = col0 + (tid % CH) * 8;          // NT % CH == 0: a thread always finishes the same 8 columns
@@ -334,6 +392,8 @@ int launch_glds(const GemmK& k, int batch, hipStream_t st) {
     if (e != hipSuccess) { (void)hipGetLastError(); return (int)e; }      // (leave no stale error behind for the next launch check)
     attr_done[c11] = true;
   }
+  static const int depi = [] { const char* e = getenv("GPV_GLDS_DEPI"); return e ? atoi(e) : 1; }();
+  p.depi = depi;
   dim3 grid(tilesM * p.tilesN, 1, batch);
   ++g_glds_launches;
   hipLaunchKernelGGL(fn, grid, dim3(BM == 256 ? 512 : 256), lds, st, p);

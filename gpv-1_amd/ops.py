@@ -442,8 +442,9 @@ class MultiLinearFn(Function):
     weight gradients per layer from the column slices of dy (row pitch n*N)."""
 
     @staticmethod
-    def forward(ctx, x, ws, sink=None):
+    def forward(ctx, x, ws, sink=None, chain=None):
         ctx.sink = sink
+        ctx.chain = chain.join() if (chain is not None and ctx.needs_input_grad[0]) else None
         K, N, n = ws[0].K, ws[0].N, len(ws)
         x2 = _c(_as_compute(x)).reshape(-1, K)
         M = x2.shape[0]
@@ -475,20 +476,25 @@ class MultiLinearFn(Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty(M, K, device=dz.device, dtype=RT.dtype)
             wcat, _, wT = _multi_get(ws)
+            ch = ctx.chain
+            epi = {'res': ch.acc.reshape(M, K), 'ldr': K} if (ch is not None and ch.acc is not None) else {}
             if wT is not None:                                                 # [K, n*N]: K-major x K-major on the pipelined kernels
-                hip.gemm(dz, wT, dx, M, K, n * N, n * N, n * N, K)
+                hip.gemm(dz, wT, dx, M, K, n * N, n * N, n * N, K, **epi)
             else:
-                hip.gemm(dz, wcat, dx, M, K, n * N, n * N, K, K, layoutB=hip.TRANS)
+                hip.gemm(dz, wcat, dx, M, K, n * N, n * N, K, K, layoutB=hip.TRANS, **epi)
             dx = dx.reshape(ctx.xshape)
-        return dx, None, None
+            if ch is not None:
+                dx = ch.done(dx)
+        return dx, None, None, None
 
 
-def multi_linear(x, ws, sink=None):
-    """sink: the ops.GradSlots through which the consumers deliver this output's gradient (released by the backward)"""
+def multi_linear(x, ws, sink=None, chain=None):
+    """sink: the ops.GradSlots through which the consumers deliver this output's gradient (released by the backward);
+    chain: the ops.GradChain of x (LinearFn's: the running gradient of x rides in the backward-data GEMM's `res`)"""
     dummy_needed = torch.is_grad_enabled() and not x.requires_grad and any(w.weight.requires_grad for w in ws)
     if dummy_needed:                     # (no caller needs it: these inputs always carry a gradient when the weights train)
         raise RuntimeError('multi_linear: input without gradient but trainable weights')
-    return MultiLinearFn.apply(x, tuple(ws), sink)
+    return MultiLinearFn.apply(x, tuple(ws), sink, chain)
 
 
 # --------------------------------------------------------------------------------------------

@@ -52,7 +52,9 @@ class BertBiAttention(nn.Module):
             grad = torch.is_grad_enabled() and (t1.requires_grad or t2.requires_grad)
             s1, s2 = (ops.GradSlots(), ops.GradSlots()) if grad else (None, None)
             qkv1 = ops.multi_linear(t1, [W(m.weight, m.bias) for m in (self.query1, self.key1, self.value1)], s1)
-            qkv2 = ops.multi_linear(t2, [W(m.weight, m.bias) for m in (self.query2, self.key2, self.value2)], s2)
+            # (the vision stream's output always carries a gradient: its projections share the chain of its residual LayerNorm;
+            #  the language stream's may not -- a detection-only batch in the last layer -- so its sum is left to autograd)
+            qkv2 = ops.multi_linear(t2, [W(m.weight, m.bias) for m in (self.query2, self.key2, self.value2)], s2, chain=own2)
             roles = ((0, 0), (1, D), (1, 2 * D))
             ctx1 = ops.attention([qkv2, qkv1], roles, B, H, T2, T1, dh, kpm=kpm1, drop_p=p1, sinks=(s2, s1) if grad else None)
             ctx2 = ops.attention([qkv1, qkv2], roles, B, H, T1, T2, dh, drop_p=p2, sinks=(s1, s2) if grad else None)
