@@ -19,6 +19,7 @@
 // (conflict-free ds_read_b128); out-of-range rows / padding taps deliver zeros through the buffer descriptor's bounds check.
 // Epilogue: alpha, rowscale, bias, residual, ReLU/GELU, dropout, ReLU-mask; fp32 tile staged through LDS in two halves.
 #include "gemm_common.h"
+#include <type_traits>
 #include <cstdlib>
 #ifndef GPV_PIPE_SWP
 #define GPV_PIPE_SWP 1
@@ -140,10 +141,18 @@ __device__ __forceinline__ void pipe_body(const GemmK& p) {
     }
   }
   const bool bz = (AMODE == OP_CONV) && cm_empty;
+  // register epilogue over permuted output columns (gemm_glds.hip, round 4): wave tiles with an even number of 16-column fragments,
+  // whole column tiles, 16-byte aligned operands
+  const bool depi = (FN % 2 == 0) && p.depi && std::is_same<TOut, bf16>::value && p.N % BN == 0 && p.ldc % 8 == 0 &&
+                    ((reinterpret_cast<uintptr_t>(p.C) | (uintptr_t)(p.sC * 2)) & 15) == 0 &&
+                    (!p.res || (p.ldr % 8 == 0 && ((reinterpret_cast<uintptr_t>(p.res) | (uintptr_t)(p.sR * 2)) & 15) == 0)) &&
+                    (!p.mask || (p.ldm % 8 == 0 && (reinterpret_cast<uintptr_t>(p.mask) & 15) == 0)) &&
+                    (!p.bias || (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0);
 #pragma unroll
   for (int j = 0; j < BI; ++j) {
     const int r = (j * NW + wave) * 8 + lrow;
-    const int n = min(col0 + r, p.N - 1);
+    const int rp = depi ? (r & ~31) + ((r & 15) >> 2) * 8 + ((r >> 4) & 1) * 4 + (r & 3) : r;
+    const int n = min(col0 + rp, p.N - 1);
     b_vo[j] = bz ? OOB : (n * (int)p.ldb + lchunk * 8) * 2;
   }
   // loads this wave issues per k-tile (the count the vmcnt waits are built from)
@@ -289,6 +298,43 @@ __device__ __forceinline__ void pipe_body(const GemmK& p) {
   const bool v_st = (p.ldc % 8 == 0) && ((reinterpret_cast<uintptr_t>(Cp) & 15) == 0);
   const bool v_res = Rp && (p.ldr % 8 == 0) && ((reinterpret_cast<uintptr_t>(Rp) & 15) == 0);
   const bool v_msk = Mp && (p.ldm % 8 == 0) && ((reinterpret_cast<uintptr_t>(Mp) & 15) == 0);
+  if constexpr (FN % 2 == 0) {
+    if (depi) {
+      const int mrow = wm * WTM + frow;
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        const int ml = mrow + i * 16, m = row0 + ml;
+        if (m >= p.M) continue;
+        int64_t mp = m;
+        if constexpr (AMODE == OP_CONV) { if (p.cg.cm) mp = s_rowpix[ml]; }
+        const float rs = p.rowscale ? p.rowscale[m] * p.alpha : p.alpha;
+#pragma unroll
+        for (int t = 0; t < FN / 2; ++t) {
+          const int n = col0 + wn * WTN + t * 32 + fkg * 8;
+          float bq[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, rv[8], mv[8];
+          if (p.bias) Ld8<float>::ld(p.bias + n, bq);
+          if (Rp) Ld8<TOut>::ld(Rp + mp * p.ldr + n, rv);
+          if (Mp) Ld8<TOut>::ld(Mp + mp * p.ldm + n, mv);
+          const uint32_t keep8 = p.dthresh ? drop_mask<8>(p.seed, ((uint64_t)batch * p.M + m) * (uint64_t)p.N + n, p.dthresh) : 0xffu;
+          float v[8] = {acc[i][2 * t][0], acc[i][2 * t][1], acc[i][2 * t][2], acc[i][2 * t][3],
+                        acc[i][2 * t + 1][0], acc[i][2 * t + 1][1], acc[i][2 * t + 1][2], acc[i][2 * t + 1][3]};
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float x = v[e] * rs;
+            x += bq[e];
+            if (Rp) x += rv[e];
+            if (p.act == GPV_ACT_RELU) x = fmaxf(x, 0.f);
+            else if (p.act == GPV_ACT_GELU) x = gelu_erf(x);
+            if (p.dthresh) x = ((keep8 >> e) & 1u) ? x * p.dscale : 0.f;
+            if (Mp) x = mv[e] > 0.f ? x : 0.f;
+            v[e] = x;
+          }
+          Ld8<TOut>::st(Cp + mp * p.ldc + n, v);
+        }
+      }
+      return;
+    }
+  }
   float bv[8];
   {
     const int nb = col0 + (tid % CH) * 8;
@@ -402,6 +448,8 @@ int launch_pipe(const GemmK& k, int batch, hipStream_t st) {
   }
   dim3 grid(tilesM * p.tilesN, 1, batch);
   ++g_pipe_launches;
+  static const int depi = [] { const char* e = getenv("GPV_GLDS_DEPI"); return e ? atoi(e) : 1; }();
+  p.depi = depi;
   hipLaunchKernelGGL(fn, grid, dim3(NT), lds, st, p);
   GPV_CHECK_LAUNCH();
   return 0;
