@@ -414,7 +414,10 @@ def main():
     local = local % max(torch.cuda.device_count(), 1)   # (only differs on a box with fewer GPUs than ranks: the gloo dry run below)
     torch.cuda.set_device(local)
     dev = f'cuda:{local}'
-    if world > 1:
+    # GPV_FORCE_COMM=1 at --gpus 1: a process group of ONE rank under the real backend -- the whole N > 1 path (RCCL init, bucketed
+    # asynchronous all-reduces between the stage graphs of the backward pass, the gloo agreement channel) on a single-GPU box
+    multi = world > 1 or os.environ.get('GPV_FORCE_COMM', '0') == '1'
+    if multi:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29511')
         backend = os.environ.get('GPV_DIST_BACKEND', 'nccl')     # 'gloo': dry run of the N > 1 path with ranks sharing one GPU
@@ -464,10 +467,10 @@ def main():
         torch.cuda.synchronize()
         ok = 1
     except RuntimeError as err:
-        if world == 1:
+        if not multi:
             raise
         ok, graphs_note = 0, '%s: %s' % (type(err).__name__, (str(err).splitlines() or [''])[0])
-    if world > 1:
+    if multi:
         flag = torch.tensor([ok], device=dev, dtype=torch.int32)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag) == 0:
@@ -481,7 +484,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     bbm.PROF = []
-    if world > 1:
+    if multi:
         tr.comm_prof = []
     import gpv1_amd.train as trm
     trm.HOST_PROF = {}
@@ -492,7 +495,7 @@ def main():
         loss = step()
         host_s += time.perf_counter() - h0              # host time inside train_step (no sync): how far the host runs ahead
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
@@ -524,12 +527,12 @@ def main():
         torch.cuda.synchronize()
     else:
         prof = prof_timed
-    if world > 1:
+    if multi:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
     comm = None
-    if world > 1:
+    if multi:
         torch.cuda.synchronize()
         exposed = [a.elapsed_time(b) for a, b in (tr.comm_prof or [])]
         tr.comm_prof = None
@@ -537,9 +540,10 @@ def main():
                 'grad_comm_dtype': str(tr.grad_comm_dtype).replace('torch.', ''), 'bytes_per_rank_per_step': tr.comm_bytes_per_step(),
                 'buckets': len(tr.buckets), 'exposed_ms_per_step': sum(exposed) / max(len(exposed), 1),
                 'graph_steps': tr.graph_steps, 'eager_steps': tr.eager_steps,
+                'milestones_last_step': [m for m, _ in tr.milestone_log], 'left_after_backward_bytes': getattr(tr, 'left_after_backward', None),
                 'what': 'exposed = GPU time between the first bucket wait and the last bucket back on the compute stream (what the overlap did not hide), rank 0'}
     if rank != 0:
-        if world > 1:
+        if multi:
             dist.destroy_process_group()
         return
     soak = None
@@ -622,7 +626,7 @@ def main():
         except Exception as e:                                     # the baseline must never sink the bench line
             out['cpu_baseline'] = {'value': None, 'unit': 'images/sec', 'cores': os.cpu_count(), 'kind': 'port', 'sample': f'failed: {e}'}
     print(json.dumps(out))
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

@@ -409,7 +409,7 @@ class GraphedBody:
             _ops.check_chains(clear=False, chains=self.chains)     # (the recorded forward -- and its chains -- serve further backward variants)
             RT.defer_list = None
             RT.backward_boundary = None
-            if deferred and tr.world > 1:
+            if deferred and tr.comm:
                 # more than one rank: the DETR layers' group runs here, at the end of B1, so that every gradient behind the
                 # backbone segment is complete when the trainer hands those buckets to RCCL (overlapped with B2)
                 self._flush(deferred)
@@ -434,7 +434,7 @@ class GraphedBody:
                     # several ranks: B2 is cut into one graph per backbone stage (layer4 | layer3 | layer2) so that the trainer
                     # can hand a finished stage's gradient buckets to the all-reduce between the replays (the exchange is not
                     # captured); tensors crossing a cut live in the shared graph pool, like c5 between F1 and F2
-                    cut = tr.world > 1 or tr.dry_overlap or os.environ.get('GPV_B2_STAGES', '0') == '1'
+                    cut = tr.comm or tr.dry_overlap or os.environ.get('GPV_B2_STAGES', '0') == '1'
                     last_li = self.body.stage_of(self.keep[0][0])
                     cur = [b2]
 
@@ -500,6 +500,10 @@ class FlatTrainer:
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
         self.rank = dist.get_rank(process_group) if self.world > 1 else 0
+        # comm: the gradient exchange and everything that exists for it (bucket milestones, the stage cut of B2, the host agreement
+        # channel) is on.  GPV_FORCE_COMM=1 turns it on for a process group of ONE rank: the whole N > 1 code path under the real
+        # backend (RCCL) on a single-GPU box -- collectives that move nothing, same streams / events / graph cuts as on a node
+        self.comm = self.world > 1 or (dist.is_available() and dist.is_initialized() and os.environ.get('GPV_FORCE_COMM', '0') == '1')
         named = [(n, p) for n, p in model.named_parameters() if p.requires_grad and not any(s in n for s in NEVER_GRAD)]
         named.sort(key=lambda np_: GROUPS.index(param_group_of(np_[0])))           # stable: module order inside a group
         self.entries = []                                                           # (name, param, group, offset, numel)
@@ -560,14 +564,14 @@ class FlatTrainer:
         # the order in which EVERY rank issues them: behind the backbone first, then the backbone stages last-to-first
         self.bucket_order = [q for q in self.buckets if q[0] >= self.backbone_end] + \
             sorted((q for q in self.buckets if q[0] < self.backbone_end), key=lambda q: -q[0])
-        self.Gc = torch.zeros(off, device=dev, dtype=torch.bfloat16) if (self.world > 1 and self.grad_comm_dtype == torch.bfloat16) else None
-        self.overlap = self.world > 1 and os.environ.get('GPV_OVERLAP', '1') != '0'
+        self.Gc = torch.zeros(off, device=dev, dtype=torch.bfloat16) if (self.comm and self.grad_comm_dtype == torch.bfloat16) else None
+        self.overlap = self.comm and os.environ.get('GPV_OVERLAP', '1') != '0'
         self.dry_overlap = False             # tests: run the milestone / guard logic without communicating
         self._closed_from, self._works, self.late_touch, self.milestones = None, [], None, 0
         self._next_bucket, self.milestone_log = 0, []
         self.defer_wgrad = os.environ.get('GPV_DEFER_WGRAD', '1') != '0'       # (with several ranks the groups stay inside B1)
         self.host_pg = None
-        if self.world > 1:
+        if self.comm:
             dist.broadcast(self.P, src=0, group=self.pg)
             # DDP broadcasts every parameter AND buffer from rank 0 at construction; the tensors this trainer does not manage
             # (frozen BERT, vocabulary embedding, FrozenBN statistics, the frozen stem / layer1) must not depend on each rank's seed
@@ -652,7 +656,7 @@ class FlatTrainer:
     def allreduce_grads(self):
         RT.backward_milestone = None
         self._closed_from = None
-        if self.world == 1:
+        if not self.comm:
             return
         # Every rank issues the buckets in the SAME order (bucket_order: behind the backbone segment, then layer4, layer3, layer2)
         # whether or not its backward reached the milestones (a rank without an applicable target runs no backward at all, see
@@ -684,7 +688,7 @@ class FlatTrainer:
     def _publish_touched(self):
         """host-side 'touched' marks of this step -> device flags (idempotent; pinned staging, asynchronous)"""
         from .misc import STAGER
-        if self._published is not None and torch.equal(self._published, self.touched) and self.world == 1:
+        if self._published is not None and torch.equal(self._published, self.touched) and not self.comm:
             return                               # (steady state: the same parameters every step -- nothing new to tell the device)
         loc = STAGER.to_device(self.touched.to(torch.int32), torch.int32, self.live.device)
         torch.maximum(self.live, loc, out=self.live)
@@ -1072,7 +1076,7 @@ class FlatTrainer:
         return None if loss is None else loss.detach()
 
     def _any_rank_has_loss(self, has):
-        if self.world == 1:
+        if not self.comm:
             return has
         t = torch.tensor([1 if has else 0], dtype=torch.int32)
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.host_pg)
