@@ -164,7 +164,7 @@ class GreedyKVDecoder:
                 self.ids.copy_(ids_in)
                 g = torch.cuda.CUDAGraph()
                 from .misc import capture_guard
-                with capture_guard(), torch.cuda.graph(g):
+                with capture_guard(), torch.cuda.graph(g, capture_error_mode='thread_local'):
                     self._step(t)
                 self.graphs[t] = g
                 self.tok.copy_(tok_in)

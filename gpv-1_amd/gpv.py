@@ -363,7 +363,7 @@ class GPV(nn.Module):
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
             from .misc import capture_guard
-            with capture_guard(), torch.cuda.graph(graph):
+            with capture_guard(), torch.cuda.graph(graph, capture_error_mode='thread_local'):
                 try:
                     out = run()
                 except BaseException:

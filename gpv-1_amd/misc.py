@@ -124,12 +124,26 @@ class AttrDict(dict):
         return d
 
 
+def quiesce_collectives():
+    """With a process group alive, a stream capture must not begin while ProcessGroupNCCL's watchdog thread still polls the
+    completion event of a collective that ran on the stream about to capture (HIP: hipErrorCapturedEvent on the query, the capture
+    invalidated, the watchdog's exception ends the process -- train.FlatTrainer.quiesce_collectives has the measurement): idle
+    device, then three polling periods for the watchdog to retire what it was watching."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or not torch.cuda.is_available():
+        return
+    import time
+    torch.cuda.synchronize()
+    time.sleep(0.35)
+
+
 @contextlib.contextmanager
 def capture_guard():
     """No cyclic garbage collection while a stream is capturing: a CUDAGraph that becomes collectable in there (the captured graphs
     of a model that was dropped earlier -- GPV and its decoders reference each other, so only the cycle collector frees them) would
     be destroyed inside the capture, which HIP refuses and PyTorch's destructor turns into std::terminate (tools/fuzz_decode.py
     found it: a new model per configuration)."""
+    quiesce_collectives()
     was = gc.isenabled()
     gc.collect()
     gc.disable()

@@ -102,7 +102,7 @@ def wgrad_linear(dz, x2, wg, bg, N, K, M, split, lda=None):
     prob = None
     if wg.stride(1) == 1 and hip.tt_group_ok(dz, x2, wg, N, K, M, lda, K, wg.stride(0)):
         prob = (dz, x2, wg, bg, N, K, M, lda, K, wg.stride(0))
-    RT.defer_list.append((run, (dz, x2), prob))
+    RT.defer_list.append((run, (dz, x2, wg), prob))            # (tensors[2]: the gradient written -- train.GraphedBody checks where it lives)
 
 
 class BoundaryFn(Function):

@@ -54,6 +54,14 @@ def warmup_linear(step, warmup_steps, t_total):
 # Stream captures prohibit "unsafe" runtime calls (event queries, allocations).  'thread_local' restricts that to the capturing
 # thread: RCCL's watchdog thread polls the events of the in-flight bucket all-reduces while B2 is being captured.
 CAPTURE_MODE = os.environ.get('GPV_CAPTURE_MODE', 'thread_local')
+_TRACE = os.environ.get('GPV_CAPTURE_TRACE', '0') == '1'
+
+
+def _trace(what):
+    if _TRACE:
+        import sys
+        import datetime
+        print('[gpv1_amd trace %s] %s' % (datetime.datetime.now().strftime('%H:%M:%S.%f'), what), file=sys.stderr, flush=True)
 
 
 def ops_check_chains(clear=True):
@@ -103,6 +111,8 @@ class GraphedBody:
         self.keep, self.c5, self.c5_leaf = None, None, None
         self.variants = {}
         RT.enable_seed_epoch(dev)
+        _trace('capture forward begin')
+        trainer.quiesce_collectives()
         torch.cuda.synchronize()
         gc.collect()
         self.pool = torch.cuda.graph_pool_handle()
@@ -298,7 +308,7 @@ class GraphedBody:
         if ev is not None:
             ev.record()
         if RT.backward_milestone is not None:
-            RT.backward_milestone('backbone')
+            RT.backward_milestone('head' if var['head_late'] else 'backbone')
         ev = bbm._prof('conv_bwd')
         for g, tag in var['b2']:                 # one graph (single GPU) or one per backbone stage (several ranks: stage milestones)
             g.replay()
@@ -351,6 +361,8 @@ class GraphedBody:
 
     def _capture_backward(self, pairs, fused=None):
         tr = self.tr
+        _trace('capture backward begin (fused=%r)' % (fused is not None,))
+        tr.quiesce_collectives()
         torch.cuda.synchronize()
         gc.collect()
         grads = [torch.zeros_like(g) for _, _, g in pairs]
@@ -409,12 +421,20 @@ class GraphedBody:
             _ops.check_chains(clear=False, chains=self.chains)     # (the recorded forward -- and its chains -- serve further backward variants)
             RT.defer_list = None
             RT.backward_boundary = None
+            head_late = False
             if deferred and tr.comm:
-                # more than one rank: the DETR layers' group runs here, at the end of B1, so that every gradient behind the
-                # backbone segment is complete when the trainer hands those buckets to RCCL (overlapped with B2)
-                self._flush(deferred)
-                side_a.extend(deferred)
-                del deferred[:]
+                # more than one rank.  The buckets behind the DETR-head segment go to RCCL between B1 and B2; the DETR layers' group
+                # may stay where it is on one GPU (a branch of B2's first stage graph, under layer4's convolutions) iff every
+                # gradient it writes lies in the head segment, whose buckets are then handed over with layer4's ('head' milestone
+                # instead of 'backbone').  Otherwise (or GPV_HEAD_LATE=0) it runs here, at the end of B1.
+                lo, hi = tr.backbone_end, tr.head_end
+                g0 = tr.G.data_ptr()
+                head_late = os.environ.get('GPV_HEAD_LATE', '1') != '0' and bool(self.keep) and self.c5_leaf.grad is not None and \
+                    all(len(t) > 2 and lo <= (t[2].data_ptr() - g0) // 4 < hi for _, t, _ in deferred)
+                if not head_late:
+                    self._flush(deferred)
+                    side_a.extend(deferred)
+                    del deferred[:]
             if side_a:
                 torch.cuda.current_stream(dev).wait_stream(self.wside)
             b1.capture_end()
@@ -464,7 +484,8 @@ class GraphedBody:
             RT.defer_list = None
             RT.backward_boundary = None
         RT.backward_milestone = milestone
-        var = {'b1': b1, 'b2': b2_list, 'grads': grads, 's_ce': s_ce, 'loss': loss_static, 'touched': tr.touched.clone(), 'dc5': dc5, 'deferred': deferred + side_a}
+        _trace('capture backward end: %d stage graphs' % len(b2_list))
+        var = {'head_late': head_late, 'b1': b1, 'b2': b2_list, 'grads': grads, 's_ce': s_ce, 'loss': loss_static, 'touched': tr.touched.clone(), 'dc5': dc5, 'deferred': deferred + side_a}
         tr.touched |= saved
         return var
 
@@ -545,6 +566,11 @@ class FlatTrainer:
             p._gpv_touch = (lambda i=i: self._mark(i))                            # kernel-accumulated gradients
             p.register_hook(lambda grad, i=i: self._mark(i))                       # autograd-delivered gradients
         self.gscale = torch.ones(1, device=dev, dtype=torch.float32)
+        # several ranks: G holds the SUM over ranks after the exchange; the 1 / world of the average rides on the factor the AdamW
+        # kernel multiplies every gradient with anyway (clip factor x avg for the DETR groups, avg alone for the others) instead
+        # of a pass over the 444 MB buffer (0.2 ms per step)
+        self.avg = 1.0 / self.world
+        self.avg_t = torch.full((1,), self.avg, device=dev, dtype=torch.float32) if self.world > 1 else None
         self._clip_ws = torch.zeros(hip.CLIP_PARTIALS, device=dev, dtype=torch.float32)
         self._published = None                   # the host 'touched' marks as last sent to the device
         self._step_state = None
@@ -559,10 +585,13 @@ class FlatTrainer:
             st = next((t for t in ('layer1', 'layer2', 'layer3', 'layer4') if '.%s.' % t in n), 'stem')
             lo, hi = self.stage_range.get(st, (o, o))
             self.stage_range[st] = (min(lo, o), max(hi, o + (k + 7) // 8 * 8))
-        cuts = sorted({0, self.backbone_end, off} | {v for r in self.stage_range.values() for v in r})
+        self.head_end = max(self.backbone_end, self.group_range.get('detr_head', (0, 0))[1])
+        cuts = sorted({0, self.backbone_end, self.head_end, off} | {v for r in self.stage_range.values() for v in r})
         self.buckets = [(s, min(hi, s + b)) for lo, hi in zip(cuts[:-1], cuts[1:]) for s in range(lo, hi, b)]   # no bucket straddles a stage / the backbone boundary
         # the order in which EVERY rank issues them: behind the backbone first, then the backbone stages last-to-first
-        self.bucket_order = [q for q in self.buckets if q[0] >= self.backbone_end] + \
+        # (behind the DETR head | the DETR head | the backbone's stages)
+        self.bucket_order = [q for q in self.buckets if q[0] >= self.head_end] + \
+            [q for q in self.buckets if self.backbone_end <= q[0] < self.head_end] + \
             sorted((q for q in self.buckets if q[0] < self.backbone_end), key=lambda q: -q[0])
         self.Gc = torch.zeros(off, device=dev, dtype=torch.bfloat16) if (self.comm and self.grad_comm_dtype == torch.bfloat16) else None
         self.overlap = self.comm and os.environ.get('GPV_OVERLAP', '1') != '0'
@@ -622,6 +651,8 @@ class FlatTrainer:
             return
         if what == 'backbone':
             start = self.backbone_end
+        elif what == 'head':                 # graphed step whose DETR weight-gradient group runs inside B2's first stage graph
+            start = self.head_end
         elif what in self.stage_range:
             start = self.stage_range[what][0]
         else:
@@ -643,10 +674,23 @@ class FlatTrainer:
 
     def _reduce_bucket(self, s, e):
         """asynchronous SUM all-reduce of G[s:e] (through the bf16 staging buffer when grad_comm_dtype is bf16)"""
+        _trace('all-reduce bucket [%d, %d) step %d' % (s, e, self.step_count))
         if self.Gc is None:
             return (dist.all_reduce(self.G[s:e], op=dist.ReduceOp.SUM, group=self.pg, async_op=True), s, e)
         self.Gc[s:e].copy_(self.G[s:e])
         return (dist.all_reduce(self.Gc[s:e], op=dist.ReduceOp.SUM, group=self.pg, async_op=True), s, e)
+
+    def quiesce_collectives(self):
+        """Before a stream capture with a process group alive.  ProcessGroupNCCL's watchdog thread polls the completion event of every
+        collective it has not yet seen finish (every 100 ms).  HIP refuses a query of an event whose last record was on a stream that
+        is capturing NOW (hipErrorCapturedEvent) and invalidates that capture: a collective issued on the trainer's stream a few
+        ms before a capture begins on the same stream -- the synchronous ones run on the caller's stream -- killed 2 of 12 runs
+        (capture error 901 + the watchdog's exception ends the process; found with GPV_FORCE_COMM=1 on one GPU).  Two measures:
+        every collective of the trainer is asynchronous (RCCL's own stream never captures), and a capture starts only after the
+        device is idle and the watchdog has had three polling periods to retire what it was watching."""
+        if self.comm:
+            from .misc import quiesce_collectives
+            quiesce_collectives()
 
     def begin_backward(self):
         self._closed_from, self._works, self.late_touch, self.milestones = None, [], None, 0
@@ -667,7 +711,8 @@ class FlatTrainer:
         self._works = []
         self.left_after_backward = sum(e - s for s, e in self.bucket_order[first_late:]) * (2 if self.Gc is not None else 4)   # bytes
         self._publish_touched()
-        dist.all_reduce(self.live, op=dist.ReduceOp.MAX, group=self.pg)          # stays on the device: no host sync
+        # (stays on the device: no host sync.  Asynchronous + wait: on RCCL's stream, see quiesce_collectives)
+        dist.all_reduce(self.live, op=dist.ReduceOp.MAX, group=self.pg, async_op=True).wait()
         prof = self.comm_prof is not None and self.G.is_cuda
         if prof:                                   # exposed communication: what the compute stream waits for from here on
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -676,7 +721,6 @@ class FlatTrainer:
             w.wait()
             if self.Gc is not None:
                 self.G[s:e].copy_(self.Gc[s:e])
-        self.G.mul_(1.0 / self.world)
         if prof:
             e1.record()
             self.comm_prof.append((e0, e1))
@@ -728,7 +772,7 @@ class FlatTrainer:
         s, e = self.group_range[g]
         b1, b2 = self.betas
         hip.adamw(self.P[s:e], self.G[s:e], self.M[s:e], self.V[s:e], self.Pb[s:e], e - s, self.lr[g] * st['sched'], b1, b2,
-                  self.eps, self.wd, st['bc'][0], st['bc'][1], self.gscale if clip_here else None,
+                  self.eps, self.wd, st['bc'][0], st['bc'][1], self.gscale if clip_here else self.avg_t,
                   seg_id=self.seg_id[s // 8:e // 8], seg_live=self.pstep)
         st['done'].add(g)
 
@@ -749,12 +793,15 @@ class FlatTrainer:
             s0, e1 = min(r[0] for r in rng), max(r[1] for r in rng)
             if sum(r[1] - r[0] for r in rng) != e1 - s0:
                 raise RuntimeError('FlatTrainer: the DETR groups are not contiguous in the flat buffer')
-            hip.clip_scale(self.G[s0:e1], self.clip, self._clip_ws, self.gscale)
+            # (G = sum over ranks: |sum| against world x max_norm is |average| against max_norm; then the average's factor on top)
+            hip.clip_scale(self.G[s0:e1], self.clip * self.world, self._clip_ws, self.gscale)
+            if self.world > 1:
+                self.gscale.mul_(self.avg)
         if hp is not None:
             t1 = time.perf_counter(); hp['opt_clip'] = hp.get('opt_clip', 0.0) + t1 - t0; t0 = t1
         for g in self.group_range:                                           # one launch per group; the kernel skips dead parameters
             if g not in st['done']:
-                self._adamw_group(g, st, use_clip and g in ('detr_backbone', 'detr_head'))
+                self._adamw_group(g, st, bool(rng) and g in ('detr_backbone', 'detr_head'))
         self._step_state = None
         RT.bump_weights(everything=False)
         if hp is not None:

@@ -59,7 +59,8 @@ def _worker(rank, world, port, out):
     local = tr.G.clone()
     touched_local = tr.touched.clone()
     tr.allreduce_grads()
-    res = {'local': local, 'avg': tr.G.clone(), 'touched_local': touched_local, 'touched': tr.live_host()}
+    res = {'local': local, 'avg': tr.G.clone() * tr.avg,           # (G = the SUM over ranks; 1 / world rides on the AdamW factor)
+            'touched_local': touched_local, 'touched': tr.live_host()}
     tr.step()
     for _ in range(1):
         tr.model.bert.model.p = 0.0
