@@ -421,10 +421,8 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29511')
         backend = os.environ.get('GPV_DIST_BACKEND', 'nccl')     # 'gloo': dry run of the N > 1 path with ranks sharing one GPU
-        if backend == 'nccl':
-            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device(dev))
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+        from gpv1_amd.train import init_process_group
+        init_process_group(rank, world, dev, backend)           # RCCL: high-priority stream, communicator bound to this rank's GPU
 
     import gpv1_amd.hip as hip
     import gpv1_amd.backbone as bbm

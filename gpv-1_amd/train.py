@@ -64,6 +64,23 @@ def _trace(what):
         print('[gpv1_amd trace %s] %s' % (datetime.datetime.now().strftime('%H:%M:%S.%f'), what), file=sys.stderr, flush=True)
 
 
+def init_process_group(rank, world, device, backend=None):
+    """torch.distributed over RCCL for one rank per GPU (train_distr.py:176-179 wraps in DDP over NCCL; here FlatTrainer exchanges
+    the flat gradient itself).  RCCL's kernels go on a HIGH-priority stream: the bucket all-reduces are issued between the backward
+    graphs and must get their few workgroups onto a chip the convolutions fill (256 CUs, two blocks each), or the overlap turns
+    into a tail.  device_id: eager communicator init bound to this rank's GPU (no lazy init inside the first step)."""
+    cuda = str(device).startswith('cuda')
+    backend = backend or ('nccl' if cuda else 'gloo')
+    if backend != 'nccl':
+        dist.init_process_group(backend, rank=rank, world_size=world)
+        return
+    opts = None
+    if os.environ.get('GPV_RCCL_HIGH_PRIO', '1') != '0':
+        opts = dist.ProcessGroupNCCL.Options()
+        opts.is_high_priority_stream = True
+    dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device(device), pg_options=opts)
+
+
 def ops_check_chains(clear=True):
     from . import ops
     ops.check_chains(clear)

@@ -130,7 +130,8 @@ def train_worker(cfg, dataset=None, device=None, log=print):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '10001')                      # dist_url tcp://localhost:10001
-        dist.init_process_group('nccl' if str(device).startswith('cuda') else 'gloo', rank=rank, world_size=world)
+        from .train import init_process_group
+        init_process_group(rank, world, device)
     tr_cfg = cfg.training
     batch_size = tr_cfg.frozen_batch_size if tr_cfg.freeze else tr_cfg.batch_size
     per_rank = max(1, batch_size // world)
