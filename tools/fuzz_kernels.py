@@ -96,7 +96,7 @@ for it in range(rounds):
     Sq, Sk = rng.randint(1, 320), rng.randint(2, 320)          # (Sk = 1: softmax is the constant 1, dQ = dK = 0 exactly: a relative error against ~0)
     causal = rng.random() < 0.2
     if causal:
-        Sk = Sq
+        Sk = Sq = max(Sq, 2)                          # (causal 1 x 1 is the same degenerate case: the two r03 / r04 "failures")
     adt = rng.choice([torch.bfloat16, torch.bfloat16, torch.float32])
     if adt == torch.float32 and Sk * dh > 192 * 32 * 2:
         Sk = max(1, 192 * 32 * 2 // dh)              # fp32 ("precise") keeps K / V (backward: + Q) of a head in LDS as hi + lo bf16 pairs: capacity
