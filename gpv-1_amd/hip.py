@@ -101,7 +101,7 @@ EXPORTS = ['gpv_abi_version', 'gpv_build_id', 'gpv_set_option', 'gpv_gemm', 'gpv
            'gpv_softmax_ce', 'gpv_roi_weights', 'gpv_add', 'gpv_add_rowbcast', 'gpv_colsum', 'gpv_cast',
            'gpv_cast_rowscale_t', 'gpv_prep_conv_weight', 'gpv_embedding', 'gpv_dropout',
            'gpv_relevance_condition', 'gpv_adamw', 'gpv_sumsq', 'gpv_clip_scale', 'gpv_act_fwd', 'gpv_act_bwd', 'gpv_set_seed_device',
-           'gpv_gemm_tt_group', 'gpv_cast_transpose_group', 'gpv_stem_pool', 'gpv_image_pipeline', 'gpv_conv1x1_dual', 'gpv_conv1x1_chain',
+           'gpv_gemm_tt_group', 'gpv_cast_transpose_group', 'gpv_stem_pool', 'gpv_image_pipeline', 'gpv_conv1x1_dual', 'gpv_conv1x1_chain', 'gpv_ffn_fused_fwd',
            'gpv_conv_wgrad_group', 'gpv_jpeg_parse', 'gpv_jpeg_decode', 'gpv_argmax_rows', 'gpv_ln_linear_rows', 'gpv_attention_row_proj']
 
 
@@ -412,6 +412,21 @@ def conv1x1_chain(a1, w1, a2, w2, s2, res, bias, y, wn, bias_n, z, B, OH, OW):
     if err == 801:
         return False
     _chk(err, 'gpv_conv1x1_chain')
+    return True
+
+
+def ffn_fused_fwd(x, w1, b1, w2, b2, gamma, beta, h, y, out, mean, rstd, M, D, F, eps, drop_p=0.0, seed1=0, seed2=0, pos=None, out2=None):
+    """gpv_ffn_fused_fwd: LayerNorm(x + dropout(linear2(dropout(relu(linear1(x)))))) in one launch (h, y, mean, rstd stored for the
+    backward); False when the shape / dtype is not one the kernel takes -- the caller then runs gemm, gemm, layernorm_fwd"""
+    ts = [t for t in (x, w1, w2, h, y, out, pos, out2) if t is not None]
+    if not all(t.dtype == torch.bfloat16 and t.is_contiguous() for t in ts) or b1 is None or b2 is None:
+        return False
+    err = lib().gpv_ffn_fused_fwd(_p(x), _p(w1), _p(_f32(b1)), _p(w2), _p(_f32(b2)), _p(_f32(gamma)), _p(_f32(beta)), _p(h), _p(y), _p(out),
+                                  _p(mean), _p(rstd), C.c_int(M), C.c_int(D), C.c_int(F), C.c_float(eps), C.c_float(drop_p), C.c_uint64(seed1), C.c_uint64(seed2),
+                                  _p(pos), C.c_int(0 if pos is None else pos.numel() // D), _p(out2), _stream())
+    if err == 801:
+        return False
+    _chk(err, 'gpv_ffn_fused_fwd')
     return True
 
 

@@ -695,6 +695,11 @@ class AddLayerNormFn(Function):
         return ((dxr if ctx.needs_input_grad[0] else None), (dsr if ctx.needs_input_grad[1] else None)) + (None,) * (nin - 2)
 
 
+# gpv_ffn_fused_fwd (csrc/ffn_fused.hip): the sub-layer as one launch.  Correct (tests/test_kernels_gpu.py) and NOT faster as built --
+# 71 us against 71 us at M = 9600, 66 against 42 at M = 3200, step 17.6 - 17.8 against 17.4 - 17.6 ms -- so it is opt-in
+FFN_FUSED = os.environ.get('GPV_FFN_FUSED', '0') == '1'
+
+
 class FFNBlockFn(Function):
     """out = LayerNorm(x + dropout(W2 . dropout(relu(W1 x + b1)) + b2)): the whole post-norm feed-forward sub-layer
     (transformer.py:156-160, 226-231) as ONE autograd node.  x has two consumers (FFN input, residual); as separate nodes
@@ -711,16 +716,20 @@ class FFNBlockFn(Function):
         M = x2.shape[0]
         h = torch.empty(M, Fh, device=x.device, dtype=RT.dtype)
         seed1 = RT.next_seed() if drop_p > 0 else 0
-        hip.gemm(x2, w1.lp(), h, M, Fh, K, K, K, Fh, bias=w1.bias_f32(), act=ACT_RELU, drop_p=drop_p, seed=seed1)
         y = torch.empty(M, K, device=x.device, dtype=RT.dtype)
-        hip.gemm(h, w2.lp(), y, M, K, Fh, Fh, Fh, K, bias=w2.bias_f32())
         out = torch.empty_like(x2)
         mean = torch.empty(M, device=x.device, dtype=torch.float32)
         rstd = torch.empty_like(mean)
         seed2 = RT.next_seed() if drop_p > 0 else 0
         p2 = None if pos is None else _pos_rows(pos, K)
         out2 = None if pos is None else torch.empty_like(x2)
-        hip.layernorm_fwd(x2, y, gamma.detach(), beta.detach(), out, mean, rstd, M, K, eps, drop_p, seed2, pos=p2, y2=out2)
+        # (opt-in: one launch when the kernel takes the shape -- the DETR layers: 256 -> 2048 -> 256, bf16; the same seeds either way)
+        if not (FFN_FUSED and RT.dtype == torch.bfloat16 and w1.bias is not None and w2.bias is not None and
+                hip.ffn_fused_fwd(x2, w1.lp(), w1.bias_f32(), w2.lp(), w2.bias_f32(), gamma.detach(), beta.detach(), h, y, out, mean, rstd,
+                                  M, K, Fh, eps, drop_p, seed1, seed2, pos=p2, out2=out2)):
+            hip.gemm(x2, w1.lp(), h, M, Fh, K, K, K, Fh, bias=w1.bias_f32(), act=ACT_RELU, drop_p=drop_p, seed=seed1)
+            hip.gemm(h, w2.lp(), y, M, K, Fh, Fh, Fh, K, bias=w2.bias_f32())
+            hip.layernorm_fwd(x2, y, gamma.detach(), beta.detach(), out, mean, rstd, M, K, eps, drop_p, seed2, pos=p2, y2=out2)
         ctx.w1, ctx.w2, ctx.gamma, ctx.beta, ctx.drop_p, ctx.seed2, ctx.xshape = w1, w2, gamma, beta, drop_p, seed2, x.shape
         ctx.pos_param = pos_param
         ctx.save_for_backward(x2, h, y, mean, rstd)

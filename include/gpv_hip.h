@@ -231,6 +231,20 @@ int gpv_conv1x1_dual(const void* a1, const void* w1, const void* a2, const void*
 int gpv_conv1x1_chain(const void* a1, const void* w1, int K1, const void* a2, const void* w2, int K2, int IH2, int IW2, int s2,
                       const void* res, const float* bias, void* y, int B, int OH, int OW, int N, const void* wn,
                       const float* bias_n, void* z, int N2, void* stream);
+/* The post-norm feed-forward sub-layer of a DETR encoder / decoder layer in ONE launch (exp/gpv/models/transformer.py:156-160
+ * encoder, :226-231 decoder: src + dropout2(linear2(dropout(relu(linear1(src))))) -> norm2):
+ *   h[M,F]   = dropout(relu(x[M,D] . w1[F,D]^T + b1))        stored: the backward's ReLU mask and the dW2 operand
+ *   y[M,D]   = h . w2[D,F]^T + b2                            stored (bf16): the LayerNorm backward recomputes x + dropout(y)
+ *   out[M,D] = LayerNorm(x + dropout(y)) * gamma + beta ;  mean[M], rstd[M] fp32 ;  out2 = out + pos[row % pos_rows] (optional, both
+ *              or neither of pos / out2, as gpv_layernorm_pos_fwd)
+ * replaces gpv_gemm (ReLU + dropout epilogue), gpv_gemm, gpv_layernorm_pos_fwd: the [M,F] activation is not read back from HBM, the
+ * second product consumes it from the first one's accumulator registers.  bf16 x / w1 / w2 / h / y / out / pos, fp32 the rest; one
+ * drop_p for both dropouts, masks = (seed1 | seed2, flat element index) exactly as the replaced launches draw them.  Same rounding
+ * points as the three launches (h, y rounded to bf16), the F-sum split in two halves.  D = 256, F % 64 == 0, 16-byte aligned pointers;
+ * anything else: hipErrorNotSupported (801) and the caller launches the three kernels. */
+int gpv_ffn_fused_fwd(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, const float* gamma,
+                      const float* beta, void* h, void* y, void* out, float* mean, float* rstd, int M, int D, int F, float eps,
+                      float drop_p, uint64_t seed1, uint64_t seed2, const void* pos, int pos_rows, void* out2, void* stream);
 /* The whole ResNet stem in one launch (exp/gpv/models/backbone.py:93-95 -> torchvision resnet50 conv1 + bn1 (frozen: scale folded
  * into w, shift here) + relu + maxpool):  y[B,PH,PW,64] = maxpool3x3s2p1(relu(conv7x7s2(x) + shift)).  x = the zero-padded NHWC4
  * bf16 image gpv_image_to_nhwc4 writes with pad 3 ([B,Hp,Wp,4], Wp even, >= 2 (CW - 1) + 8), w = [64][7][8 px][4 ch] bf16 (8th pixel /

@@ -217,6 +217,10 @@ def conv1x1_chain(a1, w1, a2, w2, s2, res, bias, y, wn, bias_n, z, B, OH, OW):
     return False                       # (bf16 kernel only: the CPU emulation runs the convolutions one by one)
 
 
+def ffn_fused_fwd(*a, **k):
+    return False                       # (bf16 kernel only: the CPU emulation runs gemm, gemm, layernorm_fwd)
+
+
 def conv_wgrad_group(problems):
     for x, dy, dw, scale, B, IH, IW, Cs, Cin, OH, OW, Cout, KH, KW, SH, SW, PH, PW in problems:
         conv2d(2, x, dy, dw, B, IH, IW, Cs, Cin, OH, OW, Cout, KH, KW, SH, SW, PH, PW, rowscale=scale)
@@ -374,7 +378,7 @@ def install(only=None):
     `only`: optional list of entry-point names (GPU bisecting: swap single kernels for torch math)."""
     import gpv1_amd.hip as h
     names = only or ['gemm', 'conv2d', 'attention_fwd', 'attention_bwd', 'layernorm_fwd', 'layernorm_bwd', 'softmax_ce',
-             'image_to_nhwc4', 'maxpool3x3s2', 'stem_pool', 'conv1x1_dual', 'conv1x1_chain', 'conv_wgrad_group', 'roi_weights', 'add', 'add_rowbcast', 'colsum', 'cast', 'cast_rowscale_t',
+             'image_to_nhwc4', 'maxpool3x3s2', 'stem_pool', 'conv1x1_dual', 'conv1x1_chain', 'ffn_fused_fwd', 'conv_wgrad_group', 'roi_weights', 'add', 'add_rowbcast', 'colsum', 'cast', 'cast_rowscale_t',
              'prep_conv_weight', 'embedding', 'dropout', 'relevance_condition', 'adamw', 'sumsq', 'clip_scale', 'act_fwd', 'act_bwd',
              'cast_transpose_group', 'argmax_rows', 'ln_linear_rows', 'attention_row_proj']
     saved = {n: getattr(h, n) for n in names}

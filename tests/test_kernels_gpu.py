@@ -1325,3 +1325,115 @@ def test_layernorm_second_output_and_second_gradient(dtype, rows, cols, prow):
     ref = rstd[:, None] * (gy - gy.mean(-1, keepdim=True) - zh * (gy * zh).mean(-1, keepdim=True))
     assert rel(dx, ref) < TOL[dtype]
     assert rel(dg, (gsum * zh).sum(0)) < 2e-3 and rel(db, gsum.sum(0)) < 2e-3
+
+
+# ----------------------------------------------------------------------------------------- fused feed-forward sub-layer
+def _bf16_ulps(a, b):
+    """distance in bf16 code points between two bf16 tensors (same sign assumed where it matters: zeros map to 0)"""
+    ia = a.view(torch.int16).to(torch.int32)
+    ib = b.view(torch.int16).to(torch.int32)
+    ia = torch.where(ia < 0, -(ia & 0x7fff), ia)
+    ib = torch.where(ib < 0, -(ib & 0x7fff), ib)
+    return (ia - ib).abs()
+
+
+@pytest.mark.parametrize('M,Fh,prow,drop', [(9600, 2048, 0, 0.0), (9600, 2048, 300, 0.1), (3200, 2048, 100, 0.1), (200, 2048, 100, 0.1),
+                                            (77, 128, 0, 0.0), (64, 64, 64, 0.25), (1, 2048, 1, 0.1)])
+def test_ffn_fused_fwd_equals_the_three_launches(M, Fh, prow, drop):
+    """gpv_ffn_fused_fwd (transformer.py:156-160, 226-231 as one launch) against gpv_gemm (ReLU + dropout) -> gpv_gemm ->
+    gpv_layernorm_pos_fwd with the same seeds.  h: the same products in the same order, the same mask: identical up to the rare 1-ulp
+    rounding flip of a different MFMA schedule; y: the F-sum is split in two halves: <= 2 bf16 ulp of a K = F sum; out: LayerNorm of
+    values that differ by those ulps.  And against fp32 math on the same inputs without dropout."""
+    h = hip()
+    D = 256
+    x = rnd(M, D, dtype=torch.bfloat16, seed=1)
+    w1, b1 = rnd(Fh, D, dtype=torch.bfloat16, seed=2, scale=0.06), 0.1 * rnd(Fh, seed=3)
+    w2, b2 = rnd(D, Fh, dtype=torch.bfloat16, seed=4, scale=0.03), 0.1 * rnd(D, seed=5)
+    gamma, beta = 1.0 + 0.1 * rnd(D, seed=6), 0.1 * rnd(D, seed=7)
+    pos = rnd(prow, D, dtype=torch.bfloat16, seed=8) if prow else None
+    seed1, seed2 = 0x1234567, 0x89abcde
+    bf = torch.bfloat16
+
+    def bufs():
+        return (torch.empty(M, Fh, device=DEV, dtype=bf), torch.empty(M, D, device=DEV, dtype=bf), torch.empty(M, D, device=DEV, dtype=bf),
+                torch.empty(M, device=DEV), torch.empty(M, device=DEV), torch.empty(M, D, device=DEV, dtype=bf) if prow else None)
+    hh, y, out, mean, rstd, out2 = bufs()
+    assert h.ffn_fused_fwd(x, w1, b1, w2, b2, gamma, beta, hh, y, out, mean, rstd, M, D, Fh, 1e-5, drop, seed1, seed2, pos=pos, out2=out2)
+    h0, y0, o0, m0, r0, o20 = bufs()
+    h.gemm(x, w1, h0, M, Fh, D, D, D, Fh, bias=b1, act=h.ACT_RELU, drop_p=drop, seed=seed1)
+    h.gemm(h0, w2, y0, M, D, Fh, Fh, Fh, D, bias=b2)
+    h.layernorm_fwd(x, y0, gamma, beta, o0, m0, r0, M, D, 1e-5, drop, seed2, pos=pos, y2=o20)
+    torch.cuda.synchronize()
+    # hidden activation: same zeros (ReLU and the dropout mask), same values
+    assert torch.equal(hh == 0, h0 == 0) or ((hh == 0) != (h0 == 0)).float().mean().item() < 1e-5
+    du = _bf16_ulps(hh, h0)
+    assert du.max().item() <= 1 and (du > 0).float().mean().item() < 2e-3, (du.max().item(), (du > 0).float().mean().item())
+    if drop > 0:
+        kept = (hh != 0).float().sum() / (F.relu(x.float() @ w1.float().t() + b1) > 0).float().sum()
+        assert abs(kept.item() - (1 - drop)) < 0.02
+    # second product from the kernel's own h in fp32: one bf16 rounding
+    yref = hh.float() @ w2.float().t() + b2
+    assert rel(y, yref) < 6e-3
+    assert (y.float() - y0.float()).abs().max().item() <= 2 * 2.0 ** -8 * yref.abs().max().item()
+    assert (out.float() - o0.float()).abs().max().item() <= 0.05 and (out.float() - o0.float()).abs().mean().item() < 2e-3
+    assert rel(mean, m0) < 2e-2 and rel(rstd, r0) < 2e-2
+    if prow:
+        want = (out.float().reshape(M // prow, prow, D) + pos.float()[None]).to(bf).reshape(M, D)
+        assert torch.equal(out2, want)
+    # LayerNorm from the kernel's own y: the epilogue alone, against fp32 math (dropout mask taken from the unfused LayerNorm's rule)
+    if drop == 0:
+        z = x.float() + y.float()
+        ref = F.layer_norm(z, (D,), gamma, beta, 1e-5)
+        assert rel(out, ref) < TOL[bf]
+        assert rel(mean, z.mean(-1)) < 1e-3 and rel(rstd, (z.var(-1, unbiased=False) + 1e-5).rsqrt()) < 1e-3
+        full = F.layer_norm(x.float() + F.relu(x.float() @ w1.float().t() + b1).to(bf).float() @ w2.float().t() + b2, (D,), gamma, beta, 1e-5)
+        assert rel(out, full) < 2 * TOL[bf]
+
+
+def test_ffn_fused_fwd_refuses_what_it_does_not_take():
+    h = hip()
+    bf = torch.bfloat16
+    x = rnd(64, 512, dtype=bf)
+    w1, w2 = rnd(128, 512, dtype=bf), rnd(512, 128, dtype=bf)
+    z = torch.zeros(512, device=DEV)
+    args = (torch.empty(64, 128, device=DEV, dtype=bf), torch.empty(64, 512, device=DEV, dtype=bf), torch.empty(64, 512, device=DEV, dtype=bf),
+            torch.empty(64, device=DEV), torch.empty(64, device=DEV))
+    assert h.ffn_fused_fwd(x, w1, torch.zeros(128, device=DEV), w2, z, z, z, *args, 64, 512, 128, 1e-5) is False       # width 512
+    x = rnd(64, 256, dtype=bf)
+    w1, w2 = rnd(96, 256, dtype=bf), rnd(256, 96, dtype=bf)
+    z = torch.zeros(256, device=DEV)
+    args = (torch.empty(64, 96, device=DEV, dtype=bf), torch.empty(64, 256, device=DEV, dtype=bf), torch.empty(64, 256, device=DEV, dtype=bf),
+            torch.empty(64, device=DEV), torch.empty(64, device=DEV))
+    assert h.ffn_fused_fwd(x, w1, torch.zeros(96, device=DEV), w2, z, z, z, *args, 64, 256, 96, 1e-5) is False        # F % 64
+    xf = rnd(64, 256)
+    assert h.ffn_fused_fwd(xf, w1, torch.zeros(96, device=DEV), w2, z, z, z, *args, 64, 256, 96, 1e-5) is False       # fp32 operands
+
+
+def test_ffn_block_with_the_fused_forward_matches_the_three_launch_node(monkeypatch):
+    """ops.FFNBlockFn with GPV_FFN_FUSED on (opt-in): the forward's saved tensors (h, y, mean, rstd) feed the unchanged backward --
+    outputs and every gradient within bf16 rounding of the default node's, same seeds, dropout on."""
+    import gpv1_amd.ops as ops
+    from gpv1_amd.transformer import LinearP, LayerNormP, ffn_block
+    hip()
+    ops.RT.set_precise(False)
+    torch.manual_seed(0)
+    M, D, Fh = 3200, 256, 2048
+    l1, l2, norm = LinearP(D, Fh).to(DEV), LinearP(Fh, D).to(DEV), LayerNormP(D).to(DEV)
+    pos = rnd(100, D, dtype=torch.bfloat16, seed=3)
+    x0 = rnd(M, D, dtype=torch.bfloat16, seed=1)
+    dy, dy2 = rnd(M, D, dtype=torch.bfloat16, seed=2), rnd(M, D, dtype=torch.bfloat16, seed=4)
+    res = {}
+    for fused in (False, True):
+        monkeypatch.setattr(ops, 'FFN_FUSED', fused)
+        ops.RT.manual_seed(77)
+        for q in list(l1.parameters()) + list(l2.parameters()) + list(norm.parameters()):
+            q.grad = None
+        x = x0.clone().requires_grad_(True)
+        out, out2 = ffn_block(x, l1, l2, norm, 0.1, pos=pos)
+        torch.autograd.backward([out, out2], [dy, dy2])
+        torch.cuda.synchronize()
+        res[fused] = [out.detach().float(), out2.detach().float(), x.grad.float()] + \
+            [q.grad.float().clone() for q in list(l1.parameters()) + list(l2.parameters()) + list(norm.parameters())]
+    for a, b in zip(res[True], res[False]):
+        assert rel(a, b) < 2e-2, rel(a, b)
+        assert torch.nn.functional.cosine_similarity(a.flatten(), b.flatten(), dim=0).item() > 0.9995
