@@ -32,9 +32,9 @@
 // 16 us of prologue + epilogue per workgroup, then 1.5 us per 64-feature chunk where the MFMAs need 0.43: with 400 VGPRs there is ONE wave
 // per SIMD, and inside a chunk the first product, its bias / ReLU / dropout / rounding (VALU, ~250 instructions of 4 cycles) and the second
 // product depend on each other in that order -- nothing overlaps; removing the fragment reads, the barrier or the h stores changes
-// nothing (1.24 - 1.34 us), removing the weight loads 0.38 us: the 64 KB in flight per CU arrive at 18 B/clk.  What would make it win:
-// the first product of chunk t + 1 issued under the epilogue arithmetic of chunk t (W1 / W2 stages one chunk out of phase) and three
-// smaller stages in flight; estimated 45 - 50 us at M = 9600, i.e. 0.12 ms per step forward -- not built.
+// nothing (1.24 - 1.34 us), removing the weight loads 0.38 us: the 64 KB in flight per CU arrive at 18 B/clk.  And overlapping the phases would not be enough: the 2 MB of
+// weights a workgroup streams through its CU at those 18 B/clk are 48 us by themselves -- rows stationary with all of F per workgroup is
+// bound by per-CU weight delivery; the three launches win by moving the [M, 2048] activation through HBM with all CUs at once.
 #include "gemm_common.h"
 
 namespace gpvk {
