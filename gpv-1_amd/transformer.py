@@ -62,7 +62,7 @@ class MultiheadAttention(nn.Module):
         nn.init.xavier_uniform_(self.in_proj_weight)
         nn.init.constant_(self.out_proj.bias, 0.)
 
-    def forward(self, q_in, k_in, v_in, B, Sq, Sk, key_padding_mask=None, causal=False, chains=(None, None, None), kv=None):
+    def forward(self, q_in, k_in, v_in, B, Sq, Sk, key_padding_mask=None, causal=False, chains=(None, None, None), kv=None, out_drop=0.0):
         """chains: ops.GradChain (or None) of the tensor behind q_in / k_in / v_in -- only where the projection's input gradient
         IS that tensor's gradient (the input itself, or input + a constant position term).
         kv = (K buffer, key column, V buffer, value column, sink_K, sink_V): keys / values already projected, as column slices of
@@ -81,7 +81,7 @@ class MultiheadAttention(nn.Module):
             o = ops.attention(bufs, roles, B, self.num_heads, Sq, Sk, self.head_dim, kpm=key_padding_mask,
                               causal=causal, drop_p=self.dropout if self.training else 0.0,
                               sinks=sinks if (sk is not None or sv is not None) else None)
-            return self.out_proj(o)
+            return self.out_proj(o, drop_p=out_drop)
         if q_in is k_in and k_in is v_in:
             bufs = [ops.linear(q_in, W(w, b, 0, 3 * E), chain=cq)]
             roles = ((0, 0), (0, E), (0, 2 * E))
@@ -97,7 +97,7 @@ class MultiheadAttention(nn.Module):
             roles = ((0, 0), (1, 0), (2, 0))
         o = ops.attention(bufs, roles, B, self.num_heads, Sq, Sk, self.head_dim, kpm=key_padding_mask, causal=causal,
                           drop_p=self.dropout if self.training else 0.0)
-        return self.out_proj(o)
+        return self.out_proj(o, drop_p=out_drop)
 
 
 class TransformerEncoderLayer(nn.Module):
@@ -118,6 +118,16 @@ class TransformerEncoderLayer(nn.Module):
         ch = ops.grad_chain(src)                 # src feeds norm1's residual, Wqk (through src + pos, pos constant) and Wv
         src = self.norm1(src, self.self_attn(qk, qk, src, B, S, S, kpm, chains=(ch, ch, ch)), p, chain=ch)
         return ffn_block(src, self.linear1, self.linear2, self.norm2, p, pos=pos)
+
+    def forward_pre(self, src, pos, B, S, kpm):
+        """transformer.py:163-175 (`pre_norm: true`; no shipped config): normalise, attend / feed forward, add to the stream.
+        Plain composition of the same kernels -- LayerNorm with its `+ pos` second output, attention, GEMMs with the dropout in
+        their epilogues, element-wise add; autograd sums the stream's two consumers.  Not tuned: correctness branch."""
+        p = self.p if self.training else 0.0
+        s2, qk = self.norm1(src, pos=pos)
+        src = ops.add(src, self.self_attn(qk, qk, s2, B, S, S, kpm, out_drop=p))
+        s2 = self.norm2(src)
+        return ops.add(src, self.linear2(self.linear1(s2, ops.ACT_RELU, p), drop_p=p))
 
 
 class TransformerDecoderLayer(nn.Module):
@@ -150,12 +160,23 @@ class TransformerDecoderLayer(nn.Module):
             return ffn_block(tgt, self.linear1, self.linear2, self.norm3, p), None
         return ffn_block(tgt, self.linear1, self.linear2, self.norm3, p, pos=qpos, pos_param=qpos_param)
 
+    def forward_pre(self, tgt, memory, mem_pos, qpos, qpos_param, B, Q, S, kpm):
+        """transformer.py:234-255 (`pre_norm: true`): see TransformerEncoderLayer.forward_pre.  query_pos enters through the
+        LayerNorms' second output, its gradient through ops._pos_sink as in forward()."""
+        p = self.p if self.training else 0.0
+        t2, tq = self.norm1(tgt, pos=qpos, pos_param=qpos_param)
+        tgt = ops.add(tgt, self.self_attn(tq, tq, t2, B, Q, Q, out_drop=p))
+        t2, tq = self.norm2(tgt, pos=qpos, pos_param=qpos_param)
+        tgt = ops.add(tgt, self.multihead_attn(tq, mem_pos, memory, B, Q, S, kpm, out_drop=p))
+        t2 = self.norm3(tgt)
+        return ops.add(tgt, self.linear2(self.linear1(t2, ops.ACT_RELU, p), drop_p=p))
+
 
 class TransformerEncoder(nn.Module):
-    def __init__(self, make_layer, num_layers):
+    def __init__(self, make_layer, num_layers, norm=None):
         super().__init__()
         self.layers = nn.ModuleList([make_layer() for _ in range(num_layers)])
-        self.norm = None
+        self.norm = norm                          # LayerNorm only with pre_norm (transformer.py:37)
 
 
 class TransformerDecoder(nn.Module):
@@ -169,10 +190,9 @@ class Transformer(nn.Module):
     def __init__(self, d_model=512, nhead=8, num_encoder_layers=6, num_decoder_layers=6, dim_feedforward=2048,
                  dropout=0.1, normalize_before=False, return_intermediate_dec=False):
         super().__init__()
-        if normalize_before:
-            raise NotImplementedError('pre_norm is False in every GPV-1 config (configs/exp/gpv*.yaml)')
+        self.normalize_before = bool(normalize_before)
         self.encoder = TransformerEncoder(lambda: TransformerEncoderLayer(d_model, nhead, dim_feedforward, dropout),
-                                          num_encoder_layers)
+                                          num_encoder_layers, LayerNormP(d_model) if normalize_before else None)
         self.decoder = TransformerDecoder(lambda: TransformerDecoderLayer(d_model, nhead, dim_feedforward, dropout),
                                           num_decoder_layers, d_model)
         self.d_model, self.nhead = d_model, nhead
@@ -188,6 +208,8 @@ class Transformer(nn.Module):
         kpm = mask.to(torch.uint8).contiguous() if mask is not None else None
         x = src.reshape(B * S, C)
         pe = pos.reshape(B * S, C)
+        if self.normalize_before:
+            return self._forward_pre(x, pe, kpm, query_embed, B, S, C, Q, need_all_layers)
         if len(self.encoder.layers) == 0:
             xq = ops.add(x, pe)
         else:
@@ -221,6 +243,27 @@ class Transformer(nn.Module):
             if need_all_layers or i == n - 1:
                 outs.append(self.decoder.norm(tgt).reshape(B, Q, C))
         return outs, memory.reshape(B, S, C)
+
+
+def _transformer_forward_pre(self, x, pe, kpm, query_embed, B, S, C, Q, need_all_layers):
+    """`pre_norm: true` (transformer.py:46-58 with forward_pre layers and the encoder's final LayerNorm): the plain schedule -- every
+    layer projects its own keys / values, no gradient chains or sinks"""
+    pe = ops._pos_rows(pe, C)
+    for layer in self.encoder.layers:
+        x = layer.forward_pre(x, pe, B, S, kpm)
+    memory, mem_pos = self.encoder.norm(x, pos=pe)
+    qp = query_embed.detach().to(ops.RT.dtype).contiguous()
+    tgt = torch.zeros(B * Q, C, device=x.device, dtype=ops.RT.dtype)
+    outs = []
+    n = len(self.decoder.layers)
+    for i, layer in enumerate(self.decoder.layers):
+        tgt = layer.forward_pre(tgt, memory, mem_pos, qp, query_embed, B, Q, S, kpm)
+        if need_all_layers or i == n - 1:
+            outs.append(self.decoder.norm(tgt).reshape(B, Q, C))
+    return outs, memory.reshape(B, S, C)
+
+
+Transformer._forward_pre = _transformer_forward_pre
 
 
 def build_transformer(args):

@@ -225,24 +225,40 @@ def sine_position(mask: Tensor, num_pos_feats: int = 128, temperature: float = 1
 # --------------------------------------------------------------------------
 # DETR transformer (transformer.py:46-58,148-161,211-232,94-123), batch-first internally
 # --------------------------------------------------------------------------
-def detr_encoder_layer(Pm: P, pre: str, src: Tensor, pos: Tensor, kpm: Tensor, nhead: int) -> Tensor:
+def _ffn(Pm: P, pre: str, x: Tensor) -> Tensor:
+    return linear(F.relu(linear(x, Pm[pre + 'linear1.weight'], Pm[pre + 'linear1.bias'])), Pm[pre + 'linear2.weight'], Pm[pre + 'linear2.bias'])
+
+
+def detr_encoder_layer(Pm: P, pre: str, src: Tensor, pos: Tensor, kpm: Tensor, nhead: int, pre_norm: bool = False) -> Tensor:
+    if pre_norm:                            # forward_pre, transformer.py:163-175: normalise, attend / feed forward, add
+        s2 = layer_norm(src, Pm[pre + 'norm1.weight'], Pm[pre + 'norm1.bias'], 1e-5)
+        qk = _r(s2 + pos)
+        src = _r(src + torch_mha(Pm, pre + 'self_attn.', qk, qk, s2, nhead, kpm))
+        s2 = layer_norm(src, Pm[pre + 'norm2.weight'], Pm[pre + 'norm2.bias'], 1e-5)
+        return _r(src + _ffn(Pm, pre, s2))
     qk = _r(src + pos)
     a = torch_mha(Pm, pre + 'self_attn.', qk, qk, src, nhead, kpm)
     src = layer_norm(src + a, Pm[pre + 'norm1.weight'], Pm[pre + 'norm1.bias'], 1e-5)
-    f = linear(F.relu(linear(src, Pm[pre + 'linear1.weight'], Pm[pre + 'linear1.bias'])),
-               Pm[pre + 'linear2.weight'], Pm[pre + 'linear2.bias'])
+    f = _ffn(Pm, pre, src)
     return layer_norm(src + f, Pm[pre + 'norm2.weight'], Pm[pre + 'norm2.bias'], 1e-5)
 
 
 def detr_decoder_layer(Pm: P, pre: str, tgt: Tensor, memory: Tensor, pos: Tensor, qpos: Tensor,
-                       kpm: Tensor, nhead: int) -> Tensor:
+                       kpm: Tensor, nhead: int, pre_norm: bool = False) -> Tensor:
+    if pre_norm:                            # forward_pre, transformer.py:234-255
+        t2 = layer_norm(tgt, Pm[pre + 'norm1.weight'], Pm[pre + 'norm1.bias'], 1e-5)
+        qk = _r(t2 + qpos)
+        tgt = _r(tgt + torch_mha(Pm, pre + 'self_attn.', qk, qk, t2, nhead))
+        t2 = layer_norm(tgt, Pm[pre + 'norm2.weight'], Pm[pre + 'norm2.bias'], 1e-5)
+        tgt = _r(tgt + torch_mha(Pm, pre + 'multihead_attn.', _r(t2 + qpos), _r(memory + pos), memory, nhead, kpm))
+        t2 = layer_norm(tgt, Pm[pre + 'norm3.weight'], Pm[pre + 'norm3.bias'], 1e-5)
+        return _r(tgt + _ffn(Pm, pre, t2))
     qk = _r(tgt + qpos)
     a = torch_mha(Pm, pre + 'self_attn.', qk, qk, tgt, nhead)
     tgt = layer_norm(tgt + a, Pm[pre + 'norm1.weight'], Pm[pre + 'norm1.bias'], 1e-5)
     a = torch_mha(Pm, pre + 'multihead_attn.', _r(tgt + qpos), _r(memory + pos), memory, nhead, kpm)
     tgt = layer_norm(tgt + a, Pm[pre + 'norm2.weight'], Pm[pre + 'norm2.bias'], 1e-5)
-    f = linear(F.relu(linear(tgt, Pm[pre + 'linear1.weight'], Pm[pre + 'linear1.bias'])),
-               Pm[pre + 'linear2.weight'], Pm[pre + 'linear2.bias'])
+    f = _ffn(Pm, pre, tgt)
     return layer_norm(tgt + f, Pm[pre + 'norm3.weight'], Pm[pre + 'norm3.bias'], 1e-5)
 
 
@@ -254,14 +270,17 @@ def detr_transformer(Pm: P, cfg, src: Tensor, mask: Tensor, pos: Tensor) -> Tupl
     pe = _r(pos.flatten(2).transpose(1, 2))
     kpm = mask.flatten(1)
     nhead = cfg['nheads']
+    pn = bool(cfg.get('pre_norm', False))
     for i in range(cfg['num_encoder_layers']):
-        x = detr_encoder_layer(Pm, f'{pre}encoder.layers.{i}.', x, pe, kpm, nhead)
+        x = detr_encoder_layer(Pm, f'{pre}encoder.layers.{i}.', x, pe, kpm, nhead, pn)
+    if pn:                                  # the encoder's own final LayerNorm exists only with pre_norm (transformer.py:37)
+        x = layer_norm(x, Pm[pre + 'encoder.norm.weight'], Pm[pre + 'encoder.norm.bias'], 1e-5)
     memory = x
     qpos = _r(Pm['detr.query_embed.weight'])[None].expand(B, -1, -1)
     tgt = torch.zeros_like(qpos)
     inter = []
     for i in range(cfg['num_decoder_layers']):
-        tgt = detr_decoder_layer(Pm, f'{pre}decoder.layers.{i}.', tgt, memory, pe, qpos, kpm, nhead)
+        tgt = detr_decoder_layer(Pm, f'{pre}decoder.layers.{i}.', tgt, memory, pe, qpos, kpm, nhead, pn)
         inter.append(layer_norm(tgt, Pm[pre + 'decoder.norm.weight'], Pm[pre + 'decoder.norm.bias'], 1e-5))
     return torch.stack(inter), memory
 
