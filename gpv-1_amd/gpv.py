@@ -120,8 +120,14 @@ class GPV(nn.Module):
         if isinstance(cfg, dict) and not isinstance(cfg, AttrDict):
             cfg = AttrDict.wrap(cfg)
         self.cfg = cfg
-        if cfg.answer_head is not None or cfg.answering_type != 'generation':
-            raise NotImplementedError('gpv1_amd covers the shipped configuration: answer_head null, answering_type generation')
+        if cfg.answering_type not in ('generation', 'classification'):
+            raise ValueError(f'answering_type {cfg.answering_type!r}: generation | classification (gpv.py:384-401)')
+        if cfg.answer_head is not None:
+            # answer_head: linear builds nn.Linear(detr.hidden_dim = 256, V) (answer_head.py:36-59, build_answer_head passes
+            # cfg.detr.hidden_dim) and applies it to the text decoder's 768-wide output (gpv.py:466): the reference itself cannot run
+            # this branch with GPV-1's widths, so there is nothing to be faithful to
+            raise NotImplementedError('answer_head: linear is shape-inconsistent in the reference itself (Linear(256, V) on 768-wide '
+                                      'decoder outputs); gpv1_amd builds answer_head: null')
         self.detr = create_detr_roi_head(cfg.detr) if cfg.roi_head is True else create_detr(cfg.detr)
         self.detr_joiner = LinearP(cfg.detr_joiner.detr_dim, cfg.detr_joiner.out_dim)
         self.init_detr_params = []
@@ -509,7 +515,7 @@ class GPV(nn.Module):
         return outputs
 
     def encode_answers(self, targets):
-        """gpv.py:377-430 (generation branch)"""
+        """gpv.py:377-430 (generation: tokenised sentence with __cls__ / __stop__ / __pad__; classification: [__cls__, answer])"""
         padded_inputs, ids = self._encode_answers_host(targets)
         dev = self.vision_token.device
         from .misc import STAGER
@@ -518,6 +524,10 @@ class GPV(nn.Module):
     def _encode_answers_host(self, targets):
         """-> (token strings per sample padded to the batch's longest, their vocabulary ids as host lists)"""
         answers = [t.get('answer', '') for t in targets]
+        if self.cfg.answering_type == 'classification':
+            # gpv.py:384-399: the answer is ONE vocabulary entry looked up as it is (no tokenisation, no lower-casing, no __stop__)
+            padded_inputs = [['__cls__', a] for a in answers]
+            return padded_inputs, [[self.word_to_idx.get(w, self.word_to_idx['__unk__']) for w in toks] for toks in padded_inputs]
         padded_inputs, S = [], 0
         for a in answers:
             sent = '__cls__ __stop__' if a == '' else f'__cls__ {a} __stop__'

@@ -56,8 +56,33 @@ class PositionEmbeddingSine(nn.Module):
         return pos
 
 
+class PositionEmbeddingLearned(nn.Module):
+    """position_encoding.py:50-75 (`position_embedding: learned | v3`; no shipped GPV-1 config): a learned row and a learned column
+    table of 50 entries each, the same grid for every image (the padding mask is not looked at).  Returned like the sine one --
+    [B, h*w, 2*num_pos_feats] rows in the compute dtype -- but WITH its autograd history: while it requires a gradient the DETR
+    transformer adds it with element-wise launches autograd can see (transformer.Transformer._forward_plain) instead of taking it
+    as a constant of the LayerNorm kernels' second output."""
+
+    def __init__(self, num_pos_feats=256):
+        super().__init__()
+        self.row_embed = nn.Embedding(50, num_pos_feats)
+        self.col_embed = nn.Embedding(50, num_pos_feats)
+        nn.init.uniform_(self.row_embed.weight)
+        nn.init.uniform_(self.col_embed.weight)
+
+    def forward(self, tensor_list):
+        B, h, w = tensor_list.mask.shape
+        if h > 50 or w > 50:
+            raise ValueError(f'learned position embedding: {h} x {w} feature map, the tables hold 50 rows / columns')
+        x_emb, y_emb = self.col_embed.weight[:w], self.row_embed.weight[:h]
+        pos = torch.cat((x_emb.unsqueeze(0).expand(h, w, -1), y_emb.unsqueeze(1).expand(h, w, -1)), -1)      # [h, w, C]: (column | row) halves
+        return pos.reshape(1, h * w, -1).expand(B, h * w, -1).to(RT.dtype)
+
+
 def build_position_encoding(args):
     n_steps = args.hidden_dim // 2
     if args.position_embedding in ('v2', 'sine'):
         return PositionEmbeddingSine(n_steps, normalize=True)
-    raise ValueError(f"not supported {args.position_embedding} (GPV-1 ships position_embedding: sine)")
+    if args.position_embedding in ('v3', 'learned'):
+        return PositionEmbeddingLearned(n_steps)
+    raise ValueError(f"not supported {args.position_embedding}")

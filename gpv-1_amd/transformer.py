@@ -119,12 +119,16 @@ class TransformerEncoderLayer(nn.Module):
         src = self.norm1(src, self.self_attn(qk, qk, src, B, S, S, kpm, chains=(ch, ch, ch)), p, chain=ch)
         return ffn_block(src, self.linear1, self.linear2, self.norm2, p, pos=pos)
 
-    def forward_pre(self, src, pos, B, S, kpm):
+    def forward_pre(self, src, pos, B, S, kpm, pos_grad=False):
         """transformer.py:163-175 (`pre_norm: true`; no shipped config): normalise, attend / feed forward, add to the stream.
         Plain composition of the same kernels -- LayerNorm with its `+ pos` second output, attention, GEMMs with the dropout in
         their epilogues, element-wise add; autograd sums the stream's two consumers.  Not tuned: correctness branch."""
         p = self.p if self.training else 0.0
-        s2, qk = self.norm1(src, pos=pos)
+        if pos_grad:                              # a LEARNED position term: the sum is a launch autograd can differentiate
+            s2 = self.norm1(src)
+            qk = ops.add(s2, pos)
+        else:
+            s2, qk = self.norm1(src, pos=pos)
         src = ops.add(src, self.self_attn(qk, qk, s2, B, S, S, kpm, out_drop=p))
         s2 = self.norm2(src)
         return ops.add(src, self.linear2(self.linear1(s2, ops.ACT_RELU, p), drop_p=p))
@@ -210,6 +214,8 @@ class Transformer(nn.Module):
         pe = pos.reshape(B * S, C)
         if self.normalize_before:
             return self._forward_pre(x, pe, kpm, query_embed, B, S, C, Q, need_all_layers)
+        if torch.is_grad_enabled() and pe.requires_grad:
+            return self._forward_plain(x, pe, kpm, query_embed, B, S, C, Q, need_all_layers)
         if len(self.encoder.layers) == 0:
             xq = ops.add(x, pe)
         else:
@@ -248,10 +254,15 @@ class Transformer(nn.Module):
 def _transformer_forward_pre(self, x, pe, kpm, query_embed, B, S, C, Q, need_all_layers):
     """`pre_norm: true` (transformer.py:46-58 with forward_pre layers and the encoder's final LayerNorm): the plain schedule -- every
     layer projects its own keys / values, no gradient chains or sinks"""
-    pe = ops._pos_rows(pe, C)
+    pos_grad = torch.is_grad_enabled() and pe.requires_grad
+    pe = ops._as_compute(pe) if pos_grad else ops._pos_rows(pe, C)
     for layer in self.encoder.layers:
-        x = layer.forward_pre(x, pe, B, S, kpm)
-    memory, mem_pos = self.encoder.norm(x, pos=pe)
+        x = layer.forward_pre(x, pe, B, S, kpm, pos_grad)
+    if pos_grad:
+        memory = self.encoder.norm(x)
+        mem_pos = ops.add(memory, pe)
+    else:
+        memory, mem_pos = self.encoder.norm(x, pos=pe)
     qp = query_embed.detach().to(ops.RT.dtype).contiguous()
     tgt = torch.zeros(B * Q, C, device=x.device, dtype=ops.RT.dtype)
     outs = []
@@ -264,6 +275,37 @@ def _transformer_forward_pre(self, x, pe, kpm, query_embed, B, S, C, Q, need_all
 
 
 Transformer._forward_pre = _transformer_forward_pre
+
+
+def _transformer_forward_plain(self, x, pe, kpm, query_embed, B, S, C, Q, need_all_layers):
+    """Post-norm layers (transformer.py:148-161, 211-232) in the reference's own order with every position sum an element-wise
+    launch autograd differentiates -- the schedule for a position term that is LEARNED (`position_embedding: learned`): forward()
+    treats pos as a constant (second output of the LayerNorm kernels), which would drop its gradient.  No gradient chains, no
+    hoisted keys / values: a correctness branch, not a tuned one."""
+    pe = ops._as_compute(pe)
+    for layer in self.encoder.layers:
+        p = layer.p if layer.training else 0.0
+        qk = ops.add(x, pe)
+        x = layer.norm1(x, layer.self_attn(qk, qk, x, B, S, S, kpm), p)
+        x = ffn_block(x, layer.linear1, layer.linear2, layer.norm2, p)
+    memory = x
+    mem_pos = ops.add(memory, pe)
+    qe = query_embed.to(ops.RT.dtype)                                  # [Q, C]: ops.add broadcasts it over the batch and sums its gradient
+    tgt = torch.zeros(B * Q, C, device=x.device, dtype=ops.RT.dtype)
+    outs = []
+    n = len(self.decoder.layers)
+    for i, layer in enumerate(self.decoder.layers):
+        p = layer.p if layer.training else 0.0
+        tq = ops.add(tgt, qe)
+        tgt = layer.norm1(tgt, layer.self_attn(tq, tq, tgt, B, Q, Q), p)
+        tgt = layer.norm2(tgt, layer.multihead_attn(ops.add(tgt, qe), mem_pos, memory, B, Q, S, kpm), p)
+        tgt = ffn_block(tgt, layer.linear1, layer.linear2, layer.norm3, p)
+        if need_all_layers or i == n - 1:
+            outs.append(self.decoder.norm(tgt).reshape(B, Q, C))
+    return outs, memory.reshape(B, S, C)
+
+
+Transformer._forward_plain = _transformer_forward_plain
 
 
 def build_transformer(args):

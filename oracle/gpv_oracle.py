@@ -222,6 +222,14 @@ def sine_position(mask: Tensor, num_pos_feats: int = 128, temperature: float = 1
     return torch.cat((py, px), dim=3).permute(0, 3, 1, 2)
 
 
+def learned_position(Pm: P, B: int, h: int, w: int, pre: str = 'detr.backbone.1.') -> Tensor:
+    """position_encoding.py:50-75 (`position_embedding: learned`): (column | row) table halves, the same grid for every image.
+    -> (B, 2*npf, h, w)"""
+    x_emb, y_emb = Pm[pre + 'col_embed.weight'][:w], Pm[pre + 'row_embed.weight'][:h]
+    pos = torch.cat((x_emb[None].expand(h, w, -1), y_emb[:, None].expand(h, w, -1)), -1)
+    return pos.permute(2, 0, 1)[None].expand(B, -1, -1, -1)
+
+
 # --------------------------------------------------------------------------
 # DETR transformer (transformer.py:46-58,148-161,211-232,94-123), batch-first internally
 # --------------------------------------------------------------------------
@@ -398,7 +406,10 @@ def detr_forward(Pm: P, cfg: dict, images: Tensor, mask: Tensor, training: bool 
     dc = cfg['detr']
     c5 = resnet50_c5(images, Pm)
     m = downsample_mask(mask, c5.shape[-2], c5.shape[-1])
-    pos = sine_position(m, dc['hidden_dim'] // 2)
+    if dc.get('position_embedding', 'sine') in ('v3', 'learned'):
+        pos = learned_position(Pm, c5.shape[0], c5.shape[-2], c5.shape[-1])
+    else:
+        pos = sine_position(m, dc['hidden_dim'] // 2)
     if _BF16[0]:
         src = _r(F.conv2d(_r(c5), _r(Pm['detr.input_proj.weight'])) + Pm['detr.input_proj.bias'].view(1, -1, 1, 1))
     else:
@@ -749,8 +760,11 @@ def simple_word_tokenize(s: str) -> List[str]:
 
 
 def encode_answers(targets: List[dict], word_to_idx: Dict[str, int], max_text_len: int,
-                   tokenize=simple_word_tokenize):
+                   tokenize=simple_word_tokenize, answering_type: str = 'generation'):
     answers = [t.get('answer', '') for t in targets]
+    if answering_type == 'classification':          # gpv.py:384-399: [__cls__, the answer as one vocabulary entry]
+        toks = [['__cls__', a] for a in answers]
+        return toks, torch.tensor([[word_to_idx.get(w, word_to_idx['__unk__']) for w in t] for t in toks], dtype=torch.long)
     toks = []
     for a in answers:
         sent = '__cls__ __stop__' if a == '' else f'__cls__ {a} __stop__'
