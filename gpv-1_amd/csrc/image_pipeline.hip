@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void resize_kernel(const gpv_image_desc* __res
     for (int k = -rx; k <= rx; ++k) { wx[k + rx] = sgx > 0.f ? __expf(-0.5f * k * k / (sgx * sgx)) : 1.f; s += wx[k + rx]; }
     for (int k = 0; k <= 2 * rx; ++k) wx[k] /= s;
   }
-  float lsum = 0.f;
+  unsigned lsum = 0u;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const int oy = i / OW, ox = i - oy * OW;
     // pixel-centre grid: input coordinate of output pixel centre, clamped like an order-1 warp with mirrored borders
@@ -131,12 +131,15 @@ __global__ __launch_bounds__(256) void resize_kernel(const gpv_image_desc* __res
     o[0] = (uint8_t)r; o[1] = (uint8_t)g; o[2] = (uint8_t)bl;
     if (d.jitter) {                                // grey of the image as it enters the contrast step
       for (int k = 0; k < 4 && d.order[k] != 1; ++k) color_step(d.order[k], d, 0.f, r, g, bl);
-      lsum += grey(r, g, bl);
+      lsum += (unsigned)grey(r, g, bl);
     }
   }
   if (d.jitter) {
-    lsum = wave_sum(lsum);
-    if ((threadIdx.x & 63) == 0) atomicAdd(grey_sum + b, lsum);
+    // integer sum (grey levels are integers, 255 x 480 x 640 < 2^27): exact and independent of the order of the atomics -- a float
+    // sum passes 2^24 at this size and made floor(mean + 0.5) depend on the run
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) lsum += __shfl_xor(lsum, o);
+    if ((threadIdx.x & 63) == 0) atomicAdd(reinterpret_cast<unsigned*>(grey_sum) + b, lsum);
   }
 }
 
@@ -147,7 +150,7 @@ __global__ __launch_bounds__(256) void color_kernel(const gpv_image_desc* __rest
   const int b = blockIdx.y;
   const gpv_image_desc d = descs[b];
   const int n = Hp * Wp;
-  const float mgrey = d.jitter ? floorf(grey_sum[b] / (float)(OH * OW) + 0.5f) : 0.f;
+  const float mgrey = d.jitter ? (float)floor((double)reinterpret_cast<const unsigned*>(grey_sum)[b] / (double)(OH * OW) + 0.5) : 0.f;
   const float mean[3] = {0.485f, 0.456f, 0.406f}, istd[3] = {1.f / 0.229f, 1.f / 0.224f, 1.f / 0.225f};
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const int yp = i / Wp, xp = i - yp * Wp;

@@ -174,6 +174,7 @@ def _f32(t):
 
 _WS = {}
 WS_MAX = 256 << 20
+_WS_RETIRED = []          # outgrown workspaces, kept alive for the graphs that captured them
 
 
 def _workspace(device, nbytes):
@@ -184,6 +185,12 @@ def _workspace(device, nbytes):
     key = (device, _raw_stream(torch.cuda.current_device()) if _raw_stream is not None else 0)
     ws = _WS.get(key)
     if ws is None or ws.numel() < need:
+        if ws is not None:
+            # captured graphs (training bodies, inference, decode) have the old buffer's address baked in and keep replaying into
+            # it: it must stay allocated for as long as they may run.  At most 64 + 128 MB are parked this way (the buffer doubles
+            # up to WS_MAX).
+            _WS_RETIRED.append(ws)
+            need = max(need, min(2 * ws.numel(), WS_MAX))
         ws = _WS[key] = torch.empty(max(need, 64 << 20), device=device, dtype=torch.uint8)
     return ws
 

@@ -535,6 +535,7 @@ class FlatTrainer:
         self.wd, self.clip, self.betas, self.eps = weight_decay, clip_max_norm, betas, eps
         self.warmup_steps, self.t_total = warmup_steps, t_total
         self.step_count = 0
+        self.evict_interval = int(os.environ.get('GPV_GRAPH_EVICT_INTERVAL', '50'))       # steps between two evictions of a captured body
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
         self.rank = dist.get_rank(process_group) if self.world > 1 else 0
@@ -1063,8 +1064,18 @@ class FlatTrainer:
             if n < 1:
                 return None
             if len(self._bodies) >= self.graph_slots:
+                # More live signatures than slots: an eviction costs a four-graph capture (+ a cache flush, + 0.7 s of collective
+                # quiescing with several ranks).  At most one per `evict_interval` steps -- a stream that cycles through more
+                # signatures than there are slots runs its misses eagerly instead of recapturing on every step.
+                last = getattr(self, '_last_evict', None)
+                if last is not None and self.step_count - last < self.evict_interval:
+                    return None
+                self._last_evict = self.step_count
                 self._bodies.popitem(last=False)                                   # least recently used
                 gc.collect()
+                if self.comm:
+                    from .misc import quiesce_collectives
+                    quiesce_collectives()                                          # (no cache flush under collectives in flight)
                 torch.cuda.empty_cache()
             try:
                 body = self._bodies[key] = GraphedBody(self, images, queries, tok, lang_extra)

@@ -168,7 +168,7 @@ int gpv_maxpool3x3s2(const void* x, void* y, int B, int H, int W, int C, int OH,
  * datasets/coco_datasets.py:26-38,137-150 (255 img).astype(uint8) -> ColorJitter / RandomHorizontalFlip / RandomGrayscale -> ToTensor
  * -> Normalize): B decoded uint8 HWC images of any size -> the stem's zero-padded NHWC4 batch out[B,Hp,Wp,4] (what
  * gpv_image_to_nhwc4 produces from a normalised fp32 batch).  descs: DEVICE array of B descriptors (the host draws the random
- * parameters); scratch_u8: B*OH*OW*3 bytes; grey_sum: B floats.  order[] = the four jitter steps in the sample's drawn order
+ * parameters); scratch_u8: B*OH*OW*3 bytes; grey_sum: B 32-bit words of scratch (an exact integer sum lives there).  order[] = the four jitter steps in the sample's drawn order
  * (0 brightness, 1 contrast, 2 saturation, 3 hue); jitter = 0 skips them.  Source side length / output side length <= 9. */
 typedef struct gpv_image_desc {
   const unsigned char* src;   /* [H][W][3] uint8, device */

@@ -1061,3 +1061,34 @@ def test_graphed_training_from_jpeg_files_through_the_device_input_pipeline(rt):
     a, b_ = losses['files'], losses['arrays']
     assert all(np.isfinite(a)) and a[-1] < a[0]
     assert max(abs(x - y) / abs(y) for x, y in zip(a, b_)) < 3e-2, (a, b_)
+
+
+def test_more_signatures_than_graph_slots_run_the_misses_eagerly(rt):
+    """FlatTrainer keeps `graph_slots` captured bodies; a stream cycling through MORE signatures must not recapture on every miss
+    (four-graph capture + cache flush per step): one eviction per `evict_interval` steps, the other misses are eager steps."""
+    from gpv1_amd.train import FlatTrainer
+    rt.set_precise(False)
+    model, _ = build_small()
+    model.to(DEV).train()
+    model.bert.model.p = 0.0
+    tr = FlatTrainer(model, lr=1e-4, lr_backbone=1e-5)
+    tr.graph_slots, tr.evict_interval = 2, 1000
+    cap = [{'task': 'CocoCaptioning', 'answer': ' '.join(f'w{(3 * i + j) % (V - 4)}' for j in range(3))} for i in range(B)]
+    sigs = []
+    for tl in (5, 7, 9):                                      # three query lengths = three signatures
+        images, mask, ids, attn = synth.synth_batch(B, H, W, tl, V, pad_to=PAD)
+        sigs.append((images.to(DEV), mask.to(DEV), ids.to(DEV), attn.to(DEV)))
+    losses, captured = [], []
+    for step in range(15):
+        images, mask, ids, attn = sigs[step % 3]
+        losses.append(float(tr.train_step(nested(images, mask), (ids, attn), [dict(t) for t in cap])))
+        captured.append(len(tr._bodies))
+    torch.cuda.synchronize()
+    assert all(l == l for l in losses)
+    assert max(captured) == 2                                  # never more bodies than slots
+    # signature 3 found the slots full: ONE eviction (its body replaced the least recently used one), after that the evicted
+    # signature's steps run eagerly instead of evicting again
+    assert tr._last_evict is not None
+    assert tr.graph_steps >= 6 and tr.eager_steps >= 5, (tr.graph_steps, tr.eager_steps)
+    n_evictions = sum(1 for a, b in zip(captured, captured[1:]) if b < a)
+    assert n_evictions == 0                                    # (an eviction and its recapture happen inside one step: the count never drops)
