@@ -16,6 +16,9 @@
 
 namespace {
 
+int g_bwd1_mode = [] { const char* e = getenv("GPV_ATTN_BWD1"); return e ? atoi(e) : 1; }();   // gpv_set_option(GPV_OPT_ATTN_BWD1, .)
+long g_bwd1_launches = 0;      // gpv_set_option(GPV_OPT_ATTN_BWD1_LAUNCHES, .)
+
 struct AttnK {
   const void* q; const void* k; const void* v; void* o;
   int64_t q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs;
@@ -887,6 +890,229 @@ __global__ __launch_bounds__(QTHR) void attn_kv2_kernel(AttnK p) {
   }
 }
 
+// The whole backward (dQ, dK, dV) in ONE launch, bf16: attn_kv2_kernel's structure -- one workgroup of 8 waves per (batch, head),
+// Q / dO resident in both orientations -- with two changes.  (1) A wave keeps ALL its key tiles (kt = wave, wave + 8, ...: K / V
+// fragments and the dK / dV accumulators, KTW of them) in registers and walks the queries in pairs of tiles ONCE: the Q / dO
+// fragments of a pair are read from LDS once for all of the wave's key tiles.  (2) The dS tile a wave has just formed (lane = key,
+// registers = queries: the B operand of dK += Q^T dS) is ALSO written transposed into a [32 queries][keys] strip in LDS; after
+// the pair's barrier the strip is complete over all keys and dQ^T[d][q] = K^T[d][:] dS^T[:][q] of those 32 queries is a K = skp
+// product per 16 x 16 output tile, owned by ONE wave (the waves with the fewest key tiles) and stored straight from the
+// accumulator: S is formed once (5 products instead of the 7 of the dQ + dK/dV pair of launches), no second exponentiation /
+// dropout pass, and no cross-wave sum at all -- the summation order is fixed, the result reproducible.  The strip is double
+// buffered: one barrier per pair of query tiles.
+// NQT / NKT = query / key tiles the loops are unrolled for (8 or 20); needs nkt <= 8 KTW.
+template <int DHK, int DHV, int NQT, int NKT, bool CAUSAL>
+__global__ __launch_bounds__(QTHR) void attn_bwd1_kernel(AttnK p) {
+  using T = bf16;
+  if (p.dthresh) p.seed = eff_seed(p.seed, p.seed_dev);
+  constexpr int KP = DHK + 8, KC = DHK / 32, DT = DHV / 16, KTW = (NKT + QW - 1) / QW;
+  const int sqp = p.sqp, QTP = sqp + 8, skp = p.skp, vtp = skp + 8;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  bf16* Qh = reinterpret_cast<bf16*>(smem_raw);
+  bf16* Dh = Qh + sqp * KP;
+  bf16* QTh = Dh + sqp * KP;
+  bf16* DTh = QTh + DHV * QTP;
+  bf16* KTh = DTh + DHV * QTP;                       // K^T [DHV][vtp]
+  bf16* dSb = KTh + DHV * vtp;                       // two strips dS [32 queries][vtp]
+  float* lse_s = reinterpret_cast<float*>(dSb + 64 * vtp);
+  float* del_s = lse_s + sqp;
+  uint32_t* rs_s = reinterpret_cast<uint32_t*>(del_s + sqp);
+
+  int b, h;
+  {
+    const int total = (int)gridDim.x;
+    const int qd = total >> 3, r = total & 7, xcd = (int)blockIdx.x & 7, loc = (int)blockIdx.x >> 3;
+    const int bh = (xcd < r ? xcd * (qd + 1) : r * (qd + 1) + (xcd - r) * qd) + loc;
+    h = bh % p.H; b = bh / p.H;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
+  const int nkt = (p.Sk + 15) >> 4;
+  const T* kg = reinterpret_cast<const T*>(p.k) + b * p.k_bs + h * p.dh;
+  const T* vg = reinterpret_cast<const T*>(p.v) + b * p.v_bs + h * p.dh;
+  // this wave's K / V rows (MFMA B operands of the score products)
+  bf16x8 kh[KTW][KC], vh[KTW][KC];
+  bool kdead[KTW];
+#pragma unroll
+  for (int j = 0; j < KTW; ++j) {
+    const int kt_ = wave + j * QW, key_ = kt_ * 16 + (lane & 15);
+    const bool ok = kt_ < nkt && key_ < p.Sk;
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) {
+      const int d0 = kc * 32 + g * 8;
+      Raw8<T> a, c;
+      if (ok && d0 < p.dh) { a.load(kg + (int64_t)key_ * p.k_rs + d0); c.load(vg + (int64_t)key_ * p.v_rs + d0); } else { a.zero(); c.zero(); }
+      kh[j][kc] = a.r; vh[j][kc] = c.r;
+    }
+    kdead[j] = !ok || (p.kpm && p.kpm[(int64_t)b * p.Sk + key_] != 0);
+  }
+
+  const T* qg = reinterpret_cast<const T*>(p.q) + b * p.q_bs + h * p.dh;
+  const T* dog = reinterpret_cast<const T*>(p.dout) + b * p.do_bs + h * p.dh;
+  const T* og = reinterpret_cast<const T*>(p.o) + b * p.o_bs + h * p.dh;
+  {
+    RowBatch<T, DHK, NQT * 16, QTHR> qr, dr;
+    ColBatch<T, DHV, NQT * 16, QTHR> qc, dc;
+    qr.load(qg, p.q_rs, p.Sq, sqp, p.dh);
+    dr.load(dog, p.do_rs, p.Sq, sqp, p.dh);
+    qc.load(qg, p.q_rs, p.Sq, sqp);
+    dc.load(dog, p.do_rs, p.Sq, sqp);
+    qr.template store<false>(sqp, Qh, nullptr);
+    dr.template store<false>(sqp, Dh, nullptr);
+    qc.template store<false>(sqp, QTP, QTh, nullptr);
+    dc.template store<false>(sqp, QTP, DTh, nullptr);
+  }
+  {
+    ColBatch<T, DHV, NKT * 16, QTHR> kc_;
+    kc_.load(kg, p.k_rs, p.Sk, skp);
+    kc_.template store<false>(skp, vtp, KTh, nullptr);
+  }
+  for (int idx = threadIdx.x; idx < 8 * vtp; idx += QTHR)       // key tiles nobody owns (>= nkt) stay zero in both strips
+    reinterpret_cast<bf16x8*>(dSb)[idx] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+  for (int r = threadIdx.x; r < sqp; r += QTHR) {
+    float dl = 0.f, ls = INFINITY;                   // padded queries: -lse = -inf -> P = 0
+    if (r < p.Sq) {
+      const T* a = dog + (int64_t)r * p.do_rs;
+      const T* c = og + (int64_t)r * p.o_rs;
+      for (int d = 0; d < p.dh; d += 8) {
+        float u[8], w[8];
+        Ld8<T>::ld(a + d, u); Ld8<T>::ld(c + d, w);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dl += u[e] * w[e];
+      }
+      ls = p.lse[((int64_t)b * p.H + h) * p.Sq + r];
+    }
+    lse_s[r] = -ls * 1.4426950408889634f; del_s[r] = dl;
+    rs_s[r] = p.dthresh ? attn_row_seed(p.seed, ((uint64_t)b * p.H + h) * p.Sq + r) : 0u;
+  }
+  __syncthreads();
+
+  const float c2k = p.scale * 1.4426950408889634f;
+  const int ts = attn_ts(p.dthresh);
+  const int nqb = sqp >> 5;                          // pairs of query tiles
+  f32x4 dkacc[KTW][DT], dvacc[KTW][DT];
+#pragma unroll
+  for (int j = 0; j < KTW; ++j)
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) { dkacc[j][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dvacc[j][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  T* dqg = reinterpret_cast<T*>(p.dq) + b * p.q_bs + h * p.dh;
+
+#pragma unroll 1
+  for (int qb = 0; qb < nqb; ++qb) {
+    bf16* dsw = dSb + (qb & 1) * 32 * vtp;
+    // operands of this pair of query tiles, shared by all of the wave's key tiles
+    bf16x8 qf[2][KC], df[2][KC], tq[DT], td[DT];
+    float ls[2][4], dl[2][4];
+    uint32_t rsd[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+      for (int kc = 0; kc < KC; ++kc) {
+        const int off = (qb * 32 + t * 16 + (lane & 15)) * KP + kc * 32 + g * 8;
+        qf[t][kc] = *reinterpret_cast<const bf16x8*>(Qh + off);
+        df[t][kc] = *reinterpret_cast<const bf16x8*>(Dh + off);
+      }
+      const int qr = qb * 32 + t * 16 + g * 4;       // query row of element i = qr + i
+      const float4 l4 = *reinterpret_cast<const float4*>(lse_s + qr);
+      const float4 d4 = *reinterpret_cast<const float4*>(del_s + qr);
+      ls[t][0] = l4.x; ls[t][1] = l4.y; ls[t][2] = l4.z; ls[t][3] = l4.w;
+      dl[t][0] = d4.x; dl[t][1] = d4.y; dl[t][2] = d4.z; dl[t][3] = d4.w;
+      rsd[t][0] = rsd[t][1] = rsd[t][2] = rsd[t][3] = 0u;
+      if (p.dthresh) {
+        const uint4 r4 = *reinterpret_cast<const uint4*>(rs_s + qr);
+        rsd[t][0] = r4.x; rsd[t][1] = r4.y; rsd[t][2] = r4.z; rsd[t][3] = r4.w;
+      }
+    }
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      const int off = (dt * 16 + (lane & 15)) * QTP + qb * 32 + g * 4;
+      tq[dt] = ld_pair64(QTh + off, QTh + off + 16);
+      td[dt] = ld_pair64(DTh + off, DTh + off + 16);
+    }
+#pragma unroll
+    for (int j = 0; j < KTW; ++j) {
+      const int kt = wave + j * QW;
+      if (kt < nkt) {                                // (wave-uniform)
+        const int key = kt * 16 + (lane & 15);
+        const uint32_t kpair = (uint32_t)(key >> 1) * ATTN_PAIR_STEP, kshift = (key & 1) * 16;
+        bf16x8 ph, sh;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          f32x4 sa = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int kc = 0; kc < KC; ++kc) {
+            sa = mfma16(qf[t][kc], kh[j][kc], sa);
+            dp = mfma16(df[t][kc], vh[j][kc], dp);
+          }
+          const int qr = qb * 32 + t * 16 + g * 4;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            float pv = __builtin_amdgcn_exp2f(fmaf(sa[i], c2k, ls[t][i]));
+            bool dead = kdead[j];
+            if (CAUSAL) dead = dead || (p.causal && key > qr + i);
+            pv = dead ? 0.f : pv;
+            float d = dp[i], pd = pv;
+            if (p.dthresh) {
+              const uint32_t w = attn_pair_bits(rsd[t][i] + kpair);
+              const bool keep = (int)(short)((w >> kshift) & 0xffffu) >= ts;
+              d = keep ? d * p.dscale : 0.f;
+              pd = keep ? pv * p.dscale : 0.f;
+            }
+            ph[t * 4 + i] = (bf16)pd;
+            sh[t * 4 + i] = (bf16)(pv * (d - dl[t][i]) * p.scale);
+          }
+        }
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          dvacc[j][dt] = mfma16(td[dt], ph, dvacc[j][dt]);
+          dkacc[j][dt] = mfma16(tq[dt], sh, dkacc[j][dt]);
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) dsw[(t * 16 + g * 4 + i) * vtp + key] = sh[t * 4 + i];
+      }
+    }
+    __syncthreads();
+    // dQ^T of these 32 queries: output tile o = (query tile t, d tile dt), all keys, one wave each
+    for (int o = QW - 1 - wave; o < 2 * DT; o += QW) {
+      const int t = o / DT, dt = o - t * DT;
+      const bf16* ap = KTh + (dt * 16 + (lane & 15)) * vtp + g * 8;
+      const bf16* bp = dsw + (t * 16 + (lane & 15)) * vtp + g * 8;
+      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kb = 0; kb < NKT / 2; ++kb) {
+        if (kb * 32 >= skp) break;
+        acc = mfma16(*reinterpret_cast<const bf16x8*>(ap + kb * 32), *reinterpret_cast<const bf16x8*>(bp + kb * 32), acc);
+      }
+      const int q = qb * 32 + t * 16 + (lane & 15), d = dt * 16 + g * 4;
+      if (q < p.Sq && d < p.dh) {
+        bf16x4 o4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o4[i] = (bf16)acc[i];
+        *reinterpret_cast<bf16x4*>(dqg + (int64_t)q * p.q_rs + d) = o4;
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < KTW; ++j) {
+    const int key = (wave + j * QW) * 16 + (lane & 15);
+    if (key >= p.Sk) continue;
+    T* dkp = reinterpret_cast<T*>(p.dk) + b * p.k_bs + (int64_t)key * p.k_rs + h * p.dh;
+    T* dvp = reinterpret_cast<T*>(p.dv) + b * p.v_bs + (int64_t)key * p.v_rs + h * p.dh;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      const int d = dt * 16 + g * 4;
+      if (d < p.dh) {
+        bf16x4 k4, v4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { k4[i] = (bf16)dkacc[j][dt][i]; v4[i] = (bf16)dvacc[j][dt][i]; }
+        *reinterpret_cast<bf16x4*>(dkp + d) = k4;
+        *reinterpret_cast<bf16x4*>(dvp + d) = v4;
+      }
+    }
+  }
+}
+
 template <typename T, int DHK, int DHV, int NT, int MODE, bool MASKED, bool FULL>
 int launch_q_f(AttnK p, hipStream_t st) {
   constexpr bool PRECISE = sizeof(T) == 4;
@@ -977,6 +1203,50 @@ int launch_kv2(AttnK p, hipStream_t st) {
   return p.causal ? launch_kv2_c<DHK, DHV, 20, true>(p, st) : launch_kv2_c<DHK, DHV, 20, false>(p, st);
 }
 
+// single-launch backward (bf16): returns -1 when the shape is outside the instantiated range or the LDS
+template <int DHK, int DHV, int NQT, int NKT, bool CAUSAL>
+int launch_bwd1_c(AttnK p, hipStream_t st) {
+  constexpr int KP = DHK + 8;
+  const int QTP = p.sqp + 8, vtp = p.skp + 8;
+  const size_t lds = ((size_t)2 * p.sqp * KP + (size_t)2 * DHV * QTP + (size_t)DHV * vtp + (size_t)64 * vtp) * 2 + (size_t)3 * p.sqp * sizeof(float);
+  if (lds > 160 * 1024) return -1;
+  auto fn = attn_bwd1_kernel<DHK, DHV, NQT, NKT, CAUSAL>;
+  static size_t attr = 0;
+  if (lds > 64 * 1024 && lds > attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { (void)hipGetLastError(); return (int)e; }
+    attr = lds;
+  }
+  p.nsplit = 1;
+  hipLaunchKernelGGL(fn, dim3(p.B * p.H), dim3(QTHR), lds, st, p);
+  GPV_CHECK_LAUNCH();
+  ++g_bwd1_launches;
+  return 0;
+}
+template <int DHK, int DHV>
+int launch_bwd1(AttnK p, hipStream_t st) {
+  if (p.Sq > 320) return -1;
+  p.sqp = ((p.Sq + 31) / 32) * 32;
+  const bool q8 = p.sqp <= 128, k8 = p.skp <= 128;
+  if (p.causal) return (q8 && k8) ? launch_bwd1_c<DHK, DHV, 8, 8, true>(p, st) : -1;
+  if (q8 && k8) return launch_bwd1_c<DHK, DHV, 8, 8, false>(p, st);
+  if constexpr (DHK == 32) {       // the DETR encoder / decoder shapes (300 keys): three key tiles per wave in registers
+    if (q8) return launch_bwd1_c<DHK, DHV, 8, 20, false>(p, st);
+    if (!k8) return launch_bwd1_c<DHK, DHV, 20, 20, false>(p, st);
+  }
+  return -1;
+}
+int dispatch_bwd1(const AttnK& p, hipStream_t st) {
+  if (g_bwd1_mode == 0 || (g_bwd1_mode == 1 && p.B * p.H < 128)) return -1;   // few (batch, head) pairs: the split launches fill the chip better
+  switch (p.dh) {
+    case 32: return launch_bwd1<32, 32>(p, st);
+    case 48: return launch_bwd1<64, 48>(p, st);
+    case 64: return launch_bwd1<64, 64>(p, st);
+    case 96: return launch_bwd1<96, 96>(p, st);
+  }
+  return -1;
+}
+
 template <typename T, int MODE>
 int dispatch_q(const AttnK& p, hipStream_t st) {
   const bool small = p.skp <= 128;
@@ -1030,6 +1300,11 @@ int fill(const gpv_attn_args* a, AttnK& p) {
 }
 }  // namespace
 
+namespace gpvk {
+int attn_bwd1_mode(int set) { const int prev = g_bwd1_mode; g_bwd1_mode = set; return prev; }
+long attn_bwd1_launches(long set) { const long prev = g_bwd1_launches; if (set >= 0) g_bwd1_launches = set; return prev; }
+}  // namespace gpvk
+
 extern "C" int gpv_attention_fwd(const gpv_attn_args* a, void* stream) {
   AttnK p{};
   int e = fill(a, p);
@@ -1045,6 +1320,10 @@ extern "C" int gpv_attention_bwd(const gpv_attn_args* a, void* stream) {
   if (e) return e;
   if (!a->o || !a->dout || !a->dq || !a->dk || !a->dv || !a->lse) return (int)hipErrorInvalidValue;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (a->dtype != GPV_F32) {
+    e = dispatch_bwd1(p, st);
+    if (e >= 0) return e;
+  }
   e = a->dtype == GPV_F32 ? dispatch_q<float, 1>(p, st) : dispatch_q<bf16, 1>(p, st);
   if (e) return e;
   return a->dtype == GPV_F32 ? dispatch_kv<float>(p, st) : dispatch_kv<bf16>(p, st);

@@ -792,6 +792,70 @@ def test_attention_dropout_consistency():
     assert rel(lhs, rhs) < 1e-4
 
 
+ATT1 = [  # H, dh, Sq, Sk, causal, kpm, drop: the model's shapes at B = 32 + ragged ones around the tile / strip boundaries
+    (8, 32, 300, 300, False, True, 0.1), (8, 32, 300, 300, False, False, 0.0), (8, 32, 100, 300, False, True, 0.1),
+    (8, 32, 100, 100, False, False, 0.1), (16, 48, 100, 6, False, False, 0.1), (16, 48, 6, 100, False, False, 0.1),
+    (16, 48, 100, 16, False, True, 0.1), (8, 96, 20, 20, True, False, 0.1), (8, 96, 20, 106, False, False, 0.1),
+    (12, 64, 6, 6, False, True, 0.1), (8, 32, 70, 130, False, True, 0.25), (8, 32, 33, 129, False, True, 0.0),
+    (8, 32, 129, 31, False, False, 0.1), (8, 96, 1, 106, False, False, 0.0), (8, 32, 320, 320, False, True, 0.1),
+    (8, 32, 17, 305, False, False, 0.1), (8, 96, 128, 128, True, False, 0.1)]
+
+
+@pytest.mark.parametrize('H,dh,Sq,Sk,causal,use_kpm,drop', ATT1)
+def test_attention_bwd_single_launch_equals_the_two_launches(H, dh, Sq, Sk, causal, use_kpm, drop):
+    """attn_bwd1_kernel (dQ, dK, dV in one launch: S formed once, dS transposed through LDS for the dQ product; reference
+    transformer.py:148-155 through nn.MultiheadAttention's backward) against the dQ + dK/dV pair of launches on the same inputs,
+    same dropout seed: dK / dV are the same products in the same order (bit-identical), dQ the same bf16 dS in another summation
+    order (fp32 accumulation: last-ulp differences of the bf16 result at most).  And against fp32 autograd when there is no dropout."""
+    h = hip()
+    Bn, D = 5, H * dh
+    qkv = rnd(Bn, max(Sq, Sk), 3 * D, dtype=torch.bfloat16, seed=140, scale=1.0)
+    q, k, v = qkv[:, :Sq, :D], qkv[:, :Sk, D:2 * D], qkv[:, :Sk, 2 * D:]
+    kpm = None
+    if use_kpm:
+        kpm = torch.zeros(Bn, Sk, dtype=torch.uint8, device=DEV)
+        kpm[1, Sk - Sk // 3:] = 1
+        kpm[2, ::5] = 1
+        if Sk > 2:
+            kpm[3, 1:] = 1
+    scale = 1.0 / math.sqrt(dh)
+    o = torch.empty(Bn, Sq, D, device=DEV, dtype=torch.bfloat16)
+    lse = torch.empty(Bn, H, Sq, device=DEV)
+    rs, bs = qkv.stride(1), qkv.stride(0)
+    strides = ((bs, rs), (bs, rs), (bs, rs), (Sq * D, D))
+    h.attention_fwd(q, k, v, o, strides, Bn, H, Sq, Sk, dh, scale, kpm=kpm, causal=causal, drop_p=drop, seed=91, lse=lse)
+    do = rnd(Bn, Sq, D, dtype=torch.bfloat16, seed=141)
+    # instantiated: at most 128 queries and 128 keys for every head size (causal or not), and the DETR shapes (dh 32, up to 320 keys)
+    q8, k8 = (Sq + 31) // 32 * 32 <= 128, (Sk + 63) // 64 * 64 <= 128
+    taken = (q8 and k8) or (not causal and dh == 32 and (q8 or not k8))
+    outs = []
+    prev = h.set_option(h.OPT_ATTN_BWD1, 0)
+    try:
+        for mode in (0, 2):
+            h.set_option(h.OPT_ATTN_BWD1, mode)
+            h.set_option(h.OPT_ATTN_BWD1_LAUNCHES, 0)
+            dqkv = torch.full_like(qkv, float('nan'))
+            dq, dk, dv = dqkv[:, :Sq, :D], dqkv[:, :Sk, D:2 * D], dqkv[:, :Sk, 2 * D:]
+            h.attention_bwd(q, k, v, o, do, dq, dk, dv, strides, (Sq * D, D), Bn, H, Sq, Sk, dh, scale, kpm=kpm, causal=causal,
+                            drop_p=drop, seed=91, lse=lse)
+            torch.cuda.synchronize()
+            assert h.set_option(h.OPT_ATTN_BWD1_LAUNCHES, 0) == (1 if mode and taken else 0)
+            outs.append((dq.float().clone(), dk.float().clone(), dv.float().clone()))
+    finally:
+        h.set_option(h.OPT_ATTN_BWD1, prev)
+    (dq0, dk0, dv0), (dq1, dk1, dv1) = outs
+    for t in (dq1, dk1, dv1):
+        assert torch.isfinite(t).all()
+    assert torch.equal(dk0, dk1) and torch.equal(dv0, dv1)
+    assert rel(dq1, dq0) < 4e-3, rel(dq1, dq0)
+    assert ((dq1 - dq0).abs() > 2 ** -7 * dq0.abs() + 1e-6 * dq0.abs().max()).float().mean().item() < 2e-3      # beyond one bf16 ulp: a handful of elements
+    if drop == 0:
+        qf, kf, vf = (t.float().contiguous().requires_grad_(True) for t in (q, k, v))
+        oref, _ = attn_ref(qf, kf, vf, H, kpm, causal, scale)
+        gq, gk, gv = torch.autograd.grad(oref, (qf, kf, vf), do.float())
+        assert rel(dq1, gq) < 2.5e-2 and rel(dk1, gk) < 2.5e-2 and rel(dv1, gv) < 2.5e-2
+
+
 # ----------------------------------------------------------------------------------------- layernorm / CE / misc
 @pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('rows,cols', [(1203, 256), (640, 768), (77, 2048), (5, 2304 // 9 * 8)])

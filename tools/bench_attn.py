@@ -31,9 +31,17 @@ def case(name, B, H, Sq, Sk, dh, p, causal=False, kpm=False):
     sc = 1 / math.sqrt(dh)
     f = lambda: hip.attention_fwd(q, k, v, o, st, B, H, Sq, Sk, dh, sc, kpm=m, causal=causal, drop_p=p, seed=11, lse=lse)
     b = lambda: hip.attention_bwd(q, k, v, o, do, dq, dk, dv, st, (Sq * D, D), B, H, Sq, Sk, dh, sc, kpm=m, causal=causal, drop_p=p, seed=11, lse=lse)
-    tf, tb = timeit(f), timeit(b)
+    tf = timeit(f)
+    prev = hip.set_option(hip.OPT_ATTN_BWD1, 0)
+    tb2 = timeit(b)                                   # dQ + dK/dV launches
+    hip.set_option(hip.OPT_ATTN_BWD1, 2)
+    hip.set_option(hip.OPT_ATTN_BWD1_LAUNCHES, 0)
+    tb = timeit(b)                                    # single launch (where the shape is instantiated)
+    n1 = hip.set_option(hip.OPT_ATTN_BWD1_LAUNCHES, 0)
+    hip.set_option(hip.OPT_ATTN_BWD1, prev)
     fl = 4.0 * B * H * Sq * Sk * dh
-    print('%-28s fwd %6.1f us (%5.1f TF)  bwd %6.1f us (%5.1f TF)' % (name, tf, fl / tf / 1e6, tb, 2.5 * fl / tb / 1e6), flush=True)
+    print('%-28s fwd %6.1f us (%5.1f TF)  bwd %6.1f us (%5.1f TF)  [two launches %6.1f us%s]' %
+          (name, tf, fl / tf / 1e6, tb, 2.5 * fl / tb / 1e6, tb2, '' if n1 else '; single launch not taken'), flush=True)
 
 
 def main():
