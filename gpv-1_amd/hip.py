@@ -57,6 +57,10 @@ class TTProblem(C.Structure):
                 ('M', C.c_int), ('N', C.c_int), ('K', C.c_int), ('lda', C.c_int), ('ldb', C.c_int), ('ldc', C.c_int)]
 
 
+class FoldProblem(C.Structure):
+    _fields_ = [('partials', C.c_void_p), ('out0', C.c_void_p), ('out1', C.c_void_p), ('nblk', C.c_int), ('cols', C.c_int)]
+
+
 class ConvWgradProblem(C.Structure):
     _fields_ = [('x', C.c_void_p), ('dy', C.c_void_p), ('dw', C.c_void_p), ('rowscale', C.c_void_p)] + \
                [(k, C.c_int) for k in ('B', 'IH', 'IW', 'Cs', 'Cin', 'OH', 'OW', 'Cout', 'KH', 'KW', 'SH', 'SW', 'PH', 'PW')]
@@ -102,7 +106,8 @@ EXPORTS = ['gpv_abi_version', 'gpv_build_id', 'gpv_set_option', 'gpv_gemm', 'gpv
            'gpv_cast_rowscale_t', 'gpv_prep_conv_weight', 'gpv_embedding', 'gpv_dropout',
            'gpv_relevance_condition', 'gpv_adamw', 'gpv_sumsq', 'gpv_clip_scale', 'gpv_act_fwd', 'gpv_act_bwd', 'gpv_set_seed_device',
            'gpv_gemm_tt_group', 'gpv_cast_transpose_group', 'gpv_stem_pool', 'gpv_image_pipeline', 'gpv_conv1x1_dual', 'gpv_conv1x1_chain', 'gpv_ffn_fused_fwd',
-           'gpv_conv_wgrad_group', 'gpv_jpeg_parse', 'gpv_jpeg_decode', 'gpv_argmax_rows', 'gpv_ln_linear_rows', 'gpv_attention_row_proj']
+           'gpv_conv_wgrad_group', 'gpv_jpeg_parse', 'gpv_jpeg_decode', 'gpv_argmax_rows', 'gpv_ln_linear_rows', 'gpv_attention_row_proj',
+           'gpv_layernorm_bwd_blocks', 'gpv_layernorm_bwd3', 'gpv_colsum_fold_group']
 
 
 def build_id():
@@ -333,14 +338,38 @@ def layernorm_fwd(x, s, gamma, beta, y, mean, rstd, rows, cols, eps, drop_p=0.0,
                                      C.c_int(dcode(x)), _stream()), 'gpv_layernorm_pos_fwd')
 
 
-def layernorm_bwd(dy, x, s, gamma, mean, rstd, dx, ds, dgamma, dbeta, rows, cols, drop_p=0.0, seed=0, dy2=None):
-    """dy2: a second gradient of the same output (came back through the forward's y2), summed on load"""
+def layernorm_bwd(dy, x, s, gamma, mean, rstd, dx, ds, dgamma, dbeta, rows, cols, drop_p=0.0, seed=0, dy2=None, partials=None):
+    """dy2: a second gradient of the same output (came back through the forward's y2), summed on load.
+    partials (instead of dgamma / dbeta): fp32 [layernorm_bwd_blocks(rows, cols), 2 * cols], one row of partial column sums per
+    workgroup, added to dgamma / dbeta later by colsum_fold_group"""
     if dy2 is not None and dy2.dtype != dy.dtype:
         raise TypeError('layernorm_bwd: dy2 dtype')
-    _chk(lib().gpv_layernorm_bwd2(_p(dy), _p(dy2), _p(x), _p(s), _p(_f32(gamma)), _p(mean), _p(rstd), _p(dx), _p(ds),
-                                  _p(_f32(dgamma)), _p(_f32(dbeta)), C.c_int(rows), C.c_int(cols),
+    if partials is not None and (partials.dtype != torch.float32 or partials.numel() < layernorm_bwd_blocks(rows, cols) * 2 * cols):
+        raise ValueError('layernorm_bwd: partials too small')
+    _chk(lib().gpv_layernorm_bwd3(_p(dy), _p(dy2), _p(x), _p(s), _p(_f32(gamma)), _p(mean), _p(rstd), _p(dx), _p(ds),
+                                  _p(_f32(dgamma)), _p(_f32(dbeta)), _p(partials), C.c_int(rows), C.c_int(cols),
                                   C.c_float(drop_p), C.c_uint64(seed), C.c_int(dcode(x)), _stream()),
-         'gpv_layernorm_bwd2')
+         'gpv_layernorm_bwd3')
+
+
+def layernorm_bwd_blocks(rows, cols):
+    """gpv_layernorm_bwd_blocks: rows of the partials buffer layernorm_bwd(..., partials=) fills for this shape"""
+    n = lib().gpv_layernorm_bwd_blocks(C.c_int(rows), C.c_int(cols))
+    if n <= 0:
+        raise ValueError('layernorm_bwd_blocks: shape refused')
+    return n
+
+
+def colsum_fold_group(problems):
+    """gpv_colsum_fold_group: problems = [(partials, out0, out1, nblk, cols), ...]: out0 += column sums of partials[:, :cols],
+    out1 += those of partials[:, cols:], all problems in one launch"""
+    if not problems:
+        return
+    arr = (FoldProblem * len(problems))()
+    for i, (part, o0, o1, nblk, cols) in enumerate(problems):
+        a = arr[i]
+        a.partials, a.out0, a.out1, a.nblk, a.cols = part.data_ptr(), _f32(o0).data_ptr(), _f32(o1).data_ptr(), nblk, cols
+    _chk(lib().gpv_colsum_fold_group(arr, C.c_int(len(problems)), _stream()), 'gpv_colsum_fold_group')
 
 
 def softmax_ce(logits, ld, target, loss, dlogits, gscale, rows, V):

@@ -634,6 +634,28 @@ def _two_grads(dy, dy2, rows, cols):
     return (b, None) if a is None else (a, b)
 
 
+LN_FOLD = os.environ.get('GPV_LN_FOLD', '1') != '0'     # 0: dgamma / dbeta by fp32 atomics inside every LayerNorm backward (A/B)
+
+
+def _ln_backward(d1, d2, x2, s2, gamma, beta, mean, rstd, dx, ds, rows, cols, drop_p, seed):
+    """gpv_layernorm_bwd3.  Nobody needs dgamma / dbeta before the optimizer: while train.GraphedBody captures a backward the
+    launch leaves its per-workgroup partial column sums in a buffer (plain stores) and the sum into the parameters' gradients
+    joins the deferred weight-gradient work (ONE grouped gpv_colsum_fold_group per flush, on the side branch) -- the same-address
+    atomics of 160 workgroups were a third of the launch on the DETR shapes, on the backward's critical chain 52 times a step"""
+    need_g = gamma is not None and gamma.requires_grad
+    gd = None if gamma is None else gamma.detach()
+    if need_g and LN_FOLD and RT.defer_list is not None:
+        nblk = hip.layernorm_bwd_blocks(rows, cols)
+        part = torch.empty(nblk, 2 * cols, device=dx.device, dtype=torch.float32)
+        hip.layernorm_bwd(d1, x2, s2, gd, mean, rstd, dx, ds, None, None, rows, cols, drop_p, seed, dy2=d2, partials=part)
+        dg, db = ensure_grad(gamma), ensure_grad(beta)
+        prob = (part, dg, db, nblk, cols)
+        RT.defer_list.append((lambda: hip.colsum_fold_group([prob]), (part, db, dg), ('fold',) + prob))
+        return
+    hip.layernorm_bwd(d1, x2, s2, gd, mean, rstd, dx, ds, ensure_grad(gamma) if need_g else None, ensure_grad(beta) if need_g else None,
+                      rows, cols, drop_p, seed, dy2=d2)
+
+
 class AddLayerNormFn(Function):
     """y = LayerNorm(x + dropout(s)); with `pos` a second output y2 = y + pos (rows broadcast): gpv_layernorm_pos_fwd"""
 
@@ -674,11 +696,7 @@ class AddLayerNormFn(Function):
         d1, d2 = _two_grads(dy, dy2, rows, cols)
         dx = torch.empty_like(x2)
         ds = torch.empty_like(x2) if (ctx.has_s and ctx.drop_p > 0) else None
-        gamma, beta = ctx.gamma, ctx.beta
-        need_g = gamma is not None and gamma.requires_grad
-        hip.layernorm_bwd(d1, x2, s2, None if gamma is None else gamma.detach(), mean, rstd, dx, ds,
-                          ensure_grad(gamma) if need_g else None, ensure_grad(beta) if need_g else None,
-                          rows, cols, ctx.drop_p, ctx.seed, dy2=d2)
+        _ln_backward(d1, d2, x2, s2, ctx.gamma, ctx.beta, mean, rstd, dx, ds, rows, cols, ctx.drop_p, ctx.seed)
         dxr = dx.reshape(ctx.shape)
         dsr = None
         if ctx.has_s:
@@ -751,9 +769,7 @@ class FFNBlockFn(Function):
         d2, d2b = _two_grads(dout, dout2, M, K)
         dx_res = torch.empty_like(x2)
         ds = torch.empty_like(x2) if ctx.drop_p > 0 else None
-        need_g = gamma.requires_grad
-        hip.layernorm_bwd(d2, x2, y, gamma.detach(), mean, rstd, dx_res, ds, ensure_grad(gamma) if need_g else None,
-                          ensure_grad(beta) if need_g else None, M, K, ctx.drop_p, ctx.seed2, dy2=d2b)
+        _ln_backward(d2, d2b, x2, y, gamma, beta, mean, rstd, dx_res, ds, M, K, ctx.drop_p, ctx.seed2)
         dy2 = ds if ds is not None else dx_res
         nb2 = w2.bias is not None and w2.bias.requires_grad
         if w2.weight.requires_grad:

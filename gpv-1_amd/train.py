@@ -367,13 +367,17 @@ class GraphedBody:
     def _flush(deferred):
         """launch the collected weight gradients: every problem the grouped kernel takes (128-multiples, bf16) in
         gpv_gemm_tt_group launches of up to 48 problems, the rest (2- and 4-wide heads, ragged shapes) one by one"""
-        group = [prob for _, _, prob in deferred if prob is not None]
+        is_fold = lambda prob: prob is not None and isinstance(prob[0], str)      # ('fold', partials, dgamma, dbeta, nblk, cols): ops._ln_backward
+        group = [prob for _, _, prob in deferred if prob is not None and not is_fold(prob)]
+        folds = [prob[1:] for _, _, prob in deferred if is_fold(prob)]
         if os.environ.get('GPV_WGRAD_GROUP', '1') == '0':
-            group = []
+            group, folds = [], []
         if group:
             hip.gemm_tt_group(group)
+        if folds:
+            hip.colsum_fold_group(folds)           # the LayerNorm backwards' partial dgamma | dbeta rows of this flush, one launch
         for fn, _, prob in deferred:
-            if prob is None or not group:
+            if prob is None or not (folds if is_fold(prob) else group):
                 fn()
 
     def _capture_backward(self, pairs, fused=None):

@@ -309,6 +309,24 @@ int gpv_layernorm_bwd2(const void* dy, const void* dy2, const void* x, const voi
                        const float* rstd, void* dx, void* ds, float* dgamma, float* dbeta, int rows, int cols, float drop_p,
                        uint64_t seed, int dtype, void* stream);
 
+/* gpv_layernorm_bwd3: the same backward with the column sums taken OFF the launch.  partials != NULL (then dgamma == dbeta == NULL):
+ * every workgroup stores its partial [dgamma | dbeta] row to partials[block][2 * cols] (fp32; gpv_layernorm_bwd_blocks(rows, cols)
+ * rows -- the grid this library launches for the shape, -1 for a shape it refuses) instead of adding it to dgamma / dbeta with
+ * fp32 atomics; gpv_colsum_fold_group adds the rows of a GROUP of such buffers to their dgamma / dbeta in one launch, in a fixed
+ * order (reproducible), wherever the caller puts it -- the gradient of a LayerNorm's affine parameters is needed by nobody until
+ * the optimizer (reference: torch.nn.LayerNorm's backward inside transformer.py:156-160,227-231, vilbert.py:845-856). */
+typedef struct gpv_fold_problem {
+  const float* partials;          /* [nblk][2 * cols] fp32 */
+  float* out0;                    /* [cols] += column sums of partials[:, :cols]   (dgamma) */
+  float* out1;                    /* [cols] += column sums of partials[:, cols:]   (dbeta) */
+  int nblk, cols;
+} gpv_fold_problem;
+int gpv_layernorm_bwd_blocks(int rows, int cols);
+int gpv_layernorm_bwd3(const void* dy, const void* dy2, const void* x, const void* s, const float* gamma, const float* mean,
+                       const float* rstd, void* dx, void* ds, float* dgamma, float* dbeta, float* partials, int rows, int cols,
+                       float drop_p, uint64_t seed, int dtype, void* stream);
+int gpv_colsum_fold_group(const gpv_fold_problem* problems, int n, void* stream);   /* problems: HOST memory */
+
 /* softmax cross-entropy over the vocabulary (losses.py:20-26, nn.CrossEntropyLoss reduction none).
  * logits [rows, V] (ld), target int64 [rows] (ignore_index < 0 rows give loss 0);
  * loss[rows] fp32; if dlogits != NULL writes dlogits = (softmax - onehot) * gscale[row]. */

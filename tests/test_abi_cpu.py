@@ -28,7 +28,7 @@ def lib_path():
 def test_library_exports_every_declared_entry_point():
     import gpv1_amd.hip as hip
     names = declared()
-    assert len(names) == 43, names
+    assert len(names) == 46, names
     assert sorted(hip.EXPORTS) == names
     lib = ctypes.CDLL(lib_path())
     for n in names:
@@ -43,7 +43,7 @@ def test_library_exports_every_declared_entry_point():
 
 def test_ctypes_structs_match_the_c_layout(tmp_path):
     import gpv1_amd.hip as hip
-    pairs = (('gpv_gemm_args', hip.GemmArgs), ('gpv_conv_args', hip.ConvArgs), ('gpv_attn_args', hip.AttnArgs), ('gpv_tt_problem', hip.TTProblem), ('gpv_tc_problem', hip.TCProblem), ('gpv_image_desc', hip.ImageDesc),
+    pairs = (('gpv_gemm_args', hip.GemmArgs), ('gpv_conv_args', hip.ConvArgs), ('gpv_attn_args', hip.AttnArgs), ('gpv_tt_problem', hip.TTProblem), ('gpv_fold_problem', hip.FoldProblem), ('gpv_tc_problem', hip.TCProblem), ('gpv_image_desc', hip.ImageDesc),
              ('gpv_conv_wgrad_problem', hip.ConvWgradProblem), ('gpv_jpeg_info', hip.JpegInfo), ('gpv_jpeg_desc', hip.JpegDesc))
     prog = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', 'int main(void) {']
     for cname, cls in pairs:

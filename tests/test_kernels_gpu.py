@@ -858,6 +858,41 @@ def test_attention_bwd_single_launch_equals_the_two_launches(H, dh, Sq, Sk, caus
 
 # ----------------------------------------------------------------------------------------- layernorm / CE / misc
 @pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('rows,cols,drop', [(9600, 256, 0.1), (3200, 256, 0.0), (3968, 768, 0.1), (640, 768, 0.1), (77, 2048, 0.1), (5, 2304 // 9 * 8, 0.0)])
+def test_layernorm_bwd_partials_and_fold_group_equal_the_atomic_column_sums(dtype, rows, cols, drop):
+    """gpv_layernorm_bwd3(partials) + gpv_colsum_fold_group against gpv_layernorm_bwd2's in-kernel atomics: dx / ds bit-identical
+    (the same arithmetic; only the launch grid may differ), dgamma / dbeta equal up to the fp32 summation order, added to what the
+    buffers held; the fold of a group (two problems, one shared output pair) is reproducible bit for bit."""
+    h = hip()
+    x, s, dy = rnd(rows, cols, dtype=dtype, seed=150), rnd(rows, cols, dtype=dtype, seed=151), rnd(rows, cols, dtype=dtype, seed=152)
+    g, b = rnd(cols, seed=153) + 1.0, rnd(cols, seed=154)
+    y = torch.empty_like(x)
+    mean, rstd = torch.empty(rows, device=DEV), torch.empty(rows, device=DEV)
+    h.layernorm_fwd(x, s, g, b, y, mean, rstd, rows, cols, 1e-5, drop, 99)
+    dx0, ds0 = torch.empty_like(x), torch.zeros_like(x)
+    dg0, db0 = torch.full((cols,), 0.5, device=DEV), torch.full((cols,), -0.25, device=DEV)
+    h.layernorm_bwd(dy, x, s, g, mean, rstd, dx0, ds0, dg0, db0, rows, cols, drop, 99)
+    nblk = h.layernorm_bwd_blocks(rows, cols)
+    outs = []
+    for _ in range(2):
+        part = torch.full((nblk, 2 * cols), float('nan'), device=DEV)
+        dx1, ds1 = torch.empty_like(x), torch.zeros_like(x)
+        h.layernorm_bwd(dy, x, s, g, mean, rstd, dx1, ds1, None, None, rows, cols, drop, 99, partials=part)
+        dg1, db1 = torch.full((cols,), 0.5, device=DEV), torch.full((cols,), -0.25, device=DEV)
+        dg2, db2 = torch.zeros(cols, device=DEV), torch.zeros(cols, device=DEV)
+        h.colsum_fold_group([(part, dg1, db1, nblk, cols), (part, dg2, db2, nblk, cols)])
+        torch.cuda.synchronize()
+        assert torch.isfinite(part).all()
+        assert torch.equal(dx1, dx0) and torch.equal(ds1, ds0)
+        outs.append((dg1.clone(), db1.clone(), dg2.clone(), db2.clone()))
+    for a, c in zip(outs[0], outs[1]):
+        assert torch.equal(a, c)
+    dg1, db1, dg2, db2 = outs[0]
+    assert rel(dg1, dg0) < 1e-5 and rel(db1, db0) < 1e-5, (rel(dg1, dg0), rel(db1, db0))
+    assert rel(dg2 + 0.5, dg0) < 1e-5 and rel(db2 - 0.25, db0) < 1e-5
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('rows,cols', [(1203, 256), (640, 768), (77, 2048), (5, 2304 // 9 * 8)])
 def test_layernorm_fwd_bwd(dtype, rows, cols):
     h = hip()
