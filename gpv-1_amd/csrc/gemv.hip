@@ -92,7 +92,11 @@ inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) =
 // never win.  16-byte pieces of the row when its base and pitch allow (V = 10000 bf16: 1250 pieces, 1.2 per thread).
 template <typename T>
 __global__ __launch_bounds__(1024) void argmax_rows_kernel(const T* __restrict__ x, int64_t ld, const float* __restrict__ addend, int V, int vec,
-                                                           int64_t* o0, int64_t s0, int64_t* o1, int64_t s1) {
+                                                           int64_t* o0, int64_t s0, int64_t* o1, int64_t s1,
+                                                           const T* __restrict__ table, int64_t ldt, const T* __restrict__ pos_row, T* xnext, int D) {
+  // table (optional): the picked index also selects the NEXT input row, xnext[r, :] = table[index, :] (+ pos_row[:]) -- the
+  // greedy decoder's embedding gather, input transform (precomputed per vocabulary entry) and position add of the next token
+  // ride in the launch that picks the token (decode.py: three graph nodes per token fewer)
   const int r = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const T* row = x + (int64_t)r * ld;
   float best = -INFINITY;
@@ -131,6 +135,21 @@ __global__ __launch_bounds__(1024) void argmax_rows_kernel(const T* __restrict__
     if (bi == 0x7fffffff) bi = 0;                     // a row of NaNs / -inf only
     if (o0) o0[(int64_t)r * s0] = bi;
     if (o1) o1[(int64_t)r * s1] = bi;
+    si[0] = bi;
+  }
+  if (table) {                                        // (uniform)
+    __syncthreads();
+    const int idx = si[0];
+    for (int d = threadIdx.x * 8; d < D; d += 8192) {
+      float f[8], a[8];
+      Ld8<T>::ld(table + (int64_t)idx * ldt + d, f);
+      if (pos_row) {
+        Ld8<T>::ld(pos_row + d, a);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] += a[e];
+      }
+      Ld8<T>::st(xnext + (int64_t)r * D + d, f);
+    }
   }
 }
 
@@ -424,19 +443,32 @@ int gemv_try_launch(const GemmK& k, int dtype_in, int dtype_out, int batch, hipS
 
 }  // namespace gpvk
 
-extern "C" int gpv_argmax_rows(const void* x, int64_t ld, const float* addend, int rows, int V, int dtype,
-                               int64_t* out0, int64_t stride0, int64_t* out1, int64_t stride1, void* stream) {
+extern "C" int gpv_argmax_rows_embed(const void* x, int64_t ld, const float* addend, int rows, int V, int dtype,
+                                     int64_t* out0, int64_t stride0, int64_t* out1, int64_t stride1,
+                                     const void* table, int64_t ldt, const void* pos_row, void* xnext, int D, void* stream) {
   if (!x || rows <= 0 || V <= 0 || (!out0 && !out1)) return (int)hipErrorInvalidValue;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int esz = dtype == GPV_F32 ? 4 : 2;
+  if (table) {
+    if (!xnext || D <= 0 || D % 8 != 0 || (ldt * esz) % 16 != 0) return (int)hipErrorInvalidValue;
+    for (const void* q : {table, pos_row, (const void*)xnext})
+      if (reinterpret_cast<uintptr_t>(q) & 15) return (int)hipErrorInvalidValue;
+  }
   const int vec = (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (ld * esz) % 16 == 0 && (!addend || (reinterpret_cast<uintptr_t>(addend) & 15) == 0);
   if (dtype == GPV_BF16)
-    gpvk::argmax_rows_kernel<bf16><<<dim3(rows), dim3(1024), 0, st>>>(reinterpret_cast<const bf16*>(x), ld, addend, V, vec, out0, stride0, out1, stride1);
+    gpvk::argmax_rows_kernel<bf16><<<dim3(rows), dim3(1024), 0, st>>>(reinterpret_cast<const bf16*>(x), ld, addend, V, vec, out0, stride0, out1, stride1,
+                                                                     reinterpret_cast<const bf16*>(table), ldt, reinterpret_cast<const bf16*>(pos_row), reinterpret_cast<bf16*>(xnext), D);
   else if (dtype == GPV_F32)
-    gpvk::argmax_rows_kernel<float><<<dim3(rows), dim3(1024), 0, st>>>(reinterpret_cast<const float*>(x), ld, addend, V, vec, out0, stride0, out1, stride1);
+    gpvk::argmax_rows_kernel<float><<<dim3(rows), dim3(1024), 0, st>>>(reinterpret_cast<const float*>(x), ld, addend, V, vec, out0, stride0, out1, stride1,
+                                                                      reinterpret_cast<const float*>(table), ldt, reinterpret_cast<const float*>(pos_row), reinterpret_cast<float*>(xnext), D);
   else
     return (int)hipErrorInvalidValue;
   return (int)hipGetLastError();
+}
+
+extern "C" int gpv_argmax_rows(const void* x, int64_t ld, const float* addend, int rows, int V, int dtype,
+                               int64_t* out0, int64_t stride0, int64_t* out1, int64_t stride1, void* stream) {
+  return gpv_argmax_rows_embed(x, ld, addend, rows, V, dtype, out0, stride0, out1, stride1, nullptr, 0, nullptr, nullptr, 0, stream);
 }
 
 extern "C" int gpv_attention_row_proj(const void* q, int64_t q_bs, const void* k, int64_t k_bs, int64_t k_rs, const void* v, int64_t v_bs,

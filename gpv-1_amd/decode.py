@@ -53,6 +53,13 @@ class GreedyKVDecoder:
         self.part = torch.empty(B, self.H, D, device=dev, dtype=torch.float32) if self.fused_rows else None
         # out-projection inside the attention launch: 5.31-5.38 -> 5.24 ms at B = 1, 7.80 -> 8.18 ms at B = 4 (same box) -- B = 1 only
         self.row_proj = os.environ.get('GPV_DECODE_ROW_PROJ', '1' if B == 1 else '0') != '0'
+        # greedy steps: the next token's input row (embedding -> transform -> + position) is written by the launch that picks the
+        # token, from the input transform applied to the WHOLE vocabulary once per weights (gpv_argmax_rows_embed): 3 of a step's
+        # dependent launches fewer.  GPV_DECODE_EMBED=0: the three launches (A/B)
+        self.embed_in_pick = os.environ.get('GPV_DECODE_EMBED', '1') != '0'
+        self.xin = torch.zeros(B, D, device=dev, dtype=dt)
+        self.table = None                      # [V, D] transformed input embeddings, built with the first decode after a weights change
+        self.pos = None                        # [T, D] position rows in the compute dtype
         self.graphs = [None] * T
         self.key = (RT.weights_epoch, RT.static_epoch, dt)
 
@@ -94,13 +101,30 @@ class GreedyKVDecoder:
         hip.attention_fwd(q, k, v, o, ((q_bs, D), (kv_bs, kv_rs), (kv_bs, kv_rs), (D, D)), B, H, 1, Sk, dh, 1.0 / dh ** 0.5)
         return att.out_proj(o)
 
-    def _step_core(self, t):
-        m, B, D, H, T, Tm = self.m, self.B, self.D, self.H, self.T, self.Tm
-        dh = D // H
-        dev = self.tok.device
+    def _input_rows(self, t):
+        """the decoder input of position t for the tokens in self.tok: embedding -> transform (+ position), gpv.py:178-183"""
+        m = self.m
         x = m.answer_input_embedings(self.tok)                                              # [B, D]
         if m.cfg.text_decoder.pos_enc is True:
             x = ops.add(x, m.pos_enc[0, t:t + 1].to(RT.dtype).contiguous())
+        return x
+
+    def _build_table(self):
+        m = self.m
+        ids = torch.arange(self.V, device=self.tok.device)
+        tab = m.answer_input_embedings(ids).to(RT.dtype).contiguous()                       # [V, D]
+        if self.table is None or self.table.dtype != tab.dtype:
+            self.table = tab
+        else:
+            self.table.copy_(tab)                                                           # (captured graphs read this address)
+        self.pos = m.pos_enc[0, :self.T].to(RT.dtype).contiguous() if m.cfg.text_decoder.pos_enc is True else None
+
+    def _step_core(self, t, x=None):
+        m, B, D, H, T, Tm = self.m, self.B, self.D, self.H, self.T, self.Tm
+        dh = D // H
+        dev = self.tok.device
+        if x is None:
+            x = self._input_rows(t)
         s = prev = None
         for l, layer in enumerate(m.text_decoder.layers):
             sa, ca = layer.self_attn, layer.multihead_attn
@@ -127,9 +151,14 @@ class GreedyKVDecoder:
         return lg
 
     def _step(self, t):
-        lg = self._step_core(t)
+        fused = self.embed_in_pick and self.table is not None
+        lg = self._step_core(t, self.xin if fused else None)
         # next input token = arg-max of logit + vocabulary mask (gpv.py:185-188), also stored as ids[:, t+1]
-        hip.argmax_rows(lg, self.vocab_mask, self.tok, self.ids[:, t + 1] if t + 1 < self.T else None)
+        if fused and t + 1 < self.T:
+            hip.argmax_rows(lg, self.vocab_mask, self.tok, self.ids[:, t + 1], table=self.table,
+                            pos_row=None if self.pos is None else self.pos[t + 1], xnext=self.xin)
+        else:
+            hip.argmax_rows(lg, self.vocab_mask, self.tok, self.ids[:, t + 1] if t + 1 < self.T else None)
 
     def reorder(self, perm, upto):
         """beam search: sequence i continues the hypothesis that lived in slot perm[i]; positions < upto are valid"""
@@ -143,6 +172,9 @@ class GreedyKVDecoder:
         if self.key != (RT.weights_epoch, RT.static_epoch, RT.dtype):       # weights changed: graphs hold stale copies
             self.graphs = [None] * self.T
             self.key = (RT.weights_epoch, RT.static_epoch, RT.dtype)
+            self.table = None
+        if self.embed_in_pick and self.table is None and not torch.cuda.is_current_stream_capturing():
+            self._build_table()              # (a decode first met inside a capture runs the three-launch input path)
         self.memory.copy_(memory.reshape(self.B * self.Tm, self.D))
         self.vocab_mask.zero_()
         if vocab_mask is not None:
@@ -152,16 +184,19 @@ class GreedyKVDecoder:
         self.tok.fill_(cls)
         self.ids.zero_()
         self.ids[:, 0] = cls
+        if self.embed_in_pick and self.table is not None:
+            self.xin.copy_(self._input_rows(0))
         for t in range(self.T):
             if not self.use_graphs:
                 self._step(t)
                 continue
             if self.graphs[t] is None:
-                tok_in, ids_in = self.tok.clone(), self.ids.clone()
+                tok_in, ids_in, xin_in = self.tok.clone(), self.ids.clone(), self.xin.clone()
                 self._step(t)                                   # warm-up (kernel attributes, caches) outside capture
                 torch.cuda.synchronize()
                 self.tok.copy_(tok_in)
                 self.ids.copy_(ids_in)
+                self.xin.copy_(xin_in)
                 g = torch.cuda.CUDAGraph()
                 from .misc import capture_guard
                 with capture_guard(), torch.cuda.graph(g, capture_error_mode='thread_local'):
@@ -169,6 +204,7 @@ class GreedyKVDecoder:
                 self.graphs[t] = g
                 self.tok.copy_(tok_in)
                 self.ids.copy_(ids_in)
+                self.xin.copy_(xin_in)
             self.graphs[t].replay()
         if self.use_graphs:
             # Drain the stream after the 20 graph launches.  Without a STREAM synchronisation every few decodes the

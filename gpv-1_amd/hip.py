@@ -107,7 +107,7 @@ EXPORTS = ['gpv_abi_version', 'gpv_build_id', 'gpv_set_option', 'gpv_gemm', 'gpv
            'gpv_relevance_condition', 'gpv_adamw', 'gpv_sumsq', 'gpv_clip_scale', 'gpv_act_fwd', 'gpv_act_bwd', 'gpv_set_seed_device',
            'gpv_gemm_tt_group', 'gpv_cast_transpose_group', 'gpv_stem_pool', 'gpv_image_pipeline', 'gpv_conv1x1_dual', 'gpv_conv1x1_chain', 'gpv_ffn_fused_fwd',
            'gpv_conv_wgrad_group', 'gpv_jpeg_parse', 'gpv_jpeg_decode', 'gpv_argmax_rows', 'gpv_ln_linear_rows', 'gpv_attention_row_proj',
-           'gpv_layernorm_bwd_blocks', 'gpv_layernorm_bwd3', 'gpv_colsum_fold_group']
+           'gpv_layernorm_bwd_blocks', 'gpv_layernorm_bwd3', 'gpv_colsum_fold_group', 'gpv_argmax_rows_embed']
 
 
 def build_id():
@@ -571,16 +571,25 @@ def act_fwd(x, y, n, act):
     _chk(lib().gpv_act_fwd(_p(x), _p(y), C.c_int64(n), act, dcode(x), _stream()), 'gpv_act_fwd')
 
 
-def argmax_rows(x, addend, out0=None, out1=None):
+def argmax_rows(x, addend, out0=None, out1=None, table=None, pos_row=None, xnext=None):
     """x [rows, V] (row pitch x.stride(0), unit column stride), addend fp32 [V] or None; out0 / out1: int64 tensors whose element
-    r * stride(0) receives row r's pick (views such as ids[:, t + 1] work)"""
+    r * stride(0) receives row r's pick (views such as ids[:, t + 1] work).  table [V, D] (+ pos_row [D]) -> xnext [rows, D]:
+    the picked entries' rows (+ the position row), gpv_argmax_rows_embed"""
     rows, V = x.shape
     assert x.stride(1) == 1 and (addend is None or (addend.dtype == torch.float32 and addend.is_contiguous()))
     for o in (out0, out1):
         assert o is None or (o.dtype == torch.int64 and o.dim() == 1 and o.shape[0] == rows)
-    _chk(lib().gpv_argmax_rows(_p(x), C.c_int64(x.stride(0)), _p(addend), rows, V, dcode(x),
-                               _p(out0), C.c_int64(out0.stride(0) if out0 is not None else 0),
-                               _p(out1), C.c_int64(out1.stride(0) if out1 is not None else 0), _stream()), 'gpv_argmax_rows')
+    D, ldt = 0, 0
+    if table is not None:
+        D, ldt = table.shape[1], table.stride(0)
+        assert table.dtype == x.dtype and table.stride(1) == 1 and table.shape[0] >= V
+        assert xnext is not None and xnext.dtype == x.dtype and xnext.is_contiguous() and tuple(xnext.shape) == (rows, D)
+        assert pos_row is None or (pos_row.dtype == x.dtype and pos_row.is_contiguous() and pos_row.numel() == D)
+    _chk(lib().gpv_argmax_rows_embed(_p(x), C.c_int64(x.stride(0)), _p(addend), rows, V, dcode(x),
+                                     _p(out0), C.c_int64(out0.stride(0) if out0 is not None else 0),
+                                     _p(out1), C.c_int64(out1.stride(0) if out1 is not None else 0),
+                                     _p(table), C.c_int64(ldt), _p(pos_row if table is not None else None),
+                                     _p(xnext if table is not None else None), C.c_int(D), _stream()), 'gpv_argmax_rows_embed')
 
 
 LN_LINEAR_MAX_ROWS, LN_LINEAR_MAX_COLS = 4, 1024

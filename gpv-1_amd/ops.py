@@ -623,8 +623,10 @@ def _pos_sink(pos_param, dy2, rows, cols):
     if pos_param is None or not pos_param.requires_grad or dy2 is None:
         return
     n = pos_param.numel()
-    g = ensure_grad(pos_param)
-    hip.colsum(dy2.reshape(-1, n), g.reshape(-1), rows * cols // n, n, n)
+    g = ensure_grad(pos_param).reshape(-1)
+    d = dy2.reshape(-1, n)
+    # (nobody reads this gradient before the optimizer: with the deferred weight gradients, off the backward chain -- 12 launches a step)
+    off_critical_path(lambda: hip.colsum(d, g, rows * cols // n, n, n), d, d, g)
 
 
 def _two_grads(dy, dy2, rows, cols):

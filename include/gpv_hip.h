@@ -366,6 +366,14 @@ int gpv_embedding(const void* table, const int64_t* ids, void* out, int64_t n_id
  * GPV.forward (exp/gpv/models/gpv.py:185-188): the next input token and the id row of the step in one launch. */
 int gpv_argmax_rows(const void* x, int64_t ld, const float* addend, int rows, int V, int dtype,
                     int64_t* out0, int64_t stride0, int64_t* out1, int64_t stride1, void* stream);
+/* The same pick, and the NEXT decoder input row in the same launch: xnext[r, :D] = table[index_r * ldt + :D] (+ pos_row[:D], NULL: no
+ * position term), dtype as x, sums in fp32 rounded once.  table = the transformed input embedding of every vocabulary entry
+ * (AnswerInputEmbedding: gpv.py:46-55 applied to the whole vocabulary once per weights), pos_row = the sinusoidal row of position
+ * t + 1 (gpv.py:178-196 builds both per token): embedding gather + transform + position add of the next token leave the chain of
+ * dependent launches of a decode step.  table == NULL: gpv_argmax_rows.  D % 8 == 0, 16-byte aligned bases and pitches. */
+int gpv_argmax_rows_embed(const void* x, int64_t ld, const float* addend, int rows, int V, int dtype,
+                          int64_t* out0, int64_t stride0, int64_t* out1, int64_t stride1,
+                          const void* table, int64_t ldt, const void* pos_row, void* xnext, int D, void* stream);
 /* LayerNorm -> Linear on at most 4 rows (the decode step at small batch; inference only, no statistics are kept):
  *   xn[r, :] = LayerNorm(x[r, :] + s[r, :]) * gamma + beta      (s, gamma / beta may be NULL; K <= 1024 columns, K % 8 == 0)
  *   y[r*ldy + n] = act(sum_k xn[r, k] W[n*ldw + k] + bias[n])    n < N

@@ -181,6 +181,29 @@ def test_argmax_rows(dtype):
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
+def test_argmax_rows_embed_writes_the_next_input_row(dtype):
+    """gpv_argmax_rows_embed: the pick, and xnext[r] = table[pick_r] (+ pos_row) rounded once -- what embedding gather, input
+    transform (applied to the whole vocabulary beforehand) and position add produce as three launches (gpv.py:178-188)"""
+    h = hip()
+    for rows, V, D in ((1, 10000, 768), (4, 10000, 768), (64, 1000, 256), (3, 37, 8)):
+        x = rnd(rows, V + 8, dtype=dtype, seed=33)[:, :V]
+        add = torch.zeros(V, device=DEV)
+        add[::3] = -10000.0
+        table = rnd(V + 5, D + 8, dtype=dtype, seed=34)[:, :D]          # row pitch D + 8, more rows than V
+        pos = rnd(D, dtype=dtype, seed=35)
+        tok = torch.full((rows,), -1, dtype=torch.long, device=DEV)
+        ids = torch.full((rows, 20), -1, dtype=torch.long, device=DEV)
+        xn = torch.full((rows, D), float('nan'), device=DEV, dtype=dtype)
+        h.argmax_rows(x, add, tok, ids[:, 3], table=table, pos_row=pos, xnext=xn)
+        ref = (x.float() + add).argmax(-1)
+        assert torch.equal(tok, ref) and torch.equal(ids[:, 3], ref)
+        assert torch.equal(xn, (table[ref].float() + pos.float()).to(dtype))
+        h.argmax_rows(x, None, tok, None, table=table, pos_row=None, xnext=xn)
+        ref = x.float().argmax(-1)
+        assert torch.equal(tok, ref) and torch.equal(xn, table[ref])
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
 def test_gemm_epilogue_and_batch(dtype):
     h = hip()
     Bt, M, N, K = 3, 200, 192, 160
