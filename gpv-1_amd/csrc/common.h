@@ -95,6 +95,27 @@ __host__ __device__ __forceinline__ uint32_t drop_thresh(float p) {
   return (uint32_t)t;
 }
 
+// Weights resident in LDS, staged once per workgroup (the streaming kernels): U 16-byte loads of every thread are issued before the
+// first LDS store.  The plain `for (idx ...) lds[dst(idx)] = glob[src(idx)]` loop compiles to load -> s_waitcnt vmcnt(0) -> ds_write
+// per iteration: 16 DEPENDENT L2 round trips for a 128 KB matrix on 512 threads -- 10-20 us at the head of every launch of
+// conv1x1_stream / _chain / _dual, conv3x3_stream and stem_pool (seen in the ISA; the A-fragment prefetch shares the counter).
+template <int NTHR, int U, typename SrcF, typename DstF>
+__device__ __forceinline__ void stage_chunks16(int total, int tid, SrcF src, DstF dst) {
+  for (int base = 0; base < total; base += NTHR * U) {
+    bf16x8 tmp[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int idx = base + u * NTHR + tid;
+      if (idx < total) tmp[u] = *reinterpret_cast<const bf16x8*>(src(idx));
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int idx = base + u * NTHR + tid;
+      if (idx < total) *reinterpret_cast<bf16x8*>(dst(idx)) = tmp[u];
+    }
+  }
+}
+
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 
 template <typename T> struct Ld8;   // load 8 consecutive elements as float[8]

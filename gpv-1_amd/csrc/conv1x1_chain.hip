@@ -73,16 +73,13 @@ __global__ __launch_bounds__(512) void c1c_kernel(ChainK p) {
     const bf16* W1 = reinterpret_cast<const bf16*>(p.w1);
     const bf16* W2 = reinterpret_cast<const bf16*>(p.w2);
     const bf16* WN = reinterpret_cast<const bf16*>(p.wn);
-    for (int idx = tid; idx < N * SL; idx += 512) {
-      const int L = idx / SL, sl = idx - L * SL;
-      const int c = c1c_chan<N>(L);
-      const bf16* src = sl < SL1 ? W1 + (int64_t)c * K1 + sl * 8 : W2 + (int64_t)c * K2 + (sl - SL1) * 8;
-      *reinterpret_cast<bf16x8*>(Wl + L * KP + sl * 8) = *reinterpret_cast<const bf16x8*>(src);
-    }
-    for (int idx = tid; idx < N2 * SL2; idx += 512) {
-      const int L = idx / SL2, sl = idx - L * SL2;
-      *reinterpret_cast<bf16x8*>(Wn + L * KP2 + sl * 8) = *reinterpret_cast<const bf16x8*>(WN + (int64_t)c1c_chan<N2>(L) * N + sl * 8);
-    }
+    stage_chunks16<512, 8>(N * SL, tid,
+        [&](int idx) { const int L = idx / SL, sl = idx - L * SL; const int c = c1c_chan<N>(L);
+                       return sl < SL1 ? W1 + (int64_t)c * K1 + sl * 8 : W2 + (int64_t)c * K2 + (sl - SL1) * 8; },
+        [&](int idx) { const int L = idx / SL, sl = idx - L * SL; return Wl + L * KP + sl * 8; });
+    stage_chunks16<512, 8>(N2 * SL2, tid,
+        [&](int idx) { const int L = idx / SL2, sl = idx - L * SL2; return WN + (int64_t)c1c_chan<N2>(L) * N + sl * 8; },
+        [&](int idx) { const int L = idx / SL2, sl = idx - L * SL2; return Wn + L * KP2 + sl * 8; });
     for (int c = tid; c < N; c += 512) bias_l[c] = p.bias ? p.bias[c] : 0.f;
     for (int c = tid; c < N2; c += 512) bias_n[c] = p.bias_n ? p.bias_n[c] : 0.f;
   }

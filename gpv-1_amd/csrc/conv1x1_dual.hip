@@ -68,12 +68,10 @@ __global__ __launch_bounds__(512) void c1d_kernel(DualK p, int ncols) {
   {
     const bf16* W1 = reinterpret_cast<const bf16*>(p.w1);
     const bf16* W2 = reinterpret_cast<const bf16*>(p.w2);
-    for (int idx = tid; idx < ncols * SL; idx += 512) {
-      const int L = idx / SL, sl = idx - L * SL;
-      const int c = cbase + c1d_chan<NH>(L);
-      const bf16* src = sl < SL1 ? W1 + (int64_t)c * K1 + sl * 8 : W2 + (int64_t)c * K2 + (sl - SL1) * 8;
-      *reinterpret_cast<bf16x8*>(Wl + L * KP + sl * 8) = *reinterpret_cast<const bf16x8*>(src);
-    }
+    stage_chunks16<512, 8>(ncols * SL, tid,
+        [&](int idx) { const int L = idx / SL, sl = idx - L * SL; const int c = cbase + c1d_chan<NH>(L);
+                       return sl < SL1 ? W1 + (int64_t)c * K1 + sl * 8 : W2 + (int64_t)c * K2 + (sl - SL1) * 8; },
+        [&](int idx) { const int L = idx / SL, sl = idx - L * SL; return Wl + L * KP + sl * 8; });
     for (int c = tid; c < ncols; c += 512) bias_l[c] = p.bias ? p.bias[cbase + c] : 0.f;
   }
   __syncthreads();

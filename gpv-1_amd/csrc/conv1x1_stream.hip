@@ -32,7 +32,10 @@ __device__ __forceinline__ int c1s_chan(int L) {
   return h * NH + (j >> 1) * 32 + (r >> 2) * 8 + (j & 1) * 4 + (r & 3);
 }
 
-template <int K, int NH, bool RES, bool MASK, bool NT>
+// LIN: the kernel as a plain linear layer's GEMM (gpv_gemm, K = 256 -> 2048 outputs: the DETR feed-forward 256 -> 2048 and its
+// backward-data product with the ReLU mask): alpha on the accumulator and the GEMM kernels' dropout
+// epilogue (same element index -> same keep pattern as gemm.hip / gemm_glds.hip / gemm_pipe.hip); the convolution instances are unchanged
+template <int K, int NH, bool RES, bool MASK, bool NT, bool LIN = false>
 __global__ __launch_bounds__(512) void c1s_kernel(GemmK p, int ncols) {
   // ncols: output channels per block row (gridDim.y slices of a wide layer: layer3's 1024 channels as four 256-channel
   // problems that share A -- the weights of one slice fit the LDS, A is small next to the output)
@@ -48,6 +51,8 @@ __global__ __launch_bounds__(512) void c1s_kernel(GemmK p, int ncols) {
   const bf16* R = reinterpret_cast<const bf16*>(p.res) + cbase;
   const bf16* Mk = reinterpret_cast<const bf16*>(p.mask) + cbase;
   const float* bias_g = p.bias ? p.bias + cbase : nullptr;
+  const int nfull = p.N;
+  if constexpr (LIN) { if (p.dthresh) p.seed = eff_seed(p.seed, p.seed_dev); }
   p.N = ncols;
   const int npass = p.N / NH;
   const int ntile = (p.M + 15) >> 4;
@@ -73,11 +78,9 @@ __global__ __launch_bounds__(512) void c1s_kernel(GemmK p, int ncols) {
     }
   };
   fetch(tile);
-  for (int idx = tid; idx < p.N * SL; idx += 512) {
-    const int L = idx / SL, sl = idx - L * SL;
-    const int c = c1s_chan<NH>(L);
-    *reinterpret_cast<bf16x8*>(Wl + L * KP + sl * 8) = *reinterpret_cast<const bf16x8*>(Wg + (int64_t)c * p.ldb + sl * 8);
-  }
+  stage_chunks16<512, 8>(p.N * SL, tid,
+      [&](int idx) { const int L = idx / SL, sl = idx - L * SL; return Wg + (int64_t)c1s_chan<NH>(L) * p.ldb + sl * 8; },
+      [&](int idx) { const int L = idx / SL, sl = idx - L * SL; return Wl + L * KP + sl * 8; });
   for (int c = tid; c < p.N; c += 512) bias_l[c] = bias_g ? bias_g[c] : 0.f;
   __syncthreads();
 
@@ -123,14 +126,21 @@ __global__ __launch_bounds__(512) void c1s_kernel(GemmK p, int ncols) {
       for (int t = 0; t < NG; ++t) {
         const int c0 = h * NH + t * 32 + g * 8;
         const float4 b0 = *reinterpret_cast<const float4*>(bias_l + c0), b1 = *reinterpret_cast<const float4*>(bias_l + c0 + 4);
+        if constexpr (LIN) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { acc[2 * t][i] *= p.alpha; acc[2 * t + 1][i] *= p.alpha; }
+        }
         float v[8] = {acc[2 * t][0] + b0.x, acc[2 * t][1] + b0.y, acc[2 * t][2] + b0.z, acc[2 * t][3] + b0.w,
                       acc[2 * t + 1][0] + b1.x, acc[2 * t + 1][1] + b1.y, acc[2 * t + 1][2] + b1.z, acc[2 * t + 1][3] + b1.w};
+        uint32_t keep8 = 0xffu;
+        if constexpr (LIN) { if (p.dthresh) keep8 = drop_mask<8>(p.seed, (uint64_t)px * (uint64_t)nfull + (uint64_t)(cbase + c0), p.dthresh); }
         bf16x8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           float x = v[e];
           if constexpr (RES) x += (float)rv[t][e];
           if (p.act == GPV_ACT_RELU) x = fmaxf(x, 0.f);
+          if constexpr (LIN) { if (p.dthresh) x = ((keep8 >> e) & 1u) ? x * p.dscale : 0.f; }
           if constexpr (MASK) x = (float)mv[t][e] > 0.f ? x : 0.f;
           o[e] = (bf16)x;
         }
@@ -150,12 +160,12 @@ inline int c1s_cols(int K, int N) {
   return N < cap ? N : cap;
 }
 
-template <int K, int NH, bool RES, bool MASK, bool NT>
+template <int K, int NH, bool RES, bool MASK, bool NT, bool LIN = false>
 int c1s_launch(const GemmK& k, hipStream_t st) {
   constexpr int KP = K + 8;
   const int ncols = c1s_cols(k.K, k.N), nsl = k.N / ncols;
   const size_t lds = (size_t)ncols * KP * 2 + (size_t)ncols * sizeof(float);
-  auto fn = c1s_kernel<K, NH, RES, MASK, NT>;
+  auto fn = c1s_kernel<K, NH, RES, MASK, NT, LIN>;
   static size_t attr = 0;
   if (lds > 64 * 1024 && lds > attr) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -176,6 +186,17 @@ int c1s_launch(const GemmK& k, hipStream_t st) {
 template <int K, int NH>
 int c1s_flags(const GemmK& k, hipStream_t st) {
   const bool r = k.res != nullptr, m = k.mask != nullptr, nt = k.nt_io != 0;
+  if (k.alpha != 1.0f || k.dthresh) {     // linear-layer extras: instantiated for the 256 -> n x 256 shapes only
+    if constexpr (K == 256 && NH == 256) {
+      if (nt) return -1;
+      if (r && m) return c1s_launch<K, NH, true, true, false, true>(k, st);
+      if (r) return c1s_launch<K, NH, true, false, false, true>(k, st);
+      if (m) return c1s_launch<K, NH, false, true, false, true>(k, st);
+      return c1s_launch<K, NH, false, false, false, true>(k, st);
+    } else {
+      return -1;
+    }
+  }
   if (nt) {      // (non-temporal: the layer1 forwards -- never with a mask)
     if (m) return -1;
     return r ? c1s_launch<K, NH, true, false, true>(k, st) : c1s_launch<K, NH, false, false, true>(k, st);
@@ -201,28 +222,35 @@ inline bool al16s(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) 
 }  // namespace
 
 int g_c1s_mode = 1;          // 0 never, 1 heuristic, 2 wherever legal (tests)
+long g_c1s_launches = 0;     // gpv_set_option(GPV_OPT_C1S_LAUNCHES, .)
 
 // 0 = launched, -1 = not applicable, > 0 = hipError_t
-int c1s_try_launch(const GemmK& k, int dtype_in, int dtype_out, hipStream_t st) {
+int c1s_try_launch(const GemmK& k, int dtype_in, int dtype_out, hipStream_t st, bool linear) {
   static const int env = [] { const char* e = getenv("GPV_C1S"); return e ? atoi(e) : -1; }();
   const int mode = env >= 0 ? env : g_c1s_mode;
   if (mode == 0 || dtype_in != GPV_BF16 || dtype_out != GPV_BF16) return -1;
   if (k.K != 64 && k.K != 128 && k.K != 256 && k.K != 512) return -1;
-  if (k.N != 64 && k.N != 128 && k.N != 256 && k.N != 512 && k.N != 1024 && k.N != 2048) return -1;
+  if (k.N != 64 && k.N != 128 && k.N != 256 && k.N != 512 && k.N != 1024 && k.N != 2048 && !(linear && k.N % 256 == 0 && k.N <= 2048)) return -1;
   const int ncols = c1s_cols(k.K, k.N), nsl = k.N / ncols;
   if ((size_t)ncols * (k.K + 8) * 2 + (size_t)ncols * 4 > 150 * 1024 || nsl > 8) return -1;
-  if (k.alpha != 1.0f || k.rowscale || k.dthresh || k.accumulate || k.split_k > 1 || k.a_rowsum) return -1;
+  if (k.rowscale || k.accumulate || k.split_k > 1 || k.a_rowsum) return -1;
+  if ((k.alpha != 1.0f || k.dthresh) && !(linear && k.K == 256 && k.N >= 256 && k.N % 256 == 0)) return -1;
+  if (linear && (k.cg.SH == 2 || k.cg.cm || k.nt_io)) return -1;
   if (k.act != GPV_ACT_NONE && k.act != GPV_ACT_RELU) return -1;
   if (k.lda % 8 || k.ldb != k.K || k.ldc % 8 || (k.res && k.ldr % 8) || (k.mask && k.ldm % 8)) return -1;
   if (!al16s(k.A) || !al16s(k.B) || !al16s(k.C) || (k.res && !al16s(k.res)) || (k.mask && !al16s(k.mask))) return -1;
-  if (mode == 1 && ((int64_t)k.M * nsl < 65536 || k.M < 32768)) return -1;   // a streaming regime needs rows (x slices): the layer1-3 maps at training batch sizes
+  if (linear) {      // gpv_gemm: 256 -> 2048 features over >= 2048 rows (the DETR feed-forward; tools/bench_c1s_linear.py: 1024 / 1536 outputs are faster on the tile kernels)
+    if (mode == 1 && (k.K != 256 || k.N < 2048 || k.M < 2048)) return -1;
+  } else if (mode == 1 && ((int64_t)k.M * nsl < 65536 || k.M < 32768)) return -1;   // a streaming regime needs rows (x slices): the layer1-3 maps at training batch sizes
+  int e = -1;
   switch (k.K) {
-    case 64: return c1s_n<64>(k, st);
-    case 128: return c1s_n<128>(k, st);
-    case 256: return c1s_n<256>(k, st);
-    case 512: return c1s_n<512>(k, st);           // (N <= 128: the weights must fit the LDS)
+    case 64: e = c1s_n<64>(k, st); break;
+    case 128: e = c1s_n<128>(k, st); break;
+    case 256: e = c1s_n<256>(k, st); break;
+    case 512: e = c1s_n<512>(k, st); break;       // (N <= 128: the weights must fit the LDS)
   }
-  return -1;
+  if (e == 0) ++g_c1s_launches;
+  return e;
 }
 
 }  // namespace gpvk

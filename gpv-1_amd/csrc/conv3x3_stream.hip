@@ -68,11 +68,9 @@ __global__ __launch_bounds__(WAVES * 64) void c3r_kernel(GemmK p, int rows_per_i
   {
     const bf16* Wg = reinterpret_cast<const bf16*>(p.B);
     constexpr int SL = KTOT / 8;
-    for (int idx = tid; idx < C3_NSL * SL; idx += WAVES * 64) {
-      const int L = idx / SL, sl = idx - L * SL;
-      const int c = cbase + (L & ~31) + c3_perm(L & 31);
-      *reinterpret_cast<bf16x8*>(Wl + L * KP + sl * 8) = *reinterpret_cast<const bf16x8*>(Wg + (int64_t)c * KTOT + sl * 8);
-    }
+    stage_chunks16<WAVES * 64, 8>(C3_NSL * SL, tid,
+        [&](int idx) { const int L = idx / SL, sl = idx - L * SL; return Wg + (int64_t)(cbase + (L & ~31) + c3_perm(L & 31)) * KTOT + sl * 8; },
+        [&](int idx) { const int L = idx / SL, sl = idx - L * SL; return Wl + L * KP + sl * 8; });
     for (int L = tid; L < C3_NSL; L += WAVES * 64) bias_l[L] = p.bias ? p.bias[cbase + (L & ~31) + c3_perm(L & 31)] : 0.f;
   }
   __syncthreads();
@@ -240,11 +238,9 @@ __global__ __launch_bounds__(WAVES * 64) void c3d2_kernel(GemmK p, int rows_per_
   {
     const bf16* Wg = reinterpret_cast<const bf16*>(p.B);
     constexpr int SL = KTOT / 8;
-    for (int idx = tid; idx < C3_NSL * SL; idx += WAVES * 64) {
-      const int L = idx / SL, sl = idx - L * SL;
-      const int c = cbase + (L & ~31) + c3_perm(L & 31);
-      *reinterpret_cast<bf16x8*>(Wl + L * KP + sl * 8) = *reinterpret_cast<const bf16x8*>(Wg + (int64_t)c * KTOT + sl * 8);
-    }
+    stage_chunks16<WAVES * 64, 8>(C3_NSL * SL, tid,
+        [&](int idx) { const int L = idx / SL, sl = idx - L * SL; return Wg + (int64_t)(cbase + (L & ~31) + c3_perm(L & 31)) * KTOT + sl * 8; },
+        [&](int idx) { const int L = idx / SL, sl = idx - L * SL; return Wl + L * KP + sl * 8; });
   }
   __syncthreads();
   const bf16* wlane = Wl + pl * KP + h * 8;

@@ -999,6 +999,11 @@ extern "C" int gpv_gemm(const gpv_gemm_args* a, void* stream) {
   if (la == GPV_KMAJOR && lb == GPV_KMAJOR) {
     const int gv = gemv_try_launch(k, a->dtype_in, a->dtype_out, a->batch, st);                // M <= 8: matrix-vector products of the decode step
     if (gv >= 0) return gv;
+    static const bool c1s_linear = [] { const char* e = getenv("GPV_C1S_LINEAR"); return !e || e[0] != '0'; }();     // 0: A/B only
+    if (a->batch == 1 && !g_kernel_forced && c1s_linear) {
+      const int cs = c1s_try_launch(k, a->dtype_in, a->dtype_out, st, true);               // K = 256 -> >= 1024 features: weights resident in LDS, rows streamed
+      if (cs >= 0) return cs;
+    }
     const int pp = pipe_try_launch(k, OP_PLAIN, a->dtype_in, a->dtype_out, a->batch, st);     // pipelined direct-to-LDS kernel (big tiles, and the small-M 6-8 stage tiles)
     if (pp >= 0) return pp;
     const int sk = skinny_try_launch(k, 0, a->dtype_in, a->dtype_out, a->batch, st);             // few tiles, long reduction: what the pipelined kernel does not take (fp32 outputs, ragged N)

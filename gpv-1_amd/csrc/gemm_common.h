@@ -57,8 +57,9 @@ long pipe_launches(long set);
 
 // conv1x1_stream.hip: streaming kernel for the K <= 256 pointwise convolutions over >= 65536 pixels (weights resident in LDS,
 // a wave per 16 pixels, register epilogue in a permuted channel order).  Same return convention; tried first on the 1x1 path.
-int c1s_try_launch(const GemmK& k, int dtype_in, int dtype_out, hipStream_t st);
+int c1s_try_launch(const GemmK& k, int dtype_in, int dtype_out, hipStream_t st, bool linear = false);   // linear: called from gpv_gemm (plain rows, alpha / dropout allowed)
 extern int g_c1s_mode;
+extern long g_c1s_launches;
 
 // conv3x3_stream.hip: streaming kernel for the 3x3 convolutions with 64 / 128 input channels over >= 65536 output pixels (weights
 // of 64 output channels resident in LDS, a wave per 32 pixels, 32x32x16 MFMA, no barriers): forward, backward-data stride 1 and

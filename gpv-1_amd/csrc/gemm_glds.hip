@@ -467,6 +467,11 @@ int glds_try_launch(const GemmK& k, int amode, int dtype_in, int dtype_out, int 
 namespace gpvk { int attn_bwd1_mode(int set); long attn_bwd1_launches(long set); }   // attention.hip
 
 extern "C" int gpv_set_option(int option, int value) {
+  if (option == GPV_OPT_C1S_LAUNCHES) {
+    const long prev = gpvk::g_c1s_launches;
+    gpvk::g_c1s_launches = value;
+    return (int)prev;
+  }
   if (option == GPV_OPT_ATTN_BWD1) return gpvk::attn_bwd1_mode(value);
   if (option == GPV_OPT_ATTN_BWD1_LAUNCHES) return (int)gpvk::attn_bwd1_launches(value);
   if (option == GPV_OPT_GLDS) {

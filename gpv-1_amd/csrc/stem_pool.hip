@@ -67,11 +67,9 @@ __global__ __launch_bounds__(WAVES * 64) void stem_pool_kernel(StemK p) {
   {
     const bf16* Wg = reinterpret_cast<const bf16*>(p.w);
     constexpr int SL = ST_K / 8;
-    for (int idx = tid; idx < 64 * SL; idx += WAVES * 64) {
-      const int L = idx / SL, sl = idx - L * SL;
-      const int c = (L & ~31) + st_perm(L & 31);
-      *reinterpret_cast<bf16x8*>(Wl + L * ST_KP + sl * 8) = *reinterpret_cast<const bf16x8*>(Wg + c * ST_K + sl * 8);
-    }
+    stage_chunks16<WAVES * 64, 8>(64 * SL, tid,
+        [&](int idx) { const int L = idx / SL, sl = idx - L * SL; return Wg + ((L & ~31) + st_perm(L & 31)) * ST_K + sl * 8; },
+        [&](int idx) { const int L = idx / SL, sl = idx - L * SL; return Wl + L * ST_KP + sl * 8; });
     for (int L = tid; L < 64; L += WAVES * 64) bias_l[L] = p.shift ? p.shift[(L & ~31) + st_perm(L & 31)] : 0.f;
   }
   __syncthreads();

@@ -119,7 +119,7 @@ def build_id():
 
 OPT_GLDS, OPT_GLDS_LAUNCHES, OPT_SKINNY, OPT_GLDS_WGRAD, OPT_PIPE, OPT_PIPE_LAUNCHES, OPT_C1S, OPT_C3S, OPT_C3S_LAUNCHES = 0, 1, 2, 3, 4, 5, 6, 7, 8
 OPT_GEMV, OPT_GEMV_LAUNCHES = 9, 10
-OPT_ATTN_BWD1, OPT_ATTN_BWD1_LAUNCHES = 11, 12
+OPT_ATTN_BWD1, OPT_ATTN_BWD1_LAUNCHES, OPT_C1S_LAUNCHES = 11, 12, 13
 
 
 def set_option(option, value):

@@ -74,6 +74,7 @@ int gpv_gemm_tt_group(const gpv_tt_problem* problems, int n, void* stream);
 #define GPV_OPT_PIPE_LAUNCHES 5 /* returns the number of pipelined-kernel launches so far, then sets the counter to value */
 #define GPV_OPT_ATTN_BWD1 11 /* single-launch attention backward (bf16; attention.hip attn_bwd1_kernel): 0 never, 1 (default) when B * H >= 128, 2 wherever legal */
 #define GPV_OPT_ATTN_BWD1_LAUNCHES 12 /* returns the number of single-launch attention backwards so far, then sets the counter to value (value >= 0) */
+#define GPV_OPT_C1S_LAUNCHES 13 /* returns the number of streaming-1x1 launches so far (convolutions and the K = 256 linear GEMMs), then sets the counter to value */
 int gpv_set_option(int option, int value);
 
 /* ---------------------------------------------------------------------------------------------

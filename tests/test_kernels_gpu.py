@@ -180,6 +180,48 @@ def test_argmax_rows(dtype):
     assert tok.tolist() == [5, 64, 0, 0]
 
 
+@pytest.mark.parametrize('M,N,mode', [(9600, 2048, 'ffn1'), (9600, 2048, 'ffn1_bwd'), (3200, 2048, 'ffn1'), (9600, 1536, 'plain'), (2049, 1024, 'ffn1_bwd')])
+def test_streaming_kernel_as_linear_gemm_equals_the_tile_kernels(M, N, mode):
+    """gpv_gemm, K = 256 -> >= 1024 features over >= 2048 rows on the streaming kernel (conv1x1_stream.hip, LIN: alpha + the GEMM
+    kernels' dropout epilogue; transformer.py:156-160 linear1 and the backward-data product through linear2 with the ReLU mask)
+    against the tile kernels on the same operands: same zeros (ReLU, dropout keep pattern, mask), values within one bf16 ulp."""
+    h = hip()
+    K = 256
+    A, B = rnd(M, K, dtype=torch.bfloat16, seed=160), rnd(N, K, dtype=torch.bfloat16, seed=161, scale=0.1)
+    bias = rnd(N, seed=162)
+    mask = (rnd(M, N, dtype=torch.bfloat16, seed=163) > 0).to(torch.bfloat16) * rnd(M, N, dtype=torch.bfloat16, seed=164).abs()
+    kw = {'ffn1': dict(bias=bias, act=h.ACT_RELU, drop_p=0.1, seed=4242), 'plain': dict(bias=bias),
+          'ffn1_bwd': dict(relu_mask=mask, ldm=N, alpha=1.0 / 0.9)}[mode]
+    outs = []
+    prev = h.set_option(h.OPT_C1S, 0)
+    try:
+        for c1s in (0, 2):                          # 2: wherever legal (the default heuristic takes the 2048-wide layers only)
+            h.set_option(h.OPT_C1S, c1s)
+            h.set_option(h.OPT_C1S_LAUNCHES, 0)
+            C = torch.full((M, N), float('nan'), device=DEV, dtype=torch.bfloat16)
+            h.gemm(A, B, C, M, N, K, K, K, N, **kw)
+            torch.cuda.synchronize()
+            assert h.set_option(h.OPT_C1S_LAUNCHES, 0) == (1 if c1s else 0)
+            outs.append(C.float())
+    finally:
+        h.set_option(h.OPT_C1S, prev)
+    c0, c1 = outs
+    assert torch.isfinite(c1).all()
+    assert torch.equal(c0 == 0, c1 == 0)
+    assert ((c1 - c0).abs() <= 2 ** -7 * c0.abs() + 1e-30).all()
+    ref = A.float() @ B.float().t()
+    if mode != 'ffn1_bwd':
+        ref = ref + bias
+    if mode == 'ffn1':
+        ref = torch.relu(ref)
+        keep = c0 != 0
+        assert rel(c1[keep], (ref / 0.9)[keep]) < 2e-2
+    elif mode == 'plain':
+        assert rel(c1, ref) < 2e-2
+    else:
+        assert rel(c1, torch.where(mask > 0, ref / 0.9, torch.zeros_like(ref))) < 2e-2
+
+
 @pytest.mark.parametrize('dtype', DTYPES)
 def test_argmax_rows_embed_writes_the_next_input_row(dtype):
     """gpv_argmax_rows_embed: the pick, and xnext[r] = table[pick_r] (+ pos_row) rounded once -- what embedding gather, input
