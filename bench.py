@@ -200,6 +200,8 @@ def attention_roofline(dev, B):
                                 'quarter-rate v_exp_f32) / 1024 SIMDs / 2.4 GHz: the time the launch needs for its vector instructions alone', 'achieved': tf, 'peak': 2500.0, 'unit': 'TFLOP/s', 'frac': tf / 2500.0,
             'kernel': 'attn_q_kernel<bf16,32,32,20,0> (DETR encoder self-attention core, forward; B x 8 heads, 300x300, dh 32, dropout on)',
             'flops_per_launch': fl, 'avg_launch_us': out['fwd'], 'bwd_us': out['bwd'],
+            'bwd_kernel': 'attn_bwd1_kernel<32,32,20,20> (dQ, dK, dV in ONE launch: S formed once, dS transposed through LDS for the dQ product; '
+                          'round 3: attn_q_kernel<..,1> + attn_kv2_kernel, 55 us)',
             'bwd_tflops': 2.5 * fl / (out['bwd'] * 1e-6) / 1e12,
             'note': 'dh = 32: 2 MFMAs per 256 scores against ~12 VALU instructions per score -- the core is VALU-bound, see DESIGN.md'}
 

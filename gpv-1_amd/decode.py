@@ -173,7 +173,7 @@ class GreedyKVDecoder:
             self.graphs = [None] * self.T
             self.key = (RT.weights_epoch, RT.static_epoch, RT.dtype)
             self.table = None
-        if self.embed_in_pick and self.table is None and not torch.cuda.is_current_stream_capturing():
+        if self.embed_in_pick and self.table is None and not (self.tok.is_cuda and torch.cuda.is_current_stream_capturing()):
             self._build_table()              # (a decode first met inside a capture runs the three-launch input path)
         self.memory.copy_(memory.reshape(self.B * self.Tm, self.D))
         self.vocab_mask.zero_()

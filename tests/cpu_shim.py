@@ -331,12 +331,15 @@ def act_fwd(x, y, n, act):
     y.copy_(_act(x.float(), act).to(y.dtype))
 
 
-def argmax_rows(x, addend, out0=None, out1=None):
+def argmax_rows(x, addend, out0=None, out1=None, table=None, pos_row=None, xnext=None):
     f = x.float() if addend is None else x.float() + addend
     idx = f.argmax(-1)                       # (first maximum)
     for o in (out0, out1):
         if o is not None:
             o.copy_(idx)
+    if table is not None:                    # gpv_argmax_rows_embed: the next input rows
+        r = table[idx].float()
+        xnext.copy_((r if pos_row is None else r + pos_row.float()).to(xnext.dtype))
 
 
 def attention_row_proj(q, q_bs, k, k_bs, k_rs, v, v_bs, v_rs, Wo, partial, B, H, Sk, dh, scale):

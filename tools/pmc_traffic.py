@@ -5,7 +5,7 @@ convolutions of the reference's algorithm -- bench.py conv_algorithmic's yardsti
 issues for them: fused stem / block tails and the grouped weight-gradient call make that number smaller)
 Units and corrections follow /opt/skills/guides/MI355X_MICROARCH.md (HBM section): rocprofv3 reports both counters in KB;
 on gfx950 FETCH_SIZE counts 128-byte requests at 64 B -> doubled; WRITE_SIZE is taken as reported (uncalibrated)."""
-import csv, glob, json, os, sys
+import csv, glob, json, os, re, sys
 
 def load(d, counter):
     out = {}
@@ -20,6 +20,8 @@ def load(d, counter):
 
 def is_conv(name):
     n = name.replace('(anonymous namespace)::', '')
+    if 'c1s_kernel' in n and re.search(r', true>\(', n):      # LIN instances: the K = 256 -> 2048 linear GEMMs of the transformer (gpv_gemm), not convolutions
+        return False
     return (('gemm_kernel' in n and 'Li2ELi0E' in n) or ('gemm_kernel<' in n and ', 1, 2, ' in n) or 'glds_kernelILi2E' in n or 'conv1x1_kernel' in n
             or 'glds_wgrad_kernel' in n or 'pipe_kernelILi2E' in n or 'c1s_kernel' in n or 'conv1x1_nt_kernel' in n
             or 'c3r_kernel' in n or 'c3d2_kernel' in n or 'c1d_kernel' in n or 'c1c_kernel' in n or 'stem_pool_kernel' in n or 'glds_wgrad_group_kernel' in n)
