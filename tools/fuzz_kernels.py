@@ -105,6 +105,11 @@ for it in range(rounds):
     # (causal + key padding is not a model shape: a padded key 0 leaves the first causal row without any key)
     run('attention', T.test_attention_fwd_bwd, adt, H, dh, Sq, Sk, causal, (not causal) and rng.random() < 0.5)
     run('layernorm', T.test_layernorm_fwd_bwd, rng.choice([torch.bfloat16, torch.float32]), rng.randint(1, 12000), 8 * rng.randint(1, 300))
+    # round 4: the single-launch backward against the two launches (forced wherever instantiated), LayerNorm partial rows + grouped fold
+    run('attention_bwd1', T.test_attention_bwd_single_launch_equals_the_two_launches, H, dh, Sq, Sk, causal, (not causal) and rng.random() < 0.5,
+        rng.choice([0.0, 0.1, 0.25]))
+    run('layernorm_fold', T.test_layernorm_bwd_partials_and_fold_group_equal_the_atomic_column_sums, rng.choice([torch.bfloat16, torch.float32]),
+        rng.randint(1, 12000), 8 * rng.randint(1, 300), rng.choice([0.0, 0.1]))
 # grouped weight gradients: random problem lists
 import math
 for it in range(max(rounds // 3, 2)):
