@@ -384,8 +384,14 @@ class ResNetBody(nn.Module):
                     hip.conv_wgrad_group(group)
                 del group[:]
             if stage_done is not None:
+                # a stage milestone hands the stage's gradient buckets to the exchange (train.FlatTrainer._on_milestone), ordered
+                # behind `main` only: every weight-gradient launch of the stage must have been joined first -- the grouped call on
+                # its branch AND the one-launch-each side stream of fp32 "precise" mode / GPV_WGRAD_GROUP=0 (that one
+                # was joined only at the end of the pass, so a bucket could leave while its gradients were still accumulating)
                 if gside is not None:
                     main.wait_stream(gside)
+                if side is not None:
+                    main.wait_stream(side)
                 stage_done(li)
         y_last = keep[-1][4]
         gz = torch.empty_like(y_last)

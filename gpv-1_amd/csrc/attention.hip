@@ -16,7 +16,7 @@
 
 namespace {
 
-int g_bwd1_mode = [] { const char* e = getenv("GPV_ATTN_BWD1"); return e ? atoi(e) : 1; }();   // gpv_set_option(GPV_OPT_ATTN_BWD1, .)
+int g_bwd1_mode = tune_env("GPV_ATTN_BWD1", 1);   // gpv_set_option(GPV_OPT_ATTN_BWD1, .)
 long g_bwd1_launches = 0;      // gpv_set_option(GPV_OPT_ATTN_BWD1_LAUNCHES, .)
 
 struct AttnK {
@@ -1135,7 +1135,7 @@ int launch_q_f(AttnK p, hipStream_t st) {
   if (nsplit > (nqt + QW - 1) / QW) nsplit = (nqt + QW - 1) / QW;
   if (nsplit < 1) nsplit = 1;
   {
-    static const int force = [] { const char* e = getenv("GPV_ATTN_SPLIT"); return e ? atoi(e) : 0; }();
+    static const int force = tune_env("GPV_ATTN_SPLIT", 0);
     if (force > 0) nsplit = force < nqt ? force : nqt;
   }
   p.nsplit = nsplit;
@@ -1263,7 +1263,7 @@ int dispatch_q(const AttnK& p, hipStream_t st) {
 template <typename T>
 int dispatch_kv(const AttnK& p, hipStream_t st) {
   if constexpr (sizeof(T) == 2) {
-    static const bool old_only = [] { const char* e = getenv("GPV_ATTN_KV_OLD"); return e && e[0] == '1'; }();
+    static const bool old_only = tune_env("GPV_ATTN_KV_OLD", 0) == 1;
     int r = -1;
     if (!old_only) {
       switch (p.dh) {

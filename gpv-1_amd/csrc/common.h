@@ -10,6 +10,17 @@ typedef bf16 __attribute__((ext_vector_type(4))) bf16x4;
 typedef bf16 __attribute__((ext_vector_type(2))) bf16x2;
 typedef float __attribute__((ext_vector_type(4))) f32x4;
 
+// Environment knobs of the kernels' launch heuristics (kernel family on / off, blocks per CU, rows per strip, forced tiles, split targets,
+// timing ablations) exist for tools/ only: they are read iff the library was compiled with -DGPV_TUNING (`make tuning` ->
+// libgpv_hip_tuning.so, loaded by gpv1_amd.hip when GPV_TUNING_LIB=1).  The production library (libgpv_hip.so) reads NO environment:
+// every knob is its default, and the run-time switches tests need go through gpv_set_option ("no global state").
+#include <stdlib.h>
+#ifdef GPV_TUNING
+static inline int tune_env(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+#else
+static inline int tune_env(const char*, int dflt) { return dflt; }
+#endif
+
 #define GPV_CHECK_LAUNCH() \
   do {                     \
     hipError_t e_ = hipGetLastError(); \

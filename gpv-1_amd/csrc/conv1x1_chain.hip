@@ -172,7 +172,7 @@ int c1c_launch(const ChainK& p, hipStream_t st) {
     attr = true;
   }
   const int ntile = (p.M + 15) / 16;
-  static const int bpc = [] { const char* e = getenv("GPV_C1C_BLOCKS"); return e ? atoi(e) : 0; }();
+  static const int bpc = tune_env("GPV_C1C_BLOCKS", 0);
   int blocks = bpc > 0 ? bpc : (lds <= 80 * 1024 ? 512 : 256);        // persistent waves: two 8-wave blocks per CU when the LDS allows
   if (blocks * 8 > ntile) blocks = (ntile + 7) / 8;
   hipLaunchKernelGGL(fn, dim3(blocks), dim3(512), lds, st, p);

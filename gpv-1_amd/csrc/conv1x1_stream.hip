@@ -174,7 +174,7 @@ int c1s_launch(const GemmK& k, hipStream_t st) {
   }
   // persistent waves: two blocks of 8 waves per CU when the weights leave room for them, one otherwise
   const int ntile = (k.M + 15) / 16;
-  static const int bpc = [] { const char* e = getenv("GPV_C1S_BLOCKS"); return e ? atoi(e) : 0; }();
+  static const int bpc = tune_env("GPV_C1S_BLOCKS", 0);
   int blocks = bpc > 0 ? bpc : (lds <= 72 * 1024 ? 512 : 256);
   blocks = (blocks + nsl - 1) / nsl;
   if (blocks * 8 > ntile) blocks = (ntile + 7) / 8;
@@ -226,7 +226,7 @@ long g_c1s_launches = 0;     // gpv_set_option(GPV_OPT_C1S_LAUNCHES, .)
 
 // 0 = launched, -1 = not applicable, > 0 = hipError_t
 int c1s_try_launch(const GemmK& k, int dtype_in, int dtype_out, hipStream_t st, bool linear) {
-  static const int env = [] { const char* e = getenv("GPV_C1S"); return e ? atoi(e) : -1; }();
+  static const int env = tune_env("GPV_C1S", -1);
   const int mode = env >= 0 ? env : g_c1s_mode;
   if (mode == 0 || dtype_in != GPV_BF16 || dtype_out != GPV_BF16) return -1;
   if (k.K != 64 && k.K != 128 && k.K != 256 && k.K != 512) return -1;

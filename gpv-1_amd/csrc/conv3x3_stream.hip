@@ -177,8 +177,8 @@ int c3r_launch_w(const GemmK& k, hipStream_t st) {
   const ConvGeom& g = k.cg;
   const int nsl = k.N / C3_NSL, Bn = k.M / (g.OH * g.OW);
   const int nstrip = (g.OW + 29) / 30;
-  static const int env_blocks = [] { const char* e = getenv("GPV_C3S_BLOCKS"); return e ? atoi(e) : 0; }();
-  static const int env_rows = [] { const char* e = getenv("GPV_C3R_ROWS"); return e ? atoi(e) : 0; }();
+  static const int env_blocks = tune_env("GPV_C3S_BLOCKS", 0);
+  static const int env_rows = tune_env("GPV_C3R_ROWS", 0);
   int blocks = env_blocks > 0 ? env_blocks : ((CIN == 64 ? 512 : 256) / nsl);
   // rows per item: a multiple of 3 such that the items fill the resident waves about twice (each segment re-reads two halo rows)
   int rows = env_rows > 0 ? env_rows : 3;
@@ -196,7 +196,7 @@ int c3r_launch_w(const GemmK& k, hipStream_t st) {
 
 template <int CIN, bool DGRAD, bool MASK>
 int c3r_launch(const GemmK& k, hipStream_t st) {
-  static const int env_waves = [] { const char* e = getenv("GPV_C3S_WAVES"); return e ? atoi(e) : 0; }();
+  static const int env_waves = tune_env("GPV_C3S_WAVES", 0);
   if (env_waves == 4) return c3r_launch_w<CIN, DGRAD, MASK, 4>(k, st);
   if (env_waves == 16) return c3r_launch_w<CIN, DGRAD, MASK, 16>(k, st);
   return c3r_launch_w<CIN, DGRAD, MASK, 8>(k, st);
@@ -349,7 +349,7 @@ int c3d2_launch(const GemmK& k, hipStream_t st) {
   const ConvGeom& g = k.cg;
   const int nsl = k.N / C3_NSL, Bn = k.M / (g.OH * g.OW);
   const int nstrip = (g.IW + 30) / 31;
-  static const int env_rows = [] { const char* e = getenv("GPV_C3D2_ROWS"); return e ? atoi(e) : 0; }();
+  static const int env_rows = tune_env("GPV_C3D2_ROWS", 0);
   int blocks = 256 / nsl;
   int rows = env_rows > 0 ? env_rows : 2;
   if (env_rows <= 0) {
@@ -381,7 +381,7 @@ long g_c3s_launches = 0;
 // k: the GemmK gpv_conv2d prepared for the implicit-GEMM path (A = input pixels, B = [N][9][Cin] weights, cg = geometry).
 // 0 = launched, -1 = not applicable, > 0 = hipError_t
 int c3s_try_launch(const GemmK& k, int dtype_in, int dtype_out, hipStream_t st) {
-  static const int env = [] { const char* e = getenv("GPV_C3S"); return e ? atoi(e) : -1; }();
+  static const int env = tune_env("GPV_C3S", -1);
   const int mode = env >= 0 ? env : g_c3s_mode;
   const ConvGeom& g = k.cg;
   if (mode == 0 || dtype_in != GPV_BF16 || dtype_out != GPV_BF16) return -1;

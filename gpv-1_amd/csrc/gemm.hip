@@ -867,7 +867,7 @@ __global__ __launch_bounds__(256) void conv_split_epilogue_kernel(const float* _
 // applies bias / residual / ReLU.  Returns 0 = launched, -1 = not applicable.
 inline bool a16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 int conv_split_try_launch(const GemmK& k, int dtype_in, int dtype_out, hipStream_t st) {
-  static const int on = [] { const char* e = getenv("GPV_CONV_SPLIT"); return e ? atoi(e) : 1; }();
+  static const int on = tune_env("GPV_CONV_SPLIT", 1);
   if (!on || g_kernel_forced || dtype_in != GPV_BF16 || dtype_out != GPV_BF16 || !k.vecA || !k.vecB || !k.ws_base) return -1;
   if (k.mask || k.rowscale || k.dthresh || k.accumulate || k.cg.dgrad || k.alpha != 1.0f || (k.act != 0 && k.act != GPV_ACT_RELU)) return -1;
   if (k.N % 4 != 0 || k.ldc != k.N || (k.res && k.ldr != k.N) || !a16(k.C) || (k.res && !a16(k.res)) || (k.bias && !a16(k.bias))) return -1;
@@ -901,7 +901,7 @@ int launch_tiles(const GemmK& k, int batch, hipStream_t st) {
   const int64_t sk = (k.split_k < 1 ? 1 : k.split_k);
   const int64_t t128 = (int64_t)((k.M + 127) / 128) * ((k.N + 127) / 128) * batch * sk;
   const int64_t t12864 = (int64_t)((k.M + 127) / 128) * ((k.N + 63) / 64) * batch * sk;
-  static const int force = [] { const char* e = getenv("GPV_FORCE_TILE"); return e ? atoi(e) : 0; }();   // tuning only
+  static const int force = tune_env("GPV_FORCE_TILE", 0);   // tuning only
   int cfg;   // 0: 128x128, 1: 128x64, 2: 64x64
   if (force) cfg = force - 1;
   else if (k.K <= 256) cfg = (k.N >= 1024 && t128 >= 384 && !k.conv1x1) ? 0 : 2;   // <= 8 k-tiles: HBM/latency bound, 64x64 keeps more bytes in flight
@@ -999,7 +999,7 @@ extern "C" int gpv_gemm(const gpv_gemm_args* a, void* stream) {
   if (la == GPV_KMAJOR && lb == GPV_KMAJOR) {
     const int gv = gemv_try_launch(k, a->dtype_in, a->dtype_out, a->batch, st);                // M <= 8: matrix-vector products of the decode step
     if (gv >= 0) return gv;
-    static const bool c1s_linear = [] { const char* e = getenv("GPV_C1S_LINEAR"); return !e || e[0] != '0'; }();     // 0: A/B only
+    static const bool c1s_linear = tune_env("GPV_C1S_LINEAR", 1) != 0;     // 0: A/B only
     if (a->batch == 1 && !g_kernel_forced && c1s_linear) {
       const int cs = c1s_try_launch(k, a->dtype_in, a->dtype_out, st, true);               // K = 256 -> >= 1024 features: weights resident in LDS, rows streamed
       if (cs >= 0) return cs;
@@ -1079,7 +1079,7 @@ extern "C" int gpv_conv2d(const gpv_conv_args* a, void* stream) {
         // outputs far beyond the 256 MB MALL (layer1's 314 MB maps) are stored -- and their residual read -- non-temporally:
         // 64 -> 256 without a residual 150 -> 106 us, with one 177 -> 168 us; smaller outputs are better left cacheable for
         // the next convolution (layer3 conv3, 79 MB: 58 -> 72 us with non-temporal stores)   [tools/bench_c1.py]
-        static const int64_t nt_min = [] { const char* e = getenv("GPV_NT_MIN_MB"); return (int64_t)(e ? atoi(e) : 200) << 20; }();
+        static const int64_t nt_min = (int64_t)tune_env("GPV_NT_MIN_MB", 200) << 20;
         k.nt_io = (int64_t)k.M * k.N * esz >= nt_min ? 1 : 0;
       }
       k.vecA = aligned16(a->x) && (a->Cs % vecel == 0) && (int64_t)k.M * a->Cs * esz < 0x7ffffff0ll ? 1 : 0;
@@ -1097,7 +1097,7 @@ extern "C" int gpv_conv2d(const gpv_conv_args* a, void* stream) {
       if (g >= 0) return g;
       return launch_dtype<OP_PLAIN, OP_PLAIN>(k, 1, a->dtype_in, a->dtype_out, st);
     }
-    static const bool s2_split = [] { const char* e = getenv("GPV_S2_DGRAD_SPLIT"); return !e || e[0] != '0'; }();
+    static const bool s2_split = tune_env("GPV_S2_DGRAD_SPLIT", 1) != 0;
     if (s2_split && a->mode == 1 && k.cg.cm && a->KH == 1 && a->KW == 1 && a->PH == 0 && a->PW == 0 && a->dtype_in == GPV_BF16 &&
         a->dtype_out == GPV_BF16 && a->Cout % 8 == 0 && aligned16(a->y) && (!a->res || aligned16(a->res)) &&
         (!a->relu_mask || aligned16(a->relu_mask)) && k.vecA && k.vecB) {
@@ -1170,7 +1170,7 @@ extern "C" int gpv_conv2d(const gpv_conv_args* a, void* stream) {
       const int gw = glds_wgrad_try_launch(k, a->dtype_in, a->dtype_out, st);
       if (gw >= 0) return gw;
     }
-    static const int wforce = [] { const char* e = getenv("GPV_FORCE_WGRAD_TILE"); return e ? atoi(e) : 0; }();   // tuning only
+    static const int wforce = tune_env("GPV_FORCE_WGRAD_TILE", 0);   // tuning only
     if (a->dtype_in == GPV_BF16) {
       const bool can128 = (a->Cin % 128 == 0) && k.M >= 128;
       int cfg;   // 0: 128x128, 1: 128x64, 2: 64x64

@@ -392,7 +392,7 @@ int launch_glds(const GemmK& k, int batch, hipStream_t st) {
     if (e != hipSuccess) { (void)hipGetLastError(); return (int)e; }      // (leave no stale error behind for the next launch check)
     attr_done[c11] = true;
   }
-  static const int depi = [] { const char* e = getenv("GPV_GLDS_DEPI"); return e ? atoi(e) : 1; }();
+  static const int depi = tune_env("GPV_GLDS_DEPI", 1);
   p.depi = depi;
   dim3 grid(tilesM * p.tilesN, 1, batch);
   ++g_glds_launches;
@@ -409,9 +409,9 @@ int launch_glds_out(const GemmK& k, int dtype_out, int batch, hipStream_t st) {
 
 }  // namespace
 int g_kernel_forced = 0;      // bit 0: GPV_OPT_GLDS >= 2, bit 1: GPV_OPT_PIPE >= 100 -- a kernel family is being forced (tests / tuning): the small-problem side paths step aside
-int g_two_per_cu = [] { const char* e = getenv("GPV_TWO_PER_CU"); return e ? atoi(e) : 1; }();
+int g_two_per_cu = tune_env("GPV_TWO_PER_CU", 1);
 namespace {
-int g_glds_mode = [] { const char* e = getenv("GPV_GLDS"); return e ? atoi(e) : 1; }();   // gpv_set_option(GPV_OPT_GLDS, .)
+int g_glds_mode = tune_env("GPV_GLDS", 1);   // gpv_set_option(GPV_OPT_GLDS, .)
 
 inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 

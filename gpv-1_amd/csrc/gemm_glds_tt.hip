@@ -330,12 +330,14 @@ __device__ __forceinline__ void wgrad_group_body(const WgGroupK& g) {
   glds_tt_core<true, ABL>(p, u - ksplit * q.tiles, ksplit);
 }
 __global__ __launch_bounds__(256) void glds_wgrad_group_kernel(WgGroupK g) { wgrad_group_body<0>(g); }
+#ifdef GPV_TUNING        // timing-ablation instances (wrong results by construction): tuning build only, never in libgpv_hip.so
 __global__ __launch_bounds__(256) void glds_wgrad_group_abl1_kernel(WgGroupK g) { wgrad_group_body<1>(g); }
 __global__ __launch_bounds__(256) void glds_wgrad_group_abl2_kernel(WgGroupK g) { wgrad_group_body<2>(g); }
 __global__ __launch_bounds__(256) void glds_wgrad_group_abl3_kernel(WgGroupK g) { wgrad_group_body<3>(g); }
 __global__ __launch_bounds__(256) void glds_wgrad_group_abl4_kernel(WgGroupK g) { wgrad_group_body<4>(g); }
 __global__ __launch_bounds__(256) void glds_wgrad_group_abl5_kernel(WgGroupK g) { wgrad_group_body<5>(g); }
 __global__ __launch_bounds__(256) void glds_wgrad_group_abl6_kernel(WgGroupK g) { wgrad_group_body<6>(g); }
+#endif
 
 struct WgRed { const float* ws; float* C; int64_t MN; int split, N, ldc, blk_start; };
 struct WgRedK { int n; int pad; WgRed r[WG_MAX]; };
@@ -369,7 +371,7 @@ int launch_tt(F fn, const GemmK& k, bool& attr_done, hipStream_t st) {
   const int kt_total = (p.K + TBK - 1) / TBK;
   // two 64 KB blocks per CU = 512 resident blocks: size the split so that (tiles x splits) fills them once -- the 544 the
   // register-staged kernel (three blocks per CU) is tuned for would leave a second, almost empty round
-  static const int target = [] { const char* e = getenv("GPV_WGRAD_TARGET"); return e ? atoi(e) : 512; }();
+  static const int target = tune_env("GPV_WGRAD_TARGET", 512);
   const int tiles = (p.M / TBM) * (p.N / TBN);
   int split = target / tiles;
   if (split > kt_total / 4) split = kt_total / 4;
@@ -396,7 +398,7 @@ inline bool al16t(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) 
 
 }  // namespace
 
-int g_wgrad_mode = [] { const char* e = getenv("GPV_GLDS_WGRAD"); return e ? atoi(e) : 1; }();   // gpv_set_option(GPV_OPT_GLDS_WGRAD, .)
+int g_wgrad_mode = tune_env("GPV_GLDS_WGRAD", 1);   // gpv_set_option(GPV_OPT_GLDS_WGRAD, .)
 
 // conv weight gradient (k as prepared by gpv_conv2d mode 2: A = dy [K][M], B = x NHWC, C = dw [M][N] fp32, split chosen).
 // returns 0 = launched (partial products + reduction), -1 = not applicable, > 0 = hipError_t
@@ -468,14 +470,18 @@ extern "C" int gpv_conv_wgrad_group(const gpv_conv_wgrad_problem* probs, int n, 
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   // k-tiles of 64 pixels per work unit: 150 = layer4's whole reduction at B = 32 (measured: 75 / 100 / 150 / 250 / 300 ->
   // 2.06 / 2.03 / 2.00 / 2.37 / 2.45 ms for the 42 gradients of the training step)
-  static const int target_kt = [] { const char* e = getenv("GPV_WGRAD_GROUP_KT"); const int v = e ? atoi(e) : 150; return v < 8 ? 8 : v; }();
+  static const int target_kt = [] { const int v = tune_env("GPV_WGRAD_GROUP_KT", 150); return v < 8 ? 8 : v; }();
   static bool attr_done = false;
   constexpr int lds = 2 * TSTAGE;
   // GPV_WG_ABL=1|2|3 (timing experiments only, wrong results): see glds_tt_core
-  static const int abl = [] { const char* e = getenv("GPV_WG_ABL"); return e ? atoi(e) : 0; }();
   typedef void (*wg_fn)(WgGroupK);
+#ifdef GPV_TUNING
+  static const int abl = tune_env("GPV_WG_ABL", 0);
   const wg_fn fn = abl == 1 ? glds_wgrad_group_abl1_kernel : abl == 2 ? glds_wgrad_group_abl2_kernel : abl == 3 ? glds_wgrad_group_abl3_kernel : abl == 4 ? glds_wgrad_group_abl4_kernel : abl == 5 ? glds_wgrad_group_abl5_kernel : abl == 6 ? glds_wgrad_group_abl6_kernel
                                                                                                         : glds_wgrad_group_kernel;
+#else
+  const wg_fn fn = glds_wgrad_group_kernel;
+#endif
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) { (void)hipGetLastError(); return (int)e; }      // (leave no stale error behind for the next launch check)

@@ -448,7 +448,7 @@ int launch_pipe(const GemmK& k, int batch, hipStream_t st) {
   }
   dim3 grid(tilesM * p.tilesN, 1, batch);
   ++g_pipe_launches;
-  static const int depi = [] { const char* e = getenv("GPV_GLDS_DEPI"); return e ? atoi(e) : 1; }();
+  static const int depi = tune_env("GPV_GLDS_DEPI", 1);
   p.depi = depi;
   hipLaunchKernelGGL(fn, grid, dim3(NT), lds, st, p);
   GPV_CHECK_LAUNCH();
@@ -479,7 +479,7 @@ int launch_cfg_idx(int idx, const GemmK& k, int batch, hipStream_t st) {
   return -1;
 }
 
-int g_pipe_mode = [] { const char* e = getenv("GPV_PIPE"); return e ? atoi(e) : 1; }();   // 0 off, 1 heuristic, 100+i: force configuration i wherever legal
+int g_pipe_mode = tune_env("GPV_PIPE", 1);   // 0 off, 1 heuristic, 100+i: force configuration i wherever legal
 
 inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 

@@ -747,7 +747,7 @@ LnBwdCfg ln_bwd_cfg(int rows, int cols, bool partial) {
   c.nv = (cols + 511) / 512;
   c.half = cols <= 256;
   c.wide = c.nv <= 2 && rows >= 2048;                    // 16 waves per block (register budget: the NV <= 2 bodies; few rows: no gain)
-  static const int rpb_div = [] { const char* e = getenv("GPV_LN_BWD_BLOCKS"); return e ? atoi(e) : 0; }();   // tuning only
+  static const int rpb_div = tune_env("GPV_LN_BWD_BLOCKS", 0);   // tuning only
   // few blocks: fewer same-address global atomics on dgamma; with per-block partials (no atomics) one block per CU
   const int target = rpb_div > 0 ? rpb_div : (c.wide ? (partial ? 256 : 160) : 512);
   const int rpi = (c.wide ? 16 : 4) * (c.half ? 2 : 1);
@@ -1035,7 +1035,7 @@ extern "C" int gpv_adamw(float* p, const float* g, float* m, float* v, void* p_l
                          float eps, float wd, float bc1, float bc2, const float* gscale, const uint16_t* seg_id,
                          const int32_t* seg_live, void* stream) {
   if ((seg_id == nullptr) != (seg_live == nullptr)) return (int)hipErrorInvalidValue;
-  static const int vec = [] { const char* e = getenv("GPV_ADAMW_VEC"); return e ? atoi(e) : 1; }();
+  static const int vec = tune_env("GPV_ADAMW_VEC", 1);
   const auto al = [](const void* q, uintptr_t a) { return (reinterpret_cast<uintptr_t>(q) & (a - 1)) == 0; };
   if (vec && n % 8 == 0 && al(p, 16) && al(g, 16) && al(m, 16) && al(v, 16) && (!p_lowp || al(p_lowp, 8))) {
     if (vec != 2) hipLaunchKernelGGL(adamw_vec4_kernel<false>, dim3(grid1d(n / 4, 256)), dim3(256), 0, ST(stream), p, g, m, v, (bf16*)p_lowp, n / 4, lr, beta1, beta2, eps, wd, bc1, bc2, gscale, seg_id, seg_live);

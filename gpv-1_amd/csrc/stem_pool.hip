@@ -185,8 +185,8 @@ extern "C" int gpv_stem_pool(const void* x, const void* w, const float* shift, v
   p.x = x; p.w = w; p.shift = shift; p.y = y;
   p.B = B; p.Hp = Hp; p.Wp = Wp; p.CH = CH; p.CW = CW; p.PH = PH; p.PW = PW;
   p.nstrip = (PW + ST_PCOLS - 1) / ST_PCOLS;
-  static const int env_rows = [] { const char* e = getenv("GPV_STEM_ROWS"); return e ? atoi(e) : 0; }();
-  static const int env_blocks = [] { const char* e = getenv("GPV_STEM_BLOCKS"); return e ? atoi(e) : 0; }();
+  static const int env_rows = tune_env("GPV_STEM_ROWS", 0);
+  static const int env_blocks = tune_env("GPV_STEM_BLOCKS", 0);
   int blocks = env_blocks > 0 ? env_blocks : 512;
   // pooled rows per item: the choice that minimises (rounds of the resident waves) x (conv rows per item, 2 rows + 1)
   int best = 1;

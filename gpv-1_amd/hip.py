@@ -14,7 +14,11 @@ ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 KMAJOR, TRANS = 0, 1
 
 _LIB = None
-_LIB_PATH = os.environ.get('GPV_HIP_LIB') or os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc', 'libgpv_hip.so')
+# GPV_TUNING_LIB=1 (tools/ only): the -DGPV_TUNING build of the same sources -- environment knobs of the launch heuristics, timing ablations,
+# experimental kernels (`make -C gpv-1_amd/csrc tuning`).  The production library reads no environment.
+TUNING = os.environ.get('GPV_TUNING_LIB', '0') == '1'
+_LIB_PATH = os.environ.get('GPV_HIP_LIB') or os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc',
+                                                          'libgpv_hip_tuning.so' if TUNING else 'libgpv_hip.so')
 
 
 class GemmArgs(C.Structure):
@@ -105,7 +109,7 @@ EXPORTS = ['gpv_abi_version', 'gpv_build_id', 'gpv_set_option', 'gpv_gemm', 'gpv
            'gpv_softmax_ce', 'gpv_roi_weights', 'gpv_add', 'gpv_add_rowbcast', 'gpv_colsum', 'gpv_cast',
            'gpv_cast_rowscale_t', 'gpv_prep_conv_weight', 'gpv_embedding', 'gpv_dropout',
            'gpv_relevance_condition', 'gpv_adamw', 'gpv_sumsq', 'gpv_clip_scale', 'gpv_act_fwd', 'gpv_act_bwd', 'gpv_set_seed_device',
-           'gpv_gemm_tt_group', 'gpv_cast_transpose_group', 'gpv_stem_pool', 'gpv_image_pipeline', 'gpv_conv1x1_dual', 'gpv_conv1x1_chain', 'gpv_ffn_fused_fwd',
+           'gpv_gemm_tt_group', 'gpv_cast_transpose_group', 'gpv_stem_pool', 'gpv_image_pipeline', 'gpv_conv1x1_dual', 'gpv_conv1x1_chain',
            'gpv_conv_wgrad_group', 'gpv_jpeg_parse', 'gpv_jpeg_decode', 'gpv_argmax_rows', 'gpv_ln_linear_rows', 'gpv_attention_row_proj',
            'gpv_layernorm_bwd_blocks', 'gpv_layernorm_bwd3', 'gpv_colsum_fold_group', 'gpv_argmax_rows_embed']
 
@@ -455,6 +459,8 @@ def conv1x1_chain(a1, w1, a2, w2, s2, res, bias, y, wn, bias_n, z, B, OH, OW):
 def ffn_fused_fwd(x, w1, b1, w2, b2, gamma, beta, h, y, out, mean, rstd, M, D, F, eps, drop_p=0.0, seed1=0, seed2=0, pos=None, out2=None):
     """gpv_ffn_fused_fwd: LayerNorm(x + dropout(linear2(dropout(relu(linear1(x)))))) in one launch (h, y, mean, rstd stored for the
     backward); False when the shape / dtype is not one the kernel takes -- the caller then runs gemm, gemm, layernorm_fwd"""
+    if not hasattr(lib(), 'gpv_ffn_fused_fwd'):          # tuning build only (csrc/Makefile TUNE_SRCS)
+        return False
     ts = [t for t in (x, w1, w2, h, y, out, pos, out2) if t is not None]
     if not all(t.dtype == torch.bfloat16 and t.is_contiguous() for t in ts) or b1 is None or b2 is None:
         return False

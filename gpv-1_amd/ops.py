@@ -318,6 +318,9 @@ class GradChain:
         self.acc = g
         return None
 
+    def rearm(self):
+        self.left, self.acc = self.total, None
+
 
 def grad_chain(x):
     return GradChain() if (GradChain.ENABLED and torch.is_grad_enabled() and torch.is_tensor(x) and x.requires_grad) else None
@@ -330,13 +333,28 @@ def check_chains(clear=True, chains=None):
     bad = 0
     for r in (GradChain._live if chains is None else chains):      # chains: the list a train.GraphedBody owns for its forward
         c = r()
-        if c is not None and c.left != c.total:
+        if c is None:
+            continue
+        # a GradSlots buffer still held after the pass: its consumer (MultiLinearFn.backward) never ran, the columns written
+        # into it reached nobody
+        if c.left != c.total or (isinstance(c, GradSlots) and c.acc is not None):
             bad += 1
-            c.left, c.acc = c.total, None
+            c.rearm()
     if clear and chains is None:
         del GradChain._live[:]
     if bad:
         raise RuntimeError('%d GradChain(s) ended a backward pass half walked: a chained consumer did not run' % bad)
+
+
+def reset_chains(chains=None):
+    """before a backward pass over a recorded forward that may have been walked before (retain_graph: train.GraphedBody captures
+    one backward per criterion variant, and retries a capture that failed): a pass that ABORTED half way leaves `acc` / `left` /
+    `fresh` of its chains mid-walk, and the next pass over the same graph would add a stale partial sum, hand out a half-filled
+    buffer or return None for a gradient.  Chains carry no state between complete passes, so re-arming is free."""
+    for r in (GradChain._live if chains is None else chains):
+        c = r()
+        if c is not None:
+            c.rearm()
 
 
 class GradSink(GradChain):
@@ -387,6 +405,9 @@ class GradSlots(GradSink):
 
     def release(self):
         self.acc, self.fresh = None, False
+
+    def rearm(self):
+        self.left, self.acc, self.fresh = self.total, None, False
 
 
 # concatenated compute copies of the weights behind a multi_linear site: [n*N, K] (forward), [K, n*N] (backward-data), fp32 biases.
@@ -793,7 +814,11 @@ class FFNBlockFn(Function):
 LN_POS = os.environ.get('GPV_LN_POS', '1') != '0'       # 0: TIMING A/B ONLY -- the sums as separate launches, query_embed loses the sink's gradient
 
 
-def _unfused_pos(y, pos):
+def _unfused_pos(y, pos, pos_param=None):
+    if pos_param is not None and pos_param.requires_grad and torch.is_grad_enabled():
+        # (the separate add takes pos as a constant -- query_embed would silently train without this share of its gradient)
+        raise RuntimeError('GPV_LN_POS=0 is a timing switch: it drops the gradient of the learned position term (query_embed); '
+                           'not available while that parameter trains')
     cols = y.shape[-1]
     return y, add(y, _pos_rows(pos, cols))
 
@@ -801,7 +826,7 @@ def _unfused_pos(y, pos):
 def ffn_block(x, w1, w2, gamma, beta, eps, drop_p=0.0, pos=None, pos_param=None):
     """LayerNorm(x + dropout(ffn(x))) -- one node when gradients flow, the plain composition otherwise; with `pos` -> (out, out + pos)"""
     if pos is not None and not LN_POS:
-        return _unfused_pos(ffn_block(x, w1, w2, gamma, beta, eps, drop_p), pos)
+        return _unfused_pos(ffn_block(x, w1, w2, gamma, beta, eps, drop_p), pos, pos_param)
     if not (torch.is_grad_enabled() and x.requires_grad):
         return add_layernorm(x, linear(linear(x, w1, ACT_RELU, drop_p), w2), gamma, beta, eps, drop_p, pos=pos, pos_param=pos_param)
     return FFNBlockFn.apply(x, w1, w2, gamma, beta, eps, drop_p, pos, pos_param)
@@ -811,7 +836,7 @@ def add_layernorm(x, s, gamma, beta, eps, drop_p=0.0, chain=None, pos=None, pos_
     """pos ([rows_p, cols], rows a multiple of rows_p; a constant for autograd): -> (y, y + pos); pos_param: the learned parameter
     behind a row-broadcast pos, whose gradient is accumulated by the backward (ops._pos_sink)"""
     if pos is not None and not LN_POS:
-        return _unfused_pos(AddLayerNormFn.apply(x, s, gamma, beta, eps, drop_p, chain, None, None), pos)
+        return _unfused_pos(AddLayerNormFn.apply(x, s, gamma, beta, eps, drop_p, chain, None, None), pos, pos_param)
     return AddLayerNormFn.apply(x, s, gamma, beta, eps, drop_p, chain, pos, pos_param)
 
 

@@ -226,9 +226,13 @@ class GraphedBody:
                 # streaming stores), instead of between the criterion and B1 on the critical path: nobody reads G between the
                 # previous step's AdamW and this step's first weight-gradient kernel (B1)
                 self.tr.G.zero_()
-        def multi_wait():                  # first multi_linear of F2: the copies are ready (long before: they follow the six encoder layers)
-            torch.cuda.current_stream(x.device).wait_event(multi_ready)
-            RT.multi_wait = None
+        waited = set()
+
+        def multi_wait():                  # first multi_linear of F2 ON EACH STREAM: the copies are ready (long before: they follow the six encoder layers)
+            cur = torch.cuda.current_stream(x.device)        # (one-shot was only right while the first call ran on the main stream;
+            if cur.cuda_stream not in waited:                #  a first call on the BERT / side branch left later main-stream calls unordered)
+                cur.wait_event(multi_ready)
+                waited.add(cur.cuda_stream)
         RT.multi_wait = multi_wait
         self.c5 = c5
         self.c5_leaf = c5.detach().requires_grad_(bool(train))
@@ -429,6 +433,8 @@ class GraphedBody:
             self._open = b1
             RT.defer_list = deferred if defer else None
             RT.backward_boundary = at_boundary if os.environ.get('GPV_WGRAD_SPLIT', '1') != '0' else None
+            from . import ops as _ops
+            _ops.reset_chains(self.chains)          # (an earlier capture over this recorded forward may have aborted mid-walk)
             if fused is None:
                 torch.autograd.backward([o for _, o, _ in pairs], grads, retain_graph=True)
             else:
@@ -438,7 +444,6 @@ class GraphedBody:
                 loss_static = loss.detach()
                 torch.autograd.backward([loss], retain_graph=True)
                 del loss
-            from . import ops as _ops
             _ops.check_chains(clear=False, chains=self.chains)     # (the recorded forward -- and its chains -- serve further backward variants)
             RT.defer_list = None
             RT.backward_boundary = None
@@ -512,6 +517,25 @@ class GraphedBody:
 
 
 class FlatTrainer:
+    """AdamW over ONE flat fp32 buffer (P / G / M / V) + the data-parallel gradient exchange (train_distr.py:228-253, 399-428).
+
+    `G` AND EVERY `p.grad` VIEW HOLD THE SUM OVER RANKS after allreduce_grads(), not the average the reference's DDP leaves in
+    `p.grad`: the 1 / world rides on the factor the AdamW kernel multiplies every gradient with (and the clip compares |sum| with
+    world x max_norm), which saves a pass over the 444 MB buffer per step.  Anything that reads gradients between the exchange and
+    the step -- norm logging, external clipping, debugging hooks -- must multiply by `grad_scale` (= 1 / world; `grad_norm()` does).
+    One consequence in the last bits: the clip factor is max_norm x world / (|sum| + 1e-6) where the reference computes
+    max_norm / (|average| + 1e-6) -- the epsilon weighs 1 / world as much (1e-6 against norms of 1e-1 .. 1e2: below fp32 resolution
+    of the factor for world <= 8)."""
+
+    @property
+    def grad_scale(self):
+        """what turns G / p.grad (sums over ranks after the exchange) into the reference's averaged gradients"""
+        return self.avg
+
+    def grad_norm(self, start=0, end=None):
+        """L2 norm of the AVERAGED gradient over the flat range [start, end) -- what the reference would log from p.grad"""
+        return self.G[start:self.total if end is None else end].norm() * self.grad_scale
+
     def __init__(self, model, lr=1e-4, lr_backbone=1e-5, weight_decay=1e-4, clip_max_norm=0.1, warmup_steps=0,
                  t_total=0, betas=(0.9, 0.999), eps=1e-8, bucket_mb=128, process_group=None, manual_gc=True, gc_interval=200,
                  graphs=None, lr_milestones=None, lr_drop=0.1, warmup_iters=0, grad_comm_dtype=None):

@@ -234,6 +234,9 @@ int gpv_conv1x1_dual(const void* a1, const void* w1, const void* a2, const void*
 int gpv_conv1x1_chain(const void* a1, const void* w1, int K1, const void* a2, const void* w2, int K2, int IH2, int IW2, int s2,
                       const void* res, const float* bias, void* y, int B, int OH, int OW, int N, const void* wn,
                       const float* bias_n, void* z, int N2, void* stream);
+#ifdef GPV_TUNING
+/* TUNING BUILD ONLY (libgpv_hip_tuning.so, `make -C gpv-1_amd/csrc tuning`; not part of the production ABI): built, correct and not faster
+ * than the three launches it replaces -- DESIGN.md section 0 / 8 -- kept compilable for the next attempt. */
 /* The post-norm feed-forward sub-layer of a DETR encoder / decoder layer in ONE launch (exp/gpv/models/transformer.py:156-160
  * encoder, :226-231 decoder: src + dropout2(linear2(dropout(relu(linear1(src))))) -> norm2):
  *   h[M,F]   = dropout(relu(x[M,D] . w1[F,D]^T + b1))        stored: the backward's ReLU mask and the dW2 operand
@@ -248,6 +251,7 @@ int gpv_conv1x1_chain(const void* a1, const void* w1, int K1, const void* a2, co
 int gpv_ffn_fused_fwd(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, const float* gamma,
                       const float* beta, void* h, void* y, void* out, float* mean, float* rstd, int M, int D, int F, float eps,
                       float drop_p, uint64_t seed1, uint64_t seed2, const void* pos, int pos_rows, void* out2, void* stream);
+#endif
 /* The whole ResNet stem in one launch (exp/gpv/models/backbone.py:93-95 -> torchvision resnet50 conv1 + bn1 (frozen: scale folded
  * into w, shift here) + relu + maxpool):  y[B,PH,PW,64] = maxpool3x3s2p1(relu(conv7x7s2(x) + shift)).  x = the zero-padded NHWC4
  * bf16 image gpv_image_to_nhwc4 writes with pad 3 ([B,Hp,Wp,4], Wp even, >= 2 (CW - 1) + 8), w = [64][7][8 px][4 ch] bf16 (8th pixel /

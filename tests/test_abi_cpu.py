@@ -13,6 +13,7 @@ HEADER = os.path.join(ROOT, 'include', 'gpv_hip.h')
 def declared():
     src = open(HEADER).read()
     src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    src = re.sub(r'#ifdef GPV_TUNING.*?#endif', '', src, flags=re.S)       # tuning-build-only entry points are not the production ABI
     return sorted(set(re.findall(r'\bint\s+(gpv_\w+)\s*\(', src)))
 
 
@@ -28,7 +29,7 @@ def lib_path():
 def test_library_exports_every_declared_entry_point():
     import gpv1_amd.hip as hip
     names = declared()
-    assert len(names) == 47, names
+    assert len(names) == 46, names
     assert sorted(hip.EXPORTS) == names
     lib = ctypes.CDLL(lib_path())
     for n in names:
@@ -39,6 +40,18 @@ def test_library_exports_every_declared_entry_point():
     out = subprocess.run(['nm', '-D', '--defined-only', lib_path()], capture_output=True, text=True).stdout
     exported = sorted({l.split()[-1] for l in out.splitlines() if l.split() and l.split()[-1].startswith('gpv_')})
     assert exported == names, set(exported) ^ set(names)
+
+
+def test_production_library_has_no_tuning_code():
+    """the timing-ablation instances of the weight-gradient kernel ("results wrong by construction"), the environment
+    reads of the launch heuristics and the kernels that did not pay live in the -DGPV_TUNING build only (libgpv_hip_tuning.so)."""
+    path = lib_path()
+    assert path.endswith('libgpv_hip.so')
+    syms = subprocess.run(['nm', '-C', path], capture_output=True, text=True).stdout
+    assert '_abl' not in syms and 'ffn_fused' not in syms
+    # the library never calls getenv (nm -D --undefined-only lists its imports)
+    und = subprocess.run(['nm', '-D', '--undefined-only', path], capture_output=True, text=True).stdout
+    assert not re.search(r'\bgetenv\b', und), 'libgpv_hip.so reads the environment'
 
 
 def test_ctypes_structs_match_the_c_layout(tmp_path):

@@ -61,6 +61,7 @@ def _worker(rank, world, port, out):
     tr.allreduce_grads()
     res = {'local': local, 'avg': tr.G.clone() * tr.avg,           # (G = the SUM over ranks; 1 / world rides on the AdamW factor)
             'touched_local': touched_local, 'touched': tr.live_host()}
+    res['grad_scale'], res['grad_norm'] = tr.grad_scale, float(tr.grad_norm())
     tr.step()
     for _ in range(1):
         tr.model.bert.model.p = 0.0
@@ -107,6 +108,8 @@ def test_two_rank_gradient_exchange(tmp_path):
     assert torch.equal(r0['P'], runs['0'][0]['P'])
     # exchanged gradient = average of the two local gradients, identical on both ranks
     avg = (r0['local'] + r1['local']) / 2
+    # (G holds the SUM over ranks: logged norms go through grad_scale = 1 / world)
+    assert r0['grad_scale'] == 0.5 and abs(r0['grad_norm'] - float(avg.norm())) <= 1e-5 * float(avg.norm())
     assert torch.equal(r0['avg'], r1['avg'])
     assert (r0['avg'] - avg).abs().max().item() <= 1e-6 * max(avg.abs().max().item(), 1.0)
     # the box head only received gradients on rank 0 (rank 1 had captions only) ...

@@ -1501,6 +1501,7 @@ def _bf16_ulps(a, b):
     return (ia - ib).abs()
 
 
+@pytest.mark.skipif(not __import__('gpv1_amd.hip', fromlist=['x']).TUNING, reason='gpv_ffn_fused_fwd lives in the tuning build only (GPV_TUNING_LIB=1)')
 @pytest.mark.parametrize('M,Fh,prow,drop', [(9600, 2048, 0, 0.0), (9600, 2048, 300, 0.1), (3200, 2048, 100, 0.1), (200, 2048, 100, 0.1),
                                             (77, 128, 0, 0.0), (64, 64, 64, 0.25), (1, 2048, 1, 0.1)])
 def test_ffn_fused_fwd_equals_the_three_launches(M, Fh, prow, drop):
@@ -1554,6 +1555,7 @@ def test_ffn_fused_fwd_equals_the_three_launches(M, Fh, prow, drop):
         assert rel(out, full) < 2 * TOL[bf]
 
 
+@pytest.mark.skipif(not __import__('gpv1_amd.hip', fromlist=['x']).TUNING, reason='gpv_ffn_fused_fwd lives in the tuning build only (GPV_TUNING_LIB=1)')
 def test_ffn_fused_fwd_refuses_what_it_does_not_take():
     h = hip()
     bf = torch.bfloat16
@@ -1573,6 +1575,7 @@ def test_ffn_fused_fwd_refuses_what_it_does_not_take():
     assert h.ffn_fused_fwd(xf, w1, torch.zeros(96, device=DEV), w2, z, z, z, *args, 64, 256, 96, 1e-5) is False       # fp32 operands
 
 
+@pytest.mark.skipif(not __import__('gpv1_amd.hip', fromlist=['x']).TUNING, reason='gpv_ffn_fused_fwd lives in the tuning build only (GPV_TUNING_LIB=1)')
 def test_ffn_block_with_the_fused_forward_matches_the_three_launch_node(monkeypatch):
     """ops.FFNBlockFn with GPV_FFN_FUSED on (opt-in): the forward's saved tensors (h, y, mean, rstd) feed the unchanged backward --
     outputs and every gradient within bf16 rounding of the default node's, same seeds, dropout on."""

@@ -240,3 +240,37 @@ def test_half_walked_grad_chain_is_an_error(shim):
     with pytest.raises(RuntimeError, match='GradChain'):
         ops.check_chains()                                          # ... which is reported, not trained on
     assert g_both.abs().sum() > 0
+
+
+def test_aborted_backward_leaves_no_stale_chain_state(shim):
+    """a backward pass that aborts half way (a capture that failed and is retried over the same recorded forward,
+    retain_graph=True) leaves GradChain.acc / GradSlots.acc mid-walk; ops.reset_chains re-arms them, and ops.check_chains reports a
+    GradSlots buffer nobody consumed."""
+    import gpv1_amd.ops as ops
+    from gpv1_amd.transformer import LinearP
+    torch.manual_seed(2)
+    a, b = LinearP(16, 16), LinearP(16, 16)
+    x = torch.randn(8, 16, requires_grad=True)
+    ops.check_chains()
+    ch = ops.grad_chain(x)
+    ya, yb = a(x, chain=ch), b(x, chain=ch)
+    loss = ya.float().sum() + yb.float().sum()
+    loss.backward(retain_graph=True)
+    ops.check_chains(clear=False)
+    want = x.grad.clone()
+    x.grad = None
+    ya.float().sum().backward(retain_graph=True)                    # "aborted" pass: only one consumer ran, the chain holds its gradient
+    assert ch.acc is not None and ch.left != ch.total
+    ops.reset_chains()
+    assert ch.acc is None and ch.left == ch.total
+    x.grad = None
+    loss.backward()
+    ops.check_chains()
+    assert torch.equal(x.grad, want)                                # no stale partial sum was added
+    # a GradSlots buffer handed to autograd but never released by its consumer
+    sl = ops.GradSlots()
+    buf = sl.slot(torch.zeros(4, 6))
+    assert sl.wrote() is buf and sl.wrote() is None
+    with pytest.raises(RuntimeError, match='GradChain'):
+        ops.check_chains()
+    assert sl.acc is None and not sl.fresh                          # re-armed by the failed check
