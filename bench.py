@@ -34,6 +34,17 @@ TL = 6
 CAP_WORDS = 18           # + __cls__ + __stop__ = 20 tokens = max_text_len
 
 
+def _note_sync():
+    """a synchronous collective just ran on the compute stream: the next capture waits for RCCL's watchdog once (misc.CollectiveClock)"""
+    from gpv1_amd.misc import note_sync_collective
+    note_sync_collective()
+
+
+def _cc():
+    from gpv1_amd.misc import CollectiveClock
+    return CollectiveClock
+
+
 def make_cfg():
     from gpv1_amd import synthetic
     g = torch.Generator().manual_seed(0)
@@ -473,6 +484,7 @@ def main():
     if multi:
         flag = torch.tensor([ok], device=dev, dtype=torch.int32)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        _note_sync()
         if int(flag) == 0:
             os.environ['GPV_GRAPHS_STRICT'] = '0'
             tr.disable_graphs(graphs_note or 'another rank failed to capture')
@@ -482,6 +494,7 @@ def main():
                 loss = step()
             torch.cuda.synchronize()
         dist.barrier()
+        _note_sync()
     torch.cuda.synchronize()
     bbm.PROF = []
     if multi:
@@ -497,6 +510,7 @@ def main():
     torch.cuda.synchronize()
     if multi:
         dist.barrier()
+        _note_sync()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     host_prof, trm.HOST_PROF = trm.HOST_PROF, None
@@ -530,6 +544,7 @@ def main():
     if multi:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        _note_sync()
         elapsed = float(t)
     comm = None
     if multi:
@@ -540,6 +555,7 @@ def main():
                 'grad_comm_dtype': str(tr.grad_comm_dtype).replace('torch.', ''), 'bytes_per_rank_per_step': tr.comm_bytes_per_step(),
                 'buckets': len(tr.buckets), 'exposed_ms_per_step': sum(exposed) / max(len(exposed), 1),
                 'graph_steps': tr.graph_steps, 'eager_steps': tr.eager_steps,
+                'capture_quiesce': {'calls': _cc().calls, 'sleeps': _cc().sleeps, 'mode': _cc().MODE},
                 'milestones_last_step': [m for m, _ in tr.milestone_log], 'left_after_backward_bytes': getattr(tr, 'left_after_backward', None),
                 'what': 'exposed = GPU time between the first bucket wait and the last bucket back on the compute stream (what the overlap did not hide), rank 0'}
     if rank != 0:

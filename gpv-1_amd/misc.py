@@ -1,5 +1,6 @@
 """Batch container + collate helpers (reference: utils/detr_misc.py:267-322, 394-410)."""
 import contextlib
+import os
 import gc
 from typing import List, Optional
 
@@ -124,17 +125,53 @@ class AttrDict(dict):
         return d
 
 
+class CollectiveClock:
+    """What a stream capture has to know about this process's collectives (quiesce_collectives).
+    pending: a SYNCHRONOUS collective (one that ran on the caller's stream: dist.broadcast / barrier / all_reduce without async_op
+    under the NCCL = RCCL backend) has been issued since the device was last observed idle for QUIET seconds.  Asynchronous
+    collectives -- everything train.FlatTrainer issues per step -- run on RCCL's own stream, which never captures: the watchdog's
+    event queries on them are legal whatever the compute stream does, so they do not arm the clock."""
+    QUIET = 0.35                   # three polling periods of ProcessGroupNCCL's watchdog (100 ms)
+    MODE = os.environ.get('GPV_QUIESCE', 'auto')      # auto | always (round 4: sleep before every capture) | never
+    pending = True                 # (process-group construction and whatever ran before the trainer existed)
+    idle_since = None
+    sleeps = 0                     # how often a capture actually had to wait (tests: a ragged stream in steady state: 0)
+    calls = 0
+
+
+def note_sync_collective():
+    """call after issuing a synchronous collective on a stream that may capture later (parameter broadcast, barriers)"""
+    CollectiveClock.pending = True
+    CollectiveClock.idle_since = None
+
+
 def quiesce_collectives():
     """With a process group alive, a stream capture must not begin while ProcessGroupNCCL's watchdog thread still polls the
-    completion event of a collective that ran on the stream about to capture (HIP: hipErrorCapturedEvent on the query, the capture
-    invalidated, the watchdog's exception ends the process -- train.FlatTrainer.quiesce_collectives has the measurement): idle
-    device, then three polling periods for the watchdog to retire what it was watching."""
+    completion event of a collective that ran ON THE STREAM ABOUT TO CAPTURE (HIP: hipErrorCapturedEvent on the query, the capture
+    invalidated, the watchdog's exception ends the process -- found with GPV_FORCE_COMM=1 on one GPU: 3 of 20 runs): idle device,
+    then three polling periods for the watchdog to retire what it was watching.
+    Round 5: that wait is paid only when such a collective is actually outstanding (CollectiveClock.pending).  Round 4 slept 0.35 s in
+    front of EVERY capture -- two per new batch signature, on every rank in lock-step: seconds of a ragged stream's first epoch.  The
+    per-step collectives of the trainer are asynchronous (RCCL's stream, never captured) and do not arm the clock; the synchronous
+    ones (parameter broadcast at construction, barriers of the drivers) do, through note_sync_collective().  GPV_QUIESCE=always
+    restores the unconditional wait."""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or not torch.cuda.is_available():
         return
     import time
+    cc = CollectiveClock
+    cc.calls += 1
     torch.cuda.synchronize()
-    time.sleep(0.35)
+    if cc.MODE == 'never' or (cc.MODE != 'always' and not cc.pending):
+        return
+    now = time.monotonic()
+    if cc.idle_since is None or cc.MODE == 'always':
+        cc.idle_since = now
+    wait = cc.QUIET - (now - cc.idle_since)
+    if wait > 0:
+        time.sleep(wait)
+        cc.sleeps += 1
+    cc.pending = False
 
 
 @contextlib.contextmanager

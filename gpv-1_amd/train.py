@@ -659,6 +659,8 @@ class FlatTrainer:
                     c = t.contiguous()
                     dist.broadcast(c, src=0, group=self.pg)
                     t.copy_(c)
+            from .misc import note_sync_collective
+            note_sync_collective()              # (synchronous broadcasts on this stream: the first capture waits for the watchdog once)
             # host-side agreement channel (train_step): gloo, so that no device synchronisation is involved
             self.host_pg = self.pg if dist.get_backend(self.pg) == 'gloo' else dist.new_group(backend='gloo')
         RT.bump_weights()
@@ -1092,8 +1094,8 @@ class FlatTrainer:
             if n < 1:
                 return None
             if len(self._bodies) >= self.graph_slots:
-                # More live signatures than slots: an eviction costs a four-graph capture (+ a cache flush, + 0.7 s of collective
-                # quiescing with several ranks).  At most one per `evict_interval` steps -- a stream that cycles through more
+                # More live signatures than slots: an eviction costs a four-graph capture (+ a cache flush; round 4: + 0.7 s of collective
+                # quiescing with several ranks -- round 5: none in steady state, misc.CollectiveClock).  At most one per `evict_interval` steps -- a stream that cycles through more
                 # signatures than there are slots runs its misses eagerly instead of recapturing on every step.
                 last = getattr(self, '_last_evict', None)
                 if last is not None and self.step_count - last < self.evict_interval:

@@ -201,6 +201,8 @@ def train_worker(cfg, dataset=None, device=None, log=print):
             break
     if world > 1:
         dist.barrier()
+        from .misc import note_sync_collective
+        note_sync_collective()
     return model, trainer, step
 
 

@@ -134,3 +134,37 @@ def test_load_pretr_detr_and_phase1_freeze(shim, tmp_path):
             assert p.requires_grad == rg_before[n], n
     freeze_detr_params(model, requires_grad=True)                           # phase 2 (finetune): released again
     assert all(p.requires_grad for n, p in model.named_parameters() if n in model.init_detr_params)
+
+
+def test_capture_quiesce_waits_only_for_synchronous_collectives(monkeypatch):
+    """round 4 slept 0.35 s in front of every stream capture with a process group alive (two per new batch signature, every
+    rank in lock-step).  misc.CollectiveClock: the wait is owed only when a SYNCHRONOUS collective ran on the compute stream since the
+    device was last seen idle; the trainer's per-step collectives are asynchronous (RCCL's own stream) and never arm it.  A ragged
+    stream of 12 new signatures (24 captures) after the construction-time broadcast: one wait."""
+    import time
+    import torch
+    import torch.distributed as dist
+    import gpv1_amd.misc as misc
+    cc = misc.CollectiveClock
+    slept = []
+    monkeypatch.setattr(time, 'sleep', lambda s: slept.append(s))
+    monkeypatch.setattr(dist, 'is_initialized', lambda: True)
+    monkeypatch.setattr(torch.cuda, 'is_available', lambda: True)
+    monkeypatch.setattr(torch.cuda, 'synchronize', lambda *a, **k: None)
+    monkeypatch.setattr(cc, 'MODE', 'auto')
+    monkeypatch.setattr(cc, 'sleeps', 0)
+    monkeypatch.setattr(cc, 'calls', 0)
+    monkeypatch.setattr(cc, 'idle_since', None)
+    monkeypatch.setattr(cc, 'pending', True)
+    misc.note_sync_collective()                       # FlatTrainer's parameter broadcast
+    for _ in range(12):                               # 12 signatures x (forward capture, backward capture); asynchronous all-reduces between
+        misc.quiesce_collectives()
+        misc.quiesce_collectives()
+    assert cc.calls == 24 and cc.sleeps == 1 and len(slept) == 1 and 0 < slept[0] <= cc.QUIET
+    misc.note_sync_collective()                       # a driver's barrier: the next capture waits again, once
+    misc.quiesce_collectives()
+    misc.quiesce_collectives()
+    assert cc.sleeps == 2
+    monkeypatch.setattr(cc, 'MODE', 'always')         # round 4's behaviour on request
+    misc.quiesce_collectives()
+    assert cc.sleeps == 3

@@ -921,6 +921,75 @@ def test_attention_bwd_single_launch_equals_the_two_launches(H, dh, Sq, Sk, caus
         assert rel(dq1, gq) < 2.5e-2 and rel(dk1, gk) < 2.5e-2 and rel(dv1, gv) < 2.5e-2
 
 
+def _attention_keep_mask(h, Bn, H, dh, Sq, Sk, drop, seed):
+    """the keep pattern the attention kernels draw for (seed, batch, head, query, key), read off the forward kernel itself: zero q / k
+    make the probabilities uniform (1 / Sk), one-hot V probes -- 32 keys at a time, channel = key % dh -- make every kept (query, key)
+    pair visible in O (the pattern depends on the indices only, not on the values)."""
+    D = H * dh
+    z = torch.zeros(Bn, max(Sq, Sk), D, device=DEV, dtype=torch.bfloat16)
+    keep = torch.zeros(Bn, H, Sq, Sk, device=DEV, dtype=torch.bool)
+    o = torch.empty(Bn, Sq, D, device=DEV, dtype=torch.bfloat16)
+    lse = torch.empty(Bn, H, Sq, device=DEV)
+    st = ((z.stride(0), z.stride(1)),) * 3 + ((Sq * D, D),)
+    for c0 in range(0, Sk, dh):
+        v = torch.zeros(Bn, Sk, D, device=DEV, dtype=torch.bfloat16)
+        n = min(dh, Sk - c0)
+        kk = torch.arange(n, device=DEV)
+        for hd in range(H):
+            v[:, c0 + kk, hd * dh + kk] = 1.0
+        stv = ((z.stride(0), z.stride(1)), (z.stride(0), z.stride(1)), (Sk * D, D), (Sq * D, D))
+        h.attention_fwd(z[:, :Sq], z[:, :Sk], v, o, stv, Bn, H, Sq, Sk, dh, 1.0, drop_p=drop, seed=seed, lse=lse)
+        keep[:, :, :, c0:c0 + n] = o.view(Bn, Sq, H, dh)[:, :, :, :n].permute(0, 2, 1, 3) > 0
+    return keep
+
+
+@pytest.mark.parametrize('Bn,H,dh,Sq,Sk,use_kpm', [(16, 8, 32, 300, 300, True), (16, 8, 32, 100, 300, False), (8, 16, 48, 100, 16, False)])
+def test_attention_bwd_single_launch_with_dropout_against_fp32_autograd(Bn, H, dh, Sq, Sk, use_kpm):
+    """attn_bwd1_kernel with dropout ON was only compared with the two-launch path (a self-comparison).  Here the
+    keep mask is reconstructed from the forward kernel (V = one-hot probes) and handed to fp32 autograd of
+    dropout(softmax(QK^T)) V (nn.MultiheadAttention, transformer.py:148-155) at B x H >= 128 -- the range the single launch serves."""
+    h = hip()
+    D, drop, seed = H * dh, 0.1, 4242
+    assert Bn * H >= 128
+    keep = _attention_keep_mask(h, Bn, H, dh, Sq, Sk, drop, seed)
+    frac = keep.float().mean().item()
+    assert abs(frac - (1 - drop)) < 5e-3, frac
+    qkv = rnd(Bn, max(Sq, Sk), 3 * D, dtype=torch.bfloat16, seed=160, scale=1.0)
+    q, k, v = qkv[:, :Sq, :D], qkv[:, :Sk, D:2 * D], qkv[:, :Sk, 2 * D:]
+    kpm = None
+    if use_kpm:
+        kpm = torch.zeros(Bn, Sk, dtype=torch.uint8, device=DEV)
+        kpm[1, Sk - Sk // 3:] = 1
+        kpm[2, ::5] = 1
+    scale = 1.0 / math.sqrt(dh)
+    o = torch.empty(Bn, Sq, D, device=DEV, dtype=torch.bfloat16)
+    lse = torch.empty(Bn, H, Sq, device=DEV)
+    strides = ((qkv.stride(0), qkv.stride(1)),) * 3 + ((Sq * D, D),)
+    h.attention_fwd(q, k, v, o, strides, Bn, H, Sq, Sk, dh, scale, kpm=kpm, drop_p=drop, seed=seed, lse=lse)
+    do = rnd(Bn, Sq, D, dtype=torch.bfloat16, seed=161)
+    dqkv = torch.full_like(qkv, float('nan'))
+    dq, dk, dv = dqkv[:, :Sq, :D], dqkv[:, :Sk, D:2 * D], dqkv[:, :Sk, 2 * D:]
+    prev = h.set_option(h.OPT_ATTN_BWD1, 2)
+    try:
+        h.set_option(h.OPT_ATTN_BWD1_LAUNCHES, 0)
+        h.attention_bwd(q, k, v, o, do, dq, dk, dv, strides, (Sq * D, D), Bn, H, Sq, Sk, dh, scale, kpm=kpm, drop_p=drop, seed=seed, lse=lse)
+        torch.cuda.synchronize()
+        assert h.set_option(h.OPT_ATTN_BWD1_LAUNCHES, 0) == 1                  # the single launch ran
+    finally:
+        h.set_option(h.OPT_ATTN_BWD1, prev)
+    qf, kf, vf = (t.float().contiguous().requires_grad_(True) for t in (q, k, v))
+    sc = (qf.view(Bn, Sq, H, dh).transpose(1, 2) @ kf.view(Bn, Sk, H, dh).transpose(1, 2).transpose(-1, -2)) * scale
+    if kpm is not None:
+        sc = sc.masked_fill(kpm[:, None, None, :].bool(), float('-inf'))
+    pd = sc.softmax(-1) * keep.float() / (1 - drop)
+    oref = (pd @ vf.view(Bn, Sk, H, dh).transpose(1, 2)).transpose(1, 2).reshape(Bn, Sq, D)
+    assert rel(o.float(), oref) < 1.5e-2                                     # (the forward with the same mask)
+    gq, gk, gv = torch.autograd.grad(oref, (qf, kf, vf), do.float())
+    for name, got, want in (('dq', dq, gq), ('dk', dk, gk), ('dv', dv, gv)):
+        assert torch.isfinite(got.float()).all()
+        assert rel(got.float(), want) < 2.5e-2, (name, rel(got.float(), want))
+
+
 # ----------------------------------------------------------------------------------------- layernorm / CE / misc
 @pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('rows,cols,drop', [(9600, 256, 0.1), (3200, 256, 0.0), (3968, 768, 0.1), (640, 768, 0.1), (77, 2048, 0.1), (5, 2304 // 9 * 8, 0.0)])

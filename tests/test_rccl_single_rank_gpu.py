@@ -36,6 +36,8 @@ def test_forced_single_rank_rccl_exchange_runs_the_multi_gpu_path_and_changes_no
     assert c['backend'] == 'nccl' and c['rccl_ranks'] == 1
     assert forced['graphs']['enabled'] and 'error' not in forced['graphs'] and c['eager_steps'] <= 2
     # hand-over order of the last (graphed) step: everything behind the DETR head, then the head with layer4, layer3, layer2
+    # captures wait for RCCL's watchdog only behind SYNCHRONOUS collectives (parameter broadcast, the bench's barriers), not per capture
+    assert c['capture_quiesce']['mode'] == 'auto' and c['capture_quiesce']['calls'] >= 2 and c['capture_quiesce']['sleeps'] <= 2, c['capture_quiesce']
     assert c['milestones_last_step'] == ['head', 'layer4', 'layer3', 'layer2']
     assert c['left_after_backward_bytes'] is not None and c['left_after_backward_bytes'] <= 30 << 20
     assert c['bytes_per_rank_per_step'] > 400 << 20
