@@ -107,5 +107,8 @@ int skinny_tt_try_launch(const GemmK& k, int dtype_in, int dtype_out, int batch,
 int glds_wgrad_try_launch(const GemmK& k, int dtype_in, int dtype_out, hipStream_t st);
 int glds_tt_try_launch(const GemmK& k, int dtype_in, int dtype_out, int batch, hipStream_t st);   // linear form (+ a_rowsum)
 extern int g_wgrad_mode;
+extern int g_wg8_mode;
+extern long g_wg8_launches;
+extern int g_w8l_mode;
 
 }  // namespace gpvk

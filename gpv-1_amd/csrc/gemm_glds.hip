@@ -495,6 +495,21 @@ extern "C" int gpv_set_option(int option, int value) {
     gpvk::g_gemv_launches = value;
     return (int)prev;
   }
+  if (option == GPV_OPT_WG8) {
+    const int prev = gpvk::g_wg8_mode;
+    gpvk::g_wg8_mode = value;
+    return prev;
+  }
+  if (option == GPV_OPT_W8L) {
+    const int prev = gpvk::g_w8l_mode;
+    gpvk::g_w8l_mode = value;
+    return prev;
+  }
+  if (option == GPV_OPT_WG8_LAUNCHES) {
+    const long prev = gpvk::g_wg8_launches;
+    gpvk::g_wg8_launches = value;
+    return (int)prev;
+  }
   if (option == GPV_OPT_GLDS_WGRAD) {
     const int prev = gpvk::g_wgrad_mode;
     gpvk::g_wgrad_mode = value;

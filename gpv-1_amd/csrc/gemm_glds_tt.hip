@@ -249,6 +249,285 @@ __device__ __forceinline__ void glds_tt_core(const GemmK& p, int tile, int kspli
   }
 }
 
+// ================================================================================================================================
+// Round 5: the same product on 256 x 256 tiles with an EIGHT-PHASE schedule (8 waves, one block per CU).
+//
+// The 128 x 128 core above is the "two barriers per k-tile, vmcnt(0) before the barrier" structure: every wave of a block loads,
+// waits, multiplies in lockstep, and two such blocks per CU overlap only by accident -- 615-690 TFLOP/s on these shapes, 64 flop per
+// byte moved L2 -> LDS (20 GB per training step, the measured bound: profiles/r04_wgrad_ablations.txt).  Here:
+//   * 256 x 256 x 64 tiles (128 flop per L2 -> LDS byte), waves 2 (M) x 4 (N), wave tile 128 x 64 = 8 x 4 MFMA tiles, 128 accumulator
+//     registers per lane;
+//   * a k-tile is staged as FOUR half-tile images of [64 pixels][128 columns] (exactly the 16 KB image of the core above, same
+//     swizzle, same transpose reads): Ah0 | Ah1 = output rows 0..127 | 128..255 of dY, Bh0 | Bh1 = columns 0..127 | 128..255 of x;
+//     wave (wm, wn) owns rows {64 wm .. + 63} of BOTH row halves and columns {32 wn .. + 31} of BOTH column halves, so that the
+//     quadrant a phase multiplies reads ONE A image and ONE B image and an image is dead as soon as its phase is over;
+//   * a k-tile is four phases of 16 MFMAs per wave: (A0,B0) (A0,B1) (A1,B1) (A1,B0); a phase = [fragment reads of the sub-tile that
+//     is new | issue ONE half-tile image of a later k-tile (2 x 1 KB LDS-DMA pieces per wave) | counted s_waitcnt vmcnt(8) |
+//     s_waitcnt lgkmcnt(0) | s_barrier | 16 MFMAs at s_setprio 1 | s_barrier].  The two wave groups (wm = 0 | 1; a SIMD hosts one wave
+//     of each) run ONE BARRIER apart: while one group's 16 MFMAs occupy the SIMD's matrix pipe the other group does its reads and
+//     DMA issue;
+//   * half-tiles are issued in the order they are read (Ah0, Bh0, Bh1, Ah1), five phases ahead: an image is overwritten two phases
+//     after its last read (both groups are past it by then) and waited for one phase before its first read -- four half-tiles
+//     (64 KB per CU) stay in flight across every barrier; two 64 KB buffers, no third stage.
+// Work units, slabs and the grouped reduce pass are those of the 128 x 128 grouped launch.
+// Measured (B = 32 bench shapes, tools/bench_wgrad_ablate.py, same box): layer4's ten gradients 456 -> 322 us, layer3's nineteen
+// 859 -> 615 us.  PMC (tools/pmc_wg8.sh): MFMA pipe 51 % busy, no LDS bank conflicts, L2 hit rate 62 %, L2 misses = 1.1 x the
+// operands' unique bytes -- what bounds it is operand delivery, which follows tools/probe/dma_rate.hip's additive model (a byte
+// that hits L2 costs a CU 1/40 clock, one that misses 1/10: 15 B/clk/CU here); every schedule variant tried (reads waited for
+// before / after the barrier, DMA issue before / after the reads, no s_setprio) measured the same +- 1 %, and an L2 prefetch from a
+// dedicated wave group (touches of k-tile t + 2 | t + 4, cooperative among the tiles that share lines) LOST 15 %: the touches hold
+// the same per-CU miss slots the real pieces wait for.
+constexpr int W8_HALF = TBK * ROWBYTES;            // 16 KB: [64 pixels][128 columns]
+constexpr int W8_BUF = 4 * W8_HALF;                // Ah0 | Ah1 | Bh0 | Bh1
+constexpr int W8_LDS = 2 * W8_BUF;                 // 128 KB
+
+// One transpose read as inline asm: the builtin carries an LDS memory operand, and in front of every such read hipcc waits
+// vmcnt(0) for ALL LDS-DMA pieces in flight (it cannot tell their destinations from the read's source) -- the pipeline would drain in
+// every phase (seen in the ISA).  The asm form is invisible to that pass; its results are ordered by the explicit
+// `s_waitcnt lgkmcnt(0)` + sched_barrier in front of the MFMAs that consume them.
+typedef short __attribute__((ext_vector_type(4))) w8_s16x4;
+typedef short __attribute__((ext_vector_type(8))) w8_s16x8;
+template <int OFF>
+__device__ __forceinline__ bf16x8 tr_frag_asm(uint32_t addr) {
+  w8_s16x4 a, b;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(a) : "v"(addr), "n"(OFF) : "memory");
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(b) : "v"(addr), "n"(OFF + 4 * ROWBYTES) : "memory");
+  w8_s16x8 r = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  return __builtin_bit_cast(bf16x8, r);
+}
+
+template <bool CONV>
+__device__ __forceinline__ void wg8_core(const GemmK& p, int tile, int ksplit) {
+  extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const ConvGeom& g = p.cg;
+  const int tm = tile / p.tilesN, tn = tile - tm * p.tilesN;
+  const int row0 = tm * 256, col0 = tn * 256;
+  const int kt_total = (p.K + TBK - 1) / TBK;
+  const int kt0 = ksplit * p.kt_per_split;
+  const int kt1 = min(kt_total, kt0 + p.kt_per_split);
+  if (kt0 >= kt1) return;                            // (uniform; the host sizes the split so that this does not happen)
+  const int nkt = kt1 - kt0;
+
+  constexpr int OOB = 0x7ffffff0;
+  const int lrow = lane >> 4;
+  const int myrow = wave * 8 + lrow;                 // piece j of this wave covers pixel rows myrow + 4 j of a k-tile, j = 0, 1
+  const int chunk = (lane & 15) ^ (2 * lrow) ^ (8 * (wave & 1));   // q(r) of row r = 8 wave + 4 j + lrow: (r & 3) = lrow, bit 3 = wave & 1
+
+  // CONV: the tile's tap and channel block (256 divides Cin: checked on the host -> one tap per tile); the lane walks the two
+  // pixel rows it fetches from k-tile to k-tile without divisions
+  int c0 = 0, dh = 0, dw = 0, adv_q = 0, adv_r = 0;
+  int px_b[2] = {0, 0}, px_oh[2] = {0, 0}, px_ow[2] = {0, 0}, px_k[2] = {0, 0};
+  if constexpr (CONV) {
+    const int tap = col0 / g.Cin;
+    c0 = col0 - tap * g.Cin;
+    const int tap_r = tap / g.KW, tap_s = tap - tap_r * g.KW;
+    dh = tap_r - g.PH; dw = tap_s - g.PW;
+    adv_q = TBK / g.OW; adv_r = TBK - adv_q * g.OW;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      px_k[j] = kt0 * TBK + myrow + 4 * j;
+      px_b[j] = px_k[j] / (g.OH * g.OW);
+      const int rem = px_k[j] - px_b[j] * (g.OH * g.OW);
+      px_oh[j] = rem / g.OW;
+      px_ow[j] = rem - px_oh[j] * g.OW;
+    }
+  }
+
+  const auto rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), (short)0, OOB, 0x00020000);
+  const auto rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), (short)0, OOB, 0x00020000);
+  const int a_vo = (myrow * (int)p.lda + row0 + chunk * 8) * 2;
+  const int a_j = 8 * (int)p.lda;                                  // piece j = 1: four rows further (bytes)
+  const int b_vo = CONV ? (c0 + chunk * 8) * 2 : (myrow * (int)p.ldb + col0 + chunk * 8) * 2;
+  const int b_j = 8 * (int)p.ldb;
+  auto bload = [&](const decltype(rsA)& rs, int voff, int soff, unsigned char* l) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)l, 16, voff, soff, 0, 0);
+  };
+  // half-tile image h of relative k-tile tx -> buffer buf; beyond the unit's last k-tile the pieces are still ISSUED (out of range:
+  // the DMA writes zeros nobody reads) so that every wave's vmcnt arithmetic is the same in every phase
+  auto issueA = [&](int tx, int h, int buf) {
+    const int kt = kt0 + tx;
+    const bool tv = tx < nkt;
+    const bool full = (kt + 1) * TBK <= p.K;
+    unsigned char* dst = smem + buf * W8_BUF + h * W8_HALF + wave * 2048;
+    const int so = tv ? kt * TBK * (int)p.lda * 2 : 0;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const bool ok = tv && (full || kt * TBK + myrow + 4 * j < p.K);
+      bload(rsA, ok ? a_vo + j * a_j + h * 256 : OOB, so, dst + j * 1024);
+    }
+  };
+  int b_off[2] = {OOB, OOB};                          // CONV: gather offsets of my two rows for the k-tile whose B halves are being issued
+  auto issueB = [&](int tx, int h, int buf) {
+    const int kt = kt0 + tx;
+    const bool tv = tx < nkt;
+    unsigned char* dst = smem + buf * W8_BUF + (2 + h) * W8_HALF + wave * 2048;
+    if constexpr (CONV) {
+      if (h == 0) {                                   // (Bh0 is issued one phase before Bh1 of the same k-tile)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int ih = px_oh[j] * g.SH + dh, iw = px_ow[j] * g.SW + dw;
+          const bool ok = tv && (unsigned)ih < (unsigned)g.IH && (unsigned)iw < (unsigned)g.IW && px_k[j] < p.K;
+          b_off[j] = ok ? ((px_b[j] * g.IH + ih) * g.IW + iw) * g.Cs * 2 + b_vo : OOB;
+          px_k[j] += TBK;
+          px_ow[j] += adv_r;
+          const int c = px_ow[j] >= g.OW ? 1 : 0;
+          px_ow[j] -= c ? g.OW : 0;
+          px_oh[j] += adv_q + c;
+          const int c2 = px_oh[j] >= g.OH ? 1 : 0;
+          px_oh[j] -= c2 ? g.OH : 0;
+          px_b[j] += c2;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j)                       // (OOB + 256 is still out of range)
+        bload(rsB, b_off[j] + h * 256, 0, dst + j * 1024);
+    } else {
+      const bool full = (kt + 1) * TBK <= p.K;
+      const int so = tv ? kt * TBK * (int)p.ldb * 2 : 0;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const bool ok = tv && (full || kt * TBK + myrow + 4 * j < p.K);
+        bload(rsB, ok ? b_vo + j * b_j + h * 256 : OOB, so, dst + j * 1024);
+      }
+    }
+  };
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // fragment addresses inside a half-tile image (see the 128 x 128 core): A sub-tile = 16-column groups 4 wm + i, B = 2 wn + j
+  const int li = lane & 15, fg = lane >> 4;
+  const int fq = (li >> 2) | ((fg & 1) << 2);
+  const int f_row = (8 * fg + (li >> 2)) * ROWBYTES + ((li & 3) >> 1) * 16 + (li & 1) * 8;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void_t*)smem;
+  uint32_t a_sl[4], b_sl[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) a_sl[i] = lds0 + f_row + (((wm * 4 + i) ^ fq) << 5);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) b_sl[j] = lds0 + f_row + (((wn * 2 + j) ^ fq) << 5);
+
+  // plain form, bias gradient: a_rowsum[m] += sum_k A[k][m], on the waves of the first column tile.  The A fragments are in
+  // registers: one more MFMA against an all-ones operand gives every lane the column sum of ITS m (lane & 15).  The four waves of a
+  // row (wn = 0..3) hold the same A fragments: wave wn takes MFMA row tile wn of either half (two accumulators, not eight)
+  const bool do_sum = !CONV && p.a_rowsum != nullptr && tn == 0;
+  f32x4 sacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  bf16x8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
+
+  bf16x8 af[4][2], b0f[2][2], b1f[2][2];
+  // 16 MFMAs: accumulator rows i0 .. i0 + 3 x columns j0, j0 + 1, both 32-pixel halves of the k-tile (operands swapped: a lane
+  // ends up with 4 consecutive columns of one row); the fragment reads are waited for BEFORE the barrier: their latency passes
+  // under the other group's MFMAs
+  auto mma = [&](int i0, int j0, const bf16x8 (&bf)[2][2], bool sum) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i0 + i][j0 + j] = mfma16(bf[j][kk], af[i][kk], acc[i0 + i][j0 + j]);
+    if constexpr (!CONV) {
+      if (sum && do_sum) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          const bf16x8 a = wn == 0 ? af[0][kk] : wn == 1 ? af[1][kk] : wn == 2 ? af[2][kk] : af[3][kk];
+          sacc[i0 >> 2] = mfma16(ones, a, sacc[i0 >> 2]);
+        }
+      }
+    }
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+#define W8_READ_A(HALF)                                                                        \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                              \
+    af[i][0] = tr_frag_asm<(HALF) * W8_HALF>(a_sl[i] + bufo);                                  \
+    af[i][1] = tr_frag_asm<(HALF) * W8_HALF + 32 * ROWBYTES>(a_sl[i] + bufo);                  \
+  }
+#define W8_READ_B(HALF, BF)                                                                    \
+  _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                              \
+    BF[j][0] = tr_frag_asm<(2 + (HALF)) * W8_HALF>(b_sl[j] + bufo);                            \
+    BF[j][1] = tr_frag_asm<(2 + (HALF)) * W8_HALF + 32 * ROWBYTES>(b_sl[j] + bufo);            \
+  }
+
+  // ---- prologue: k-tile 0 whole, Ah0 / Bh0 of k-tile 1 (12 pieces per wave); Ah0, Bh0 of k-tile 0 landed before the first read ----
+  issueA(0, 0, 0); issueB(0, 0, 0); issueB(0, 1, 0); issueA(0, 1, 0); issueA(1, 0, 1); issueB(1, 0, 1);
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (wm == 1) __builtin_amdgcn_s_barrier();         // the second wave group runs one barrier behind the first
+  asm volatile("" ::: "memory");
+
+  for (int t = 0; t < nkt; ++t) {
+    const int buf = t & 1;
+    const uint32_t bufo = buf * W8_BUF;
+    // phase 1: (A0, B0)
+    W8_READ_B(0, b0f)
+    W8_READ_A(0)
+    __builtin_amdgcn_sched_barrier(0);
+    issueB(t + 1, 1, buf ^ 1);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // Bh1 of this k-tile (phase 2) has landed: 4 half-tiles stay in flight
+    mma(0, 0, b0f, true);
+    // phase 2: (A0, B1)
+    W8_READ_B(1, b1f)
+    __builtin_amdgcn_sched_barrier(0);
+    issueA(t + 1, 1, buf ^ 1);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // Ah1 of this k-tile (phase 3)
+    mma(0, 2, b1f, false);
+    // phase 3: (A1, B1)
+    W8_READ_A(1)
+    __builtin_amdgcn_sched_barrier(0);
+    issueA(t + 2, 0, buf);                            // over Ah0 of this k-tile: last read two phases ago by either group
+    mma(4, 2, b1f, true);
+    // phase 4: (A1, B0)
+    issueB(t + 2, 0, buf);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // Ah0, Bh0 of the next k-tile (its phase 1)
+    mma(4, 0, b0f, false);
+  }
+#undef W8_READ_A
+#undef W8_READ_B
+  if (wm == 0) __builtin_amdgcn_s_barrier();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the trailing zero-fill pieces)
+
+  if constexpr (!CONV) {
+    if (do_sum && fg == 0) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) atomicAdd(p.a_rowsum + row0 + h * 128 + wm * 64 + wn * 16 + li, sacc[h][0]);
+    }
+  }
+
+  // ---------------- epilogue: straight from the accumulators (a lane holds 4 consecutive columns of row li of each MFMA tile) --------
+  const bool direct = p.ws == nullptr;
+  float* Cp = direct ? reinterpret_cast<float*>(p.C) : p.ws + (int64_t)ksplit * p.M * p.N;
+  const int64_t cpitch = direct ? p.ldc : p.N;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int m = row0 + (i >> 2) * 128 + wm * 64 + (i & 3) * 16 + li;
+    const float rs = p.rowscale ? p.rowscale[m] * p.alpha : p.alpha;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = col0 + (j >> 1) * 128 + wn * 32 + (j & 1) * 16 + fg * 4;
+      float4* dst = reinterpret_cast<float4*>(Cp + (int64_t)m * cpitch + n);
+      float4 v = make_float4(acc[i][j][0] * rs, acc[i][j][1] * rs, acc[i][j][2] * rs, acc[i][j][3] * rs);
+      if (direct) { const float4 c = *dst; v.x += c.x; v.y += c.y; v.z += c.z; v.w += c.w; }
+      *dst = v;
+    }
+  }
+}
+
 template <bool CONV>
 __device__ __forceinline__ void glds_tt_body(const GemmK& p) {
   // (tile, split) plane, split-major, contiguous range per XCD (see gemm.hip): an XCD runs all tiles of one reduction slice
@@ -330,6 +609,26 @@ __device__ __forceinline__ void wgrad_group_body(const WgGroupK& g) {
   glds_tt_core<true, ABL>(p, u - ksplit * q.tiles, ksplit);
 }
 __global__ __launch_bounds__(256) void glds_wgrad_group_kernel(WgGroupK g) { wgrad_group_body<0>(g); }
+// the problems whose Cout and Cin are multiples of 256 (layer3, layer4): the same units on 256 x 256 tiles, eight-phase core
+__global__ __launch_bounds__(512) void wg8_group_kernel(WgGroupK g) {
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+  const int v = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;     // contiguous unit range per XCD
+  int pi = 0;
+  while (pi + 1 < g.n && v >= g.prob[pi + 1].unit_start) ++pi;
+  const WgProb& q = g.prob[pi];
+  GemmK p{};
+  p.A = q.A; p.B = q.B; p.C = q.C; p.rowscale = q.rowscale;
+  p.M = q.M; p.N = q.N; p.K = q.K; p.lda = q.lda; p.ldb = 0; p.ldc = q.ldc;
+  p.alpha = 1.0f;
+  p.ws = q.direct ? nullptr : g.ws + q.ws_off;
+  p.tilesN = q.tilesN; p.kt_per_split = q.kt_per_split;
+  p.cg.IH = q.IH; p.cg.IW = q.IW; p.cg.Cs = q.Cs; p.cg.Cin = q.Cin; p.cg.OH = q.OH; p.cg.OW = q.OW;
+  p.cg.KH = q.KH; p.cg.KW = q.KW; p.cg.SH = q.SH; p.cg.SW = q.SW; p.cg.PH = q.PH; p.cg.PW = q.PW;
+  const int u = v - q.unit_start;
+  const int ksplit = u / q.tiles;
+  wg8_core<true>(p, u - ksplit * q.tiles, ksplit);
+}
 #ifdef GPV_TUNING        // timing-ablation instances (wrong results by construction): tuning build only, never in libgpv_hip.so
 __global__ __launch_bounds__(256) void glds_wgrad_group_abl1_kernel(WgGroupK g) { wgrad_group_body<1>(g); }
 __global__ __launch_bounds__(256) void glds_wgrad_group_abl2_kernel(WgGroupK g) { wgrad_group_body<2>(g); }
@@ -338,6 +637,45 @@ __global__ __launch_bounds__(256) void glds_wgrad_group_abl4_kernel(WgGroupK g) 
 __global__ __launch_bounds__(256) void glds_wgrad_group_abl5_kernel(WgGroupK g) { wgrad_group_body<5>(g); }
 __global__ __launch_bounds__(256) void glds_wgrad_group_abl6_kernel(WgGroupK g) { wgrad_group_body<6>(g); }
 #endif
+
+// ---- grouped launch, linear weight gradients on the eight-phase core (round 5) ------------------------------------------------------
+// gpv_gemm_tt_group's problems whose M and N are multiples of 256 (every nn.Linear of the DETR transformer, the co-attention layers
+// and the text decoder at the shipped widths 256 / 768 / 2048 / 3072).  Unlike the conv groups the reductions differ (9600 / 3392 /
+// 3200 / 640 / 192 rows) and a 256 x 256 output is ONE tile: long reductions are cut into slices of ~W8L_KT k-tiles (partial tiles
+// through the caller's workspace + the grouped reduce pass), and the work units -- (problem, slice, tile), between 3 and ~75 k-tiles
+// long -- are dealt to the 8 XCDs as whole (problem, slice) GROUPS, longest first to the least loaded XCD: the tiles of a group share
+// operand rows (one L2), and an XCD's units start in descending length, so the grid drains through its short units.  Block b runs on
+// XCD b % 8: XCD x owns units [x Q, x Q + cnt[x]) of the table, the surplus blocks of the shorter lists exit at once.
+constexpr int W8L_PMAX = GPV_TT_GROUP_MAX, W8L_GMAX = 200;
+struct W8LProb {                                    // 64 bytes: 48 of them + the group table fit the 4 KB kernel-argument segment
+  const void* A; const void* B; float* C; float* a_rowsum;
+  int MN, N, K, lda, ldb, ldc;
+  int kt_per_split;
+  int ws_off;                                       // floats into the workspace; < 0: the tile is added into C (no slices)
+};
+struct W8LGrp { unsigned short v_start; unsigned char prob, slice; };
+struct W8LGroupK { int n_prob, n_grp, Q, pad; int cnt[8]; float* ws; W8LProb prob[W8L_PMAX]; W8LGrp grp[W8L_GMAX]; };
+static_assert(sizeof(W8LProb) == 64 && sizeof(W8LGrp) == 4 && sizeof(W8LGroupK) <= 4096, "kernel argument segment");
+
+__global__ __launch_bounds__(512) void wg8_tt_group_kernel(W8LGroupK g) {
+  const int bid = blockIdx.x, xcd = bid & 7, loc = bid >> 3;
+  if (loc >= g.cnt[xcd]) return;
+  const int v = xcd * g.Q + loc;
+  int lo = 0, hi = g.n_grp - 1;                       // last group whose v_start <= v (uniform scalar search)
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if ((int)g.grp[mid].v_start <= v) lo = mid; else hi = mid - 1;
+  }
+  const W8LGrp gr = g.grp[lo];
+  const W8LProb& q = g.prob[gr.prob];
+  GemmK p{};
+  p.A = q.A; p.B = q.B; p.C = q.C; p.a_rowsum = q.a_rowsum;
+  p.M = q.MN / q.N; p.N = q.N; p.K = q.K; p.lda = q.lda; p.ldb = q.ldb; p.ldc = q.ldc;
+  p.alpha = 1.0f;
+  p.ws = q.ws_off < 0 ? nullptr : g.ws + q.ws_off;
+  p.tilesN = q.N / 256; p.kt_per_split = q.kt_per_split;
+  wg8_core<false>(p, v - gr.v_start, gr.slice);
+}
 
 struct WgRed { const float* ws; float* C; int64_t MN; int split, N, ldc, blk_start; };
 struct WgRedK { int n; int pad; WgRed r[WG_MAX]; };
@@ -399,6 +737,11 @@ inline bool al16t(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) 
 }  // namespace
 
 int g_wgrad_mode = tune_env("GPV_GLDS_WGRAD", 1);   // gpv_set_option(GPV_OPT_GLDS_WGRAD, .)
+int g_wg8_mode = tune_env("GPV_WG8", 1);            // gpv_set_option(GPV_OPT_WG8, .): eight-phase 256 x 256 weight-gradient kernel
+long g_wg8_launches = 0;
+int g_w8l_mode = tune_env("GPV_W8L", 0);            // gpv_set_option(GPV_OPT_W8L, .): the same kernel on the linear weight-gradient groups -- OFF by default: alone on the chip the step's 123
+                                                    // linear gradients take 810 instead of 885 us with it, inside the step nothing (16.63 / 16.60 ms off, 16.66 / 16.77 on, same box): its
+                                                    // 128 KB blocks take whole CUs from the backward chain they run beside
 
 // conv weight gradient (k as prepared by gpv_conv2d mode 2: A = dy [K][M], B = x NHWC, C = dw [M][N] fp32, split chosen).
 // returns 0 = launched (partial products + reduction), -1 = not applicable, > 0 = hipError_t
@@ -487,21 +830,55 @@ extern "C" int gpv_conv_wgrad_group(const gpv_conv_wgrad_problem* probs, int n, 
     if (e != hipSuccess) { (void)hipGetLastError(); return (int)e; }      // (leave no stale error behind for the next launch check)
     attr_done = true;
   }
-  WgGroupK g{};
+  // the eight-phase 256 x 256 kernel takes the problems whose Cout and Cin are multiples of 256 (one tap per column tile) -- when
+  // the call has enough of them to fill the chip: the two kernels run one after the other, and a handful of 256 x 256 units alone
+  // on 256 CUs (layer2's call: its down-sample projection only) costs more than it saves (695 -> 955 us measured)
+  static bool attr8_done = false;
+  if (!attr8_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wg8_group_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, W8_LDS);
+    if (e != hipSuccess) { (void)hipGetLastError(); return (int)e; }
+    attr8_done = true;
+  }
+  static const int target_kt8 = [] { const int v = tune_env("GPV_WG8_KT", 150); return v < 8 ? 8 : v; }();
+  auto eligible8 = [&](const gpv_conv_wgrad_problem& q) {
+    const int64_t K64 = (int64_t)q.B * q.OH * q.OW;
+    return q.Cout % 256 == 0 && q.Cin % 256 == 0 && q.Cs % 8 == 0 && al16t(q.dy) && al16t(q.x) && al16t(q.dw) &&
+           TBK / q.OW + 2 <= q.OH && (int64_t)q.IH * q.IW * q.Cs * q.B < (1ll << 30) && K64 * q.Cout < (1ll << 30) && K64 >= 8 * TBK;
+  };
+  bool use8 = g_wg8_mode != 0;
+  if (use8 && g_wg8_mode == 1) {
+    int64_t u8 = 0;
+    for (int i = 0; i < n; ++i) {
+      const gpv_conv_wgrad_problem& q = probs[i];
+      if (!eligible8(q)) continue;
+      const int64_t kt = ((int64_t)q.B * q.OH * q.OW + TBK - 1) / TBK;
+      u8 += (int64_t)(q.Cout / 256) * (q.KH * q.KW * q.Cin / 256) * ((kt + target_kt8 / 2) / target_kt8 > 0 ? (kt + target_kt8 / 2) / target_kt8 : 1);
+    }
+    use8 = u8 >= 128;
+  }
+  WgGroupK g{}, g8{};
   WgRedK rk{};
-  int units = 0, rblocks = 0;
+  int units = 0, units8 = 0, rblocks = 0;
   int64_t ws_used = 0;
   const int64_t ws_floats = workspace ? workspace_bytes / 4 : 0;
   auto flush = [&]() -> int {
-    if (g.n == 0) return 0;
-    g.ws = reinterpret_cast<float*>(workspace);
-    hipLaunchKernelGGL(fn, dim3(units), dim3(256), lds, st, g);
-    GPV_CHECK_LAUNCH();
+    if (g.n == 0 && g8.n == 0) return 0;
+    if (g8.n > 0) {
+      g8.ws = reinterpret_cast<float*>(workspace);
+      hipLaunchKernelGGL(wg8_group_kernel, dim3(units8), dim3(512), W8_LDS, st, g8);
+      GPV_CHECK_LAUNCH();
+      ++g_wg8_launches;
+    }
+    if (g.n > 0) {
+      g.ws = reinterpret_cast<float*>(workspace);
+      hipLaunchKernelGGL(fn, dim3(units), dim3(256), lds, st, g);
+      GPV_CHECK_LAUNCH();
+    }
     if (rk.n > 0) {
       hipLaunchKernelGGL(wgrad_group_reduce_kernel, dim3(rblocks), dim3(256), 0, st, rk);
       GPV_CHECK_LAUNCH();
     }
-    g.n = 0; rk.n = 0; units = 0; rblocks = 0; ws_used = 0;
+    g.n = 0; g8.n = 0; rk.n = 0; units = 0; units8 = 0; rblocks = 0; ws_used = 0;
     return 0;
   };
   for (int i = 0; i < n; ++i) {
@@ -524,26 +901,31 @@ extern "C" int gpv_conv_wgrad_group(const gpv_conv_wgrad_problem* probs, int n, 
       if (e) return e;
       continue;
     }
+    const bool big = use8 && eligible8(q);
+    const int tb = big ? 256 : TBM;
     const int K = (int)K64;
     const int kt_total = (K + TBK - 1) / TBK;
-    int split = (kt_total + target_kt / 2) / target_kt;
+    const int tkt = big ? target_kt8 : target_kt;
+    int split = (kt_total + tkt / 2) / tkt;
     if (split < 1) split = 1;
     const int64_t MN = (int64_t)M * N;
     while (split > 1 && (int64_t)split * MN > ws_floats) --split;
     const int kps = (kt_total + split - 1) / split;
     split = (kt_total + kps - 1) / kps;
-    if (g.n == WG_MAX || (split > 1 && ws_used + (int64_t)split * MN > ws_floats)) {
+    WgGroupK& gg = big ? g8 : g;
+    if (gg.n == WG_MAX || (split > 1 && (rk.n == WG_MAX || ws_used + (int64_t)split * MN > ws_floats))) {
       const int e = flush();
       if (e) return e;
     }
-    WgProb& d = g.prob[g.n];
+    int& uu = big ? units8 : units;
+    WgProb& d = gg.prob[gg.n];
     d.A = q.dy; d.B = q.x; d.C = q.dw; d.rowscale = q.rowscale;
     d.M = M; d.N = N; d.K = K; d.lda = M; d.ldc = N;
-    d.kt_per_split = kps; d.tilesN = N / TBN; d.tiles = (M / TBM) * (N / TBN);
-    d.unit_start = units; d.direct = split == 1 ? 1 : 0; d.ws_off = ws_used;
+    d.kt_per_split = kps; d.tilesN = N / tb; d.tiles = (M / tb) * (N / tb);
+    d.unit_start = uu; d.direct = split == 1 ? 1 : 0; d.ws_off = ws_used;
     d.IH = q.IH; d.IW = q.IW; d.Cs = q.Cs; d.Cin = q.Cin; d.OH = q.OH; d.OW = q.OW;
     d.KH = q.KH; d.KW = q.KW; d.SH = q.SH; d.SW = q.SW; d.PH = q.PH; d.PW = q.PW;
-    units += d.tiles * split;
+    uu += d.tiles * split;
     if (split > 1) {
       WgRed& r = rk.r[rk.n];
       r.ws = reinterpret_cast<const float*>(workspace) + ws_used; r.C = q.dw; r.MN = MN; r.split = split; r.N = N; r.ldc = N;
@@ -552,7 +934,127 @@ extern "C" int gpv_conv_wgrad_group(const gpv_conv_wgrad_problem* probs, int n, 
       ++rk.n;
       ws_used += (int64_t)split * MN;
     }
-    ++g.n;
+    ++gg.n;
   }
   return flush();
+}
+
+extern "C" int gpv_gemm_tt_group_ws(const gpv_tt_problem* problems, int n, void* workspace, int64_t workspace_bytes, void* stream) {
+  using namespace gpvk;
+  if (!problems || n <= 0) return (int)hipErrorInvalidValue;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  // k-tiles per work unit (16 / 24 / 32 / 48 / 64 / 100 -> 927 / 818 / 835 / 761 / 815 / 809 us for the step's 123 problems alone on the
+  // chip, tools/bench_tt_group.py; the 128 x 128 grouped launches: 880): these gradients move 128 flop per operand byte at best -- a
+  // 256 x 256 output is ONE tile that reads both operands once -- and a lone tile pulls its misses at ~10 B/clk (3 us per k-tile):
+  // shorter units balance the CUs, longer ones write fewer partial tiles
+  static const int target_kt = [] { const int v = tune_env("GPV_W8L_KT", 48); return v < 8 ? 8 : v; }();
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wg8_tt_group_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, W8_LDS);
+    if (e != hipSuccess) { (void)hipGetLastError(); return (int)e; }
+    attr_done = true;
+  }
+  const int64_t ws_floats = workspace ? workspace_bytes / 4 : 0;
+  // the problems the 256 x 256 kernel does not take keep the 128 x 128 grouped launch (after the big ones: they are the short ones)
+  gpv_tt_problem rest[GPV_TT_GROUP_MAX];
+  int n_rest = 0;
+  auto flush_rest = [&]() -> int {
+    if (n_rest == 0) return 0;
+    const int e = gpv_gemm_tt_group(rest, n_rest, stream);
+    n_rest = 0;
+    return e;
+  };
+  struct Grp { int prob, slice, tiles, kps; };
+  W8LGroupK g{};
+  WgRedK rk{};
+  Grp grp[W8L_GMAX];
+  int n_grp = 0, rblocks = 0;
+  int64_t ws_used = 0;
+  auto flush = [&]() -> int {
+    if (g.n_prob == 0) return 0;
+    // longest groups first, each to the XCD with the least work so far
+    for (int i = 1; i < n_grp; ++i) {                   // (insertion sort: <= 160 entries, mostly sorted already)
+      const Grp x = grp[i];
+      int j = i - 1;
+      while (j >= 0 && grp[j].kps < x.kps) { grp[j + 1] = grp[j]; --j; }
+      grp[j + 1] = x;
+    }
+    int64_t load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int bin_of[W8L_GMAX], cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < n_grp; ++i) {
+      int b = 0;
+      for (int x = 1; x < 8; ++x) if (load[x] < load[b]) b = x;
+      bin_of[i] = b;
+      load[b] += (int64_t)grp[i].tiles * grp[i].kps;
+      cnt[b] += grp[i].tiles;
+    }
+    int Q = 0;
+    for (int x = 0; x < 8; ++x) { g.cnt[x] = cnt[x]; if (cnt[x] > Q) Q = cnt[x]; }
+    if (8 * Q >= 65536) return (int)hipErrorInvalidValue;
+    g.Q = Q; g.n_grp = n_grp;
+    int k = 0;
+    for (int x = 0; x < 8; ++x) {
+      int off = 0;
+      for (int i = 0; i < n_grp; ++i) {
+        if (bin_of[i] != x) continue;
+        g.grp[k].v_start = (unsigned short)(x * Q + off); g.grp[k].prob = (unsigned char)grp[i].prob; g.grp[k].slice = (unsigned char)grp[i].slice;
+        off += grp[i].tiles;
+        ++k;
+      }
+    }
+    g.ws = reinterpret_cast<float*>(workspace);
+    hipLaunchKernelGGL(wg8_tt_group_kernel, dim3(8 * Q), dim3(512), W8_LDS, st, g);
+    GPV_CHECK_LAUNCH();
+    ++g_wg8_launches;
+    if (rk.n > 0) {
+      hipLaunchKernelGGL(wgrad_group_reduce_kernel, dim3(rblocks), dim3(256), 0, st, rk);
+      GPV_CHECK_LAUNCH();
+    }
+    g.n_prob = 0; n_grp = 0; rk.n = 0; rblocks = 0; ws_used = 0;
+    return 0;
+  };
+  for (int i = 0; i < n; ++i) {
+    const gpv_tt_problem& q = problems[i];
+    const bool big = g_w8l_mode != 0 && q.A && q.B && q.C && q.M > 0 && q.N > 0 && q.M % 256 == 0 && q.N % 256 == 0 && q.K >= 2 * TBK && (int64_t)q.M * q.N < (1ll << 30) &&
+                     q.lda % 8 == 0 && q.ldb % 8 == 0 && q.ldc % 4 == 0 && al16t(q.A) && al16t(q.B) && al16t(q.C) &&
+                     (int64_t)q.K * q.lda < (1ll << 30) && (int64_t)q.K * q.ldb < (1ll << 30);
+    if (!big) {
+      if (n_rest == GPV_TT_GROUP_MAX) { const int e = flush_rest(); if (e) return e; }
+      rest[n_rest++] = q;
+      continue;
+    }
+    const int kt_total = (q.K + TBK - 1) / TBK;
+    int split = (kt_total + target_kt / 2) / target_kt;
+    if (split < 1) split = 1;
+    const int64_t MN = (int64_t)q.M * q.N;
+    while (split > 1 && (int64_t)split * MN > ws_floats) --split;
+    const int kps = (kt_total + split - 1) / split;
+    split = (kt_total + kps - 1) / kps;
+    if (split > 255) return (int)hipErrorInvalidValue;
+    if (g.n_prob == W8L_PMAX || n_grp + split > W8L_GMAX || ws_used + (int64_t)split * MN >= (1ll << 31) || (split > 1 && (rk.n == WG_MAX || ws_used + (int64_t)split * MN > ws_floats))) {
+      const int e = flush();
+      if (e) return e;
+    }
+    W8LProb& d = g.prob[g.n_prob];
+    d.A = q.A; d.B = q.B; d.C = q.C; d.a_rowsum = q.a_rowsum;
+    d.MN = (int)MN; d.N = q.N; d.K = q.K; d.lda = q.lda; d.ldb = q.ldb; d.ldc = q.ldc;
+    d.kt_per_split = kps; d.ws_off = split == 1 ? -1 : (int)ws_used;
+    const int tiles = (q.M / 256) * (q.N / 256);
+    for (int sidx = 0; sidx < split; ++sidx) {
+      const int len = (sidx + 1) * kps <= kt_total ? kps : kt_total - sidx * kps;
+      grp[n_grp++] = Grp{g.n_prob, sidx, tiles, len};
+    }
+    if (split > 1) {
+      WgRed& r = rk.r[rk.n];
+      r.ws = reinterpret_cast<const float*>(workspace) + ws_used; r.C = q.C; r.MN = MN; r.split = split; r.N = q.N; r.ldc = q.ldc;
+      r.blk_start = rblocks;
+      rblocks += (int)((MN / 4 + 255) / 256);
+      ++rk.n;
+      ws_used += (int64_t)split * MN;
+    }
+    ++g.n_prob;
+  }
+  int e = flush();
+  if (e) return e;
+  return flush_rest();
 }

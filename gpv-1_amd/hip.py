@@ -109,7 +109,7 @@ EXPORTS = ['gpv_abi_version', 'gpv_build_id', 'gpv_set_option', 'gpv_gemm', 'gpv
            'gpv_softmax_ce', 'gpv_roi_weights', 'gpv_add', 'gpv_add_rowbcast', 'gpv_colsum', 'gpv_cast',
            'gpv_cast_rowscale_t', 'gpv_prep_conv_weight', 'gpv_embedding', 'gpv_dropout',
            'gpv_relevance_condition', 'gpv_adamw', 'gpv_sumsq', 'gpv_clip_scale', 'gpv_act_fwd', 'gpv_act_bwd', 'gpv_set_seed_device',
-           'gpv_gemm_tt_group', 'gpv_cast_transpose_group', 'gpv_stem_pool', 'gpv_image_pipeline', 'gpv_conv1x1_dual', 'gpv_conv1x1_chain',
+           'gpv_gemm_tt_group', 'gpv_gemm_tt_group_ws', 'gpv_cast_transpose_group', 'gpv_stem_pool', 'gpv_image_pipeline', 'gpv_conv1x1_dual', 'gpv_conv1x1_chain',
            'gpv_conv_wgrad_group', 'gpv_jpeg_parse', 'gpv_jpeg_decode', 'gpv_argmax_rows', 'gpv_ln_linear_rows', 'gpv_attention_row_proj',
            'gpv_layernorm_bwd_blocks', 'gpv_layernorm_bwd3', 'gpv_colsum_fold_group', 'gpv_argmax_rows_embed']
 
@@ -123,7 +123,7 @@ def build_id():
 
 OPT_GLDS, OPT_GLDS_LAUNCHES, OPT_SKINNY, OPT_GLDS_WGRAD, OPT_PIPE, OPT_PIPE_LAUNCHES, OPT_C1S, OPT_C3S, OPT_C3S_LAUNCHES = 0, 1, 2, 3, 4, 5, 6, 7, 8
 OPT_GEMV, OPT_GEMV_LAUNCHES = 9, 10
-OPT_ATTN_BWD1, OPT_ATTN_BWD1_LAUNCHES, OPT_C1S_LAUNCHES = 11, 12, 13
+OPT_ATTN_BWD1, OPT_ATTN_BWD1_LAUNCHES, OPT_C1S_LAUNCHES, OPT_WG8, OPT_WG8_LAUNCHES, OPT_W8L = 11, 12, 13, 14, 15, 16
 
 
 def set_option(option, value):
@@ -253,7 +253,8 @@ def gemm_tt_group(problems):
         a = arr[i]
         a.A, a.B, a.C, a.a_rowsum = dy.data_ptr(), x.data_ptr(), dw.data_ptr(), (bg.data_ptr() if bg is not None else None)
         a.M, a.N, a.K, a.lda, a.ldb, a.ldc = M, N, K, lda, ldb, ldc
-    _chk(lib().gpv_gemm_tt_group(arr, C.c_int(len(problems)), _stream()), 'gpv_gemm_tt_group')
+    ws = _workspace(problems[0][0].device, WS_MAX)
+    _chk(lib().gpv_gemm_tt_group_ws(arr, C.c_int(len(problems)), _p(ws), C.c_int64(ws.numel()), _stream()), 'gpv_gemm_tt_group_ws')
 
 
 def conv2d(mode, x, w, y, B, IH, IW, Cs, Cin, OH, OW, Cout, KH, KW, SH, SW, PH, PW, rowscale=None, bias=None,

@@ -56,6 +56,11 @@ typedef struct {
   int lda, ldb, ldc;
 } gpv_tt_problem;
 int gpv_gemm_tt_group(const gpv_tt_problem* problems, int n, void* stream);
+/* The same products with a caller-lent workspace (fp32 partial tiles of the reductions the library slices; workspace may be NULL:
+ * no slicing): the problems whose M and N are multiples of 256 run on 256 x 256 tiles with the eight-phase schedule
+ * (gemm_glds_tt.hip wg8_*), long reductions cut into slices so that every (problem, slice, tile) unit walks <= ~64 k-tiles of 64
+ * rows and the units of all problems fill the chip together; the rest goes through gpv_gemm_tt_group.  Same reference call sites. */
+int gpv_gemm_tt_group_ws(const gpv_tt_problem* problems, int n, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* Kernel-selection knob (process-wide; tests and tuning only; never changes results beyond fp32 summation order).
  *   option GPV_OPT_GLDS: 0 = 4-wave register-staged GEMM/conv kernel only, 1 (default) = use the direct-to-LDS
@@ -74,6 +79,9 @@ int gpv_gemm_tt_group(const gpv_tt_problem* problems, int n, void* stream);
 #define GPV_OPT_PIPE_LAUNCHES 5 /* returns the number of pipelined-kernel launches so far, then sets the counter to value */
 #define GPV_OPT_ATTN_BWD1 11 /* single-launch attention backward (bf16; attention.hip attn_bwd1_kernel): 0 never, 1 (default) when B * H >= 128, 2 wherever legal */
 #define GPV_OPT_ATTN_BWD1_LAUNCHES 12 /* returns the number of single-launch attention backwards so far, then sets the counter to value (value >= 0) */
+#define GPV_OPT_WG8 14 /* eight-phase 256 x 256 weight-gradient kernel (gemm_glds_tt.hip wg8_*) in gpv_conv_wgrad_group, problems with Cout, Cin multiples of 256: 0 never, 1 (default) when the call holds >= 128 such work units, 2 wherever legal */
+#define GPV_OPT_WG8_LAUNCHES 15 /* returns the number of eight-phase weight-gradient launches (conv and linear) so far, then sets the counter to value */
+#define GPV_OPT_W8L 16 /* the same kernel in gpv_gemm_tt_group_ws (problems with M, N multiples of 256): 0 (default) never, 1 wherever legal */
 #define GPV_OPT_C1S_LAUNCHES 13 /* returns the number of streaming-1x1 launches so far (convolutions and the K = 256 linear GEMMs), then sets the counter to value */
 int gpv_set_option(int option, int value);
 

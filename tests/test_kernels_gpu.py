@@ -477,6 +477,50 @@ def test_conv_wgrad_group_equals_single_launches():
         assert rel(q[2], ref) < 1e-5, (c, rel(q[2], ref))
 
 
+def test_conv_wgrad_group_eight_phase_kernel():
+    """the eight-phase 256 x 256 weight-gradient kernel (gemm_glds_tt.hip wg8_*; Cout and Cin multiples of 256) against the 128 x 128
+    grouped kernel on the same problems (same bf16 products, fp32 sums in another order) and against fp32 autograd: no split
+    (tiles add themselves into dw), sliced reductions, a ragged last k-tile, a unit of ONE k-tile (pipeline shorter than its
+    look-ahead), stride 2 with 3x3 borders, 1x1 stride 2, several row and column tiles, short image rows"""
+    h, dtype = hip(), torch.bfloat16
+    cases = [(512, 512, 3, 1, 1, 15, 20, 4),       # 2 x 18 tiles, K = 1200 pixels: 19 k-tiles (ragged), no split
+             (256, 256, 3, 1, 1, 30, 40, 32),      # 1 x 9 tiles, 600 k-tiles -> 4 slices
+             (256, 256, 3, 2, 1, 60, 80, 8),       # stride 2
+             (256, 512, 1, 1, 0, 15, 20, 5),       # 1x1, K = 1500: ragged last k-tile
+             (1024, 256, 1, 1, 0, 30, 40, 16),     # 1 x 4 tiles, sliced
+             (512, 1024, 1, 2, 0, 30, 40, 8),      # the stride-2 projection
+             (256, 256, 3, 1, 1, 8, 24, 3),        # short rows, 9 k-tiles
+             (256, 256, 1, 1, 0, 16, 32, 1)]       # 8 k-tiles: the shortest reduction the grouped call accepts
+    probs = {0: [], 1: []}
+    refs = []
+    for i, (Cin, Cout, k, s, p, H, W, Bn) in enumerate(cases):
+        x = nhwc(rnd(Bn, Cin, H, W, dtype=dtype, seed=160 + i))
+        OH, OW = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+        dy = nhwc(rnd(Bn, Cout, OH, OW, dtype=dtype, seed=180 + i))
+        scale = rnd(Cout, seed=190 + i).abs() + 0.5
+        for mode in (0, 1):
+            dw = torch.full((Cout, k, k, Cin), 0.25, device=DEV)
+            probs[mode].append((x, dy, dw, scale, Bn, H, W, Cin, Cin, OH, OW, Cout, k, k, s, s, p, p))
+        if i in (0, 3, 6):
+            wf = torch.zeros(Cout, Cin, k, k, device=DEV, requires_grad=True)
+            xf = x.float().permute(0, 3, 1, 2)
+            gw, = torch.autograd.grad(F.conv2d(xf, wf, stride=s, padding=p), wf, dy.float().permute(0, 3, 1, 2))
+            refs.append((i, (gw * scale.view(-1, 1, 1, 1)).permute(0, 2, 3, 1) + 0.25))
+    prev = h.set_option(h.OPT_WG8, 0)
+    h.conv_wgrad_group(probs[0])
+    h.set_option(h.OPT_WG8, 2)                          # (1 = only when the call has enough 256 x 256 units to fill the chip)
+    n0 = h.set_option(h.OPT_WG8_LAUNCHES, 0)
+    h.conv_wgrad_group(probs[1])
+    used = h.set_option(h.OPT_WG8_LAUNCHES, n0)
+    h.set_option(h.OPT_WG8, prev)
+    torch.cuda.synchronize()
+    assert used >= 1, used
+    for a, b, c in zip(probs[1], probs[0], cases):
+        assert rel(a[2], b[2]) < 1e-5, (c, rel(a[2], b[2]))
+    for i, ref in refs:
+        assert rel(probs[1][i][2], ref) < 3e-3, (cases[i], rel(probs[1][i][2], ref))
+
+
 @pytest.mark.parametrize('Cin,Cout,k,H,W,Bn', [
     (64, 256, 3, 50, 80, 8),        # 32000 rows x 256: 200 x 2 tiles of 160 x 128 (two per CU), K = 576
     (64, 512, 3, 30, 40, 8),        # 9600 rows x 512: 100 x 4 tiles of 96 x 128
@@ -1214,6 +1258,46 @@ def test_grouped_weight_gradient_gemm():
         if bg is not None:
             assert rel(bg, rb) < 3e-3
     assert not h.tt_group_ok(probs[0][0], probs[0][1], probs[0][2], 100, 768, 192, 768, 768, 768)      # M not a multiple of 128
+
+
+def test_grouped_weight_gradient_gemm_eight_phase():
+    """gpv_gemm_tt_group_ws: the problems with M, N multiples of 256 on the eight-phase 256 x 256 kernel -- sliced reductions (partial
+    tiles through the workspace + the grouped reduce pass), whole reductions added in place, a ragged last k-tile, a 3-k-tile unit,
+    bias gradients from several slices, gradients that are row slices of a larger buffer, more problems than one launch holds --
+    against fp32 math and against the 128 x 128 grouped kernel on the same operands"""
+    h = hip()
+    shapes = [(9600, 256, 256), (9600, 256, 2048), (9600, 2048, 256), (9600, 512, 256), (3200, 768, 768), (3392, 1536, 768), (3200, 768, 3072),
+              (640, 768, 768), (192, 768, 768), (1000, 256, 256), (130, 256, 512), (3200, 256, 256), (3200, 256, 256), (3200, 256, 256)]
+    out = {}
+    for mode in (0, 1):
+        probs, refs = [], []
+        for rep in range(3):                                  # 42 problems: two eight-phase launches
+            for i, (K, M, N) in enumerate(shapes):
+                dy = rnd(K, M, dtype=torch.bfloat16, seed=2100 + 20 * rep + i)
+                x = rnd(K, N, dtype=torch.bfloat16, seed=2500 + 20 * rep + i)
+                big = rnd(M + 128, N, seed=2900 + 20 * rep + i)
+                dw = big[64:64 + M]
+                bg = rnd(M, seed=3300 + 20 * rep + i) if i % 2 == 0 else None
+                if mode == 1 and rep == 0:
+                    refs.append((dw.clone() + dy.float().t() @ x.float(), None if bg is None else bg.clone() + dy.float().sum(0)))
+                probs.append((dy, x, dw, bg, M, N, K, M, N, N))
+        prev = h.set_option(h.OPT_W8L, mode)
+        n0 = h.set_option(h.OPT_WG8_LAUNCHES, 0)
+        h.gemm_tt_group(probs)
+        used = h.set_option(h.OPT_WG8_LAUNCHES, n0)
+        h.set_option(h.OPT_W8L, prev)
+        torch.cuda.synchronize()
+        assert (used >= 2) if mode else (used == 0), (mode, used)
+        out[mode] = probs
+        if mode == 1:
+            for (dy, x, dw, bg, M, N, K, *_), (rw, rb) in zip(probs, refs):
+                assert rel(dw, rw) < 3e-3, (M, N, K, rel(dw, rw))
+                if bg is not None:
+                    assert rel(bg, rb) < 3e-3, (M, N, K)
+    for a, b in zip(out[1], out[0]):
+        assert rel(a[2], b[2]) < 1e-5, (a[4:7], rel(a[2], b[2]))
+        if a[3] is not None:
+            assert rel(a[3], b[3]) < 1e-5, a[4:7]
 
 
 def test_cast_transpose_group_and_mirrored_dx_gemm():

@@ -18,6 +18,8 @@ for (N, K, M, calls) in SHAPES:
         if hip.tt_group_ok(dy, x, dw, N, K, M, N, K, K):
             probs.append((dy, x, dw, db, N, K, M, N, K, K)); flops += 2.0 * N * K * M
 print('%d problems, %.0f GFLOP' % (len(probs), flops / 1e9))
+if os.environ.get('WG8') is not None:
+    hip.set_option(hip.OPT_W8L, int(os.environ['WG8']))
 t = timeit(lambda: hip.gemm_tt_group(probs), n=10)
 print('all in gpv_gemm_tt_group launches of <= 48: %.0f us = %.0f TFLOP/s' % (t, flops / t / 1e6))
 for name, sel in (('reduction 9600 only', lambda q: q[6] == 9600), ('reduction <= 3392 only', lambda q: q[6] <= 3392)):

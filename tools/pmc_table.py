@@ -10,5 +10,5 @@ for r in rows:
 names = sorted({c for v in agg.values() for c in v})
 print('kernel | grid | ' + ' | '.join(names))
 for k, v in agg.items():
-    if not any(t in k[0] for t in ('gemm_kernel', 'glds_', 'skinny', 'pipe_', 'attn_', 'c3r_', 'c3s_', 'c1s_', 'c1c_', 'c1d_', 'stem_', 'wgrad')): continue
+    if not any(t in k[0] for t in ('gemm_kernel', 'glds_', 'skinny', 'pipe_', 'attn_', 'c3r_', 'c3s_', 'c1s_', 'c1c_', 'c1d_', 'stem_', 'wgrad', 'wg8', 'tt8')): continue
     print(k[0][-40:], '|', k[1], '| ' + ' | '.join('%.4g' % (sum(v[c]) / len(v[c])) if c in v else '-' for c in names))
