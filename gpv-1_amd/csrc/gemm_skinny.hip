@@ -33,22 +33,33 @@ __device__ __forceinline__ bf16x8 tr_frag(const bf16* tile, int cbase, int lane)
   return __builtin_bit_cast(bf16x8, r);
 }
 
-template <typename TOut, bool BT>
+// PF = k-steps of global loads in flight per thread (register ring), BM x BN = output tile (64 | 32 each; reduction-major B: BN = 64).
+// Round 5, measured (tools/bench_skinny_pf.py): a k-step of the 64 x 64 tile costs 0.75 - 0.85 us WHATEVER the prefetch depth
+// (300 x 256 x 2048: 16.2 / 14.3 / 15.2 / 13.7 us at PF = 1 / 2 / 3 / 4) -- the 32 KB a step pulls through ONE CU arrive at
+// ~ 18 B / clk, the per-CU operand delivery rate every GEMM in this tree meets; the loop was never latency-bound.  What shortens it
+// is fewer bytes per CU: with 20 - 120 tiles of 64 x 64 on 256 CUs, 32-row / 32-column tiles put 2 - 4 x as many CUs on the problem and
+// each pulls (BM + BN) / 128 of the bytes (the extra L2 reads are free here).  PF = 2 is kept: the loop is branch-free -- the
+// step count is rounded up to a multiple of PF and steps beyond the reduction fetch through out-of-range offsets (hardware zeros, no
+// memory traffic) -- so that hipcc's counted vmcnt keeps PF - 1 steps in flight across every barrier.
+template <typename TOut, bool BT, int PF, int BM, int BN>
 __global__ __launch_bounds__(256) void skinny_kernel(GemmK p) {
+  static_assert(!BT || BN == 64, "reduction-major B tiles are [128][64]");
   if (p.dthresh) p.seed = eff_seed(p.seed, p.seed_dev);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   bf16* lds = reinterpret_cast<bf16*>(smem);
-  constexpr int TILE = SBM * SPITCH;                  // elements of a K-major operand tile
-  constexpr int BTILE = BT ? SBK * TPITCH : TILE;      // reduction-major B tile is [128][80]
-  constexpr int STAGE = TILE + BTILE;
+  constexpr int FM = BM / 16, FN = BN / 16;           // MFMA tiles per wave (every wave multiplies the WHOLE tile over its k-quarter)
+  constexpr int ATILE = BM * SPITCH;                  // elements of a K-major operand tile
+  constexpr int BTILE = BT ? SBK * TPITCH : BN * SPITCH;      // reduction-major B tile is [128][80]
+  constexpr int STAGE = ATILE + BTILE;
+  constexpr int NB = BT ? 4 : FN;                     // loads per thread and step for B
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tn = blockIdx.x % p.tilesN, tm = blockIdx.x / p.tilesN;
-  const int row0 = tm * SBM, col0 = tn * SBN;
+  const int row0 = tm * BM, col0 = tn * BN;
   const bf16* A = reinterpret_cast<const bf16*>(p.A);
   const bf16* B = reinterpret_cast<const bf16*>(p.B);
   const int nk = (p.K + SBK - 1) / SBK;
 
-  // loader: 64 rows x 16 chunks of 16 B per operand = 1024 chunks -> 4 per thread (same chunk column, rows +16)
+  // loader: rows x 16 chunks of 16 B per operand -> BM / 16 (BN / 16) per thread (same chunk column, rows +16)
   const int lc = tid & 15, lr = tid >> 4;
   // operands through buffer loads: per-thread 32-bit byte offsets fixed for the tile, the k-step offset in the scalar soffset,
   // an out-of-range offset (reduction tail, columns beyond N) = hardware zeros -- no 64-bit address add, no safe-address
@@ -57,95 +68,107 @@ __global__ __launch_bounds__(256) void skinny_kernel(GemmK p) {
   constexpr int OOB = 0x7ffffff0;
   const auto rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(A), (short)0, OOB, 0x00020000);
   const auto rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(B), (short)0, OOB, 0x00020000);
-  int avo[4], bvo[4];
+  int avo[FM], bvo[NB];
   // reduction-major B (BT): tile rows are reduction indices, a row is 64 output columns = 8 chunks -> thread (row tr + 32 i, chunk tc)
   const int tc = tid & 7, tr = tid >> 3;
   const bool bcol_ok = col0 + tc * 8 < p.N;            // N % 8 == 0 (host)
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    avo[i] = (min(row0 + lr + 16 * i, p.M - 1) * (int)p.lda + lc * 8) * 2;
+  for (int i = 0; i < FM; ++i) avo[i] = (min(row0 + lr + 16 * i, p.M - 1) * (int)p.lda + lc * 8) * 2;
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
     if constexpr (BT) bvo[i] = bcol_ok ? ((tr + 32 * i) * (int)p.ldb + col0 + tc * 8) * 2 : OOB;
     else bvo[i] = (min(col0 + lr + 16 * i, p.N - 1) * (int)p.ldb + lc * 8) * 2;
   }
-  uint4 ra[4], rb[4];
+  uint4 ra[PF][FM], rb[PF][NB];
   auto bl = [&](const decltype(rsA)& rs, int vo, int so) {
     const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, so, 0);
     return make_uint4(t[0], t[1], t[2], t[3]);
   };
-  auto load = [&](int kt) {
-    const bool full = (kt + 1) * SBK <= p.K;           // uniform
-    const bool ok = full || kt * SBK + lc * 8 < p.K;   // K % 8 == 0 (host): a chunk is entirely inside or outside
+  auto load = [&](int kt, uint4 (&qa)[FM], uint4 (&qb)[NB]) {
+    const bool in = kt < nk;                           // uniform; beyond the reduction: zeros through the descriptor
+    const bool full = in && (kt + 1) * SBK <= p.K;
+    const bool ok = full || (in && kt * SBK + lc * 8 < p.K);   // K % 8 == 0 (host): a chunk is entirely inside or outside
+    const int so = in ? kt * SBK * 2 : 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      ra[i] = bl(rsA, ok ? avo[i] : OOB, kt * SBK * 2);
-      if constexpr (BT) rb[i] = bl(rsB, (full || kt * SBK + tr + 32 * i < p.K) ? bvo[i] : OOB, kt * SBK * (int)p.ldb * 2);
-      else rb[i] = bl(rsB, ok ? bvo[i] : OOB, kt * SBK * 2);
+    for (int i = 0; i < FM; ++i) qa[i] = bl(rsA, ok ? avo[i] : OOB, so);
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      if constexpr (BT) qb[i] = bl(rsB, (full || (in && kt * SBK + tr + 32 * i < p.K)) ? bvo[i] : OOB, so * (int)p.ldb);
+      else qb[i] = bl(rsB, ok ? bvo[i] : OOB, so);
     }
   };
-  auto store = [&](int stage) {
+  auto store = [&](int stage, const uint4 (&qa)[FM], const uint4 (&qb)[NB]) {
     bf16* sa = lds + stage * STAGE;
-    bf16* sb = sa + TILE;
+    bf16* sb = sa + ATILE;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      *reinterpret_cast<uint4*>(sa + (lr + 16 * i) * SPITCH + lc * 8) = ra[i];
-      if constexpr (BT) *reinterpret_cast<uint4*>(sb + (tr + 32 * i) * TPITCH + tc * 8) = rb[i];
-      else *reinterpret_cast<uint4*>(sb + (lr + 16 * i) * SPITCH + lc * 8) = rb[i];
+    for (int i = 0; i < FM; ++i) *reinterpret_cast<uint4*>(sa + (lr + 16 * i) * SPITCH + lc * 8) = qa[i];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      if constexpr (BT) *reinterpret_cast<uint4*>(sb + (tr + 32 * i) * TPITCH + tc * 8) = qb[i];
+      else *reinterpret_cast<uint4*>(sb + (lr + 16 * i) * SPITCH + lc * 8) = qb[i];
     }
   };
 
-  f32x4 acc[4][4];
+  f32x4 acc[FM][FN];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < FM; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int foff = (lane & 15) * SPITCH + wave * 32 + (lane >> 4) * 8;      // this wave's quarter of the k-step
 
-  load(0);
-  store(0);
+#pragma unroll
+  for (int s = 0; s < PF; ++s) load(s, ra[s], rb[s]);
+  store(0, ra[0], rb[0]);
   __syncthreads();
-  for (int t = 0; t < nk; ++t) {
-    if (t + 1 < nk) load(t + 1);                       // in flight while tile t is multiplied
-    const bf16* sa = lds + (t & 1) * STAGE;
-    const bf16* sb = sa + TILE;
-    bf16x8 af[4], bfr[4];
+  const int nkp = (nk + PF - 1) / PF * PF;
+  for (int t0 = 0; t0 < nkp; t0 += PF) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      af[i] = *reinterpret_cast<const bf16x8*>(sa + i * 16 * SPITCH + foff);
-      if constexpr (BT) bfr[i] = tr_frag(sb + wave * 32 * TPITCH, i * 16, lane);
-      else bfr[i] = *reinterpret_cast<const bf16x8*>(sb + i * 16 * SPITCH + foff);
+    for (int s = 0; s < PF; ++s) {
+      const int t = t0 + s;
+      load(t + PF, ra[s], rb[s]);                      // slot s held tile t: in LDS since the previous step
+      const bf16* sa = lds + (t & 1) * STAGE;
+      const bf16* sb = sa + ATILE;
+      bf16x8 af[FM], bfr[FN];
+#pragma unroll
+      for (int i = 0; i < FM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sa + i * 16 * SPITCH + foff);
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        if constexpr (BT) bfr[j] = tr_frag(sb + wave * 32 * TPITCH, j * 16, lane);
+        else bfr[j] = *reinterpret_cast<const bf16x8*>(sb + j * 16 * SPITCH + foff);
+      }
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = mfma16(bfr[j], af[i], acc[i][j]);    // swapped: lane holds 4 consecutive columns
+      store((t + 1) & 1, ra[(s + 1) % PF], rb[(s + 1) % PF]);                           // tile t + 1 (PF - 1 younger steps stay in flight)
+      __syncthreads();
     }
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(bfr[j], af[i], acc[i][j]);    // swapped: lane holds 4 consecutive columns
-    if (t + 1 < nk) store((t + 1) & 1);
-    __syncthreads();
   }
 
   // ---- sum the four waves' partial tiles through LDS (fragment-native order: every access is lane-contiguous) ----
   float* red = reinterpret_cast<float*>(smem);
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < FM; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-      *reinterpret_cast<f32x4*>(red + wave * (SBM * SBN) + (i * 4 + j) * 256 + lane * 4) = acc[i][j];
+    for (int j = 0; j < FN; ++j)
+      *reinterpret_cast<f32x4*>(red + wave * (BM * BN) + (i * FN + j) * 256 + lane * 4) = acc[i][j];
   __syncthreads();
 
   TOut* Cp = reinterpret_cast<TOut*>(p.C);
   const TOut* Rp = reinterpret_cast<const TOut*>(p.res);
   const TOut* Mp = reinterpret_cast<const TOut*>(p.mask);
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
+  for (int r = 0; r < (FM * FN) / 4; ++r) {
     const int q = tid + 256 * r;
     const int ij = q >> 6, l = q & 63;
     f32x4 v = *reinterpret_cast<const f32x4*>(red + ij * 256 + l * 4);
 #pragma unroll
     for (int w = 1; w < 4; ++w) {
-      const f32x4 u = *reinterpret_cast<const f32x4*>(red + w * (SBM * SBN) + ij * 256 + l * 4);
+      const f32x4 u = *reinterpret_cast<const f32x4*>(red + w * (BM * BN) + ij * 256 + l * 4);
       v[0] += u[0]; v[1] += u[1]; v[2] += u[2]; v[3] += u[3];
     }
-    const int m = row0 + (ij >> 2) * 16 + (l & 15);
-    const int n = col0 + (ij & 3) * 16 + (l >> 4) * 4;
+    const int m = row0 + (ij / FN) * 16 + (l & 15);
+    const int n = col0 + (ij % FN) * 16 + (l >> 4) * 4;
     if (m >= p.M || n >= p.N) continue;
     const float rs = p.rowscale ? p.rowscale[m] * p.alpha : p.alpha;
     // the 4 columns' bias / residual / mask as one vector load each when they are whole and aligned (per-element global
@@ -211,24 +234,48 @@ __global__ __launch_bounds__(256) void skinny_kernel(GemmK p) {
   }
 }
 
-template <typename TOut, bool BT>
-int launch_skinny(const GemmK& k, hipStream_t st) {
-  constexpr size_t stage = (size_t)2 * (SBM * SPITCH + (BT ? SBK * TPITCH : SBM * SPITCH)) * 2;      // two stages x (A, B) tiles
-  constexpr size_t redb = (size_t)4 * SBM * SBN * 4;
+int g_skinny_tile = tune_env("GPV_SKINNY_TILE", 0);     // tuning build: 0 = by cost, 1 = 64 x 64, 2 = 32 x 64, 3 = 32 x 32
+
+template <typename TOut, bool BT, int BM, int BN>
+int launch_skinny_tile(const GemmK& k, hipStream_t st) {
+  constexpr size_t stage = (size_t)2 * (BM * SPITCH + (BT ? SBK * TPITCH : BN * SPITCH)) * 2;      // two stages x (A, B) tiles
+  constexpr size_t redb = (size_t)4 * BM * BN * 4;
   constexpr size_t lds = stage > redb ? stage : redb;
   GemmK p = k;
-  p.tilesN = (p.N + SBN - 1) / SBN;
-  const int tilesM = (p.M + SBM - 1) / SBM;
-  auto fn = skinny_kernel<TOut, BT>;
+  p.tilesN = (p.N + BN - 1) / BN;
+  const int tilesM = (p.M + BM - 1) / BM;
+  const int nk = (p.K + SBK - 1) / SBK;
+  auto fn = nk >= 2 ? skinny_kernel<TOut, BT, 2, BM, BN> : skinny_kernel<TOut, BT, 1, BM, BN>;
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) { (void)hipGetLastError(); return (int)e; }      // (leave no stale error behind for the next launch check)
+    for (auto f : {skinny_kernel<TOut, BT, 1, BM, BN>, skinny_kernel<TOut, BT, 2, BM, BN>}) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) { (void)hipGetLastError(); return (int)e; }      // (leave no stale error behind for the next launch check)
+    }
     attr_done = true;
   }
   hipLaunchKernelGGL(fn, dim3(tilesM * p.tilesN), dim3(256), lds, st, p);
   GPV_CHECK_LAUNCH();
   return 0;
+}
+
+// Tile by measurement (tools/bench_skinny_pf.py, tools/ab_skinny_pf.sh; us at 64 x 64 | 32 x 64 | 32 x 32):
+//   300 x 256 x 2048 (20 tiles of 64 x 64) 14.2 | 10.4 | 7.8     100 x 768 x 3072 (24) 18.3 | 13.3 | 9.9     192 x 768 x 3072 (36) 18.3 | 13.2 | 11.3
+//   640 x 768 x 768 (120) 8.6 | 9.5 | 8.4     640 x 768 x 2048 (120) 15.3 | 15.6 | 15.3 (126 MB through L2 at 32 x 32: the L2s bound it)
+//   640 x 2304 x 768 (360) 12.5 | 11.0 | 12.3     640 x 2048 x 768 (320) 12.0 | 10.6 | 10.8     192 x 3072 x 768 (144) 8.4 | 9.1 | 8.4
+//   reduction-major B: 640 x 768 x 2048 16.8 | 12.6     640 x 768 x 2304 18.1 | 13.6     3200 x 256 x 2048 (200) 20.1 | 16.3
+// i.e. up to ~ 160 tiles of 64 x 64 the smallest tile (4 x as many CUs, half the bytes each), above that 32 x 64 (two co-resident blocks
+// per CU); batch-1 inference 4.88 -> 4.5 - 4.7 ms, train step -0.2 ms (same box, alternating twice).
+template <typename TOut, bool BT>
+int launch_skinny(const GemmK& k, hipStream_t st) {
+  int pick = g_skinny_tile;
+  if (pick == 0) {
+    const int64_t t64 = (int64_t)((k.M + 63) / 64) * ((k.N + 63) / 64);
+    pick = (!BT && t64 <= 160) ? 3 : 2;
+  }
+  if (pick == 2) return launch_skinny_tile<TOut, BT, 32, 64>(k, st);
+  if constexpr (!BT) { if (pick == 3) return launch_skinny_tile<TOut, BT, 32, 32>(k, st); }
+  return launch_skinny_tile<TOut, BT, 64, 64>(k, st);
 }
 
 // ---- weight-gradient form: C[M,N] (+)= A^T B with A [K][M], B [K][N] both reduction-major (dW = dY^T X) -------------

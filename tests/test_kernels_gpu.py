@@ -739,7 +739,7 @@ def skinny():
 
 
 @pytest.mark.parametrize('M,N,K', [(192, 768, 768), (192, 768, 3072), (640, 2304, 768), (70, 130, 200), (1, 768, 768), (640, 768, 10000),
-                                   (65, 64, 128), (300, 100, 8)])
+                                   (65, 64, 128), (300, 100, 8), (300, 256, 2048), (100, 768, 3072), (640, 768, 768), (33, 40, 136)])      # (tiles of 64 x 64 | 32 x 64 | 32 x 32 by cost)
 def test_skinny_gemm(skinny, M, N, K):
     h, dtype = skinny, torch.bfloat16
     A, B = rnd(M, K, dtype=dtype, seed=1), rnd(N, K, dtype=dtype, seed=2)
