@@ -563,6 +563,241 @@ __global__ __launch_bounds__(QTHR) void attn_q_kernel(AttnK p) {
   }
 }
 
+// ================================================================================================================================
+// Round 5: self-attention with the q | k | v PROJECTIONS inside the launch (ref: exp/gpv/models/transformer.py:148-155 -- q = k =
+// src + pos, value = src, nn.MultiheadAttention's in_proj; transformer.py:216-219 for the decoder's self-attention).
+//
+//   q = xp Wq^T + bq, k = xp Wk^T + bk, v = x Wv^T + bv      (xp = x + pos: the second output of the LayerNorm that produced x)
+//   o = softmax(q k^T scale + key bias) v                      per (batch, head), dh = 32, model width 256, bf16
+//
+// The three launches it replaces (q | k GEMM 9600 x 512 x 256: 12.5 us, v GEMM 9600 x 256 x 256: 9.8 us, core 17 us inside the step's
+// graph) are latency-shaped: 1.9 GFLOP of projections under 22 us of launch ramps and a 15 MB round trip through HBM.  Here the
+// workgroup of one (batch, head) first multiplies its rows by ITS 96 rows of in_proj_weight (staged in LDS once, 50 KB):
+//   * Q^T / K^T tiles = mfma(A = W rows (d), B = xp rows (token)): a lane ends up with d = 4 g + i and 16 + 4 g + i of ONE token -- packed,
+//     that IS the lane's operand fragment of S^T = K Q^T in the k-slot order {4 g + i} U {16 + 4 g + i} (any order works as long as both
+//     operands use it): Q never leaves the registers of the wave that owns the query tile, K goes to LDS as one 16-byte store;
+//   * V tiles = mfma(A = x rows (token), B = W rows (d)): a lane holds 4 consecutive tokens of one d = 8 bytes of the V^T image;
+//   * q, k, v are also written to HBM in the layout of the projection GEMMs' outputs (the backward -- attn_bwd1_kernel, the
+//     backward-data and weight-gradient GEMMs -- is unchanged and needs them);
+// then the core of attn_q_kernel runs on the staged K / V^T (same softmax, same dropout words, same lse).
+// MFMA work per launch: 6.7 GFLOP (projections 3.8 + core 2.9) instead of the core's 2.9 on the same VALU work.
+struct QkvK { const bf16* xp; const bf16* x; int64_t x_bs, x_rs; const bf16* w; const float* bias; };
+
+template <int NT, bool FULL>
+__global__ __launch_bounds__(QTHR) void attn_qkv_kernel(AttnK p, QkvK xk) {
+  if (p.dthresh) p.seed = eff_seed(p.seed, p.seed_dev);
+  constexpr int DH = 32, KP = DH + 8, KD = 256, WP = KD + 8, KCX = KD / 32, DT = 2, NR = (NT + QW - 1) / QW;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  bf16* sm = reinterpret_cast<bf16*>(smem_raw);
+  const int skp = FULL ? NT * 16 : p.skp, ntr = FULL ? NT : skp / 16, vtp = skp + 8;
+  bf16* Kh = sm;                                          // K[skp][KP], d in k-slot order
+  bf16* Th = Kh + skp * KP;                               // V^T[DH][vtp]
+  float* kbias = reinterpret_cast<float*>(Th + DH * vtp);
+  bf16* Wl = reinterpret_cast<bf16*>(kbias + skp);        // rows 0..31 Wq_h, 32..63 Wk_h, 64..95 Wv_h, [96][WP]
+  float* bl = reinterpret_cast<float*>(Wl + 96 * WP);     // the 96 biases
+  int b, h;
+  {
+    const int total = (int)gridDim.x;
+    const int qd = total >> 3, r = total & 7, xcd = (int)blockIdx.x & 7, loc = (int)blockIdx.x >> 3;
+    const int v = (xcd < r ? xcd * (qd + 1) : r * (qd + 1) + (xcd - r) * qd) + loc;     // contiguous (batch, head) range per XCD: the heads of an image share x
+    h = v % p.H; b = v / p.H;
+  }
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
+  const int nqt = (p.Sq + 15) >> 4;
+  const bf16* xpg = xk.xp + b * xk.x_bs;
+  const bf16* xg = xk.x + b * xk.x_bs;
+
+  bf16x8 nxp[KCX], nx[KCX];
+  auto fetch = [&](int t) {
+    const int tok = t * 16 + li;
+    const bool ok = t < nqt && tok < p.Sq;
+#pragma unroll
+    for (int kc = 0; kc < KCX; ++kc) {
+      if (ok) {
+        nxp[kc] = *reinterpret_cast<const bf16x8*>(xpg + (int64_t)tok * xk.x_rs + kc * 32 + g * 8);
+        nx[kc] = *reinterpret_cast<const bf16x8*>(xg + (int64_t)tok * xk.x_rs + kc * 32 + g * 8);
+      } else {
+        nxp[kc] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        nx[kc] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      }
+    }
+  };
+  fetch(wave);
+  stage_chunks16<QTHR, 6>(96 * (KD / 8), tid,
+      [&](int idx) { const int r = idx >> 5, c = idx & 31; return xk.w + (int64_t)((r >> 5) * KD + h * DH + (r & 31)) * KD + c * 8; },
+      [&](int idx) { const int r = idx >> 5, c = idx & 31; return Wl + r * WP + c * 8; });
+  if (tid < 96) bl[tid] = xk.bias ? xk.bias[(tid >> 5) * KD + h * DH + (tid & 31)] : 0.f;
+  for (int idx = tid; idx < skp; idx += QTHR)
+    kbias[idx] = (idx >= p.Sk || (p.kpm && p.kpm[(int64_t)b * p.Sk + idx])) ? -INFINITY : 0.f;
+  __syncthreads();
+
+  // ---- projections: this wave's token tiles (tiles beyond the sequence are multiplied too -- zero rows + bias: the padded K rows and
+  // V^T columns must hold finite values, their probabilities are exactly 0) ----
+  bf16x8 qreg[NR];
+  bf16* qg = reinterpret_cast<bf16*>(const_cast<void*>(p.q)) + b * p.q_bs + h * DH;
+  bf16* kg = reinterpret_cast<bf16*>(const_cast<void*>(p.k)) + b * p.k_bs + h * DH;
+  bf16* vg = reinterpret_cast<bf16*>(const_cast<void*>(p.v)) + b * p.v_bs + h * DH;
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    const int t = wave + r * QW;
+    qreg[r] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    if (t < ntr) {
+      bf16x8 xpf[KCX], xf[KCX];
+#pragma unroll
+      for (int kc = 0; kc < KCX; ++kc) { xpf[kc] = nxp[kc]; xf[kc] = nx[kc]; }
+      fetch(t + QW);
+      f32x4 aq[DT], ak[DT], av[DT];
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        const f32x4 bq = *reinterpret_cast<const f32x4*>(bl + dt * 16 + g * 4);
+        const f32x4 bk = *reinterpret_cast<const f32x4*>(bl + 32 + dt * 16 + g * 4);
+        const float bv = bl[64 + dt * 16 + li];
+        aq[dt] = bq; ak[dt] = bk; av[dt] = f32x4{bv, bv, bv, bv};
+      }
+#pragma unroll
+      for (int kc = 0; kc < KCX; ++kc) {
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          const bf16* wr = Wl + (dt * 16 + li) * WP + kc * 32 + g * 8;
+          const bf16x8 wq = *reinterpret_cast<const bf16x8*>(wr);
+          const bf16x8 wk = *reinterpret_cast<const bf16x8*>(wr + 32 * WP);
+          const bf16x8 wv = *reinterpret_cast<const bf16x8*>(wr + 64 * WP);
+          aq[dt] = mfma16(wq, xpf[kc], aq[dt]);
+          ak[dt] = mfma16(wk, xpf[kc], ak[dt]);
+          av[dt] = mfma16(xf[kc], wv, av[dt]);
+        }
+      }
+      bf16x8 qf, kf;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        qf[i] = (bf16)aq[0][i]; qf[4 + i] = (bf16)aq[1][i];
+        kf[i] = (bf16)ak[0][i]; kf[4 + i] = (bf16)ak[1][i];
+      }
+      qreg[r] = qf;
+      const int tok = t * 16 + li;
+      *reinterpret_cast<bf16x8*>(Kh + tok * KP + g * 8) = kf;
+      bf16x4 v4[DT];
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v4[dt][i] = (bf16)av[dt][i];
+        *reinterpret_cast<bf16x4*>(Th + (dt * 16 + li) * vtp + t * 16 + g * 4) = v4[dt];
+      }
+      if (tok < p.Sq) {
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          bf16x4 q4, k4;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { q4[i] = qf[dt * 4 + i]; k4[i] = kf[dt * 4 + i]; }
+          *reinterpret_cast<bf16x4*>(qg + (int64_t)tok * p.q_rs + dt * 16 + g * 4) = q4;
+          *reinterpret_cast<bf16x4*>(kg + (int64_t)tok * p.k_rs + dt * 16 + g * 4) = k4;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int tv = t * 16 + g * 4 + i;
+        if (tv < p.Sq) {
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt) vg[(int64_t)tv * p.v_rs + dt * 16 + li] = v4[dt][i];
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- core (attn_q_kernel MODE 0, bf16) with the Q fragments from registers ----
+  const float c2 = p.scale * 1.4426950408889634f;
+  const int ts = attn_ts(p.dthresh);
+  const uint32_t ts2 = ((uint32_t)ts & 0xffffu) * 0x10001u;
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    const int qt = wave + r * QW;
+    if (qt >= nqt) continue;
+    const int q = qt * 16 + li;
+    const bool qok = q < p.Sq;
+    const bf16x8 qh = qreg[r];
+    f32x4 s[NT];
+#pragma unroll
+    for (int j0 = 0; j0 < NT; j0 += 4) {
+      if (j0 < ntr) {
+#pragma unroll
+        for (int j = j0; j < j0 + 4; ++j) {
+          s[j] = *reinterpret_cast<const f32x4*>(kbias + j * 16 + g * 4);
+          const bf16x8 kh = *reinterpret_cast<const bf16x8*>(Kh + (j * 16 + li) * KP + g * 8);
+          s[j] = mfma16(kh, qh, s[j]);
+        }
+      } else {
+#pragma unroll
+        for (int j = j0; j < j0 + 4; ++j) s[j] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+      }
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) mx = fmaxf(mx, s[j][i]);
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float nm = mx == -INFINITY ? 0.f : -mx * c2;
+    float lsum = 0.f;
+#pragma unroll
+    for (int j0 = 0; j0 < NT; j0 += 4) {
+      if (j0 < ntr) {
+#pragma unroll
+        for (int j = j0; j < j0 + 4; ++j)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { const float e = __builtin_amdgcn_exp2f(fmaf(s[j][i], c2, nm)); s[j][i] = e; lsum += e; }
+      }
+    }
+    lsum += __shfl_xor(lsum, 16);
+    lsum += __shfl_xor(lsum, 32);
+    if (g == 0 && qok && p.lse) p.lse[((int64_t)b * p.H + h) * p.Sq + q] = (mx == -INFINITY ? 0.f : mx * p.scale) + logf(lsum);
+    const uint32_t gb = p.dthresh ? attn_row_seed(p.seed, ((uint64_t)b * p.H + h) * p.Sq + q) + (uint32_t)(g * 2) * ATTN_PAIR_STEP : 0u;
+    f32x4 oacc[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j0 = 0; j0 < NT; j0 += 4) {
+      __builtin_amdgcn_sched_barrier(0);
+      if (j0 < ntr) {
+#pragma unroll
+        for (int kb = j0 / 2; kb < j0 / 2 + 2; ++kb) {
+          bf16x8 ph;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { ph[i] = (bf16)s[2 * kb][i]; ph[4 + i] = (bf16)s[2 * kb + 1][i]; }
+          if (p.dthresh) {
+            u32x4 pw = __builtin_bit_cast(u32x4, ph);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+              const uint32_t pb = gb + (uint32_t)((2 * kb + t) * 8) * ATTN_PAIR_STEP;
+              pw[2 * t] &= ~attn_drop_bits(attn_pair_bits(pb), ts2);
+              pw[2 * t + 1] &= ~attn_drop_bits(attn_pair_bits(pb + ATTN_PAIR_STEP), ts2);
+            }
+            ph = __builtin_bit_cast(bf16x8, pw);
+          }
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt) {
+            const int off = (dt * 16 + li) * vtp + kb * 32 + g * 4;
+            const bf16x8 xh = ld_pair64(Th + off, Th + off + 16);
+            oacc[dt] = mfma16(xh, ph, oacc[dt]);
+          }
+        }
+      }
+    }
+    if (!qok) continue;
+    bf16* outp = reinterpret_cast<bf16*>(p.o) + b * p.o_bs + (int64_t)q * p.o_rs + h * DH;
+    const float inv = lsum > 0.f ? (p.dthresh ? p.dscale : 1.f) / lsum : 0.f;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      bf16x4 o4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o4[i] = (bf16)(oacc[dt][i] * inv);
+      *reinterpret_cast<bf16x4*>(outp + dt * 16 + g * 4) = o4;
+    }
+  }
+}
+
 // dK / dV: workgroup = 64 keys of one (b,h); wave = 16 keys; queries streamed in chunks of 64.
 template <typename T, int DHK, int DHV>
 __global__ __launch_bounds__(256) void attn_kv_kernel(AttnK p) {
@@ -1312,6 +1547,40 @@ extern "C" int gpv_attention_fwd(const gpv_attn_args* a, void* stream) {
   if (!a->o) return (int)hipErrorInvalidValue;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   return a->dtype == GPV_F32 ? dispatch_q<float, 0>(p, st) : dispatch_q<bf16, 0>(p, st);
+}
+
+template <int NT, bool FULL>
+int launch_qkv(AttnK p, const QkvK& xk, hipStream_t st) {
+  constexpr int KP = 40, WP = 264;
+  const size_t lds = ((size_t)p.skp * KP + (size_t)32 * (p.skp + 8) + (size_t)96 * WP) * 2 + (size_t)p.skp * 4 + 96 * 4;
+  auto fn = attn_qkv_kernel<NT, FULL>;
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024);
+    if (e != hipSuccess) { (void)hipGetLastError(); return (int)e; }
+    attr = true;
+  }
+  hipLaunchKernelGGL(fn, dim3(p.B * p.H), dim3(QTHR), lds, st, p, xk);
+  GPV_CHECK_LAUNCH();
+  return 0;
+}
+
+/* Self-attention with the in-projection inside the launch (attn_qkv_kernel): a->q / a->k / a->v are OUTPUTS here (the projected
+ * rows, written where the projection GEMMs would have written them: the backward reads them), xp / x: [B, S, 256] rows (x_bs / x_rs in
+ * elements), w: in_proj_weight [768, 256] bf16, bias: [768] fp32 or NULL.  bf16, dh = 32, H * dh = 256, Sq == Sk <= 320, not causal. */
+extern "C" int gpv_attention_qkv_fwd(const gpv_attn_args* a, const void* xp, const void* x, int64_t x_bs, int64_t x_rs, const void* w,
+                                     const float* bias, void* stream) {
+  AttnK p{};
+  int e = fill(a, p);
+  if (e) return e;
+  if (!a->o || !xp || !x || !w || a->dtype != GPV_BF16 || a->dh != 32 || a->H * a->dh != 256 || a->Sq != a->Sk || a->causal) return (int)hipErrorInvalidValue;
+  if ((x_rs & 7) || (x_bs & 7) || (a->q_rs & 3) || (a->k_rs & 3) || (a->o_rs & 3)) return (int)hipErrorInvalidValue;
+  if ((reinterpret_cast<uintptr_t>(xp) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w)) & 15) return (int)hipErrorInvalidValue;
+  if ((reinterpret_cast<uintptr_t>(a->q) | reinterpret_cast<uintptr_t>(a->k) | reinterpret_cast<uintptr_t>(a->o)) & 7) return (int)hipErrorInvalidValue;
+  QkvK xk{reinterpret_cast<const bf16*>(xp), reinterpret_cast<const bf16*>(x), x_bs, x_rs, reinterpret_cast<const bf16*>(w), bias};
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (p.skp <= 128) return p.skp == 128 ? launch_qkv<8, true>(p, xk, st) : launch_qkv<8, false>(p, xk, st);
+  return p.skp == 320 ? launch_qkv<20, true>(p, xk, st) : launch_qkv<20, false>(p, xk, st);
 }
 
 extern "C" int gpv_attention_bwd(const gpv_attn_args* a, void* stream) {

@@ -105,7 +105,7 @@ def lib():
 
 
 EXPORTS = ['gpv_abi_version', 'gpv_build_id', 'gpv_set_option', 'gpv_gemm', 'gpv_conv2d', 'gpv_image_to_nhwc4', 'gpv_maxpool3x3s2',
-           'gpv_attention_fwd', 'gpv_attention_bwd', 'gpv_layernorm_fwd', 'gpv_layernorm_bwd', 'gpv_layernorm_pos_fwd', 'gpv_layernorm_bwd2',
+           'gpv_attention_fwd', 'gpv_attention_bwd', 'gpv_attention_qkv_fwd', 'gpv_layernorm_fwd', 'gpv_layernorm_bwd', 'gpv_layernorm_pos_fwd', 'gpv_layernorm_bwd2',
            'gpv_softmax_ce', 'gpv_roi_weights', 'gpv_add', 'gpv_add_rowbcast', 'gpv_colsum', 'gpv_cast',
            'gpv_cast_rowscale_t', 'gpv_prep_conv_weight', 'gpv_embedding', 'gpv_dropout',
            'gpv_relevance_condition', 'gpv_adamw', 'gpv_sumsq', 'gpv_clip_scale', 'gpv_act_fwd', 'gpv_act_bwd', 'gpv_set_seed_device',
@@ -320,6 +320,13 @@ def attention_fwd(q, k, v, o, strides, B, H, Sq, Sk, dh, scale, kpm=None, causal
     """strides = ((q_bs,q_rs),(k_bs,k_rs),(v_bs,v_rs),(o_bs,o_rs)) in elements."""
     a = _attn_args(q, k, v, o, strides, B, H, Sq, Sk, dh, scale, kpm, causal, drop_p, seed, lse)
     _chk(lib().gpv_attention_fwd(C.byref(a), _stream()), 'gpv_attention_fwd')
+
+
+def attention_qkv_fwd(xp, x, w, bias, q, k, v, o, strides, B, H, S, scale, kpm=None, drop_p=0.0, seed=0, lse=None):
+    """gpv_attention_qkv_fwd: q / k / v (column slices of the projection buffers) are WRITTEN; xp, x: [B * S, 256] rows"""
+    a = _attn_args(q, k, v, o, strides, B, H, S, S, 32, scale, kpm, False, drop_p, seed, lse)
+    _chk(lib().gpv_attention_qkv_fwd(C.byref(a), _p(xp), _p(x), C.c_int64(S * x.stride(0)), C.c_int64(x.stride(0)), _p(w), _p(_f32(bias)),
+                                     _stream()), 'gpv_attention_qkv_fwd')
 
 
 def attention_bwd(q, k, v, o, dout, dq, dk, dv, strides, do_strides, B, H, Sq, Sk, dh, scale, kpm=None,

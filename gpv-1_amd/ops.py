@@ -521,6 +521,32 @@ def multi_linear(x, ws, sink=None, chain=None):
 # --------------------------------------------------------------------------------------------
 # Linear:  y = dropout(act(x W^T + b))      (x: [..., K])
 # --------------------------------------------------------------------------------------------
+def _linear_backward(w, x2, dz, chain, need_dx, xshape):
+    """backward of y = x2 w^T + b given dz = dL/dy [M, N] (contiguous, compute dtype): weight / bias gradients (deferred while a
+    backward is captured), dx = dz W with the chain's running sum in the epilogue; -> the gradient to hand to autograd (None while
+    other consumers of the chain are still to run)"""
+    K, N = w.K, w.N
+    M = x2.shape[0]
+    need_b = w.bias is not None and w.bias.requires_grad
+    if w.weight.requires_grad:
+        # dW += dz^T x ; the bias gradient (column sums of dz) rides along in the same launch (a_rowsum)
+        wgrad_linear(dz, x2, w.wgrad(), w.bgrad() if need_b else None, N, K, M, _split_k(N, K, M))
+    elif need_b:
+        hip.colsum(dz, w.bgrad(), M, N, N)
+    dx = None
+    if need_dx:
+        dx = torch.empty(M, K, device=dz.device, dtype=RT.dtype)
+        ch = chain
+        if ch is not None and ch.acc is not None:
+            w.dx_gemm(dz, dx, M, res=ch.acc.reshape(M, K), ldr=K)         # dx = dz W + (the other consumers' gradients so far)
+        else:
+            w.dx_gemm(dz, dx, M)                                           # dx = dz W
+        dx = dx.reshape(xshape)
+        if ch is not None:
+            dx = ch.done(dx)
+    return dx
+
+
 class LinearFn(Function):
     @staticmethod
     def forward(ctx, x, w, act, drop_p, out_f32, dummy=None, chain=None):
@@ -557,23 +583,7 @@ class LinearFn(Function):
             t = torch.empty_like(dz)
             hip.act_bwd(dz, _as_compute(z), t, M * N, ACT_GELU, 1.0)
             dz = t
-        need_b = w.bias is not None and w.bias.requires_grad
-        if w.weight.requires_grad:
-            # dW += dz^T x ; the bias gradient (column sums of dz) rides along in the same launch (a_rowsum)
-            wgrad_linear(dz, x2, w.wgrad(), w.bgrad() if need_b else None, N, K, M, _split_k(N, K, M))
-        elif need_b:
-            hip.colsum(dz, w.bgrad(), M, N, N)
-        dx = None
-        if ctx.needs_input_grad[0]:
-            dx = torch.empty(M, K, device=dz.device, dtype=RT.dtype)
-            ch = ctx.chain
-            if ch is not None and ch.acc is not None:
-                w.dx_gemm(dz, dx, M, res=ch.acc.reshape(M, K), ldr=K)         # dx = dz W + (the other consumers' gradients so far)
-            else:
-                w.dx_gemm(dz, dx, M)                                           # dx = dz W
-            dx = dx.reshape(ctx.xshape)
-            if ch is not None:
-                dx = ch.done(dx)
+        dx = _linear_backward(w, x2, dz, ctx.chain, ctx.needs_input_grad[0], ctx.xshape)
         return dx, None, None, None, None, None, None
 
 
@@ -885,6 +895,65 @@ class AttentionFn(Function):
 def attention(bufs, roles, B, H, Sq, Sk, dh, kpm=None, causal=False, drop_p=0.0, sinks=None):
     """sinks: per buffer None or the ops.GradSink of a buffer shared with other attention calls (see AttentionFn.backward)"""
     return AttentionFn.apply((roles, B, H, Sq, Sk, dh, kpm, causal, drop_p, sinks), *bufs)
+
+
+ATTN_QKV = os.environ.get('GPV_ATTN_QKV', '1') != '0'
+
+
+def attention_qkv_ok(E, H, S, causal):
+    """gpv_attention_qkv_fwd's range: the DETR encoder / decoder self-attention (width 256, 8 heads of 32, <= 320 tokens, bf16)"""
+    return ATTN_QKV and RT.dtype == torch.bfloat16 and E == 256 and H == 8 and 0 < S <= 320 and not causal
+
+
+class SelfAttnQKVFn(Function):
+    """o = attention(xp Wq^T + bq, xp Wk^T + bk, x Wv^T + bv) with the projections INSIDE the attention launch
+    (gpv_attention_qkv_fwd; transformer.py:148-155, 216-219).  The launch also writes q | k and v where the projection GEMMs
+    would have: the backward is the one of the three launches it replaces -- gpv_attention_bwd, then the two projections'
+    weight / bias gradients and backward-data GEMMs (value first, as autograd orders them) with their GradChains."""
+
+    @staticmethod
+    def forward(ctx, meta, xp, x, dummy=None):
+        w, B, H, S, kpm, drop_p, chain_qk, chain_v = meta
+        E = w.K
+        xp2 = _c(_as_compute(xp)).reshape(-1, E)
+        x2 = _c(_as_compute(x)).reshape(-1, E)
+        M = xp2.shape[0]
+        qk = torch.empty(M, 2 * E, device=x2.device, dtype=RT.dtype)
+        v = torch.empty(M, E, device=x2.device, dtype=RT.dtype)
+        o = torch.empty(M, E, device=x2.device, dtype=RT.dtype)
+        lse = torch.empty(B, H, S, device=x2.device, dtype=torch.float32)
+        st = ((S * 2 * E, 2 * E), (S * 2 * E, 2 * E), (S * E, E), (S * E, E))
+        seed = RT.next_seed() if drop_p > 0 else 0
+        scale = 1.0 / math.sqrt(E // H)
+        hip.attention_qkv_fwd(xp2, x2, w.lp(), w.bias_f32(), qk[:, :E], qk[:, E:], v, o, st, B, H, S, scale, kpm=kpm, drop_p=drop_p,
+                              seed=seed, lse=lse)
+        ctx.cq = chain_qk.join() if (chain_qk is not None and ctx.needs_input_grad[1]) else None
+        ctx.cv = chain_v.join() if (chain_v is not None and ctx.needs_input_grad[2]) else None
+        ctx.meta, ctx.seed, ctx.st, ctx.scale = meta, seed, st, scale
+        ctx.xp_shape, ctx.x_shape = xp.shape, x.shape
+        ctx.save_for_backward(xp2, x2, qk, v, o, lse)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        w, B, H, S, kpm, drop_p = ctx.meta[:6]
+        E = w.K
+        xp2, x2, qk, v, o, lse = ctx.saved_tensors
+        do = _c(_as_compute(do))
+        dqk, dv = torch.empty_like(qk), torch.empty_like(v)
+        hip.attention_bwd(qk[:, :E], qk[:, E:], v, o, do, dqk[:, :E], dqk[:, E:], dv, ctx.st, (S * E, E), B, H, S, S, E // H, ctx.scale,
+                          kpm=kpm, drop_p=drop_p, seed=ctx.seed, lse=lse)
+        dx = _linear_backward(W(w.weight, w.bias, 2 * E, 3 * E), x2, dv, ctx.cv, ctx.needs_input_grad[2], ctx.x_shape)
+        dxp = _linear_backward(W(w.weight, w.bias, 0, 2 * E), xp2, dqk, ctx.cq, ctx.needs_input_grad[1], ctx.xp_shape)
+        return None, dxp, dx, None
+
+
+def attention_qkv(xp, x, w, B, H, S, kpm=None, drop_p=0.0, chains=(None, None)):
+    """w: ops.W over ALL 3 E rows of in_proj_weight (+ bias); chains: the GradChains of xp (q | k projection) and x (value projection)"""
+    dummy = None
+    if torch.is_grad_enabled() and not (xp.requires_grad or x.requires_grad) and (w.weight.requires_grad or (w.bias is not None and w.bias.requires_grad)):
+        dummy = _dummy(x.device)
+    return SelfAttnQKVFn.apply((w, B, H, S, kpm, drop_p, chains[0], chains[1]), xp, x, dummy)
 
 
 # --------------------------------------------------------------------------------------------

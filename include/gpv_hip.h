@@ -293,6 +293,15 @@ typedef struct {
 } gpv_attn_args;
 int gpv_attention_fwd(const gpv_attn_args* a, void* stream);
 int gpv_attention_bwd(const gpv_attn_args* a, void* stream);
+/* Self-attention with nn.MultiheadAttention's in-projection INSIDE the launch (transformer.py:148-155: q = k = src + pos, value = src;
+ * :216-219 the decoder's self-attention; torch F.multi_head_attention_forward's in_proj):
+ *   q = xp Wq^T + bq,  k = xp Wk^T + bk,  v = x Wv^T + bv,  o = dropout(softmax(q k^T scale + key padding)) v
+ * a->q / a->k / a->v are OUTPUTS here: the projected rows, written where the projection GEMMs would have written them (addressing as
+ * above) -- gpv_attention_bwd and the backward GEMMs read them; a->o, a->lse as in gpv_attention_fwd.  xp, x: [B, Sq, 256] rows
+ * (x_bs / x_rs in elements, multiples of 8), w: in_proj_weight [768, 256] bf16 contiguous, bias: [768] fp32 or NULL.
+ * bf16 only, dh = 32, H * dh = 256, Sq == Sk <= 320, not causal; anything else: hipErrorInvalidValue before anything is launched. */
+int gpv_attention_qkv_fwd(const gpv_attn_args* a, const void* xp, const void* x, int64_t x_bs, int64_t x_rs, const void* w,
+                          const float* bias, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * y = LayerNorm(x + dropout(s)) * gamma + beta     (post-norm residual blocks:

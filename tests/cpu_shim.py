@@ -136,6 +136,20 @@ def attention_fwd(q, k, v, o, strides, B, H, Sq, Sk, dh, scale, kpm=None, causal
         lse.copy_(l)
 
 
+def attention_qkv_fwd(xp, x, w, bias, q, k, v, o, strides, B, H, S, scale, kpm=None, drop_p=0.0, seed=0, lse=None):
+    """gpv_attention_qkv_fwd: the in-projection (rounded to the buffers' dtype, as the launch stores it) + the core"""
+    assert drop_p == 0.0
+    E = w.shape[1]
+    (qb, qr), (kb, kr), (vb, vr), _ = strides
+    bb = bias.float() if bias is not None else torch.zeros(3 * E)
+    yqk = xp.float() @ w[:2 * E].float().t() + bb[:2 * E]
+    yv = x.float() @ w[2 * E:].float().t() + bb[2 * E:]
+    _sv(q, (B * S, E), (qr, 1)).copy_(yqk[:, :E].to(q.dtype))
+    _sv(k, (B * S, E), (kr, 1)).copy_(yqk[:, E:].to(k.dtype))
+    _sv(v, (B * S, E), (vr, 1)).copy_(yv.to(v.dtype))
+    attention_fwd(q, k, v, o, strides, B, H, S, S, E // H, scale, kpm=kpm, lse=lse)
+
+
 def attention_bwd(q, k, v, o, dout, dq, dk, dv, strides, do_strides, B, H, Sq, Sk, dh, scale, kpm=None, causal=False,
                   drop_p=0.0, seed=0, lse=None):
     assert drop_p == 0.0
@@ -380,7 +394,7 @@ def install(only=None):
     """monkeypatch gpv1_amd.hip with the emulations above; returns an uninstall callable.
     `only`: optional list of entry-point names (GPU bisecting: swap single kernels for torch math)."""
     import gpv1_amd.hip as h
-    names = only or ['gemm', 'conv2d', 'attention_fwd', 'attention_bwd', 'layernorm_fwd', 'layernorm_bwd', 'softmax_ce',
+    names = only or ['gemm', 'conv2d', 'attention_fwd', 'attention_bwd', 'attention_qkv_fwd', 'layernorm_fwd', 'layernorm_bwd', 'softmax_ce',
              'image_to_nhwc4', 'maxpool3x3s2', 'stem_pool', 'conv1x1_dual', 'conv1x1_chain', 'ffn_fused_fwd', 'conv_wgrad_group', 'roi_weights', 'add', 'add_rowbcast', 'colsum', 'cast', 'cast_rowscale_t',
              'prep_conv_weight', 'embedding', 'dropout', 'relevance_condition', 'adamw', 'sumsq', 'clip_scale', 'act_fwd', 'act_bwd',
              'cast_transpose_group', 'argmax_rows', 'ln_linear_rows', 'attention_row_proj']

@@ -901,6 +901,47 @@ def test_attention_dropout_consistency():
     assert rel(lhs, rhs) < 1e-4
 
 
+@pytest.mark.parametrize('Bn,S,use_kpm,drop', [(32, 300, False, 0.1), (3, 300, True, 0.1), (2, 100, False, 0.1), (32, 100, False, 0.0), (2, 37, True, 0.25),
+                                              (1, 320, False, 0.0), (2, 129, True, 0.1), (5, 16, False, 0.0)])
+def test_attention_with_in_projection_equals_the_three_launches(Bn, S, use_kpm, drop):
+    """gpv_attention_qkv_fwd (q | k | v projections inside the attention launch, transformer.py:148-155): the projected rows it writes
+    against fp32 math and against the projection GEMMs; its output / lse against gpv_attention_fwd run on ITS OWN q, k, v with the same
+    seed (same dropout words, same softmax: only the order of the 32-term score sums differs)"""
+    h, dt = hip(), torch.bfloat16
+    H, dh, D = 8, 32, 256
+    M = Bn * S
+    x, pos = rnd(M, D, dtype=dt, seed=31), rnd(M, D, dtype=dt, seed=32, scale=0.5)
+    xp = (x.float() + pos.float()).to(dt)
+    w, bias = rnd(3 * D, D, dtype=dt, seed=33, scale=D ** -0.5), rnd(3 * D, seed=34, scale=0.2)
+    kpm = None
+    if use_kpm:
+        kpm = torch.zeros(Bn, S, dtype=torch.uint8, device=DEV)
+        kpm[0, S - S // 3:] = 1
+        kpm[-1, 1::5] = 1
+    qk = torch.full((M, 2 * D), float('nan'), device=DEV, dtype=dt)
+    v = torch.full((M, D), float('nan'), device=DEV, dtype=dt)
+    o = torch.full((M, D), float('nan'), device=DEV, dtype=dt)
+    lse = torch.empty(Bn, H, S, device=DEV)
+    st = ((S * 2 * D, 2 * D), (S * 2 * D, 2 * D), (S * D, D), (S * D, D))
+    scale = dh ** -0.5
+    h.attention_qkv_fwd(xp, x, w, bias, qk[:, :D], qk[:, D:], v, o, st, Bn, H, S, scale, kpm=kpm, drop_p=drop, seed=91, lse=lse)
+    ref_qk = xp.float() @ w[:2 * D].float().t() + bias[:2 * D]
+    ref_v = x.float() @ w[2 * D:].float().t() + bias[2 * D:]
+    assert rel(qk, ref_qk) < TOL[dt] and rel(v, ref_v) < TOL[dt]
+    g_qk, g_v = torch.empty_like(qk), torch.empty_like(v)
+    h.gemm(xp, w[:2 * D], g_qk, M, 2 * D, D, D, D, 2 * D, bias=bias[:2 * D].contiguous())
+    h.gemm(x, w[2 * D:], g_v, M, D, D, D, D, D, bias=bias[2 * D:].contiguous())
+    assert rel(qk, g_qk.float()) < 8e-3 and rel(v, g_v.float()) < 8e-3       # same math, another fp32 summation order + one bf16 rounding
+    o2 = torch.empty_like(o)
+    lse2 = torch.empty_like(lse)
+    h.attention_fwd(qk[:, :D], qk[:, D:], v, o2, st, Bn, H, S, S, dh, scale, kpm=kpm, drop_p=drop, seed=91, lse=lse2)
+    assert torch.isfinite(o.float()).all()
+    assert rel(o, o2.float()) < 8e-3
+    assert (lse - lse2).abs().max().item() < 1e-3
+    if drop > 0:                                                              # same keep pattern: a dropped probability is an exact zero in neither output, but the
+        assert ((o.float() - o2.float()).abs() > 0.05 * o2.float().abs().max()).float().mean().item() < 1e-4   # outputs would differ by whole terms
+
+
 ATT1 = [  # H, dh, Sq, Sk, causal, kpm, drop: the model's shapes at B = 32 + ragged ones around the tile / strip boundaries
     (8, 32, 300, 300, False, True, 0.1), (8, 32, 300, 300, False, False, 0.0), (8, 32, 100, 300, False, True, 0.1),
     (8, 32, 100, 100, False, False, 0.1), (16, 48, 100, 6, False, False, 0.1), (16, 48, 6, 100, False, False, 0.1),
