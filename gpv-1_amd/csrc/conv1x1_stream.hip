@@ -84,6 +84,16 @@ __global__ __launch_bounds__(512) void c1s_kernel(GemmK p, int ncols) {
   for (int c = tid; c < p.N; c += 512) bias_l[c] = bias_g ? bias_g[c] : 0.f;
   __syncthreads();
 
+  // LIN dropout (round 5): the keep words of common.h's drop_pair_bits, bit for bit, at a tenth of the instructions.  The epilogue below
+  // WAS the launch: 42 VALU instructions per output element (two quarter-rate 32-bit multiplies and 64-bit index arithmetic per PAIR,
+  // shift / and / compare / select / multiply per element) against 2 MFMAs per 64 elements -- 13 K cycles of VALU per 16-row tile
+  // beside 2 K of MFMA (ISA count; the 256 -> 2048 feed-forward GEMM ran at 29 - 37 us for 4 us of matrix work).  A lane's pairs in a
+  // tile are pair0 + const: the first multiply is ONE per tile (the rest are literal adds), the second (high words) is constant while the
+  // low word does not wrap (checked per tile, wave-uniform; the general path stays for the wrap), and the keep test is applied to the
+  // PACKED bf16 pairs: flip the sign bits of the two 16-bit fields, saturating packed subtract of the threshold, arithmetic shift ->
+  // 0xffff per dropped half, and-not (attention.hip's attn_drop_bits).
+  const uint32_t t16 = LIN ? (p.dthresh >> 16) : 0u;
+  const uint32_t ts2 = ((t16 - 32768u) & 0xffffu) * 0x10001u;
   for (; tile < ntile; tile += nw) {
     bf16x8 af[KC];
 #pragma unroll
@@ -91,6 +101,15 @@ __global__ __launch_bounds__(512) void c1s_kernel(GemmK p, int ncols) {
     fetch(tile + nw);
     const int px = tile * 16 + pl;
     const bool pok = px < p.M;
+    uint32_t hbase = 0u;
+    bool hfast = false;
+    if constexpr (LIN) {
+      if (p.dthresh) {
+        const uint64_t pr = ((uint64_t)px * (uint64_t)nfull + (uint64_t)(cbase + g * 8)) >> 1;        // pair index of this lane's first group
+        hbase = (uint32_t)pr * 0x9E3779B9u + (uint32_t)p.seed + ((uint32_t)(pr >> 32) ^ (uint32_t)(p.seed >> 32)) * 0x85EBCA6Bu;
+        hfast = !__any((uint32_t)pr > 0xffffffffu - (uint32_t)(p.N / 2 + 8));
+      }
+    }
     for (int h = 0; h < npass; ++h) {
       // epilogue operands of this pass: requested before the MFMAs, consumed after them
       bf16x8 rv[RES ? NG : 1], mv[MASK ? NG : 1];
@@ -132,17 +151,53 @@ __global__ __launch_bounds__(512) void c1s_kernel(GemmK p, int ncols) {
         }
         float v[8] = {acc[2 * t][0] + b0.x, acc[2 * t][1] + b0.y, acc[2 * t][2] + b0.z, acc[2 * t][3] + b0.w,
                       acc[2 * t + 1][0] + b1.x, acc[2 * t + 1][1] + b1.y, acc[2 * t + 1][2] + b1.z, acc[2 * t + 1][3] + b1.w};
-        uint32_t keep8 = 0xffu;
-        if constexpr (LIN) { if (p.dthresh) keep8 = drop_mask<8>(p.seed, (uint64_t)px * (uint64_t)nfull + (uint64_t)(cbase + c0), p.dthresh); }
         bf16x8 o;
+        bool masked = false;
+        if constexpr (LIN) {
+          if (p.dthresh) {
+            masked = true;
+            uint32_t dropw[4];                      // 0xffff in every dropped half of pair q (elements c0 + 2 q, c0 + 2 q + 1)
+            if (hfast) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          float x = v[e];
-          if constexpr (RES) x += (float)rv[t][e];
-          if (p.act == GPV_ACT_RELU) x = fmaxf(x, 0.f);
-          if constexpr (LIN) { if (p.dthresh) x = ((keep8 >> e) & 1u) ? x * p.dscale : 0.f; }
-          if constexpr (MASK) x = (float)mv[t][e] > 0.f ? x : 0.f;
-          o[e] = (bf16)x;
+              for (int q = 0; q < 4; ++q) {
+                uint32_t x = hbase + (uint32_t)(h * (NH / 2) + t * 16 + q) * 0x9E3779B9u;
+                x ^= x >> 16; x = __umul24(x, 0x85EBCBu);
+                x ^= x >> 13; x = __umul24(x, 0xC2B2AFu);
+                x ^= x >> 16;
+                typedef short s16x2 __attribute__((ext_vector_type(2)));
+                const s16x2 d = __builtin_elementwise_sub_sat(__builtin_bit_cast(s16x2, x ^ 0x80008000u), __builtin_bit_cast(s16x2, ts2));
+                dropw[q] = __builtin_bit_cast(uint32_t, (s16x2)(d >> (s16x2){15, 15}));
+              }
+            } else {
+              const uint32_t keep8 = drop_mask<8>(p.seed, (uint64_t)px * (uint64_t)nfull + (uint64_t)(cbase + c0), p.dthresh);
+#pragma unroll
+              for (int q = 0; q < 4; ++q)
+                dropw[q] = (((keep8 >> (2 * q)) & 1u) ? 0u : 0xffffu) | (((keep8 >> (2 * q + 1)) & 1u) ? 0u : 0xffff0000u);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              float x = v[e];
+              if constexpr (RES) x += (float)rv[t][e];
+              if (p.act == GPV_ACT_RELU) x = fmaxf(x, 0.f);
+              x *= p.dscale;
+              if constexpr (MASK) x = (float)mv[t][e] > 0.f ? x : 0.f;
+              o[e] = (bf16)x;
+            }
+            u32x4 ow = __builtin_bit_cast(u32x4, o);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) ow[q] &= ~dropw[q];
+            o = __builtin_bit_cast(bf16x8, ow);
+          }
+        }
+        if (!masked) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float x = v[e];
+            if constexpr (RES) x += (float)rv[t][e];
+            if (p.act == GPV_ACT_RELU) x = fmaxf(x, 0.f);
+            if constexpr (MASK) x = (float)mv[t][e] > 0.f ? x : 0.f;
+            o[e] = (bf16)x;
+          }
         }
         if (pok) {
           bf16* q = C + (int64_t)px * p.ldc + c0;

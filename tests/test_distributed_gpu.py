@@ -128,7 +128,9 @@ def test_overlapped_exchange_with_side_stream_weight_gradients(tmp_path, mode):
         runs[overlap] = torch.load(os.path.join(out, 'rank0.pt'))
     a, b = runs['1'], runs['0']
     lo, hi = a['head']
-    tol = 1e-3 if mode == 'precise' else 2e-2
+    # run-to-run noise of this 5-step run, measured with tools/dbg_overlap.py (overlap 0 against overlap 0, precise): backbone segment 0.3 - 0.8 %,
+    # 1.7 % seen once (fp32 atomics reorder sums, five optimizer steps and the assignment amplify it); a bucket exchanged stale is O(1)
+    tol = 4e-2
     for name, (s, e) in {'backbone': (0, lo), 'detr head': (lo, hi), 'behind the head': (hi, a['G'].numel())}.items():
         ga, gb = a['G'][s:e].double(), b['G'][s:e].double()
         assert gb.norm() > 0
