@@ -110,6 +110,10 @@ __host__ __device__ __forceinline__ uint32_t drop_thresh(float p) {
 // first LDS store.  The plain `for (idx ...) lds[dst(idx)] = glob[src(idx)]` loop compiles to load -> s_waitcnt vmcnt(0) -> ds_write
 // per iteration: 16 DEPENDENT L2 round trips for a 128 KB matrix on 512 threads -- 10-20 us at the head of every launch of
 // conv1x1_stream / _chain / _dual, conv3x3_stream and stem_pool (seen in the ISA; the A-fragment prefetch shares the counter).
+// Round 5: the loads are UNCONDITIONAL (a thread beyond the end re-reads the last chunk); only the LDS stores are predicated.  With a
+// `if (idx < total)` around each load hipcc branched around every load and put `s_waitcnt vmcnt(0)` in front of the next one (seen in
+// the ISA of every user): the "eight loads in flight" were eight -- sixteen for a 128 KB matrix -- dependent round trips, 16 K cycles
+// (7 us, timed with s_memtime) at the head of every streaming launch.
 template <int NTHR, int U, typename SrcF, typename DstF>
 __device__ __forceinline__ void stage_chunks16(int total, int tid, SrcF src, DstF dst) {
   for (int base = 0; base < total; base += NTHR * U) {
@@ -117,7 +121,7 @@ __device__ __forceinline__ void stage_chunks16(int total, int tid, SrcF src, Dst
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int idx = base + u * NTHR + tid;
-      if (idx < total) tmp[u] = *reinterpret_cast<const bf16x8*>(src(idx));
+      tmp[u] = *reinterpret_cast<const bf16x8*>(src(idx < total ? idx : total - 1));
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {

@@ -35,7 +35,7 @@ __device__ __forceinline__ int c1s_chan(int L) {
 // LIN: the kernel as a plain linear layer's GEMM (gpv_gemm, K = 256 -> 2048 outputs: the DETR feed-forward 256 -> 2048 and its
 // backward-data product with the ReLU mask): alpha on the accumulator and the GEMM kernels' dropout
 // epilogue (same element index -> same keep pattern as gemm.hip / gemm_glds.hip / gemm_pipe.hip); the convolution instances are unchanged
-template <int K, int NH, bool RES, bool MASK, bool NT, bool LIN = false>
+template <int K, int NH, bool RES, bool MASK, bool NT, bool LIN = false, int NP = 1>
 __global__ __launch_bounds__(512) void c1s_kernel(GemmK p, int ncols) {
   // ncols: output channels per block row (gridDim.y slices of a wide layer: layer3's 1024 channels as four 256-channel
   // problems that share A -- the weights of one slice fit the LDS, A is small next to the output)
@@ -54,7 +54,6 @@ __global__ __launch_bounds__(512) void c1s_kernel(GemmK p, int ncols) {
   const int nfull = p.N;
   if constexpr (LIN) { if (p.dthresh) p.seed = eff_seed(p.seed, p.seed_dev); }
   p.N = ncols;
-  const int npass = p.N / NH;
   const int ntile = (p.M + 15) >> 4;
   const int nw = (int)gridDim.x * 8;
   int tile = (int)blockIdx.x * 8 + wave;
@@ -63,19 +62,17 @@ __global__ __launch_bounds__(512) void c1s_kernel(GemmK p, int ncols) {
   bf16x8 an[KC];
   // stride 2 (the downsample projections, forward): output pixel (b, oh, ow) reads input pixel (b, 2 oh, 2 ow)
   const int ow_ = p.cg.OW, ohw = p.cg.OH * p.cg.OW, ihw = p.cg.IH * p.cg.IW, iw_ = p.cg.IW, sxy = p.cg.SH;
+  // (rows beyond the map -- the last tile's tail, the prefetch past a wave's last tile -- re-read the LAST row: no predicate per load;
+  //  with `if (ok)` around them hipcc branched around every pair of loads and waited for the pair before the next one)
   auto fetch = [&](int t) {
-    const int px = t * 16 + pl;
-    const bool ok = t < ntile && px < p.M;
+    const int px = min(t * 16 + pl, p.M - 1);
     int64_t ipx = px;
     if (sxy == 2) {
       const int b = px / ohw, r = px - b * ohw, oh = r / ow_, ow = r - oh * ow_;
       ipx = (int64_t)b * ihw + (int64_t)(2 * oh) * iw_ + 2 * ow;
     }
 #pragma unroll
-    for (int kc = 0; kc < KC; ++kc) {
-      if (ok) an[kc] = *reinterpret_cast<const bf16x8*>(A + ipx * p.lda + kc * 32 + g * 8);
-      else an[kc] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-    }
+    for (int kc = 0; kc < KC; ++kc) an[kc] = *reinterpret_cast<const bf16x8*>(A + ipx * p.lda + kc * 32 + g * 8);
   };
   fetch(tile);
   stage_chunks16<512, 8>(p.N * SL, tid,
@@ -101,6 +98,7 @@ __global__ __launch_bounds__(512) void c1s_kernel(GemmK p, int ncols) {
     fetch(tile + nw);
     const int px = tile * 16 + pl;
     const bool pok = px < p.M;
+    const int pxc = min(px, p.M - 1);
     uint32_t hbase = 0u;
     bool hfast = false;
     if constexpr (LIN) {
@@ -110,29 +108,33 @@ __global__ __launch_bounds__(512) void c1s_kernel(GemmK p, int ncols) {
         hfast = !__any((uint32_t)pr > 0xffffffffu - (uint32_t)(p.N / 2 + 8));
       }
     }
-    for (int h = 0; h < npass; ++h) {
+    // Every LOAD of the tile loop is unconditional (rows beyond the map read the last row) and the pass loop is unrolled (NP = channels
+    // per block / NH, 1 | 2).  With `if (pok)` around the loads and a run-time pass loop hipcc could not count what is in flight and
+    // drained the queue -- `s_waitcnt vmcnt(0)` -- between the prefetch and the first MFMA of every tile (seen in the ISA).
+#pragma unroll
+    for (int h = 0; h < NP; ++h) {
       // epilogue operands of this pass: requested before the MFMAs, consumed after them
       bf16x8 rv[RES ? NG : 1], mv[MASK ? NG : 1];
       if constexpr (RES) {
 #pragma unroll
         for (int t = 0; t < NG; ++t) {
-          const bf16* q = R + (int64_t)px * p.ldr + h * NH + t * 32 + g * 8;
-          if (pok) rv[t] = NT ? __builtin_bit_cast(bf16x8, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(q)))
-                              : *reinterpret_cast<const bf16x8*>(q);
-          else rv[t] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+          const bf16* q = R + (int64_t)pxc * p.ldr + h * NH + t * 32 + g * 8;
+          rv[t] = NT ? __builtin_bit_cast(bf16x8, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(q)))
+                     : *reinterpret_cast<const bf16x8*>(q);
         }
       }
       if constexpr (MASK) {
 #pragma unroll
         for (int t = 0; t < NG; ++t) {
-          if (pok) mv[t] = *reinterpret_cast<const bf16x8*>(Mk + (int64_t)px * p.ldm + h * NH + t * 32 + g * 8);
-          else mv[t] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+          mv[t] = *reinterpret_cast<const bf16x8*>(Mk + (int64_t)pxc * p.ldm + h * NH + t * 32 + g * 8);
         }
       }
       f32x4 acc[NTL];
 #pragma unroll
       for (int j = 0; j < NTL; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-      const bf16* wrow = Wl + (h * NH + pl) * KP + g * 8;
+      int woff = (h * NH + pl) * KP + g * 8;
+      asm volatile("" : "+v"(woff));                 // opaque per tile: with the pass loop unrolled the fragment reads are loop-invariant and hipcc hoists all 128 of them out of the tile loop (into scratch)
+      const bf16* wrow = Wl + woff;
 #pragma unroll
       for (int kc = 0; kc < KC; ++kc) {
 #pragma unroll
@@ -199,7 +201,7 @@ __global__ __launch_bounds__(512) void c1s_kernel(GemmK p, int ncols) {
             o[e] = (bf16)x;
           }
         }
-        if (pok) {
+        if (pok) {         // (a buffer store with a dropped out-of-range offset instead of the branch was measured: 25 - 35 % SLOWER launches)
           bf16* q = C + (int64_t)px * p.ldc + c0;
           if constexpr (NT) __builtin_nontemporal_store(__builtin_bit_cast(u32x4, o), reinterpret_cast<u32x4*>(q));
           else *reinterpret_cast<bf16x8*>(q) = o;
@@ -215,12 +217,12 @@ inline int c1s_cols(int K, int N) {
   return N < cap ? N : cap;
 }
 
-template <int K, int NH, bool RES, bool MASK, bool NT, bool LIN = false>
-int c1s_launch(const GemmK& k, hipStream_t st) {
+template <int K, int NH, bool RES, bool MASK, bool NT, bool LIN = false, int NP = 1>
+int c1s_launch_np(const GemmK& k, hipStream_t st) {
   constexpr int KP = K + 8;
   const int ncols = c1s_cols(k.K, k.N), nsl = k.N / ncols;
   const size_t lds = (size_t)ncols * KP * 2 + (size_t)ncols * sizeof(float);
-  auto fn = c1s_kernel<K, NH, RES, MASK, NT, LIN>;
+  auto fn = c1s_kernel<K, NH, RES, MASK, NT, LIN, NP>;
   static size_t attr = 0;
   if (lds > 64 * 1024 && lds > attr) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -236,6 +238,14 @@ int c1s_launch(const GemmK& k, hipStream_t st) {
   hipLaunchKernelGGL(fn, dim3(blocks, nsl), dim3(512), lds, st, k, ncols);
   GPV_CHECK_LAUNCH();
   return 0;
+}
+
+template <int K, int NH, bool RES, bool MASK, bool NT, bool LIN = false>
+int c1s_launch(const GemmK& k, hipStream_t st) {
+  const int np = c1s_cols(k.K, k.N) / NH;
+  if (np == 1) return c1s_launch_np<K, NH, RES, MASK, NT, LIN, 1>(k, st);
+  if constexpr (K <= 128 && NH == 256 && !LIN) { if (np == 2) return c1s_launch_np<K, NH, RES, MASK, NT, LIN, 2>(k, st); }
+  return -1;
 }
 
 template <int K, int NH>
