@@ -109,14 +109,19 @@ template <> struct Raw8<float> {
 // per thread and iteration (8 dependent round trips to L2/HBM before the first MFMA: the waves spent 57 % of their life in
 // s_waitcnt, PMC in profiles/r02_pmc_attention.txt).  MAXR bounds the rows at compile time, so the loops unroll and every
 // load of the block's staging is issued before the first LDS store.
+// Round 5: the loads are UNCONDITIONAL (a row / slice beyond the tile re-reads the last valid one) and the zero padding is applied in
+// store(): with `if (in range) load; else zero` per element hipcc branched around every load and drained the queue (vmcnt(0)) at joins
+// (seen in the ISA) -- "all loads first" was several dependent round trips.
 template <typename T, int DH, int MAXR, int NTHR> struct RowBatch {      // [rows][DH] row-major -> LDS [rows_pad][DH + 8]
   static constexpr int SL = DH / 8, IT = (MAXR * SL + NTHR - 1) / NTHR;
   Raw8<T> x[IT];
+  int rv_, dh_;
   __device__ __forceinline__ void load(const T* g, int64_t rs, int rows_valid, int rows_pad, int dh) {
+    rv_ = rows_valid; dh_ = dh;
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
       const int idx = threadIdx.x + it * NTHR, r = idx / SL, sl = idx - r * SL;
-      if (idx < rows_pad * SL && r < rows_valid && sl * 8 < dh) x[it].load(g + (int64_t)r * rs + sl * 8); else x[it].zero();
+      x[it].load(g + (int64_t)min(r, rows_valid - 1) * rs + min(sl * 8, dh - 8));
     }
   }
   template <bool PRECISE> __device__ __forceinline__ void store(int rows_pad, bf16* hi, bf16* lo) const {
@@ -125,7 +130,8 @@ template <typename T, int DH, int MAXR, int NTHR> struct RowBatch {      // [row
     for (int it = 0; it < IT; ++it) {
       const int idx = threadIdx.x + it * NTHR, r = idx / SL, sl = idx - r * SL;
       if (idx < rows_pad * SL) {
-        const R8<T> v = x[it].get();
+        R8<T> v = x[it].get();
+        if (r >= rv_ || sl * 8 >= dh_) v.zero();
         *reinterpret_cast<bf16x8*>(hi + r * PITCH + sl * 8) = v.hi();
         if (PRECISE) *reinterpret_cast<bf16x8*>(lo + r * PITCH + sl * 8) = v.lo();
       }
@@ -135,14 +141,15 @@ template <typename T, int DH, int MAXR, int NTHR> struct RowBatch {      // [row
 template <typename T, int DH, int MAXR, int NTHR> struct ColBatch {      // transposed: LDS [DH][pitch], element (d, r) = g[r][d]
   static constexpr int DG = DH / 8, IT = ((MAXR / 2) * DG + NTHR - 1) / NTHR;
   Raw8<T> a[IT], b[IT];
+  int rv_;
   __device__ __forceinline__ void load(const T* g, int64_t rs, int rows_valid, int rows_pad) {
     const int np = rows_pad / 2;
+    rv_ = rows_valid;
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
-      const int idx = threadIdx.x + it * NTHR, dg = idx / np, rp = idx - dg * np;
-      const bool in = idx < np * DG;
-      if (in && 2 * rp < rows_valid) a[it].load(g + (int64_t)(2 * rp) * rs + dg * 8); else a[it].zero();
-      if (in && 2 * rp + 1 < rows_valid) b[it].load(g + (int64_t)(2 * rp + 1) * rs + dg * 8); else b[it].zero();
+      const int idx = threadIdx.x + it * NTHR, dg = min(idx / np, DG - 1), rp = idx - (idx / np) * np;
+      a[it].load(g + (int64_t)min(2 * rp, rows_valid - 1) * rs + dg * 8);
+      b[it].load(g + (int64_t)min(2 * rp + 1, rows_valid - 1) * rs + dg * 8);
     }
   }
   template <bool PRECISE> __device__ __forceinline__ void store(int rows_pad, int pitch, bf16* hi, bf16* lo) const {
@@ -151,7 +158,9 @@ template <typename T, int DH, int MAXR, int NTHR> struct ColBatch {      // tran
     for (int it = 0; it < IT; ++it) {
       const int idx = threadIdx.x + it * NTHR, dg = idx / np, rp = idx - dg * np;
       if (idx < np * DG) {
-        const R8<T> u = a[it].get(), w = b[it].get();
+        R8<T> u = a[it].get(), w = b[it].get();
+        if (2 * rp >= rv_) u.zero();
+        if (2 * rp + 1 >= rv_) w.zero();
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
           bf16x2 h; h[0] = (bf16)u.v[c]; h[1] = (bf16)w.v[c];
@@ -256,21 +265,24 @@ __global__ __launch_bounds__(QTHR) void attn_q_kernel(AttnK p) {
   const int qt_first = xs * per + wave;
   Raw8<T> nq[KC], nd[MODE ? KC : 1], no[MODE ? KC : 1];
   float nlse = 0.f;
+  // Unconditional loads (round 5): a tile / row beyond the range re-reads the LAST query row -- such rows are never stored -- and the
+  // zero padding of the head dimension (dh = 48 in a 64-wide fragment) is applied where the fragment is USED.  With `if (ok) load; else
+  // zero` hipcc branched around the load and waited for it -- s_waitcnt vmcnt(0) -- at the join: the "prefetch" of the next tile's Q
+  // was an exposed L2 round trip per tile (seen in the ISA).
   auto fetch = [&](int qt_) {
-    const int q_ = qt_ * 16 + (lane & 15);
-    const bool ok = qt_ < qt_end && q_ < p.Sq;
+    const int q_ = min(qt_ * 16 + (lane & 15), p.Sq - 1);
     const T* qp = reinterpret_cast<const T*>(p.q) + b * p.q_bs + (int64_t)q_ * p.q_rs + h * p.dh;
   #pragma unroll
     for (int kc = 0; kc < KC; ++kc) {
-      const int d0 = kc * 32 + g * 8;
-      if (ok && d0 < p.dh) nq[kc].load(qp + d0); else nq[kc].zero();
+      const int d0 = min(kc * 32 + g * 8, p.dh - 8);
+      nq[kc].load(qp + d0);
       if constexpr (MODE == 1) {
         const T* dop = reinterpret_cast<const T*>(p.dout) + b * p.do_bs + (int64_t)q_ * p.do_rs + h * p.dh;
         const T* op = reinterpret_cast<const T*>(p.o) + b * p.o_bs + (int64_t)q_ * p.o_rs + h * p.dh;
-        if (ok && d0 < p.dh) { nd[kc].load(dop + d0); no[kc].load(op + d0); } else { nd[kc].zero(); no[kc].zero(); }
+        nd[kc].load(dop + d0); no[kc].load(op + d0);
       }
     }
-    if constexpr (MODE == 1) nlse = ok ? p.lse[((int64_t)b * p.H + h) * p.Sq + q_] : 0.f;
+    if constexpr (MODE == 1) nlse = p.lse[((int64_t)b * p.H + h) * p.Sq + q_];
   };
   fetch(qt_first);
   if constexpr (PRECISE) {            // (fp32 test path: the plain loops)
@@ -313,10 +325,13 @@ __global__ __launch_bounds__(QTHR) void attn_q_kernel(AttnK p) {
     const float lse0 = nlse;
   #pragma unroll
     for (int kc = 0; kc < KC; ++kc) {
-      const R8<T> x = nq[kc].get();
+      const bool dpad = kc * 32 + g * 8 >= p.dh;          // (head dimension padded to the fragment width: zeros)
+      R8<T> x = nq[kc].get();
+      if (dpad) x.zero();
       qh[kc] = x.hi(); ql[kc] = x.lo();
       if (MODE) {
-        const R8<T> y = nd[kc].get(), z = no[kc].get();
+        R8<T> y = nd[kc].get(), z = no[kc].get();
+        if (dpad) { y.zero(); z.zero(); }
         doh[kc] = y.hi(); dol[kc] = y.lo();
   #pragma unroll
         for (int e = 0; e < 8; ++e) delta += y.v[e] * z.v[e];
@@ -608,6 +623,8 @@ __global__ __launch_bounds__(QTHR) void attn_qkv_kernel(AttnK p, QkvK xk) {
   const bf16* xg = xk.x + b * xk.x_bs;
 
   bf16x8 nxp[KCX], nx[KCX];
+  // (predicated loads, zero rows beyond the sequence: the unconditional clamped form of attn_q_kernel's fetch measured 1.5 us SLOWER here,
+  //  28.0 -> 29.5 us, three boxes each)
   auto fetch = [&](int t) {
     const int tok = t * 16 + li;
     const bool ok = t < nqt && tok < p.Sq;
