@@ -105,7 +105,7 @@ def lib():
 
 
 EXPORTS = ['gpv_abi_version', 'gpv_build_id', 'gpv_set_option', 'gpv_gemm', 'gpv_conv2d', 'gpv_image_to_nhwc4', 'gpv_maxpool3x3s2',
-           'gpv_attention_fwd', 'gpv_attention_bwd', 'gpv_attention_qkv_fwd', 'gpv_layernorm_fwd', 'gpv_layernorm_bwd', 'gpv_layernorm_pos_fwd', 'gpv_layernorm_bwd2',
+           'gpv_attention_fwd', 'gpv_attention_bwd', 'gpv_attention_qkv_fwd', 'gpv_layernorm_fwd', 'gpv_layernorm_bwd', 'gpv_layernorm_pos_fwd', 'gpv_layernorm_bwd2', 'gpv_linear_layernorm_fwd',
            'gpv_softmax_ce', 'gpv_roi_weights', 'gpv_add', 'gpv_add_rowbcast', 'gpv_colsum', 'gpv_cast',
            'gpv_cast_rowscale_t', 'gpv_prep_conv_weight', 'gpv_embedding', 'gpv_dropout',
            'gpv_relevance_condition', 'gpv_adamw', 'gpv_sumsq', 'gpv_clip_scale', 'gpv_act_fwd', 'gpv_act_bwd', 'gpv_set_seed_device',
@@ -336,6 +336,17 @@ def attention_bwd(q, k, v, o, dout, dq, dk, dv, strides, do_strides, B, H, Sq, S
     a.do_bs, a.do_rs = do_strides
     a.dq, a.dk, a.dv = _p(dq), _p(dk), _p(dv)
     _chk(lib().gpv_attention_bwd(C.byref(a), _stream()), 'gpv_attention_bwd')
+
+
+def linear_layernorm_fwd(a, w, bias, x, gamma, beta, s, y, mean, rstd, rows, eps, drop_p=0.0, seed=0, pos=None, y2=None):
+    """gpv_linear_layernorm_fwd: s = a w^T + bias (written), y = LayerNorm(x + dropout(s)) * gamma + beta, y2 = y + pos rows; width 256, bf16"""
+    if (pos is None) != (y2 is None):
+        raise ValueError('pos and y2 come together')
+    if any(t.dtype != torch.bfloat16 for t in (a, w, x, s, y)):
+        raise TypeError('linear_layernorm_fwd: bf16 activations and weight')
+    _chk(lib().gpv_linear_layernorm_fwd(_p(a), _p(w), _p(_f32(bias)), _p(x), _p(_f32(gamma)), _p(_f32(beta)), _p(s), _p(y), _p(_f32(mean)),
+                                        _p(_f32(rstd)), C.c_int(rows), C.c_int(w.shape[1]), C.c_int(w.shape[0]), C.c_float(eps), C.c_float(drop_p), C.c_uint64(seed),
+                                        _p(pos), C.c_int(0 if pos is None else pos.numel() // w.shape[0]), _p(y2), _stream()), 'gpv_linear_layernorm_fwd')
 
 
 def layernorm_fwd(x, s, gamma, beta, y, mean, rstd, rows, cols, eps, drop_p=0.0, seed=0, pos=None, y2=None):

@@ -746,6 +746,75 @@ class AddLayerNormFn(Function):
         return ((dxr if ctx.needs_input_grad[0] else None), (dsr if ctx.needs_input_grad[1] else None)) + (None,) * (nin - 2)
 
 
+PROJ_LN = os.environ.get('GPV_PROJ_LN', '1') != '0'
+
+
+def proj_layernorm_ok(w, x):
+    """gpv_linear_layernorm_fwd's range: a 256 -> 256 projection in front of a width-256 LayerNorm, bf16 (the DETR attention sublayers)"""
+    return PROJ_LN and RT.dtype == torch.bfloat16 and w.K == 256 and w.N == 256 and x.shape[-1] == 256 and w.bias is not None
+
+
+class ProjAddLayerNormFn(Function):
+    """y = LayerNorm(x + dropout(a w^T + b)) (+ y2 = y + pos) with the projection INSIDE the LayerNorm launch
+    (gpv_linear_layernorm_fwd; transformer.py:153-157, 218-226: out_proj of nn.MultiheadAttention, then norm).  The launch also
+    writes s = a w^T + b where the GEMM would have: the backward is the one of the two launches it replaces -- AddLayerNormFn's
+    (gpv_layernorm_bwd3, the residual's GradChain) followed by LinearFn's (weight / bias gradient deferred, backward-data GEMM)."""
+
+    @staticmethod
+    def forward(ctx, x, a, w, gamma, beta, eps, drop_p, chain=None, pos=None, pos_param=None):
+        ctx.chain = chain.join() if (chain is not None and ctx.needs_input_grad[0]) else None
+        ctx.set_materialize_grads(False)
+        cols = x.shape[-1]
+        x2 = _c(_as_compute(x)).reshape(-1, cols)
+        a2 = _c(_as_compute(a)).reshape(-1, w.K)
+        rows = x2.shape[0]
+        s2 = torch.empty_like(x2)
+        y = torch.empty_like(x2)
+        mean = torch.empty(rows, device=x.device, dtype=torch.float32)
+        rstd = torch.empty_like(mean)
+        seed = RT.next_seed() if drop_p > 0 else 0
+        p2 = None if pos is None else _pos_rows(pos, cols)
+        y2 = None if pos is None else torch.empty_like(x2)
+        hip.linear_layernorm_fwd(a2, w.lp(), w.bias_f32(), x2, None if gamma is None else gamma.detach(), None if beta is None else beta.detach(),
+                                 s2, y, mean, rstd, rows, eps, drop_p, seed, pos=p2, y2=y2)
+        ctx.gamma, ctx.beta, ctx.drop_p, ctx.seed, ctx.shape, ctx.ashape = gamma, beta, drop_p, seed, x.shape, a.shape
+        ctx.w, ctx.pos_param = w, pos_param
+        ctx.save_for_backward(x2, s2, mean, rstd, a2)
+        if pos is None:
+            return y.reshape(x.shape)
+        return y.reshape(x.shape), y2.reshape(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy, dy2=None):
+        nin = 10
+        if dy is None and dy2 is None:
+            return (None,) * nin
+        x2, s2, mean, rstd, a2 = ctx.saved_tensors
+        rows, cols = x2.shape
+        if dy2 is not None:
+            _pos_sink(ctx.pos_param, _c(_as_compute(dy2)).reshape(rows, cols), rows, cols)
+        d1, d2 = _two_grads(dy, dy2, rows, cols)
+        dx = torch.empty_like(x2)
+        ds = torch.empty_like(x2) if ctx.drop_p > 0 else None
+        _ln_backward(d1, d2, x2, s2, ctx.gamma, ctx.beta, mean, rstd, dx, ds, rows, cols, ctx.drop_p, ctx.seed)
+        dxr = dx.reshape(ctx.shape)
+        if ctx.chain is not None and ctx.needs_input_grad[0]:
+            ch = ctx.chain
+            if ch.acc is not None:                      # (a LayerNorm is normally the first consumer to run; if not: one add)
+                t = torch.empty_like(dx)
+                hip.add(dx, _c(ch.acc).reshape(rows, cols), t, t.numel())
+                dxr = t.reshape(ctx.shape)
+            elif ds is None:
+                dxr = dxr.clone()                       # dx doubles as ds here: the chain's later `res` reads must not alias the projection's dz
+            dxr = ch.done(dxr)
+        da = _linear_backward(ctx.w, a2, ds if ds is not None else dx, None, ctx.needs_input_grad[1], ctx.ashape)
+        return ((dxr if ctx.needs_input_grad[0] else None), da) + (None,) * (nin - 2)
+
+
+def proj_add_layernorm(x, a, w, gamma, beta, eps, drop_p=0.0, chain=None, pos=None, pos_param=None):
+    return ProjAddLayerNormFn.apply(x, a, w, gamma, beta, eps, drop_p, chain, pos, pos_param)
+
+
 # gpv_ffn_fused_fwd (csrc/ffn_fused.hip): the sub-layer as one launch.  Correct (tests/test_kernels_gpu.py) and NOT faster as built --
 # 71 us against 71 us at M = 9600, 66 against 42 at M = 3200, step 17.6 - 17.8 against 17.4 - 17.6 ms -- so it is opt-in
 FFN_FUSED = os.environ.get('GPV_FFN_FUSED', '0') == '1'

@@ -48,6 +48,13 @@ class LayerNormP(nn.Module):
         pos (rows broadcast): -> (y, y + pos) from one launch, pos_param: the learned parameter behind pos (gradient sink)"""
         return ops.add_layernorm(x, s, self.weight, self.bias, self.eps, drop_p, chain, pos, pos_param)
 
+    def proj(self, x, a, lin, drop_p=0.0, chain=None, pos=None, pos_param=None):
+        """LayerNorm(x + dropout(lin(a))): the projection inside the LayerNorm launch where the kernel takes it (width 256, bf16)"""
+        w = W(lin.weight, lin.bias)
+        if ops.proj_layernorm_ok(w, x):
+            return ops.proj_add_layernorm(x, a, w, self.weight, self.bias, self.eps, drop_p, chain, pos, pos_param)
+        return self.forward(x, lin(a), drop_p, chain, pos, pos_param)
+
 
 class MultiheadAttention(nn.Module):
     """torch.nn.MultiheadAttention parameters (packed in_proj), HIP attention core."""
@@ -62,12 +69,14 @@ class MultiheadAttention(nn.Module):
         nn.init.xavier_uniform_(self.in_proj_weight)
         nn.init.constant_(self.out_proj.bias, 0.)
 
-    def forward(self, q_in, k_in, v_in, B, Sq, Sk, key_padding_mask=None, causal=False, chains=(None, None, None), kv=None, out_drop=0.0):
+    def forward(self, q_in, k_in, v_in, B, Sq, Sk, key_padding_mask=None, causal=False, chains=(None, None, None), kv=None, out_drop=0.0,
+                no_proj=False):
         """chains: ops.GradChain (or None) of the tensor behind q_in / k_in / v_in -- only where the projection's input gradient
         IS that tensor's gradient (the input itself, or input + a constant position term).
         kv = (K buffer, key column, V buffer, value column, sink_K, sink_V): keys / values already projected, as column slices of
         buffers shared with other layers (ops.multi_linear over all decoder layers; K and V may be the SAME buffer, then one
-        sink); k_in / v_in are then unused"""
+        sink); k_in / v_in are then unused.  no_proj: return the heads' output BEFORE out_proj (the caller folds the projection into
+        the LayerNorm launch: LayerNormP.proj)"""
         E = self.embed_dim
         w, b = self.in_proj_weight, self.in_proj_bias
         cq, ck, cv = chains
@@ -81,7 +90,7 @@ class MultiheadAttention(nn.Module):
             o = ops.attention(bufs, roles, B, self.num_heads, Sq, Sk, self.head_dim, kpm=key_padding_mask,
                               causal=causal, drop_p=self.dropout if self.training else 0.0,
                               sinks=sinks if (sk is not None or sv is not None) else None)
-            return self.out_proj(o, drop_p=out_drop)
+            return o if no_proj else self.out_proj(o, drop_p=out_drop)
         if q_in is k_in and k_in is v_in:
             bufs = [ops.linear(q_in, W(w, b, 0, 3 * E), chain=cq)]
             roles = ((0, 0), (0, E), (0, 2 * E))
@@ -90,7 +99,7 @@ class MultiheadAttention(nn.Module):
                 # q = k = x + pos, value = x: the three projections inside the attention launch (gpv_attention_qkv_fwd)
                 o = ops.attention_qkv(q_in, v_in, W(w, b, 0, 3 * E), B, self.num_heads, Sq, kpm=key_padding_mask,
                                       drop_p=self.dropout if self.training else 0.0, chains=(cq, cv))
-                return self.out_proj(o, drop_p=out_drop)
+                return o if no_proj else self.out_proj(o, drop_p=out_drop)
             bufs = [ops.linear(q_in, W(w, b, 0, 2 * E), chain=cq), ops.linear(v_in, W(w, b, 2 * E, 3 * E), chain=cv)]
             roles = ((0, 0), (0, E), (1, 0))
         elif k_in is v_in:
@@ -102,7 +111,7 @@ class MultiheadAttention(nn.Module):
             roles = ((0, 0), (1, 0), (2, 0))
         o = ops.attention(bufs, roles, B, self.num_heads, Sq, Sk, self.head_dim, kpm=key_padding_mask, causal=causal,
                           drop_p=self.dropout if self.training else 0.0)
-        return self.out_proj(o, drop_p=out_drop)
+        return o if no_proj else self.out_proj(o, drop_p=out_drop)
 
 
 class TransformerEncoderLayer(nn.Module):
@@ -121,7 +130,9 @@ class TransformerEncoderLayer(nn.Module):
         -> (out, out + pos)"""
         p = self.p if self.training else 0.0
         ch = ops.grad_chain(src)                 # src feeds norm1's residual, Wqk (through src + pos, pos constant) and Wv
-        src = self.norm1(src, self.self_attn(qk, qk, src, B, S, S, kpm, chains=(ch, ch, ch)), p, chain=ch)
+        # (out_proj rides in norm1's launch: LayerNormP.proj)
+        o = self.self_attn(qk, qk, src, B, S, S, kpm, chains=(ch, ch, ch), no_proj=True)
+        src = self.norm1.proj(src, o, self.self_attn.out_proj, p, chain=ch)
         return ffn_block(src, self.linear1, self.linear2, self.norm2, p, pos=pos)
 
     def forward_pre(self, src, pos, B, S, kpm, pos_grad=False):
@@ -161,10 +172,10 @@ class TransformerDecoderLayer(nn.Module):
         -> (out, out + query_pos | None)"""
         p = self.p if self.training else 0.0
         ch = ops.grad_chain(tgt)                 # tgt feeds norm1's residual and Wv (and, through tgt + query_pos, Wqk)
-        tgt, tq = self.norm1(tgt, self.self_attn(tgt_qp, tgt_qp, tgt, B, Q, Q, chains=(None, None, ch)), p, chain=ch,
-                             pos=qpos, pos_param=qpos_param)
-        a = self.multihead_attn(tq, mem_pos, memory, B, Q, S, kpm, chains=(None, mem_chain, mem_chain), kv=kv)
-        tgt = self.norm2(tgt, a, p)
+        o = self.self_attn(tgt_qp, tgt_qp, tgt, B, Q, Q, chains=(None, None, ch), no_proj=True)
+        tgt, tq = self.norm1.proj(tgt, o, self.self_attn.out_proj, p, chain=ch, pos=qpos, pos_param=qpos_param)
+        a = self.multihead_attn(tq, mem_pos, memory, B, Q, S, kpm, chains=(None, mem_chain, mem_chain), kv=kv, no_proj=True)
+        tgt = self.norm2.proj(tgt, a, self.multihead_attn.out_proj, p)
         if not emit:
             return ffn_block(tgt, self.linear1, self.linear2, self.norm3, p), None
         return ffn_block(tgt, self.linear1, self.linear2, self.norm3, p, pos=qpos, pos_param=qpos_param)

@@ -331,6 +331,16 @@ int gpv_layernorm_bwd2(const void* dy, const void* dy2, const void* x, const voi
                        const float* rstd, void* dx, void* ds, float* dgamma, float* dbeta, int rows, int cols, float drop_p,
                        uint64_t seed, int dtype, void* stream);
 
+/* The attention sublayer's out-projection AND the LayerNorm behind it in one launch (transformer.py:156-157 norm1(src + dropout1(src2)),
+ * 218-219 / 224-226 in the decoder; nn.MultiheadAttention's out_proj):
+ *   s = a w^T + bias  (rounded to bf16, WRITTEN: the backward -- gpv_layernorm_bwd3, the projection's weight gradient and backward-data
+ *   GEMM -- reads it),  y = LayerNorm(x + dropout(s)) * gamma + beta,  y2 = y + pos[row % pos_rows]  (pos == y2 == NULL: no second output).
+ * a, x, s, y, y2, pos: bf16 [rows, 256] contiguous; w: [256, 256] bf16 (rows = output features); bias, gamma, beta: fp32 [256] (gamma ==
+ * beta == NULL: no affine); mean / rstd: fp32 [rows].  Same dropout words as gpv_layernorm_fwd for (seed, row * 256 + column).
+ * K == N == 256 only (hipErrorInvalidValue otherwise, before anything is launched). */
+int gpv_linear_layernorm_fwd(const void* a, const void* w, const float* bias, const void* x, const float* gamma, const float* beta,
+                             void* s, void* y, float* mean, float* rstd, int rows, int K, int N, float eps, float drop_p, uint64_t seed,
+                             const void* pos, int pos_rows, void* y2, void* stream);
 /* gpv_layernorm_bwd3: the same backward with the column sums taken OFF the launch.  partials != NULL (then dgamma == dbeta == NULL):
  * every workgroup stores its partial [dgamma | dbeta] row to partials[block][2 * cols] (fp32; gpv_layernorm_bwd_blocks(rows, cols)
  * rows -- the grid this library launches for the shape, -1 for a shape it refuses) instead of adding it to dgamma / dbeta with

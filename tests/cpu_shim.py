@@ -183,6 +183,15 @@ def layernorm_fwd(x, s, gamma, beta, y, mean, rstd, rows, cols, eps, drop_p=0.0,
     rstd.copy_(rs)
 
 
+def linear_layernorm_fwd(a, w, bias, x, gamma, beta, s, y, mean, rstd, rows, eps, drop_p=0.0, seed=0, pos=None, y2=None):
+    """gpv_linear_layernorm_fwd: the projection (rounded to the activation dtype, as the launch stores it), then the LayerNorm"""
+    sv = a.float() @ w.float().t()
+    if bias is not None:
+        sv = sv + bias.float()
+    s.copy_(sv.to(s.dtype))
+    layernorm_fwd(x, s, gamma, beta, y, mean, rstd, rows, x.shape[-1], eps, drop_p, seed, pos=pos, y2=y2)
+
+
 def layernorm_bwd(dy, x, s, gamma, mean, rstd, dx, ds, dgamma, dbeta, rows, cols, drop_p=0.0, seed=0, dy2=None):
     assert drop_p == 0.0
     z = x.float().reshape(rows, cols) + (0 if s is None else s.float().reshape(rows, cols))
@@ -394,7 +403,7 @@ def install(only=None):
     """monkeypatch gpv1_amd.hip with the emulations above; returns an uninstall callable.
     `only`: optional list of entry-point names (GPU bisecting: swap single kernels for torch math)."""
     import gpv1_amd.hip as h
-    names = only or ['gemm', 'conv2d', 'attention_fwd', 'attention_bwd', 'attention_qkv_fwd', 'layernorm_fwd', 'layernorm_bwd', 'softmax_ce',
+    names = only or ['gemm', 'conv2d', 'attention_fwd', 'attention_bwd', 'attention_qkv_fwd', 'layernorm_fwd', 'layernorm_bwd', 'linear_layernorm_fwd', 'softmax_ce',
              'image_to_nhwc4', 'maxpool3x3s2', 'stem_pool', 'conv1x1_dual', 'conv1x1_chain', 'ffn_fused_fwd', 'conv_wgrad_group', 'roi_weights', 'add', 'add_rowbcast', 'colsum', 'cast', 'cast_rowscale_t',
              'prep_conv_weight', 'embedding', 'dropout', 'relevance_condition', 'adamw', 'sumsq', 'clip_scale', 'act_fwd', 'act_bwd',
              'cast_transpose_group', 'argmax_rows', 'ln_linear_rows', 'attention_row_proj']

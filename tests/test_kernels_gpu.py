@@ -942,6 +942,41 @@ def test_attention_with_in_projection_equals_the_three_launches(Bn, S, use_kpm, 
         assert ((o.float() - o2.float()).abs() > 0.05 * o2.float().abs().max()).float().mean().item() < 1e-4   # outputs would differ by whole terms
 
 
+@pytest.mark.parametrize('rows,drop,with_pos,affine', [(9600, 0.1, True, True), (3200, 0.1, True, True), (3200, 0.1, False, True), (300, 0.0, False, True),
+                                                       (100, 0.25, True, False), (37, 0.0, True, True), (16, 0.1, False, True), (4099, 0.1, True, True)])
+def test_linear_layernorm_one_launch_equals_gemm_then_layernorm(rows, drop, with_pos, affine):
+    """gpv_linear_layernorm_fwd (out-projection inside the LayerNorm launch, transformer.py:153-157) against the two launches it replaces on
+    the same operands and seed: s within one bf16 rounding of the GEMM's (same products, possibly another fp32 order), y / y2 / mean / rstd
+    from the SAME rounded s and dropout words (row sums in another order: last-bit differences), and against fp32 math"""
+    h, dt, D = hip(), torch.bfloat16, 256
+    a, x = rnd(rows, D, dtype=dt, seed=41), rnd(rows, D, dtype=dt, seed=42)
+    w, bias = rnd(D, D, dtype=dt, seed=43, scale=D ** -0.5), rnd(D, seed=44, scale=0.3)
+    gamma, beta = (rnd(D, seed=45) * 0.2 + 1.0, rnd(D, seed=46) * 0.1) if affine else (None, None)
+    npos = 100 if rows % 100 == 0 else rows
+    pos = rnd(npos, D, dtype=dt, seed=47, scale=0.5) if with_pos else None
+    mk = lambda: torch.full((rows, D), float('nan'), device=DEV, dtype=dt)
+    s1, y1, z1 = mk(), mk(), (mk() if with_pos else None)
+    m1, r1 = torch.empty(rows, device=DEV), torch.empty(rows, device=DEV)
+    h.linear_layernorm_fwd(a, w, bias, x, gamma, beta, s1, y1, m1, r1, rows, 1e-5, drop_p=drop, seed=123, pos=pos, y2=z1)
+    s0, y0, z0 = mk(), mk(), (mk() if with_pos else None)
+    m0, r0 = torch.empty(rows, device=DEV), torch.empty(rows, device=DEV)
+    h.gemm(a, w, s0, rows, D, D, D, D, D, bias=bias)
+    h.layernorm_fwd(x, s0, gamma, beta, y0, m0, r0, rows, D, 1e-5, drop_p=drop, seed=123, pos=pos, y2=z0)
+    assert rel(s1, a.float() @ w.float().t() + bias) < TOL[dt]
+    assert rel(s1, s0.float()) < 8e-3
+    same = (s1 == s0).all(1)                                   # rows whose projected values are bit-identical: everything downstream must agree closely
+    assert same.float().mean().item() > 0.5
+    assert torch.isfinite(y1.float()).all()
+    assert (y1.float()[same] - y0.float()[same]).abs().max().item() <= 2 ** -6 * max(1.0, y0.float().abs().max().item())      # (one bf16 ulp at |y| ~ 4)
+    assert (m1[same] - m0[same]).abs().max().item() < 1e-5 and (r1[same] / r0[same] - 1).abs().max().item() < 1e-5
+    if with_pos:
+        assert torch.equal(z1, (y1.float() + pos.float().repeat(rows // npos, 1)).to(dt))
+    if drop == 0:
+        v = x.float() + s1.float()
+        ref = F.layer_norm(v, (D,), gamma, beta, 1e-5)
+        assert rel(y1, ref) < TOL[dt]
+
+
 ATT1 = [  # H, dh, Sq, Sk, causal, kpm, drop: the model's shapes at B = 32 + ragged ones around the tile / strip boundaries
     (8, 32, 300, 300, False, True, 0.1), (8, 32, 300, 300, False, False, 0.0), (8, 32, 100, 300, False, True, 0.1),
     (8, 32, 100, 100, False, False, 0.1), (16, 48, 100, 6, False, False, 0.1), (16, 48, 6, 100, False, False, 0.1),
