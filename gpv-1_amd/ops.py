@@ -969,9 +969,11 @@ def attention(bufs, roles, B, H, Sq, Sk, dh, kpm=None, causal=False, drop_p=0.0,
 ATTN_QKV = os.environ.get('GPV_ATTN_QKV', '1') != '0'
 
 
-def attention_qkv_ok(E, H, S, causal):
-    """gpv_attention_qkv_fwd's range: the DETR encoder / decoder self-attention (width 256, 8 heads of 32, <= 320 tokens, bf16)"""
-    return ATTN_QKV and RT.dtype == torch.bfloat16 and E == 256 and H == 8 and 0 < S <= 320 and not causal
+def attention_qkv_ok(E, H, S, causal, B=None):
+    """gpv_attention_qkv_fwd's range: the DETR encoder / decoder self-attention (width 256, 8 heads of 32, <= 320 tokens, bf16); one
+    workgroup per (batch, head) multiplies all of its rows: below 64 of them (batch-1 inference: 8) the projection GEMMs, which
+    spread over the chip, are faster (23 us against 21 at batch 1)"""
+    return ATTN_QKV and RT.dtype == torch.bfloat16 and E == 256 and H == 8 and 0 < S <= 320 and not causal and (B is None or B * H >= 64)
 
 
 class SelfAttnQKVFn(Function):

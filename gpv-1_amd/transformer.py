@@ -95,7 +95,7 @@ class MultiheadAttention(nn.Module):
             bufs = [ops.linear(q_in, W(w, b, 0, 3 * E), chain=cq)]
             roles = ((0, 0), (0, E), (0, 2 * E))
         elif q_in is k_in:
-            if Sq == Sk and ops.attention_qkv_ok(E, self.num_heads, Sq, causal):
+            if Sq == Sk and ops.attention_qkv_ok(E, self.num_heads, Sq, causal, B):
                 # q = k = x + pos, value = x: the three projections inside the attention launch (gpv_attention_qkv_fwd)
                 o = ops.attention_qkv(q_in, v_in, W(w, b, 0, 3 * E), B, self.num_heads, Sq, kpm=key_padding_mask,
                                       drop_p=self.dropout if self.training else 0.0, chains=(cq, cv))
