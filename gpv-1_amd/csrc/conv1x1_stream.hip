@@ -39,10 +39,10 @@ template <int K, int NH, bool RES, bool MASK, bool NT, bool LIN = false, int NP 
 __global__ __launch_bounds__(512) void c1s_kernel(GemmK p, int ncols) {
   // ncols: output channels per block row (gridDim.y slices of a wide layer: layer3's 1024 channels as four 256-channel
   // problems that share A -- the weights of one slice fit the LDS, A is small next to the output)
-  constexpr int KP = K + 8, KC = K / 32, NTL = NH / 16, NG = NH / 32, SL = K / 8;
+  constexpr int KC = K / 32, NTL = NH / 16, NG = NH / 32, SL = K / 8, ROWB = K * 2;      // LDS row = K bf16, no padding: XOR swizzle (below)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   bf16* Wl = reinterpret_cast<bf16*>(smem_raw);
-  float* bias_l = reinterpret_cast<float*>(Wl + (size_t)ncols * KP);
+  float* bias_l = reinterpret_cast<float*>(Wl + (size_t)ncols * K);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, pl = lane & 15;
   const int cbase = (int)blockIdx.y * ncols;
   const bf16* A = reinterpret_cast<const bf16*>(p.A);
@@ -75,10 +75,28 @@ __global__ __launch_bounds__(512) void c1s_kernel(GemmK p, int ncols) {
     for (int kc = 0; kc < KC; ++kc) an[kc] = *reinterpret_cast<const bf16x8*>(A + ipx * p.lda + kc * 32 + g * 8);
   };
   fetch(tile);
-  stage_chunks16<512, 8>(p.N * SL, tid,
-      [&](int idx) { const int L = idx / SL, sl = idx - L * SL; return Wg + (int64_t)c1s_chan<NH>(L) * p.ldb + sl * 8; },
-      [&](int idx) { const int L = idx / SL, sl = idx - L * SL; return Wl + L * KP + sl * 8; });
+  // The weights go L2 -> LDS by DMA (buffer_load ... lds: no staging registers, a wave's whole share in flight at once -- through
+  // registers the 128 KB of a 256 x 256 slice were dependent round trips of eight loads per thread: 16 K cycles before round 5's
+  // unconditional loads, ~ 8 K after, 4 K by DMA, timed with s_memtime in linear_ln.hip).  The DMA writes lane-linear 1 KB images
+  // (instruction i = LDS rows i R .. i R + R - 1, R = 512 / K; lane = (row, 16-byte slot)), so the bank-conflict-free layout is made on
+  // the SOURCE side: slot s of LDS row L receives chunk s ^ swz(L) of channel chan(L), swz(L) = L & 15 (K >= 128: a row covers all 64
+  // banks at least once) | (L >> 1) & 7 (K = 64: two rows per 256 bytes), and the fragment read of chunk c of row L looks at slot
+  // c ^ swz(L) -- checked against the ds_read_b128 lane groups of MI355X_MICROARCH.md ({0-3, 12-15, 20-27}, ...: g pairs (0,1), (2,3)).
+  {
+    typedef __attribute__((address_space(3))) void lds_void_t;
+    constexpr int OOB = 0x7ffffff0, R = 512 / K, SPR = K / 8;
+    const auto rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(Wg), (short)0, OOB, 0x00020000);
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const int ninst = p.N * K / 512;                         // 1 KB each; a multiple of 8 (N, K multiples of 64)
+    for (int i = wv; i < ninst; i += 8) {
+      const int L = i * R + (R > 1 ? lane / SPR : 0), sl = lane % SPR;
+      const int sw = K >= 128 ? (L & 15) : ((L >> 1) & 7);
+      const int voff = (c1s_chan<NH>(L) * (int)p.ldb + ((sl ^ sw) * 8)) * 2;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_void_t*)(smem_raw + i * 1024), 16, voff, 0, 0, 0);
+    }
+  }
   for (int c = tid; c < p.N; c += 512) bias_l[c] = bias_g ? bias_g[c] : 0.f;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (this wave's DMA pieces have landed; the barrier orders everyone's for the fragment reads)
   __syncthreads();
 
   // LIN dropout (round 5): the keep words of common.h's drop_pair_bits, bit for bit, at a tenth of the instructions.  The epilogue below
@@ -132,14 +150,16 @@ __global__ __launch_bounds__(512) void c1s_kernel(GemmK p, int ncols) {
       f32x4 acc[NTL];
 #pragma unroll
       for (int j = 0; j < NTL; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-      int woff = (h * NH + pl) * KP + g * 8;
+      int woff = (h * NH + pl) * ROWB;               // bytes
       asm volatile("" : "+v"(woff));                 // opaque per tile: with the pass loop unrolled the fragment reads are loop-invariant and hipcc hoists all 128 of them out of the tile loop (into scratch)
-      const bf16* wrow = Wl + woff;
+      const unsigned char* wrow = smem_raw + woff;
+      const int tx = (g ^ (K >= 128 ? pl : (pl >> 1))) * 16;       // chunk 4 kc + g of row L sits in slot (4 kc + g) ^ swz(L) = 4 kc ^ (g ^ swz)
 #pragma unroll
       for (int kc = 0; kc < KC; ++kc) {
+        const unsigned char* wk = wrow + ((kc * 64) ^ tx);
 #pragma unroll
         for (int j = 0; j < NTL; ++j) {
-          const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wrow + j * 16 * KP + kc * 32);
+          const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wk + j * 16 * ROWB);
           acc[j] = mfma16s(wf, af[kc], acc[j]);
         }
       }
@@ -219,9 +239,8 @@ inline int c1s_cols(int K, int N) {
 
 template <int K, int NH, bool RES, bool MASK, bool NT, bool LIN = false, int NP = 1>
 int c1s_launch_np(const GemmK& k, hipStream_t st) {
-  constexpr int KP = K + 8;
   const int ncols = c1s_cols(k.K, k.N), nsl = k.N / ncols;
-  const size_t lds = (size_t)ncols * KP * 2 + (size_t)ncols * sizeof(float);
+  const size_t lds = (size_t)ncols * K * 2 + (size_t)ncols * sizeof(float);
   auto fn = c1s_kernel<K, NH, RES, MASK, NT, LIN, NP>;
   static size_t attr = 0;
   if (lds > 64 * 1024 && lds > attr) {
