@@ -197,6 +197,27 @@ def attention_roofline(dev, B):
         out[name] = e0.elapsed_time(e1) / 20 * 1e3
     fl = 4.0 * B * H * S * S * dh
     tf = fl / (out['fwd'] * 1e-6) / 1e12
+    # the launch the encoder layers actually run since round 5: q | k | v projections + core in ONE launch (gpv_attention_qkv_fwd);
+    # flops = projections (2 M 256 768) + core ("with projections")
+    g2 = torch.Generator().manual_seed(6)
+    x = torch.randn(B * S, D, generator=g2).to(dev).to(torch.bfloat16)
+    xp = (x.float() + torch.randn(B * S, D, generator=g2).to(dev)).to(torch.bfloat16)
+    w = (torch.randn(3 * D, D, generator=g2) / 16).to(dev).to(torch.bfloat16)
+    bias = torch.randn(3 * D, generator=g2).to(dev)
+
+    def fused():
+        hip.attention_qkv_fwd(xp, x, w, bias, qk[:, :D], qk[:, D:], v, o, st, B, H, S, scale, drop_p=0.1, seed=11, lse=lse)
+    for _ in range(3):
+        fused()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        fused()
+    e1.record()
+    torch.cuda.synchronize()
+    fused_us = e0.elapsed_time(e1) / 20 * 1e3
+    fl_proj = 2.0 * B * S * D * 3 * D
+    fused_tf = (fl + fl_proj) / (fused_us * 1e-6) / 1e12
     # The VALU ceiling the core sits under: instruction count x issue rate.  SQ_INSTS_VALU of the forward launch at
     # this shape = 4.579e6 wave-instructions (profiles/r03_pmc_attention.txt: rocprofv3 --pmc, per launch, B = 32); a wave64 VALU
     # instruction occupies its SIMD16 for 4 cycles, v_exp_f32 (one per score and lane: B h S^2 / 64 = 3.6e5 of them) for 16; the
@@ -214,6 +235,8 @@ def attention_roofline(dev, B):
             'bwd_kernel': 'attn_bwd1_kernel<32,32,20,20> (dQ, dK, dV in ONE launch: S formed once, dS transposed through LDS for the dQ product; '
                           'round 3: attn_q_kernel<..,1> + attn_kv2_kernel, 55 us)',
             'bwd_tflops': 2.5 * fl / (out['bwd'] * 1e-6) / 1e12,
+            'with_projections': {'kernel': 'attn_qkv_kernel<20> (q | k | v in-projection + core in one launch: what an encoder layer runs)',
+                                 'flops_per_launch': fl + fl_proj, 'avg_launch_us': fused_us, 'achieved': fused_tf, 'frac': fused_tf / 2500.0},
             'note': 'dh = 32: 2 MFMAs per 256 scores against ~12 VALU instructions per score -- the core is VALU-bound, see DESIGN.md'}
 
 
