@@ -134,6 +134,38 @@ for it in range(max(rounds // 3, 2)):
             r = T.rel(q[2], ref)
             assert r < 1e-5, (q[4:], r)
     run('wgrad_group', one)
+# round 5: the fused in-projection attention and the projection + LayerNorm launch on random batch / sequence sizes, the small-M kernel's
+# three tile shapes, the streaming 1x1 kernel (DMA-staged, swizzled weights) as a plain GEMM on every (K, N) it instantiates
+for it in range(rounds):
+    run('attention_qkv', T.test_attention_with_in_projection_equals_the_three_launches, rng.randint(1, 40), rng.randint(2, 320), rng.random() < 0.5,
+        rng.choice([0.0, 0.1, 0.25]))
+    run('linear_layernorm', T.test_linear_layernorm_one_launch_equals_gemm_then_layernorm, rng.randint(1, 12000), rng.choice([0.0, 0.1, 0.25]),
+        rng.random() < 0.5, rng.random() < 0.8)
+    prev = h.set_option(h.OPT_SKINNY, 2); prevg = h.set_option(h.OPT_GLDS, 0)
+    run('skinny', T.test_skinny_gemm.__wrapped__ if hasattr(T.test_skinny_gemm, '__wrapped__') else T.test_skinny_gemm, h, rng.randint(1, 700), 8 * rng.randint(1, 300),
+        8 * rng.randint(1, 400))
+    run('skinny_bt', T.test_skinny_gemm_reduction_major_b.__wrapped__ if hasattr(T.test_skinny_gemm_reduction_major_b, '__wrapped__') else T.test_skinny_gemm_reduction_major_b,
+        h, rng.randint(1, 3300), 8 * rng.randint(1, 100), 8 * rng.randint(1, 300))
+    h.set_option(h.OPT_SKINNY, prev); h.set_option(h.OPT_GLDS, prevg)
+
+    def c1s_case():
+        K = rng.choice([64, 128, 256, 512])
+        N = rng.choice([n for n in (64, 128, 256, 512, 1024, 2048) if n * (K + 8) <= 75 * 1024 * max(1, n // (512 if K <= 128 else 256 if K == 256 else 128))])
+        M = rng.randint(1, 70000)
+        A, B = T.rnd(M, K, dtype=torch.bfloat16, seed=3), T.rnd(N, K, dtype=torch.bfloat16, seed=4, scale=K ** -0.5)
+        bias = T.rnd(N, seed=5)
+        res = T.rnd(M, N, dtype=torch.bfloat16, seed=6) if rng.random() < 0.5 else None
+        Cm = torch.full((M, N), float('nan'), device=T.DEV, dtype=torch.bfloat16)
+        prevc = h.set_option(h.OPT_C1S, 2)
+        h.set_option(h.OPT_C1S_LAUNCHES, 0)
+        try:
+            h.gemm(A, B, Cm, M, N, K, K, K, N, bias=bias, res=res, ldr=N, act=h.ACT_RELU)
+        finally:
+            used = h.set_option(h.OPT_C1S_LAUNCHES, 0)
+            h.set_option(h.OPT_C1S, prevc)
+        ref = F.relu(A.float() @ B.float().t() + bias + (res.float() if res is not None else 0))
+        assert T.rel(Cm, ref) < T.TOL[torch.bfloat16], ('c1s', M, N, K, used, T.rel(Cm, ref))
+    run('c1s_plain', c1s_case)
 print('fuzz done: %d failures (%d attention shapes refused as out of range)' % (len(fails), out_of_range))
 for f in fails:
     print(f)
