@@ -72,8 +72,16 @@ extern long g_c3s_launches;
 // round's slots, more than 384 tiles), 0 = none
 extern int g_two_per_cu;
 extern int g_kernel_forced;
+extern int g_bm96_fill;
 inline int two_per_cu_bm(const GemmK& k, int batch) {
   if (k.N % 128 != 0 || batch != 1) return 0;
+  if (g_bm96_fill && k.M <= 1024) {
+    // round 5, measured (tools/bench_skinny_pf.py, GPV_BM96 in the tuning build): at <= 1024 rows the two-per-CU 96 x 128 direct-to-LDS kernel beats the
+    // small-M kernel wherever 96-row tiles are more tiles than 128-row ones -- 640 x 768 x 2048 15.4 -> 10.6 us, 640 x 768 x 768 8.5 -> 6.6,
+    // 100 x 768 x 768 7.9 -> 6.5 -- and loses on the 3200- / 9600-row GEMMs (9600 x 256 x 2048 23.6 -> 25.1, 3200 x 768 x 3072 32.1 -> 33.3)
+    const int64_t t128 = (int64_t)((k.M + 127) / 128) * (k.N / 128), t96 = (int64_t)((k.M + 95) / 96) * (k.N / 128);
+    if (t96 <= 256 && t96 * 10 >= t128 * 12) return 96;
+  }
   int best = 0;
   double best_u = 0.0;
   for (int bm : {160, 96}) {

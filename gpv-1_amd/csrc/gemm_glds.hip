@@ -410,6 +410,7 @@ int launch_glds_out(const GemmK& k, int dtype_out, int batch, hipStream_t st) {
 }  // namespace
 int g_kernel_forced = 0;      // bit 0: GPV_OPT_GLDS >= 2, bit 1: GPV_OPT_PIPE >= 100 -- a kernel family is being forced (tests / tuning): the small-problem side paths step aside
 int g_two_per_cu = tune_env("GPV_TWO_PER_CU", 1);
+int g_bm96_fill = tune_env("GPV_BM96", 1);       // 96-row tiles for <= 1024-row GEMMs (gemm_common.h two_per_cu_bm)
 namespace {
 int g_glds_mode = tune_env("GPV_GLDS", 1);   // gpv_set_option(GPV_OPT_GLDS, .)
 
