@@ -20,7 +20,7 @@ def load(d, counter):
 
 def is_conv(name):
     n = name.replace('(anonymous namespace)::', '')
-    if 'c1s_kernel' in n and re.search(r', true>\(', n):      # LIN instances: the K = 256 -> 2048 linear GEMMs of the transformer (gpv_gemm), not convolutions
+    if 'c1s_kernel' in n and re.search(r', true(, \d+)?>\(', n):      # (round 5: a trailing pass-count argument)      # LIN instances: the K = 256 -> 2048 linear GEMMs of the transformer (gpv_gemm), not convolutions
         return False
     return (('gemm_kernel' in n and 'Li2ELi0E' in n) or ('gemm_kernel<' in n and ', 1, 2, ' in n) or 'glds_kernelILi2E' in n or 'conv1x1_kernel' in n
             or 'glds_wgrad_kernel' in n or 'pipe_kernelILi2E' in n or 'c1s_kernel' in n or 'conv1x1_nt_kernel' in n
