@@ -53,6 +53,7 @@ int glds_try_launch(const GemmK& k, int amode, int dtype_in, int dtype_out, int 
 // Same return convention; tried before glds_try_launch.
 int pipe_try_launch(const GemmK& k, int amode, int dtype_in, int dtype_out, int batch, hipStream_t st);
 int pipe_set_mode(int v);
+int pipe_set_small(int v);     // gpv_set_option(GPV_OPT_PIPE_SMALL, .)
 long pipe_launches(long set);
 
 // conv1x1_stream.hip: streaming kernel for the K <= 256 pointwise convolutions over >= 65536 pixels (weights resident in LDS,

@@ -501,6 +501,7 @@ extern "C" int gpv_set_option(int option, int value) {
     gpvk::g_wg8_mode = value;
     return prev;
   }
+  if (option == GPV_OPT_PIPE_SMALL) return gpvk::pipe_set_small(value);
   if (option == GPV_OPT_W8L) {
     const int prev = gpvk::g_w8l_mode;
     gpvk::g_w8l_mode = value;

@@ -479,6 +479,7 @@ int launch_cfg_idx(int idx, const GemmK& k, int batch, hipStream_t st) {
   return -1;
 }
 
+int g_pipe_small = tune_env("GPV_PIPE_SMALL", 1);   // the small-M configurations (64 x 64 / 32 x 64, 6 / 8 stages)
 int g_pipe_mode = tune_env("GPV_PIPE", 1);   // 0 off, 1 heuristic, 100+i: force configuration i wherever legal
 
 inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
@@ -523,7 +524,7 @@ int pipe_try_launch(const GemmK& k, int amode, int dtype_in, int dtype_out, int 
   if (mode >= 100) {
     idx = mode - 100;
     if (idx >= kNumCfgs || k.N % kCfgs[idx].bn != 0 || (idx >= kNumBig && amode != OP_PLAIN)) return -1;
-  } else if (amode == OP_PLAIN && !k.conv1x1 && k.K >= 256 &&
+  } else if (g_pipe_small && amode == OP_PLAIN && !k.conv1x1 && k.K >= 256 &&
              (int64_t)((k.M + 63) / 64) * (k.N / 64) * batch <= 250 &&
              ((int64_t)((k.M + 63) / 64) * (k.N / 64) * batch >= 100 || k.K <= 1024)) {
     // small-M GEMMs (BERT and the co-attention text stream at M = 192, the text decoder at 640 rows): too few 64x64 tiles to
@@ -549,6 +550,7 @@ int pipe_try_launch(const GemmK& k, int amode, int dtype_in, int dtype_out, int 
 }
 
 int pipe_set_mode(int v) { const int prev = g_pipe_mode; g_pipe_mode = v; return prev; }
+int pipe_set_small(int v) { const int prev = g_pipe_small; g_pipe_small = v; return prev; }
 long pipe_launches(long set) { const long prev = g_pipe_launches; if (set >= 0) g_pipe_launches = set; return prev; }
 
 }  // namespace gpvk

@@ -123,12 +123,27 @@ def build_id():
 
 OPT_GLDS, OPT_GLDS_LAUNCHES, OPT_SKINNY, OPT_GLDS_WGRAD, OPT_PIPE, OPT_PIPE_LAUNCHES, OPT_C1S, OPT_C3S, OPT_C3S_LAUNCHES = 0, 1, 2, 3, 4, 5, 6, 7, 8
 OPT_GEMV, OPT_GEMV_LAUNCHES = 9, 10
-OPT_ATTN_BWD1, OPT_ATTN_BWD1_LAUNCHES, OPT_C1S_LAUNCHES, OPT_WG8, OPT_WG8_LAUNCHES, OPT_W8L = 11, 12, 13, 14, 15, 16
+OPT_ATTN_BWD1, OPT_ATTN_BWD1_LAUNCHES, OPT_C1S_LAUNCHES, OPT_WG8, OPT_WG8_LAUNCHES, OPT_W8L, OPT_PIPE_SMALL = 11, 12, 13, 14, 15, 16, 17
 
 
 def set_option(option, value):
     """gpv_set_option: kernel-selection knob (tests / tuning); returns the previous value"""
     return lib().gpv_set_option(C.c_int(option), C.c_int(value))
+
+
+class option:
+    """with hip.option(OPT_X, v): ... -- a kernel-selection option for the launches (or the graph capture) inside the block"""
+
+    def __init__(self, opt, value):
+        self.opt, self.value = opt, value
+
+    def __enter__(self):
+        self.prev = set_option(self.opt, self.value)
+        return self
+
+    def __exit__(self, *exc):
+        set_option(self.opt, self.prev)
+        return False
 
 
 _SEED_DEV = None

@@ -81,6 +81,8 @@ int gpv_gemm_tt_group_ws(const gpv_tt_problem* problems, int n, void* workspace,
 #define GPV_OPT_ATTN_BWD1_LAUNCHES 12 /* returns the number of single-launch attention backwards so far, then sets the counter to value (value >= 0) */
 #define GPV_OPT_WG8 14 /* eight-phase 256 x 256 weight-gradient kernel (gemm_glds_tt.hip wg8_*) in gpv_conv_wgrad_group, problems with Cout, Cin multiples of 256: 0 never, 1 (default) when the call holds >= 128 such work units, 2 wherever legal */
 #define GPV_OPT_WG8_LAUNCHES 15 /* returns the number of eight-phase weight-gradient launches (conv and linear) so far, then sets the counter to value */
+#define GPV_OPT_PIPE_SMALL 17 /* gemm_pipe.hip's small-M configurations (64 x 64 / 32 x 64 tiles, 6 / 8 stages): 1 (default) by heuristic, 0 never -- the inference paths switch them off
+                                 (greedy batch 64: 15.0 -> 14.05 ms per batch; the training step's backward shapes prefer them: B1 +0.1 ms without) */
 #define GPV_OPT_W8L 16 /* the same kernel in gpv_gemm_tt_group_ws (problems with M, N multiples of 256): 0 (default) never, 1 wherever legal */
 #define GPV_OPT_C1S_LAUNCHES 13 /* returns the number of streaming-1x1 launches so far (convolutions and the K = 256 linear GEMMs), then sets the counter to value */
 int gpv_set_option(int option, int value);
