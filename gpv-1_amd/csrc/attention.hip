@@ -601,15 +601,15 @@ struct QkvK { const bf16* xp; const bf16* x; int64_t x_bs, x_rs; const bf16* w; 
 template <int NT, bool FULL>
 __global__ __launch_bounds__(QTHR) void attn_qkv_kernel(AttnK p, QkvK xk) {
   if (p.dthresh) p.seed = eff_seed(p.seed, p.seed_dev);
-  constexpr int DH = 32, KP = DH + 8, KD = 256, WP = KD + 8, KCX = KD / 32, DT = 2, NR = (NT + QW - 1) / QW;
+  constexpr int DH = 32, KP = DH + 8, KD = 256, WROW = KD * 2, KCX = KD / 32, DT = 2, NR = (NT + QW - 1) / QW;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   bf16* sm = reinterpret_cast<bf16*>(smem_raw);
   const int skp = FULL ? NT * 16 : p.skp, ntr = FULL ? NT : skp / 16, vtp = skp + 8;
   bf16* Kh = sm;                                          // K[skp][KP], d in k-slot order
   bf16* Th = Kh + skp * KP;                               // V^T[DH][vtp]
   float* kbias = reinterpret_cast<float*>(Th + DH * vtp);
-  bf16* Wl = reinterpret_cast<bf16*>(kbias + skp);        // rows 0..31 Wq_h, 32..63 Wk_h, 64..95 Wv_h, [96][WP]
-  float* bl = reinterpret_cast<float*>(Wl + 96 * WP);     // the 96 biases
+  bf16* Wl = reinterpret_cast<bf16*>(kbias + skp);        // rows 0..31 Wq_h, 32..63 Wk_h, 64..95 Wv_h: [96][256] bf16, 16-byte slots XOR-swizzled by (row & 15)
+  float* bl = reinterpret_cast<float*>(Wl + 96 * KD);     // the 96 biases
   int b, h;
   {
     const int total = (int)gridDim.x;
@@ -640,16 +640,30 @@ __global__ __launch_bounds__(QTHR) void attn_qkv_kernel(AttnK p, QkvK xk) {
     }
   };
   fetch(wave);
-  stage_chunks16<QTHR, 6>(96 * (KD / 8), tid,
-      [&](int idx) { const int r = idx >> 5, c = idx & 31; return xk.w + (int64_t)((r >> 5) * KD + h * DH + (r & 31)) * KD + c * 8; },
-      [&](int idx) { const int r = idx >> 5, c = idx & 31; return Wl + r * WP + c * 8; });
+  // this head's 96 weight rows go L2 -> LDS by DMA, 512-byte rows without padding, the bank swizzle made on the source side (slot s of row L
+  // <- chunk s ^ (L & 15): linear_ln.hip / conv1x1_stream.hip); 48 instructions of 1 KB, six per wave, all in flight with the first rows of x
+  {
+    typedef __attribute__((address_space(3))) void lds_void_t;
+    constexpr int OOB = 0x7ffffff0;
+    const auto rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(xk.w), (short)0, OOB, 0x00020000);
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int inst = wv * 6 + i;
+      const int L = inst * 2 + (lane >> 5), sl = lane & 31;
+      const int voff = (((L >> 5) * KD + h * DH + (L & 31)) * KD + ((sl ^ (L & 15)) * 8)) * 2;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_void_t*)(reinterpret_cast<unsigned char*>(Wl) + inst * 1024), 16, voff, 0, 0, 0);
+    }
+  }
   if (tid < 96) bl[tid] = xk.bias ? xk.bias[(tid >> 5) * KD + h * DH + (tid & 31)] : 0.f;
   for (int idx = tid; idx < skp; idx += QTHR)
     kbias[idx] = (idx >= p.Sk || (p.kpm && p.kpm[(int64_t)b * p.Sk + idx])) ? -INFINITY : 0.f;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (this wave's DMA pieces have landed; the barrier orders everyone's for the fragment reads)
   __syncthreads();
 
   // ---- projections: this wave's token tiles (tiles beyond the sequence are multiplied too -- zero rows + bias: the padded K rows and
   // V^T columns must hold finite values, their probabilities are exactly 0) ----
+  const int wtx = (g ^ li) * 16;                          // chunk 4 kc + g of weight row (16 n + li) sits in slot (4 kc + g) ^ li = 4 kc ^ (g ^ li)
   bf16x8 qreg[NR];
   bf16* qg = reinterpret_cast<bf16*>(const_cast<void*>(p.q)) + b * p.q_bs + h * DH;
   bf16* kg = reinterpret_cast<bf16*>(const_cast<void*>(p.k)) + b * p.k_bs + h * DH;
@@ -675,10 +689,10 @@ __global__ __launch_bounds__(QTHR) void attn_qkv_kernel(AttnK p, QkvK xk) {
       for (int kc = 0; kc < KCX; ++kc) {
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
-          const bf16* wr = Wl + (dt * 16 + li) * WP + kc * 32 + g * 8;
+          const unsigned char* wr = reinterpret_cast<const unsigned char*>(Wl) + (dt * 16 + li) * WROW + ((kc * 64) ^ wtx);
           const bf16x8 wq = *reinterpret_cast<const bf16x8*>(wr);
-          const bf16x8 wk = *reinterpret_cast<const bf16x8*>(wr + 32 * WP);
-          const bf16x8 wv = *reinterpret_cast<const bf16x8*>(wr + 64 * WP);
+          const bf16x8 wk = *reinterpret_cast<const bf16x8*>(wr + 32 * WROW);
+          const bf16x8 wv = *reinterpret_cast<const bf16x8*>(wr + 64 * WROW);
           aq[dt] = mfma16(wq, xpf[kc], aq[dt]);
           ak[dt] = mfma16(wk, xpf[kc], ak[dt]);
           av[dt] = mfma16(xf[kc], wv, av[dt]);
@@ -1568,8 +1582,8 @@ extern "C" int gpv_attention_fwd(const gpv_attn_args* a, void* stream) {
 
 template <int NT, bool FULL>
 int launch_qkv(AttnK p, const QkvK& xk, hipStream_t st) {
-  constexpr int KP = 40, WP = 264;
-  const size_t lds = ((size_t)p.skp * KP + (size_t)32 * (p.skp + 8) + (size_t)96 * WP) * 2 + (size_t)p.skp * 4 + 96 * 4;
+  constexpr int KP = 40;
+  const size_t lds = ((size_t)p.skp * KP + (size_t)32 * (p.skp + 8) + (size_t)96 * 256) * 2 + (size_t)p.skp * 4 + 96 * 4;
   auto fn = attn_qkv_kernel<NT, FULL>;
   static bool attr = false;
   if (!attr) {
