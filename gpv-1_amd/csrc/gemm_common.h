@@ -119,5 +119,6 @@ extern int g_wgrad_mode;
 extern int g_wg8_mode;
 extern long g_wg8_launches;
 extern int g_w8l_mode;
+extern int g_wg8h_mode;
 
 }  // namespace gpvk

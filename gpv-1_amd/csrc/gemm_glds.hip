@@ -502,6 +502,11 @@ extern "C" int gpv_set_option(int option, int value) {
     return prev;
   }
   if (option == GPV_OPT_PIPE_SMALL) return gpvk::pipe_set_small(value);
+  if (option == GPV_OPT_WG8H) {
+    const int prev = gpvk::g_wg8h_mode;
+    gpvk::g_wg8h_mode = value;
+    return prev;
+  }
   if (option == GPV_OPT_W8L) {
     const int prev = gpvk::g_w8l_mode;
     gpvk::g_w8l_mode = value;

@@ -528,6 +528,215 @@ __device__ __forceinline__ void wg8_core(const GemmK& p, int tile, int ksplit) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Half-width eight-phase tiles (round 5): layer2's weight gradients have a 128-wide side (Cout = 128, or Cin = 128 with one tap per
+// 128 columns) and ran on the 128 x 128 core above at 570 TFLOP/s -- exactly what 15 B/clk/CU of operand delivery gives a tile that
+// does 64 flop per delivered byte.  The same pipeline on 128 x 256 (AH = 1, BH = 2) or 256 x 128 (AH = 2, BH = 1) tiles does 85:
+//   * a k-tile is THREE half-tile images, in the order they are read: H0 = Ah0, H1 = Bh0, H2 = Bh1 | Ah1; two phases of 16 MFMAs
+//     per wave: (A0, B0) then (A0, B1) | (A1, B0);
+//   * three 48 KB stages (144 KB): phase 1 of k-tile t issues H0, H1 of k-tile t + 2, phase 2 issues its H2 -- six half-tiles
+//     (96 KB) in flight across every barrier; a stage is overwritten a whole k-tile after its last read;
+//   * a 256-column tile over Cin = 128 is TWO taps (each half gathers with its own tap offsets); the ragged last column tile of
+//     9 x 128 columns issues its missing half out of range (zeros) and does not store it.
+// Wave groups, barriers, fragment reads and the epilogue are those of wg8_core.
+constexpr int W8H_BUF = 3 * W8_HALF;               // H0 | H1 | H2
+constexpr int W8H_LDS = 3 * W8H_BUF;               // 144 KB
+
+template <int AH, int BH>
+__device__ __forceinline__ void wg8h_core(const GemmK& p, int tile, int ksplit) {
+  static_assert(AH + BH == 3, "three half-tile images per k-tile");
+  extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const ConvGeom& g = p.cg;
+  const int tm = tile / p.tilesN, tn = tile - tm * p.tilesN;
+  const int row0 = tm * (128 * AH), col0 = tn * (128 * BH);
+  const int kt_total = (p.K + TBK - 1) / TBK;
+  const int kt0 = ksplit * p.kt_per_split;
+  const int kt1 = min(kt_total, kt0 + p.kt_per_split);
+  if (kt0 >= kt1) return;
+  const int nkt = kt1 - kt0;
+
+  constexpr int OOB = 0x7ffffff0;
+  const int lrow = lane >> 4;
+  const int myrow = wave * 8 + lrow;
+  const int chunk = (lane & 15) ^ (2 * lrow) ^ (8 * (wave & 1));
+
+  // the tap and channel block of either column half (128 divides Cin: one tap per half); a half beyond N is never fetched
+  int hc0[BH], hdh[BH], hdw[BH];
+  bool hval[BH];
+#pragma unroll
+  for (int h = 0; h < BH; ++h) {
+    const int c = col0 + h * 128;
+    hval[h] = c < p.N;
+    const int tap = min(c, p.N - 128) / g.Cin;
+    hc0[h] = min(c, p.N - 128) - tap * g.Cin;
+    const int tap_r = tap / g.KW, tap_s = tap - tap_r * g.KW;
+    hdh[h] = tap_r - g.PH; hdw[h] = tap_s - g.PW;
+  }
+  const int adv_q = TBK / g.OW, adv_r = TBK - adv_q * g.OW;
+  int px_b[2], px_oh[2], px_ow[2], px_k[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    px_k[j] = kt0 * TBK + myrow + 4 * j;
+    px_b[j] = px_k[j] / (g.OH * g.OW);
+    const int rem = px_k[j] - px_b[j] * (g.OH * g.OW);
+    px_oh[j] = rem / g.OW;
+    px_ow[j] = rem - px_oh[j] * g.OW;
+  }
+
+  const auto rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), (short)0, OOB, 0x00020000);
+  const auto rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), (short)0, OOB, 0x00020000);
+  const int a_vo = (myrow * (int)p.lda + row0 + chunk * 8) * 2;
+  const int a_j = 8 * (int)p.lda;
+  auto bload = [&](const decltype(rsA)& rs, int voff, int soff, unsigned char* l) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)l, 16, voff, soff, 0, 0);
+  };
+  // image slots inside a stage: Ah0 -> 0, Bh0 -> 1, the third image (Bh1 | Ah1) -> 2
+  auto issueA = [&](int tx, int h, int buf) {
+    const int kt = kt0 + tx;
+    const bool tv = tx < nkt;
+    const bool full = (kt + 1) * TBK <= p.K;
+    unsigned char* dst = smem + buf * W8H_BUF + (h == 0 ? 0 : 2) * W8_HALF + wave * 2048;
+    const int so = tv ? kt * TBK * (int)p.lda * 2 : 0;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const bool ok = tv && (full || kt * TBK + myrow + 4 * j < p.K);
+      bload(rsA, ok ? a_vo + j * a_j + h * 256 : OOB, so, dst + j * 1024);
+    }
+  };
+  int b_off[BH][2];
+#pragma unroll
+  for (int h = 0; h < BH; ++h) b_off[h][0] = b_off[h][1] = OOB;
+  auto issueB = [&](int tx, int h, int buf) {
+    const bool tv = tx < nkt;
+    unsigned char* dst = smem + buf * W8H_BUF + (1 + h) * W8_HALF + wave * 2048;
+    if (h == 0) {                                     // (Bh0 is issued before Bh1 of the same k-tile: the gather of both, then the walk)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+#pragma unroll
+        for (int hh = 0; hh < BH; ++hh) {
+          const int ih = px_oh[j] * g.SH + hdh[hh], iw = px_ow[j] * g.SW + hdw[hh];
+          const bool ok = tv && hval[hh] && (unsigned)ih < (unsigned)g.IH && (unsigned)iw < (unsigned)g.IW && px_k[j] < p.K;
+          b_off[hh][j] = ok ? ((px_b[j] * g.IH + ih) * g.IW + iw) * g.Cs * 2 + (hc0[hh] + chunk * 8) * 2 : OOB;
+        }
+        px_k[j] += TBK;
+        px_ow[j] += adv_r;
+        const int c = px_ow[j] >= g.OW ? 1 : 0;
+        px_ow[j] -= c ? g.OW : 0;
+        px_oh[j] += adv_q + c;
+        const int c2 = px_oh[j] >= g.OH ? 1 : 0;
+        px_oh[j] -= c2 ? g.OH : 0;
+        px_b[j] += c2;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) bload(rsB, b_off[h][j], 0, dst + j * 1024);
+  };
+  auto issue01 = [&](int tx, int buf) { issueA(tx, 0, buf); issueB(tx, 0, buf); };
+  auto issue2 = [&](int tx, int buf) {
+    if constexpr (BH == 2) issueB(tx, 1, buf); else issueA(tx, 1, buf);
+  };
+
+  constexpr int NI = 4 * AH, NJ = 2 * BH;
+  f32x4 acc[NI][NJ];
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int li = lane & 15, fg = lane >> 4;
+  const int fq = (li >> 2) | ((fg & 1) << 2);
+  const int f_row = (8 * fg + (li >> 2)) * ROWBYTES + ((li & 3) >> 1) * 16 + (li & 1) * 8;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void_t*)smem;
+  uint32_t a_sl[4], b_sl[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) a_sl[i] = lds0 + f_row + (((wm * 4 + i) ^ fq) << 5);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) b_sl[j] = lds0 + f_row + (((wn * 2 + j) ^ fq) << 5);
+
+  bf16x8 af[4][2], bfr[2][2];
+  auto mma = [&](int i0, int j0) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i0 + i][j0 + j] = mfma16(bfr[j][kk], af[i][kk], acc[i0 + i][j0 + j]);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+#define W8H_READ_A(SLOT)                                                                       \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                              \
+    af[i][0] = tr_frag_asm<(SLOT) * W8_HALF>(a_sl[i] + bufo);                                  \
+    af[i][1] = tr_frag_asm<(SLOT) * W8_HALF + 32 * ROWBYTES>(a_sl[i] + bufo);                  \
+  }
+#define W8H_READ_B(SLOT)                                                                       \
+  _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                              \
+    bfr[j][0] = tr_frag_asm<(SLOT) * W8_HALF>(b_sl[j] + bufo);                                 \
+    bfr[j][1] = tr_frag_asm<(SLOT) * W8_HALF + 32 * ROWBYTES>(b_sl[j] + bufo);                 \
+  }
+
+  // ---- prologue: k-tiles 0 and 1 whole (12 pieces per wave); H0, H1 of k-tile 0 landed before the first read ----
+  issue01(0, 0); issue2(0, 0); issue01(1, 1); issue2(1, 1);
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (wm == 1) __builtin_amdgcn_s_barrier();         // the second wave group runs one barrier behind the first
+  asm volatile("" ::: "memory");
+
+  int buf = 0, buf2 = 2;                             // stage of k-tile t | of k-tile t + 2
+  for (int t = 0; t < nkt; ++t) {
+    const uint32_t bufo = buf * W8H_BUF;
+    // phase 1: (A0, B0)
+    W8H_READ_B(1)
+    W8H_READ_A(0)
+    __builtin_amdgcn_sched_barrier(0);
+    issue01(t + 2, buf2);
+    asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); // H2 of this k-tile (phase 2) has landed: five half-tiles stay in flight
+    mma(0, 0);
+    // phase 2: (A0, B1) | (A1, B0)
+    if constexpr (BH == 2) { W8H_READ_B(2) } else { W8H_READ_A(2) }
+    __builtin_amdgcn_sched_barrier(0);
+    issue2(t + 2, buf2);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // H0, H1 of the next k-tile (its phase 1)
+    if constexpr (BH == 2) mma(0, 2); else mma(4, 0);
+    buf = buf == 2 ? 0 : buf + 1;
+    buf2 = buf2 == 2 ? 0 : buf2 + 1;
+  }
+#undef W8H_READ_A
+#undef W8H_READ_B
+  if (wm == 0) __builtin_amdgcn_s_barrier();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  const bool direct = p.ws == nullptr;
+  float* Cp = direct ? reinterpret_cast<float*>(p.C) : p.ws + (int64_t)ksplit * p.M * p.N;
+  const int64_t cpitch = direct ? p.ldc : p.N;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int m = row0 + (i >> 2) * 128 + wm * 64 + (i & 3) * 16 + li;
+    const float rs = p.rowscale ? p.rowscale[m] * p.alpha : p.alpha;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      if (!hval[j >> 1]) continue;
+      const int n = col0 + (j >> 1) * 128 + wn * 32 + (j & 1) * 16 + fg * 4;
+      float4* dst = reinterpret_cast<float4*>(Cp + (int64_t)m * cpitch + n);
+      float4 v = make_float4(acc[i][j][0] * rs, acc[i][j][1] * rs, acc[i][j][2] * rs, acc[i][j][3] * rs);
+      if (direct) { const float4 c = *dst; v.x += c.x; v.y += c.y; v.z += c.z; v.w += c.w; }
+      *dst = v;
+    }
+  }
+}
+
 template <bool CONV>
 __device__ __forceinline__ void glds_tt_body(const GemmK& p) {
   // (tile, split) plane, split-major, contiguous range per XCD (see gemm.hip): an XCD runs all tiles of one reduction slice
@@ -628,6 +837,28 @@ __global__ __launch_bounds__(512) void wg8_group_kernel(WgGroupK g) {
   const int u = v - q.unit_start;
   const int ksplit = u / q.tiles;
   wg8_core<true>(p, u - ksplit * q.tiles, ksplit);
+}
+// layer2's problems (a 128-wide side): the same units on 128 x 256 | 256 x 128 tiles, wg8h_core; WgProb::direct carries the tile
+// shape in bit 1 (0 = 128 x 256, 1 = 256 x 128)
+__global__ __launch_bounds__(512) void wg8h_group_kernel(WgGroupK g) {
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+  const int v = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;     // contiguous unit range per XCD
+  int pi = 0;
+  while (pi + 1 < g.n && v >= g.prob[pi + 1].unit_start) ++pi;
+  const WgProb& q = g.prob[pi];
+  GemmK p{};
+  p.A = q.A; p.B = q.B; p.C = q.C; p.rowscale = q.rowscale;
+  p.M = q.M; p.N = q.N; p.K = q.K; p.lda = q.lda; p.ldb = 0; p.ldc = q.ldc;
+  p.alpha = 1.0f;
+  p.ws = (q.direct & 1) ? nullptr : g.ws + q.ws_off;
+  p.tilesN = q.tilesN; p.kt_per_split = q.kt_per_split;
+  p.cg.IH = q.IH; p.cg.IW = q.IW; p.cg.Cs = q.Cs; p.cg.Cin = q.Cin; p.cg.OH = q.OH; p.cg.OW = q.OW;
+  p.cg.KH = q.KH; p.cg.KW = q.KW; p.cg.SH = q.SH; p.cg.SW = q.SW; p.cg.PH = q.PH; p.cg.PW = q.PW;
+  const int u = v - q.unit_start;
+  const int ksplit = u / q.tiles;
+  if (q.direct & 2) wg8h_core<2, 1>(p, u - ksplit * q.tiles, ksplit);
+  else wg8h_core<1, 2>(p, u - ksplit * q.tiles, ksplit);
 }
 #ifdef GPV_TUNING        // timing-ablation instances (wrong results by construction): tuning build only, never in libgpv_hip.so
 __global__ __launch_bounds__(256) void glds_wgrad_group_abl1_kernel(WgGroupK g) { wgrad_group_body<1>(g); }
@@ -739,6 +970,7 @@ inline bool al16t(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) 
 int g_wgrad_mode = tune_env("GPV_GLDS_WGRAD", 1);   // gpv_set_option(GPV_OPT_GLDS_WGRAD, .)
 int g_wg8_mode = tune_env("GPV_WG8", 1);            // gpv_set_option(GPV_OPT_WG8, .): eight-phase 256 x 256 weight-gradient kernel
 long g_wg8_launches = 0;
+int g_wg8h_mode = tune_env("GPV_WG8H", 1);          // gpv_set_option(GPV_OPT_WG8H, .): the 128 x 256 | 256 x 128 eight-phase tiles for the problems with a 128-wide side (layer2)
 int g_w8l_mode = tune_env("GPV_W8L", 0);            // gpv_set_option(GPV_OPT_W8L, .): the same kernel on the linear weight-gradient groups -- OFF by default: alone on the chip the step's 123
                                                     // linear gradients take 810 instead of 885 us with it, inside the step nothing (16.63 / 16.60 ms off, 16.66 / 16.77 on, same box): its
                                                     // 128 KB blocks take whole CUs from the backward chain they run beside
@@ -845,6 +1077,20 @@ extern "C" int gpv_conv_wgrad_group(const gpv_conv_wgrad_problem* probs, int n, 
     return q.Cout % 256 == 0 && q.Cin % 256 == 0 && q.Cs % 8 == 0 && al16t(q.dy) && al16t(q.x) && al16t(q.dw) &&
            TBK / q.OW + 2 <= q.OH && (int64_t)q.IH * q.IW * q.Cs * q.B < (1ll << 30) && K64 * q.Cout < (1ll << 30) && K64 >= 8 * TBK;
   };
+  static bool attr8h_done = false;
+  if (!attr8h_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wg8h_group_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, W8H_LDS);
+    if (e != hipSuccess) { (void)hipGetLastError(); return (int)e; }
+    attr8h_done = true;
+  }
+  static const int forced_kt8h = tune_env("GPV_WG8H_KT", 0);       // 0: chosen per call (below)
+  static const int ramp_kt8h = tune_env("GPV_WG8H_C", 15);
+  // a 128-wide side: Cout or Cin an odd multiple of 128 (or a 256-multiple problem the 256 x 256 launch did not take)
+  auto eligible8h = [&](const gpv_conv_wgrad_problem& q) {
+    const int64_t K64 = (int64_t)q.B * q.OH * q.OW;
+    return g_wg8h_mode != 0 && q.Cout % 128 == 0 && q.Cin % 128 == 0 && q.Cs % 8 == 0 && al16t(q.dy) && al16t(q.x) && al16t(q.dw) &&
+           TBK / q.OW + 2 <= q.OH && (int64_t)q.IH * q.IW * q.Cs * q.B < (1ll << 30) && K64 * q.Cout < (1ll << 30) && K64 >= 8 * TBK;
+  };
   bool use8 = g_wg8_mode != 0;
   if (use8 && g_wg8_mode == 1) {
     int64_t u8 = 0;
@@ -856,16 +1102,48 @@ extern "C" int gpv_conv_wgrad_group(const gpv_conv_wgrad_problem* probs, int n, 
     }
     use8 = u8 >= 128;
   }
-  WgGroupK g{}, g8{};
+  // work-unit length of the half-width launch: one 144 KB block per CU, so the launch runs in whole rounds of 256 units and its
+  // makespan is rounds x (unit length + ramp) -- measured on layer2's call (B = 32): 60 / 75 / 100 / 120 / 150 / 200 / 300 k-tiles
+  // per unit = 7 / 6 / 4 / 4 / 3 / 2 / 2 rounds -> 676 / 698 / 617 / 700 / 644 / 590 / 807 us.  Pick the length that minimises it.
+  int target_kt8h = forced_kt8h >= 8 ? forced_kt8h : 150;
+  if (forced_kt8h < 8 && g_wg8h_mode != 0) {
+    int64_t best = -1;
+    for (int kt = 64; kt <= 640; kt += 4) {
+      int64_t u = 0;
+      int longest = 0;
+      for (int i = 0; i < n; ++i) {
+        const gpv_conv_wgrad_problem& q = probs[i];
+        if ((use8 && eligible8(q)) || !eligible8h(q)) continue;
+        const int M = q.Cout, N = q.KH * q.KW * q.Cin;
+        const int kt_total = (int)(((int64_t)q.B * q.OH * q.OW + TBK - 1) / TBK);
+        int split = (kt_total + kt / 2) / kt;
+        if (split < 1) split = 1;
+        const int kps = (kt_total + split - 1) / split;
+        split = (kt_total + kps - 1) / kps;
+        u += (int64_t)(M % 256 == 0 ? (M / 256) * (N / 128) : (M / 128) * ((N + 255) / 256)) * split;
+        if (kps > longest) longest = kps;
+      }
+      if (u == 0) break;
+      const int64_t cost = ((u + 255) / 256) * (longest + ramp_kt8h);
+      if (best < 0 || cost < best) { best = cost; target_kt8h = kt; }
+    }
+  }
+  WgGroupK g{}, g8{}, gh{};
   WgRedK rk{};
-  int units = 0, units8 = 0, rblocks = 0;
+  int units = 0, units8 = 0, unitsh = 0, rblocks = 0;
   int64_t ws_used = 0;
   const int64_t ws_floats = workspace ? workspace_bytes / 4 : 0;
   auto flush = [&]() -> int {
-    if (g.n == 0 && g8.n == 0) return 0;
+    if (g.n == 0 && g8.n == 0 && gh.n == 0) return 0;
     if (g8.n > 0) {
       g8.ws = reinterpret_cast<float*>(workspace);
       hipLaunchKernelGGL(wg8_group_kernel, dim3(units8), dim3(512), W8_LDS, st, g8);
+      GPV_CHECK_LAUNCH();
+      ++g_wg8_launches;
+    }
+    if (gh.n > 0) {
+      gh.ws = reinterpret_cast<float*>(workspace);
+      hipLaunchKernelGGL(wg8h_group_kernel, dim3(unitsh), dim3(512), W8H_LDS, st, gh);
       GPV_CHECK_LAUNCH();
       ++g_wg8_launches;
     }
@@ -878,7 +1156,7 @@ extern "C" int gpv_conv_wgrad_group(const gpv_conv_wgrad_problem* probs, int n, 
       hipLaunchKernelGGL(wgrad_group_reduce_kernel, dim3(rblocks), dim3(256), 0, st, rk);
       GPV_CHECK_LAUNCH();
     }
-    g.n = 0; g8.n = 0; rk.n = 0; units = 0; units8 = 0; rblocks = 0; ws_used = 0;
+    g.n = 0; g8.n = 0; gh.n = 0; rk.n = 0; units = 0; units8 = 0; unitsh = 0; rblocks = 0; ws_used = 0;
     return 0;
   };
   for (int i = 0; i < n; ++i) {
@@ -902,27 +1180,29 @@ extern "C" int gpv_conv_wgrad_group(const gpv_conv_wgrad_problem* probs, int n, 
       continue;
     }
     const bool big = use8 && eligible8(q);
-    const int tb = big ? 256 : TBM;
+    const bool half = !big && eligible8h(q);
+    const bool tall = half && M % 256 == 0;          // 256 x 128 tiles | 128 x 256
+    const int tbm = big ? 256 : half ? (tall ? 256 : 128) : TBM, tbn = big ? 256 : half ? (tall ? 128 : 256) : TBN;
     const int K = (int)K64;
     const int kt_total = (K + TBK - 1) / TBK;
-    const int tkt = big ? target_kt8 : target_kt;
+    const int tkt = big ? target_kt8 : half ? target_kt8h : target_kt;
     int split = (kt_total + tkt / 2) / tkt;
     if (split < 1) split = 1;
     const int64_t MN = (int64_t)M * N;
     while (split > 1 && (int64_t)split * MN > ws_floats) --split;
     const int kps = (kt_total + split - 1) / split;
     split = (kt_total + kps - 1) / kps;
-    WgGroupK& gg = big ? g8 : g;
+    WgGroupK& gg = big ? g8 : half ? gh : g;
     if (gg.n == WG_MAX || (split > 1 && (rk.n == WG_MAX || ws_used + (int64_t)split * MN > ws_floats))) {
       const int e = flush();
       if (e) return e;
     }
-    int& uu = big ? units8 : units;
+    int& uu = big ? units8 : half ? unitsh : units;
     WgProb& d = gg.prob[gg.n];
     d.A = q.dy; d.B = q.x; d.C = q.dw; d.rowscale = q.rowscale;
     d.M = M; d.N = N; d.K = K; d.lda = M; d.ldc = N;
-    d.kt_per_split = kps; d.tilesN = N / tb; d.tiles = (M / tb) * (N / tb);
-    d.unit_start = uu; d.direct = split == 1 ? 1 : 0; d.ws_off = ws_used;
+    d.kt_per_split = kps; d.tilesN = (N + tbn - 1) / tbn; d.tiles = (M / tbm) * d.tilesN;
+    d.unit_start = uu; d.direct = (split == 1 ? 1 : 0) | (tall ? 2 : 0); d.ws_off = ws_used;
     d.IH = q.IH; d.IW = q.IW; d.Cs = q.Cs; d.Cin = q.Cin; d.OH = q.OH; d.OW = q.OW;
     d.KH = q.KH; d.KW = q.KW; d.SH = q.SH; d.SW = q.SW; d.PH = q.PH; d.PW = q.PW;
     uu += d.tiles * split;

@@ -521,6 +521,53 @@ def test_conv_wgrad_group_eight_phase_kernel():
         assert rel(probs[1][i][2], ref) < 3e-3, (cases[i], rel(probs[1][i][2], ref))
 
 
+def test_conv_wgrad_group_half_width_eight_phase_tiles():
+    """the eight-phase kernel on 128 x 256 | 256 x 128 tiles (gemm_glds_tt.hip wg8h_*: problems with a 128-wide side, layer2) against
+    the 128 x 128 grouped kernel on the same problems and against fp32 autograd: two taps per column tile with the ragged ninth tap,
+    direct and sliced reductions, stride 2, the tall form over 3x3 taps, several row tiles, a channel count of 384, ragged k-tiles"""
+    h, dtype = hip(), torch.bfloat16
+    cases = [(128, 128, 3, 1, 1, 60, 80, 2),       # 128 x 1152: 5 column tiles (the last one half empty), 150 k-tiles, no split
+             (128, 128, 3, 1, 1, 60, 80, 8),       # sliced
+             (128, 128, 3, 2, 1, 120, 160, 2),     # stride 2
+             (512, 128, 1, 1, 0, 60, 80, 4),       # 128 x 512
+             (128, 512, 1, 1, 0, 60, 80, 4),       # 512 x 128: tall tiles
+             (256, 512, 1, 2, 0, 120, 160, 2),     # the stride-2 projection (tall)
+             (256, 128, 1, 1, 0, 120, 160, 2),     # 128 x 256, long reduction
+             (128, 384, 3, 1, 1, 8, 24, 3),        # three row tiles, short image rows, 9 k-tiles
+             (384, 128, 1, 1, 0, 16, 32, 1),       # Cin = 384: a tile's halves in the same tap, ragged second tile; 8 k-tiles
+             (128, 256, 3, 1, 1, 15, 20, 5)]       # tall over nine taps, K = 1500: ragged last k-tile
+    probs = {0: [], 1: []}
+    refs = []
+    for i, (Cin, Cout, k, s, p, H, W, Bn) in enumerate(cases):
+        x = nhwc(rnd(Bn, Cin, H, W, dtype=dtype, seed=260 + i))
+        OH, OW = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+        dy = nhwc(rnd(Bn, Cout, OH, OW, dtype=dtype, seed=280 + i))
+        scale = rnd(Cout, seed=290 + i).abs() + 0.5
+        for mode in (0, 1):
+            dw = torch.full((Cout, k, k, Cin), 0.25, device=DEV)
+            probs[mode].append((x, dy, dw, scale, Bn, H, W, Cin, Cin, OH, OW, Cout, k, k, s, s, p, p))
+        if i in (0, 2, 4, 7, 8, 9):
+            wf = torch.zeros(Cout, Cin, k, k, device=DEV, requires_grad=True)
+            xf = x.float().permute(0, 3, 1, 2)
+            gw, = torch.autograd.grad(F.conv2d(xf, wf, stride=s, padding=p), wf, dy.float().permute(0, 3, 1, 2))
+            refs.append((i, (gw * scale.view(-1, 1, 1, 1)).permute(0, 2, 3, 1) + 0.25))
+    prev8 = h.set_option(h.OPT_WG8, 0)
+    prev = h.set_option(h.OPT_WG8H, 0)
+    h.conv_wgrad_group(probs[0])
+    h.set_option(h.OPT_WG8H, 1)
+    n0 = h.set_option(h.OPT_WG8_LAUNCHES, 0)
+    h.conv_wgrad_group(probs[1])
+    used = h.set_option(h.OPT_WG8_LAUNCHES, n0)
+    h.set_option(h.OPT_WG8H, prev)
+    h.set_option(h.OPT_WG8, prev8)
+    torch.cuda.synchronize()
+    assert used >= 1, used
+    for a, b, c in zip(probs[1], probs[0], cases):
+        assert rel(a[2], b[2]) < 1e-5, (c, rel(a[2], b[2]))
+    for i, ref in refs:
+        assert rel(probs[1][i][2], ref) < 3e-3, (cases[i], rel(probs[1][i][2], ref))
+
+
 @pytest.mark.parametrize('Cin,Cout,k,H,W,Bn', [
     (64, 256, 3, 50, 80, 8),        # 32000 rows x 256: 200 x 2 tiles of 160 x 128 (two per CU), K = 576
     (64, 512, 3, 30, 40, 8),        # 9600 rows x 512: 100 x 4 tiles of 96 x 128

@@ -42,6 +42,8 @@ torch.cuda.synchronize()
 tot = 0.0
 if os.environ.get('WG8') is not None:            # A/B of the eight-phase 256 x 256 kernel in one process: WG8=0 | 1
     hip.set_option(hip.OPT_WG8, int(os.environ['WG8']))
+if os.environ.get('WG8H') is not None:           # the half-width tiles (layer2's call): WG8H=0 | 1
+    hip.set_option(hip.OPT_WG8H, int(os.environ['WG8H']))
 for ci, probs in enumerate(calls):
     fl = sum(2.0 * q[4] * q[10] * q[11] * q[12] * q[13] * q[8] for q in probs)          # B*OH*OW*Cout*KH*KW*Cin
     for _ in range(3):
@@ -55,4 +57,4 @@ for ci, probs in enumerate(calls):
     us = ev[0].elapsed_time(ev[1]) * 100.0
     tot += us
     print('ABL=%s call %d: %2d problems  %8.1f us  %6.1f TFLOP/s' % (os.environ.get('GPV_WG_ABL', '0'), ci, len(probs), us, fl / us * 1e-6), flush=True)
-print('ABL=%s WG8=%s total %.1f us' % (os.environ.get('GPV_WG_ABL', '0'), os.environ.get('WG8', 'default'), tot))
+print('ABL=%s WG8=%s WG8H=%s KT=%s total %.1f us' % (os.environ.get('GPV_WG_ABL', '0'), os.environ.get('WG8', 'default'), os.environ.get('WG8H', 'default'), os.environ.get('GPV_WG8H_KT', '-'), tot))
