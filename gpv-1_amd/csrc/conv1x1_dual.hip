@@ -32,8 +32,16 @@ __device__ __forceinline__ int c1d_chan(int L) {      // (conv1x1_stream.hip c1s
   return hh * NH + (j >> 1) * 32 + (r >> 2) * 8 + (j & 1) * 4 + (r & 3);
 }
 
-template <int K1, int K2, int NH>
-__global__ __launch_bounds__(512) void c1d_kernel(DualK p, int ncols) {
+template <int K1, int K2, int NH, bool NT>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void c1d_kernel(DualK p, int ncols) {
+  // A wave owns 32 pixels (two MFMA row tiles): every weight fragment read from LDS feeds TWO MFMAs -- with 16 pixels per wave the
+  // launch was bound by the LDS read pipe (96 ds_read_b128 per 96 MFMAs and wave: 109 us for layer2's 60 GFLOP).  The A fragments of
+  // the NEXT tile are loaded straight into the registers of the k-chunk that has just been consumed (rolling prefetch, no second
+  // register image); ncols == NH (one pass per tile, checked by the launch).  The weight fragments are read one group of four
+  // column tiles (8 MFMAs) ahead, pinned with sched_barrier: left alone hipcc reads two fragments and waits for them.  No branch in
+  // the tile loop (rows beyond M are clamped to row M - 1 on load, so they hold row M - 1's results and store them again): with
+  // conditional stores in the loop the waitcnt pass gives up counting and waits vmcnt(0) for the rolling loads.  amdgpu_waves_per_eu(2, 2): one 8-wave block per CU is
+  // all the LDS image allows, and without the hint hipcc schedules for three waves per SIMD and serialises read -> wait -> MFMA.
   constexpr int KT = K1 + K2, KP = KT + 8, KC1 = K1 / 32, KC = KT / 32, NTL = NH / 16, NG = NH / 32, SL1 = K1 / 8, SL = KT / 8;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   bf16* Wl = reinterpret_cast<bf16*>(smem_raw);
@@ -43,28 +51,34 @@ __global__ __launch_bounds__(512) void c1d_kernel(DualK p, int ncols) {
   const bf16* A1 = reinterpret_cast<const bf16*>(p.a1);
   const bf16* A2 = reinterpret_cast<const bf16*>(p.a2);
   bf16* C = reinterpret_cast<bf16*>(p.y) + cbase;
-  const int npass = ncols / NH;
-  const int ntile = (p.M + 15) >> 4;
+  const int ntile = (p.M + 31) >> 5;
   const int nw = (int)gridDim.x * 8;
   int tile = (int)blockIdx.x * 8 + wave;
   const int ohw = p.OH * p.OW, ihw = p.IH2 * p.IW2;
-  bf16x8 an[KC];
-  auto fetch = [&](int t) {
-    const int px = t * 16 + pl;
-    const bool ok = t < ntile && px < p.M;
-    int64_t ipx = px;
-    if (p.S2 == 2) {
-      const int b = px / ohw, r = px - b * ohw, oh = r / p.OW, ow = r - oh * p.OW;
-      ipx = (int64_t)b * ihw + (int64_t)(2 * oh) * p.IW2 + 2 * ow;
-    }
+  // rows of tile t as this lane reads them: unconditional loads from a clamped pixel (a predicate around a load makes hipcc branch
+  // and wait vmcnt(0) at the join -- DESIGN section 0, finding 1); rows beyond M are computed and not stored
+  const bf16* r1[2];
+  const bf16* r2[2];
+  auto rows = [&](int t) {
 #pragma unroll
-    for (int kc = 0; kc < KC; ++kc) {
-      const bf16* src = kc < KC1 ? A1 + (int64_t)px * p.ld1 + kc * 32 + g * 8 : A2 + ipx * p.ld2 + (kc - KC1) * 32 + g * 8;
-      if (ok) an[kc] = *reinterpret_cast<const bf16x8*>(src);
-      else an[kc] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    for (int m = 0; m < 2; ++m) {
+      const int px = min(t * 32 + m * 16 + pl, p.M - 1);
+      int64_t ipx = px;
+      if (p.S2 == 2) {
+        const int b = px / ohw, r = px - b * ohw, oh = r / p.OW, ow = r - oh * p.OW;
+        ipx = (int64_t)b * ihw + (int64_t)(2 * oh) * p.IW2 + 2 * ow;
+      }
+      r1[m] = A1 + (int64_t)px * p.ld1 + g * 8;
+      r2[m] = A2 + ipx * p.ld2 + g * 8;
     }
   };
-  fetch(tile);
+  bf16x8 af[2][KC];
+  auto fetch = [&](int m, int kc) {
+    af[m][kc] = *reinterpret_cast<const bf16x8*>(kc < KC1 ? r1[m] + kc * 32 : r2[m] + (kc - KC1) * 32);
+  };
+  rows(tile);
+#pragma unroll
+  for (int kc = 0; kc < KC; ++kc) { fetch(0, kc); fetch(1, kc); }
   {
     const bf16* W1 = reinterpret_cast<const bf16*>(p.w1);
     const bf16* W2 = reinterpret_cast<const bf16*>(p.w2);
@@ -75,63 +89,91 @@ __global__ __launch_bounds__(512) void c1d_kernel(DualK p, int ncols) {
     for (int c = tid; c < ncols; c += 512) bias_l[c] = p.bias ? p.bias[cbase + c] : 0.f;
   }
   __syncthreads();
+  __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0): nothing pending at the loop header, or the waitcnt pass -- which merges the
+                                                       // staging loop's unknown state into it -- waits vmcnt(0) at the top of EVERY tile
+  const bf16* wrow = Wl + pl * KP + g * 8;
   for (; tile < ntile; tile += nw) {
-    bf16x8 af[KC];
+    const int px0 = tile * 32 + pl;
+    rows(min(tile + nw, ntile - 1));                   // (the last tile of a wave re-reads a valid tile; nobody uses it)
+    int woff = 0;
+    asm volatile("" : "+v"(woff));                     // the fragment reads are loop-invariant: opaque, or hipcc hoists all of them into scratch
+    const bf16* wr = wrow + woff;
+    f32x4 acc[2][NTL];
 #pragma unroll
-    for (int kc = 0; kc < KC; ++kc) af[kc] = an[kc];
-    fetch(tile + nw);
-    const int px = tile * 16 + pl;
-    const bool pok = px < p.M;
-    for (int hh = 0; hh < npass; ++hh) {
-      f32x4 acc[NTL];
+    for (int m = 0; m < 2; ++m)
 #pragma unroll
-      for (int j = 0; j < NTL; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-      const bf16* wrow = Wl + (hh * NH + pl) * KP + g * 8;
+      for (int j = 0; j < NTL; ++j) acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr int JG = 4, NGJ = NTL / JG, NGRP = KC * NGJ;
+    bf16x8 wf[2][JG];
+    auto ldw = [&](int grp, int b) {
+      const int kc = grp / NGJ, jh = grp - kc * NGJ;
 #pragma unroll
-      for (int kc = 0; kc < KC; ++kc) {
+      for (int jj = 0; jj < JG; ++jj) wf[b][jj] = *reinterpret_cast<const bf16x8*>(wr + (jh * JG + jj) * 16 * KP + kc * 32);
+    };
+    ldw(0, 0);
 #pragma unroll
-        for (int j = 0; j < NTL; ++j) {
-          const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wrow + j * 16 * KP + kc * 32);
-          acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af[kc], acc[j], 0, 0, 0);
-        }
+    for (int grp = 0; grp < NGRP; ++grp) {
+      const int kc = grp / NGJ, jh = grp - kc * NGJ;
+      if (grp + 1 < NGRP) ldw(grp + 1, (grp + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int jj = 0; jj < JG; ++jj) {
+        acc[0][jh * JG + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[grp & 1][jj], af[0][kc], acc[0][jh * JG + jj], 0, 0, 0);
+        acc[1][jh * JG + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[grp & 1][jj], af[1][kc], acc[1][jh * JG + jj], 0, 0, 0);
       }
+      if (jh == NGJ - 1) { fetch(0, kc); fetch(1, kc); }   // this k-chunk of the next tile, into the registers just consumed
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const int px = min(px0 + m * 16, p.M - 1);
 #pragma unroll
       for (int t = 0; t < NG; ++t) {
-        const int c0 = hh * NH + t * 32 + g * 8;
+        const int c0 = t * 32 + g * 8;
         const float4 b0 = *reinterpret_cast<const float4*>(bias_l + c0), b1 = *reinterpret_cast<const float4*>(bias_l + c0 + 4);
-        float v[8] = {acc[2 * t][0] + b0.x, acc[2 * t][1] + b0.y, acc[2 * t][2] + b0.z, acc[2 * t][3] + b0.w,
-                      acc[2 * t + 1][0] + b1.x, acc[2 * t + 1][1] + b1.y, acc[2 * t + 1][2] + b1.z, acc[2 * t + 1][3] + b1.w};
+        float v[8] = {acc[m][2 * t][0] + b0.x, acc[m][2 * t][1] + b0.y, acc[m][2 * t][2] + b0.z, acc[m][2 * t][3] + b0.w,
+                      acc[m][2 * t + 1][0] + b1.x, acc[m][2 * t + 1][1] + b1.y, acc[m][2 * t + 1][2] + b1.z, acc[m][2 * t + 1][3] + b1.w};
         bf16x8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = (bf16)(p.relu ? fmaxf(v[e], 0.f) : v[e]);
-        if (pok) {
-          bf16* q = C + (int64_t)px * p.N + c0;
-          if (p.nt) __builtin_nontemporal_store(__builtin_bit_cast(u32x4, o), reinterpret_cast<u32x4*>(q));
-          else *reinterpret_cast<bf16x8*>(q) = o;
-        }
+        // the store as inline asm: a store hipcc can see makes its waitcnt pass treat the vm counter as out of order (loads and stores
+        // pending together) and wait vmcnt(0) -- for the previous tile's stores -- before the first MFMA of every tile.  Invisible
+        // stores only make its counted waits for the rolling loads later than necessary, never earlier (they add to the counter).
+        bf16* q = C + (int64_t)px * p.N + c0;
+        const u32x4 ov = __builtin_bit_cast(u32x4, o);
+        // (s_nop 1: a 16-byte store's data registers must not be written by the VALU for two wait states -- the hazard recognizer
+        //  cannot see into the asm; without it rows 12..15 of a tile's last store carried the next tile's values)
+        if constexpr (NT) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" :: "v"(q), "v"(ov) : "memory");
+        else asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" :: "v"(q), "v"(ov) : "memory");
       }
     }
   }
 }
 
-template <int K1, int K2, int NH>
-int c1d_launch(const DualK& p, int ncols, hipStream_t st) {
+template <int K1, int K2, int NH, bool NT>
+int c1d_launch_nt(const DualK& p, int ncols, hipStream_t st) {
   constexpr int KP = K1 + K2 + 8;
   const size_t lds = (size_t)ncols * KP * 2 + (size_t)ncols * sizeof(float);
-  auto fn = c1d_kernel<K1, K2, NH>;
+  auto fn = c1d_kernel<K1, K2, NH, NT>;
   static size_t attr = 0;
   if (lds > 64 * 1024 && lds > attr) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { (void)hipGetLastError(); return (int)e; }      // (leave no stale error behind for the next launch check)
     attr = lds;
   }
-  const int nsl = p.N / ncols, ntile = (p.M + 15) / 16;
+  if (ncols != NH) return (int)hipErrorInvalidValue;             // one pass per tile (c1d_kernel's rolling prefetch)
+  const int nsl = p.N / ncols, ntile = (p.M + 31) / 32;
   int blocks = (lds <= 72 * 1024 ? 512 : 256);
   blocks = (blocks + nsl - 1) / nsl;
   if (blocks * 8 > ntile) blocks = (ntile + 7) / 8;
   hipLaunchKernelGGL(fn, dim3(blocks, nsl), dim3(512), lds, st, p, ncols);
   GPV_CHECK_LAUNCH();
   return 0;
+}
+
+template <int K1, int K2, int NH>
+int c1d_launch(const DualK& p, int ncols, hipStream_t st) {
+  return p.nt ? c1d_launch_nt<K1, K2, NH, true>(p, ncols, st) : c1d_launch_nt<K1, K2, NH, false>(p, ncols, st);
 }
 
 }  // namespace

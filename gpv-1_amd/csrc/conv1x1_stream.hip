@@ -35,11 +35,16 @@ __device__ __forceinline__ int c1s_chan(int L) {
 // LIN: the kernel as a plain linear layer's GEMM (gpv_gemm, K = 256 -> 2048 outputs: the DETR feed-forward 256 -> 2048 and its
 // backward-data product with the ReLU mask): alpha on the accumulator and the GEMM kernels' dropout
 // epilogue (same element index -> same keep pattern as gemm.hip / gemm_glds.hip / gemm_pipe.hip); the convolution instances are unchanged
+// amdgpu_waves_per_eu(2, 2) on the instances whose weights leave room for ONE 8-wave block per CU (> 72 KB of LDS): without the hint
+// hipcc schedules for three or four waves per SIMD, keeps one fragment register and serialises ds_read -> s_waitcnt lgkmcnt(0) -> MFMA
+// (97 of the 128 MFMAs of the 256 x 256 instance waited for a read issued right before them).
 template <int K, int NH, bool RES, bool MASK, bool NT, bool LIN = false, int NP = 1>
-__global__ __launch_bounds__(512) void c1s_kernel(GemmK p, int ncols) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu((NP == 1 && NH * K * 2 > 72 * 1024) ? 2 : 1, (NP == 1 && NH * K * 2 > 72 * 1024) ? 2 : 8)))
+void c1s_kernel(GemmK p, int ncols) {
   // ncols: output channels per block row (gridDim.y slices of a wide layer: layer3's 1024 channels as four 256-channel
   // problems that share A -- the weights of one slice fit the LDS, A is small next to the output)
   constexpr int KC = K / 32, NTL = NH / 16, NG = NH / 32, SL = K / 8, ROWB = K * 2;      // LDS row = K bf16, no padding: XOR swizzle (below)
+  constexpr bool BIG = NP == 1 && NH * K * 2 > 72 * 1024;                                 // one block per CU (the two-pass K = 128 instance measured 3 % slower this way)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   bf16* Wl = reinterpret_cast<bf16*>(smem_raw);
   float* bias_l = reinterpret_cast<float*>(Wl + (size_t)ncols * K);
@@ -96,7 +101,11 @@ __global__ __launch_bounds__(512) void c1s_kernel(GemmK p, int ncols) {
     }
   }
   for (int c = tid; c < p.N; c += 512) bias_l[c] = bias_g ? bias_g[c] : 0.f;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (this wave's DMA pieces have landed; the barrier orders everyone's for the fragment reads)
+  // this wave's DMA pieces have landed; the barrier orders everyone's for the fragment reads.  The BUILTIN, not inline asm: the waitcnt
+  // pass must know that nothing is pending at the tile loop's header, or it merges the prologue's unknown state into it and drains the
+  // queue at the top of every tile (conv1x1_dual.hip)
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  asm volatile("" ::: "memory");
   __syncthreads();
 
   // LIN dropout (round 5): the keep words of common.h's drop_pair_bits, bit for bit, at a tenth of the instructions.  The epilogue below
@@ -115,13 +124,12 @@ __global__ __launch_bounds__(512) void c1s_kernel(GemmK p, int ncols) {
     for (int kc = 0; kc < KC; ++kc) af[kc] = an[kc];
     fetch(tile + nw);
     const int px = tile * 16 + pl;
-    const bool pok = px < p.M;
     const int pxc = min(px, p.M - 1);
     uint32_t hbase = 0u;
     bool hfast = false;
     if constexpr (LIN) {
       if (p.dthresh) {
-        const uint64_t pr = ((uint64_t)px * (uint64_t)nfull + (uint64_t)(cbase + g * 8)) >> 1;        // pair index of this lane's first group
+        const uint64_t pr = ((uint64_t)pxc * (uint64_t)nfull + (uint64_t)(cbase + g * 8)) >> 1;       // pair index of this lane's first group (rows beyond M: the last row's, see the stores)
         hbase = (uint32_t)pr * 0x9E3779B9u + (uint32_t)p.seed + ((uint32_t)(pr >> 32) ^ (uint32_t)(p.seed >> 32)) * 0x85EBCA6Bu;
         hfast = !__any((uint32_t)pr > 0xffffffffu - (uint32_t)(p.N / 2 + 8));
       }
@@ -154,13 +162,36 @@ __global__ __launch_bounds__(512) void c1s_kernel(GemmK p, int ncols) {
       asm volatile("" : "+v"(woff));                 // opaque per tile: with the pass loop unrolled the fragment reads are loop-invariant and hipcc hoists all 128 of them out of the tile loop (into scratch)
       const unsigned char* wrow = smem_raw + woff;
       const int tx = (g ^ (K >= 128 ? pl : (pl >> 1))) * 16;       // chunk 4 kc + g of row L sits in slot (4 kc + g) ^ swz(L) = 4 kc ^ (g ^ swz)
+      if constexpr (BIG) {
+        // one block per CU = two waves per SIMD: the fragments are read a group of eight column tiles (8 MFMAs) ahead of their use,
+        // pinned with sched_barrier -- left alone hipcc keeps one fragment register and waits for every read right before its MFMA
+        constexpr int JG = NTL >= 8 ? (((RES && MASK) || LIN) ? 4 : 8) : NTL, NGJ = NTL / JG, NGRP = KC * NGJ;   // (residual + mask operands in flight: 256 registers are reached with groups of eight)
+        bf16x8 wf[2][JG];
+        auto ldw = [&](int grp, int b) {
+          const int kc = grp / NGJ, jh = grp - kc * NGJ;
+          const unsigned char* wk = wrow + ((kc * 64) ^ tx);
 #pragma unroll
-      for (int kc = 0; kc < KC; ++kc) {
-        const unsigned char* wk = wrow + ((kc * 64) ^ tx);
+          for (int jj = 0; jj < JG; ++jj) wf[b][jj] = *reinterpret_cast<const bf16x8*>(wk + (jh * JG + jj) * 16 * ROWB);
+        };
+        ldw(0, 0);
 #pragma unroll
-        for (int j = 0; j < NTL; ++j) {
-          const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wk + j * 16 * ROWB);
-          acc[j] = mfma16s(wf, af[kc], acc[j]);
+        for (int grp = 0; grp < NGRP; ++grp) {
+          const int kc = grp / NGJ, jh = grp - kc * NGJ;
+          if (grp + 1 < NGRP) ldw(grp + 1, (grp + 1) & 1);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int jj = 0; jj < JG; ++jj) acc[jh * JG + jj] = mfma16s(wf[grp & 1][jj], af[kc], acc[jh * JG + jj]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {
+          const unsigned char* wk = wrow + ((kc * 64) ^ tx);
+#pragma unroll
+          for (int j = 0; j < NTL; ++j) {
+            const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wk + j * 16 * ROWB);
+            acc[j] = mfma16s(wf, af[kc], acc[j]);
+          }
         }
       }
 #pragma unroll
@@ -191,7 +222,7 @@ __global__ __launch_bounds__(512) void c1s_kernel(GemmK p, int ncols) {
                 dropw[q] = __builtin_bit_cast(uint32_t, (s16x2)(d >> (s16x2){15, 15}));
               }
             } else {
-              const uint32_t keep8 = drop_mask<8>(p.seed, (uint64_t)px * (uint64_t)nfull + (uint64_t)(cbase + c0), p.dthresh);
+              const uint32_t keep8 = drop_mask<8>(p.seed, (uint64_t)pxc * (uint64_t)nfull + (uint64_t)(cbase + c0), p.dthresh);
 #pragma unroll
               for (int q = 0; q < 4; ++q)
                 dropw[q] = (((keep8 >> (2 * q)) & 1u) ? 0u : 0xffffu) | (((keep8 >> (2 * q + 1)) & 1u) ? 0u : 0xffff0000u);
@@ -221,10 +252,16 @@ __global__ __launch_bounds__(512) void c1s_kernel(GemmK p, int ncols) {
             o[e] = (bf16)x;
           }
         }
-        if (pok) {         // (a buffer store with a dropped out-of-range offset instead of the branch was measured: 25 - 35 % SLOWER launches)
-          bf16* q = C + (int64_t)px * p.ldc + c0;
-          if constexpr (NT) __builtin_nontemporal_store(__builtin_bit_cast(u32x4, o), reinterpret_cast<u32x4*>(q));
-          else *reinterpret_cast<bf16x8*>(q) = o;
+        // No branch and no store hipcc can see in the tile loop (conv1x1_dual.hip): rows beyond M were LOADED from row M - 1 (A,
+        // residual, mask, dropout index), so they hold row M - 1's results and store them there again; the store is inline asm because
+        // a visible one makes the waitcnt pass treat the vm counter as out of order and drain it -- the previous tile's stores included
+        // -- before the first MFMA of every tile.  s_nop 1: the two wait states a 16-byte store's data registers need before a VALU
+        // write (the hazard recognizer cannot see into the asm).  (A buffer store with a dropped out-of-range offset: 25 - 35 % slower.)
+        {
+          bf16* q = C + (int64_t)pxc * p.ldc + c0;
+          const u32x4 ov = __builtin_bit_cast(u32x4, o);
+          if constexpr (NT) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" :: "v"(q), "v"(ov) : "memory");
+          else asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" :: "v"(q), "v"(ov) : "memory");
         }
       }
     }
