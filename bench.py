@@ -623,7 +623,7 @@ def main():
     roof = {'bound': 'hbm', 'achieved': ach_gbs, 'peak': 8000.0, 'unit': 'GB/s', 'frac': ach_gbs / 8000.0, 'traffic': traffic,
             'traffic_source': traffic_source,
             'frac_mixed_per_conv_bound': alg['mixed_bound_s'] / (conv_ms * 1e-3),      # sum over launches of max(bytes / 8 TB/s, flops / 2.5 PF) / measured time
-            'kernel': 'c1s_kernel (streaming 1x1) / c3r_kernel (streaming 3x3) / stem_pool_kernel / c1d_kernel / glds_wgrad_group_kernel + wg8_group_kernel (the 42 weight gradients as one grouped call per stage) / glds_kernel<OP_CONV> / pipe_kernel<OP_CONV> / pipe_conv1x1_kernel / conv1x1_kernel / gemm_kernel<OP_CONV> (NHWC conv fwd/dgrad/wgrad, ResNet-50 body)',
+            'kernel': 'c1s_kernel (streaming 1x1) / c3r_kernel (streaming 3x3) / stem_pool_kernel / c1d_kernel / glds_wgrad_group_kernel + wg8_group_kernel + wg8h_group_kernel (the 42 weight gradients as one grouped call per stage) / glds_kernel<OP_CONV> / pipe_kernel<OP_CONV> / pipe_conv1x1_kernel / conv1x1_kernel / gemm_kernel<OP_CONV> (NHWC conv fwd/dgrad/wgrad, ResNet-50 body)',
             'launches_per_step': launches, 'avg_launch_us': conv_ms * 1e3 / launches,
             'algorithmic_bytes_per_launch': bytes_step / launches,
             'fwd_ms': ms['conv_fwd'] / args.steps, 'bwd_ms': ms['conv_bwd'] / args.steps,

@@ -54,6 +54,17 @@ def test_production_library_has_no_tuning_code():
     assert not re.search(r'\bgetenv\b', und), 'libgpv_hip.so reads the environment'
 
 
+def test_every_switch_is_documented():
+    """INTEGRATION.md section 3 lists every GPV_* switch the tree reads (os.environ in the Python layer, tune_env in
+    the native sources) -- regenerate the table with `python tools/list_knobs.py` when this fails."""
+    names = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'list_knobs.py'), '--names'], capture_output=True, text=True).stdout.split()
+    assert len(names) > 60
+    doc = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    table = doc[doc.index('<!-- knobs:begin -->'):doc.index('<!-- knobs:end -->')]
+    listed = set(re.findall(r'^\| `(GPV_[A-Z0-9_]+)` \|', table, flags=re.M))
+    assert sorted(listed) == sorted(names), (sorted(set(names) - listed), sorted(listed - set(names)))
+
+
 def test_ctypes_structs_match_the_c_layout(tmp_path):
     import gpv1_amd.hip as hip
     pairs = (('gpv_gemm_args', hip.GemmArgs), ('gpv_conv_args', hip.ConvArgs), ('gpv_attn_args', hip.AttnArgs), ('gpv_tt_problem', hip.TTProblem), ('gpv_fold_problem', hip.FoldProblem), ('gpv_tc_problem', hip.TCProblem), ('gpv_image_desc', hip.ImageDesc),
