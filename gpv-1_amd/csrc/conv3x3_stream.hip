@@ -40,7 +40,8 @@ __device__ __forceinline__ int c3_perm(int m) { return (m & 0x13) | ((m & 4) << 
 // shifts of the taps are DPP wave shifts of those registers (v_mov_b32 wave_shl:1 -- lane i takes lane i+1; the lanes that
 // pick up a neighbour from the wrong half only feed the two discarded columns 30, 31).  Weights: LDS, as above.
 template <int CIN, bool DGRAD, bool MASK, int WAVES>
-__global__ __launch_bounds__(WAVES * 64) void c3r_kernel(GemmK p, int rows_per_item, int nstrip, int nseg, int nitems) {
+__global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu((CIN >= 128 && WAVES == 8) ? 2 : 1, (CIN >= 128 && WAVES == 8) ? 2 : 8)))
+void c3r_kernel(GemmK p, int rows_per_item, int nstrip, int nseg, int nitems) {
   constexpr int KTOT = 9 * CIN, KP = KTOT + 8, KCN = CIN / 16, SWO = 30;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   bf16* Wl = reinterpret_cast<bf16*>(smem_raw);
@@ -121,6 +122,43 @@ __global__ __launch_bounds__(WAVES * 64) void c3r_kernel(GemmK p, int rows_per_i
           for (int c = 0; c < 4; ++c)
             mv[c] = sok ? *reinterpret_cast<const bf16x8*>(Mk + (int64_t)opix * p.ldm + (c >> 1) * 32 + (c & 1) * 16 + h * 8) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
         }
+        if constexpr (CIN >= 128 && WAVES == 8) {
+          // One block per CU = two waves per SIMD: the six weight fragments of the NEXT (tap row, channel chunk) are read while the six
+          // MFMAs of this one run, pinned with sched_barrier.  Left alone hipcc reads a fragment, waits lgkmcnt(0) and multiplies --
+          // 115 of the 144 MFMAs of an output row started behind a full LDS round trip (halving the reads changed nothing: it is the
+          // latency, not the LDS bandwidth; waves_per_eu(2, 2) alone did not change the schedule either).
+          constexpr int NGR = 3 * KCN;
+          bf16x8 wfg[2][3][2];
+          auto ldg = [&](int grp, int b) {
+            const int r = grp / KCN, kc = grp - r * KCN;
+#pragma unroll
+            for (int s2 = 0; s2 < 3; ++s2) {
+              const int tap = DGRAD ? 8 - (r * 3 + s2) : r * 3 + s2;
+#pragma unroll
+              for (int nt = 0; nt < 2; ++nt) wfg[b][s2][nt] = *reinterpret_cast<const bf16x8*>(wl + nt * 32 * KP + tap * CIN + kc * 16);
+            }
+          };
+          ldg(0, 0);
+#pragma unroll
+          for (int grp = 0; grp < NGR; ++grp) {
+            const int r = grp / KCN, kc = grp - r * KCN, slot = (jj + r) % 3;
+            if (grp + 1 < NGR) ldg(grp + 1, (grp + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            u32x4 a = row[slot][kc];
+#pragma unroll
+            for (int s2 = 0; s2 < 3; ++s2) {
+              if (s2 > 0) {
+#pragma unroll
+                for (int d = 0; d < 4; ++d) a[d] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)a[d], 0x130 /* wave_shl:1 */, 0xf, 0xf, true);
+              }
+#pragma unroll
+              for (int nt = 0; nt < 2; ++nt)
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfg[grp & 1][s2][nt], __builtin_bit_cast(bf16x8, a), acc[nt], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (grp == KCN - 1) load_row(oh + 2, jj % 3);   // the row that left the window makes room for the next one
+          }
+        } else {
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
           const int slot = (jj + r) % 3;
@@ -142,6 +180,7 @@ __global__ __launch_bounds__(WAVES * 64) void c3r_kernel(GemmK p, int rows_per_i
             }
           }
           if (r == 0) load_row(oh + 2, jj % 3);           // the row that left the window makes room for the next one
+        }
         }
         if (sok) {
 #pragma unroll
