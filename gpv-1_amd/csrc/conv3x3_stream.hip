@@ -34,6 +34,16 @@ constexpr int C3_NSL = 64;              // output channels per block
 // the channels 16 (q >> 1) + 8 h + 4 (q & 1) + j (two runs of 8 consecutive channels per lane): swap bits 2 and 3 of m
 __device__ __forceinline__ int c3_perm(int m) { return (m & 0x13) | ((m & 4) << 1) | ((m & 8) >> 1); }
 
+// A 16-byte store the compiler cannot see.  With a visible store in the row loop the waitcnt pass holds loads and stores pending together,
+// treats the vm counter as out of order and waits vmcnt(0) before every tile's stores -- for the ReLU-mask loads of the whole row AND for
+// the previous tile's stores (four serialised store round trips per dy row in the stride-2 backward-data).  s_nop 1: the two wait states a
+// 16-byte store's data registers need before a VALU write (conv1x1_dual.hip).
+__device__ __forceinline__ void c3_store16(bf16* q, const bf16x8& o) {
+  typedef unsigned int c3_u32x4 __attribute__((ext_vector_type(4)));
+  const c3_u32x4 ov = __builtin_bit_cast(c3_u32x4, o);
+  asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" :: "v"(q), "v"(ov) : "memory");
+}
+
 // Row-walking kernel (stride 1, forward and backward-data).  The input passes through the vector memory path ONCE: a wave owns a strip of 30 output columns and walks DOWN it; the three input rows a 3x3 needs live in REGISTERS
 // (32 lanes = input columns x0-1 .. x0+30, two 8-channel groups per 16-channel chunk on the two lane halves), each new output
 // row loads one new input row (Cin/16 loads per lane) into the slot of the row that just left the window, and the column
@@ -118,9 +128,11 @@ void c3r_kernel(GemmK p, int rows_per_item, int nstrip, int nseg, int nitems) {
         }
         bf16x8 mv[MASK ? 4 : 1];
         if constexpr (MASK) {
+          // unconditional, from pixel 0 for the lanes that store nothing: `sok ? load : 0` is a branch per load
+          const int64_t mpix = sok ? opix : 0;
 #pragma unroll
           for (int c = 0; c < 4; ++c)
-            mv[c] = sok ? *reinterpret_cast<const bf16x8*>(Mk + (int64_t)opix * p.ldm + (c >> 1) * 32 + (c & 1) * 16 + h * 8) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            mv[c] = *reinterpret_cast<const bf16x8*>(Mk + mpix * p.ldm + (c >> 1) * 32 + (c & 1) * 16 + h * 8);
         }
         if constexpr (CIN >= 128 && WAVES == 8) {
           // One block per CU = two waves per SIMD: the six weight fragments of the NEXT (tap row, channel chunk) are read while the six
@@ -194,7 +206,7 @@ void c3r_kernel(GemmK p, int rows_per_item, int nstrip, int nseg, int nitems) {
               if constexpr (MASK) x = (float)mv[c][e] > 0.f ? x : 0.f;
               o[e] = (bf16)x;
             }
-            *reinterpret_cast<bf16x8*>(Y + (int64_t)opix * p.ldc + nt * 32 + hi * 16 + h * 8) = o;
+            c3_store16(Y + (int64_t)opix * p.ldc + nt * 32 + hi * 16 + h * 8, o);
           }
         }
       }
@@ -313,8 +325,8 @@ __global__ __launch_bounds__(WAVES * 64) void c3d2_kernel(GemmK p, int rows_per_
             for (int t = 0; t < 4; ++t) {
               const int opix = (b * g.OH + 2 * y + (t >> 1)) * g.OW + 2 * xd + (t & 1);
 #pragma unroll
-              for (int c = 0; c < 4; ++c)
-                mv[t * 4 + c] = cok ? *reinterpret_cast<const bf16x8*>(Mk + (int64_t)opix * p.ldm + (c >> 1) * 32 + (c & 1) * 16 + h * 8) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+              for (int c = 0; c < 4; ++c)       // (unconditional: pixel 0 for the lanes that store nothing)
+                mv[t * 4 + c] = *reinterpret_cast<const bf16x8*>(Mk + (int64_t)(cok ? opix : 0) * p.ldm + (c >> 1) * 32 + (c & 1) * 16 + h * 8);
             }
           }
 #pragma unroll
@@ -363,7 +375,7 @@ __global__ __launch_bounds__(WAVES * 64) void c3d2_kernel(GemmK p, int rows_per_
                   if constexpr (MASK) x = (float)mv[t * 4 + c][e] > 0.f ? x : 0.f;
                   o[e] = (bf16)x;
                 }
-                *reinterpret_cast<bf16x8*>(Y + (int64_t)opix * p.ldc + nt * 32 + hi * 16 + h * 8) = o;
+                c3_store16(Y + (int64_t)opix * p.ldc + nt * 32 + hi * 16 + h * 8, o);
               }
             }
           }
