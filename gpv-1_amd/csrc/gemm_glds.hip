@@ -59,6 +59,30 @@ __device__ __forceinline__ void glds_body(const GemmK& p) {
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
     tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
   }
+  if constexpr (AMODE == OP_CONV) {
+    if (p.cg.cm && p.cg.cls_rows % BM == 0 && p.M == 4 * p.cg.cls_rows) {
+      // Stride-2 backward-data: row panel tm is parity class tm & 3 (next remap), so an XCD's contiguous tile range holds the four
+      // classes of the same dy pixels (shared L2 lines) -- but in launch order every resident slot kept drawing the SAME class: the
+      // slots on the 4-tap class (4 x the k-tiles of the 1-tap one) finished last.  Inside its range an XCD now takes the LONGEST
+      // tiles first: class 3 (four taps), then 1 and 2 (two), then 0 (one); list scheduling of the same 1920 tiles on 512 slots:
+      // makespan 80 -> 68 in units of k-tiles (ramp 8).
+      const int nwg = gridDim.x, bid = blockIdx.x;
+      const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+      const int s0 = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q, cnt = q + (xcd < r ? 1 : 0);
+      const int tN = p.tilesN, G = 4 * tN;
+      auto below = [&](int x, int c) { const int m = x / G, u = x - m * G - c * tN; return m * tN + (u < 0 ? 0 : (u > tN ? tN : u)); };   // tiles < x of class c
+      int left = loc, pick = 0, before = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int c = k == 0 ? 3 : k == 1 ? 1 : k == 2 ? 2 : 0;
+        const int b = below(s0, c), n = below(s0 + cnt, c) - b;
+        if (k == 3 || left < n) { pick = c; before = b; break; }
+        left -= n;
+      }
+      const int ord = before + left;                    // the ord-th tile of class `pick` in the whole launch
+      tile = (ord / tN) * G + pick * tN + (ord - (ord / tN) * tN);
+    }
+  }
   int tm = __builtin_amdgcn_readfirstlane(tile / p.tilesN);      // (the division is done on the VALU)
   const int tn = tile - tm * p.tilesN;
   if constexpr (AMODE == OP_CONV) {
