@@ -274,34 +274,63 @@ __device__ __forceinline__ void glds_body(const GemmK& p) {
         for (int e = 0; e < 8; ++e) bq[t][e] = 0.f;
       }
     }
+    // The residual / mask operands are requested two accumulator rows (eight 16-byte loads) at a time, unconditionally, from rows clamped
+    // into the matrix, BEFORE the first of them is used.  The loop this replaces loaded inside `if (m >= M) continue; if (Rp) ...;
+    // if (Mp) ...` and used each value at once: load -> s_waitcnt vmcnt(0) -> load -> s_waitcnt vmcnt(0) -> compute -> store, FM x 2
+    // times -- up to twenty dependent round trips at the end of every tile (the tile kernels' ramp).  Not all FM rows at
+    // once: with the 80 accumulator registers (AGPRs) that is 284 registers = ONE block per CU instead of two (measured: +50 %).
+    if constexpr (std::is_same<TOut, bf16>::value) {
+      constexpr int CHK = 2;
 #pragma unroll
-    for (int i = 0; i < FM; ++i) {
-      const int ml = mrow + i * 16, m = row0 + ml;
-      if (m >= p.M) continue;
-      int64_t mp = m;
-      if constexpr (AMODE == OP_CONV) { if (p.cg.cm) mp = s_rowpix[ml]; }
-      const float rs = p.rowscale ? p.rowscale[m] * p.alpha : p.alpha;
+      for (int i0 = 0; i0 < FM; i0 += CHK) {
+        bf16x8 rraw[CHK][2], mraw[CHK][2];
+        int64_t mpv[CHK];
+        float rsv[CHK];
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const int n = col0 + wn * 64 + t * 32 + fkg * 8;
-        float rv[8], mv[8];
-        if (Rp) Ld8<TOut>::ld(Rp + mp * p.ldr + n, rv);
-        if (Mp) Ld8<TOut>::ld(Mp + mp * p.ldm + n, mv);
-        const uint32_t keep8 = p.dthresh ? drop_mask<8>(p.seed, ((uint64_t)batch * p.M + m) * (uint64_t)p.N + n, p.dthresh) : 0xffu;
-        float v[8] = {acc[i][2 * t][0], acc[i][2 * t][1], acc[i][2 * t][2], acc[i][2 * t][3],
-                      acc[i][2 * t + 1][0], acc[i][2 * t + 1][1], acc[i][2 * t + 1][2], acc[i][2 * t + 1][3]};
+        for (int ii = 0; ii < CHK; ++ii) {
+          const int i = i0 + ii;
+          if (i < FM) {
+            const int ml = mrow + i * 16, m = min(row0 + ml, p.M - 1);
+            rsv[ii] = p.rowscale ? p.rowscale[m] : 1.0f;
+            int64_t mp = m;
+            if constexpr (AMODE == OP_CONV) { if (p.cg.cm) mp = s_rowpix[ml]; }     // (filled from rows clamped the same way)
+            mpv[ii] = mp;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          float x = v[e] * rs;
-          x += bq[t][e];
-          if (Rp) x += rv[e];
-          if (p.act == GPV_ACT_RELU) x = fmaxf(x, 0.f);
-          else if (p.act == GPV_ACT_GELU) x = gelu_erf(x);
-          if (p.dthresh) x = ((keep8 >> e) & 1u) ? x * p.dscale : 0.f;
-          if (Mp) x = mv[e] > 0.f ? x : 0.f;
-          v[e] = x;
+            for (int t = 0; t < 2; ++t) {
+              const int n = col0 + wn * 64 + t * 32 + fkg * 8;
+              if (Rp) rraw[ii][t] = *reinterpret_cast<const bf16x8*>(Rp + mp * p.ldr + n);
+              if (Mp) mraw[ii][t] = *reinterpret_cast<const bf16x8*>(Mp + mp * p.ldm + n);
+            }
+          }
         }
-        Ld8<TOut>::st(Cp + mp * p.ldc + n, v);
+#pragma unroll
+        for (int ii = 0; ii < CHK; ++ii) {
+          const int i = i0 + ii;
+          if (i < FM) {
+            const int ml = mrow + i * 16, m = row0 + ml;
+            const int mc = min(m, p.M - 1);
+            const float rs = rsv[ii] * p.alpha;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+              const int n = col0 + wn * 64 + t * 32 + fkg * 8;
+              const uint32_t keep8 = p.dthresh ? drop_mask<8>(p.seed, ((uint64_t)batch * p.M + mc) * (uint64_t)p.N + n, p.dthresh) : 0xffu;
+              float v[8] = {acc[i][2 * t][0], acc[i][2 * t][1], acc[i][2 * t][2], acc[i][2 * t][3],
+                            acc[i][2 * t + 1][0], acc[i][2 * t + 1][1], acc[i][2 * t + 1][2], acc[i][2 * t + 1][3]};
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                float x = v[e] * rs;
+                x += bq[t][e];
+                if (Rp) x += (float)rraw[ii][t][e];
+                if (p.act == GPV_ACT_RELU) x = fmaxf(x, 0.f);
+                else if (p.act == GPV_ACT_GELU) x = gelu_erf(x);
+                if (p.dthresh) x = ((keep8 >> e) & 1u) ? x * p.dscale : 0.f;
+                if (Mp) x = (float)mraw[ii][t][e] > 0.f ? x : 0.f;
+                v[e] = x;
+              }
+              if (m < p.M) Ld8<TOut>::st(Cp + mpv[ii] * p.ldc + n, v);
+            }
+          }
+        }
       }
     }
     return;
