@@ -421,6 +421,227 @@ __global__ __launch_bounds__(BM == 256 ? 512 : 256) void glds_kernel(GemmK p) {
   glds_body<AMODE, BM, BN, TOut>(p);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Stride-1 3x3 convolution (forward / backward-data), two blocks per CU, with ONE HALO IMAGE per channel block instead of nine tap
+// tiles (round 5).  The tile kernel above fetches its A operand once per tap: 9 x BM rows per 64 channels, although the nine tiles are
+// the same BM + 2 (W + 1) consecutive pixel rows (x is pixel-major) shifted by r W + s.  Its main loop is bound by L2 -> LDS delivery
+// (~ 20 B/clk/CU at two blocks per CU), so here:
+//   * the halo image [BM + 96 rows][64 channels] of channel block c is ONE contiguous LDS-DMA (rows row0 - (W + 1) ..; out of the
+//     tensor: zeros), staged once for nine taps; the weights keep their two stages (one tap x 64 channels each);
+//   * the k-loop runs (channel block, tap); tap (r, s) reads its A fragments at row offset r W + s (backward-data: mirrored), with the
+//     swizzle key of the SHIFTED row, and the lanes whose pixel has no such neighbour (image border) zero their fragment -- what an
+//     out-of-range DMA offset did per tap;
+//   * delivered bytes per 64 channels: (BM + 96) x 128 + 9 x 16 KB instead of 9 x (BM x 128 + 16 KB).
+// Register epilogue, XCD-aware tile order, loaders and fragment layout are glds_body's.  W <= 47, Cin % 64 == 0, N % 128 == 0.
+int g_halo_mode = tune_env("GPV_C3_HALO", 1);       // gpv_set_option(GPV_OPT_C3_HALO, .)
+long g_halo_launches = 0;
+
+template <int BM>
+__global__ __launch_bounds__(256) void glds_halo_kernel(GemmK p) {
+  constexpr int BN = 128, NW = 4, WN = 2, WTM = BM / 2, FM = WTM / 16, FN = 4;
+  constexpr int HROWS = BM + 96;
+  constexpr int A_BYTES = HROWS * ROWB, B_BYTES = BN * ROWB;
+  constexpr int AIH = HROWS / (8 * NW), BI = BN / (8 * NW);
+  static_assert(HROWS % (8 * NW) == 0 && WTM % 16 == 0, "tile shape");
+  extern __shared__ __attribute__((aligned(128))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave - wm * WN;
+  int tile;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  const int tm = __builtin_amdgcn_readfirstlane(tile / p.tilesN);
+  const int tn = tile - tm * p.tilesN;
+  const int row0 = tm * BM, col0 = tn * BN;
+  const ConvGeom& g = p.cg;
+  const int W = g.IW, HW = g.IH * g.IW;
+  const int nC = g.Cin / GBK, nsteps = nC * 9;
+  const bool dg = g.dgrad != 0;
+
+  constexpr int OOB = 0x7ffffff0;
+  const int lrow = lane >> 3;
+  const int lchunk = (lane & 7) ^ lrow;
+  const bf16* Ab = reinterpret_cast<const bf16*>(p.A);
+  const bf16* Bb = reinterpret_cast<const bf16*>(p.B);
+  const auto rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(Ab), (short)0, OOB, 0x00020000);
+  const auto rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(Bb), (short)0, OOB, 0x00020000);
+  int a_vo[AIH], b_vo[BI];
+#pragma unroll
+  for (int j = 0; j < AIH; ++j) {
+    const int h = wave * (AIH * 8) + j * 8 + lrow;           // halo row = pixel row0 - (W + 1) + h
+    const int px = row0 - (W + 1) + h;
+    a_vo[j] = (px >= 0 && px < p.M) ? (px * g.Cs + lchunk * 8) * 2 : OOB;
+  }
+#pragma unroll
+  for (int j = 0; j < BI; ++j) {
+    const int r = wave * (BI * 8) + j * 8 + lrow;
+    const int rp = (r & ~31) + ((r & 15) >> 2) * 8 + ((r >> 4) & 1) * 4 + (r & 3);      // permuted output columns (glds_body's register epilogue)
+    b_vo[j] = ((col0 + rp) * (int)p.ldb + lchunk * 8) * 2;
+  }
+  auto bload = [&](const decltype(rsA)& rs, int voff, int soff, unsigned char* l) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)l, 16, voff, soff, 0, 0);
+  };
+  auto issueA = [&](int c) {
+    unsigned char* sa = smem + wave * (AIH * 1024);
+#pragma unroll
+    for (int j = 0; j < AIH; ++j) bload(rsA, a_vo[j], c * GBK * 2, sa + j * 1024);
+  };
+  auto issueB = [&](int c, int tap, int stage) {
+    unsigned char* sb = smem + A_BYTES + stage * B_BYTES + wave * (BI * 1024);
+    const int k0 = tap * g.Cin + c * GBK;
+#pragma unroll
+    for (int j = 0; j < BI; ++j) bload(rsB, b_vo[j], k0 * 2, sb + j * 1024);
+  };
+
+  f32x4 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15, fkg = lane >> 4, fsw = lane & 7;
+  const int a_row = wm * WTM + frow;
+  const int b_off = A_BYTES + (wn * 64 + frow) * ROWB;
+  // image-border bits of this lane's FM output pixels: 1 top row, 2 bottom row, 4 left column, 8 right column
+  int bord[FM];
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+    const int m = min(row0 + a_row + i * 16, p.M - 1);
+    const int rem = m % HW, oh = rem / W, ow = rem - oh * W;
+    bord[i] = (oh == 0 ? 1 : 0) | (oh == g.IH - 1 ? 2 : 0) | (ow == 0 ? 4 : 0) | (ow == W - 1 ? 8 : 0);
+  }
+
+  issueA(0);
+  issueB(0, 0, 0);
+  int c = 0, tap = 0;
+  for (int t = 0; t < nsteps; ++t) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int tap_n = tap == 8 ? 0 : tap + 1, c_n = tap == 8 ? c + 1 : c;
+    if (t + 1 < nsteps) issueB(c_n, tap_n, (t + 1) & 1);
+    const int r = tap / 3, s2 = tap - r * 3;
+    const int rr = dg ? 2 - r : r, ss = dg ? 2 - s2 : s2;            // offset of the input pixel: (rr - 1, ss - 1)
+    const int shift = rr * W + ss;
+    const int tmask = (rr == 0 ? 1 : 0) | (rr == 2 ? 2 : 0) | (ss == 0 ? 4 : 0) | (ss == 2 ? 8 : 0);
+    const int hkey = (frow + shift) & 7;                             // swizzle key of the shifted halo row (WTM, 16 i: multiples of 8)
+    const unsigned char* sa = smem + (a_row + shift) * ROWB;
+    const unsigned char* sb = smem + (t & 1) * B_BYTES + b_off;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int slot_b = ((kk * 4 + fkg) ^ fsw) << 4, slot_a = ((kk * 4 + fkg) ^ hkey) << 4;
+      bf16x8 af[FM], bfr[FN];
+#pragma unroll
+      for (int j = 0; j < FN; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(sb + j * 16 * ROWB + slot_b);
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        af[i] = *reinterpret_cast<const bf16x8*>(sa + i * 16 * ROWB + slot_a);
+        if (bord[i] & tmask) af[i] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      }
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = mfma16(bfr[j], af[i], acc[i][j]);
+    }
+    if (tap == 8 && c + 1 < nC) {                                    // every wave is done with this channel block's halo image
+      __syncthreads();
+      issueA(c + 1);
+    }
+    tap = tap_n; c = c_n;
+  }
+
+  // ---------------- register epilogue (glds_body's, bf16, whole column tiles) ----------------
+  bf16* Cp = reinterpret_cast<bf16*>(p.C);
+  const bf16* Rp = reinterpret_cast<const bf16*>(p.res);
+  const bf16* Mp = reinterpret_cast<const bf16*>(p.mask);
+  float bq[2][8];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int n = col0 + wn * 64 + t * 32 + fkg * 8;
+    if (p.bias) {
+      const float4 b0 = *reinterpret_cast<const float4*>(p.bias + n), b1 = *reinterpret_cast<const float4*>(p.bias + n + 4);
+      bq[t][0] = b0.x; bq[t][1] = b0.y; bq[t][2] = b0.z; bq[t][3] = b0.w; bq[t][4] = b1.x; bq[t][5] = b1.y; bq[t][6] = b1.z; bq[t][7] = b1.w;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) bq[t][e] = 0.f;
+    }
+  }
+  constexpr int CHK = 2;
+#pragma unroll
+  for (int i0 = 0; i0 < FM; i0 += CHK) {
+    bf16x8 rraw[CHK][2], mraw[CHK][2];
+    float rsv[CHK];
+#pragma unroll
+    for (int ii = 0; ii < CHK; ++ii) {
+      const int i = i0 + ii;
+      if (i < FM) {
+        const int64_t m = min(row0 + a_row + i * 16, p.M - 1);
+        rsv[ii] = p.rowscale ? p.rowscale[m] : 1.0f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int n = col0 + wn * 64 + t * 32 + fkg * 8;
+          if (Rp) rraw[ii][t] = *reinterpret_cast<const bf16x8*>(Rp + m * p.ldr + n);
+          if (Mp) mraw[ii][t] = *reinterpret_cast<const bf16x8*>(Mp + m * p.ldm + n);
+        }
+      }
+    }
+#pragma unroll
+    for (int ii = 0; ii < CHK; ++ii) {
+      const int i = i0 + ii;
+      if (i < FM) {
+        const int m = row0 + a_row + i * 16;
+        const float rs = rsv[ii] * p.alpha;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int n = col0 + wn * 64 + t * 32 + fkg * 8;
+          float v[8] = {acc[i][2 * t][0], acc[i][2 * t][1], acc[i][2 * t][2], acc[i][2 * t][3],
+                        acc[i][2 * t + 1][0], acc[i][2 * t + 1][1], acc[i][2 * t + 1][2], acc[i][2 * t + 1][3]};
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float x = v[e] * rs + bq[t][e];
+            if (Rp) x += (float)rraw[ii][t][e];
+            if (p.act == GPV_ACT_RELU) x = fmaxf(x, 0.f);
+            if (Mp) x = (float)mraw[ii][t][e] > 0.f ? x : 0.f;
+            v[e] = x;
+          }
+          if (m < p.M) Ld8<bf16>::st(Cp + (int64_t)m * p.ldc + n, v);
+        }
+      }
+    }
+  }
+}
+
+template <int BM>
+int launch_halo(const GemmK& k, hipStream_t st) {
+  constexpr size_t lds = (size_t)(BM + 96) * ROWB + (size_t)2 * 128 * ROWB;
+  GemmK p = k;
+  const int tilesM = (p.M + BM - 1) / BM;
+  p.tilesN = p.N / 128;
+  auto fn = glds_halo_kernel<BM>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { (void)hipGetLastError(); return (int)e; }
+    attr_done = true;
+  }
+  ++g_halo_launches;
+  ++g_glds_launches;                  // (a launch of the two-per-CU tile family: tests that ask whether a shape took it count these too)
+  hipLaunchKernelGGL(fn, dim3(tilesM * p.tilesN), dim3(256), lds, st, p);
+  GPV_CHECK_LAUNCH();
+  return 0;
+}
+
+inline bool halo_ok(const GemmK& k, int dtype_out, int batch) {
+  const ConvGeom& g = k.cg;
+  auto a16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  return g_halo_mode != 0 && dtype_out == GPV_BF16 && batch == 1 && g.KH == 3 && g.KW == 3 && g.SH == 1 && g.SW == 1 && g.PH == 1 && g.PW == 1 &&
+         !g.cm && g.OH == g.IH && g.OW == g.IW && g.IW <= 47 && g.Cin % GBK == 0 && k.N % 128 == 0 && k.K == 9 * g.Cin &&
+         k.M % (g.IH * g.IW) == 0 && k.ldc % 8 == 0 && a16(k.C) && (!k.res || (k.ldr % 8 == 0 && a16(k.res))) &&
+         (!k.mask || (k.ldm % 8 == 0 && a16(k.mask))) && (!k.bias || a16(k.bias)) && !k.dthresh && k.act != GPV_ACT_GELU;
+}
+
 // 1x1 stride-1 convolutions are plain GEMMs over the NHWC rows; their own kernel name keeps them attributable to the
 // backbone in rocprofv3 traces and PMC passes (like conv1x1_kernel in gemm.hip)
 template <int BM, int BN, typename TOut>
@@ -493,6 +714,10 @@ int glds_try_launch(const GemmK& k, int amode, int dtype_in, int dtype_out, int 
   // tiles, 96 x 128 for the 9600-row maps) let one block's epilogue run under the other's main loop.
   if (glds_two_per_cu(k, batch) && mode != 2 && mode != 3) {
     const int bm2 = two_per_cu_bm(k, batch);
+    if (amode == OP_CONV && halo_ok(k, dtype_out, batch)) {
+      if (bm2 == 160) return launch_halo<160>(k, st);
+      if (bm2 == 96) return launch_halo<96>(k, st);
+    }
     if (bm2 == 160) return amode == OP_CONV ? launch_glds_out<OP_CONV, 160, 128>(k, dtype_out, batch, st) : launch_glds_out<OP_PLAIN, 160, 128>(k, dtype_out, batch, st);
     if (bm2 == 96) return amode == OP_CONV ? launch_glds_out<OP_CONV, 96, 128>(k, dtype_out, batch, st) : launch_glds_out<OP_PLAIN, 96, 128>(k, dtype_out, batch, st);
   }
@@ -595,6 +820,16 @@ extern "C" int gpv_set_option(int option, int value) {
     return gpvk::pipe_set_mode(value);
   }
   if (option == GPV_OPT_PIPE_LAUNCHES) return (int)gpvk::pipe_launches(value);
+  if (option == GPV_OPT_C3_HALO) {
+    const int prev = gpvk::g_halo_mode;
+    gpvk::g_halo_mode = value;
+    return prev;
+  }
+  if (option == GPV_OPT_C3_HALO_LAUNCHES) {
+    const long prev = gpvk::g_halo_launches;
+    gpvk::g_halo_launches = value;
+    return (int)prev;
+  }
   if (option == GPV_OPT_GLDS_LAUNCHES) {
     const long prev = gpvk::g_glds_launches;
     gpvk::g_glds_launches = value;

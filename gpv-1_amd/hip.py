@@ -123,7 +123,7 @@ def build_id():
 
 OPT_GLDS, OPT_GLDS_LAUNCHES, OPT_SKINNY, OPT_GLDS_WGRAD, OPT_PIPE, OPT_PIPE_LAUNCHES, OPT_C1S, OPT_C3S, OPT_C3S_LAUNCHES = 0, 1, 2, 3, 4, 5, 6, 7, 8
 OPT_GEMV, OPT_GEMV_LAUNCHES = 9, 10
-OPT_ATTN_BWD1, OPT_ATTN_BWD1_LAUNCHES, OPT_C1S_LAUNCHES, OPT_WG8, OPT_WG8_LAUNCHES, OPT_W8L, OPT_PIPE_SMALL, OPT_WG8H = 11, 12, 13, 14, 15, 16, 17, 18
+OPT_ATTN_BWD1, OPT_ATTN_BWD1_LAUNCHES, OPT_C1S_LAUNCHES, OPT_WG8, OPT_WG8_LAUNCHES, OPT_W8L, OPT_PIPE_SMALL, OPT_WG8H, OPT_C3_HALO, OPT_C3_HALO_LAUNCHES = 11, 12, 13, 14, 15, 16, 17, 18, 19, 20
 
 
 def set_option(option, value):

@@ -583,6 +583,44 @@ def test_conv_two_tiles_per_cu_variants(Cin, Cout, k, H, W, Bn):
     assert used >= 1, used
 
 
+@pytest.mark.parametrize('Cin,Cout,H,W,Bn', [
+    (256, 256, 30, 40, 32),         # layer3 conv2 at the bench batch: 240 x 2 tiles of 160 rows, four channel blocks
+    (512, 512, 15, 20, 32),         # layer4 conv2: 100 x 4 tiles of 96 rows, eight channel blocks, tiles spanning whole images
+    (128, 256, 29, 43, 32),         # odd image (1247 pixels), rows not a multiple of the tile: tail tile, borders at every offset
+    (64, 256, 47, 47, 16),          # the widest image the halo covers (W + 1 = 48), one channel block
+    (192, 128, 9, 21, 240),         # many small images per tile (189 pixels each), three channel blocks, one column tile
+    (128, 128, 1, 47, 800),         # one-row images: every pixel is on the top AND the bottom border
+    (128, 256, 40, 1, 900),         # one-column images: left and right border at once
+    (128, 128, 2, 2, 9600)])        # 2 x 2 images: every pixel in a corner
+def test_conv3x3_halo_image_kernel(Cin, Cout, H, W, Bn):
+    """stride-1 3x3 forward (bias + residual + ReLU) and backward-data (addend + ReLU mask) on the halo-image tile kernel
+    (gemm_glds.hip glds_halo_kernel: one halo image per channel block, taps as shifted fragment reads, border lanes zeroed) against
+    fp32 torch and against the nine-tap-tile kernel on the same operands; and that these shapes really take it"""
+    h = hip()
+    prev = h.set_option(h.OPT_C3_HALO, 1)
+    n0 = h.set_option(h.OPT_C3_HALO_LAUNCHES, 0)
+    try:
+        test_conv_fwd_dgrad_wgrad(torch.bfloat16, Cin, Cout, 3, 1, 1, H, W, Bn=Bn)
+        used = h.set_option(h.OPT_C3_HALO_LAUNCHES, n0)
+        assert used >= (2 if (Cin, Cout) in ((256, 256), (512, 512)) else 1), used     # (the model's shapes: forward AND backward-data; elsewhere the backward-data
+        #  may have too few tiles for the two-per-CU launch or 64 output columns)
+        # the same products in another summation order: forward outputs of the two kernels
+        dtype = torch.bfloat16
+        x = nhwc(rnd(Bn, Cin, H, W, dtype=dtype, seed=40))
+        w = rnd(Cout, Cin, 3, 3, dtype=dtype, seed=41, scale=1.0 / math.sqrt(Cin * 9)).permute(0, 2, 3, 1).contiguous()
+        bias = rnd(Cout, seed=42)
+        ys = []
+        for mode in (1, 0):
+            h.set_option(h.OPT_C3_HALO, mode)
+            y = torch.empty(Bn, H, W, Cout, device=DEV, dtype=dtype)
+            h.conv2d(0, x, w, y, Bn, H, W, Cin, Cin, H, W, Cout, 3, 3, 1, 1, 1, 1, bias=bias, act=h.ACT_RELU)
+            ys.append(y)
+        torch.cuda.synchronize()
+        assert rel(ys[0], ys[1]) < 4e-3, rel(ys[0], ys[1])
+    finally:
+        h.set_option(h.OPT_C3_HALO, prev)
+
+
 @pytest.mark.parametrize('Cin,Cout,k,s,H,W', [
     (512, 512, 3, 1, 15, 20),       # layer4 conv2 at batch 1: 300 pixels, K = 4608 -> split 8
     (256, 256, 3, 1, 30, 40),       # layer3 conv2: 1200 pixels, K = 2304
