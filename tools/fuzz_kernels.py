@@ -134,6 +134,12 @@ for it in range(max(rounds // 3, 2)):
             r = T.rel(q[2], ref)
             assert r < 1e-5, (q[4:], r)
     run('wgrad_group', one)
+# round 5: the halo-image 3x3 tile kernel (stride 1, image width <= 47, enough pixels for the two-per-CU launch) on random image sizes
+for it in range(max(rounds // 2, 3)):
+    H, W = rng.randint(1, 47), rng.randint(1, 47)
+    Cin, Cout = 64 * rng.randint(1, 8), 128 * rng.randint(1, 4)
+    Bn = max(1, (rng.randint(31000, 42000) + H * W - 1) // (H * W))
+    run('conv3x3_halo', T.test_conv3x3_halo_image_kernel, Cin, Cout, H, W, Bn, False)      # (whether a random shape fills the two-per-CU slots is not the point here)
 # round 5: the fused in-projection attention and the projection + LayerNorm launch on random batch / sequence sizes, the small-M kernel's
 # three tile shapes, the streaming 1x1 kernel (DMA-staged, swizzled weights) as a plain GEMM on every (K, N) it instantiates
 for it in range(rounds):

@@ -1,4 +1,4 @@
-( echo "# tools/fuzz_kernels.py 5 30 | fuzz_model.py | fuzz_decode.py | fuzz_full.py at the end of round 5 (small-M tile shapes, fused in-projection attention, projection + LayerNorm launch, DMA-staged streaming kernel, half-width weight-gradient tiles, inline-asm stores of the streaming 1x1 kernels in)"
+( echo "# tools/fuzz_kernels.py 5 30 | fuzz_model.py | fuzz_decode.py | fuzz_full.py at the end of round 5 (small-M tile shapes, fused in-projection attention, projection + LayerNorm launch, DMA-staged streaming kernel, half-width weight-gradient tiles, inline-asm stores of the streaming 1x1 kernels, halo-image 3x3 tile kernel in)"
 python tools/fuzz_kernels.py 5 30 2>&1 | tail -12
 python tools/fuzz_model.py 2>&1 | tail -6
 python tools/fuzz_decode.py 2>&1 | tail -5
