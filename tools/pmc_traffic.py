@@ -24,7 +24,7 @@ def is_conv(name):
         return False
     return (('gemm_kernel' in n and 'Li2ELi0E' in n) or ('gemm_kernel<' in n and ', 1, 2, ' in n) or 'glds_kernelILi2E' in n or 'conv1x1_kernel' in n
             or 'glds_wgrad_kernel' in n or 'pipe_kernelILi2E' in n or 'c1s_kernel' in n or 'conv1x1_nt_kernel' in n
-            or 'c3r_kernel' in n or 'c3d2_kernel' in n or 'c1d_kernel' in n or 'c1c_kernel' in n or 'stem_pool_kernel' in n or 'glds_wgrad_group_kernel' in n or 'wg8_group_kernel' in n or 'wg8h_group_kernel' in n)
+            or 'c3r_kernel' in n or 'c3d2_kernel' in n or 'c1d_kernel' in n or 'c1c_kernel' in n or 'stem_pool_kernel' in n or 'glds_wgrad_group_kernel' in n or 'wg8_group_kernel' in n or 'wg8h_group_kernel' in n or 'glds_halo_kernel' in n)
 
 
 def is_conv_helper(name):          # second kernel of a conv launch (1x1 stride-2 backward-data: the element-wise three quarters): bytes count, launches do not
@@ -38,7 +38,7 @@ write_kb = sum(v[0] for k, v in Wr.items() if is_conv(k) or is_conv_helper(k)); 
 steps = sum(v[1] for k, v in F.items() if 'stem_pool_kernel' in k) or nf / LAUNCHES_PER_PASS
 kernels_per_pass = nf / steps
 res = {
-    'what': 'c1s_kernel / c1c_kernel / c3r_kernel / stem_pool_kernel / gemm_kernel<OP_CONV,...> / conv1x1_kernel / pipe_kernel<OP_CONV> / pipe_conv1x1_kernel / glds_kernel<OP_CONV> / glds_conv1x1_kernel / c3d2_kernel / c1d_kernel / glds_wgrad_group_kernel / wg8_group_kernel / wg8h_group_kernel (+ s2_dgrad_fill_kernel, wgrad_group_reduce_kernel bytes) launches of `python bench.py` (B=32 train step)',
+    'what': 'c1s_kernel / c1c_kernel / c3r_kernel / stem_pool_kernel / gemm_kernel<OP_CONV,...> / conv1x1_kernel / pipe_kernel<OP_CONV> / pipe_conv1x1_kernel / glds_kernel<OP_CONV> / glds_halo_kernel / glds_conv1x1_kernel / c3d2_kernel / c1d_kernel / glds_wgrad_group_kernel / wg8_group_kernel / wg8h_group_kernel (+ s2_dgrad_fill_kernel, wgrad_group_reduce_kernel bytes) launches of `python bench.py` (B=32 train step)',
     'passes_profiled': steps, 'conv_kernel_launches_per_pass': kernels_per_pass, 'conv_launches_fetch_pass': nf, 'conv_launches_write_pass': nw,
     'FETCH_SIZE_KB_raw': fetch_kb, 'WRITE_SIZE_KB_raw': write_kb,
     'fetch_bytes_corrected_x2': fetch_kb * 1024 * 2, 'write_bytes': write_kb * 1024,
