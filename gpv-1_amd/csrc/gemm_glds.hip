@@ -433,7 +433,7 @@ __global__ __launch_bounds__(BM == 256 ? 512 : 256) void glds_kernel(GemmK p) {
 //     out-of-range DMA offset did per tap;
 //   * delivered bytes per 64 channels: (BM + 96) x 128 + 9 x 16 KB instead of 9 x (BM x 128 + 16 KB).
 // Register epilogue, XCD-aware tile order, loaders and fragment layout are glds_body's.  W <= 47, Cin % 64 == 0, N % 128 == 0.
-int g_halo_mode = tune_env("GPV_C3_HALO", 1);       // gpv_set_option(GPV_OPT_C3_HALO, .)
+int g_halo_mode = tune_env("GPV_C3_HALO", 1);       // gpv_set_option(GPV_OPT_C3_HALO, .): 0 never, 1 the 160-row tiles (where it wins), 2 the 96-row tiles as well
 long g_halo_launches = 0;
 
 template <int BM>
@@ -716,7 +716,7 @@ int glds_try_launch(const GemmK& k, int amode, int dtype_in, int dtype_out, int 
     const int bm2 = two_per_cu_bm(k, batch);
     if (amode == OP_CONV && halo_ok(k, dtype_out, batch)) {
       if (bm2 == 160) return launch_halo<160>(k, st);
-      if (bm2 == 96) return launch_halo<96>(k, st);
+      if (bm2 == 96 && g_halo_mode >= 2) return launch_halo<96>(k, st);     // 96-row tiles (layer4): forward 57.2 against 55.0 us, backward-data equal (tools/bench_c3_halo.py) -- tests only
     }
     if (bm2 == 160) return amode == OP_CONV ? launch_glds_out<OP_CONV, 160, 128>(k, dtype_out, batch, st) : launch_glds_out<OP_PLAIN, 160, 128>(k, dtype_out, batch, st);
     if (bm2 == 96) return amode == OP_CONV ? launch_glds_out<OP_CONV, 96, 128>(k, dtype_out, batch, st) : launch_glds_out<OP_PLAIN, 96, 128>(k, dtype_out, batch, st);

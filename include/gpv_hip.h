@@ -84,7 +84,7 @@ int gpv_gemm_tt_group_ws(const gpv_tt_problem* problems, int n, void* workspace,
 #define GPV_OPT_PIPE_SMALL 17 /* gemm_pipe.hip's small-M configurations (64 x 64 / 32 x 64 tiles, 6 / 8 stages): 1 (default) by heuristic, 0 never -- the inference paths switch them off
                                  (greedy batch 64: 15.0 -> 14.05 ms per batch; the training step's backward shapes prefer them: B1 +0.1 ms without) */
 #define GPV_OPT_WG8H 18 /* the eight-phase kernel on 128 x 256 | 256 x 128 tiles (gemm_glds_tt.hip wg8h_*) in gpv_conv_wgrad_group, problems with Cout, Cin multiples of 128 that the 256 x 256 launch does not take (layer2): 1 (default) wherever legal, 0 never */
-#define GPV_OPT_C3_HALO 19 /* stride-1 3x3 convolutions (forward / backward-data) of the two-blocks-per-CU tile kernel with ONE halo image per channel block instead of nine tap tiles (gemm_glds.hip glds_halo_kernel; image width <= 47, Cin % 64 == 0, N % 128 == 0): 1 (default) wherever legal, 0 never */
+#define GPV_OPT_C3_HALO 19 /* stride-1 3x3 convolutions (forward / backward-data) of the two-blocks-per-CU tile kernel with ONE halo image per channel block instead of nine tap tiles (gemm_glds.hip glds_halo_kernel; image width <= 47, Cin % 64 == 0, N % 128 == 0): 0 never, 1 (default) the 160-row tiles, 2 the 96-row tiles as well (no gain there: tests) */
 #define GPV_OPT_C3_HALO_LAUNCHES 20 /* returns the number of halo-image launches so far, then sets the counter to value */
 #define GPV_OPT_W8L 16 /* the same kernel in gpv_gemm_tt_group_ws (problems with M, N multiples of 256): 0 (default) never, 1 wherever legal */
 #define GPV_OPT_C1S_LAUNCHES 13 /* returns the number of streaming-1x1 launches so far (convolutions and the K = 256 linear GEMMs), then sets the counter to value */

@@ -597,7 +597,7 @@ def test_conv3x3_halo_image_kernel(Cin, Cout, H, W, Bn, check_used=True):
     (gemm_glds.hip glds_halo_kernel: one halo image per channel block, taps as shifted fragment reads, border lanes zeroed) against
     fp32 torch and against the nine-tap-tile kernel on the same operands; and that these shapes really take it"""
     h = hip()
-    prev = h.set_option(h.OPT_C3_HALO, 1)
+    prev = h.set_option(h.OPT_C3_HALO, 2)                 # (2: the 96-row tiles as well -- the default keeps those on the nine-tap kernel)
     n0 = h.set_option(h.OPT_C3_HALO_LAUNCHES, 0)
     try:
         test_conv_fwd_dgrad_wgrad(torch.bfloat16, Cin, Cout, 3, 1, 1, H, W, Bn=Bn)
@@ -610,7 +610,7 @@ def test_conv3x3_halo_image_kernel(Cin, Cout, H, W, Bn, check_used=True):
         w = rnd(Cout, Cin, 3, 3, dtype=dtype, seed=41, scale=1.0 / math.sqrt(Cin * 9)).permute(0, 2, 3, 1).contiguous()
         bias = rnd(Cout, seed=42)
         ys = []
-        for mode in (1, 0):
+        for mode in (2, 0):
             h.set_option(h.OPT_C3_HALO, mode)
             y = torch.empty(Bn, H, W, Cout, device=DEV, dtype=dtype)
             h.conv2d(0, x, w, y, Bn, H, W, Cin, Cin, H, W, Cout, 3, 3, 1, 1, 1, 1, bias=bias, act=h.ACT_RELU)
