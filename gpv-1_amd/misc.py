@@ -145,6 +145,71 @@ def note_sync_collective():
     CollectiveClock.idle_since = None
 
 
+# Round 6: the clock is armed by the collectives THEMSELVES, not by the callers' good manners.  Every
+# torch.distributed entry point that runs on the caller's stream when called without async_op=True is wrapped once per process
+# (install_collective_hooks: idempotent, installed by train.init_process_group, FlatTrainer and the first quiesce_collectives with a
+# process group alive): an eval loop's all_gather of metrics, a checkpoint barrier or a driver's broadcast_object_list now make
+# the next capture wait for the watchdog exactly like the trainer's own announced ones.  A collective reached through a name bound
+# BEFORE the hooks went in (`from torch.distributed import barrier` at import time) is the documented residue: such drivers call
+# note_sync_collective() or run with GPV_QUIESCE=always.
+_SYNC_COLLECTIVES = ('broadcast', 'all_reduce', 'all_reduce_coalesced', 'reduce', 'all_gather', 'all_gather_into_tensor',
+                     'all_gather_coalesced', 'gather', 'scatter', 'reduce_scatter', 'reduce_scatter_tensor', 'all_to_all',
+                     'all_to_all_single', 'barrier', 'monitored_barrier', 'send', 'recv', 'broadcast_object_list',
+                     'all_gather_object', 'gather_object', 'scatter_object_list', '_all_gather_base', '_reduce_scatter_base')
+_HOOKED = [False]
+ARM_BACKENDS = ('nccl',)            # backends whose synchronous collectives run on the caller's DEVICE stream (tests add 'gloo')
+
+
+def _runs_on_device_stream(group):
+    """does a synchronous collective of this process group run on the calling thread's device stream?  (gloo -- the trainer's
+    host-side agreement channel -- runs on the host: nothing for a capture to trip over)"""
+    import torch.distributed as dist
+    try:
+        return any(b in str(dist.get_backend(group)) for b in ARM_BACKENDS)
+    except Exception:
+        return True                 # (unknown group: the safe side)
+
+
+def install_collective_hooks():
+    """wrap torch.distributed's collectives so that a synchronous call arms CollectiveClock (asynchronous ones -- async_op=True: on
+    RCCL's own stream, which never captures -- do not).  Returns the number of entry points wrapped by THIS call."""
+    if _HOOKED[0]:
+        return 0
+    import functools
+    import torch.distributed as dist
+    if not dist.is_available():
+        return 0
+    mods = [dist]
+    c10d = getattr(dist, 'distributed_c10d', None)
+    if c10d is not None:
+        mods.append(c10d)
+    n = 0
+    for name in _SYNC_COLLECTIVES:
+        fn = getattr(mods[-1], name, None) or getattr(dist, name, None)
+        if fn is None or getattr(fn, '_gpv_sync_hook', False):
+            continue
+
+        def make(fn):
+            @functools.wraps(fn)
+            def hooked(*a, **k):
+                try:
+                    return fn(*a, **k)
+                finally:
+                    if not k.get('async_op', False) and _runs_on_device_stream(k.get('group')):
+                        note_sync_collective()
+            hooked._gpv_sync_hook = True
+            hooked._gpv_wrapped = fn
+            return hooked
+        h = make(fn)
+        for m in mods:
+            if getattr(m, name, None) is fn:
+                setattr(m, name, h)
+        n += 1
+    _HOOKED[0] = True
+    note_sync_collective()             # whatever ran before the hooks existed is unknown: the next capture waits once
+    return n
+
+
 def quiesce_collectives():
     """With a process group alive, a stream capture must not begin while ProcessGroupNCCL's watchdog thread still polls the
     completion event of a collective that ran ON THE STREAM ABOUT TO CAPTURE (HIP: hipErrorCapturedEvent on the query, the capture
@@ -153,14 +218,16 @@ def quiesce_collectives():
     Round 5: that wait is paid only when such a collective is actually outstanding (CollectiveClock.pending).  Round 4 slept 0.35 s in
     front of EVERY capture -- two per new batch signature, on every rank in lock-step: seconds of a ragged stream's first epoch.  The
     per-step collectives of the trainer are asynchronous (RCCL's stream, never captured) and do not arm the clock; the synchronous
-    ones (parameter broadcast at construction, barriers of the drivers) do, through note_sync_collective().  GPV_QUIESCE=always
-    restores the unconditional wait."""
+    ones (parameter broadcast at construction, barriers of the drivers, any eval / checkpoint collective) do: torch.distributed's
+    entry points are wrapped (install_collective_hooks, round 6) and arm the clock themselves; note_sync_collective() remains for
+    collectives issued through other bindings.  GPV_QUIESCE=always restores the unconditional wait."""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or not torch.cuda.is_available():
         return
     import time
     cc = CollectiveClock
     cc.calls += 1
+    install_collective_hooks()          # (no-op after the first call; a first call arms the clock: history unknown)
     torch.cuda.synchronize()
     if cc.MODE == 'never' or (cc.MODE != 'always' and not cc.pending):
         return

@@ -71,6 +71,8 @@ def init_process_group(rank, world, device, backend=None):
     into a tail.  device_id: eager communicator init bound to this rank's GPU (no lazy init inside the first step)."""
     cuda = str(device).startswith('cuda')
     backend = backend or ('nccl' if cuda else 'gloo')
+    from .misc import install_collective_hooks
+    install_collective_hooks()           # synchronous collectives arm the capture quiesce themselves (misc.CollectiveClock)
     if backend != 'nccl':
         dist.init_process_group(backend, rank=rank, world_size=world)
         return
@@ -647,6 +649,8 @@ class FlatTrainer:
         self.defer_wgrad = os.environ.get('GPV_DEFER_WGRAD', '1') != '0'       # (with several ranks the groups stay inside B1)
         self.host_pg = None
         if self.comm:
+            from .misc import install_collective_hooks
+            install_collective_hooks()       # (a process group the caller built itself: the hooks go in here at the latest)
             dist.broadcast(self.P, src=0, group=self.pg)
             # DDP broadcasts every parameter AND buffer from rank 0 at construction; the tensors this trainer does not manage
             # (frozen BERT, vocabulary embedding, FrozenBN statistics, the frozen stem / layer1) must not depend on each rank's seed

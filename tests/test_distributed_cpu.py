@@ -72,6 +72,38 @@ def _worker(rank, world, port, out):
     res['left_after_backward'], res['backbone_end'], res['total'] = getattr(tr, 'left_after_backward', None), tr.backbone_end, tr.total
     res['P'] = tr.P.clone()
     res['names'] = [e[0] for e in tr.entries]
+    # an UNANNOUNCED synchronous collective (an eval loop's all_gather, a checkpoint barrier: nobody calls
+    # note_sync_collective) must arm the capture quiesce by itself -- the trainer installed the hooks; the per-step asynchronous
+    # collectives must not (a ragged stream would wait 0.35 s per capture again)
+    import gpv1_amd.misc as misc
+    cc = misc.CollectiveClock
+    arm = {}
+    misc.ARM_BACKENDS = ('nccl', 'gloo')          # (this test's "device" backend is gloo)
+    cc.pending = False
+    dist.barrier()
+    arm['barrier'], cc.pending = cc.pending, False
+    t = torch.ones(4)
+    dist.all_reduce(t)
+    arm['all_reduce_sync'], cc.pending = cc.pending, False
+    dist.all_reduce(t, async_op=True).wait()
+    arm['all_reduce_async'], cc.pending = cc.pending, False
+    objs = [{'rank': rank}]
+    dist.broadcast_object_list(objs, src=0)
+    arm['broadcast_object_list'], cc.pending = cc.pending, False
+    misc.ARM_BACKENDS = ('nccl',)
+    dist.barrier()                                # a host-side (gloo) collective: nothing on a device stream
+    arm['gloo_barrier_as_host_channel'] = cc.pending
+    # a whole step, with the step's own process group treated as the device backend: every device collective of train_step must
+    # be asynchronous (RCCL's own stream); the one synchronous call is the host agreement channel (FlatTrainer.host_pg)
+    sync_calls = []
+    real = misc.note_sync_collective
+    misc.ARM_BACKENDS = ('nccl', 'gloo')
+    misc.note_sync_collective = lambda: (sync_calls.append(''.join(__import__('traceback').format_stack(limit=4))), real())[-1]
+    tr.train_step(nested(images, mask), (ids, attn), _targets(rank, V))
+    misc.note_sync_collective = real
+    arm['train_step_sync_calls'] = len(sync_calls)
+    arm['train_step_sync_is_host_channel'] = all('_any_rank_has_loss' in c for c in sync_calls)
+    res['arm'] = arm
     torch.save(res, os.path.join(out, f'rank{rank}.pt'))
     dist.destroy_process_group()
 
@@ -88,6 +120,10 @@ def test_two_rank_gradient_exchange(tmp_path):
     os.environ.pop('GPV_OVERLAP')
     r0, r1 = runs['1']
     assert r0['overlap'] and r0['late_touch'] is None and r1['late_touch'] is None
+    for r in (r0, r1):                              # synchronous collectives arm the capture quiesce by themselves, asynchronous ones do not
+        assert r['arm'] == {'barrier': True, 'all_reduce_sync': True, 'all_reduce_async': False, 'broadcast_object_list': True,
+                            'gloo_barrier_as_host_channel': False, 'train_step_sync_calls': 1,
+                            'train_step_sync_is_host_channel': True}, r['arm']
     # hand-over order: everything behind the backbone segment when the backward pass reaches the backbone, then the backbone's
     # stages as each one's weight gradients have been issued -- layer4 (the largest) while layer3 / layer2 still compute
     for r in (r0, r1):

@@ -48,3 +48,60 @@ def test_forced_single_rank_rccl_exchange_runs_the_multi_gpu_path_and_changes_no
     assert half['comm']['grad_comm_dtype'] == 'bfloat16' and half['graphs']['enabled']
     h = half['config']['final_loss']
     assert h == h and abs(h - a) <= 5e-2 * abs(a), (a, h)                  # gradients rounded to bf16 once: close, not equal
+
+
+_UNANNOUNCED = r'''
+import os, sys, json
+sys.path.insert(0, os.environ['GPV_ROOT'])
+import torch
+import torch.distributed as dist
+from tests import synth
+from tests.test_model_cpu import build_small, nested, V, B, H, W, Tl, PAD
+import gpv1_amd.misc as misc
+from gpv1_amd.train import FlatTrainer, init_process_group
+torch.cuda.set_device(0)
+init_process_group(0, 1, 'cuda:0')                      # RCCL, one rank; installs the collective hooks
+model, _ = build_small()
+model.to('cuda').train()
+model.bert.model.p = 0.0
+tr = FlatTrainer(model, lr=1e-4, lr_backbone=1e-5, bucket_mb=8)
+assert tr.comm and dist.get_backend() == 'nccl'
+images, mask, ids, attn = [t.cuda() for t in synth.synth_batch(B, H, W, Tl, V, seed=1234, pad_to=PAD)]
+cc = misc.CollectiveClock
+losses, sleeps = [], []
+for S in (4, 12, 20, 28):                                  # four answer-length classes = four signatures = eight captures
+    tg = synth.synth_targets(B, V, S=S, tasks=('CocoCaptioning',))
+    loss = tr.train_step(nested(images, mask), (ids, attn), tg)          # first sight of the signature: eager
+    before = cc.sleeps
+    # what an eval loop / checkpoint writer does between steps, WITHOUT telling anybody (ADVICE r5): synchronous collectives on the
+    # compute stream, then immediately a step whose signature is captured now -- inside the watchdog's 100 ms polling period
+    dist.barrier()
+    t = torch.ones(8, device='cuda')
+    dist.all_reduce(t)
+    loss = tr.train_step(nested(images, mask), (ids, attn), tg)          # second sight: GraphedBody captures F1 | F2 | B1 | B2
+    loss = tr.train_step(nested(images, mask), (ids, attn), tg)          # replay
+    torch.cuda.synchronize()
+    losses.append(float(loss))
+    sleeps.append(cc.sleeps - before)
+print(json.dumps({'losses': losses, 'sleeps': sleeps, 'graph_steps': tr.graph_steps, 'eager_steps': tr.eager_steps, 'graphs': bool(tr.graphs),
+                  'bodies': len(tr._bodies), 'mode': cc.MODE}))
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.timeout(900)
+def test_unannounced_synchronous_collective_before_a_capture_is_quiesced():
+    """ADVICE r5 (medium): in GPV_QUIESCE=auto a capture skipped the watchdog wait unless a caller had announced its synchronous
+    collective (note_sync_collective); a checkpoint barrier or an eval all-reduce nobody announced left the next capture to die with
+    hipErrorCapturedEvent (round 4: 3 of 20 runs).  Round 6: torch.distributed's entry points arm the clock themselves
+    (misc.install_collective_hooks).  Real backend, one rank: unannounced barrier + all_reduce right in front of four new-signature
+    captures -- every one of them waits once, none fails (strict mode: a failed capture raises)."""
+    env = dict(os.environ)
+    env.update({'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': '29547', 'HSA_ENABLE_IPC_MODE_LEGACY': '0', 'GPV_GRAPHS_STRICT': '1',
+                'GPV_FORCE_COMM': '1', 'GPV_ROOT': ROOT, 'RANK': '0', 'WORLD_SIZE': '1'})
+    r = subprocess.run([sys.executable, '-c', _UNANNOUNCED], cwd=ROOT, env=env, capture_output=True, text=True, timeout=800)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+    assert out['mode'] == 'auto' and out['graphs'] and out['bodies'] == 4 and out['graph_steps'] >= 8, out
+    assert all(s >= 1 for s in out['sleeps']), out                  # the unannounced collectives armed the clock every time
+    assert all(l == l for l in out['losses']), out
