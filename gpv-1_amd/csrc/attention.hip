@@ -1608,6 +1608,10 @@ extern "C" int gpv_attention_qkv_fwd(const gpv_attn_args* a, const void* xp, con
   if ((x_rs & 7) || (x_bs & 7) || (a->q_rs & 3) || (a->k_rs & 3) || (a->o_rs & 3)) return (int)hipErrorInvalidValue;
   if ((reinterpret_cast<uintptr_t>(xp) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w)) & 15) return (int)hipErrorInvalidValue;
   if ((reinterpret_cast<uintptr_t>(a->q) | reinterpret_cast<uintptr_t>(a->k) | reinterpret_cast<uintptr_t>(a->o)) & 7) return (int)hipErrorInvalidValue;
+  // v is WRITTEN (element stores: 2-byte alignment is all the kernel needs -- the core re-reads V^T from LDS, not from here); the bias is
+  // read as single floats.  Both are checked so that everything the header promises is refused before a launch.
+  if (!a->v || (reinterpret_cast<uintptr_t>(a->v) & 1) || (reinterpret_cast<uintptr_t>(bias) & 3) || a->v_rs < a->H * a->dh || a->q_rs < a->H * a->dh ||
+      a->k_rs < a->H * a->dh) return (int)hipErrorInvalidValue;
   QkvK xk{reinterpret_cast<const bf16*>(xp), reinterpret_cast<const bf16*>(x), x_bs, x_rs, reinterpret_cast<const bf16*>(w), bias};
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (p.skp <= 128) return p.skp == 128 ? launch_qkv<8, true>(p, xk, st) : launch_qkv<8, false>(p, xk, st);

@@ -969,6 +969,7 @@ extern "C" int gpv_gemm(const gpv_gemm_args* a, void* stream) {
   k.dscale = a->drop_p > 0.f ? 1.0f / (1.0f - a->drop_p) : 1.0f;
   k.accumulate = a->accumulate; k.split_k = a->split_k;
   k.a_rowsum = a->a_rowsum;
+  k.no_small = (a->flags & GPV_GEMM_NO_PIPE_SMALL) ? 1 : 0;
   k.ws_base = a->workspace; k.ws_bytes = a->workspace ? a->workspace_bytes : 0;
   if (k.a_rowsum && !(a->layoutA == GPV_TRANS && a->layoutB == GPV_TRANS && a->batch == 1)) return (int)hipErrorInvalidValue;
   if (a->accumulate && a->split_k <= 1 && !a->res) {

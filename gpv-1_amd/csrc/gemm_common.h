@@ -27,6 +27,7 @@ struct GemmK {
   int vecA, vecB;
   int conv1x1;         // launched from gpv_conv2d as a plain GEMM: use the conv1x1_kernel name
   int depi;            // gemm_glds.hip: register epilogue over permuted output columns (set by launch_glds)
+  int no_small;        // host side: gpv_gemm_args.flags & GPV_GEMM_NO_PIPE_SMALL (pipe_try_launch skips its small-M configurations for this call)
   int nt_io;           // epilogue stores / residual loads non-temporal (outputs far larger than the 256 MB MALL: layer1's 314 MB maps)
   void* ws_base; int64_t ws_bytes;   // host side: caller workspace for split reductions
   float* ws;                         // kernel side: != NULL -> split s writes its partial product to ws[s][M][N]

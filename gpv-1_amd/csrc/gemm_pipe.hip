@@ -524,7 +524,7 @@ int pipe_try_launch(const GemmK& k, int amode, int dtype_in, int dtype_out, int 
   if (mode >= 100) {
     idx = mode - 100;
     if (idx >= kNumCfgs || k.N % kCfgs[idx].bn != 0 || (idx >= kNumBig && amode != OP_PLAIN)) return -1;
-  } else if (g_pipe_small && amode == OP_PLAIN && !k.conv1x1 && k.K >= 256 &&
+  } else if (g_pipe_small && !k.no_small && amode == OP_PLAIN && !k.conv1x1 && k.K >= 256 &&
              (int64_t)((k.M + 63) / 64) * (k.N / 64) * batch <= 250 &&
              ((int64_t)((k.M + 63) / 64) * (k.N / 64) * batch >= 100 || k.K <= 1024)) {
     // small-M GEMMs (BERT and the co-attention text stream at M = 192, the text decoder at 640 rows): too few 64x64 tiles to

@@ -279,7 +279,7 @@ class GPV(nn.Module):
         if not self.training and not torch.is_grad_enabled() and images_on_gpu(images):
             # inference: the small GEMMs of these batch sizes run faster without gemm_pipe.hip's small-M configurations (greedy batch 64
             # 15.0 -> 14.05 ms, batch 1 -0.08 ms; same box) -- the option is read when the launches are issued / captured
-            with hip.option(hip.OPT_PIPE_SMALL, 0):
+            with hip.gemm_flags(hip.GEMM_NO_PIPE_SMALL):          # per call, this thread only (not the process-wide GPV_OPT_PIPE_SMALL)
                 return self._forward_entry(images, queries, answer_token_ids, targets, vocab_mask)
         return self._forward_entry(images, queries, answer_token_ids, targets, vocab_mask)
 

@@ -6,6 +6,7 @@ Tensors are passed as raw device pointers (``tensor.data_ptr()``) + the current 
 """
 import ctypes as C
 import os
+import threading
 
 import torch
 
@@ -126,8 +127,35 @@ OPT_GEMV, OPT_GEMV_LAUNCHES = 9, 10
 OPT_ATTN_BWD1, OPT_ATTN_BWD1_LAUNCHES, OPT_C1S_LAUNCHES, OPT_WG8, OPT_WG8_LAUNCHES, OPT_W8L, OPT_PIPE_SMALL, OPT_WG8H, OPT_C3_HALO, OPT_C3_HALO_LAUNCHES = 11, 12, 13, 14, 15, 16, 17, 18, 19, 20
 
 
+GEMM_NO_PIPE_SMALL = 2      # gpv_gemm_args.flags: GPV_GEMM_NO_PIPE_SMALL
+_TL = threading.local()
+
+
+class gemm_flags:
+    """with hip.gemm_flags(GEMM_NO_PIPE_SMALL): ... -- flags or-ed into every gpv_gemm call THIS THREAD issues inside the block (and
+    into the launches a graph capture inside it records).  Per call and per thread: the autograd thread of a running backward, a
+    data-loader thread or a second model never see it (round 5 flipped the process-wide GPV_OPT_PIPE_SMALL around every eval
+    forward)."""
+
+    def __init__(self, flags):
+        self.flags = flags
+
+    def __enter__(self):
+        self.prev = getattr(_TL, 'gemm_flags', 0)
+        _TL.gemm_flags = self.prev | self.flags
+        return self
+
+    def __exit__(self, *exc):
+        _TL.gemm_flags = self.prev
+        return False
+
+
+_OPT_SET = {}          # option -> the value this process last set (the library's defaults are not mirrored here)
+
+
 def set_option(option, value):
     """gpv_set_option: kernel-selection knob (tests / tuning); returns the previous value"""
+    _OPT_SET[option] = value
     return lib().gpv_set_option(C.c_int(option), C.c_int(value))
 
 
@@ -242,7 +270,7 @@ def gemm(A, B, Cm, M, N, K, lda, ldb, ldc, layoutA=KMAJOR, layoutB=KMAJOR, batch
     a.act, a.drop_p, a.seed = act, drop_p, seed
     a.accumulate, a.split_k = int(accumulate), split_k
     a.a_rowsum = _p(_f32(a_rowsum))
-    a.flags = 1 if kpad_finite else 0                   # GPV_GEMM_KPAD_FINITE
+    a.flags = (1 if kpad_finite else 0) | getattr(_TL, 'gemm_flags', 0)      # GPV_GEMM_KPAD_FINITE | the calling thread's per-call flags
     if accumulate and batch == 1:                      # the library may split the reduction (further) when it has scratch
         # (the direct-to-LDS weight-gradient kernel sizes its own split: 512 blocks of 128x128 fp32 partials = 32 MiB)
         ws = _workspace(A.device, max(max(split_k, 8) * M * N * 4, 512 * 128 * 128 * 4))
@@ -268,8 +296,14 @@ def gemm_tt_group(problems):
         a = arr[i]
         a.A, a.B, a.C, a.a_rowsum = dy.data_ptr(), x.data_ptr(), dw.data_ptr(), (bg.data_ptr() if bg is not None else None)
         a.M, a.N, a.K, a.lda, a.ldb, a.ldc = M, N, K, lda, ldb, ldc
-    ws = _workspace(problems[0][0].device, WS_MAX)
-    _chk(lib().gpv_gemm_tt_group_ws(arr, C.c_int(len(problems)), _p(ws), C.c_int64(ws.numel()), _stream()), 'gpv_gemm_tt_group_ws')
+    # the workspace only serves the 256 x 256 eight-phase path (GPV_OPT_W8L, off by default; the tuning build may switch it on
+    # from the environment): without it every problem falls through to gpv_gemm_tt_group and NULL is legal -- no 256 MB grown per
+    # (device, stream) for nothing
+    if _OPT_SET.get(OPT_W8L, 0) or os.environ.get('GPV_W8L', '0') not in ('', '0'):
+        ws = _workspace(problems[0][0].device, WS_MAX)
+        _chk(lib().gpv_gemm_tt_group_ws(arr, C.c_int(len(problems)), _p(ws), C.c_int64(ws.numel()), _stream()), 'gpv_gemm_tt_group_ws')
+    else:
+        _chk(lib().gpv_gemm_tt_group_ws(arr, C.c_int(len(problems)), None, C.c_int64(0), _stream()), 'gpv_gemm_tt_group_ws')
 
 
 def conv2d(mode, x, w, y, B, IH, IW, Cs, Cin, OH, OW, Cout, KH, KW, SH, SW, PH, PW, rowscale=None, bias=None,
@@ -339,6 +373,8 @@ def attention_fwd(q, k, v, o, strides, B, H, Sq, Sk, dh, scale, kpm=None, causal
 
 def attention_qkv_fwd(xp, x, w, bias, q, k, v, o, strides, B, H, S, scale, kpm=None, drop_p=0.0, seed=0, lse=None):
     """gpv_attention_qkv_fwd: q / k / v (column slices of the projection buffers) are WRITTEN; xp, x: [B * S, 256] rows"""
+    if xp.stride() != x.stride() or xp.shape != x.shape or x.stride(-1) != 1 or xp.dtype != x.dtype:
+        raise ValueError('attention_qkv_fwd: xp and x must share one row layout (the library takes ONE pair of strides for both)')
     a = _attn_args(q, k, v, o, strides, B, H, S, S, 32, scale, kpm, False, drop_p, seed, lse)
     _chk(lib().gpv_attention_qkv_fwd(C.byref(a), _p(xp), _p(x), C.c_int64(S * x.stride(0)), C.c_int64(x.stride(0)), _p(w), _p(_f32(bias)),
                                      _stream()), 'gpv_attention_qkv_fwd')

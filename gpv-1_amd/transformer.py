@@ -51,7 +51,9 @@ class LayerNormP(nn.Module):
     def proj(self, x, a, lin, drop_p=0.0, chain=None, pos=None, pos_param=None):
         """LayerNorm(x + dropout(lin(a))): the projection inside the LayerNorm launch where the kernel takes it (width 256, bf16)"""
         w = W(lin.weight, lin.bias)
-        if ops.proj_layernorm_ok(w, x):
+        # (GPV_LN_POS=0 -- the timing A/B of the fused position sum -- must switch THIS site too: the two-launch path goes through
+        #  add_layernorm's handling of the switch and its guard, ADVICE r5)
+        if ops.proj_layernorm_ok(w, x) and (pos is None or ops.LN_POS):
             return ops.proj_add_layernorm(x, a, w, self.weight, self.bias, self.eps, drop_p, chain, pos, pos_param)
         return self.forward(x, lin(a), drop_p, chain, pos, pos_param)
 

@@ -128,6 +128,8 @@ typedef struct {
                                      of 8 (RoI pooling: K = H*W = 300 of a 320-pitch weight row) use the 16-byte load path */
 } gpv_gemm_args;
 #define GPV_GEMM_KPAD_FINITE 1
+#define GPV_GEMM_NO_PIPE_SMALL 2  /* this call never takes gemm_pipe.hip's small-M configurations (what GPV_OPT_PIPE_SMALL = 0 does process-wide):
+                                     the inference paths pass it per call (round 6, ADVICE r5: the process-wide switch raced with launches of other threads) */
 int gpv_gemm(const gpv_gemm_args* a, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
