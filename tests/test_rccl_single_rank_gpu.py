@@ -66,11 +66,11 @@ model.to('cuda').train()
 model.bert.model.p = 0.0
 tr = FlatTrainer(model, lr=1e-4, lr_backbone=1e-5, bucket_mb=8)
 assert tr.comm and dist.get_backend() == 'nccl'
-images, mask, ids, attn = [t.cuda() for t in synth.synth_batch(B, H, W, Tl, V, seed=1234, pad_to=PAD)]
 cc = misc.CollectiveClock
 losses, sleeps = [], []
-for S in (4, 12, 20, 28):                                  # four answer-length classes = four signatures = eight captures
-    tg = synth.synth_targets(B, V, S=S, tasks=('CocoCaptioning',))
+tg = synth.synth_targets(B, V, S=6, tasks=('CocoCaptioning',))
+for T_q in (5, 6, 7, 8):                                   # four query lengths (exact classes up to 8 tokens) = four signatures = eight captures
+    images, mask, ids, attn = [t.cuda() for t in synth.synth_batch(B, H, W, T_q, V, seed=1234, pad_to=PAD)]
     loss = tr.train_step(nested(images, mask), (ids, attn), tg)          # first sight of the signature: eager
     before = cc.sleeps
     # what an eval loop / checkpoint writer does between steps, WITHOUT telling anybody (ADVICE r5): synchronous collectives on the
