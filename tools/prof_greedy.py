@@ -67,3 +67,12 @@ if len(emb) >= 3:
         s, e = int(r['Start_Timestamp']), int(r['End_Timestamp'])
         print('   gap %5.1f  dur %5.1f  %s' % ((s - prev) / 1e3, (e - s) / 1e3, short(r['Kernel_Name'])))
         prev = e
+if len(sys.argv) > 2 and sys.argv[2] == 'timeline':
+    # every node of the last inference in start order: start (us from the first node), duration, gap to the previous END, queue, grid, name
+    print('# timeline of the last inference')
+    prev_end = t0
+    for i, r in enumerate(seq):
+        s, e = int(r['Start_Timestamp']), int(r['End_Timestamp'])
+        print('%4d %9.1f us  dur %6.1f  gap %6.1f  q %s  grid %8s  %s' % (i, (s - t0) / 1e3, (e - s) / 1e3, (s - prev_end) / 1e3, r.get('Queue_Id', '?'),
+                                                                        r.get('Grid_Size', r.get('Grid_Size_X', '?')), short(r['Kernel_Name'])))
+        prev_end = max(prev_end, e)
