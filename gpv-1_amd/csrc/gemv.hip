@@ -168,9 +168,41 @@ __global__ __launch_bounds__(256) void ln_gemv_kernel(LnGemvK p) {
   constexpr int NV = 2;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n0 = (blockIdx.x * 4 + wave) * NW;
-  if (n0 >= p.N) return;
-  const bool writer = blockIdx.x == 0 && wave == 0;
+  // Round 6: with per-head partial rows as the sublayer output (attn1_proj_kernel) every WAVE used to fetch all of them -- 8 heads x
+  // 768 floats = 24 KB per wave, 96 KB per workgroup through ONE CU's vector-memory path (12 - 18 B/clk: ~2 us; a plain 768 x 768
+  // matrix-vector node is 2.3 us, this one was 5.0 -- tools/probe_decode_nodes.py).  Now the workgroup sums them ONCE: thread c owns
+  // the 8-column piece c of a row, adds its eight partial pieces in head order (the same additions in the same order as before) and
+  // leaves the rounded sublayer output in LDS; every wave then runs the unchanged LayerNorm on it.  Bit-identical results.
+  __shared__ float s_sum[MR][NV * 64 * 8];
   const int cols = p.K;
+  if (p.s_part) {
+    const int pieces = cols >> 3;
+    for (int idx = threadIdx.x; idx < p.rows * pieces; idx += 256) {
+      const int m = idx / pieces, c = (idx - m * pieces) * 8;
+      float t[8];
+      if (p.s_bias) Ld8<float>::ld(p.s_bias + c, t);
+      else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) t[e] = 0.f;
+      }
+      for (int h0 = 0; h0 < p.s_parts; h0 += 8) {                 // eight partial rows requested at once, added in head order
+        float uu[8][8];
+#pragma unroll
+        for (int hh = 0; hh < 8; ++hh)
+          if (h0 + hh < p.s_parts) Ld8<float>::ld(p.s_part + ((int64_t)m * p.s_parts + h0 + hh) * cols + c, uu[hh]);
+#pragma unroll
+        for (int hh = 0; hh < 8; ++hh)
+          if (h0 + hh < p.s_parts) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t[e] += uu[hh][e];
+          }
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s_sum[m][c + e] = (float)(T)t[e];      // (what a stored sublayer output would hold)
+    }
+  }
+  const bool active = n0 < p.N;
+  const bool writer = blockIdx.x == 0 && wave == 0;
   // the weight pieces and gamma / beta are requested first: their latency passes under the LayerNorm arithmetic
   typedef typename std::conditional<std::is_same<T, float>::value, float __attribute__((ext_vector_type(8))), bf16x8>::type RawT;
   const T* Wp = reinterpret_cast<const T*>(p.W);
@@ -181,10 +213,12 @@ __global__ __launch_bounds__(256) void ln_gemv_kernel(LnGemvK p) {
     const int c = (i * 64 + lane) * 8;
     if (c < cols) {
 #pragma unroll
-      for (int j = 0; j < NW; ++j) wraw[i][j] = *reinterpret_cast<const RawT*>(Wp + (int64_t)min(n0 + j, p.N - 1) * p.ldw + c);
+      for (int j = 0; j < NW; ++j) wraw[i][j] = *reinterpret_cast<const RawT*>(Wp + (int64_t)min(min(n0, p.N - 1) + j, p.N - 1) * p.ldw + c);
       if (p.gamma) { Ld8<float>::ld(p.gamma + c, gm[i]); Ld8<float>::ld(p.beta + c, bt[i]); }
     }
   }
+  if (p.s_part) __syncthreads();                    // (uniform: a kernel argument)
+  if (!active) return;
   float xn[MR][NV][8];
 #pragma unroll
   for (int m = 0; m < MR; ++m) {
@@ -208,27 +242,9 @@ __global__ __launch_bounds__(256) void ln_gemv_kernel(LnGemvK p) {
           Ld8<T>::ld(sr + c, t);
 #pragma unroll
           for (int e = 0; e < 8; ++e) xn[m][i][e] += t[e];
-        } else if (p.s_part) {                       // the sublayer output as per-head partial sums (attn1_proj_kernel), summed in head order
-          float t[8];
-          if (p.s_bias) Ld8<float>::ld(p.s_bias + c, t);
-          else {
+        } else if (p.s_part) {                       // the sublayer output as per-head partial sums (attn1_proj_kernel), summed above
 #pragma unroll
-            for (int e = 0; e < 8; ++e) t[e] = 0.f;
-          }
-          for (int h0 = 0; h0 < p.s_parts; h0 += 8) {                 // eight partial rows requested at once, added in head order
-            float uu[8][8];
-#pragma unroll
-            for (int hh = 0; hh < 8; ++hh)
-              if (h0 + hh < p.s_parts) Ld8<float>::ld(p.s_part + ((int64_t)m * p.s_parts + h0 + hh) * cols + c, uu[hh]);
-#pragma unroll
-            for (int hh = 0; hh < 8; ++hh)
-              if (h0 + hh < p.s_parts) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) t[e] += uu[hh][e];
-              }
-          }
-#pragma unroll
-          for (int e = 0; e < 8; ++e) xn[m][i][e] += (float)(T)t[e];      // (what a stored sublayer output would hold)
+          for (int e = 0; e < 8; ++e) xn[m][i][e] += s_sum[m][c + e];
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) sum += xn[m][i][e];
