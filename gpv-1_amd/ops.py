@@ -747,11 +747,16 @@ class AddLayerNormFn(Function):
 
 
 PROJ_LN = os.environ.get('GPV_PROJ_LN', '1') != '0'
+PROJ_LN_MIN_ROWS = int(os.environ.get('GPV_PROJ_LN_MIN_ROWS', '2048'))
 
 
 def proj_layernorm_ok(w, x):
     """gpv_linear_layernorm_fwd's range: a 256 -> 256 projection in front of a width-256 LayerNorm, bf16 (the DETR attention sublayers)"""
-    return PROJ_LN and RT.dtype == torch.bfloat16 and w.K == 256 and w.N == 256 and x.shape[-1] == 256 and w.bias is not None
+    # rows: the one launch stages the whole 128 KB weight per workgroup (8.7 us whatever the row count); as nodes of a hipGraph chain
+    # GEMM + LayerNorm take 6.6 us up to ~1200 rows and 9.6 at 3200 against 9.3 (tools/bench_linear_ln_small.py): batch-1 inference
+    # (300 / 100 rows) keeps the two launches, the training shapes (9600 / 3200 rows) the one
+    return (PROJ_LN and RT.dtype == torch.bfloat16 and w.K == 256 and w.N == 256 and x.shape[-1] == 256 and w.bias is not None
+            and x.numel() // 256 >= PROJ_LN_MIN_ROWS)
 
 
 class ProjAddLayerNormFn(Function):
