@@ -34,6 +34,48 @@ TL = 6
 CAP_WORDS = 18           # + __cls__ + __stop__ = 20 tokens = max_text_len
 
 
+def live_conv_traffic():
+    """roofline.traffic measured by the run that prints the line (a committed figure cannot notice a regression):
+    two child runs of this file under `rocprofv3 --pmc` -- FETCH_SIZE, then WRITE_SIZE, each counter in its own pass and with no trace
+    domain beside it, exactly as the guide's HBM section prescribes -- after the timed region, with the GPU otherwise idle.
+    -> tools/pmc_traffic.py's dict, {'error': ...} when a pass failed, None when rocprofv3 is not there."""
+    import importlib.util
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which('rocprofv3') or ('/opt/rocm/bin/rocprofv3' if os.path.exists('/opt/rocm/bin/rocprofv3') else None)
+    if exe is None:
+        return None
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location('pmc_traffic', os.path.join(here, 'tools', 'pmc_traffic.py'))
+    pt = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(pt)
+    tmp = tempfile.mkdtemp(prefix='gpv_pmc_', dir='/tmp')
+    env = dict(os.environ, TMPDIR='/tmp')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE'):
+        env.pop(k, None)
+    dirs = {}
+    try:
+        for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+            d = dirs[counter] = os.path.join(tmp, counter)
+            cmd = [exe, '--pmc', counter, '--output-format', 'csv', '-d', d, '-o', 'r', '--', sys.executable, os.path.abspath(__file__), '--no-cpu-baseline',
+                   '--no-decode', '--no-ragged', '--no-extra', '--no-traffic', '--steps', '4', '--warmup', '3']
+            r = subprocess.run(cmd, cwd='/tmp', env=env, capture_output=True, text=True, timeout=900)
+            if r.returncode != 0:
+                return {'error': '%s pass: rc %d: %s' % (counter, r.returncode, (r.stderr or r.stdout)[-300:])}
+        res = pt.compute(dirs['FETCH_SIZE'], dirs['WRITE_SIZE'])
+        passes = res['passes_profiled']
+        if not (passes >= 1 and passes == int(passes) and res['conv_launches_fetch_pass'] == res['conv_launches_write_pass']
+                and res['conv_launches_fetch_pass'] % int(passes) == 0):
+            return {'error': 'the two passes do not hold the same whole passes of the body: %r' % {k: res[k] for k in ('passes_profiled', 'conv_launches_fetch_pass', 'conv_launches_write_pass')}}
+        res.pop('by_kernel_KB', None)
+        return res
+    except Exception as e:                                  # (a profiler hiccup must not cost the run its line)
+        return {'error': '%s: %s' % (type(e).__name__, str(e)[:300])}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def _note_sync():
     """a synchronous collective just ran on the compute stream: the next capture waits for RCCL's watchdog once (misc.CollectiveClock)"""
     from gpv1_amd.misc import note_sync_collective
@@ -435,6 +477,7 @@ def main():
     ap.add_argument('--no-decode', action='store_true')
     ap.add_argument('--no-ragged', action='store_true', help='skip the string-query / ragged-length run reported next to the fixed-shape number')
     ap.add_argument('--no-extra', action='store_true', help='skip BASELINE configs[3] (beam 5, bs64) and configs[4] (detection-only bs64)')
+    ap.add_argument('--no-traffic', action='store_true', help='do not run the two rocprofv3 --pmc passes of this command (roofline.traffic then comes from the committed profile)')
     ap.add_argument('--soak', type=int, default=0, help='after the timed region: this many more graphed steps (soak of the hipGraph replay path)')
     args = ap.parse_args()
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -609,7 +652,17 @@ def main():
     # missing or does not hold whole passes.
     traffic = None
     traffic_source = None
+    traffic_live = None
+    if not (args.no_traffic or args.no_extra) and world == 1 and args.batch == BATCH:
+        traffic_live = live_conv_traffic()
+        if traffic_live is not None and 'traffic_bytes_per_launch' in traffic_live:
+            traffic = traffic_live['traffic_bytes_per_launch']
+            traffic_source = ('live: two rocprofv3 --pmc passes (FETCH_SIZE, then WRITE_SIZE) of `python bench.py --steps 4 --warmup 3` run by THIS process after the timed region '
+                              '(%d whole passes of the body; FETCH_SIZE x 2 on gfx950, units and corrections as /opt/skills/guides/MI355X_MICROARCH.md; tools/pmc_traffic.py)'
+                              % int(traffic_live['passes_profiled']))
     try:
+        if traffic is not None:
+            raise OSError('live')
         import glob
         latest = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r*_pmc_conv_traffic.json')))[-1]
         pm = json.load(open(latest))
@@ -622,6 +675,8 @@ def main():
         pass
     roof = {'bound': 'hbm', 'achieved': ach_gbs, 'peak': 8000.0, 'unit': 'GB/s', 'frac': ach_gbs / 8000.0, 'traffic': traffic,
             'traffic_source': traffic_source,
+            'traffic_over_algorithmic': None if traffic is None else traffic / (bytes_step / launches),
+            'traffic_live_error': None if (traffic_live is None or 'error' not in traffic_live) else traffic_live['error'],
             'frac_mixed_per_conv_bound': alg['mixed_bound_s'] / (conv_ms * 1e-3),      # sum over launches of max(bytes / 8 TB/s, flops / 2.5 PF) / measured time
             'kernel': 'c1s_kernel (streaming 1x1) / c3r_kernel (streaming 3x3) / stem_pool_kernel / c1d_kernel / glds_wgrad_group_kernel + wg8_group_kernel + wg8h_group_kernel (the 42 weight gradients as one grouped call per stage) / glds_kernel<OP_CONV> / pipe_kernel<OP_CONV> / pipe_conv1x1_kernel / conv1x1_kernel / gemm_kernel<OP_CONV> (NHWC conv fwd/dgrad/wgrad, ResNet-50 body)',
             'launches_per_step': launches, 'avg_launch_us': conv_ms * 1e3 / launches,

@@ -30,21 +30,28 @@ def is_conv(name):
 def is_conv_helper(name):          # second kernel of a conv launch (1x1 stride-2 backward-data: the element-wise three quarters): bytes count, launches do not
     return 's2_dgrad_fill_kernel' in name or 'wgrad_group_reduce_kernel' in name      # (+ the slab pass of the grouped weight gradients)
 
-fd, wd = sys.argv[1], sys.argv[2]
 LAUNCHES_PER_PASS = 135          # conv launches of one forward + backward of the body (bench.py conv_algorithmic)
-F, Wr = load(fd, 'FETCH_SIZE'), load(wd, 'WRITE_SIZE')
-fetch_kb = sum(v[0] for k, v in F.items() if is_conv(k) or is_conv_helper(k)); nf = sum(v[1] for k, v in F.items() if is_conv(k))
-write_kb = sum(v[0] for k, v in Wr.items() if is_conv(k) or is_conv_helper(k)); nw = sum(v[1] for k, v in Wr.items() if is_conv(k))
-steps = sum(v[1] for k, v in F.items() if 'stem_pool_kernel' in k) or nf / LAUNCHES_PER_PASS
-kernels_per_pass = nf / steps
-res = {
-    'what': 'c1s_kernel / c1c_kernel / c3r_kernel / stem_pool_kernel / gemm_kernel<OP_CONV,...> / conv1x1_kernel / pipe_kernel<OP_CONV> / pipe_conv1x1_kernel / glds_kernel<OP_CONV> / glds_halo_kernel / glds_conv1x1_kernel / c3d2_kernel / c1d_kernel / glds_wgrad_group_kernel / wg8_group_kernel / wg8h_group_kernel (+ s2_dgrad_fill_kernel, wgrad_group_reduce_kernel bytes) launches of `python bench.py` (B=32 train step)',
-    'passes_profiled': steps, 'conv_kernel_launches_per_pass': kernels_per_pass, 'conv_launches_fetch_pass': nf, 'conv_launches_write_pass': nw,
-    'FETCH_SIZE_KB_raw': fetch_kb, 'WRITE_SIZE_KB_raw': write_kb,
-    'fetch_bytes_corrected_x2': fetch_kb * 1024 * 2, 'write_bytes': write_kb * 1024,
-    'traffic_bytes_per_step': (fetch_kb * 2 + write_kb) * 1024 / steps,
-    'traffic_bytes_per_launch': (fetch_kb * 2 + write_kb) * 1024 / steps / LAUNCHES_PER_PASS,
-    'by_kernel_KB': {k.replace('(anonymous namespace)::', '')[:90]: {'fetch_raw': F.get(k, [0, 0])[0], 'write': Wr.get(k, [0, 0])[0], 'launches': F.get(k, [0, 0])[1]}
-                     for k in F if is_conv(k) or is_conv_helper(k)},
-}
-print(json.dumps(res, indent=1))
+
+
+def compute(fd, wd):
+    """-> the result dict from the two pass directories (bench.py runs the passes itself and calls this: roofline.traffic is live)"""
+    F, Wr = load(fd, 'FETCH_SIZE'), load(wd, 'WRITE_SIZE')
+    fetch_kb = sum(v[0] for k, v in F.items() if is_conv(k) or is_conv_helper(k)); nf = sum(v[1] for k, v in F.items() if is_conv(k))
+    write_kb = sum(v[0] for k, v in Wr.items() if is_conv(k) or is_conv_helper(k)); nw = sum(v[1] for k, v in Wr.items() if is_conv(k))
+    steps = sum(v[1] for k, v in F.items() if 'stem_pool_kernel' in k) or nf / LAUNCHES_PER_PASS
+    kernels_per_pass = nf / steps
+    res = {
+        'what': 'c1s_kernel / c1c_kernel / c3r_kernel / stem_pool_kernel / gemm_kernel<OP_CONV,...> / conv1x1_kernel / pipe_kernel<OP_CONV> / pipe_conv1x1_kernel / glds_kernel<OP_CONV> / glds_halo_kernel / glds_conv1x1_kernel / c3d2_kernel / c1d_kernel / glds_wgrad_group_kernel / wg8_group_kernel / wg8h_group_kernel (+ s2_dgrad_fill_kernel, wgrad_group_reduce_kernel bytes) launches of `python bench.py` (B=32 train step)',
+        'passes_profiled': steps, 'conv_kernel_launches_per_pass': kernels_per_pass, 'conv_launches_fetch_pass': nf, 'conv_launches_write_pass': nw,
+        'FETCH_SIZE_KB_raw': fetch_kb, 'WRITE_SIZE_KB_raw': write_kb,
+        'fetch_bytes_corrected_x2': fetch_kb * 1024 * 2, 'write_bytes': write_kb * 1024,
+        'traffic_bytes_per_step': (fetch_kb * 2 + write_kb) * 1024 / steps,
+        'traffic_bytes_per_launch': (fetch_kb * 2 + write_kb) * 1024 / steps / LAUNCHES_PER_PASS,
+        'by_kernel_KB': {k.replace('(anonymous namespace)::', '')[:90]: {'fetch_raw': F.get(k, [0, 0])[0], 'write': Wr.get(k, [0, 0])[0], 'launches': F.get(k, [0, 0])[1]}
+                         for k in F if is_conv(k) or is_conv_helper(k)},
+    }
+    return res
+
+
+if __name__ == '__main__':
+    print(json.dumps(compute(sys.argv[1], sys.argv[2]), indent=1))
