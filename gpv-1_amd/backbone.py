@@ -145,13 +145,41 @@ class Bottleneck(nn.Module):
         return any(c.weight.requires_grad for c, _ in self.convs())
 
 
-def _conv_fwd(x, conv, bn, need_wd, act, res=None):
+# Round 6: ReLU masks as one bit per element (include/gpv_hip.h gpv_conv_args.y_mask_bits / relu_mask_bits).  A block's output serves the
+# backward pass twice: as the operand of the next block's conv1 weight gradient, and as "was it > 0" in that conv1's backward-data
+# epilogue -- read there as bf16 it is a third of the launch's bytes (157 MB per layer2 block at B = 32).  Where the streaming 1x1 kernel
+# writes the block output (conv3 + identity + ReLU of layer2 / layer3) it also writes the bits; the tensor carries them (`_gpv_bits`)
+# and _conv_dgrad hands them over instead of the bf16 mask where the kernel reads them.  Bit-identical results.  GPV_MASK_BITS=0: off.
+MASK_BITS = os.environ.get('GPV_MASK_BITS', '1') != '0'
+_BITS_OK = {}
+
+
+def _bits_ok(key, args, kw):
+    """cached gpv_conv2d_mask_bits_ok per call signature (shapes + which operands exist; the allocator's 512-byte alignment makes the
+    pointer checks shape-independent)"""
+    hit = _BITS_OK.get(key)
+    if hit is None:
+        hit = _BITS_OK[key] = hip.conv2d_mask_bits_ok(*args, **kw)
+    return hit
+
+
+def _conv_fwd(x, conv, bn, need_wd, act, res=None, bits=False):
+    """bits: also produce the one-bit ReLU mask of the output (kept on the tensor as `_gpv_bits`) when the launch can"""
     B, H, Wd, Cin = x.shape
     OH, OW = _out(H, conv.k, conv.stride, conv.pad), _out(Wd, conv.k, conv.stride, conv.pad)
     wf, _, _, shift = _conv_copies(conv, bn, need_wd)
     y = torch.empty(B, OH, OW, conv.cout, device=x.device, dtype=RT.dtype)
-    hip.conv2d(0, x, wf, y, B, H, Wd, Cin, Cin, OH, OW, conv.cout, conv.k, conv.k, conv.stride, conv.stride, conv.pad,
-               conv.pad, bias=shift, res=res, act=act)
+    args = (0, x, wf, y, B, H, Wd, Cin, Cin, OH, OW, conv.cout, conv.k, conv.k, conv.stride, conv.stride, conv.pad, conv.pad)
+    if bits and MASK_BITS and x.is_cuda and RT.dtype == torch.bfloat16 and conv.k == 1 and conv.stride == 1 and res is not None and act == RELU \
+            and conv.cout % 32 == 0:
+        mb = torch.empty(B * OH * OW, conv.cout // 32, device=x.device, dtype=torch.int32)
+        kw = dict(bias=shift, res=res, act=act, y_mask_bits=mb)
+        if _bits_ok(('f', B, H, Wd, Cin, conv.cout, hip.get_option_cached(hip.OPT_C1S)), args, kw):
+            hip.conv2d(*args, **kw)
+            y._gpv_bits = mb
+            return y
+        del mb
+    hip.conv2d(*args, bias=shift, res=res, act=act)
     return y
 
 
@@ -208,8 +236,14 @@ def _conv_dgrad(dy, conv, bn, xshape, res=None, relu_mask=None):
     _, OH, OW, Cout = dy.shape
     _, wd, _, _ = _conv_copies(conv, bn, True)
     dx = torch.empty(B, H, Wd, Cin, device=dy.device, dtype=RT.dtype)
-    hip.conv2d(1, dy, wd, dx, B, OH, OW, Cout, Cout, H, Wd, Cin, conv.k, conv.k, conv.stride, conv.stride, conv.pad,
-               conv.pad, res=res, relu_mask=relu_mask)
+    args = (1, dy, wd, dx, B, OH, OW, Cout, Cout, H, Wd, Cin, conv.k, conv.k, conv.stride, conv.stride, conv.pad, conv.pad)
+    mb = getattr(relu_mask, '_gpv_bits', None) if relu_mask is not None else None
+    if mb is not None and MASK_BITS:
+        kw = dict(res=res, relu_mask_bits=mb)
+        if _bits_ok(('d', B, H, Wd, Cin, Cout, res is not None, hip.get_option_cached(hip.OPT_C1S)), args, kw):
+            hip.conv2d(*args, **kw)          # the mask as one bit per element, written by the forward launch that produced relu_mask
+            return dx
+    hip.conv2d(*args, res=res, relu_mask=relu_mask)
     return dx
 
 
@@ -317,7 +351,7 @@ class ResNetBody(nn.Module):
                 yb = _block_tail_fused(x, a2, blk, tr, need_wd) if (blk.downsample is not None and FUSED_TAIL and RT.dtype == torch.bfloat16) else None
             if yb is None:
                 idt = x if blk.downsample is None else _conv_fwd(x, blk.downsample[0], blk.downsample[1], need_wd, hip.ACT_NONE)
-                yb = _conv_fwd(a2, blk.conv3, blk.bn3, tr, RELU, res=idt)
+                yb = _conv_fwd(a2, blk.conv3, blk.bn3, tr, RELU, res=idt, bits=keep is not None)
             if tr:
                 keep.append((blk, x, a1, a2, yb, seen_trainable))
                 seen_trainable = True

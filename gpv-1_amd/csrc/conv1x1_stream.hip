@@ -38,7 +38,11 @@ __device__ __forceinline__ int c1s_chan(int L) {
 // amdgpu_waves_per_eu(2, 2) on the instances whose weights leave room for ONE 8-wave block per CU (> 72 KB of LDS): without the hint
 // hipcc schedules for three or four waves per SIMD, keeps one fragment register and serialises ds_read -> s_waitcnt lgkmcnt(0) -> MFMA
 // (97 of the 128 MFMAs of the 256 x 256 instance waited for a read issued right before them).
-template <int K, int NH, bool RES, bool MASK, bool NT, bool LIN = false, int NP = 1>
+// BITS (round 6): ReLU masks as one bit per element (include/gpv_hip.h gpv_conv_args.y_mask_bits / relu_mask_bits).  MASK: the mask operand
+// is p.mask_bits -- a lane's 8 channels of tile pair t are byte g of word [pixel][(cbase + h NH) / 32 + t], 4 bytes per lane and pair
+// instead of 16.  !MASK: the launch also writes (output > 0) of its ReLU outputs in that layout: the four lanes that hold a pixel's 32
+// channels of pair t or their bytes together with two cross-row shuffles and lane g == (t & 3) stores the word.
+template <int K, int NH, bool RES, bool MASK, bool NT, bool LIN = false, int NP = 1, bool BITS = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu((NP == 1 && NH * K * 2 > 72 * 1024) ? 2 : 1, (NP == 1 && NH * K * 2 > 72 * 1024) ? 2 : 8)))
 void c1s_kernel(GemmK p, int ncols) {
   // ncols: output channels per block row (gridDim.y slices of a wide layer: layer3's 1024 channels as four 256-channel
@@ -57,6 +61,7 @@ void c1s_kernel(GemmK p, int ncols) {
   const bf16* Mk = reinterpret_cast<const bf16*>(p.mask) + cbase;
   const float* bias_g = p.bias ? p.bias + cbase : nullptr;
   const int nfull = p.N;
+  const int wpp = nfull >> 5, wbase = cbase >> 5;          // BITS: mask words per pixel, this slice's first word
   if constexpr (LIN) { if (p.dthresh) p.seed = eff_seed(p.seed, p.seed_dev); }
   p.N = ncols;
   const int ntile = (p.M + 15) >> 4;
@@ -149,7 +154,20 @@ void c1s_kernel(GemmK p, int ncols) {
                      : *reinterpret_cast<const bf16x8*>(q);
         }
       }
-      if constexpr (MASK) {
+      uint32_t mw[(MASK && BITS) ? NG : 1];
+      if constexpr (MASK && BITS) {
+        const uint32_t* mq = p.mask_bits + (int64_t)pxc * wpp + wbase + h * NG;
+        if constexpr (NG % 4 == 0) {
+#pragma unroll
+          for (int t = 0; t < NG; t += 4) {
+            const u32x4 w4 = *reinterpret_cast<const u32x4*>(mq + t);
+            mw[t] = w4[0]; mw[t + 1] = w4[1]; mw[t + 2] = w4[2]; mw[t + 3] = w4[3];
+          }
+        } else {
+#pragma unroll
+          for (int t = 0; t < NG; ++t) mw[t] = mq[t];
+        }
+      } else if constexpr (MASK) {
 #pragma unroll
         for (int t = 0; t < NG; ++t) {
           mv[t] = *reinterpret_cast<const bf16x8*>(Mk + (int64_t)pxc * p.ldm + h * NH + t * 32 + g * 8);
@@ -248,9 +266,20 @@ void c1s_kernel(GemmK p, int ncols) {
             float x = v[e];
             if constexpr (RES) x += (float)rv[t][e];
             if (p.act == GPV_ACT_RELU) x = fmaxf(x, 0.f);
-            if constexpr (MASK) x = (float)mv[t][e] > 0.f ? x : 0.f;
+            if constexpr (MASK && BITS) x = ((mw[t] >> (g * 8 + e)) & 1u) ? x : 0.f;
+            else if constexpr (MASK) x = (float)mv[t][e] > 0.f ? x : 0.f;
             o[e] = (bf16)x;
           }
+        }
+        if constexpr (BITS && !MASK) {
+          // (output > 0) of the STORED bf16 values, what a later (float)mask > 0.f test would see
+          uint32_t wb = 0u;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) wb |= ((float)o[e] > 0.f ? 1u : 0u) << e;
+          wb <<= g * 8;
+          wb |= (uint32_t)__shfl_xor((int)wb, 16);
+          wb |= (uint32_t)__shfl_xor((int)wb, 32);
+          if (g == (t & 3) && px < p.M) p.out_bits[(int64_t)pxc * wpp + wbase + h * NG + t] = wb;
         }
         // No branch and no store hipcc can see in the tile loop (conv1x1_dual.hip): rows beyond M were LOADED from row M - 1 (A,
         // residual, mask, dropout index), so they hold row M - 1's results and store them there again; the store is inline asm because
@@ -274,11 +303,11 @@ inline int c1s_cols(int K, int N) {
   return N < cap ? N : cap;
 }
 
-template <int K, int NH, bool RES, bool MASK, bool NT, bool LIN = false, int NP = 1>
+template <int K, int NH, bool RES, bool MASK, bool NT, bool LIN = false, int NP = 1, bool BITS = false>
 int c1s_launch_np(const GemmK& k, hipStream_t st) {
   const int ncols = c1s_cols(k.K, k.N), nsl = k.N / ncols;
   const size_t lds = (size_t)ncols * K * 2 + (size_t)ncols * sizeof(float);
-  auto fn = c1s_kernel<K, NH, RES, MASK, NT, LIN, NP>;
+  auto fn = c1s_kernel<K, NH, RES, MASK, NT, LIN, NP, BITS>;
   static size_t attr = 0;
   if (lds > 64 * 1024 && lds > attr) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -296,11 +325,11 @@ int c1s_launch_np(const GemmK& k, hipStream_t st) {
   return 0;
 }
 
-template <int K, int NH, bool RES, bool MASK, bool NT, bool LIN = false>
+template <int K, int NH, bool RES, bool MASK, bool NT, bool LIN = false, bool BITS = false>
 int c1s_launch(const GemmK& k, hipStream_t st) {
   const int np = c1s_cols(k.K, k.N) / NH;
-  if (np == 1) return c1s_launch_np<K, NH, RES, MASK, NT, LIN, 1>(k, st);
-  if constexpr (K <= 128 && NH == 256 && !LIN) { if (np == 2) return c1s_launch_np<K, NH, RES, MASK, NT, LIN, 2>(k, st); }
+  if (np == 1) return c1s_launch_np<K, NH, RES, MASK, NT, LIN, 1, BITS>(k, st);
+  if constexpr (K <= 128 && NH == 256 && !LIN) { if (np == 2) return c1s_launch_np<K, NH, RES, MASK, NT, LIN, 2, BITS>(k, st); }
   return -1;
 }
 
@@ -314,6 +343,20 @@ int c1s_flags(const GemmK& k, hipStream_t st) {
       if (r) return c1s_launch<K, NH, true, false, false, true>(k, st);
       if (m) return c1s_launch<K, NH, false, true, false, true>(k, st);
       return c1s_launch<K, NH, false, false, false, true>(k, st);
+    } else {
+      return -1;
+    }
+  }
+  if (k.mask_bits || k.out_bits) {
+    // one-bit ReLU masks: the instances the ResNet body uses -- conv3 + residual + ReLU of layer2 / layer3 writes them (K = 128 | 256,
+    // 256 channels per pass), conv1's backward-data (residual + mask) of layer2 / layer3 / layer4.0 reads them (+ K = 512 -> 128-wide passes)
+    if (nt || !r || (k.mask_bits && k.out_bits)) return -1;
+    if constexpr ((K == 128 || K == 256) && NH == 256) {
+      if (k.out_bits) return (m || k.act != GPV_ACT_RELU) ? -1 : c1s_launch<K, NH, true, false, false, false, true>(k, st);
+      return c1s_launch<K, NH, true, true, false, false, true>(k, st);
+    } else if constexpr (K == 512 && NH == 128) {
+      if (k.out_bits) return -1;
+      return c1s_launch<K, NH, true, true, false, false, true>(k, st);
     } else {
       return -1;
     }
@@ -346,7 +389,7 @@ int g_c1s_mode = 1;          // 0 never, 1 heuristic, 2 wherever legal (tests)
 long g_c1s_launches = 0;     // gpv_set_option(GPV_OPT_C1S_LAUNCHES, .)
 
 // 0 = launched, -1 = not applicable, > 0 = hipError_t
-int c1s_try_launch(const GemmK& k, int dtype_in, int dtype_out, hipStream_t st, bool linear) {
+int c1s_try_launch(const GemmK& k, int dtype_in, int dtype_out, hipStream_t st, bool linear, bool dry) {
   static const int env = tune_env("GPV_C1S", -1);
   const int mode = env >= 0 ? env : g_c1s_mode;
   if (mode == 0 || dtype_in != GPV_BF16 || dtype_out != GPV_BF16) return -1;
@@ -363,6 +406,16 @@ int c1s_try_launch(const GemmK& k, int dtype_in, int dtype_out, hipStream_t st, 
   if (linear) {      // gpv_gemm: 256 -> 2048 features over >= 2048 rows (the DETR feed-forward; tools/bench_c1s_linear.py: 1024 / 1536 outputs are faster on the tile kernels)
     if (mode == 1 && (k.K != 256 || k.N < 2048 || k.M < 2048)) return -1;
   } else if (mode == 1 && ((int64_t)k.M * nsl < 65536 || k.M < 32768)) return -1;   // a streaming regime needs rows (x slices): the layer1-3 maps at training batch sizes
+  if (k.mask_bits || k.out_bits) {
+    // instances that exist with mask bits (c1s_flags) -- decided here so that a dry run (gpv_conv2d_mask_bits_ok) answers what a launch would do
+    const int nh = ncols >= 256 ? 256 : ncols;
+    const bool inst = ((k.K == 128 || k.K == 256) && nh == 256) || (k.K == 512 && nh == 128 && !k.out_bits);
+    if (linear || !inst || !k.res || k.nt_io || (k.mask_bits && k.out_bits) || k.N % 32 != 0 || (k.out_bits && (k.mask && !k.mask_bits))) return -1;
+    if (k.out_bits && k.act != GPV_ACT_RELU) return -1;
+    if (k.K <= 128 && ncols / nh > 2) return -1;
+    if (k.K > 128 && ncols / nh != 1) return -1;
+  }
+  if (dry) return 0;
   int e = -1;
   switch (k.K) {
     case 64: e = c1s_n<64>(k, st); break;

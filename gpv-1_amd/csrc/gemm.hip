@@ -1032,11 +1032,20 @@ extern "C" int gpv_gemm(const gpv_gemm_args* a, void* stream) {
   return (int)hipErrorInvalidValue;
 }
 
-extern "C" int gpv_conv2d(const gpv_conv_args* a, void* stream) {
+// dry: check only (gpv_conv2d_mask_bits_ok) -- valid for calls that ask for mask bits, which return before any other launch path
+static int conv2d_impl(const gpv_conv_args* a, hipStream_t st, bool dry) {
   if (!a || !a->x || !a->w || !a->y) return (int)hipErrorInvalidValue;
   if (a->Cin % 32 != 0) return (int)hipErrorInvalidValue;
   if ((a->SH != 1 && a->SH != 2) || (a->SW != 1 && a->SW != 2)) return (int)hipErrorInvalidValue;
-  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const bool want_bits = a->y_mask_bits != nullptr || a->relu_mask_bits != nullptr;
+  if (want_bits) {
+    // one-bit ReLU masks: the streaming 1x1 kernel only (stride 1, pointwise), forward with ReLU writes them, backward-data reads them
+    if (a->KH != 1 || a->KW != 1 || a->SH != 1 || a->SW != 1 || a->PH != 0 || a->PW != 0 || a->IH != a->OH || a->IW != a->OW) return (int)hipErrorInvalidValue;
+    if (a->Cout % 32 != 0 || (a->y_mask_bits && (a->mode != 0 || a->act != GPV_ACT_RELU || a->relu_mask)) || (a->relu_mask_bits && a->mode != 1)) return (int)hipErrorInvalidValue;
+    if ((reinterpret_cast<uintptr_t>(a->y_mask_bits) | reinterpret_cast<uintptr_t>(a->relu_mask_bits)) & 15) return (int)hipErrorInvalidValue;
+  } else if (dry) {
+    return (int)hipErrorInvalidValue;
+  }
   GemmK k{};
   k.alpha = 1.0f; k.rowscale = a->rowscale; k.bias = a->bias; k.act = a->act;
   k.cg = ConvGeom{a->IH, a->IW, a->Cs, a->Cin, a->OH, a->OW, a->KH, a->KW, a->SH, a->SW, a->PH, a->PW, a->mode == 1, 0, 0};
@@ -1084,6 +1093,14 @@ extern "C" int gpv_conv2d(const gpv_conv_args* a, void* stream) {
         k.nt_io = (int64_t)k.M * k.N * esz >= nt_min ? 1 : 0;
       }
       k.vecA = aligned16(a->x) && (a->Cs % vecel == 0) && (int64_t)k.M * a->Cs * esz < 0x7ffffff0ll ? 1 : 0;
+      if (want_bits) {
+        if (!k.vecA) return (int)hipErrorInvalidValue;
+        k.out_bits = reinterpret_cast<uint32_t*>(a->y_mask_bits);
+        k.mask_bits = reinterpret_cast<const uint32_t*>(a->relu_mask_bits);
+        if (k.mask_bits) { k.mask = a->relu_mask_bits; k.ldm = a->Cout; }      // (selects the masked instances; never dereferenced as bf16)
+        const int cs = c1s_try_launch(k, a->dtype_in, a->dtype_out, st, false, dry);
+        return cs >= 0 ? cs : (int)hipErrorInvalidValue;
+      }
       if (k.vecA) {
         const int cs = c1s_try_launch(k, a->dtype_in, a->dtype_out, st);
         if (cs >= 0) return cs;
@@ -1187,3 +1204,7 @@ extern "C" int gpv_conv2d(const gpv_conv_args* a, void* stream) {
   }
   return (int)hipErrorInvalidValue;
 }
+
+extern "C" int gpv_conv2d(const gpv_conv_args* a, void* stream) { return conv2d_impl(a, reinterpret_cast<hipStream_t>(stream), false); }
+
+extern "C" int gpv_conv2d_mask_bits_ok(const gpv_conv_args* a) { return conv2d_impl(a, nullptr, true) == 0 ? 1 : 0; }

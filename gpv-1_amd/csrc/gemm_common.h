@@ -31,6 +31,8 @@ struct GemmK {
   int nt_io;           // epilogue stores / residual loads non-temporal (outputs far larger than the 256 MB MALL: layer1's 314 MB maps)
   void* ws_base; int64_t ws_bytes;   // host side: caller workspace for split reductions
   float* ws;                         // kernel side: != NULL -> split s writes its partial product to ws[s][M][N]
+  const uint32_t* mask_bits;   // conv1x1_stream.hip: the ReLU mask as ONE BIT per element, word [row][n >> 5] bit n & 31 (read instead of `mask`, which is then only non-NULL)
+  uint32_t* out_bits;          // conv1x1_stream.hip: (output > 0) of a ReLU forward written in the same layout
   float* a_rowsum;     // TRANS x TRANS only: a_rowsum[m] += sum_k A[m,k]  (bias gradient fused into the weight-gradient GEMM)
   ConvGeom cg;
 };
@@ -59,7 +61,7 @@ long pipe_launches(long set);
 
 // conv1x1_stream.hip: streaming kernel for the K <= 256 pointwise convolutions over >= 65536 pixels (weights resident in LDS,
 // a wave per 16 pixels, register epilogue in a permuted channel order).  Same return convention; tried first on the 1x1 path.
-int c1s_try_launch(const GemmK& k, int dtype_in, int dtype_out, hipStream_t st, bool linear = false);   // linear: called from gpv_gemm (plain rows, alpha / dropout allowed)
+int c1s_try_launch(const GemmK& k, int dtype_in, int dtype_out, hipStream_t st, bool linear = false, bool dry = false);   // linear: called from gpv_gemm (plain rows, alpha / dropout allowed)
 extern int g_c1s_mode;
 extern long g_c1s_launches;
 

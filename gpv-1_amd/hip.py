@@ -43,7 +43,8 @@ class ConvArgs(C.Structure):
                 ('KH', C.c_int), ('KW', C.c_int), ('SH', C.c_int), ('SW', C.c_int), ('PH', C.c_int), ('PW', C.c_int),
                 ('dtype_in', C.c_int), ('dtype_out', C.c_int),
                 ('rowscale', C.c_void_p), ('bias', C.c_void_p), ('res', C.c_void_p), ('relu_mask', C.c_void_p),
-                ('act', C.c_int), ('split_k', C.c_int), ('workspace', C.c_void_p), ('workspace_bytes', C.c_int64)]
+                ('act', C.c_int), ('split_k', C.c_int), ('workspace', C.c_void_p), ('workspace_bytes', C.c_int64),
+                ('y_mask_bits', C.c_void_p), ('relu_mask_bits', C.c_void_p)]
 
 
 class AttnArgs(C.Structure):
@@ -105,7 +106,7 @@ def lib():
     return _LIB
 
 
-EXPORTS = ['gpv_abi_version', 'gpv_build_id', 'gpv_set_option', 'gpv_gemm', 'gpv_conv2d', 'gpv_image_to_nhwc4', 'gpv_maxpool3x3s2',
+EXPORTS = ['gpv_abi_version', 'gpv_build_id', 'gpv_set_option', 'gpv_gemm', 'gpv_conv2d', 'gpv_conv2d_mask_bits_ok', 'gpv_image_to_nhwc4', 'gpv_maxpool3x3s2',
            'gpv_attention_fwd', 'gpv_attention_bwd', 'gpv_attention_qkv_fwd', 'gpv_layernorm_fwd', 'gpv_layernorm_bwd', 'gpv_layernorm_pos_fwd', 'gpv_layernorm_bwd2', 'gpv_linear_layernorm_fwd',
            'gpv_softmax_ce', 'gpv_roi_weights', 'gpv_add', 'gpv_add_rowbcast', 'gpv_colsum', 'gpv_cast',
            'gpv_cast_rowscale_t', 'gpv_prep_conv_weight', 'gpv_embedding', 'gpv_dropout',
@@ -157,6 +158,11 @@ def set_option(option, value):
     """gpv_set_option: kernel-selection knob (tests / tuning); returns the previous value"""
     _OPT_SET[option] = value
     return lib().gpv_set_option(C.c_int(option), C.c_int(value))
+
+
+def get_option_cached(option):
+    """the value this process last set for `option` through set_option (None: never set -- the library's default)"""
+    return _OPT_SET.get(option)
 
 
 class option:
@@ -306,8 +312,8 @@ def gemm_tt_group(problems):
         _chk(lib().gpv_gemm_tt_group_ws(arr, C.c_int(len(problems)), None, C.c_int64(0), _stream()), 'gpv_gemm_tt_group_ws')
 
 
-def conv2d(mode, x, w, y, B, IH, IW, Cs, Cin, OH, OW, Cout, KH, KW, SH, SW, PH, PW, rowscale=None, bias=None,
-           res=None, relu_mask=None, act=ACT_NONE, split_k=0):
+def _conv_args(mode, x, w, y, B, IH, IW, Cs, Cin, OH, OW, Cout, KH, KW, SH, SW, PH, PW, rowscale=None, bias=None,
+               res=None, relu_mask=None, act=ACT_NONE, split_k=0, y_mask_bits=None, relu_mask_bits=None):
     a = ConvArgs()
     a.mode = mode
     a.x, a.w, a.y = _p(x), _p(w), _p(y)
@@ -322,6 +328,22 @@ def conv2d(mode, x, w, y, B, IH, IW, Cs, Cin, OH, OW, Cout, KH, KW, SH, SW, PH, 
             raise TypeError('conv2d: res/mask dtype must equal output dtype')
     a.res, a.relu_mask = _p(res), _p(relu_mask)
     a.act, a.split_k = act, split_k
+    for t in (y_mask_bits, relu_mask_bits):           # one-bit ReLU masks: int32 [pixels, Cout / 32] (gpv_conv_args.y_mask_bits / relu_mask_bits)
+        if t is not None and (t.dtype != torch.int32 or not t.is_contiguous() or t.numel() * 32 != B * OH * OW * Cout):
+            raise TypeError('conv2d: mask bits are a contiguous int32 [pixels, Cout / 32] tensor')
+    a.y_mask_bits, a.relu_mask_bits = _p(y_mask_bits), _p(relu_mask_bits)
+    return a
+
+
+def conv2d_mask_bits_ok(*args, **kw):
+    """gpv_conv2d_mask_bits_ok: would gpv_conv2d serve this call's y_mask_bits / relu_mask_bits?  (same arguments as conv2d; no launch)"""
+    return bool(lib().gpv_conv2d_mask_bits_ok(C.byref(_conv_args(*args, **kw))))
+
+
+def conv2d(mode, x, w, y, B, IH, IW, Cs, Cin, OH, OW, Cout, KH, KW, SH, SW, PH, PW, rowscale=None, bias=None,
+           res=None, relu_mask=None, act=ACT_NONE, split_k=0, y_mask_bits=None, relu_mask_bits=None):
+    a = _conv_args(mode, x, w, y, B, IH, IW, Cs, Cin, OH, OW, Cout, KH, KW, SH, SW, PH, PW, rowscale, bias, res, relu_mask, act, split_k,
+                   y_mask_bits, relu_mask_bits)
     if mode == 2:                                      # wgrad: the library picks the split; lend it the shared scratch
         ws = _workspace(x.device, WS_MAX)
         a.workspace, a.workspace_bytes = _p(ws), ws.numel()

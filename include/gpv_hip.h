@@ -158,8 +158,20 @@ typedef struct {
   int split_k;                             /* wgrad only */
   void* workspace; int64_t workspace_bytes; /* optional split-reduction scratch, same contract as gpv_gemm_args: wgrad, and forward
                                                convolutions over <= 8192 output pixels (fp32 slabs + a second pass with the epilogue) */
+  /* Round 6: ReLU masks as ONE BIT per element (both optional; NULL = as before).  The backward pass needs a post-ReLU activation only
+     as "was this element > 0" (the dgrad epilogue's * (relu_mask > 0)); read as bf16 that is 16 bits per element of the widest tensors
+     of a bottleneck (157 MB per layer2 block at B = 32: a third of such a launch's bytes).  Layout of both: uint32 [pixels][Cout / 32],
+     bit (c & 31) of word [pixel][c >> 5] = (y[pixel, c] > 0) of the bf16 value as stored.
+       y_mask_bits    (mode 0, act = GPV_ACT_RELU): the launch ALSO writes the bits of its output;
+       relu_mask_bits (mode 1): read INSTEAD of relu_mask (relu_mask may then be NULL); results are bit-identical to the bf16 mask's.
+     Only the streaming 1x1 kernel serves them: gpv_conv2d_mask_bits_ok() tells whether a call would be served, gpv_conv2d returns
+     hipErrorInvalidValue (nothing launched) for one that would not. */
+  void* y_mask_bits; const void* relu_mask_bits;
 } gpv_conv_args;
 int gpv_conv2d(const gpv_conv_args* a, void* stream);
+/* 1 when gpv_conv2d would serve these arguments' y_mask_bits / relu_mask_bits (same checks, nothing launched; pointers must be the real ones:
+   alignment counts), else 0 */
+int gpv_conv2d_mask_bits_ok(const gpv_conv_args* a);
 
 /* All conv weight gradients of a backward pass in one call (the 42 trainable convolutions of ResNet-50 layer2-4,
  * exp/gpv/models/backbone.py:61-63: what autograd's 42 cudnn_convolution_backward_weight calls compute):

@@ -58,8 +58,13 @@ def gemm(A, B, Cm, M, N, K, lda, ldb, ldc, layoutA=0, layoutB=0, batch=1, sA=0, 
         out.copy_(y.to(out.dtype))
 
 
+def conv2d_mask_bits_ok(*a, **k):
+    return False                      # (the one-bit ReLU masks are a GPU-kernel matter: the emulation keeps the bf16 masks)
+
+
 def conv2d(mode, x, w, y, B, IH, IW, Cs, Cin, OH, OW, Cout, KH, KW, SH, SW, PH, PW, rowscale=None, bias=None, res=None,
-           relu_mask=None, act=0, split_k=0):
+           relu_mask=None, act=0, split_k=0, y_mask_bits=None, relu_mask_bits=None):
+    assert y_mask_bits is None and relu_mask_bits is None
     if Cs != Cin:
         # stem trick: a tap reads Cin contiguous elements starting at the pixel -> unfold explicitly
         cols = []
@@ -403,7 +408,7 @@ def install(only=None):
     """monkeypatch gpv1_amd.hip with the emulations above; returns an uninstall callable.
     `only`: optional list of entry-point names (GPU bisecting: swap single kernels for torch math)."""
     import gpv1_amd.hip as h
-    names = only or ['gemm', 'conv2d', 'attention_fwd', 'attention_bwd', 'attention_qkv_fwd', 'layernorm_fwd', 'layernorm_bwd', 'linear_layernorm_fwd', 'softmax_ce',
+    names = only or ['gemm', 'conv2d', 'conv2d_mask_bits_ok', 'attention_fwd', 'attention_bwd', 'attention_qkv_fwd', 'layernorm_fwd', 'layernorm_bwd', 'linear_layernorm_fwd', 'softmax_ce',
              'image_to_nhwc4', 'maxpool3x3s2', 'stem_pool', 'conv1x1_dual', 'conv1x1_chain', 'ffn_fused_fwd', 'conv_wgrad_group', 'roi_weights', 'add', 'add_rowbcast', 'colsum', 'cast', 'cast_rowscale_t',
              'prep_conv_weight', 'embedding', 'dropout', 'relevance_condition', 'adamw', 'sumsq', 'clip_scale', 'act_fwd', 'act_bwd',
              'cast_transpose_group', 'argmax_rows', 'ln_linear_rows', 'attention_row_proj']

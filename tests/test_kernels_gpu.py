@@ -1918,3 +1918,79 @@ def test_ffn_block_with_the_fused_forward_matches_the_three_launch_node(monkeypa
     for a, b in zip(res[True], res[False]):
         assert rel(a, b) < 2e-2, rel(a, b)
         assert torch.nn.functional.cosine_similarity(a.flatten(), b.flatten(), dim=0).item() > 0.9995
+
+
+def _pack_bits(y):
+    """[px, C] -> int32 [px, C / 32], bit (c & 31) of word c >> 5 = (y > 0): the layout of gpv_conv_args.y_mask_bits"""
+    px, Cc = y.shape
+    b = (y.float() > 0).view(px, Cc // 32, 32).to(torch.int64)
+    w = (b << torch.arange(32, device=y.device, dtype=torch.int64)).sum(-1)
+    return torch.where(w >= 2 ** 31, w - 2 ** 32, w).to(torch.int32)
+
+
+@pytest.mark.parametrize('K,N,px', [(128, 512, 4813), (256, 1024, 2400), (256, 512, 1000), (128, 512, 16), (256, 1024, 33)])
+def test_streaming_1x1_writes_one_bit_relu_masks(K, N, px):
+    """Round 6: conv3 + identity + ReLU of a bottleneck (backbone.py:93-95 -> torchvision Bottleneck.forward) on the streaming kernel ALSO
+    writes (output > 0) as one bit per element (gpv_conv_args.y_mask_bits): the output is the launch's without the bits, bit for bit, and the
+    words are the packed signs of the stored bf16 values -- ragged pixel counts included (rows beyond the map are never written)."""
+    h = hip()
+    B, H, W = 1, 1, px
+    x, w = rnd(px, K, dtype=torch.bfloat16, seed=300), rnd(N, K, dtype=torch.bfloat16, seed=301, scale=0.08)
+    res, bias = rnd(px, N, dtype=torch.bfloat16, seed=302), rnd(N, seed=303)
+    prev = h.set_option(h.OPT_C1S, 2)
+    try:
+        y0 = torch.empty(px, N, device=DEV, dtype=torch.bfloat16)
+        h.conv2d(0, x, w, y0, B, H, W, K, K, H, W, N, 1, 1, 1, 1, 0, 0, bias=bias, res=res, act=h.ACT_RELU)
+        y1 = torch.empty_like(y0)
+        bits = torch.full((px + 3, N // 32), 0x5a5a5a5a, device=DEV, dtype=torch.int32)          # three guard rows behind the map
+        args = (0, x, w, y1, B, H, W, K, K, H, W, N, 1, 1, 1, 1, 0, 0)
+        kw = dict(bias=bias, res=res, act=h.ACT_RELU, y_mask_bits=bits[:px])
+        assert h.conv2d_mask_bits_ok(*args, **kw)
+        h.set_option(h.OPT_C1S_LAUNCHES, 0)
+        h.conv2d(*args, **kw)
+        torch.cuda.synchronize()
+        assert h.set_option(h.OPT_C1S_LAUNCHES, 0) == 1
+        assert torch.equal(y0, y1)
+        assert torch.equal(bits[:px], _pack_bits(y1)) and (bits[px:] == 0x5a5a5a5a).all()
+        assert 0.2 < (y1 > 0).float().mean() < 0.8
+        # what the library refuses, it refuses before launching anything: no ReLU, a 3x3, the generic kernels
+        assert not h.conv2d_mask_bits_ok(*args, bias=bias, res=res, act=h.ACT_NONE, y_mask_bits=bits[:px])
+        with pytest.raises(RuntimeError):
+            h.conv2d(*args, bias=bias, res=res, act=h.ACT_NONE, y_mask_bits=bits[:px])
+        h.set_option(h.OPT_C1S, 0)
+        assert not h.conv2d_mask_bits_ok(*args, **kw)
+    finally:
+        h.set_option(h.OPT_C1S, prev)
+
+
+@pytest.mark.parametrize('K,N,px,with_res', [(128, 512, 4813, True), (256, 1024, 2400, True), (256, 512, 777, True), (512, 1024, 1200, True), (512, 1024, 50, True)])
+def test_streaming_1x1_backward_data_reads_one_bit_relu_masks(K, N, px, with_res):
+    """Round 6: conv1's backward-data launch (dx = (dy W + identity gradient) * (x > 0)) with the mask as one bit per element
+    (gpv_conv_args.relu_mask_bits) against the same launch with the bf16 activation as the mask: bit-identical."""
+    h = hip()
+    B, H, W = 1, 1, px
+    dy, wd = rnd(px, K, dtype=torch.bfloat16, seed=310), rnd(N, K, dtype=torch.bfloat16, seed=311, scale=0.08)
+    res = rnd(px, N, dtype=torch.bfloat16, seed=312) if with_res else None
+    act = torch.relu(rnd(px, N, dtype=torch.bfloat16, seed=313))                        # the saved post-ReLU activation
+    act[::7, ::5] = -0.0                                                                # (a stored -0 is not > 0)
+    bits = _pack_bits(act)
+    prev = h.set_option(h.OPT_C1S, 2)
+    try:
+        d0 = torch.empty(px, N, device=DEV, dtype=torch.bfloat16)
+        args0 = (1, dy, wd, d0, B, H, W, K, K, H, W, N, 1, 1, 1, 1, 0, 0)
+        h.conv2d(*args0, res=res, relu_mask=act)
+        d1 = torch.full_like(d0, float('nan'))
+        args1 = (1, dy, wd, d1, B, H, W, K, K, H, W, N, 1, 1, 1, 1, 0, 0)
+        assert h.conv2d_mask_bits_ok(*args1, res=res, relu_mask_bits=bits)
+        h.set_option(h.OPT_C1S_LAUNCHES, 0)
+        h.conv2d(*args1, res=res, relu_mask_bits=bits)
+        torch.cuda.synchronize()
+        assert h.set_option(h.OPT_C1S_LAUNCHES, 0) == 1
+        assert torch.equal(d0, d1)
+        assert torch.equal(d1 == 0, ~(act.float() > 0) | (d1 == 0)) and ((d1 != 0) & ~(act.float() > 0)).sum() == 0
+        # against fp32 math
+        ref = dy.float() @ wd.float().t() + (res.float() if res is not None else 0)
+        ref = torch.where(act.float() > 0, ref, torch.zeros_like(ref))
+        assert rel(d1, ref) < TOL[torch.bfloat16]
+    finally:
+        h.set_option(h.OPT_C1S, prev)

@@ -17,6 +17,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--batch', type=int, default=32)
 ap.add_argument('--iters', type=int, default=20)
 ap.add_argument('--filter', default='')
+ap.add_argument('--nomask', action='store_true', help='backward-data launches also WITHOUT their ReLU-mask operand (wrong numbers, right bytes: what a 1-bit mask could save at most)')
 args = ap.parse_args()
 dev = 'cuda'
 hip.lib()
@@ -109,6 +110,7 @@ def describe(k, a, kw):
 
 
 tot = {'fwd': [0.0, 0.0], 'bwd': [0.0, 0.0]}
+nomask_saved = [0.0]
 print('%-4s %-34s %9s %9s %8s %8s %7s' % ('', 'launch', 'us', 'bound us', 'TF/s', 'GB/s', 'excess'))
 rows = []
 for ph, k, a, kw in calls:
@@ -132,6 +134,22 @@ for ph, k, a, kw in calls:
     tot[ph][0] += us
     tot[ph][1] += bound
     rows.append((us - bound, nm, ph))
-    print('%-4s %-34s %9.1f %9.1f %8.1f %8.0f %7.1f' % (ph, nm, us, bound, fl / us / 1e6 if us else 0, by / us / 1e3 if us else 0, us - bound))
+    extra = ''
+    if args.nomask and k == 'conv2d' and a[0] == 1 and kw.get('relu_mask') is not None:
+        kw2 = dict(kw); kw2['relu_mask'] = None
+        for _ in range(3):
+            fn(*a, **kw2)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(args.iters):
+            fn(*a, **kw2)
+        e1.record()
+        torch.cuda.synchronize()
+        us2 = e0.elapsed_time(e1) * 1e3 / args.iters
+        nomask_saved[0] += us - us2
+        extra = '   without the mask operand %6.1f us (%+.1f)' % (us2, us2 - us)
+    print('%-4s %-34s %9.1f %9.1f %8.1f %8.0f %7.1f%s' % (ph, nm, us, bound, fl / us / 1e6 if us else 0, by / us / 1e3 if us else 0, us - bound, extra))
 for ph in ('fwd', 'bwd'):
     print('%s total %.1f us, sum of per-launch bounds %.1f us (%.2f)' % (ph, tot[ph][0], tot[ph][1], tot[ph][1] / max(tot[ph][0], 1e-9)))
+if args.nomask:
+    print('backward-data without the bf16 ReLU-mask operands: %.1f us less per pass' % nomask_saved[0])
