@@ -171,7 +171,7 @@ def _conv_fwd(x, conv, bn, need_wd, act, res=None, bits=False):
     y = torch.empty(B, OH, OW, conv.cout, device=x.device, dtype=RT.dtype)
     args = (0, x, wf, y, B, H, Wd, Cin, Cin, OH, OW, conv.cout, conv.k, conv.k, conv.stride, conv.stride, conv.pad, conv.pad)
     if bits and MASK_BITS and x.is_cuda and RT.dtype == torch.bfloat16 and conv.k == 1 and conv.stride == 1 and res is not None and act == RELU \
-            and conv.cout % 32 == 0:
+            and conv.cout % 256 == 0:
         mb = torch.empty(B * OH * OW, conv.cout // 32, device=x.device, dtype=torch.int32)
         kw = dict(bias=shift, res=res, act=act, y_mask_bits=mb)
         if _bits_ok(('f', B, H, Wd, Cin, conv.cout, hip.get_option_cached(hip.OPT_C1S)), args, kw):

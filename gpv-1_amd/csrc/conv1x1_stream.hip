@@ -38,10 +38,13 @@ __device__ __forceinline__ int c1s_chan(int L) {
 // amdgpu_waves_per_eu(2, 2) on the instances whose weights leave room for ONE 8-wave block per CU (> 72 KB of LDS): without the hint
 // hipcc schedules for three or four waves per SIMD, keeps one fragment register and serialises ds_read -> s_waitcnt lgkmcnt(0) -> MFMA
 // (97 of the 128 MFMAs of the 256 x 256 instance waited for a read issued right before them).
-// BITS (round 6): ReLU masks as one bit per element (include/gpv_hip.h gpv_conv_args.y_mask_bits / relu_mask_bits).  MASK: the mask operand
-// is p.mask_bits -- a lane's 8 channels of tile pair t are byte g of word [pixel][(cbase + h NH) / 32 + t], 4 bytes per lane and pair
-// instead of 16.  !MASK: the launch also writes (output > 0) of its ReLU outputs in that layout: the four lanes that hold a pixel's 32
-// channels of pair t or their bytes together with two cross-row shuffles and lane g == (t & 3) stores the word.
+// BITS (round 6): ReLU masks as one bit per element (include/gpv_hip.h gpv_conv_args.y_mask_bits / relu_mask_bits).  The byte order inside a
+// pixel's row of bits follows THIS kernel's accumulator layout, so that neither side needs a cross-lane operation: channel c of a pixel is
+// bit (c & 7) of byte  32 (c / 256) + 8 ((c % 32) / 8) + (c % 256) / 32  -- lane (pixel, g) of a 256-channel pass holds the 8 channels
+// 32 t + 8 g .. + 7 of its eight tile pairs t: their eight bytes are CONSECUTIVE (one 8-byte store / load per lane and pass; the K = 512
+// instances' 128-channel passes read four of them).  !MASK: the launch also writes (output > 0) of its ReLU outputs; MASK: the mask
+// operand is p.mask_bits, 8 (4) bytes per lane and pass instead of 128 (64).  (First build: channel-linear words, two cross-row shuffles
+// and a 4-byte store per tile pair in the producer -- the forward launches lost 13 / 6 us of the 25 / 11 the backward-data ones gained.)
 template <int K, int NH, bool RES, bool MASK, bool NT, bool LIN = false, int NP = 1, bool BITS = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu((NP == 1 && NH * K * 2 > 72 * 1024) ? 2 : 1, (NP == 1 && NH * K * 2 > 72 * 1024) ? 2 : 8)))
 void c1s_kernel(GemmK p, int ncols) {
@@ -61,7 +64,7 @@ void c1s_kernel(GemmK p, int ncols) {
   const bf16* Mk = reinterpret_cast<const bf16*>(p.mask) + cbase;
   const float* bias_g = p.bias ? p.bias + cbase : nullptr;
   const int nfull = p.N;
-  const int wpp = nfull >> 5, wbase = cbase >> 5;          // BITS: mask words per pixel, this slice's first word
+  const int bpp = nfull >> 3;                              // BITS: mask bytes per pixel
   if constexpr (LIN) { if (p.dthresh) p.seed = eff_seed(p.seed, p.seed_dev); }
   p.N = ncols;
   const int ntile = (p.M + 15) >> 4;
@@ -154,18 +157,18 @@ void c1s_kernel(GemmK p, int ncols) {
                      : *reinterpret_cast<const bf16x8*>(q);
         }
       }
-      uint32_t mw[(MASK && BITS) ? NG : 1];
+      // BITS: this pass covers channels c0p .. c0p + NH - 1 of the pixel: byte 32 (c0p / 256) + 8 g + (c0p % 256) / 32 onwards, NG bytes
+      const int c0p = cbase + h * NH;
+      const int64_t boff = (int64_t)pxc * bpp + (c0p >> 8) * 32 + g * 8 + ((c0p & 255) >> 5);
+      uint32_t mw[2] = {0u, 0u};
       if constexpr (MASK && BITS) {
-        const uint32_t* mq = p.mask_bits + (int64_t)pxc * wpp + wbase + h * NG;
-        if constexpr (NG % 4 == 0) {
-#pragma unroll
-          for (int t = 0; t < NG; t += 4) {
-            const u32x4 w4 = *reinterpret_cast<const u32x4*>(mq + t);
-            mw[t] = w4[0]; mw[t + 1] = w4[1]; mw[t + 2] = w4[2]; mw[t + 3] = w4[3];
-          }
+        const unsigned char* mq = reinterpret_cast<const unsigned char*>(p.mask_bits) + boff;
+        if constexpr (NG == 8) {
+          const uint2 w2 = *reinterpret_cast<const uint2*>(mq);
+          mw[0] = w2.x; mw[1] = w2.y;
         } else {
-#pragma unroll
-          for (int t = 0; t < NG; ++t) mw[t] = mq[t];
+          static_assert(NG == 4 || !(MASK && BITS), "mask bits: 256- or 128-channel passes");
+          mw[0] = *reinterpret_cast<const uint32_t*>(mq);
         }
       } else if constexpr (MASK) {
 #pragma unroll
@@ -212,6 +215,7 @@ void c1s_kernel(GemmK p, int ncols) {
           }
         }
       }
+      uint32_t bits_acc[2] = {0u, 0u};
 #pragma unroll
       for (int t = 0; t < NG; ++t) {
         const int c0 = h * NH + t * 32 + g * 8;
@@ -266,20 +270,30 @@ void c1s_kernel(GemmK p, int ncols) {
             float x = v[e];
             if constexpr (RES) x += (float)rv[t][e];
             if (p.act == GPV_ACT_RELU) x = fmaxf(x, 0.f);
-            if constexpr (MASK && BITS) x = ((mw[t] >> (g * 8 + e)) & 1u) ? x : 0.f;
+            if constexpr (MASK && BITS) x = ((mw[t >> 2] >> ((t & 3) * 8 + e)) & 1u) ? x : 0.f;
             else if constexpr (MASK) x = (float)mv[t][e] > 0.f ? x : 0.f;
             o[e] = (bf16)x;
           }
         }
         if constexpr (BITS && !MASK) {
-          // (output > 0) of the STORED bf16 values, what a later (float)mask > 0.f test would see
-          uint32_t wb = 0u;
+          // (output > 0) of the STORED bf16 values -- as 16-bit integers: > 0 (a stored -0 or negative is not; what a later
+          // (float)mask > 0.f test sees) -- eight of them into one byte in 13 instructions: packed min(., 1) / max(., 0) leave 0 | 1 per
+          // half, a byte permute gathers four halves' low bytes, a 4 x 8-bit dot product with (1, 2, 4, 8) makes the nibble
+          // (inline asm: written with __builtin_elementwise_min / max on short2 values hipcc 7.2 derived all four words' flags from
+          //  the FIRST word -- v_cmp_lt_i16 on elements 0 and 1 only, seen in the ISA -- and every byte came out as 0x00 / 55 / aa / ff)
+          const u32x4 ow = __builtin_bit_cast(u32x4, o);
+          const uint32_t one2 = 0x00010001u, zero2 = 0u;
+          uint32_t m[4];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) wb |= ((float)o[e] > 0.f ? 1u : 0u) << e;
-          wb <<= g * 8;
-          wb |= (uint32_t)__shfl_xor((int)wb, 16);
-          wb |= (uint32_t)__shfl_xor((int)wb, 32);
-          if (g == (t & 3) && px < p.M) p.out_bits[(int64_t)pxc * wpp + wbase + h * NG + t] = wb;
+          for (int q = 0; q < 4; ++q) {
+            uint32_t tq;
+            asm("v_pk_min_i16 %0, %1, %2" : "=v"(tq) : "v"(ow[q]), "v"(one2));
+            asm("v_pk_max_i16 %0, %1, %2" : "=v"(m[q]) : "v"(tq), "v"(zero2));
+          }
+          const uint32_t b03 = __builtin_amdgcn_perm(m[1], m[0], 0x06040200u);      // bytes (m0.b0, m0.b2, m1.b0, m1.b2) = elements 0..3
+          const uint32_t b47 = __builtin_amdgcn_perm(m[3], m[2], 0x06040200u);
+          const uint32_t byte = __builtin_amdgcn_udot4(b03, 0x08040201u, 0u, false) | (__builtin_amdgcn_udot4(b47, 0x08040201u, 0u, false) << 4);
+          bits_acc[t >> 2] |= byte << ((t & 3) * 8);
         }
         // No branch and no store hipcc can see in the tile loop (conv1x1_dual.hip): rows beyond M were LOADED from row M - 1 (A,
         // residual, mask, dropout index), so they hold row M - 1's results and store them there again; the store is inline asm because
@@ -292,6 +306,14 @@ void c1s_kernel(GemmK p, int ncols) {
           if constexpr (NT) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" :: "v"(q), "v"(ov) : "memory");
           else asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" :: "v"(q), "v"(ov) : "memory");
         }
+      }
+      if constexpr (BITS && !MASK) {
+        // the pass's eight mask bytes of this lane: one 8-byte store, invisible to the waitcnt pass like the data stores (rows beyond M
+        // hold row M - 1's values and store them there again)
+        static_assert(NG == 8 || !(BITS && !MASK), "mask bits are written by 256-channel passes");
+        unsigned char* bq = reinterpret_cast<unsigned char*>(p.out_bits) + boff;
+        const uint2 bv = make_uint2(bits_acc[0], bits_acc[1]);
+        asm volatile("global_store_dwordx2 %0, %1, off\n\ts_nop 0" :: "v"(bq), "v"(bv) : "memory");
       }
     }
   }
@@ -410,7 +432,7 @@ int c1s_try_launch(const GemmK& k, int dtype_in, int dtype_out, hipStream_t st, 
     // instances that exist with mask bits (c1s_flags) -- decided here so that a dry run (gpv_conv2d_mask_bits_ok) answers what a launch would do
     const int nh = ncols >= 256 ? 256 : ncols;
     const bool inst = ((k.K == 128 || k.K == 256) && nh == 256) || (k.K == 512 && nh == 128 && !k.out_bits);
-    if (linear || !inst || !k.res || k.nt_io || (k.mask_bits && k.out_bits) || k.N % 32 != 0 || (k.out_bits && (k.mask && !k.mask_bits))) return -1;
+    if (linear || !inst || !k.res || k.nt_io || (k.mask_bits && k.out_bits) || k.N % 256 != 0 || (k.out_bits && (k.mask && !k.mask_bits))) return -1;
     if (k.out_bits && k.act != GPV_ACT_RELU) return -1;
     if (k.K <= 128 && ncols / nh > 2) return -1;
     if (k.K > 128 && ncols / nh != 1) return -1;

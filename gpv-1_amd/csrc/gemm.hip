@@ -1041,7 +1041,7 @@ static int conv2d_impl(const gpv_conv_args* a, hipStream_t st, bool dry) {
   if (want_bits) {
     // one-bit ReLU masks: the streaming 1x1 kernel only (stride 1, pointwise), forward with ReLU writes them, backward-data reads them
     if (a->KH != 1 || a->KW != 1 || a->SH != 1 || a->SW != 1 || a->PH != 0 || a->PW != 0 || a->IH != a->OH || a->IW != a->OW) return (int)hipErrorInvalidValue;
-    if (a->Cout % 32 != 0 || (a->y_mask_bits && (a->mode != 0 || a->act != GPV_ACT_RELU || a->relu_mask)) || (a->relu_mask_bits && a->mode != 1)) return (int)hipErrorInvalidValue;
+    if (a->Cout % 256 != 0 || (a->y_mask_bits && (a->mode != 0 || a->act != GPV_ACT_RELU || a->relu_mask)) || (a->relu_mask_bits && a->mode != 1)) return (int)hipErrorInvalidValue;
     if ((reinterpret_cast<uintptr_t>(a->y_mask_bits) | reinterpret_cast<uintptr_t>(a->relu_mask_bits)) & 15) return (int)hipErrorInvalidValue;
   } else if (dry) {
     return (int)hipErrorInvalidValue;

@@ -160,8 +160,9 @@ typedef struct {
                                                convolutions over <= 8192 output pixels (fp32 slabs + a second pass with the epilogue) */
   /* Round 6: ReLU masks as ONE BIT per element (both optional; NULL = as before).  The backward pass needs a post-ReLU activation only
      as "was this element > 0" (the dgrad epilogue's * (relu_mask > 0)); read as bf16 that is 16 bits per element of the widest tensors
-     of a bottleneck (157 MB per layer2 block at B = 32: a third of such a launch's bytes).  Layout of both: uint32 [pixels][Cout / 32],
-     bit (c & 31) of word [pixel][c >> 5] = (y[pixel, c] > 0) of the bf16 value as stored.
+     of a bottleneck (157 MB per layer2 block at B = 32: a third of such a launch's bytes).  Both: Cout / 8 bytes per pixel, Cout a multiple
+     of 256, (y[pixel, c] > 0) of the bf16 value as stored = bit (c & 7) of byte  32 (c / 256) + 8 ((c % 32) / 8) + (c % 256) / 32  of the pixel's
+     row (the streaming kernel's accumulator order inside a 256-channel group: neither side needs a cross-lane operation); 16-byte aligned.
        y_mask_bits    (mode 0, act = GPV_ACT_RELU): the launch ALSO writes the bits of its output;
        relu_mask_bits (mode 1): read INSTEAD of relu_mask (relu_mask may then be NULL); results are bit-identical to the bf16 mask's.
      Only the streaming 1x1 kernel serves them: gpv_conv2d_mask_bits_ok() tells whether a call would be served, gpv_conv2d returns

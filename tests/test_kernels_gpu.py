@@ -1921,11 +1921,13 @@ def test_ffn_block_with_the_fused_forward_matches_the_three_launch_node(monkeypa
 
 
 def _pack_bits(y):
-    """[px, C] -> int32 [px, C / 32], bit (c & 31) of word c >> 5 = (y > 0): the layout of gpv_conv_args.y_mask_bits"""
+    """[px, C] -> int32 [px, C / 32] holding gpv_conv_args.y_mask_bits' bytes: (y[px, c] > 0) = bit (c & 7) of byte
+    32 (c / 256) + 8 ((c % 32) / 8) + (c % 256) / 32 of the pixel's row (include/gpv_hip.h)"""
     px, Cc = y.shape
-    b = (y.float() > 0).view(px, Cc // 32, 32).to(torch.int64)
-    w = (b << torch.arange(32, device=y.device, dtype=torch.int64)).sum(-1)
-    return torch.where(w >= 2 ** 31, w - 2 ** 32, w).to(torch.int32)
+    b = (y.float() > 0).view(px, Cc // 256, 8, 4, 8).to(torch.int32)              # [px, group of 256, t = (c % 256) / 32, g = (c % 32) / 8, e = c & 7]
+    byte = (b << torch.arange(8, device=y.device, dtype=torch.int32)).sum(-1)     # [px, group, t, g]
+    byte = byte.permute(0, 1, 3, 2).contiguous().to(torch.uint8)                  # byte order inside a group: 8 g + t
+    return byte.view(px, Cc // 8).view(torch.int32)
 
 
 @pytest.mark.parametrize('K,N,px', [(128, 512, 4813), (256, 1024, 2400), (256, 512, 1000), (128, 512, 16), (256, 1024, 33)])
