@@ -198,6 +198,13 @@ def _block_tail_fused(x, a2, blk, tr, need_wd):
     if hit is None or hit[0] != RT.static_epoch:
         hit = RT.cache[key] = (RT.static_epoch, (s3 + sd).contiguous())          # FrozenBN shifts: constants of the static epoch
     y = torch.empty(B, OH, OW, c3.cout, device=x.device, dtype=RT.dtype)
+    if tr and MASK_BITS and (K1, K2, c3.cout) == (128, 256, 512) and x.is_cuda:
+        # layer2's first block output is the ReLU mask of the second block's conv1 backward-data: its bits ride in this launch
+        mb = torch.empty(B * OH * OW, c3.cout // 32, device=x.device, dtype=torch.int32)
+        if hip.conv1x1_dual(a2, w3, x, wd, hit[1], y, B, OH, OW, K1, IH, IW, K2, cd.stride, c3.cout, RELU, y_mask_bits=mb):
+            y._gpv_bits = mb
+            return y
+        del mb
     if not hip.conv1x1_dual(a2, w3, x, wd, hit[1], y, B, OH, OW, K1, IH, IW, K2, cd.stride, c3.cout, RELU):
         return None
     return y

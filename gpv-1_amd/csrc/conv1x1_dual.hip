@@ -24,6 +24,7 @@ struct DualK {
   int OH, OW, IH2, IW2, S2;       // a2's spatial extent and stride (a1 has the output's)
   int ld1, ld2;                   // channel strides of a1 / a2 pixels
   int relu, nt;
+  void* bits;                     // round 6: (y > 0) as one bit per element in conv1x1_stream.hip's byte order (gpv_conv_args.y_mask_bits), or NULL
 };
 
 template <int NH>
@@ -32,7 +33,7 @@ __device__ __forceinline__ int c1d_chan(int L) {      // (conv1x1_stream.hip c1s
   return hh * NH + (j >> 1) * 32 + (r >> 2) * 8 + (j & 1) * 4 + (r & 3);
 }
 
-template <int K1, int K2, int NH, bool NT>
+template <int K1, int K2, int NH, bool NT, bool BITS = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void c1d_kernel(DualK p, int ncols) {
   // A wave owns 32 pixels (two MFMA row tiles): every weight fragment read from LDS feeds TWO MFMAs -- with 16 pixels per wave the
   // launch was bound by the LDS read pipe (96 ds_read_b128 per 96 MFMAs and wave: 109 us for layer2's 60 GFLOP).  The A fragments of
@@ -127,6 +128,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
       const int px = min(px0 + m * 16, p.M - 1);
+      uint32_t bits_acc = 0u;
 #pragma unroll
       for (int t = 0; t < NG; ++t) {
         const int c0 = t * 32 + g * 8;
@@ -145,16 +147,35 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         //  cannot see into the asm; without it rows 12..15 of a tile's last store carried the next tile's values)
         if constexpr (NT) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" :: "v"(q), "v"(ov) : "memory");
         else asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" :: "v"(q), "v"(ov) : "memory");
+        if constexpr (BITS) {
+          // (output > 0) of the stored bf16 values, eight into a byte (conv1x1_stream.hip: packed min / max as inline asm, byte permute, 4 x 8-bit dot)
+          const uint32_t one2 = 0x00010001u, zero2 = 0u;
+          uint32_t mq[4];
+#pragma unroll
+          for (int q2 = 0; q2 < 4; ++q2) {
+            uint32_t tq;
+            asm("v_pk_min_i16 %0, %1, %2" : "=v"(tq) : "v"(ov[q2]), "v"(one2));
+            asm("v_pk_max_i16 %0, %1, %2" : "=v"(mq[q2]) : "v"(tq), "v"(zero2));
+          }
+          const uint32_t b03 = __builtin_amdgcn_perm(mq[1], mq[0], 0x06040200u), b47 = __builtin_amdgcn_perm(mq[3], mq[2], 0x06040200u);
+          bits_acc |= (__builtin_amdgcn_udot4(b03, 0x08040201u, 0u, false) | (__builtin_amdgcn_udot4(b47, 0x08040201u, 0u, false) << 4)) << (t * 8);
+        }
+      }
+      if constexpr (BITS) {
+        // this lane's four mask bytes of the pixel's 128-channel slice: bytes 32 (c / 256) + 8 g + (c % 256) / 32 .. + 3, c = cbase
+        static_assert(!BITS || NG == 4, "mask bits: 128-channel passes");
+        unsigned char* bq = reinterpret_cast<unsigned char*>(p.bits) + (int64_t)px * (p.N >> 3) + (cbase >> 8) * 32 + g * 8 + ((cbase & 255) >> 5);
+        asm volatile("global_store_dword %0, %1, off\n\ts_nop 0" :: "v"(bq), "v"(bits_acc) : "memory");
       }
     }
   }
 }
 
-template <int K1, int K2, int NH, bool NT>
+template <int K1, int K2, int NH, bool NT, bool BITS = false>
 int c1d_launch_nt(const DualK& p, int ncols, hipStream_t st) {
   constexpr int KP = K1 + K2 + 8;
   const size_t lds = (size_t)ncols * KP * 2 + (size_t)ncols * sizeof(float);
-  auto fn = c1d_kernel<K1, K2, NH, NT>;
+  auto fn = c1d_kernel<K1, K2, NH, NT, BITS>;
   static size_t attr = 0;
   if (lds > 64 * 1024 && lds > attr) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -173,6 +194,10 @@ int c1d_launch_nt(const DualK& p, int ncols, hipStream_t st) {
 
 template <int K1, int K2, int NH>
 int c1d_launch(const DualK& p, int ncols, hipStream_t st) {
+  if (p.bits) {
+    if constexpr (NH == 128) { if (!p.nt && p.relu && p.N % 256 == 0) return c1d_launch_nt<K1, K2, NH, false, true>(p, ncols, st); }
+    return (int)hipErrorNotSupported;
+  }
   return p.nt ? c1d_launch_nt<K1, K2, NH, true>(p, ncols, st) : c1d_launch_nt<K1, K2, NH, false>(p, ncols, st);
 }
 
@@ -184,8 +209,16 @@ int c1d_launch(const DualK& p, int ncols, hipStream_t st) {
 // (the caller then runs the two convolutions one after the other).
 extern "C" int gpv_conv1x1_dual(const void* a1, const void* w1, const void* a2, const void* w2, const float* bias, void* y, int B, int OH,
                                 int OW, int K1, int IH2, int IW2, int K2, int s2, int N, int act, void* stream) {
+  return gpv_conv1x1_dual_bits(a1, w1, a2, w2, bias, y, B, OH, OW, K1, IH2, IW2, K2, s2, N, act, nullptr, stream);
+}
+
+// + y_mask_bits (or NULL): (y > 0) as one bit per element in gpv_conv_args.y_mask_bits' layout (the (128, 256) -> 512 shape with ReLU only:
+// hipErrorNotSupported otherwise, nothing launched)
+extern "C" int gpv_conv1x1_dual_bits(const void* a1, const void* w1, const void* a2, const void* w2, const float* bias, void* y, int B, int OH,
+                                     int OW, int K1, int IH2, int IW2, int K2, int s2, int N, int act, void* y_mask_bits, void* stream) {
   using namespace gpvk;
   if (!a1 || !a2 || !w1 || !w2 || !y || B <= 0) return (int)hipErrorInvalidValue;
+  if (reinterpret_cast<uintptr_t>(y_mask_bits) & 15) return (int)hipErrorInvalidValue;
   if ((s2 != 1 && s2 != 2) || (OH - 1) * s2 >= IH2 || (OW - 1) * s2 >= IW2) return (int)hipErrorInvalidValue;
   if (act != GPV_ACT_NONE && act != GPV_ACT_RELU) return (int)hipErrorInvalidValue;
   if ((reinterpret_cast<uintptr_t>(a1) | reinterpret_cast<uintptr_t>(a2) | reinterpret_cast<uintptr_t>(w1) | reinterpret_cast<uintptr_t>(w2) |
@@ -194,6 +227,7 @@ extern "C" int gpv_conv1x1_dual(const void* a1, const void* w1, const void* a2, 
   p.a1 = a1; p.a2 = a2; p.w1 = w1; p.w2 = w2; p.bias = bias; p.y = y;
   p.M = B * OH * OW; p.N = N; p.OH = OH; p.OW = OW; p.IH2 = IH2; p.IW2 = IW2; p.S2 = s2; p.ld1 = K1; p.ld2 = K2;
   p.relu = act == GPV_ACT_RELU;
+  p.bits = y_mask_bits;
   p.nt = (int64_t)p.M * N * 2 >= ((int64_t)200 << 20);          // outputs beyond the 256 MB MALL are stored non-temporally (conv1x1_stream.hip)
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (K1 == 64 && K2 == 64 && N == 256) return c1d_launch<64, 64, 256>(p, 256, st);

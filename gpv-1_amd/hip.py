@@ -106,7 +106,7 @@ def lib():
     return _LIB
 
 
-EXPORTS = ['gpv_abi_version', 'gpv_build_id', 'gpv_set_option', 'gpv_gemm', 'gpv_conv2d', 'gpv_conv2d_mask_bits_ok', 'gpv_image_to_nhwc4', 'gpv_maxpool3x3s2',
+EXPORTS = ['gpv_abi_version', 'gpv_build_id', 'gpv_set_option', 'gpv_gemm', 'gpv_conv2d', 'gpv_conv2d_mask_bits_ok', 'gpv_conv1x1_dual_bits', 'gpv_image_to_nhwc4', 'gpv_maxpool3x3s2',
            'gpv_attention_fwd', 'gpv_attention_bwd', 'gpv_attention_qkv_fwd', 'gpv_layernorm_fwd', 'gpv_layernorm_bwd', 'gpv_layernorm_pos_fwd', 'gpv_layernorm_bwd2', 'gpv_linear_layernorm_fwd',
            'gpv_softmax_ce', 'gpv_roi_weights', 'gpv_add', 'gpv_add_rowbcast', 'gpv_colsum', 'gpv_cast',
            'gpv_cast_rowscale_t', 'gpv_prep_conv_weight', 'gpv_embedding', 'gpv_dropout',
@@ -519,12 +519,18 @@ def jpeg_decode(descs_dev, B, max_blocks, max_pixels):
     _chk(lib().gpv_jpeg_decode(_p(descs_dev), B, int(max_blocks), C.c_int64(int(max_pixels)), _stream()), 'gpv_jpeg_decode')
 
 
-def conv1x1_dual(a1, w1, a2, w2, bias, y, B, OH, OW, K1, IH2, IW2, K2, s2, N, act=ACT_RELU):
-    """gpv_conv1x1_dual: y = act(a1 . w1^T + a2(stride s2) . w2^T + bias); returns False when the shape is not one the kernel
-    takes (hipErrorNotSupported) -- the caller then runs the two convolutions"""
+def conv1x1_dual(a1, w1, a2, w2, bias, y, B, OH, OW, K1, IH2, IW2, K2, s2, N, act=ACT_RELU, y_mask_bits=None):
+    """gpv_conv1x1_dual(_bits): y = act(a1 . w1^T + a2(stride s2) . w2^T + bias) (+ the one-bit ReLU mask of y); returns False when the
+    shape is not one the kernel takes (hipErrorNotSupported) -- the caller then runs the two convolutions"""
     if not all(t.dtype == torch.bfloat16 for t in (a1, w1, a2, w2, y)):
         return False
-    err = lib().gpv_conv1x1_dual(_p(a1), _p(w1), _p(a2), _p(w2), _p(_f32(bias)), _p(y), B, OH, OW, K1, IH2, IW2, K2, s2, N, act, _stream())
+    if y_mask_bits is not None:
+        if y_mask_bits.dtype != torch.int32 or not y_mask_bits.is_contiguous() or y_mask_bits.numel() * 32 != B * OH * OW * N:
+            raise TypeError('conv1x1_dual: mask bits are a contiguous int32 [pixels, N / 32] tensor')
+        err = lib().gpv_conv1x1_dual_bits(_p(a1), _p(w1), _p(a2), _p(w2), _p(_f32(bias)), _p(y), B, OH, OW, K1, IH2, IW2, K2, s2, N, act, _p(y_mask_bits),
+                                          _stream())
+    else:
+        err = lib().gpv_conv1x1_dual(_p(a1), _p(w1), _p(a2), _p(w2), _p(_f32(bias)), _p(y), B, OH, OW, K1, IH2, IW2, K2, s2, N, act, _stream())
     if err == 801:
         return False
     _chk(err, 'gpv_conv1x1_dual')

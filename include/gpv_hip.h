@@ -250,6 +250,11 @@ int gpv_jpeg_decode(const gpv_jpeg_desc* descs, int B, int max_blocks, int64_t m
  * hipErrorNotSupported (801) for anything else -- the caller then issues the two convolutions. */
 int gpv_conv1x1_dual(const void* a1, const void* w1, const void* a2, const void* w2, const float* bias, void* y, int B, int OH, int OW,
                      int K1, int IH2, int IW2, int K2, int s2, int N, int act, void* stream);
+/* the same launch, also writing y_mask_bits = (y > 0) as one bit per element in gpv_conv_args.y_mask_bits' layout (round 6: the mask
+ * of the next bottleneck's conv1 backward-data, backbone.py:61-63 trains layer2): (K1, K2, N) = (128, 256, 512) with ReLU only -- 801
+ * otherwise, nothing launched; y_mask_bits == NULL is gpv_conv1x1_dual */
+int gpv_conv1x1_dual_bits(const void* a1, const void* w1, const void* a2, const void* w2, const float* bias, void* y, int B, int OH, int OW,
+                          int K1, int IH2, int IW2, int K2, int s2, int N, int act, void* y_mask_bits, void* stream);
 
 /* A layer1 bottleneck tail AND the conv1 of the bottleneck that follows, one launch (torchvision Bottleneck.forward twice:
  * exp/gpv/models/backbone.py:93-95; conv1 / layer1 are frozen, :61-63, so nothing in between is needed by a backward pass):

@@ -237,7 +237,7 @@ def image_pipeline(descs_dev, B, scratch, grey_sum, out, OH, OW, pad, Hp, Wp):
     raise RuntimeError('cpu_shim: the device input pipeline has no CPU emulation (oracle/image_oracle.py is its checker)')
 
 
-def conv1x1_dual(a1, w1, a2, w2, bias, y, B, OH, OW, K1, IH2, IW2, K2, s2, N, act=1):
+def conv1x1_dual(a1, w1, a2, w2, bias, y, B, OH, OW, K1, IH2, IW2, K2, s2, N, act=1, y_mask_bits=None):
     return False                       # (bf16 kernel only: the CPU emulation runs the two convolutions)
 
 

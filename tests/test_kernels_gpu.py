@@ -1705,6 +1705,17 @@ def test_fused_block_tail_conv3_plus_downsample(K1, K2, N, s2, OH, OW, Bn):
     h.conv2d(0, a2, w3.view(N, 1, K1), y2, Bn, OH, OW, K1, K1, OH, OW, N, 1, 1, 1, 1, 0, 0, bias=b3, res=idt, act=h.ACT_RELU)
     assert rel(y, y2) < 1.2e-2
     assert not h.conv1x1_dual(a2[..., :32].contiguous(), w3[:, :32].contiguous(), x, wd, b3, y, Bn, OH, OW, 32, IH, IW, K2, s2, N, h.ACT_RELU)
+    # round 6: the same launch also writing the one-bit ReLU mask of its output (gpv_conv1x1_dual_bits; layer2's shape only)
+    bits = torch.full((Bn * OH * OW + 2, N // 32), 0x5a5a5a5a, device=DEV, dtype=torch.int32)
+    y3 = torch.full_like(y, float('nan'))
+    took = h.conv1x1_dual(a2, w3, x, wd, (b3 + bd).contiguous(), y3, Bn, OH, OW, K1, IH, IW, K2, s2, N, h.ACT_RELU, y_mask_bits=bits[:Bn * OH * OW])
+    assert took == ((K1, K2, N) == (128, 256, 512))
+    if took:
+        torch.cuda.synchronize()
+        assert torch.equal(y3, y)
+        assert torch.equal(bits[:Bn * OH * OW], _pack_bits(y3.view(-1, N))) and (bits[Bn * OH * OW:] == 0x5a5a5a5a).all()
+    else:
+        assert (bits == 0x5a5a5a5a).all() and torch.isnan(y3.float()).all()               # refused before anything was launched
 
 
 @pytest.mark.parametrize('branch', ['identity', 'downsample', 'plain'])

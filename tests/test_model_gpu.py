@@ -928,9 +928,10 @@ def test_graphed_training_on_string_queries_and_ragged_lengths(rt):
     # summation-order noise into +-lr steps, see the frozen-backbone test): tight for the first 10 steps, loose for the rest.  That
     # the size-class masking itself is exact is the next test's business.
     # (round 5: the two runs launch DIFFERENT kernels for their differently padded <= 1024-row GEMMs since the 96-row tile rule -- other
-    #  fp32 summation orders from the first step on: steps 1..3 measured 4e-4 / 1.2e-3 / 1.1e-3, step 4 5.4e-3)
+    #  fp32 summation orders from the first step on: steps 1..3 measured 4e-4 / 1.2e-3 / 1.1e-3, step 4 5.4e-3; round 6: these row counts
+    #  run GEMM + LayerNorm instead of the one-launch projection + LayerNorm (ops.PROJ_LN_MIN_ROWS): 4e-4 / 1.6e-3 / 1.0e-3, step 4 1.0e-2)
     for i, (a, b_) in enumerate(zip(l0[:4], l1[:4])):
-        assert abs(a - b_) <= (5e-3 if i < 3 else 1e-2) * max(abs(a), 1.0), (l0[:4], l1[:4])
+        assert abs(a - b_) <= (5e-3 if i < 3 else 2e-2) * max(abs(a), 1.0), (l0[:4], l1[:4])
     dev_ = [abs(a - b_) / max(abs(a), 1.0) for a, b_ in zip(l0, l1)]
     print('RAGGED loss deviation: max %.3f, mean %.4f; param rel %.4f' % (max(dev_), sum(dev_) / len(dev_), rel(p1, p0.cpu())))
     assert sum(dev_) / len(dev_) <= 0.1, (max(dev_), sum(dev_) / len(dev_))          # (measured: mean 0.048, one step at 0.73)
