@@ -861,62 +861,12 @@ __global__ __launch_bounds__(256) void conv_split_epilogue_kernel(const float* _
   *reinterpret_cast<bf16x4*>(y + off) = out;
 }
 
-// Round 6: the split forward convolution as ONE launch.  The split blocks of a tile count themselves off on a per-tile counter; the
-// block that arrives last (the other splits' slabs are complete and, after the fences, visible) sums the tile's slabs in split order and
-// applies the epilogue -- conv_split_epilogue_kernel's arithmetic in its order, so the result is bit-identical to the two launches -- and
-// puts the counter back to zero for the next launch.  One graph node less per 3x3 convolution of batch-1 inference (14 per image at
-// ~5 us each; tools/probe_decode_nodes.py: a node's floor is 1.7 us, the epilogue's dependent loads made it 5).
-struct SplitFin { unsigned* counters; const float* bias; const bf16* res; bf16* y; int act, split; };
-
-__global__ __launch_bounds__(256) void conv_split_fused_kernel(GemmK p, SplitFin f) {
-  gemm_body<bf16, float, OP_CONV, OP_PLAIN, 64, 64, true>(p);
-  // (gemm_body's tile of this block: its XCD-aware order over the (tiles, splits) plane)
-  const int gx = gridDim.x, nwg = gx * (int)gridDim.y, bid = (int)blockIdx.x + gx * (int)blockIdx.y;
-  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
-  const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-  const int tile = v - (v / gx) * gx;
-  const int tm = tile / p.tilesN, tn = tile - tm * p.tilesN, row0 = tm * 64, col0 = tn * 64;
-  __shared__ int s_last;
-  __threadfence();                                   // this block's slab tile is visible device-wide ...
-  __syncthreads();
-  if (threadIdx.x == 0) s_last = atomicAdd(f.counters + tile, 1u) == (unsigned)(f.split - 1);      // ... before it counts itself off
-  __syncthreads();
-  if (!s_last) return;
-  __threadfence();                                   // (acquire: the other splits' tiles, written through other XCDs' L2s)
-  const int64_t slab = (int64_t)p.M * p.N;
-  for (int i = threadIdx.x; i < 64 * 16; i += 256) {
-    const int m = row0 + (i >> 4), n = col0 + (i & 15) * 4;
-    if (m >= p.M || n >= p.N) continue;
-    const int64_t off = (int64_t)m * p.N + n;
-    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int sidx = 0; sidx < f.split; ++sidx) {
-      const float4 w = *reinterpret_cast<const float4*>(p.ws + sidx * slab + off);
-      a.x += w.x; a.y += w.y; a.z += w.z; a.w += w.w;
-    }
-    float o[4] = {a.x, a.y, a.z, a.w};
-    if (f.bias) {
-      const float4 b = *reinterpret_cast<const float4*>(f.bias + n);
-      o[0] += b.x; o[1] += b.y; o[2] += b.z; o[3] += b.w;
-    }
-    if (f.res) {
-      const bf16x4 rr = *reinterpret_cast<const bf16x4*>(f.res + off);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] += (float)rr[e];
-    }
-    bf16x4 out;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) out[e] = (bf16)(f.act == GPV_ACT_RELU ? fmaxf(o[e], 0.f) : o[e]);
-    *reinterpret_cast<bf16x4*>(f.y + off) = out;
-  }
-  if (threadIdx.x == 0) f.counters[tile] = 0u;        // re-armed for the next launch on this stream
-}
-
 // Forward convolutions over a few hundred to a few thousand output pixels (inference at batch 1: layer2-4 see 4800 / 1200 / 300
 // pixels): 12..40 tiles of a 128-wide kernel walk K = 1152..4608 alone on a 256-CU chip.  The reduction is split over grid.y
 // into fp32 slabs of the caller's workspace (64 x 64 tiles, ~300 workgroups of >= 8 k-tiles), a second launch sums the slabs and
 // applies bias / residual / ReLU.  Returns 0 = launched, -1 = not applicable.
 inline bool a16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
-int conv_split_try_launch(const GemmK& k, int dtype_in, int dtype_out, hipStream_t st, unsigned* counters = nullptr) {
+int conv_split_try_launch(const GemmK& k, int dtype_in, int dtype_out, hipStream_t st) {
   static const int on = tune_env("GPV_CONV_SPLIT", 1);
   if (!on || g_kernel_forced || dtype_in != GPV_BF16 || dtype_out != GPV_BF16 || !k.vecA || !k.vecB || !k.ws_base) return -1;
   if (k.mask || k.rowscale || k.dthresh || k.accumulate || k.cg.dgrad || k.alpha != 1.0f || (k.act != 0 && k.act != GPV_ACT_RELU)) return -1;
@@ -937,12 +887,6 @@ int conv_split_try_launch(const GemmK& k, int dtype_in, int dtype_out, hipStream
   p.ws = reinterpret_cast<float*>(k.ws_base);
   p.res = nullptr; p.bias = nullptr; p.act = 0;
   constexpr size_t lds = (size_t)2 * (64 + 64) * LDK * 2;
-  if (counters && tiles <= GPV_CONV_TILE_COUNTERS && k.N % 64 == 0) {       // (whole 64-column tiles: the finishing block's quads stay inside its tile)
-    const SplitFin f{counters, k.bias, reinterpret_cast<const bf16*>(k.res), reinterpret_cast<bf16*>(k.C), k.act, split};
-    hipLaunchKernelGGL(conv_split_fused_kernel, dim3(tiles, split, 1), dim3(256), lds, st, p, f);
-    GPV_CHECK_LAUNCH();
-    return 0;
-  }
   hipLaunchKernelGGL((gemm_kernel<bf16, float, OP_CONV, OP_PLAIN, 64, 64, true>), dim3(tiles, split, 1), dim3(256), lds, st, p);
   GPV_CHECK_LAUNCH();
   const int64_t quads = (int64_t)k.M * (k.N / 4);
@@ -1198,7 +1142,7 @@ static int conv2d_impl(const gpv_conv_args* a, hipStream_t st, bool dry) {
       if (a->mode == 0 && a->workspace) {                  // few output pixels, long reduction (inference at batch 1): split + second pass
         GemmK ks = k;
         ks.ws_base = a->workspace; ks.ws_bytes = a->workspace_bytes;
-        const int cs = conv_split_try_launch(ks, a->dtype_in, a->dtype_out, st, reinterpret_cast<unsigned*>(a->tile_counters));
+        const int cs = conv_split_try_launch(ks, a->dtype_in, a->dtype_out, st);
         if (cs >= 0) return cs;
       }
       const int pp = pipe_try_launch(k, OP_CONV, a->dtype_in, a->dtype_out, 1, st);

@@ -44,7 +44,7 @@ class ConvArgs(C.Structure):
                 ('dtype_in', C.c_int), ('dtype_out', C.c_int),
                 ('rowscale', C.c_void_p), ('bias', C.c_void_p), ('res', C.c_void_p), ('relu_mask', C.c_void_p),
                 ('act', C.c_int), ('split_k', C.c_int), ('workspace', C.c_void_p), ('workspace_bytes', C.c_int64),
-                ('y_mask_bits', C.c_void_p), ('relu_mask_bits', C.c_void_p), ('tile_counters', C.c_void_p)]
+                ('y_mask_bits', C.c_void_p), ('relu_mask_bits', C.c_void_p)]
 
 
 class AttnArgs(C.Structure):
@@ -236,21 +236,6 @@ WS_MAX = 256 << 20
 _WS_RETIRED = []          # outgrown workspaces, kept alive for the graphs that captured them
 
 
-SPLIT_FUSED = os.environ.get('GPV_CONV_SPLIT_FUSED', '1') != '0'      # 0: the split forward convolutions as two launches (A/B)
-_COUNTERS = {}
-
-
-def _tile_counters(device):
-    """gpv_conv_args.tile_counters: GPV_CONV_TILE_COUNTERS zero words per (device, stream), zeroed once (every launch leaves them zero)"""
-    key = (device, _raw_stream(torch.cuda.current_device()) if _raw_stream is not None else 0)
-    c = _COUNTERS.get(key)
-    if c is None:
-        if torch.cuda.is_current_stream_capturing():
-            return None                       # (first met inside a capture: this graph keeps the two launches; never the case after a warm-up)
-        c = _COUNTERS[key] = torch.zeros(1024, device=device, dtype=torch.int32)
-    return c
-
-
 def _workspace(device, nbytes):
     """split-reduction scratch (include/gpv_hip.h, gpv_gemm_args.workspace): one buffer per (device, stream), grown on
     demand up to WS_MAX, shared by all launches of that stream.  A launch that would need more gets the buffer as it is
@@ -366,8 +351,6 @@ def conv2d(mode, x, w, y, B, IH, IW, Cs, Cin, OH, OW, Cout, KH, KW, SH, SW, PH, 
         # forward over a few thousand pixels with a long reduction (inference at batch 1): the library may split it
         ws = _workspace(x.device, 16 * B * OH * OW * Cout * 4)
         a.workspace, a.workspace_bytes = _p(ws), ws.numel()
-        if SPLIT_FUSED:
-            a.tile_counters = _p(_tile_counters(x.device))          # ... and finish the split in the same launch
     _chk(lib().gpv_conv2d(C.byref(a), _stream()), 'gpv_conv2d')
 
 

@@ -168,13 +168,7 @@ typedef struct {
      Only the streaming 1x1 kernel serves them: gpv_conv2d_mask_bits_ok() tells whether a call would be served, gpv_conv2d returns
      hipErrorInvalidValue (nothing launched) for one that would not. */
   void* y_mask_bits; const void* relu_mask_bits;
-  /* Round 6, optional: GPV_CONV_TILE_COUNTERS 32-bit words, ZERO before the first launch that uses them and left zero by every launch
-     (one array per stream: launches that may run concurrently must not share it).  With them a forward convolution that splits its
-     reduction through `workspace` (few output pixels: batch-1 inference) finishes in ONE launch -- the last split block of a tile sums
-     the slabs and applies the epilogue -- instead of two; results are bit-identical. */
-  void* tile_counters;
 } gpv_conv_args;
-#define GPV_CONV_TILE_COUNTERS 1024
 int gpv_conv2d(const gpv_conv_args* a, void* stream);
 /* 1 when gpv_conv2d would serve these arguments' y_mask_bits / relu_mask_bits (same checks, nothing launched; pointers must be the real ones:
    alignment counts), else 0 */

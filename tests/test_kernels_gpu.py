@@ -634,41 +634,6 @@ def test_conv_forward_at_batch_one(Cin, Cout, k, s, H, W):
     test_conv_fwd_dgrad_wgrad(torch.bfloat16, Cin, Cout, k, s, k // 2, H, W, Bn=2)
 
 
-@pytest.mark.parametrize('Cin,Cout,H,W,with_res', [(512, 512, 15, 20, False), (256, 256, 30, 40, False), (256, 256, 30, 40, True), (512, 512, 7, 9, True)])
-def test_split_forward_convolution_in_one_launch_equals_the_two_launches(Cin, Cout, H, W, with_res):
-    """Round 6 (gpv_conv_args.tile_counters): the forward 3x3 convolutions of batch-1 inference split their reduction into fp32 slabs; with
-    per-tile counters the LAST split block of a tile sums the slabs and applies bias / residual / ReLU itself (conv_split_fused_kernel)
-    instead of a second launch.  Same additions in the same order: bit-identical; the counters are back at zero after every launch
-    (five launches in a row on the same counters), ragged pixel counts included."""
-    import gpv1_amd.hip as hh
-    h, dtype = hip(), torch.bfloat16
-    x = rnd(1, H, W, Cin, dtype=dtype, seed=80)
-    w = rnd(Cout, 3, 3, Cin, dtype=dtype, seed=81, scale=1.0 / math.sqrt(9 * Cin))
-    bias = rnd(Cout, seed=82)
-    res = rnd(1, H, W, Cout, dtype=dtype, seed=83) if with_res else None
-    outs = {}
-    prev = hh.SPLIT_FUSED
-    try:
-        for fused in (False, True):
-            hh.SPLIT_FUSED = fused
-            ys = []
-            for _ in range(5 if fused else 1):
-                y = torch.full((1, H, W, Cout), float('nan'), device=DEV, dtype=dtype)
-                h.conv2d(0, x, w, y, 1, H, W, Cin, Cin, H, W, Cout, 3, 3, 1, 1, 1, 1, bias=bias, res=res, act=h.ACT_RELU)
-                ys.append(y)
-            torch.cuda.synchronize()
-            outs[fused] = ys
-    finally:
-        hh.SPLIT_FUSED = prev
-    for y in outs[True]:
-        assert torch.equal(y, outs[False][0])
-    cnt = hh._tile_counters(x.device)
-    assert cnt is not None and int(cnt.abs().sum()) == 0
-    ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), padding=1) + bias.view(1, -1, 1, 1)
-    ref = nhwc(ref) + (res.float() if res is not None else 0)
-    assert rel(outs[True][0], F.relu(ref)) < TOL[dtype]
-
-
 @pytest.mark.parametrize('dtype', DTYPES)
 def test_stem_conv_image_prep_and_maxpool(dtype):
     h = hip()

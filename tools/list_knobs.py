@@ -46,7 +46,6 @@ NOTES = {
     'GPV_NO_GRAPHS': 'bench.py: eager steps only',
     'GPV_OVERLAP': 'all-reduce buckets overlapped with the backbone backward (0: after the pass)',
     'GPV_PREP_BRANCH': 'conv weight casts / copies on a branch of F1',
-    'GPV_CONV_SPLIT_FUSED': 'split forward convolutions of batch-1 inference finish in one launch (per-tile counters; 0: slab pass as a second launch)',
     'GPV_MASK_BITS': 'ReLU masks of the layer2 / layer3 block outputs as one bit per element (written by the conv3 launch, read by the next conv1 backward-data)',
     'GPV_PROJ_LN_MIN_ROWS': 'fewest rows for which the projection rides in the LayerNorm launch (below: GEMM + LayerNorm, faster as graph nodes up to ~1200 rows)',
     'GPV_PROJ_LN': 'attention out-projection inside the LayerNorm launch (gpv_linear_layernorm_fwd)',
