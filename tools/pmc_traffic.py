@@ -20,8 +20,11 @@ def load(d, counter):
 
 def is_conv(name):
     n = name.replace('(anonymous namespace)::', '')
-    if 'c1s_kernel' in n and re.search(r', true(, \d+)?>\(', n):      # (round 5: a trailing pass-count argument)      # LIN instances: the K = 256 -> 2048 linear GEMMs of the transformer (gpv_gemm), not convolutions
-        return False
+    m = re.search(r'c1s_kernel<([^>]*)>', n)
+    if m:                               # template arguments <K, NH, RES, MASK, NT, LIN, NP, BITS>: the LIN instances are the K = 256 -> 2048 linear GEMMs of the transformer (gpv_gemm), not convolutions
+        targs = [t.strip() for t in m.group(1).split(',')]
+        if len(targs) > 5 and targs[5] == 'true':
+            return False
     return (('gemm_kernel' in n and 'Li2ELi0E' in n) or ('gemm_kernel<' in n and ', 1, 2, ' in n) or 'glds_kernelILi2E' in n or 'conv1x1_kernel' in n
             or 'glds_wgrad_kernel' in n or 'pipe_kernelILi2E' in n or 'c1s_kernel' in n or 'conv1x1_nt_kernel' in n
             or 'c3r_kernel' in n or 'c3d2_kernel' in n or 'c1d_kernel' in n or 'c1c_kernel' in n or 'stem_pool_kernel' in n or 'glds_wgrad_group_kernel' in n or 'wg8_group_kernel' in n or 'wg8h_group_kernel' in n or 'glds_halo_kernel' in n)
