@@ -19,6 +19,8 @@ import torch.nn as nn
 from . import hip, ops
 from .transformer import LinearP, LayerNormP
 
+BERT_NO_PIPE_SMALL = os.environ.get('GPV_BERT_NO_PIPE_SMALL', '1') != '0'
+
 
 class WordPieceTokenizer:
     """bert-base-uncased BasicTokenizer (lower-case, strip accents, split punctuation) + greedy
@@ -201,6 +203,15 @@ class BertModel(nn.Module):
 
     @torch.no_grad()
     def forward(self, input_ids, attention_mask):
+        # The frozen BERT's GEMMs (B x T = 192 rows in the training step) are nodes of a dependent chain on their graph branch: timed that way
+        # (tools/tune_gemms.py --chain) they are 1.4 - 2.7 us shorter WITHOUT gemm_pipe.hip's small-M configurations (7.4 -> 4.7 us for
+        # 192 x 768 x 768; back-to-back stream launches, which overlap their ramps, had preferred them): 96 us less on the branch per step
+        if BERT_NO_PIPE_SMALL and input_ids.is_cuda:
+            with hip.gemm_flags(hip.GEMM_NO_PIPE_SMALL):
+                return self._forward(input_ids, attention_mask)
+        return self._forward(input_ids, attention_mask)
+
+    def _forward(self, input_ids, attention_mask):
         B, T = input_ids.shape
         D, H = self.hidden, self.heads
         p = self.p if self.training else 0.0

@@ -426,7 +426,7 @@ int c1s_try_launch(const GemmK& k, int dtype_in, int dtype_out, hipStream_t st, 
   if (k.lda % 8 || k.ldb != k.K || k.ldc % 8 || (k.res && k.ldr % 8) || (k.mask && k.ldm % 8)) return -1;
   if (!al16s(k.A) || !al16s(k.B) || !al16s(k.C) || (k.res && !al16s(k.res)) || (k.mask && !al16s(k.mask))) return -1;
   if (linear) {      // gpv_gemm: 256 -> 2048 features over >= 2048 rows (the DETR feed-forward; tools/bench_c1s_linear.py: 1024 / 1536 outputs are faster on the tile kernels)
-    if (mode == 1 && (k.K != 256 || k.N < 2048 || k.M < 2048)) return -1;
+    if (mode == 1 && (k.K != 256 || k.N < 1536 || k.M < 2048)) return -1;      // (1536: as graph nodes 20.8 against 26.8 us at 9600 rows, tools/tune_gemms.py --chain; 1024 stays on the tile kernels)
   } else if (mode == 1 && ((int64_t)k.M * nsl < 65536 || k.M < 32768)) return -1;   // a streaming regime needs rows (x slices): the layer1-3 maps at training batch sizes
   if (k.mask_bits || k.out_bits) {
     // instances that exist with mask bits (c1s_flags) -- decided here so that a dry run (gpv_conv2d_mask_bits_ok) answers what a launch would do

@@ -447,7 +447,9 @@ int c3s_try_launch(const GemmK& k, int dtype_in, int dtype_out, hipStream_t st) 
   // input extent addressed with 32-bit byte offsets (dgrad: the "input" is dy)
   const int64_t in_px = (int64_t)(k.M / (g.OH * g.OW)) * g.IH * g.IW;
   if (in_px * g.Cs * 2 >= (int64_t)C3_OOB) return -1;
-  if (mode == 1 && k.M < 65536) return -1;          // a streaming regime needs rows: the layer1 / layer2 maps at training batch sizes
+  // a streaming regime needs rows: the layer1 / layer2 maps at training batch sizes -- and layer1's 64-channel map of ONE image (19200
+  // pixels, forward): 12.4 us as a graph node against 15.2 for the 64 x 64 tile kernel (tools/bench_c3_bs1.py); layer2's 4800 pixels: 20.9 against 18.2
+  if (mode == 1 && k.M < 65536 && !(g.Cin == 64 && !g.dgrad && k.M >= 16384)) return -1;
   int e;
   if (d2) e = k.mask ? c3d2_launch<128, true>(k, st) : c3d2_launch<128, false>(k, st);
   else e = g.Cin == 64 ? c3r_mode<64>(k, g.dgrad != 0, st) : c3r_mode<128>(k, g.dgrad != 0, st);

@@ -20,6 +20,7 @@ NOTES = {
     'GPV_ATTN_SPLIT': 'query tiles of one (image, head) split over several workgroups (few-head shapes)',
     'GPV_BERT_VOCAB': 'path of bert-base-uncased vocab.txt (string queries)',
     'GPV_BERT_WEIGHTS': 'path of the frozen BERT weights (.bin / .safetensors); random init without',
+    'GPV_BERT_NO_PIPE_SMALL': 'the frozen BERT branch without gemm_pipe.hip small-M configurations (shorter as dependent graph nodes)',
     'GPV_BOUNDARY': 'roi: RoI features from the DETR decoder output (the reference); other values are debugging cuts',
     'GPV_C1C_BLOCKS': 'workgroups of the chained 1x1 kernel (0: heuristic)',
     'GPV_C1S': 'streaming 1x1 policy: 0 never, 1 heuristic, 2 wherever legal (-1: leave the default)',

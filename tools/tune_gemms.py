@@ -3,8 +3,30 @@ dispatch is not the fastest.   usage (GPU box): python tools/tune_gemms.py [shap
 import os, sys, json, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import gpv1_amd.hip as hip
-from bench_attn import timeit
+from bench_attn import timeit as _timeit
 dev = 'cuda'
+CHAIN = '--chain' in sys.argv          # round 6: time every candidate as a chain of dependent hipGraph nodes (what a launch costs INSIDE the step's graphs:
+if CHAIN:                              # ramp + tail + node boundary) instead of back-to-back stream launches (throughput: launches overlap their ramps)
+    sys.argv.remove('--chain')
+
+
+def _chain(f, n=50):
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        f(); torch.cuda.synchronize()
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr, stream=st):
+            for _ in range(n):
+                f()
+        best = 1e9
+        for _ in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(st); gr.replay(); e1.record(st); torch.cuda.synchronize()
+            best = min(best, e0.elapsed_time(e1))
+    return best * 1000.0 / n
+
+
+timeit = _chain if CHAIN else _timeit
 path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.abspath(__file__)), 'gemm_shapes_step.json')
 rows = json.load(open(path))
 FAM = [('pipe off', hip.OPT_PIPE, 0)] + [('pipe cfg %d' % i, hip.OPT_PIPE, 100 + i) for i in range(8)] + \
