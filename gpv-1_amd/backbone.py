@@ -233,6 +233,13 @@ def _block_tail_chain(x, a2, blk, nxt, tr_next):
             hit = RT.cache[key] = (RT.static_epoch, (s3 + sd).contiguous())
         ok = hip.conv1x1_chain(a2, w3, x, wd, 1, None, hit[1], yb, wn, sn, an, B, OH, OW)
     else:
+        if tr_next and MASK_BITS and c1n.cout == 128 and x.is_cuda:
+            # layer2.0's conv1 output is the ReLU mask of that block's stride-2 3x3 backward-data (157 MB as bf16 at B = 32): its bits ride here
+            mb = torch.empty(B * OH * OW, c1n.cout // 32, device=x.device, dtype=torch.int32)
+            if hip.conv1x1_chain(a2, w3, None, None, 1, x, s3, yb, wn, sn, an, B, OH, OW, z_mask_bits=mb):
+                an._gpv_bits = mb
+                return yb, an
+            del mb
         ok = hip.conv1x1_chain(a2, w3, None, None, 1, x, s3, yb, wn, sn, an, B, OH, OW)
     return (yb, an) if ok else None
 
@@ -247,7 +254,7 @@ def _conv_dgrad(dy, conv, bn, xshape, res=None, relu_mask=None):
     mb = getattr(relu_mask, '_gpv_bits', None) if relu_mask is not None else None
     if mb is not None and MASK_BITS:
         kw = dict(res=res, relu_mask_bits=mb)
-        if _bits_ok(('d', B, H, Wd, Cin, Cout, res is not None, hip.get_option_cached(hip.OPT_C1S)), args, kw):
+        if _bits_ok(('d', B, H, Wd, Cin, Cout, conv.k, conv.stride, res is not None, hip.get_option_cached(hip.OPT_C1S), hip.get_option_cached(hip.OPT_C3S)), args, kw):
             hip.conv2d(*args, **kw)          # the mask as one bit per element, written by the forward launch that produced relu_mask
             return dx
     hip.conv2d(*args, res=res, relu_mask=relu_mask)

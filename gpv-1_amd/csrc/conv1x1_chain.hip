@@ -24,6 +24,7 @@ struct ChainK {
   int M;                          // output pixels
   int OH, OW, IH2, IW2, S2;       // a2's spatial extent and stride (a1 has the output's)
   int nt;
+  void* zbits;                    // round 6: (z > 0) as one bit per element, N2 = 128: bit c & 7 of byte 4 ((c % 32) / 8) + c / 32 of the pixel's 16 (gpv_conv_args.y_mask_bits' order for 128 channels), or NULL
 };
 
 template <int NH>
@@ -33,7 +34,7 @@ __device__ __forceinline__ int c1c_chan(int L) {      // (conv1x1_stream.hip c1s
 }
 
 // K1 = 64 channels of a1 (+ K2 = 64 of a2: the downsample branch of a stage's first block), N = 256, N2 = 64 | 128
-template <int K1, int K2, int N2, bool RES>
+template <int K1, int K2, int N2, bool RES, bool BITS = false>
 __global__ __launch_bounds__(512) void c1c_kernel(ChainK p) {
   constexpr int N = 256, KT = K1 + K2, KP = KT + 8, KC1 = K1 / 32, KC = KT / 32, NTL = N / 16, NG = N / 32, SL1 = K1 / 8, SL = KT / 8;
   constexpr int KP2 = N + 8, NTL2 = N2 / 16, NG2 = N2 / 32, SL2 = N / 8;
@@ -146,6 +147,7 @@ __global__ __launch_bounds__(512) void c1c_kernel(ChainK p) {
         acc2[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, o, acc2[j], 0, 0, 0);
       }
     }
+    uint32_t zb = 0u;
 #pragma unroll
     for (int u = 0; u < NG2; ++u) {
       const int c0 = u * 32 + g * 8;
@@ -156,15 +158,33 @@ __global__ __launch_bounds__(512) void c1c_kernel(ChainK p) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) o[e] = (bf16)fmaxf(v[e], 0.f);
       if (pok) *reinterpret_cast<bf16x8*>(Z + (int64_t)px * N2 + c0) = o;
+      if constexpr (BITS) {
+        // (z > 0) of the stored bf16 values, eight into a byte (conv1x1_stream.hip: packed min / max as inline asm, byte permute, 4 x 8-bit dot)
+        const u32x4 ow = __builtin_bit_cast(u32x4, o);
+        const uint32_t one2 = 0x00010001u, zero2 = 0u;
+        uint32_t mq[4];
+#pragma unroll
+        for (int q2 = 0; q2 < 4; ++q2) {
+          uint32_t tq;
+          asm("v_pk_min_i16 %0, %1, %2" : "=v"(tq) : "v"(ow[q2]), "v"(one2));
+          asm("v_pk_max_i16 %0, %1, %2" : "=v"(mq[q2]) : "v"(tq), "v"(zero2));
+        }
+        const uint32_t b03 = __builtin_amdgcn_perm(mq[1], mq[0], 0x06040200u), b47 = __builtin_amdgcn_perm(mq[3], mq[2], 0x06040200u);
+        zb |= (__builtin_amdgcn_udot4(b03, 0x08040201u, 0u, false) | (__builtin_amdgcn_udot4(b47, 0x08040201u, 0u, false) << 4)) << (u * 8);
+      }
+    }
+    if constexpr (BITS) {
+      static_assert(!BITS || NG2 == 4, "mask bits: the 128-channel conv1 of layer2.0");
+      if (pok) *reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(p.zbits) + (int64_t)px * (N2 / 8) + g * 4) = zb;
     }
   }
 }
 
-template <int K1, int K2, int N2, bool RES>
+template <int K1, int K2, int N2, bool RES, bool BITS = false>
 int c1c_launch(const ChainK& p, hipStream_t st) {
   constexpr int N = 256;
   const size_t lds = (size_t)N * (K1 + K2 + 8) * 2 + (size_t)N2 * (N + 8) * 2 + (size_t)(N + N2) * sizeof(float);
-  auto fn = c1c_kernel<K1, K2, N2, RES>;
+  auto fn = c1c_kernel<K1, K2, N2, RES, BITS>;
   static bool attr = false;
   if (!attr) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -191,8 +211,18 @@ int c1c_launch(const ChainK& p, hipStream_t st) {
 extern "C" int gpv_conv1x1_chain(const void* a1, const void* w1, int K1, const void* a2, const void* w2, int K2, int IH2, int IW2, int s2,
                                  const void* res, const float* bias, void* y, int B, int OH, int OW, int N, const void* wn,
                                  const float* bias_n, void* z, int N2, void* stream) {
+  return gpv_conv1x1_chain_bits(a1, w1, K1, a2, w2, K2, IH2, IW2, s2, res, bias, y, B, OH, OW, N, wn, bias_n, z, N2, nullptr, stream);
+}
+
+// + z_mask_bits (or NULL): (z > 0) as one bit per element (gpv_conv_args.y_mask_bits' layout for 128 channels); the identity-branch form with
+// N2 = 128 only (layer1's last tail + layer2.0's conv1, whose output is the ReLU mask of layer2.0's stride-2 3x3 backward-data): 801 otherwise
+extern "C" int gpv_conv1x1_chain_bits(const void* a1, const void* w1, int K1, const void* a2, const void* w2, int K2, int IH2, int IW2, int s2,
+                                      const void* res, const float* bias, void* y, int B, int OH, int OW, int N, const void* wn,
+                                      const float* bias_n, void* z, int N2, void* z_mask_bits, void* stream) {
   using namespace gpvk;
   if (!a1 || !w1 || !y || !wn || !z || B <= 0) return (int)hipErrorInvalidValue;
+  if (z_mask_bits && (K2 != 0 || !res || N2 != 128)) return (int)hipErrorNotSupported;
+  if (reinterpret_cast<uintptr_t>(z_mask_bits) & 15) return (int)hipErrorInvalidValue;
   if (K1 != 64 || N != 256 || (K2 != 0 && K2 != 64) || (N2 != 64 && N2 != 128)) return (int)hipErrorNotSupported;
   if ((K2 != 0) != (a2 != nullptr && w2 != nullptr) || (K2 != 0 && res != nullptr)) return (int)hipErrorInvalidValue;
   if (K2 != 0 && ((s2 != 1 && s2 != 2) || (OH - 1) * s2 >= IH2 || (OW - 1) * s2 >= IW2)) return (int)hipErrorInvalidValue;
@@ -205,6 +235,8 @@ extern "C" int gpv_conv1x1_chain(const void* a1, const void* w1, int K1, const v
   p.nt = (int64_t)p.M * N * 2 >= ((int64_t)200 << 20);          // outputs beyond the 256 MB MALL are stored (and their residual read) non-temporally
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (K2 == 64) return N2 == 64 ? c1c_launch<64, 64, 64, false>(p, st) : c1c_launch<64, 64, 128, false>(p, st);
+  p.zbits = z_mask_bits;
+  if (z_mask_bits) return c1c_launch<64, 0, 128, true, true>(p, st);
   if (res) return N2 == 64 ? c1c_launch<64, 0, 64, true>(p, st) : c1c_launch<64, 0, 128, true>(p, st);
   return N2 == 64 ? c1c_launch<64, 0, 64, false>(p, st) : c1c_launch<64, 0, 128, false>(p, st);
 }

@@ -262,7 +262,9 @@ int c3r_launch(const GemmK& k, hipStream_t st) {
 // 2y, 2y+1 (1 + 2 + 2 + 4 = 9 tap products, 31 of the 32 columns: lane 31 only lends its column to lane 30's odd outputs).  The
 // tile kernels ran this launch (layer2.0 conv2, B = 32) at 213 us by parity-class tiles with gathered rows; its bytes (dy 39 MB,
 // mask + dx 2 x 157 MB) take 56 us at the measured 6.3 TB/s.
-template <int CIN, bool MASK, int WAVES>
+// BITS (round 6): the ReLU mask as one bit per element (gpv_conv_args.relu_mask_bits, 128 channels: bit c & 7 of byte 4 ((c % 32) / 8) + c / 32
+// of the pixel's 16 bytes): ONE 16-byte load per output pixel and lane instead of four.
+template <int CIN, bool MASK, int WAVES, bool BITS = false>
 __global__ __launch_bounds__(WAVES * 64) void c3d2_kernel(GemmK p, int rows_per_item, int nstrip, int nseg, int nitems) {
   constexpr int KTOT = 9 * CIN, KP = KTOT + 8, KCN = CIN / 16, SWD = 31;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -319,8 +321,15 @@ __global__ __launch_bounds__(WAVES * 64) void c3d2_kernel(GemmK p, int rows_per_
           const int y = y0 + j0 + jj;
           // four parity tiles: (py, px); taps of tile = {r in R(py)} x {s in S(px)}; r = 1 | {2, 0} reads slot jj | {jj, jj ^ 1}
           // the ReLU masks of all four tiles are requested up front: the first tile has only 16 MFMAs to hide an HBM read behind
-          bf16x8 mv[MASK ? 16 : 1];
-          if constexpr (MASK) {
+          bf16x8 mv[(MASK && !BITS) ? 16 : 1];
+          u32x4 mbits[(MASK && BITS) ? 4 : 1];
+          if constexpr (MASK && BITS) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              const int opix = (b * g.OH + 2 * y + (t >> 1)) * g.OW + 2 * xd + (t & 1);
+              mbits[t] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(p.mask_bits) + (int64_t)(cok ? opix : 0) * 16);
+            }
+          } else if constexpr (MASK) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
               const int opix = (b * g.OH + 2 * y + (t >> 1)) * g.OW + 2 * xd + (t & 1);
@@ -372,7 +381,12 @@ __global__ __launch_bounds__(WAVES * 64) void c3d2_kernel(GemmK p, int rows_per_
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                   float x = acc[nt][hi * 8 + e];
-                  if constexpr (MASK) x = (float)mv[t * 4 + c][e] > 0.f ? x : 0.f;
+                  if constexpr (MASK && BITS) {
+                    // channels cbase + 32 nt + 16 hi + 8 h .. + 7: byte 4 (2 hi + h) + cbase / 32 + nt of the pixel's 16
+                    const int bidx = 4 * (2 * hi + h) + (cbase >> 5) + nt;
+                    const uint32_t wsel = (bidx >> 2) == 0 ? mbits[t][0] : ((bidx >> 2) == 1 ? mbits[t][1] : ((bidx >> 2) == 2 ? mbits[t][2] : mbits[t][3]));
+                    x = ((wsel >> ((bidx & 3) * 8 + e)) & 1u) ? x : 0.f;
+                  } else if constexpr (MASK) x = (float)mv[t * 4 + c][e] > 0.f ? x : 0.f;
                   o[e] = (bf16)x;
                 }
                 c3_store16(Y + (int64_t)opix * p.ldc + nt * 32 + hi * 16 + h * 8, o);
@@ -386,11 +400,11 @@ __global__ __launch_bounds__(WAVES * 64) void c3d2_kernel(GemmK p, int rows_per_
   }
 }
 
-template <int CIN, bool MASK>
+template <int CIN, bool MASK, bool BITS = false>
 int c3d2_launch(const GemmK& k, hipStream_t st) {
   constexpr int WAVES = 8, KP = 9 * CIN + 8;
   const size_t lds = (size_t)C3_NSL * KP * 2;
-  auto fn = c3d2_kernel<CIN, MASK, WAVES>;
+  auto fn = c3d2_kernel<CIN, MASK, WAVES, BITS>;
   static bool attr = false;
   if (!attr) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -431,7 +445,7 @@ long g_c3s_launches = 0;
 
 // k: the GemmK gpv_conv2d prepared for the implicit-GEMM path (A = input pixels, B = [N][9][Cin] weights, cg = geometry).
 // 0 = launched, -1 = not applicable, > 0 = hipError_t
-int c3s_try_launch(const GemmK& k, int dtype_in, int dtype_out, hipStream_t st) {
+int c3s_try_launch(const GemmK& k, int dtype_in, int dtype_out, hipStream_t st, bool dry) {
   static const int env = tune_env("GPV_C3S", -1);
   const int mode = env >= 0 ? env : g_c3s_mode;
   const ConvGeom& g = k.cg;
@@ -450,8 +464,11 @@ int c3s_try_launch(const GemmK& k, int dtype_in, int dtype_out, hipStream_t st) 
   // a streaming regime needs rows: the layer1 / layer2 maps at training batch sizes -- and layer1's 64-channel map of ONE image (19200
   // pixels, forward): 12.4 us as a graph node against 15.2 for the 64 x 64 tile kernel (tools/bench_c3_bs1.py); layer2's 4800 pixels: 20.9 against 18.2
   if (mode == 1 && k.M < 65536 && !(g.Cin == 64 && !g.dgrad && k.M >= 16384)) return -1;
+  if (k.out_bits || (k.mask_bits && !(d2 && k.N == 128 && (reinterpret_cast<uintptr_t>(k.mask_bits) & 15) == 0))) return -1;      // mask bits: the stride-2 backward-data over 128 channels only
+  if (dry) return 0;
   int e;
-  if (d2) e = k.mask ? c3d2_launch<128, true>(k, st) : c3d2_launch<128, false>(k, st);
+  if (d2 && k.mask_bits) e = c3d2_launch<128, true, true>(k, st);
+  else if (d2) e = k.mask ? c3d2_launch<128, true>(k, st) : c3d2_launch<128, false>(k, st);
   else e = g.Cin == 64 ? c3r_mode<64>(k, g.dgrad != 0, st) : c3r_mode<128>(k, g.dgrad != 0, st);
   if (e == 0) ++g_c3s_launches;
   return e;

@@ -1040,8 +1040,10 @@ static int conv2d_impl(const gpv_conv_args* a, hipStream_t st, bool dry) {
   const bool want_bits = a->y_mask_bits != nullptr || a->relu_mask_bits != nullptr;
   if (want_bits) {
     // one-bit ReLU masks: the streaming 1x1 kernel only (stride 1, pointwise), forward with ReLU writes them, backward-data reads them
-    if (a->KH != 1 || a->KW != 1 || a->SH != 1 || a->SW != 1 || a->PH != 0 || a->PW != 0 || a->IH != a->OH || a->IW != a->OW) return (int)hipErrorInvalidValue;
-    if (a->Cout % 256 != 0 || (a->y_mask_bits && (a->mode != 0 || a->act != GPV_ACT_RELU || a->relu_mask)) || (a->relu_mask_bits && a->mode != 1)) return (int)hipErrorInvalidValue;
+    const bool pw1 = a->KH == 1 && a->KW == 1 && a->SH == 1 && a->SW == 1 && a->PH == 0 && a->PW == 0 && a->IH == a->OH && a->IW == a->OW;
+    const bool d3s2 = a->mode == 1 && a->KH == 3 && a->KW == 3 && a->SH == 2 && a->SW == 2 && a->PH == 1 && a->PW == 1 && a->Cout == 128 && !a->y_mask_bits;
+    if (!pw1 && !d3s2) return (int)hipErrorInvalidValue;
+    if ((pw1 && a->Cout % 256 != 0) || (a->y_mask_bits && (a->mode != 0 || a->act != GPV_ACT_RELU || a->relu_mask)) || (a->relu_mask_bits && a->mode != 1)) return (int)hipErrorInvalidValue;
     if ((reinterpret_cast<uintptr_t>(a->y_mask_bits) | reinterpret_cast<uintptr_t>(a->relu_mask_bits)) & 15) return (int)hipErrorInvalidValue;
   } else if (dry) {
     return (int)hipErrorInvalidValue;
@@ -1132,6 +1134,14 @@ static int conv2d_impl(const gpv_conv_args* a, hipStream_t st, bool dry) {
                          reinterpret_cast<const bf16*>(a->res), reinterpret_cast<const bf16*>(a->relu_mask), chunks, a->OW, a->OH, C8);
       GPV_CHECK_LAUNCH();
       return 0;
+    }
+    if (want_bits) {
+      // (not the pointwise form, which returned above: the stride-2 3x3 backward-data over 128 channels on the streaming kernel, or nothing)
+      if (!(a->KH == 3 && a->KW == 3 && k.vecA && k.vecB)) return (int)hipErrorInvalidValue;
+      k.mask_bits = reinterpret_cast<const uint32_t*>(a->relu_mask_bits);
+      k.mask = a->relu_mask_bits; k.ldm = a->Cout;
+      const int c3 = c3s_try_launch(k, a->dtype_in, a->dtype_out, st, dry);
+      return c3 >= 0 ? c3 : (int)hipErrorInvalidValue;
     }
     if (a->KH == 3 && a->KW == 3 && k.vecA && k.vecB) {
       // 3x3 with 64 / 128 input channels over the layer1 / layer2 maps: weights resident in LDS, barrier-free streaming kernel

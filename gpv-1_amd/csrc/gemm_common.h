@@ -68,7 +68,7 @@ extern long g_c1s_launches;
 // conv3x3_stream.hip: streaming kernel for the 3x3 convolutions with 64 / 128 input channels over >= 65536 output pixels (weights
 // of 64 output channels resident in LDS, a wave per 32 pixels, 32x32x16 MFMA, no barriers): forward, backward-data stride 1 and
 // the stride-2 backward-data parity classes.  Same return convention; tried first on the 3x3 path.
-int c3s_try_launch(const GemmK& k, int dtype_in, int dtype_out, hipStream_t st);
+int c3s_try_launch(const GemmK& k, int dtype_in, int dtype_out, hipStream_t st, bool dry = false);
 extern int g_c3s_mode;
 extern long g_c3s_launches;
 

@@ -106,7 +106,7 @@ def lib():
     return _LIB
 
 
-EXPORTS = ['gpv_abi_version', 'gpv_build_id', 'gpv_set_option', 'gpv_gemm', 'gpv_conv2d', 'gpv_conv2d_mask_bits_ok', 'gpv_conv1x1_dual_bits', 'gpv_image_to_nhwc4', 'gpv_maxpool3x3s2',
+EXPORTS = ['gpv_abi_version', 'gpv_build_id', 'gpv_set_option', 'gpv_gemm', 'gpv_conv2d', 'gpv_conv2d_mask_bits_ok', 'gpv_conv1x1_dual_bits', 'gpv_conv1x1_chain_bits', 'gpv_image_to_nhwc4', 'gpv_maxpool3x3s2',
            'gpv_attention_fwd', 'gpv_attention_bwd', 'gpv_attention_qkv_fwd', 'gpv_layernorm_fwd', 'gpv_layernorm_bwd', 'gpv_layernorm_pos_fwd', 'gpv_layernorm_bwd2', 'gpv_linear_layernorm_fwd',
            'gpv_softmax_ce', 'gpv_roi_weights', 'gpv_add', 'gpv_add_rowbcast', 'gpv_colsum', 'gpv_cast',
            'gpv_cast_rowscale_t', 'gpv_prep_conv_weight', 'gpv_embedding', 'gpv_dropout',
@@ -537,17 +537,23 @@ def conv1x1_dual(a1, w1, a2, w2, bias, y, B, OH, OW, K1, IH2, IW2, K2, s2, N, ac
     return True
 
 
-def conv1x1_chain(a1, w1, a2, w2, s2, res, bias, y, wn, bias_n, z, B, OH, OW):
-    """gpv_conv1x1_chain: y = relu(a1 . w1^T (+ a2[::s2] . w2^T) (+ res) + bias), z = relu(y . wn^T + bias_n) in one launch; False when
-    the shape is not one the kernel takes -- the caller then runs the convolutions one by one"""
+def conv1x1_chain(a1, w1, a2, w2, s2, res, bias, y, wn, bias_n, z, B, OH, OW, z_mask_bits=None):
+    """gpv_conv1x1_chain(_bits): y = relu(a1 . w1^T (+ a2[::s2] . w2^T) (+ res) + bias), z = relu(y . wn^T + bias_n) in one launch (+ the
+    one-bit ReLU mask of z); False when the shape is not one the kernel takes -- the caller then runs the convolutions one by one"""
     ts = [t for t in (a1, w1, a2, w2, res, y, wn, z) if t is not None]
     if not all(t.dtype == torch.bfloat16 for t in ts):
         return False
     K1, N, N2 = a1.shape[-1], y.shape[-1], z.shape[-1]
     K2 = 0 if a2 is None else a2.shape[-1]
     IH2, IW2 = (a2.shape[1], a2.shape[2]) if a2 is not None else (OH, OW)
-    err = lib().gpv_conv1x1_chain(_p(a1), _p(w1), K1, _p(a2), _p(w2), K2, IH2, IW2, s2, _p(res), _p(_f32(bias)), _p(y), B, OH, OW, N,
-                                  _p(wn), _p(_f32(bias_n)), _p(z), N2, _stream())
+    if z_mask_bits is not None:
+        if z_mask_bits.dtype != torch.int32 or not z_mask_bits.is_contiguous() or z_mask_bits.numel() * 32 != B * OH * OW * N2:
+            raise TypeError('conv1x1_chain: mask bits are a contiguous int32 [pixels, N2 / 32] tensor')
+        err = lib().gpv_conv1x1_chain_bits(_p(a1), _p(w1), K1, _p(a2), _p(w2), K2, IH2, IW2, s2, _p(res), _p(_f32(bias)), _p(y), B, OH, OW, N,
+                                           _p(wn), _p(_f32(bias_n)), _p(z), N2, _p(z_mask_bits), _stream())
+    else:
+        err = lib().gpv_conv1x1_chain(_p(a1), _p(w1), K1, _p(a2), _p(w2), K2, IH2, IW2, s2, _p(res), _p(_f32(bias)), _p(y), B, OH, OW, N,
+                                      _p(wn), _p(_f32(bias_n)), _p(z), N2, _stream())
     if err == 801:
         return False
     _chk(err, 'gpv_conv1x1_chain')

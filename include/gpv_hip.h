@@ -163,10 +163,13 @@ typedef struct {
      of a bottleneck (157 MB per layer2 block at B = 32: a third of such a launch's bytes).  Both: Cout / 8 bytes per pixel, Cout a multiple
      of 256, (y[pixel, c] > 0) of the bf16 value as stored = bit (c & 7) of byte  32 (c / 256) + 8 ((c % 32) / 8) + (c % 256) / 32  of the pixel's
      row (the streaming kernel's accumulator order inside a 256-channel group: neither side needs a cross-lane operation); 16-byte aligned.
+     Cout = 128 (the stride-2 3x3 backward-data of layer2's first block reads them; gpv_conv1x1_chain_bits writes them): 16 bytes per pixel,
+     bit (c & 7) of byte  4 ((c % 32) / 8) + c / 32.
        y_mask_bits    (mode 0, act = GPV_ACT_RELU): the launch ALSO writes the bits of its output;
        relu_mask_bits (mode 1): read INSTEAD of relu_mask (relu_mask may then be NULL); results are bit-identical to the bf16 mask's.
-     Only the streaming 1x1 kernel serves them: gpv_conv2d_mask_bits_ok() tells whether a call would be served, gpv_conv2d returns
-     hipErrorInvalidValue (nothing launched) for one that would not. */
+     Only the streaming kernels serve them (pointwise stride-1 forward / backward-data; relu_mask_bits also the 3x3 stride-2 backward-data
+     over 128 channels): gpv_conv2d_mask_bits_ok() tells whether a call would be served, gpv_conv2d returns hipErrorInvalidValue (nothing
+     launched) for one that would not. */
   void* y_mask_bits; const void* relu_mask_bits;
 } gpv_conv_args;
 int gpv_conv2d(const gpv_conv_args* a, void* stream);
@@ -267,6 +270,11 @@ int gpv_conv1x1_dual_bits(const void* a1, const void* w1, const void* a2, const 
 int gpv_conv1x1_chain(const void* a1, const void* w1, int K1, const void* a2, const void* w2, int K2, int IH2, int IW2, int s2,
                       const void* res, const float* bias, void* y, int B, int OH, int OW, int N, const void* wn,
                       const float* bias_n, void* z, int N2, void* stream);
+/* the same launch, also writing z_mask_bits = (z > 0) as one bit per element (gpv_conv_args.y_mask_bits' layout for 128 channels; round 6):
+ * the identity-branch form with N2 = 128 only (layer1's last tail + layer2.0's conv1) -- 801 otherwise, nothing launched; NULL is gpv_conv1x1_chain */
+int gpv_conv1x1_chain_bits(const void* a1, const void* w1, int K1, const void* a2, const void* w2, int K2, int IH2, int IW2, int s2,
+                      const void* res, const float* bias, void* y, int B, int OH, int OW, int N, const void* wn,
+                      const float* bias_n, void* z, int N2, void* z_mask_bits, void* stream);
 #ifdef GPV_TUNING
 /* TUNING BUILD ONLY (libgpv_hip_tuning.so, `make -C gpv-1_amd/csrc tuning`; not part of the production ABI): built, correct and not faster
  * than the three launches it replaces -- DESIGN.md section 0 / 8 -- kept compilable for the next attempt. */

@@ -241,7 +241,7 @@ def conv1x1_dual(a1, w1, a2, w2, bias, y, B, OH, OW, K1, IH2, IW2, K2, s2, N, ac
     return False                       # (bf16 kernel only: the CPU emulation runs the two convolutions)
 
 
-def conv1x1_chain(a1, w1, a2, w2, s2, res, bias, y, wn, bias_n, z, B, OH, OW):
+def conv1x1_chain(a1, w1, a2, w2, s2, res, bias, y, wn, bias_n, z, B, OH, OW, z_mask_bits=None):
     return False                       # (bf16 kernel only: the CPU emulation runs the convolutions one by one)
 
 

@@ -1760,6 +1760,51 @@ def test_conv1x1_chain_equals_the_two_launches(branch, N2, OH, OW, Bn):
     assert rel(z, F.relu(y.float() @ wn.float().t() + bn_)) < TOL[dtype]
     a32 = a[..., :32].contiguous()
     assert not h.conv1x1_chain(a32, w3[:, :32].contiguous(), None, None, 1, None, b3, y, wn, bn_, z, Bn, OH, OW)
+    # round 6: the identity-branch launch with a 128-channel conv1 also writes the one-bit ReLU mask of z (gpv_conv1x1_chain_bits)
+    px = Bn * OH * OW
+    bits = torch.full((px + 2, N2 // 32), 0x5a5a5a5a, device=DEV, dtype=torch.int32)
+    y3, z3 = torch.full_like(y, float('nan')), torch.full_like(z, float('nan'))
+    xa = x if branch == 'identity' else None
+    a2_, w2_ = (x, wd) if branch == 'downsample' else (None, None)
+    took = h.conv1x1_chain(a, w3, a2_, w2_, 1, xa, b3, y3, wn, bn_, z3, Bn, OH, OW, z_mask_bits=bits[:px])
+    assert took == (branch == 'identity' and N2 == 128)
+    torch.cuda.synchronize()
+    if took:
+        assert torch.equal(y3, y) and torch.equal(z3, z)
+        assert torch.equal(bits[:px], _pack_bits(z3.view(-1, N2))) and (bits[px:] == 0x5a5a5a5a).all()
+    else:
+        assert (bits == 0x5a5a5a5a).all()
+
+
+@pytest.mark.parametrize('Bn,OH,OW', [(2, 16, 24), (1, 9, 33), (3, 30, 40)])
+def test_stride2_3x3_backward_data_reads_one_bit_relu_masks(Bn, OH, OW):
+    """Round 6: layer2.0's conv2 backward-data (3x3 stride 2 over 128 channels, conv3x3_stream.hip c3d2_kernel) with its ReLU mask as one
+    bit per element (the bits gpv_conv1x1_chain_bits wrote with the activation) against the same launch with the bf16 activation: bit-identical."""
+    h, dtype = hip(), torch.bfloat16
+    C = 128
+    IH, IW = 2 * OH, 2 * OW                                    # dx extent; dy is OH x OW
+    dy = rnd(Bn, OH, OW, C, dtype=dtype, seed=320)
+    wd = rnd(C, 3, 3, C, dtype=dtype, seed=321, scale=1.0 / math.sqrt(9 * C))
+    act = torch.relu(rnd(Bn, IH, IW, C, dtype=dtype, seed=322))
+    act[:, ::3, ::5, ::7] = -0.0
+    bits = _pack_bits(act.view(-1, C))
+    prev = h.set_option(h.OPT_C3S, 2)
+    try:
+        d0 = torch.empty(Bn, IH, IW, C, device=DEV, dtype=dtype)
+        h.set_option(h.OPT_C3S_LAUNCHES, 0)
+        h.conv2d(1, dy, wd, d0, Bn, OH, OW, C, C, IH, IW, C, 3, 3, 2, 2, 1, 1, relu_mask=act)
+        d1 = torch.full_like(d0, float('nan'))
+        args = (1, dy, wd, d1, Bn, OH, OW, C, C, IH, IW, C, 3, 3, 2, 2, 1, 1)
+        assert h.conv2d_mask_bits_ok(*args, relu_mask_bits=bits)
+        h.conv2d(*args, relu_mask_bits=bits)
+        torch.cuda.synchronize()
+        assert h.set_option(h.OPT_C3S_LAUNCHES, 0) == 2
+        assert torch.equal(d0, d1)
+        assert ((d1 != 0) & ~(act.float() > 0)).sum() == 0 and 0.2 < (d1 != 0).float().mean() < 0.8
+        # a stride-1 3x3 with bits is refused before anything is launched
+        assert not h.conv2d_mask_bits_ok(1, dy, wd, d1[:, :OH, :OW].contiguous(), Bn, OH, OW, C, C, OH, OW, C, 3, 3, 1, 1, 1, 1, relu_mask_bits=bits[:Bn * OH * OW])
+    finally:
+        h.set_option(h.OPT_C3S, prev)
 
 
 def test_clip_scale_is_deterministic_and_matches_torch():
@@ -1935,7 +1980,8 @@ def _pack_bits(y):
     """[px, C] -> int32 [px, C / 32] holding gpv_conv_args.y_mask_bits' bytes: (y[px, c] > 0) = bit (c & 7) of byte
     32 (c / 256) + 8 ((c % 32) / 8) + (c % 256) / 32 of the pixel's row (include/gpv_hip.h)"""
     px, Cc = y.shape
-    b = (y.float() > 0).view(px, Cc // 256, 8, 4, 8).to(torch.int32)              # [px, group of 256, t = (c % 256) / 32, g = (c % 32) / 8, e = c & 7]
+    G = min(256, Cc)                                                              # 128 channels: one group of 16 bytes, byte 4 g + t
+    b = (y.float() > 0).view(px, Cc // G, G // 32, 4, 8).to(torch.int32)          # [px, group, t = (c % G) / 32, g = (c % 32) / 8, e = c & 7]
     byte = (b << torch.arange(8, device=y.device, dtype=torch.int32)).sum(-1)     # [px, group, t, g]
     byte = byte.permute(0, 1, 3, 2).contiguous().to(torch.uint8)                  # byte order inside a group: 8 g + t
     return byte.view(px, Cc // 8).view(torch.int32)
