@@ -367,11 +367,28 @@ class GradSink(GradChain):
     def __init__(self, n):
         super().__init__()
         self.total = self.left = n
+        self.events = []
 
     def slot(self, like):
         if self.acc is None:
             self.acc = torch.empty_like(like)
         return self.acc
+
+    def note_writer(self):
+        """a backward has just launched its writes into the buffer on the current stream: the buffer's consumer may run on another
+        stream (ops.Branch) and autograd orders it only behind the writer that HANDED the buffer over"""
+        if Branch.ENABLED and self.acc is not None and self.acc.is_cuda:
+            ev = torch.cuda.Event()
+            ev.record()
+            self.events.append(ev)
+
+    def sync_writers(self):
+        """the consumer's stream waits for every writer (no-ops for writers of the same stream)"""
+        evs, self.events = self.events, []
+        if evs:
+            cur = torch.cuda.current_stream()
+            for ev in evs:
+                cur.wait_event(ev)
 
     def wrote(self):
         self.left -= 1
@@ -404,10 +421,44 @@ class GradSlots(GradSink):
         return None
 
     def release(self):
+        self.sync_writers()
         self.acc, self.fresh = None, False
 
     def rearm(self):
-        self.left, self.acc, self.fresh = self.total, None, False
+        self.left, self.acc, self.fresh, self.events = self.total, None, False, []
+
+
+class Branch:
+    """Round 6: a side stream for work that is independent of the main chain between a fork and a join -- the co-attention layer's
+    LANGUAGE stream (192 rows at B = 32: eight launches of 5 - 13 us per layer that used to sit in line with the vision stream's,
+    vilbert.BertConnectionLayer).  Inside a capture the side stream's launches become a parallel branch of the graph; autograd runs the
+    backward of what was recorded on the side stream there too and orders every gradient edge between the streams itself.  What does
+    NOT travel on an autograd edge is ordered here: a GradSlots buffer that a main-stream attention backward fills in place after it
+    was handed over (GradSink.note_writer / sync_writers).  The deferred weight gradients are launched behind a boundary node whose
+    own inputs come after the last side-stream backward (the language stream's gradient returns to the main stream through
+    bert_joiner's backward), so their operands are complete.  GPV_COATT_BRANCH=0: in line."""
+    ENABLED = os.environ.get('GPV_COATT_BRANCH', '1') != '0'
+    _streams = {}
+
+    def __init__(self, device):
+        self.dev = device
+        st = Branch._streams.get(device)
+        if st is None:
+            st = Branch._streams[device] = torch.cuda.Stream(device=device)
+        self.side = st
+
+    def fork(self):
+        self.side.wait_stream(torch.cuda.current_stream(self.dev))
+
+    def join(self):
+        torch.cuda.current_stream(self.dev).wait_stream(self.side)
+
+    def on(self):
+        return torch.cuda.stream(self.side)
+
+
+def branch_for(x):
+    return Branch(x.device) if (Branch.ENABLED and torch.is_tensor(x) and x.is_cuda) else None
 
 
 # concatenated compute copies of the weights behind a multi_linear site: [n*N, K] (forward), [K, n*N] (backward-data), fp32 biases.
@@ -963,6 +1014,9 @@ class AttentionFn(Function):
         hip.attention_bwd(bufs[qi][:, qo:], bufs[ki][:, ko:], bufs[vi][:, vo:], o, do,
                           grads[qi][:, qo:], grads[ki][:, ko:], grads[vi][:, vo:], ctx.st, (Sq * D, D),
                           B, H, Sq, Sk, dh, ctx.scale, kpm=kpm, causal=causal, drop_p=drop_p, seed=ctx.seed, lse=lse)
+        for s_ in sinks:
+            if s_ is not None:
+                s_.note_writer()
         return (None, *[g if s is None else s.wrote() for g, s in zip(grads, sinks)])
 
 

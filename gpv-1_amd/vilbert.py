@@ -37,7 +37,7 @@ class BertBiAttention(nn.Module):
         self.p1 = cfg.v_attention_probs_dropout_prob
         self.p2 = cfg.attention_probs_dropout_prob
 
-    def forward(self, t1, t2, B, T1, T2, own1=None, own2=None, kpm1=None):
+    def forward(self, t1, t2, B, T1, T2, own1=None, own2=None, kpm1=None, branch=None):
         """t1 [B*T1, D] (language), t2 [B*T2, D] (vision) -> ctx1 [B*T2, D], ctx2 [B*T1, D].
         ops.GradChain: a chain's members must all sit behind the same layer output (a detection-only batch gives the language
         output of the last layer no gradient).  ctx2 -> stream 1's output uses q1, k2, v2; ctx1 -> stream 2's output uses q2, k1, v1:
@@ -51,10 +51,17 @@ class BertBiAttention(nn.Module):
             # write their gradient columns into shared buffers (ops.GradSlots: either call may be absent from a backward pass)
             grad = torch.is_grad_enabled() and (t1.requires_grad or t2.requires_grad)
             s1, s2 = (ops.GradSlots(), ops.GradSlots()) if grad else (None, None)
-            qkv1 = ops.multi_linear(t1, [W(m.weight, m.bias) for m in (self.query1, self.key1, self.value1)], s1)
+            if branch is not None:                      # the language stream's projection on the side stream, beside the vision stream's
+                branch.fork()
+                with branch.on():
+                    qkv1 = ops.multi_linear(t1, [W(m.weight, m.bias) for m in (self.query1, self.key1, self.value1)], s1)
+            else:
+                qkv1 = ops.multi_linear(t1, [W(m.weight, m.bias) for m in (self.query1, self.key1, self.value1)], s1)
             # (the vision stream's output always carries a gradient: its projections share the chain of its residual LayerNorm;
             #  the language stream's may not -- a detection-only batch in the last layer -- so its sum is left to autograd)
             qkv2 = ops.multi_linear(t2, [W(m.weight, m.bias) for m in (self.query2, self.key2, self.value2)], s2, chain=own2)
+            if branch is not None:
+                branch.join()                           # both attention calls read both buffers: they run on the main stream
             roles = ((0, 0), (1, D), (1, 2 * D))
             ctx1 = ops.attention([qkv2, qkv1], roles, B, H, T2, T1, dh, kpm=kpm1, drop_p=p1, sinks=(s2, s1) if grad else None)
             ctx2 = ops.attention([qkv1, qkv2], roles, B, H, T1, T2, dh, drop_p=p2, sinks=(s1, s2) if grad else None)
@@ -124,9 +131,26 @@ class BertConnectionLayer(nn.Module):
         kpm1 (uint8 [B, T1], 1 = ignore): NOT a reference argument -- the trainer's size-classed batches (train.FlatTrainer) carry
         language tokens beyond the batch's own longest query; masking exactly those keys reproduces the unpadded batch."""
         c1, c2 = ops.grad_chain(t1), ops.grad_chain(t2)          # each stream input: three projections + a residual
-        bi1, bi2 = self.biattention(t1, t2, B, T1, T2, c1, c2, kpm1)
-        a1, a2 = self.biOutput(bi2, t1, bi1, t2, c1, c2)
-        ca1, ca2 = ops.grad_chain(a1), ops.grad_chain(a2)        # feed-forward input + residual
-        o1 = self.v_output(self.v_intermediate(a1, ca1), a1, ca1)
+        # round 6: stream 1 (language: B * T1 = 192 rows at B = 32) runs on a side stream / graph branch beside stream 2 (vision: 3200 rows)
+        # wherever the two are independent -- its q | k | v projection, and everything behind the two attention calls (ops.Branch)
+        br = ops.branch_for(t1) if (FUSE_QKV and t1.shape[-1] == t2.shape[-1]) else None
+        bi1, bi2 = self.biattention(t1, t2, B, T1, T2, c1, c2, kpm1, branch=br)
+        bo = self.biOutput
+        if br is None:
+            a1, a2 = bo(bi2, t1, bi1, t2, c1, c2)
+            ca1, ca2 = ops.grad_chain(a1), ops.grad_chain(a2)    # feed-forward input + residual
+            o1 = self.v_output(self.v_intermediate(a1, ca1), a1, ca1)
+            o2 = self.t_output(self.t_intermediate(a2, ca2), a2, ca2)
+            return o1, o2
+        # (the launches are ISSUED in the in-line order -- stream 1's, stream 2's, stream 1's, stream 2's -- so that the dropout seeds are
+        #  drawn in the same order with and without the branch: same masks, bit-identical results)
+        br.fork()
+        with br.on():
+            a1 = bo.LayerNorm1(t1, bo.dense1(bi2), bo.p1 if bo.training else 0.0, chain=c1)
+        a2 = bo.LayerNorm2(t2, bo.dense2(bi1), bo.p2 if bo.training else 0.0, chain=c2)
+        ca1, ca2 = ops.grad_chain(a1), ops.grad_chain(a2)
+        with br.on():
+            o1 = self.v_output(self.v_intermediate(a1, ca1), a1, ca1)
         o2 = self.t_output(self.t_intermediate(a2, ca2), a2, ca2)
+        br.join()
         return o1, o2

@@ -31,6 +31,7 @@ NOTES = {
     'GPV_C3S_BLOCKS': 'workgroups of the streaming 3x3 kernel (0: heuristic)',
     'GPV_C3S_WAVES': 'waves per workgroup of the streaming 3x3 kernel (0: 8)',
     'GPV_CAPTURE_TRACE': 'print every hipGraph capture / replay decision of the trainer',
+    'GPV_COATT_BRANCH': 'co-attention language stream on a side stream / graph branch beside the vision stream (ops.Branch)',
     'GPV_COATT_QKV': 'co-attention q | k | v as one GEMM over concatenated weights',
     'GPV_CONV_SPLIT': 'split-K for the register-staged conv weight gradient (0: never)',
     'GPV_DEBUG_SYNC': 'synchronise and check after every launch (also disables the graphs in bench.py)',
