@@ -379,6 +379,69 @@ def test_baseline_config1_caption_only_bs32_graphed_equals_eager(rt):
     assert l0[-1] < l0[0] and l1[-1] < l1[0]
 
 
+@pytest.mark.parametrize('graphs', [False, True])
+def test_coattention_language_branch_changes_nothing(rt, graphs):
+    """Round 6 (ops.Branch, vilbert.BertConnectionLayer): the co-attention layer's language stream runs on a side stream / graph branch
+    beside the vision stream.  Same launches with the same operands in another interleaving: the gradients of a multitask batch at full
+    size (B = 16, dropout off) equal the in-line run's to the noise two in-line runs have between themselves (fp32 atomics of the
+    grouped weight gradients) -- per parameter group of the co-attention / BERT joiner / text decoder, whose gradients cross the two
+    streams (GradSlots buffers filled from the main stream, deferred weight gradients whose operands the side stream wrote).  Three
+    runs each way: a race would show as an outlier."""
+    import gpv1_amd.ops as ops
+    from gpv1_amd.train import FlatTrainer
+    rt.set_precise(False)
+    Vf, Bf = 2048, 16
+    g, images, mask, ids, attn = _full_batch(Bf, Vf, tl=8)
+    tasks = ['CocoCaptioning', 'CocoVqa', 'CocoClassification', 'CocoDetection']
+    tg = []
+    for i in range(Bf):
+        if tasks[i % 4] == 'CocoDetection':
+            n = 1 + i % 3
+            bx = torch.cat([0.25 + 0.5 * torch.rand(n, 2, generator=g), 0.05 + 0.3 * torch.rand(n, 2, generator=g)], 1).to(DEV)
+            tg.append({'task': 'CocoDetection', 'boxes': bx, 'labels': torch.zeros(n, dtype=torch.long, device=DEV)})
+        else:
+            tg.append({'task': tasks[i % 4], 'answer': ' '.join(f'w{(5 * i + j) % (Vf - 4)}' for j in range(12 if i % 4 == 0 else 2))})
+    prev = ops.Branch.ENABLED
+    runs = {True: [], False: []}
+    try:
+        for rep in range(3):
+            for br in (False, True):
+                ops.Branch.ENABLED = br
+                model = full_model(Vf, dropout=0.0)
+                model.bert.model.p = 0.0
+                tr = FlatTrainer(model, lr=1e-4, lr_backbone=1e-5, graphs=graphs)
+                for it in range(3 if graphs else 1):                  # graphs: eager warm-up, capture, replay
+                    loss = tr.train_step(nested(images, mask), (ids, attn), [dict(t) for t in tg])
+                torch.cuda.synchronize()
+                assert torch.isfinite(loss)
+                if graphs:
+                    assert tr.graph_steps >= 2
+                runs[br].append((float(loss), tr.P.clone(), [(e[0], e[3], e[4]) for e in tr.entries]))
+                del tr, model
+                torch.cuda.empty_cache()
+    finally:
+        ops.Branch.ENABLED = prev
+    entries = runs[True][0][2]
+    groups = {'co_att_transformer': [], 'bert_joiner': [], 'text_decoder': [], 'detr_joiner': [], 'detr.transformer.decoder': [], 'relevance': []}
+    for n, o, k in entries:
+        for key in groups:
+            if key in n:
+                groups[key].append((o, k))
+    p_ref = runs[False][0][1]
+    def dist(p, q, segs):
+        num = sum(float((p[o:o + k] - q[o:o + k]).double().pow(2).sum()) for o, k in segs)
+        den = sum(float((q[o:o + k] - 0).double().pow(2).sum()) for o, k in segs)
+        return (num / max(den, 1e-30)) ** 0.5
+    for key, segs in groups.items():
+        assert segs, key
+        noise = max(dist(runs[False][i][1], p_ref, segs) for i in (1, 2))
+        worst = max(dist(runs[True][i][1], p_ref, segs) for i in range(3))
+        print('BRANCH %-28s in-line run-to-run %.3e   branch vs in-line %.3e' % (key, noise, worst))
+        assert worst <= 3 * noise + 1e-6, (key, noise, worst)
+    l_ref = runs[False][0][0]
+    assert all(abs(r[0] - l_ref) <= 2e-3 * abs(l_ref) for br in (True, False) for r in runs[br])
+
+
 def test_baseline_config3_beam_search_and_config0_single_image(rt):
     """configs[3]: beam_size 5 decode of a batch of 64 480x640 images (K*B = 320 decoder rows, KV caches following the beams,
     the whole search one hipGraph); configs[0]: one image, greedy.  Probabilities in (0,1], beams sorted best-first, greedy
