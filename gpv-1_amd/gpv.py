@@ -97,10 +97,10 @@ class AnswerHead(nn.Module):
             self._wc = ((RT.weights_epoch, RT.static_epoch, RT.dtype), wc)
         return wc
 
-    def forward(self, h):
+    def forward(self, h, wc=None):
         """h [..., D] -> [..., V]"""
         D = h.shape[-1]
-        return ops.matmul_nt(h.reshape(-1, D), self.classifiers()).reshape(*h.shape[:-1], -1)
+        return ops.matmul_nt(h.reshape(-1, D), self.classifiers() if wc is None else wc).reshape(*h.shape[:-1], -1)
 
 
 class AnswerInputEmbedding(nn.Module):
@@ -200,10 +200,12 @@ class GPV(nn.Module):
         self.load_state_dict(cur)
 
     # ------------------------------------------------------------------ encoder shared by all branches
-    def _encode(self, images, queries, query_encodings=None, lang_extra=None):
+    def _encode(self, images, queries, query_encodings=None, lang_extra=None, after_detr=None):
         """query_encodings: BERT features computed by the caller (train.GraphedBody runs the frozen, no_grad BERT as a
         parallel branch of the backbone's hipGraph: 110 launches of <= 144 workgroups hide under the convolutions)"""
         outputs = self.detr(images)
+        if after_detr is not None:
+            after_detr(outputs)             # (work that does not depend on the encoder: forked here, beside the co-attention stage)
         # (backward: everything downstream of the DETR stream -- text decoder, answer head, co-attention -- is done when this fires)
         if not detr_mod.BOUNDARY_BELOW_ROI:
             outputs['detr_hs'] = ops.boundary(outputs['detr_hs'], 'detr')
@@ -235,8 +237,9 @@ class GPV(nn.Module):
         memory = torch.cat((vl2.reshape(B, Tv, D), lv2.reshape(B, Tl, D)), 1)      # [B, Tv+Tl, D]
         return outputs, memory
 
-    def decode_text(self, target, memory, mem_kpm=None):
-        """target [B,Tt,D], memory [B,Tm,D] -> logits [B,Tt,V]   (gpv.py:449-466)"""
+    def decode_text(self, target, memory, mem_kpm=None, wc=None):
+        """target [B,Tt,D], memory [B,Tm,D] -> logits [B,Tt,V]   (gpv.py:449-466); wc: the vocabulary classifiers when the caller
+        has already computed them (on a branch)"""
         B, Tt, D = target.shape
         Tm = memory.shape[1]
         if self.cfg.text_decoder.pos_enc is True:
@@ -252,11 +255,11 @@ class GPV(nn.Module):
             sink = ops.GradSink(len(layers)) if (torch.is_grad_enabled() and kv_all.requires_grad) else None
             for i, layer in enumerate(layers):
                 x = layer(x, mem, B, Tt, Tm, None, mem_kpm, kv=(kv_all, 2 * D * i, kv_all, 2 * D * i + D, sink, sink))
-            return self.answer_head(x).reshape(B, Tt, -1)
+            return self.answer_head(x, wc).reshape(B, Tt, -1)
         mem_chain = ops.grad_chain(mem)                # the co-attention output feeds the K|V projection of every layer
         for layer in layers:
             x = layer(x, mem, B, Tt, Tm, mem_chain, mem_kpm)
-        return self.answer_head(x).reshape(B, Tt, -1)
+        return self.answer_head(x, wc).reshape(B, Tt, -1)
 
     # ------------------------------------------------------------------ reference API
     def _host_tokenize(self, images, queries):
@@ -386,6 +389,7 @@ class GPV(nn.Module):
             with capture_guard(), torch.cuda.graph(graph, capture_error_mode='thread_local'):
                 try:
                     out = run()
+                    ops.Branch.join_captured(x.device)
                 except BaseException:
                     import traceback
                     traceback.print_exc()          # (the capture's teardown can abort the process before the exception surfaces)
@@ -408,7 +412,21 @@ class GPV(nn.Module):
         """lang_extra (uint8 [B, T_l], 1 = a query token beyond the batch's own longest query): the trainer pads queries to a few
         size classes so that one captured hipGraph serves many batches (train.FlatTrainer); those tokens are masked as keys in the
         co-attention and in the text decoder's memory, which reproduces the unpadded batch exactly.  Teacher forcing only."""
-        outputs, memory = self._encode(images, queries, query_encodings, lang_extra)
+        # teacher forcing: the target embedding (gather + input transform) and the vocabulary classifiers (10000 x 768 x 768) depend on the
+        # answer ids / the weights only -- forked beside the co-attention stage (ops.Branch), joined where decode_text needs them
+        pre = {}
+
+        def early(outs):
+            ref = outs['pred_boxes']
+            br = ops.branch_for(ref)
+            if br is None:
+                return
+            br.fork()
+            with br.on():
+                pre['target'] = self.answer_input_embedings(answer_token_ids.to(ref.device))
+                pre['wc'] = self.answer_head.classifiers()
+            pre['br'] = br
+        outputs, memory = self._encode(images, queries, query_encodings, lang_extra, after_detr=early if answer_token_ids is not None else None)
         B = memory.shape[0]
         dev = memory.device
         if answer_token_ids is None:                                               # greedy, gpv.py:178-196
@@ -424,12 +442,16 @@ class GPV(nn.Module):
             else:
                 outputs['answer_logits'] = self.greedy_full_prefix(memory, vocab_mask)
         else:                                                                      # teacher forcing, :197-201
-            target = self.answer_input_embedings(answer_token_ids.to(dev))
+            if 'br' in pre:
+                pre['br'].join()
+                target = pre['target']
+            else:
+                target = self.answer_input_embedings(answer_token_ids.to(dev))
             mem_kpm = None
             if lang_extra is not None:                                             # memory = [vision tokens | language tokens]
                 Tv = memory.shape[1] - lang_extra.shape[1]
                 mem_kpm = torch.cat((torch.zeros(B, Tv, dtype=torch.uint8, device=dev), lang_extra), 1).contiguous()
-            outputs['answer_logits'] = self.decode_text(target, memory, mem_kpm)[:, :-1].unsqueeze(0)
+            outputs['answer_logits'] = self.decode_text(target, memory, mem_kpm, wc=pre.get('wc'))[:, :-1].unsqueeze(0)
         if targets is None:
             return outputs
         return self.criterion(outputs, targets)[0]

@@ -457,6 +457,21 @@ class Branch:
         return torch.cuda.stream(self.side)
 
 
+    @staticmethod
+    def join_captured(device):
+        """before a capture ends: if the side stream is part of it, the capturing stream waits for it once more (every fork above is
+        joined where its results are needed, and autograd joins what it moves between the streams -- this closes whatever a backward
+        pass may have left on the side stream behind its last gradient edge; a capture that ends with work on a forked stream is
+        invalid, and ROCm 7.2 answered one with a segmentation fault in a LATER capture_end instead of an error)"""
+        st = Branch._streams.get(device)
+        if st is None:
+            return
+        with torch.cuda.stream(st):
+            cap = torch.cuda.is_current_stream_capturing()
+        if cap:
+            torch.cuda.current_stream(device).wait_stream(st)
+
+
 def branch_for(x):
     return Branch(x.device) if (Branch.ENABLED and torch.is_tensor(x) and x.is_cuda) else None
 

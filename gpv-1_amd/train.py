@@ -167,6 +167,7 @@ class GraphedBody:
             if self._open is not self.f2:
                 raise RuntimeError('GraphedBody: the model never reached backbone_forward (F1 was not closed)')
             torch.cuda.current_stream(dev).wait_stream(self.wside)          # join the weight-mirror branch
+            _ops.Branch.join_captured(dev)
             self.f2.capture_end()
             self._open = None
         except BaseException:
@@ -465,6 +466,7 @@ class GraphedBody:
                     del deferred[:]
             if side_a:
                 torch.cuda.current_stream(dev).wait_stream(self.wside)
+            _ops.Branch.join_captured(dev)
             b1.capture_end()
             self._open = None
             dc5 = self.c5_leaf.grad
