@@ -386,7 +386,9 @@ class GPV(nn.Module):
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
             from .misc import capture_guard
+            bside = torch.cuda.Stream(device=x.device)      # ops.Branch's side stream inside THIS graph (kept with it: see ops.Branch)
             with capture_guard(), torch.cuda.graph(graph, capture_error_mode='thread_local'):
+                RT.branch_stream = bside
                 try:
                     out = run()
                     ops.Branch.join_captured(x.device)
@@ -394,9 +396,11 @@ class GPV(nn.Module):
                     import traceback
                     traceback.print_exc()          # (the capture's teardown can abort the process before the exception surfaces)
                     raise
-            ent = self._igraphs[key] = (graph, (sx, sm, sids, sattn, svm, sex), out, self._last_q_enc)
+                finally:
+                    RT.branch_stream = None
+            ent = self._igraphs[key] = (graph, (sx, sm, sids, sattn, svm, sex, bside), out, self._last_q_enc)
         self._igraphs[key] = self._igraphs.pop(key)                               # most recently used last
-        graph, (sx, sm, sids, sattn, svm, sex), out, self._graph_q_enc = ent        # (_graph_q_enc: the static BERT output this graph rewrites)
+        graph, (sx, sm, sids, sattn, svm, sex, _bside), out, self._graph_q_enc = ent        # (_graph_q_enc: the static BERT output this graph rewrites)
         sx.copy_(x); sm.copy_(m); sids.copy_(ids); sattn.copy_(attn)
         if svm is not None:
             svm.copy_(vocab_mask)

@@ -38,6 +38,7 @@ class Runtime:
         self.seed_dev = None             # device int64 word lent to the library as the dropout seed epoch (hipGraph replays)
         self.defer_list = None           # set by train.GraphedBody while it captures a backward: deferred weight-gradient launches
         self.backward_boundary = None    # callback(tag) from ops.BoundaryFn.backward (same capture)
+        self.branch_stream = None        # the side stream a capture owner lends to ops.Branch for the duration of its capture
         self.multi_wait = None           # set by train.GraphedBody while it captures F2: joins the branch that ran refresh_multi
 
     def set_precise(self, on=True):
@@ -438,14 +439,15 @@ class Branch:
     own inputs come after the last side-stream backward (the language stream's gradient returns to the main stream through
     bert_joiner's backward), so their operands are complete.  GPV_COATT_BRANCH=0: in line."""
     ENABLED = os.environ.get('GPV_COATT_BRANCH', '1') != '0'
-    _streams = {}
+    _streams = {}                 # device -> the side stream of EAGER launches (never part of a capture)
 
-    def __init__(self, device):
+    # Inside a capture the side stream is the capture owner's (RT.branch_stream: train.GraphedBody / GPV._graphed create one per body /
+    # per inference graph and keep it for as long as their graphs live).  A process-wide stream that had been part of the captures of
+    # graphs destroyed since -- evicted bodies, dropped models -- made a LATER capture_end segfault on ROCm 7.2 (the ragged-stream test
+    # after ~25 tests of captures and evictions; never with per-owner streams, like the BERT / weight branches have always been).
+    def __init__(self, device, stream):
         self.dev = device
-        st = Branch._streams.get(device)
-        if st is None:
-            st = Branch._streams[device] = torch.cuda.Stream(device=device)
-        self.side = st
+        self.side = stream
 
     def fork(self):
         self.side.wait_stream(torch.cuda.current_stream(self.dev))
@@ -463,7 +465,7 @@ class Branch:
         joined where its results are needed, and autograd joins what it moves between the streams -- this closes whatever a backward
         pass may have left on the side stream behind its last gradient edge; a capture that ends with work on a forked stream is
         invalid, and ROCm 7.2 answered one with a segmentation fault in a LATER capture_end instead of an error)"""
-        st = Branch._streams.get(device)
+        st = RT.branch_stream
         if st is None:
             return
         with torch.cuda.stream(st):
@@ -473,7 +475,15 @@ class Branch:
 
 
 def branch_for(x):
-    return Branch(x.device) if (Branch.ENABLED and torch.is_tensor(x) and x.is_cuda) else None
+    if not (Branch.ENABLED and torch.is_tensor(x) and x.is_cuda):
+        return None
+    if torch.cuda.is_current_stream_capturing():
+        st = RT.branch_stream                  # (a capture whose owner lends no side stream runs in line)
+        return Branch(x.device, st) if st is not None else None
+    st = Branch._streams.get(x.device)
+    if st is None:
+        st = Branch._streams[x.device] = torch.cuda.Stream(device=x.device)
+    return Branch(x.device, st)
 
 
 # concatenated compute copies of the weights behind a multi_linear site: [n*N, K] (forward), [K, n*N] (backward-data), fp32 biases.

@@ -144,12 +144,14 @@ class GraphedBody:
         self.bert_mode = int(os.environ.get('GPV_BERT_BRANCH', '2'))      # 2: branch of F2 beside the DETR transformer (F1 3.88 -> 3.71 ms, F2 3.68 -> 3.81), 1: branch of F1, 0: in line
         self.side = torch.cuda.Stream(device=dev) if self.bert_mode else None
         self.wside = torch.cuda.Stream(device=dev)
+        self.bside = torch.cuda.Stream(device=dev)          # ops.Branch's side stream inside this body's captures (forward and backward variants)
         self.zero_in_graph = os.environ.get('GPV_ZERO_IN_GRAPH', '1') != '0'
         # the gradient chains of THIS recorded forward belong to the body: an eager step's check_chains(clear=True) must not
         # drop them from under the backward variants captured later (ops.GradChain._live is the eager steps' list)
         from . import ops as _ops
         live_before, _ops.GradChain._live = _ops.GradChain._live, []
         RT.split = self
+        RT.branch_stream = self.bside
         self._open = None                      # the graph whose capture is open (ended / aborted on any failure below)
         try:
             self.f1.capture_begin(pool=self.pool, capture_error_mode=CAPTURE_MODE)
@@ -175,6 +177,7 @@ class GraphedBody:
             raise
         finally:
             RT.split = None
+            RT.branch_stream = None
             RT.multi_wait = None
             self.chains, _ops.GradChain._live = _ops.GradChain._live, live_before
         self.fwd_touched = trainer.touched.clone()            # (forward kernels never write gradients: stays empty)
@@ -188,7 +191,7 @@ class GraphedBody:
                 g.capture_end()
             except Exception:
                 pass
-        for st in (self.side, self.wside):
+        for st in (self.side, self.wside, self.bside):
             if st is not None:
                 try:
                     st.synchronize()
@@ -431,6 +434,7 @@ class GraphedBody:
                 self._flush(deferred)
             side_a.extend(deferred)
             del deferred[:]
+        RT.branch_stream = self.bside
         try:
             b1.capture_begin(pool=self.pool, capture_error_mode=CAPTURE_MODE)
             self._open = b1
@@ -513,6 +517,7 @@ class GraphedBody:
         finally:
             RT.defer_list = None
             RT.backward_boundary = None
+            RT.branch_stream = None
         RT.backward_milestone = milestone
         _trace('capture backward end: %d stage graphs' % len(b2_list))
         var = {'head_late': head_late, 'b1': b1, 'b2': b2_list, 'grads': grads, 's_ce': s_ce, 'loss': loss_static, 'touched': tr.touched.clone(), 'dc5': dc5, 'deferred': deferred + side_a}
