@@ -47,6 +47,9 @@ def positionalencoding1d(d_model, length):
     return pe
 
 
+TEXT_EARLY = os.environ.get('GPV_TEXT_EARLY', '1') != '0'      # teacher forcing: target embedding, vocabulary classifiers and the first text-decoder layer's self-attention on a branch beside the co-attention stage
+
+
 class TextDecoderLayer(nn.Module):
     """torch.nn.TransformerDecoderLayer(d_model, nhead, dim_feedforward=2048, relu, post-norm) parameters."""
 
@@ -59,11 +62,19 @@ class TextDecoderLayer(nn.Module):
         self.norm1, self.norm2, self.norm3 = LayerNormP(d_model), LayerNormP(d_model), LayerNormP(d_model)
         self.p = dropout
 
-    def forward(self, tgt, memory, B, Tt, Tm, mem_chain=None, mem_kpm=None, kv=None):
-        """kv: the cross-attention keys | values of this layer as columns of the buffer GPV.decode_text projected for all layers"""
+    def self_part(self, tgt, B, Tt):
+        """the causal self-attention sublayer alone: it depends on the target tokens only -- teacher forcing runs the FIRST layer's on a
+        branch beside the co-attention stage (GPV._forward_impl)"""
         p = self.p if self.training else 0.0
         c0 = ops.grad_chain(tgt)                       # (ops.GradChain: tgt feeds the projection and the residual)
-        tgt = self.norm1(tgt, self.self_attn(tgt, tgt, tgt, B, Tt, Tt, causal=True, chains=(c0, c0, c0)), p, chain=c0)
+        return self.norm1(tgt, self.self_attn(tgt, tgt, tgt, B, Tt, Tt, causal=True, chains=(c0, c0, c0)), p, chain=c0)
+
+    def forward(self, tgt, memory, B, Tt, Tm, mem_chain=None, mem_kpm=None, kv=None, self_done=False):
+        """kv: the cross-attention keys | values of this layer as columns of the buffer GPV.decode_text projected for all layers;
+        self_done: tgt is already self_part's output"""
+        p = self.p if self.training else 0.0
+        if not self_done:
+            tgt = self.self_part(tgt, B, Tt)
         c1 = ops.grad_chain(tgt)
         tgt = self.norm2(tgt, self.multihead_attn(tgt, memory, memory, B, Tt, Tm, key_padding_mask=mem_kpm,
                                                   chains=(c1, mem_chain, mem_chain), kv=kv), p,
@@ -204,11 +215,14 @@ class GPV(nn.Module):
         """query_encodings: BERT features computed by the caller (train.GraphedBody runs the frozen, no_grad BERT as a
         parallel branch of the backbone's hipGraph: 110 launches of <= 144 workgroups hide under the convolutions)"""
         outputs = self.detr(images)
-        if after_detr is not None:
-            after_detr(outputs)             # (work that does not depend on the encoder: forked here, beside the co-attention stage)
         # (backward: everything downstream of the DETR stream -- text decoder, answer head, co-attention -- is done when this fires)
         if not detr_mod.BOUNDARY_BELOW_ROI:
             outputs['detr_hs'] = ops.boundary(outputs['detr_hs'], 'detr')
+        if after_detr is not None:
+            # work that does not depend on the encoder: forked here, beside the co-attention stage.  AFTER the boundary node: autograd runs
+            # ready nodes latest-created first, so these nodes' backward -- and the weight gradients it defers -- come before the boundary
+            # fires and launches the deferred group (created before it they ran after it: the group missed them)
+            after_detr(outputs)
         outputs['detr_hs'] = self.detr_joiner(outputs['detr_hs'])     # [L,B,Q,768]
         forked = callable(query_encodings)
         if forked:                                     # (a branch forked earlier: joined here, where the features are first needed)
@@ -237,14 +251,19 @@ class GPV(nn.Module):
         memory = torch.cat((vl2.reshape(B, Tv, D), lv2.reshape(B, Tl, D)), 1)      # [B, Tv+Tl, D]
         return outputs, memory
 
-    def decode_text(self, target, memory, mem_kpm=None, wc=None):
-        """target [B,Tt,D], memory [B,Tm,D] -> logits [B,Tt,V]   (gpv.py:449-466); wc: the vocabulary classifiers when the caller
-        has already computed them (on a branch)"""
+    def _text_input(self, target):
+        """target embeddings [B,Tt,D] (+ position encoding) -> the first decoder layer's input rows [B*Tt, D]"""
         B, Tt, D = target.shape
-        Tm = memory.shape[1]
         if self.cfg.text_decoder.pos_enc is True:
             target = ops.add(target.reshape(B * Tt, D), self.pos_enc[0, :Tt].to(RT.dtype)).reshape(B, Tt, D)
-        x = target.reshape(B * Tt, D)
+        return target.reshape(B * Tt, D)
+
+    def decode_text(self, target, memory, mem_kpm=None, wc=None, x0=None):
+        """target [B,Tt,D], memory [B,Tm,D] -> logits [B,Tt,V]   (gpv.py:449-466); wc: the vocabulary classifiers, x0: the first layer's
+        self-attention sublayer output, when the caller has already computed them (on a branch)"""
+        B, Tt, D = target.shape
+        Tm = memory.shape[1]
+        x = self._text_input(target) if x0 is None else x0
         mem = memory.reshape(B * Tm, D)
         layers = self.text_decoder.layers
         if transformer_mod.HOIST_KV and len(layers) > 1:
@@ -254,11 +273,11 @@ class GPV(nn.Module):
             kv_all = ops.multi_linear(mem, ws)
             sink = ops.GradSink(len(layers)) if (torch.is_grad_enabled() and kv_all.requires_grad) else None
             for i, layer in enumerate(layers):
-                x = layer(x, mem, B, Tt, Tm, None, mem_kpm, kv=(kv_all, 2 * D * i, kv_all, 2 * D * i + D, sink, sink))
+                x = layer(x, mem, B, Tt, Tm, None, mem_kpm, kv=(kv_all, 2 * D * i, kv_all, 2 * D * i + D, sink, sink), self_done=(i == 0 and x0 is not None))
             return self.answer_head(x, wc).reshape(B, Tt, -1)
         mem_chain = ops.grad_chain(mem)                # the co-attention output feeds the K|V projection of every layer
-        for layer in layers:
-            x = layer(x, mem, B, Tt, Tm, mem_chain, mem_kpm)
+        for i, layer in enumerate(layers):
+            x = layer(x, mem, B, Tt, Tm, mem_chain, mem_kpm, self_done=(i == 0 and x0 is not None))
         return self.answer_head(x, wc).reshape(B, Tt, -1)
 
     # ------------------------------------------------------------------ reference API
@@ -422,13 +441,15 @@ class GPV(nn.Module):
 
         def early(outs):
             ref = outs['pred_boxes']
-            br = ops.branch_for(ref)
+            br = ops.branch_for(ref) if TEXT_EARLY else None
             if br is None:
                 return
             br.fork()
             with br.on():
                 pre['target'] = self.answer_input_embedings(answer_token_ids.to(ref.device))
                 pre['wc'] = self.answer_head.classifiers()
+                tshape = pre['target'].shape
+                pre['x0'] = self.text_decoder.layers[0].self_part(self._text_input(pre['target']), tshape[0], tshape[1])
             pre['br'] = br
         outputs, memory = self._encode(images, queries, query_encodings, lang_extra, after_detr=early if answer_token_ids is not None else None)
         B = memory.shape[0]
@@ -455,7 +476,7 @@ class GPV(nn.Module):
             if lang_extra is not None:                                             # memory = [vision tokens | language tokens]
                 Tv = memory.shape[1] - lang_extra.shape[1]
                 mem_kpm = torch.cat((torch.zeros(B, Tv, dtype=torch.uint8, device=dev), lang_extra), 1).contiguous()
-            outputs['answer_logits'] = self.decode_text(target, memory, mem_kpm, wc=pre.get('wc'))[:, :-1].unsqueeze(0)
+            outputs['answer_logits'] = self.decode_text(target, memory, mem_kpm, wc=pre.get('wc'), x0=pre.get('x0'))[:, :-1].unsqueeze(0)
         if targets is None:
             return outputs
         return self.criterion(outputs, targets)[0]

@@ -474,6 +474,20 @@ class Branch:
             torch.cuda.current_stream(device).wait_stream(st)
 
 
+def branch_wait(waiter):
+    """`waiter` (a stream about to launch work whose operands a backward on the branch stream may have written -- the deferred weight
+    gradients on train.GraphedBody's weight branch) waits for the capture owner's branch stream, if that stream is part of the capture:
+    a side-stream backward that ends in frozen inputs (the target-embedding transform) hands no gradient back to the main stream, so no
+    autograd edge orders it before the main stream's next launches"""
+    st = RT.branch_stream
+    if st is None or st is waiter:
+        return
+    with torch.cuda.stream(st):
+        cap = torch.cuda.is_current_stream_capturing()
+    if cap:
+        waiter.wait_stream(st)
+
+
 def branch_for(x):
     if not (Branch.ENABLED and torch.is_tensor(x) and x.is_cuda):
         return None

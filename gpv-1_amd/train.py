@@ -391,6 +391,7 @@ class GraphedBody:
                 fn()
 
     def _capture_backward(self, pairs, fused=None):
+        from . import ops as _ops
         tr = self.tr
         _trace('capture backward begin (fused=%r)' % (fused is not None,))
         tr.quiesce_collectives()
@@ -430,6 +431,7 @@ class GraphedBody:
                 return
             cur = torch.cuda.current_stream(dev)
             self.wside.wait_stream(cur)
+            _ops.branch_wait(self.wside)            # (operands written by backward nodes on the branch stream, ops.Branch)
             with torch.cuda.stream(self.wside):
                 self._flush(deferred)
             side_a.extend(deferred)
@@ -465,6 +467,7 @@ class GraphedBody:
                 head_late = os.environ.get('GPV_HEAD_LATE', '1') != '0' and bool(self.keep) and self.c5_leaf.grad is not None and \
                     all(len(t) > 2 and lo <= (t[2].data_ptr() - g0) // 4 < hi for _, t, _ in deferred)
                 if not head_late:
+                    _ops.branch_wait(torch.cuda.current_stream(dev))
                     self._flush(deferred)
                     side_a.extend(deferred)
                     del deferred[:]

@@ -49,6 +49,7 @@ NOTES = {
     'GPV_OVERLAP': 'all-reduce buckets overlapped with the backbone backward (0: after the pass)',
     'GPV_PREP_BRANCH': 'conv weight casts / copies on a branch of F1',
     'GPV_MASK_BITS': 'ReLU masks of the layer2 / layer3 block outputs as one bit per element (written by the conv3 launch, read by the next conv1 backward-data)',
+    'GPV_TEXT_EARLY': 'teacher forcing: target embedding, vocabulary classifiers and the first text-decoder self-attention forked beside the co-attention stage',
     'GPV_PROJ_LN_MIN_ROWS': 'fewest rows for which the projection rides in the LayerNorm launch (below: GEMM + LayerNorm, faster as graph nodes up to ~1200 rows)',
     'GPV_PROJ_LN': 'attention out-projection inside the LayerNorm launch (gpv_linear_layernorm_fwd)',
     'GPV_RCCL_HIGH_PRIO': 'RCCL stream created with high priority',
