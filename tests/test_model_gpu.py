@@ -437,7 +437,9 @@ def test_coattention_language_branch_changes_nothing(rt, graphs):
         noise = max(dist(runs[False][i][1], p_ref, segs) for i in (1, 2))
         worst = max(dist(runs[True][i][1], p_ref, segs) for i in range(3))
         print('BRANCH %-28s in-line run-to-run %.3e   branch vs in-line %.3e' % (key, noise, worst))
-        assert worst <= 3 * noise + 1e-6, (key, noise, worst)
+        # (the in-line runs differ from each other by 5e-7 .. 4e-6 from run to run -- fp32 atomics of the grouped weight gradients through
+        #  three Adam steps; two samples do not bound that noise: a floor of 2e-5.  A race reads stale or half-written operands: 1e-2 and up)
+        assert worst <= max(3 * noise, 2e-5), (key, noise, worst)
     l_ref = runs[False][0][0]
     assert all(abs(r[0] - l_ref) <= 2e-3 * abs(l_ref) for br in (True, False) for r in runs[br])
 
