@@ -356,9 +356,11 @@ int c1s_launch(const GemmK& k, hipStream_t st) {
 }
 
 template <int K, int NH>
-int c1s_flags(const GemmK& k, hipStream_t st) {
+int c1s_flags(const GemmK& k, hipStream_t st, bool linear) {
   const bool r = k.res != nullptr, m = k.mask != nullptr, nt = k.nt_io != 0;
-  if (k.alpha != 1.0f || k.dthresh) {     // linear-layer extras: instantiated for the 256 -> n x 256 shapes only
+  // gpv_gemm's calls always take the LIN instances (alpha = 1 and no dropout are exact no-ops there): a linear layer's launch is then
+  // told from a convolution's by its NAME -- profiles and bench.py's live HBM-traffic passes (tools/pmc_traffic.py) classify by it
+  if (linear || k.alpha != 1.0f || k.dthresh) {     // linear-layer extras: instantiated for the 256 -> n x 256 shapes only
     if constexpr (K == 256 && NH == 256) {
       if (nt) return -1;
       if (r && m) return c1s_launch<K, NH, true, true, false, true>(k, st);
@@ -394,11 +396,11 @@ int c1s_flags(const GemmK& k, hipStream_t st) {
 }
 
 template <int K>
-int c1s_n(const GemmK& k, hipStream_t st) {
+int c1s_n(const GemmK& k, hipStream_t st, bool linear) {
   switch (c1s_cols(K, k.N)) {          // channels per block -> channels per register pass
-    case 64: return c1s_flags<K, 64>(k, st);
-    case 128: return c1s_flags<K, 128>(k, st);
-    case 256: case 512: if constexpr (K <= 256) return c1s_flags<K, 256>(k, st); else return -1;
+    case 64: return c1s_flags<K, 64>(k, st, linear);
+    case 128: return c1s_flags<K, 128>(k, st, linear);
+    case 256: case 512: if constexpr (K <= 256) return c1s_flags<K, 256>(k, st, linear); else return -1;
   }
   return -1;
 }
@@ -440,10 +442,10 @@ int c1s_try_launch(const GemmK& k, int dtype_in, int dtype_out, hipStream_t st, 
   if (dry) return 0;
   int e = -1;
   switch (k.K) {
-    case 64: e = c1s_n<64>(k, st); break;
-    case 128: e = c1s_n<128>(k, st); break;
-    case 256: e = c1s_n<256>(k, st); break;
-    case 512: e = c1s_n<512>(k, st); break;       // (N <= 128: the weights must fit the LDS)
+    case 64: e = c1s_n<64>(k, st, linear); break;
+    case 128: e = c1s_n<128>(k, st, linear); break;
+    case 256: e = c1s_n<256>(k, st, linear); break;
+    case 512: e = c1s_n<512>(k, st, linear); break;       // (N <= 128: the weights must fit the LDS)
   }
   if (e == 0) ++g_c1s_launches;
   return e;
