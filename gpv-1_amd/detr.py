@@ -72,8 +72,6 @@ class DETR(nn.Module):
         B, h, w, C = c5.shape
         rows = c5.reshape(B, h * w, C)
         src = self.input_proj(rows)                            # [B,S,256]
-        if ops.RT.split is not None:
-            ops.RT.split.start_weight_branch()                # (train.GraphedBody: the weight branch of F2 starts BEHIND this HBM-heavy GEMM)
         need_all = not (self.last_layer_only is True or self.training is not True)
         outs, _ = self.transformer(src, mask.flatten(1), self.query_embed.weight, pos[-1], need_all or self.aux_loss)
         # (backward: when the gradient arrives here, the text decoder, the co-attention, the heads and the RoI head have run --

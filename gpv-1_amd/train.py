@@ -168,7 +168,6 @@ class GraphedBody:
                                             self.s_tok, None, query_encodings=q_enc, lang_extra=self.s_extra)
             if self._open is not self.f2:
                 raise RuntimeError('GraphedBody: the model never reached backbone_forward (F1 was not closed)')
-            self.start_weight_branch(dev)          # (a model whose forward never called it: the branch still runs, at the end)
             torch.cuda.current_stream(dev).wait_stream(self.wside)          # join the weight-mirror branch
             _ops.Branch.join_captured(dev)
             self.f2.capture_end()
@@ -221,31 +220,7 @@ class GraphedBody:
         # cast-transpose launch on a branch of F2: 360 MB of streaming under a chain of latency-bound kernels.  (As a branch of
         # F1 it ran beside the stem convolution and cost it 0.2 ms.)
         from . import ops
-        self.c5 = c5
-        self.c5_leaf = c5.detach().requires_grad_(bool(train))
-        self.body = body
-        self._weights_started = False
-        # round 6: the weight branch (360 MB of transposes, 27 concatenations, the 444 MB gradient clear) used to start WITH F2 -- beside
-        # input_proj, the one HBM-heavy GEMM at the head of the chain (9600 x 256 x 2048: 23 us alone, 81 us under the branch's streams in
-        # profiles/r06_step_chain.txt).  It now starts when DETR.forward has issued input_proj (start_weight_branch); GPV_WEIGHT_BRANCH_LATE=0: at once
-        dev0 = x.device
-
-        def first_multi():                 # a multi_linear met before DETR.forward's call (another model layout): the branch starts here, then the wait
-            self.start_weight_branch(dev0)
-            RT.multi_wait()
-        RT.multi_wait = first_multi
-        if os.environ.get('GPV_WEIGHT_BRANCH_LATE', '1') == '0':
-            self.start_weight_branch(dev0)
-        return self.c5_leaf
-
-    def start_weight_branch(self, device=None):
-        """fork the weight branch of F2 from the current point of the capturing stream (once per capture)"""
-        if self._weights_started or self._open is not self.f2:
-            return
-        self._weights_started = True
-        from . import ops
-        dev = device if device is not None else self.s_img.device
-        cur = torch.cuda.current_stream(dev)
+        cur = torch.cuda.current_stream(x.device)
         self.wside.wait_stream(cur)
         with torch.cuda.stream(self.wside):
             ops.refresh_transposed()
@@ -260,11 +235,15 @@ class GraphedBody:
         waited = set()
 
         def multi_wait():                  # first multi_linear of F2 ON EACH STREAM: the copies are ready (long before: they follow the six encoder layers)
-            cur = torch.cuda.current_stream(dev)             # (one-shot was only right while the first call ran on the main stream;
+            cur = torch.cuda.current_stream(x.device)        # (one-shot was only right while the first call ran on the main stream;
             if cur.cuda_stream not in waited:                #  a first call on the BERT / side branch left later main-stream calls unordered)
                 cur.wait_event(multi_ready)
                 waited.add(cur.cuda_stream)
         RT.multi_wait = multi_wait
+        self.c5 = c5
+        self.c5_leaf = c5.detach().requires_grad_(bool(train))
+        self.body = body
+        return self.c5_leaf
 
     def _bert_join(self):
         torch.cuda.current_stream(self.s_img.device).wait_stream(self.side)

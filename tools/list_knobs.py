@@ -59,7 +59,6 @@ NOTES = {
     'GPV_TWO_PER_CU': 'two half-width tiles per CU in the direct-to-LDS GEMM (0: one 8-wave tile)',
     'GPV_WG8H_C': 'ramp (in k-tiles) the half-width weight-gradient launch adds per round when it picks its work-unit length',
     'GPV_WG8_KT': 'k-tiles per work unit of the 256 x 256 eight-phase weight-gradient launch',
-    'GPV_WEIGHT_BRANCH_LATE': 'the weight branch of F2 (transposes, concatenations, gradient clear) starts behind input_proj instead of with F2',
     'GPV_WGRAD_FLUSH': 'where the deferred Linear weight gradients are issued (detr: behind the DETR transformer backward)',
     'GPV_WGRAD_SPLIT': 'grouped Linear weight gradients in three calls along the backward (0: one)',
     'GPV_WGRAD_STREAM': 'ungrouped conv weight gradients on a side stream',
