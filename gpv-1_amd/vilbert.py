@@ -143,7 +143,8 @@ class BertConnectionLayer(nn.Module):
             o2 = self.t_output(self.t_intermediate(a2, ca2), a2, ca2)
             return o1, o2
         # (the launches are ISSUED in the in-line order -- stream 1's, stream 2's, stream 1's, stream 2's -- so that the dropout seeds are
-        #  drawn in the same order with and without the branch: same masks, bit-identical results)
+        #  drawn in the same order with and without the branch: same masks; what remains between the two runs is the run-to-run spread of the
+        #  grouped weight gradients' atomics, tests/test_model_gpu.py::test_coattention_language_branch_changes_nothing)
         br.fork()
         with br.on():
             a1 = bo.LayerNorm1(t1, bo.dense1(bi2), bo.p1 if bo.training else 0.0, chain=c1)
