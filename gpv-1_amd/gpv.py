@@ -9,6 +9,7 @@ no CPU path; the module raises if it is called with CPU tensors or without the l
 import copy
 import json
 import math
+import contextlib
 import os
 import re
 
@@ -440,12 +441,17 @@ class GPV(nn.Module):
         pre = {}
 
         def early(outs):
-            ref = outs['pred_boxes']
-            br = ops.branch_for(ref) if TEXT_EARLY else None
-            if br is None:
+            # ISSUED here whether or not there is a side stream to put it on (ops.branch_for -> None: in line, at this position): layer 0's
+            # self-attention sublayer draws two dropout seeds, and drawn behind the co-attention stage in one configuration and ahead of it
+            # in the other they shifted every seed in between -- other masks with GPV_COATT_BRANCH=0 than with 1 (found by the dropout-on
+            # arm of test_coattention_language_branch_changes_nothing).  GPV_TEXT_EARLY=0 is the knob that moves the issue position.
+            if not TEXT_EARLY:
                 return
-            br.fork()
-            with br.on():
+            ref = outs['pred_boxes']
+            br = ops.branch_for(ref)
+            if br is not None:
+                br.fork()
+            with (br.on() if br is not None else contextlib.nullcontext()):
                 pre['target'] = self.answer_input_embedings(answer_token_ids.to(ref.device))
                 pre['wc'] = self.answer_head.classifiers()
                 tshape = pre['target'].shape
@@ -467,8 +473,9 @@ class GPV(nn.Module):
             else:
                 outputs['answer_logits'] = self.greedy_full_prefix(memory, vocab_mask)
         else:                                                                      # teacher forcing, :197-201
-            if 'br' in pre:
-                pre['br'].join()
+            if 'target' in pre:
+                if pre['br'] is not None:
+                    pre['br'].join()
                 target = pre['target']
             else:
                 target = self.answer_input_embedings(answer_token_ids.to(dev))

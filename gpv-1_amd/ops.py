@@ -66,7 +66,14 @@ class Runtime:
         return self.weights_epoch if getattr(p, '_gpv_managed', False) else self.static_epoch
 
     def manual_seed(self, s):
+        """restart the dropout stream: the host counter behind next_seed() AND the device-resident epoch the replayed graphs add to their
+        frozen seeds (train.GraphedBody bumps it once per replayed step; it is process-wide and outlives trainers) -- without the second,
+        a graphed run from the same seed drew other masks than the run before it.  Not inside a capture (the reset would become a node)."""
         self.seed, self._ctr = int(s), 0
+        if self.seed_dev is not None:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError('Runtime.manual_seed inside a stream capture')
+            self.seed_dev.zero_()
 
     def next_seed(self):
         self._ctr += 1
