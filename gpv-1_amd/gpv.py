@@ -435,7 +435,9 @@ class GPV(nn.Module):
                       lang_extra=None):
         """lang_extra (uint8 [B, T_l], 1 = a query token beyond the batch's own longest query): the trainer pads queries to a few
         size classes so that one captured hipGraph serves many batches (train.FlatTrainer); those tokens are masked as keys in the
-        co-attention and in the text decoder's memory, which reproduces the unpadded batch exactly.  Teacher forcing only."""
+        co-attention and in the text decoder's memory, which reproduces the unpadded batch: the masked positions contribute exact zeros, so the
+        result is the unpadded batch's up to the summation order of the kernels the two row counts dispatch to (bit-for-bit when they are the
+        same kernels; see train.FlatTrainer._classed).  Teacher forcing only."""
         # teacher forcing: the target embedding (gather + input transform) and the vocabulary classifiers (10000 x 768 x 768) depend on the
         # answer ids / the weights only -- forked beside the co-attention stage (ops.Branch), joined where decode_text needs them
         pre = {}

@@ -1007,7 +1007,7 @@ class FlatTrainer:
         if cls is not None:
             # hipGraph path: string queries are tokenised here on the host; query and answer token axes are padded to a few size
             # classes with the padding masked out exactly (GPV._forward_impl `lang_extra`, CE target -100), so one captured body
-            # serves every batch of its class with the numerics of the unpadded batch
+            # serves every batch of its class with the unpadded batch's result (up to kernel summation order: _classed)
             queries, lang_extra, answer_token_ids, ce_targets = cls
             for i, t in enumerate(targets):
                 t['answer_token_ids'] = ce_targets[i]
@@ -1054,7 +1054,13 @@ class FlatTrainer:
         enter the numerics (padded BERT tokens are attended by the co-attention, pad answer tokens are CE targets), so a captured
         graph is only valid for one (T, S).  Real batches vary in both: the token axes are therefore padded on to a few size
         classes and the EXTRA positions are masked out exactly -- query tokens beyond the batch's longest as attention keys,
-        answer positions beyond the batch's longest as CE rows -- which leaves loss and gradients those of the unpadded batch."""
+        answer positions beyond the batch's longest as CE rows -- which leaves loss and gradients those of the unpadded batch in exact
+        arithmetic: the extra positions contribute exact zeros.  Bit-for-bit it is the unpadded batch only where both row counts take the
+        same kernels: B x T_b and B x T_c rows can fall on different sides of a row-count dispatch rule (small-M GEMM families, the
+        projection + LayerNorm launch), whose k-summation orders differ -- measured with tools/fuzz_model.py (FUZZ_ONLY=1: 9 tokens -> 16,
+        27 -> 48 language rows): parameters 1e-8 .. 4e-6 apart after one step against the unpadded eager step, loss 5.6e-4 apart after four
+        (Adam turns noise-level gradient differences into lr-sized steps); exactly 0 with the queries taken unpadded (FUZZ_T_EXACT=16) and
+        for every case of <= 8 tokens."""
         if not self._graphs_apply(images):
             return None
         from .misc import STAGER

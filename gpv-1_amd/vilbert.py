@@ -129,7 +129,8 @@ class BertConnectionLayer(nn.Module):
     def forward(self, t1, t2, B, T1, T2, kpm1=None):
         """vilbert.py:872-900.  No attention masks: GPV passes None, so padded BERT tokens are attended.
         kpm1 (uint8 [B, T1], 1 = ignore): NOT a reference argument -- the trainer's size-classed batches (train.FlatTrainer) carry
-        language tokens beyond the batch's own longest query; masking exactly those keys reproduces the unpadded batch."""
+        language tokens beyond the batch's own longest query; masking exactly those keys reproduces the unpadded batch (up to the
+        summation order of the kernels the two row counts dispatch to: train.FlatTrainer._classed)."""
         c1, c2 = ops.grad_chain(t1), ops.grad_chain(t2)          # each stream input: three projections + a residual
         # round 6: stream 1 (language: B * T1 = 192 rows at B = 32) runs on a side stream / graph branch beside stream 2 (vision: 3200 rows)
         # wherever the two are independent -- its q | k | v projection, and everything behind the two attention calls (ops.Branch)

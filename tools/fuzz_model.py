@@ -1,7 +1,7 @@
 """Model-level random sweep: the small GPV (tests/test_model_cpu.build_small) on random batch sizes, image sizes, ragged padding,
 query lengths and task mixes -- precise-mode forward + loss + backward on the GPU against the CPU oracle (what __graft_entry__.smoke()
 does for one fixed shape), then the same batch through the bf16 trainer eagerly and on the hipGraph path (losses must agree).
-usage: python tools/fuzz_model.py [seed] [n]        (GPU box; the oracle is the checker only)"""
+usage: python tools/fuzz_model.py [seed] [n]        (GPU box; the oracle is the checker only; FUZZ_ONLY=<case index>, FUZZ_VERBOSE=1: per-step losses)"""
 import os, sys, random
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -18,6 +18,8 @@ n = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 rng = random.Random(seed)
 hip.lib()
 dev = 'cuda:0'
+if os.environ.get('FUZZ_T_EXACT'):             # queries up to this many tokens enter the graph path unpadded (train.FlatTrainer._classed)
+    FlatTrainer.T_EXACT = int(os.environ['FUZZ_T_EXACT'])
 bad = 0
 for it in range(n):
     B, H, W, Tl = rng.randint(1, 5), 32 * rng.randint(2, 5) + rng.choice([0, 0, 7, 16]), 32 * rng.randint(2, 6) + rng.choice([0, 0, 5, 24]), rng.randint(3, 9)
@@ -25,6 +27,8 @@ for it in range(n):
     tasks = rng.choice([('CocoCaptioning',), ('CocoDetection',), ('CocoCaptioning', 'CocoVqa', 'CocoClassification', 'CocoDetection'), ('CocoVqa', 'CocoDetection')])
     images, mask, ids, attn = synth.synth_batch(B, H, W, Tl, V, seed=100 + it, pad_to=pad)
     targets = synth.synth_targets(B, V, S=rng.randint(2, 8), seed=7 + it, tasks=tasks)
+    if os.environ.get('FUZZ_ONLY') not in (None, str(it)):          # one case of the sweep (the random draws above stay in step)
+        continue
     ops.RT.set_precise(True)
     model, man = build_small()
     model.to(dev).train()
@@ -66,9 +70,30 @@ for it in range(n):
             if hasattr(mod, 'p') and isinstance(getattr(mod, 'p'), float):
                 mod.p = 0.0
         tr = FlatTrainer(m2, lr=1e-4, lr_backbone=1e-5, graphs=graphs)
-        ls[graphs] = [float(tr.train_step(samples, (ids.to(dev), attn.to(dev)), [{k: v for k, v in t.items() if k != 'answer_token_ids'} for t in gt])) for _ in range(4)]
+        ls[graphs], snaps = [], []
+        for _ in range(4):
+            ls[graphs].append(float(tr.train_step(samples, (ids.to(dev), attn.to(dev)), [{k: v for k, v in t.items() if k != 'answer_token_ids'} for t in gt])))
+            if os.environ.get('FUZZ_VERBOSE'):
+                torch.cuda.synchronize()
+                snaps.append(tr.P.clone())
+        if os.environ.get('FUZZ_VERBOSE'):
+            if not graphs:
+                snaps_eager = snaps
+            else:                       # first step / parameters where the graphed arm leaves the eager one
+                for st, (pe, pg) in enumerate(zip(snaps_eager, snaps)):
+                    rows = []
+                    for e in tr.entries:
+                        nme, o, k = e[0], e[3], e[4]
+                        d = float((pe[o:o + k] - pg[o:o + k]).abs().max())
+                        if d > 0:
+                            rows.append((d / max(float(pe[o:o + k].abs().max()), 1e-30), nme))
+                    rows.sort(reverse=True)
+                    print('   after step %d: %d of %d parameters differ%s' % (st + 1, len(rows), len(tr.entries), ''.join('\n      %.2e %s' % r for r in rows[:14])))
         gs = tr.graph_steps
     dev_ = max(abs(a - b) / max(abs(a), 1e-6) for a, b in zip(ls[False], ls[True]))
+    if os.environ.get('FUZZ_VERBOSE'):
+        print('   eager  ', ' '.join('%.9g' % v for v in ls[False]))
+        print('   graphed', ' '.join('%.9g' % v for v in ls[True]))
     ok2 = dev_ < 2e-2 and gs >= 2
     print('%s  precise vs oracle: loss %.1e grad %.1e %s | bf16 eager vs graphs: %.1e (graph steps %d) %s' % (tag, e_loss, e_grad, 'ok' if ok else 'FAIL', dev_, gs, 'ok' if ok2 else 'FAIL'), flush=True)
     bad += (not ok) + (not ok2)
