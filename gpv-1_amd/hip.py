@@ -266,6 +266,8 @@ def gemm(A, B, Cm, M, N, K, lda, ldb, ldc, layoutA=KMAJOR, layoutB=KMAJOR, batch
         raise TypeError('gemm: A and B dtypes differ')
     a.dtype_in, a.dtype_out = dcode(A), dcode(Cm)
     a.alpha = alpha
+    if rowscale is not None or bias is not None:
+        check_epilogue_extents('gemm', M, N, rowscale, bias)
     a.rowscale, a.bias = _p(_f32(rowscale)), _p(_f32(bias))
     if res is not None and res.dtype != Cm.dtype:
         raise TypeError('gemm: residual dtype must equal output dtype')
@@ -312,6 +314,18 @@ def gemm_tt_group(problems):
         _chk(lib().gpv_gemm_tt_group_ws(arr, C.c_int(len(problems)), None, C.c_int64(0), _stream()), 'gpv_gemm_tt_group_ws')
 
 
+def check_epilogue_extents(what, rows, cols, rowscale, bias):
+    """The C ABI takes plain pointers: it cannot see that an epilogue vector is shorter than what the kernels index.  This mirror has the
+    tensors, so it refuses here, before any launch.  rowscale is indexed by the OUTPUT ROW (gpv_gemm: rowscale[m], m < M; gpv_conv2d modes
+    0 / 1: one factor per output PIXEL, B * OH * OW of them -- NOT the per-channel BatchNorm scale, which gpv_cast_rowscale_t folds into the
+    weight copy; mode 2: one per Cout = the rows of dw), bias by the output column (N / Cout).  Found when tools/tune_gemms_bs1.py passed a
+    [Cout] vector as a forward convolution's rowscale: the kernel read 19200 floats from a 64-float tensor -- a memory access fault."""
+    if rowscale is not None and rowscale.numel() < rows:
+        raise ValueError('%s: rowscale has %d elements, the epilogue indexes it by output row: %d needed' % (what, rowscale.numel(), rows))
+    if bias is not None and bias.numel() < cols:
+        raise ValueError('%s: bias has %d elements, the epilogue indexes it by output column: %d needed' % (what, bias.numel(), cols))
+
+
 def _conv_args(mode, x, w, y, B, IH, IW, Cs, Cin, OH, OW, Cout, KH, KW, SH, SW, PH, PW, rowscale=None, bias=None,
                res=None, relu_mask=None, act=ACT_NONE, split_k=0, y_mask_bits=None, relu_mask_bits=None):
     a = ConvArgs()
@@ -322,6 +336,8 @@ def _conv_args(mode, x, w, y, B, IH, IW, Cs, Cin, OH, OW, Cout, KH, KW, SH, SW, 
     a.dtype_in, a.dtype_out = dcode(x), dcode(y)
     if x.dtype != w.dtype:
         raise TypeError('conv2d: operand dtypes differ')
+    if rowscale is not None or bias is not None:
+        check_epilogue_extents('conv2d mode %d' % mode, Cout if mode == 2 else B * OH * OW, KH * KW * Cin if mode == 2 else Cout, rowscale, bias)
     a.rowscale, a.bias = _p(_f32(rowscale)), _p(_f32(bias))
     for t in (res, relu_mask):
         if t is not None and t.dtype != y.dtype:

@@ -134,7 +134,9 @@ int gpv_gemm(const gpv_gemm_args* a, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * NHWC convolution as implicit GEMM (ResNet-50 body, backbone.py:93-95 + FrozenBatchNorm2d
- * backbone.py:44-54 folded into rowscale/bias, ReLU and the bottleneck residual fused).
+ * backbone.py:44-54: its per-channel scale is folded into the WEIGHT copy the caller passes
+ * (gpv_cast_rowscale_t: w[co, :] *= scale[co]; for the weight gradient it is `rowscale`, see
+ * mode 2), its shift is `bias`; ReLU and the bottleneck residual fused).
  *   mode 0 forward : y[b,oh,ow,co] = epi( sum_{r,s,ci} x[b, oh*SH+r-PH, ow*SW+s-PW, ci] w[co,r,s,ci] )
  *   mode 1 dgrad   : dx[b,ih,iw,ci] = epi( sum_{r,s,co} dy[b,(ih+PH-r)/SH,(iw+PW-s)/SW,co] wd[ci,r,s,co] )
  *                    (taps whose division is inexact / out of range contribute 0)
@@ -152,7 +154,10 @@ typedef struct {
   int OH, OW, Cout;                        /* the other tensor: B x OH x OW x Cout */
   int KH, KW, SH, SW, PH, PW;
   int dtype_in, dtype_out;
-  const float* rowscale; const float* bias;
+  const float* rowscale; const float* bias; /* EXTENTS (plain pointers: the library cannot check them, a short vector is an out-of-bounds read):
+                                               rowscale is indexed by the output ROW as in gpv_gemm -- modes 0 / 1: B * OH * OW floats, one per output
+                                               PIXEL (not per channel; the ResNet path passes NULL), mode 2: Cout floats (the rows of dw);
+                                               bias by the output column -- modes 0 / 1: Cout floats; either may be NULL */
   const void* res; const void* relu_mask;  /* same shape as y */
   int act;
   int split_k;                             /* wgrad only */

@@ -107,3 +107,22 @@ def test_product_refuses_to_run_without_the_library(monkeypatch, tmp_path):
         raise AssertionError('expected RuntimeError')
     except RuntimeError as e:
         assert 'GPU' in str(e)
+
+
+def test_the_mirror_refuses_short_epilogue_vectors():
+    """The C ABI takes plain pointers and cannot see a short rowscale / bias; the Python mirror has the tensors and refuses before any
+    launch (hip.check_epilogue_extents; include/gpv_hip.h gpv_conv_args: rowscale is per output ROW -- per PIXEL in conv modes 0 / 1,
+    per Cout in mode 2).  Round 6: a tool passed a [Cout] rowscale to a forward convolution and the kernel read 19200 floats from 64."""
+    import pytest
+    import torch
+    import gpv1_amd.hip as hip
+    B, OH, OW, Cout, Cin = 1, 120, 160, 64, 64
+    hip.check_epilogue_extents('conv2d mode 0', B * OH * OW, Cout, torch.ones(B * OH * OW), torch.zeros(Cout))
+    hip.check_epilogue_extents('conv2d mode 2', Cout, Cin, torch.ones(Cout), None)
+    hip.check_epilogue_extents('gemm', 192, 768, None, None)
+    with pytest.raises(ValueError, match='rowscale has 64 elements.*19200 needed'):
+        hip.check_epilogue_extents('conv2d mode 0', B * OH * OW, Cout, torch.ones(Cout), torch.zeros(Cout))
+    with pytest.raises(ValueError, match='bias has 32 elements.*64 needed'):
+        hip.check_epilogue_extents('conv2d mode 0', B * OH * OW, Cout, None, torch.zeros(32))
+    with pytest.raises(ValueError, match='rowscale'):
+        hip.check_epilogue_extents('gemm', 192, 768, torch.ones(191), torch.zeros(768))

@@ -2053,3 +2053,35 @@ def test_streaming_1x1_backward_data_reads_one_bit_relu_masks(K, N, px, with_res
         assert rel(d1, ref) < TOL[torch.bfloat16]
     finally:
         h.set_option(h.OPT_C1S, prev)
+
+
+def test_conv_rowscale_is_per_output_pixel_and_short_vectors_are_refused():
+    """include/gpv_hip.h gpv_conv_args: in modes 0 / 1 `rowscale` is one factor per output PIXEL (the GEMM epilogue's rowscale[m]), not the
+    per-channel BatchNorm scale (that one is folded into the weight copy).  Round 6: tools/tune_gemms_bs1.py passed a [Cout] vector on this
+    shape (one 120 x 160 image, 64 -> 64 pointwise: the generic tile kernel, every operand an exact-size allocation) and the launch read
+    19200 floats from a 64-float tensor -- a memory access fault.  The mirror refuses that before launching; the correctly sized call
+    gives y = relu(rowscale[pixel] * (x w^T) + bias[channel])."""
+    h = hip()
+    B, H, W, Cin, Cout = 1, 120, 160, 64, 64
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(B * H * W, Cin, generator=g).to(DEV).bfloat16()
+    w = (torch.randn(Cout, Cin, generator=g) / 8).to(DEV).bfloat16()
+    bias = torch.randn(Cout, generator=g).to(DEV)
+    y = torch.full((B * H * W, Cout), float('nan'), device=DEV, dtype=torch.bfloat16)
+    args = (0, x, w, y, B, H, W, Cin, Cin, H, W, Cout, 1, 1, 1, 1, 0, 0)
+    with pytest.raises(ValueError, match='rowscale has 64 elements'):
+        h.conv2d(*args, rowscale=torch.ones(Cout, device=DEV), bias=bias, act=h.ACT_RELU)
+    with pytest.raises(ValueError, match='bias has 32 elements'):
+        h.conv2d(*args, bias=bias[:32].contiguous(), act=h.ACT_RELU)
+    torch.cuda.synchronize()
+    assert torch.isnan(y.float()).all()                      # nothing was launched
+    rs = (0.5 + torch.rand(B * H * W, generator=g)).to(DEV)
+    h.conv2d(*args, rowscale=rs, bias=bias, act=h.ACT_RELU)
+    torch.cuda.synchronize()
+    ref = torch.relu(rs[:, None] * (x.float() @ w.float().t()) + bias[None, :])
+    assert rel(y, ref) < TOL[torch.bfloat16]
+    # and the call the ResNet path makes on this shape (no rowscale), same exact-size operands
+    y2 = torch.full_like(y, float('nan'))
+    h.conv2d(0, x, w, y2, B, H, W, Cin, Cin, H, W, Cout, 1, 1, 1, 1, 0, 0, bias=bias, act=h.ACT_RELU)
+    torch.cuda.synchronize()
+    assert rel(y2, torch.relu(x.float() @ w.float().t() + bias[None, :])) < TOL[torch.bfloat16]

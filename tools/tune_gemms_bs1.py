@@ -65,7 +65,7 @@ FAM = [('pipe off', hip.OPT_PIPE, 0)] + [('pipe cfg %d' % i, hip.OPT_PIPE, 100 +
 bf = torch.bfloat16
 print('# gpv_gemm shapes with M > 8 of one batch-1 inference before the token loop: us per graph node')
 tot_d = tot_b = 0.0
-for (M, N, K, la, lb, batch, has_res, act, f32o, has_bias, lda, ldb, ldc), cnt in gemms.items():
+for (M, N, K, la, lb, batch, has_res, act, f32o, has_bias, lda, ldb, ldc), cnt in ({} if os.environ.get('TUNE_SKIP_GEMM') else gemms).items():
     if batch != 1:
         print('%3d x M=%5d N=%5d K=%5d batch %d  (batched: skipped)' % (cnt, M, N, K, batch)); continue
     A = torch.randn(K * lda if la else M * lda, device=dev).to(bf)
@@ -101,9 +101,10 @@ for (mode, B, IH, IW, Cs, Cin, OH, OW, Cout, KH, KW, SH, SW, PH, PW, has_res, ac
     x = torch.randn(B * IH * IW * Cs, device=dev).to(bf)
     w = (torch.randn(Cout * KH * KW * Cin, device=dev) / (KH * KW * Cin) ** 0.5).to(bf)
     y = torch.empty(B * OH * OW * Cout, device=dev, dtype=bf)
-    kw = dict(rowscale=torch.ones(Cout, device=dev), bias=torch.zeros(Cout, device=dev), act=act)
+    kw = dict(bias=torch.zeros(Cout, device=dev), act=act)          # as backbone._conv_fwd calls it: the BatchNorm scale is in the weight copy (rowscale is per output PIXEL in modes 0 / 1)
     if has_res: kw['res'] = torch.randn(B * OH * OW * Cout, device=dev).to(bf)
     run = lambda: hip.conv2d(mode, x, w, y, B, IH, IW, Cs, Cin, OH, OW, Cout, KH, KW, SH, SW, PH, PW, **kw)
+    print('  -> mode %d B %d in %dx%dx%d(stride %d) out %dx%dx%d k %dx%d s %dx%d p %dx%d res%d act%d' % (mode, B, IH, IW, Cin, Cs, OH, OW, Cout, KH, KW, SH, SW, PH, PW, has_res, act), flush=True)
     try:
         t = chain(run)
     except RuntimeError as e:
