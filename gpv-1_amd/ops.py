@@ -31,6 +31,7 @@ class Runtime:
         self.weights_epoch = 0       # bumped after every optimizer step (trainer-managed parameters changed)
         self.static_epoch = 0        # bumped only when ANY tensor may have changed (load_state_dict, .to(), manual edits)
         self.seed = 0x5EED
+        self.seed_explicit = False       # manual_seed() was called: per_rank_seed() leaves the stream alone
         self._ctr = 0
         self.cache = {}
         self.backward_milestone = None   # set by train.FlatTrainer for the duration of a backward pass (gradient-exchange overlap)
@@ -69,11 +70,19 @@ class Runtime:
         """restart the dropout stream: the host counter behind next_seed() AND the device-resident epoch the replayed graphs add to their
         frozen seeds (train.GraphedBody bumps it once per replayed step; it is process-wide and outlives trainers) -- without the second,
         a graphed run from the same seed drew other masks than the run before it.  Not inside a capture (the reset would become a node)."""
-        self.seed, self._ctr = int(s), 0
+        self.seed, self._ctr, self.seed_explicit = int(s), 0, True
         if self.seed_dev is not None:
             if torch.cuda.is_current_stream_capturing():
                 raise RuntimeError('Runtime.manual_seed inside a stream capture')
             self.seed_dev.zero_()
+
+    def per_rank_seed(self, rank):
+        """A trainer on a process group calls this once: unless the caller seeded the stream itself (manual_seed), fold the rank into the
+        default seed so that the data-parallel ranks draw DIFFERENT dropout masks.  The reference never seeds (exp/gpv/train_distr.py):
+        each of its processes starts from torch's own per-process default seed, i.e. independent masks per rank; with one default seed
+        here every rank applied the same masks to its shard of the global batch.  Idempotent per rank; the host counter is kept."""
+        if not self.seed_explicit and rank:
+            self.seed = (0x5EED + int(rank) * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFF
 
     def next_seed(self):
         self._ctr += 1

@@ -661,6 +661,7 @@ class FlatTrainer:
         if self.comm:
             from .misc import install_collective_hooks
             install_collective_hooks()       # (a process group the caller built itself: the hooks go in here at the latest)
+            RT.per_rank_seed(self.rank)      # independent dropout masks per rank unless the caller seeded (ops.Runtime.per_rank_seed)
             dist.broadcast(self.P, src=0, group=self.pg)
             # DDP broadcasts every parameter AND buffer from rank 0 at construction; the tensors this trainer does not manage
             # (frozen BERT, vocabulary embedding, FrozenBN statistics, the frozen stem / layer1) must not depend on each rank's seed

@@ -203,6 +203,7 @@ def _worker_noloss(rank, world, port, out):
     res['steps'] = tr.step_count
     res['P'] = tr.P.clone()
     res['moved'] = bool((tr.P != P0).any())
+    res['dropout_seed'] = (ops.RT.seed, ops.RT.seed_explicit)
     torch.save(res, os.path.join(out, f'rank{rank}.pt'))
     dist.destroy_process_group()
 
@@ -215,3 +216,23 @@ def test_rank_without_applicable_target_stays_in_step(tmp_path):
     assert r0['steps_after_all_none'] == 0 and r1['steps_after_all_none'] == 0
     assert r0['steps'] == 2 and r1['steps'] == 2
     assert r0['moved'] and torch.equal(r0['P'], r1['P'])
+    # nobody seeded the dropout stream: the trainer folded the rank into the default seed (ops.Runtime.per_rank_seed) -- other masks per rank,
+    # as the reference's unseeded processes have (exp/gpv/train_distr.py never seeds)
+    assert r0['dropout_seed'] == (0x5EED, False) and r1['dropout_seed'][0] != 0x5EED and r1['dropout_seed'][1] is False
+
+
+def test_per_rank_dropout_seed_rule():
+    """ops.Runtime.per_rank_seed: rank 0 keeps the default, other ranks get their own, an explicit manual_seed is left alone, the draws of
+    two ranks differ from the first one on."""
+    from gpv1_amd.ops import Runtime
+    a, b, c = Runtime(), Runtime(), Runtime()
+    a.per_rank_seed(0); b.per_rank_seed(1); b.per_rank_seed(1)
+    assert a.seed == 0x5EED and b.seed != a.seed and 0 <= b.seed < (1 << 48)
+    assert [a.next_seed() for _ in range(4)] != [b.next_seed() for _ in range(4)]
+    c.manual_seed(7)
+    c.per_rank_seed(3)
+    assert c.seed == 7 and c.seed_explicit
+    seeds = set()
+    for r in range(64):
+        t = Runtime(); t.per_rank_seed(r); seeds.add(t.seed)
+    assert len(seeds) == 64
