@@ -2085,3 +2085,69 @@ def test_conv_rowscale_is_per_output_pixel_and_short_vectors_are_refused():
     h.conv2d(0, x, w, y2, B, H, W, Cin, Cin, H, W, Cout, 1, 1, 1, 1, 0, 0, bias=bias, act=h.ACT_RELU)
     torch.cuda.synchronize()
     assert rel(y2, torch.relu(x.float() @ w.float().t() + bias[None, :])) < TOL[torch.bfloat16]
+
+
+# ------------------------------------------------------------- dropout masks against the host restatement of the specification
+def _epoch():
+    """the device seed epoch, if a trainer of this process installed one (gpv_set_seed_device is process-wide): csrc/common.h eff_seed"""
+    import gpv1_amd.ops as ops
+    return None if ops.RT.seed_dev is None else int(ops.RT.seed_dev.item())
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('p,n', [(0.1, 4096 * 33 + 1), (0.5, 70001)])
+def test_dropout_kernel_mask_equals_the_specification(dtype, p, n):
+    """gpv_dropout keeps exactly the elements tests/dropout_ref.keep_flat says (drop_pair_bits, one 32-bit word per pair of elements),
+    bit for bit, and scales them by 1 / (1 - p).  Until round 6 no mask in this suite was compared with anything but another kernel."""
+    from tests import dropout_ref as R
+    h = hip()
+    seed = 0x5EED0000BEEF
+    x = torch.ones(n, device=DEV, dtype=dtype)
+    y = torch.full_like(x, float('nan'))
+    h.dropout(x, y, n, p, seed)
+    torch.cuda.synchronize()
+    ref = R.keep_flat(R.eff_seed(seed, _epoch()), np.arange(n, dtype=np.uint64), p)
+    got = (y != 0).cpu().numpy()
+    assert np.array_equal(got, ref), int((got != ref).sum())
+    scale = 1.0 / (1.0 - float(np.float32(p)))
+    assert rel(y[torch.from_numpy(ref).to(DEV)], torch.full((int(ref.sum()),), scale, device=DEV)) < (1e-6 if dtype == torch.float32 else 4e-3)
+
+
+@pytest.mark.parametrize('Bn,H,dh,Sq,Sk', [(16, 8, 32, 300, 300), (8, 16, 48, 100, 16), (2, 8, 32, 100, 300)])
+def test_attention_dropout_mask_equals_the_specification(Bn, H, dh, Sq, Sk):
+    """the (batch, head, query, key) keep pattern of the attention kernels -- packed saturating subtract + shift on pairs of probabilities
+    (attention.hip attn_drop_bits: the instruction family hipcc 7.2 miscompiled elsewhere this round) -- equals
+    tests/dropout_ref.keep_attention bit for bit.  The pattern is read off the forward kernel with one-hot V probes; the backward
+    kernels are tied to the forward's by the dropout gradient tests."""
+    from tests import dropout_ref as R
+    h = hip()
+    drop, seed = 0.1, 4242
+    keep = _attention_keep_mask(h, Bn, H, dh, Sq, Sk, drop, seed).cpu().numpy()
+    ref = R.keep_attention(R.eff_seed(seed, _epoch()), Bn, H, Sq, Sk, drop)
+    assert np.array_equal(keep, ref), (int((keep != ref).sum()), keep.mean(), ref.mean())
+
+
+@pytest.mark.parametrize('M,N,K,act', [(9600, 2048, 256, 1), (3200, 256, 2048, 0), (300, 256, 2048, 0), (640, 768, 768, 0), (192, 3072, 768, 2),
+                                       (9600, 256, 256, 0), (100, 768, 3072, 0), (4, 768, 768, 0)])
+def test_gemm_epilogue_dropout_mask_equals_the_specification(M, N, K, act):
+    """every GEMM family's dropout epilogue (streaming 1x1 kernel's packed compare for the 256 -> 2048 feed-forward expansion, pipe, small-M,
+    direct-to-LDS, generic, matrix-vector) keeps exactly keep_flat(seed, m * N + n): the same GEMM without dropout tells which outputs are
+    non-zero before the mask, there (output != 0) must equal the specification and the value must be the undropped one / (1 - p)."""
+    from tests import dropout_ref as R
+    h = hip()
+    p, seed = 0.1, 987654321
+    A = rnd(M, K, dtype=torch.bfloat16, seed=300)
+    B = rnd(N, K, dtype=torch.bfloat16, seed=301, scale=K ** -0.5)
+    bias = rnd(N, seed=302)
+    y0 = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    y1 = torch.full_like(y0, float('nan'))
+    h.gemm(A, B, y0, M, N, K, K, K, N, bias=bias, act=act)
+    h.gemm(A, B, y1, M, N, K, K, K, N, bias=bias, act=act, drop_p=p, seed=seed)
+    torch.cuda.synchronize()
+    ref = torch.from_numpy(R.keep_flat(R.eff_seed(seed, _epoch()), np.arange(M * N, dtype=np.uint64), p).reshape(M, N)).to(DEV)
+    live = y0 != 0
+    assert live.float().mean() > 0.3
+    assert torch.equal((y1 != 0) & live, ref & live), int((((y1 != 0) & live) != (ref & live)).sum())
+    assert ((y1 != 0) & ~live).sum() == 0
+    sel = ref & live
+    assert rel(y1[sel], y0[sel].float() / (1.0 - float(np.float32(p)))) < 1.2e-2
