@@ -394,9 +394,9 @@ class GPV(nn.Module):
         ent = self._igraphs.get(key)
         if ent is None:
             for k in [k for k in self._igraphs if k[-2:] != key[-2:]]:          # weights changed: those graphs hold stale copies
-                del self._igraphs[k]
+                self._drop_igraph(k)
             while len(self._igraphs) >= int(self.cfg.get('inference_graph_slots', 8)):      # string queries: one graph per (batch, query length)
-                self._igraphs.pop(next(iter(self._igraphs)))                      # least recently used first (re-inserted on every hit below)
+                self._drop_igraph(next(iter(self._igraphs)))                      # least recently used first (re-inserted on every hit below)
             sx, sm, sids, sattn = x.clone(), m.clone(), ids.clone(), attn.clone()
             svm = vocab_mask.clone().float() if vocab_mask is not None else None
             sex = extra.clone() if extra is not None else None                    # (a further static input: cached BERT features)
@@ -406,7 +406,7 @@ class GPV(nn.Module):
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
             from .misc import capture_guard
-            bside = torch.cuda.Stream(device=x.device)      # ops.Branch's side stream inside THIS graph (kept with it: see ops.Branch)
+            bside = ops.owned_stream(x.device)              # ops.Branch's side stream inside THIS graph: a hipStream of the graph's own, destroyed with it (_drop_igraph)
             with capture_guard(), torch.cuda.graph(graph, capture_error_mode='thread_local'):
                 RT.branch_stream = bside
                 try:
@@ -430,6 +430,18 @@ class GPV(nn.Module):
         res = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in out.items()}     # the graph's outputs are overwritten by the next replay
         torch.cuda.current_stream().synchronize()       # see decode.py: graph launches are not left queued behind a busy GPU
         return res
+
+    def _drop_igraph(self, key):
+        """destroy one captured inference graph: the graph first, then -- the device idle -- the stream of its own it was captured on
+        (ops.owned_stream: a stream that took part in the capture of a destroyed graph is never used again)"""
+        ent = self._igraphs.pop(key, None)
+        if ent is None:
+            return
+        bside = ent[1][6]
+        del ent
+        if getattr(bside, '_gpv_handle', None):
+            torch.cuda.synchronize()
+            ops.release_stream(bside)
 
     def _forward_impl(self, images, queries, answer_token_ids, targets=None, vocab_mask=None, kv_graphs=None, query_encodings=None,
                       lang_extra=None):

@@ -490,6 +490,89 @@ class Branch:
             torch.cuda.current_stream(device).wait_stream(st)
 
 
+def report_unpinned_leaves(roots, pinned, model, where):
+    """debugging aid (GPV_DEBUG_STREAMS=1): the AccumulateGrad nodes reachable from `roots` that are not among `pinned` (the trainer's, made
+    on its own stream) -- each is created lazily on the stream of its first use and shared by every graph recorded while it lives; this
+    walk found the process-wide dummy leaf of linear() (see _dummy)"""
+    pinned_ids = {id(a) for a in pinned}
+    names = {id(p): n for n, p in model.named_parameters()}
+    seen, todo, odd = {}, [t.grad_fn for t in roots if t.grad_fn is not None], []
+    while todo:
+        nd = todo.pop()
+        if nd is None or id(nd) in seen:
+            continue
+        seen[id(nd)] = nd                      # (kept alive: the wrappers' ids are recycled otherwise)
+        if nd.name().endswith('AccumulateGrad') and id(nd) not in pinned_ids:
+            odd.append((names.get(id(nd.variable), 'not a parameter'), tuple(nd.variable.shape)))
+        todo.extend(f for f, _ in nd.next_functions)
+    print('[gpv debug] %s: %d nodes, AccumulateGrad nodes that are not pinned: %s' % (where, len(seen), odd[:16]), flush=True)
+
+
+FRESH_STREAMS = os.environ.get('GPV_FRESH_STREAMS', '1') != '0'
+DEBUG_STREAMS = os.environ.get('GPV_DEBUG_STREAMS', '0') == '1'      # debugging: owned streams are never destroyed, foreign_capturing() reports
+_ALL_OWNED = []
+
+
+def foreign_capturing(own, where):
+    """debugging aid (GPV_DEBUG_STREAMS=1): which owned streams that do NOT belong to the capturing owner are in capture mode right now --
+    something forked them into this capture (an autograd node that remembers a stream of another body, a stale event wait)"""
+    if not DEBUG_STREAMS:
+        return
+    mine = {getattr(st, '_gpv_handle', None) for st in own if st is not None}
+    for i, st in enumerate(_ALL_OWNED):
+        if st._gpv_handle in mine:
+            continue
+        with torch.cuda.stream(st):
+            cap = torch.cuda.is_current_stream_capturing()
+        if cap:
+            print('[gpv debug] %s: owned stream #%d (role %s of an OTHER owner) is capturing' % (where, i, ('side', 'wside', 'bside')[i % 3]), flush=True)
+_hiprt = None
+
+
+def owned_stream(device):
+    """A side stream that is its owner's alone: a hipStream created here (hipStreamCreateWithFlags, non-blocking) and wrapped as
+    torch.cuda.ExternalStream; release_stream() destroys it once the graphs captured on it are gone.
+    torch.cuda.Stream() does NOT create a stream: it hands out one of a fixed pool of 32 hipStreams per device, round-robin.  A capture owner
+    that takes three of them (BERT, weight and ops.Branch side streams) recycles the pool after ten owners -- and a hipStream that had been
+    part of the capture of a graph destroyed since is what made later capture_end / replay calls segfault on ROCm 7.2 (round 6: first with one
+    process-wide branch stream, then -- tools/soak_evict.py: 2 graph slots, an eviction on every miss -- with "per-owner" streams from the
+    pool after 12 - 16 evictions).  GPV_FRESH_STREAMS=0: streams from torch's pool, as before."""
+    global _hiprt
+    device = torch.device(device)
+    if not FRESH_STREAMS:
+        return torch.cuda.Stream(device=device)
+    import ctypes
+    if _hiprt is None:
+        _hiprt = ctypes.CDLL('libamdhip64.so')
+        _hiprt.hipStreamCreateWithFlags.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint]
+        _hiprt.hipStreamDestroy.argtypes = [ctypes.c_void_p]
+    h = ctypes.c_void_p()
+    with torch.cuda.device(device):
+        err = _hiprt.hipStreamCreateWithFlags(ctypes.byref(h), 1)          # hipStreamNonBlocking
+    if err != 0 or not h.value:
+        raise RuntimeError('hipStreamCreateWithFlags failed: hipError %d' % err)
+    st = torch.cuda.ExternalStream(h.value, device=device)
+    st._gpv_handle = h.value
+    if DEBUG_STREAMS:
+        _ALL_OWNED.append(st)
+    return st
+
+
+def release_stream(st):
+    """destroy a stream made by owned_stream (after its owner's graphs were destroyed and the device is idle); pool streams: nothing to do"""
+    h = getattr(st, '_gpv_handle', None) if st is not None else None
+    if DEBUG_STREAMS:
+        return                              # (kept: foreign_capturing() asks them)
+    if h and _hiprt is not None:
+        st._gpv_handle = None
+        _hiprt.hipStreamDestroy(ctypes_void_p(h))
+
+
+def ctypes_void_p(v):
+    import ctypes
+    return ctypes.c_void_p(v)
+
+
 def branch_wait(waiter):
     """`waiter` (a stream about to launch work whose operands a backward on the branch stream may have written -- the deferred weight
     gradients on train.GraphedBody's weight branch) waits for the capture owner's branch stream, if that stream is part of the capture:
@@ -698,10 +781,25 @@ _DUMMY = {}
 
 def _dummy(device):
     """1-element leaf that requires grad: forces autograd to call our backward (parameter gradients are
-    accumulated by the kernels, not by autograd) when the activation input itself needs no gradient."""
-    d = _DUMMY.get(device)
+    accumulated by the kernels, not by autograd) when the activation input itself needs no gradient.
+    ONE PER STREAM.  autograd visits the leaf's AccumulateGrad node in every backward that reaches it (with an undefined gradient) and
+    ends the pass by recording an event on that node's stream -- the stream that was current when the node was CREATED, which happens
+    lazily and lasts for as long as some recorded graph references the leaf.  One process-wide leaf, first used on a captured body's
+    branch stream (round 6: the teacher-forcing prologue -- the target-embedding transform and the vocabulary classifiers read frozen
+    inputs), tied every later body's backward to THAT body's stream: after its eviction an event record on a stream that belonged to
+    somebody else or no longer existed (GraphTask::exec_post_processing -> hipErrorInvalidHandle with streams of their own, a
+    segmentation fault in a later replay with torch's recycled pool streams; tools/soak_evict.py).  Keyed by the stream in use, the
+    node always lives on the stream that is current -- inside a capture: part of it."""
+    device = torch.device(device)
+    key = (device, torch.cuda.current_stream(device).cuda_stream) if device.type == 'cuda' else (device, 0)
+    d = _DUMMY.get(key)
     if d is None:
-        d = _DUMMY[device] = torch.zeros(1, device=device, requires_grad=True)
+        # (no allocation per key: a new key's first use may be inside a capture, whose allocations belong to the capture owner's private
+        #  pool -- every leaf aliases ONE element allocated on first use, which the eager warm-up step in front of every capture makes)
+        base = _DUMMY.get(device)
+        if base is None:
+            base = _DUMMY[device] = torch.zeros(1, device=device)
+        d = _DUMMY[key] = base.detach().requires_grad_(True)
     return d
 
 

@@ -142,9 +142,10 @@ class GraphedBody:
         # branch (fork / join on a second stream) -- beside the DETR transformer's latency-bound chain in F2, where its small
         # kernels find idle CUs (under the backbone's full-chip convolutions in F1 they cost the convolutions more)
         self.bert_mode = int(os.environ.get('GPV_BERT_BRANCH', '2'))      # 2: branch of F2 beside the DETR transformer (F1 3.88 -> 3.71 ms, F2 3.68 -> 3.81), 1: branch of F1, 0: in line
-        self.side = torch.cuda.Stream(device=dev) if self.bert_mode else None
-        self.wside = torch.cuda.Stream(device=dev)
-        self.bside = torch.cuda.Stream(device=dev)          # ops.Branch's side stream inside this body's captures (forward and backward variants)
+        from .ops import owned_stream
+        self.side = owned_stream(dev) if self.bert_mode else None                  # (streams of this body's own: ops.owned_stream)
+        self.wside = owned_stream(dev)
+        self.bside = owned_stream(dev)          # ops.Branch's side stream inside this body's captures (forward and backward variants)
         self.zero_in_graph = os.environ.get('GPV_ZERO_IN_GRAPH', '1') != '0'
         # the gradient chains of THIS recorded forward belong to the body: an eager step's check_chains(clear=True) must not
         # drop them from under the backward variants captured later (ops.GradChain._live is the eager steps' list)
@@ -170,6 +171,7 @@ class GraphedBody:
                 raise RuntimeError('GraphedBody: the model never reached backbone_forward (F1 was not closed)')
             torch.cuda.current_stream(dev).wait_stream(self.wside)          # join the weight-mirror branch
             _ops.Branch.join_captured(dev)
+            _ops.foreign_capturing((self.side, self.wside, self.bside), 'F2 end')
             self.f2.capture_end()
             self._open = None
         except BaseException:
@@ -267,6 +269,25 @@ class GraphedBody:
 
     def stale(self):
         return self.epochs != (RT.static_epoch, RT.dtype)
+
+    def __del__(self):
+        """graphs first, then -- with the device idle -- the streams they were captured on (ops.owned_stream)"""
+        try:
+            from .ops import release_stream
+            streams = [getattr(self, n, None) for n in ('side', 'wside', 'bside')]
+            if not any(getattr(st, '_gpv_handle', None) for st in streams if st is not None):
+                return
+            for n in ('f1', 'f2'):
+                if hasattr(self, n):
+                    setattr(self, n, None)
+            if hasattr(self, 'variants'):
+                self.variants.clear()
+            self.keep = None
+            torch.cuda.synchronize()
+            for st in streams:
+                release_stream(st)
+        except Exception:                      # (interpreter shutdown: modules may be gone)
+            pass
 
     def forward(self, images, queries, tok, lang_extra=None, leaves=True):
         """replay F1 + F2 on the current stream; returns the outputs dict as fresh autograd leaves (leaves=False: nothing -- the
@@ -451,6 +472,8 @@ class GraphedBody:
                 if loss is None:
                     raise RuntimeError('GraphedBody: the fused criterion found no applicable loss for task %r' % (fused[0],))
                 loss_static = loss.detach()
+                if _ops.DEBUG_STREAMS:
+                    _ops.report_unpinned_leaves([loss] + [v for v in self.outs.values() if torch.is_tensor(v)], tr._grad_accs, tr.model, 'B1 capture')
                 torch.autograd.backward([loss], retain_graph=True)
                 del loss
             _ops.check_chains(clear=False, chains=self.chains)     # (the recorded forward -- and its chains -- serve further backward variants)
@@ -474,6 +497,7 @@ class GraphedBody:
             if side_a:
                 torch.cuda.current_stream(dev).wait_stream(self.wside)
             _ops.Branch.join_captured(dev)
+            _ops.foreign_capturing((self.side, self.wside, self.bside), 'B1 end')
             b1.capture_end()
             self._open = None
             dc5 = self.c5_leaf.grad
@@ -623,6 +647,20 @@ class FlatTrainer:
             p._gpv_lp_static = -1                                                  # mirror not yet written (ops._lp casts on first use)
             p._gpv_touch = (lambda i=i: self._mark(i))                            # kernel-accumulated gradients
             p.register_hook(lambda grad, i=i: self._mark(i))                       # autograd-delivered gradients
+        # Every parameter's AccumulateGrad node is made HERE, on the trainer's stream, and kept for the trainer's life.  autograd runs such
+        # a node on the stream that was current when the node was CREATED, and creates it lazily where the parameter is first used: a
+        # parameter first used on a captured body's branch stream (ops.Branch: the co-attention language weights, the teacher-forcing
+        # prologue) had its accumulation pinned to THAT body's stream -- a later body's backward capture then ran it on a stream outside
+        # its capture (forked in by the engine's event wait, joined by nobody: an invalid capture that ROCm 7.2 answers with a
+        # segmentation fault in some later replay / capture_end), or, once the old body was evicted, on a stream that no longer existed
+        # (round 6, tools/soak_evict.py: 2 graph slots, an eviction on every miss -- 12 evictions to the crash; with the branches off,
+        # or without evictions, never).  On the trainer's stream the engine's wait is the join of the branch.
+        self._grad_accs = []
+        if getattr(self, 'stream', None) is not None:
+            with torch.cuda.stream(self.stream), torch.enable_grad():
+                for (n, p, g, o, k) in self.entries:
+                    if p.requires_grad:
+                        self._grad_accs.append(p.view_as(p).grad_fn.next_functions[0][0])
         self.gscale = torch.ones(1, device=dev, dtype=torch.float32)
         # several ranks: G holds the SUM over ranks after the exchange; the 1 / world of the average rides on the factor the AdamW
         # kernel multiplies every gradient with anyway (clip factor x avg for the DETR groups, avg alone for the others) instead

@@ -11,6 +11,7 @@
 """
 import json
 import os
+import re
 
 import numpy as np
 import pytest
@@ -1193,3 +1194,26 @@ def test_more_signatures_than_graph_slots_run_the_misses_eagerly(rt):
     assert tr.graph_steps >= 6 and tr.eager_steps >= 5, (tr.graph_steps, tr.eager_steps)
     n_evictions = sum(1 for a, b in zip(captured, captured[1:]) if b < a)
     assert n_evictions == 0                                    # (an eviction and its recapture happen inside one step: the count never drops)
+
+
+@pytest.mark.timeout(900)
+def test_capture_evict_destroy_recapture_soak():
+    """tools/soak_evict.py in a process of its own (the failures it guards against are segmentation faults): the ragged string-query stream
+    against a trainer with TWO graph slots and an eviction on every miss -- 80 steps, ~17 captures / evictions of whole bodies (four graphs +
+    their side streams) -- with inference graphs of four batch sizes cycling through two slots in between.  Round 6 found three things
+    here, each fatal after 8 - 16 evictions and none visible with the default 8 slots: the process-wide dummy leaf of ops.linear (its
+    AccumulateGrad node lived on the branch stream of the FIRST body that used it), parameter accumulators created lazily on a branch
+    stream (pinned to the trainer's stream now), and torch's 32 pooled streams recycled as "new" side streams of later bodies
+    (ops.owned_stream).  GPV_FRESH_STREAMS=0 brings the last one back."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.pop('GPV_FRESH_STREAMS', None)
+    r = subprocess.run([sys.executable, '-X', 'faulthandler', os.path.join(root, 'tools', 'soak_evict.py'), '80'], cwd=root, env=env,
+                       capture_output=True, text=True, timeout=800)
+    tail = (r.stdout + r.stderr)[-3000:]
+    assert r.returncode == 0, tail
+    assert 'soak_evict done: 80 steps' in r.stdout, tail
+    m = re.search(r'(\d+) captures, (\d+) evictions', r.stdout)
+    assert m and int(m.group(1)) >= 13 and int(m.group(2)) >= 10, tail
