@@ -49,6 +49,8 @@ NOTES = {
     'GPV_OVERLAP': 'all-reduce buckets overlapped with the backbone backward (0: after the pass)',
     'GPV_PREP_BRANCH': 'conv weight casts / copies on a branch of F1',
     'GPV_MASK_BITS': 'ReLU masks of the layer2 / layer3 block outputs as one bit per element (written by the conv3 launch, read by the next conv1 backward-data)',
+    'GPV_FRESH_STREAMS': 'the side streams of a capture owner (a trainer body: BERT / weight / ops.Branch branches; an inference graph: its ops.Branch branch) are hipStreams of its own, destroyed with its graphs (ops.owned_stream); 0: torch.cuda.Stream(), i.e. one of 32 pooled streams handed out round-robin -- recycled across destroyed graphs: a segmentation fault after 8 - 16 body evictions (tools/soak_evict.py)',
+    'GPV_DEBUG_STREAMS': 'debugging the capture lifetimes: owned streams are kept instead of destroyed, ops.foreign_capturing() reports side streams of OTHER owners found in capture mode before a capture ends, ops.report_unpinned_leaves() lists the AccumulateGrad nodes of a body that are not the trainer-pinned ones',
     'GPV_TEXT_EARLY': 'teacher forcing: target embedding, vocabulary classifiers and the first text-decoder self-attention forked beside the co-attention stage',
     'GPV_PROJ_LN_MIN_ROWS': 'fewest rows for which the projection rides in the LayerNorm launch (below: GEMM + LayerNorm, faster as graph nodes up to ~1200 rows)',
     'GPV_PROJ_LN': 'attention out-projection inside the LayerNorm launch (gpv_linear_layernorm_fwd)',
