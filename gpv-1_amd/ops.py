@@ -457,10 +457,11 @@ class Branch:
     ENABLED = os.environ.get('GPV_COATT_BRANCH', '1') != '0'
     _streams = {}                 # device -> the side stream of EAGER launches (never part of a capture)
 
-    # Inside a capture the side stream is the capture owner's (RT.branch_stream: train.GraphedBody / GPV._graphed create one per body /
-    # per inference graph and keep it for as long as their graphs live).  A process-wide stream that had been part of the captures of
-    # graphs destroyed since -- evicted bodies, dropped models -- made a LATER capture_end segfault on ROCm 7.2 (the ragged-stream test
-    # after ~25 tests of captures and evictions; never with per-owner streams, like the BERT / weight branches have always been).
+    # Inside a capture the side stream is the capture owner's (RT.branch_stream: train.GraphedBody / GPV._graphed make one per body /
+    # per inference graph -- owned_stream(): a hipStream of the owner's own -- and destroy it after the owner's graphs).  What went wrong
+    # with anything less (a process-wide stream; then torch's pooled streams per owner): a segmentation fault in a later replay /
+    # capture_end after 8 - 16 evictions, from three causes -- owned_stream(), _dummy() and train.FlatTrainer._grad_accs say which
+    # (tools/soak_evict.py is the reproducer and the test).
     def __init__(self, device, stream):
         self.dev = device
         self.side = stream
@@ -479,8 +480,8 @@ class Branch:
     def join_captured(device):
         """before a capture ends: if the side stream is part of it, the capturing stream waits for it once more (every fork above is
         joined where its results are needed, and autograd joins what it moves between the streams -- this closes whatever a backward
-        pass may have left on the side stream behind its last gradient edge; a capture that ends with work on a forked stream is
-        invalid, and ROCm 7.2 answered one with a segmentation fault in a LATER capture_end instead of an error)"""
+        pass may have left on the side stream behind its last gradient edge: a capture must not end with unjoined work on a forked
+        stream)"""
         st = RT.branch_stream
         if st is None:
             return
