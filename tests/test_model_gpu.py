@@ -1215,5 +1215,5 @@ def test_capture_evict_destroy_recapture_soak():
     tail = (r.stdout + r.stderr)[-3000:]
     assert r.returncode == 0, tail
     assert 'soak_evict done: 80 steps' in r.stdout, tail
-    m = re.search(r'(\d+) captures, (\d+) evictions', r.stdout)
-    assert m and int(m.group(1)) >= 13 and int(m.group(2)) >= 10, tail
+    m = re.search(r'(\d+) captures, (\d+) evictions, (\d+) resumes', r.stdout)
+    assert m and int(m.group(1)) >= 13 and int(m.group(2)) >= 10 and int(m.group(3)) >= 1, tail

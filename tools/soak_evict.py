@@ -1,7 +1,7 @@
 """Soak of the capture -> evict -> destroy -> recapture cycle: the ragged string-query stream of bench.py (six size-class signatures) against a
 trainer with TWO graph slots and an eviction allowed on every miss, so that nearly every step destroys one captured body (four hipGraphs, its
 weight / BERT / branch side streams, its activation pool) and captures another; every 25 steps an inference of another batch size with
-2 inference-graph slots churns GPV's inference graphs as well.  This is the sequence that ended in a segfault inside a later capture_end
+2 inference-graph slots churns GPV's inference graphs as well; every 60 steps an in-process resume (model + optimizer state through their state dicts) makes every graph stale.  This is the sequence that ended in a segfault inside a later capture_end
 before the side stream of a capture became the capture owner's (round 6, ops.Branch: a process-wide side stream outlived the graphs it had been
 captured into).  Losses must stay finite, the last loss of every signature must be below its first.
 usage (GPU box): python tools/soak_evict.py [steps=240]"""
@@ -47,7 +47,7 @@ def make(it):
 batches = [make(it) for it in range(18)]
 inf = {b: bench.make_batch(7 + b, b, dev) for b in (1, 2, 3, 4)}
 first, last = {}, {}
-captures = evictions = 0
+captures = evictions = resumes = 0
 seen_bodies = set()
 t0 = time.perf_counter()
 for it in range(steps):
@@ -71,14 +71,25 @@ for it in range(steps):
                 o = model(nested_tensor_from_tensor_list(images), (ids, attn), None, None)
                 assert torch.isfinite(o['answer_logits'].float()).all()
         model.train()
+    if it % 60 == 59 and not os.environ.get('SOAK_NO_RESUME'):
+        # an in-process resume: model and optimizer state through their state dicts (train_distr.py:381-389 / 262-275).  load_state_dict
+        # bumps the static epoch: every captured body and inference graph is stale, destroyed and recaptured on its next use
+        torch.cuda.synchronize()
+        msd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        osd = tr.state_dict()
+        P_before = tr.P.clone()
+        model.load_state_dict(msd)
+        tr.load_state_dict(osd)
+        assert torch.equal(tr.P, P_before) and tr.step_count == it + 1
+        resumes += 1
     if it % 40 == 39:
         torch.cuda.synchronize()
         print('step %4d  loss %.4f  graph steps %d eager %d  captures %d evictions %d  bodies %d  inference graphs %d  %.1f s' %
               (it + 1, lv, tr.graph_steps, tr.eager_steps, captures, evictions, len(tr._bodies), len(model._igraphs), time.perf_counter() - t0), flush=True)
 torch.cuda.synchronize()
 down = sum(last[k] < first[k] for k in first)
-print('soak_evict done: %d steps, %d captures, %d evictions, %d graph steps, %d eager steps, %d / %d batches ended below their first loss, %.1f s' %
-      (steps, captures, evictions, tr.graph_steps, tr.eager_steps, down, len(first), time.perf_counter() - t0))
+print('soak_evict done: %d steps, %d captures, %d evictions, %d resumes, %d graph steps, %d eager steps, %d / %d batches ended below their first loss, %.1f s' %
+      (steps, captures, evictions, resumes, tr.graph_steps, tr.eager_steps, down, len(first), time.perf_counter() - t0))
 if not os.environ.get('SOAK_SLOTS') and not os.environ.get('SOAK_EVICT_INTERVAL'):
     assert captures >= steps // 6 and evictions >= steps // 8, (captures, evictions)
 assert down >= len(first) - 2, (first, last)
