@@ -404,6 +404,7 @@ class GPV(nn.Module):
             for _ in range(2):                                                    # warm-up: weight copies, kernel attributes, decoder buffers
                 run()
             torch.cuda.synchronize()
+            ops.release_pending()
             graph = torch.cuda.CUDAGraph()
             from .misc import capture_guard
             bside = ops.owned_stream(x.device)              # ops.Branch's side stream inside THIS graph: a hipStream of the graph's own, destroyed with it (_drop_igraph)
@@ -437,11 +438,9 @@ class GPV(nn.Module):
         ent = self._igraphs.pop(key, None)
         if ent is None:
             return
-        bside = ent[1][6]
+        graphs, bside = [ent[0]], ent[1][6]
         del ent
-        if getattr(bside, '_gpv_handle', None):
-            torch.cuda.synchronize()
-            ops.release_stream(bside)
+        ops.retire(graphs, [bside])
 
     def _forward_impl(self, images, queries, answer_token_ids, targets=None, vocab_mask=None, kv_graphs=None, query_encodings=None,
                       lang_extra=None):

@@ -509,9 +509,23 @@ def report_unpinned_leaves(roots, pinned, model, where):
     print('[gpv debug] %s: %d nodes, AccumulateGrad nodes that are not pinned: %s' % (where, len(seen), odd[:16]), flush=True)
 
 
+def still_capturing(own, where):
+    """debugging aid (GPV_DEBUG_STREAMS=1): right AFTER a capture ended, none of the owner's side streams may still be in capture mode"""
+    if not DEBUG_STREAMS:
+        return
+    for name, st in own:
+        if st is None:
+            continue
+        with torch.cuda.stream(st):
+            cap = torch.cuda.is_current_stream_capturing()
+        if cap:
+            print('[gpv debug] %s: own stream %s is STILL capturing after capture_end' % (where, name), flush=True)
+
+
 FRESH_STREAMS = os.environ.get('GPV_FRESH_STREAMS', '1') != '0'
 DEBUG_STREAMS = os.environ.get('GPV_DEBUG_STREAMS', '0') == '1'      # debugging: owned streams are never destroyed, foreign_capturing() reports
 _ALL_OWNED = []
+_LEAKED = []                    # (handle, hipError) of side streams the runtime refused to destroy (release_stream)
 
 
 def foreign_capturing(own, where):
@@ -566,7 +580,41 @@ def release_stream(st):
         return                              # (kept: foreign_capturing() asks them)
     if h and _hiprt is not None:
         st._gpv_handle = None
-        _hiprt.hipStreamDestroy(ctypes_void_p(h))
+        err = _hiprt.hipStreamDestroy(ctypes_void_p(h))
+        if err != 0:
+            # The runtime refused (seen once in ~300 destroyed bodies: hipErrorStreamCaptureUnsupported -- it still counted the stream
+            # as part of a capture).  Its last-error word is sticky per thread and torch reads it behind its NEXT launch: unchecked,
+            # the refusal surfaced as 'operation not permitted when stream is capturing' from an innocent tensor.clone().  Clear it and
+            # keep the stream (a leaked handle, never used again) instead of breaking the step.
+            _hiprt.hipGetLastError()
+            _LEAKED.append((h, err))
+            if len(_LEAKED) in (1, 10, 100):
+                import sys
+                print('[gpv1_amd] hipStreamDestroy refused a side stream (hipError %d); kept alive, %d so far' % (err, len(_LEAKED)), file=sys.stderr, flush=True)
+
+
+_PENDING = []                   # (graphs, streams) of capture owners finalised while a capture was in progress: release_pending()
+
+
+def retire(graphs, streams):
+    """a capture owner is done: destroy its graphs, then -- the device idle -- the streams of its own.  If a capture is in progress on this
+    thread right now (the cyclic collector may finalise an owner at any allocation), neither a synchronize nor a stream destroy is legal:
+    the resources are parked and release_pending() retires them at the next point where the caller has just synchronised anyway"""
+    if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+        _PENDING.append((graphs, streams))
+        return
+    del graphs[:]
+    if any(getattr(st, '_gpv_handle', None) for st in streams if st is not None):
+        torch.cuda.synchronize()
+        for st in streams:
+            release_stream(st)
+
+
+def release_pending():
+    """call where no capture is open and the device has just been synchronised (train.GraphedBody before its captures)"""
+    while _PENDING:
+        graphs, streams = _PENDING.pop()
+        retire(graphs, streams)
 
 
 def ctypes_void_p(v):

@@ -134,6 +134,8 @@ class GraphedBody:
         trainer.quiesce_collectives()
         torch.cuda.synchronize()
         gc.collect()
+        from .ops import release_pending
+        release_pending()                  # (capture owners finalised while another capture was open: ops.retire)
         self.pool = torch.cuda.graph_pool_handle()
         self.f1, self.f2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         saved = trainer.touched.clone()
@@ -174,6 +176,7 @@ class GraphedBody:
             _ops.foreign_capturing((self.side, self.wside, self.bside), 'F2 end')
             self.f2.capture_end()
             self._open = None
+            _ops.still_capturing((('side', self.side), ('wside', self.wside), ('bside', self.bside)), 'after F2')
         except BaseException:
             self._abort_open()
             raise
@@ -211,6 +214,8 @@ class GraphedBody:
         self._prep_forked = False
         self.f1.capture_end()
         self._open = None
+        from . import ops as _ops2
+        _ops2.still_capturing((('side', self.side), ('wside', self.wside), ('bside', self.bside)), 'after F1')
         self.f2.capture_begin(pool=self.pool, capture_error_mode=CAPTURE_MODE)
         self._open = self.f2
         if self.bert_mode == 2:
@@ -271,21 +276,16 @@ class GraphedBody:
         return self.epochs != (RT.static_epoch, RT.dtype)
 
     def __del__(self):
-        """graphs first, then -- with the device idle -- the streams they were captured on (ops.owned_stream)"""
+        """graphs first, then -- with the device idle -- the streams they were captured on (ops.retire; parked if a capture is open)"""
         try:
-            from .ops import release_stream
+            from .ops import retire
             streams = [getattr(self, n, None) for n in ('side', 'wside', 'bside')]
-            if not any(getattr(st, '_gpv_handle', None) for st in streams if st is not None):
-                return
-            for n in ('f1', 'f2'):
-                if hasattr(self, n):
-                    setattr(self, n, None)
+            graphs = [getattr(self, n, None) for n in ('f1', 'f2')] + list(getattr(self, 'variants', {}).values())
+            self.f1 = self.f2 = None
             if hasattr(self, 'variants'):
                 self.variants.clear()
             self.keep = None
-            torch.cuda.synchronize()
-            for st in streams:
-                release_stream(st)
+            retire(graphs, streams)
         except Exception:                      # (interpreter shutdown: modules may be gone)
             pass
 
@@ -418,6 +418,7 @@ class GraphedBody:
         tr.quiesce_collectives()
         torch.cuda.synchronize()
         gc.collect()
+        _ops.release_pending()
         grads = [torch.zeros_like(g) for _, _, g in pairs]
         s_ce, s_targets, loss_static = None, None, None
         if fused is not None:
@@ -500,6 +501,7 @@ class GraphedBody:
             _ops.foreign_capturing((self.side, self.wside, self.bside), 'B1 end')
             b1.capture_end()
             self._open = None
+            _ops.still_capturing((('side', self.side), ('wside', self.wside), ('bside', self.bside)), 'after B1')
             dc5 = self.c5_leaf.grad
             bb_bwd = bool(self.keep) and dc5 is not None        # (frozen backbone: c5 is a constant, nothing behind it)
             if deferred or bb_bwd:
@@ -536,6 +538,7 @@ class GraphedBody:
                     b2_list.append((cur[0], 'layer%d' % last_li))
                 else:
                     b2.capture_end()
+                    _ops.still_capturing((('side', self.side), ('wside', self.wside), ('bside', self.bside)), 'after B2')
                     b2_list.append((b2, None))
                 self._open = None
         except BaseException:
