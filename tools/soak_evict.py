@@ -62,7 +62,12 @@ for it in range(steps):
     captures += len(after - before)
     evictions += len(before - after)
     lv = float(loss)
-    assert lv == lv and abs(lv) < 1e6, (it, lv)
+    if not (lv == lv and abs(lv) < 1e6):
+        torch.cuda.synchronize()
+        print('NON-FINITE loss %r at step %d (sig %d, shape %s, graph steps %d, eager %d, captures %d, evictions %d): P finite %s, M finite %s, V finite %s, G finite %s' %
+              (lv, it, it % len(batches), SHAPES[(it // 7) % len(SHAPES)], tr.graph_steps, tr.eager_steps, captures, evictions,
+               bool(torch.isfinite(tr.P).all()), bool(torch.isfinite(tr.M).all()), bool(torch.isfinite(tr.V).all()), bool(torch.isfinite(tr.G).all())), flush=True)
+        raise SystemExit(3)
     if os.environ.get('SOAK_TRACE'):
         print('  step %d sig %d loss %.4f captures %d evictions %d bodies %d' % (it, it % len(batches), lv, captures, evictions, len(tr._bodies)), flush=True)
     key = (it % len(batches), (it // 7) % len(samples_by_shape))
